@@ -1,0 +1,184 @@
+/* sleap_amd.h -- C ABI of libsleap_amd.so: the MI355X (gfx950) kernels behind the SLEAP
+ * bottom-up inference hot path.
+ *
+ * The reference (talmolab/sleap v1.4.1) has no FFI for this path: it is pure Python on
+ * TensorFlow. Each entry point below therefore names the reference *Python* function (or the
+ * TensorFlow op that function lowers to) whose arithmetic it replaces; the Python host layer in
+ * `sleap_amd/nn/` mirrors the reference's signatures and binds these symbols with `ctypes`
+ * (see INTEGRATION.md).
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative `SA_ERR_*` code otherwise;
+ *     `sa_last_error()` returns a thread-local message for the last failure
+ *   - all pointers except those marked HOST are DEVICE pointers owned by the caller; nothing is
+ *     allocated behind the caller's back
+ *   - `stream` is a `hipStream_t` passed as `void*`; all work is enqueued asynchronously
+ *   - image-like tensors are NHWC; activations inside the network are bf16 with the channel count
+ *     padded to a multiple of 16 ("CP" below), network heads / maps are float32 with exact channels
+ */
+#ifndef SLEAP_AMD_H
+#define SLEAP_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SA_ABI_VERSION 1
+
+#define SA_OK 0
+#define SA_ERR_INVALID_ARG (-1)
+#define SA_ERR_HIP (-2)
+#define SA_ERR_UNSUPPORTED (-3)
+#define SA_ERR_WORKSPACE (-4)
+
+/* per-frame status bits written by the post-processing kernels into `status[b]` */
+#define SA_STATUS_PEAK_OVERFLOW 1      /* more local peaks than `max_peaks` */
+#define SA_STATUS_NODE_PEAK_OVERFLOW 2 /* more peaks of one node type than `max_node_peaks` */
+#define SA_STATUS_INSTANCE_OVERFLOW 4  /* more instances than `max_instances` */
+#define SA_STATUS_LSA_INFEASIBLE 8     /* scipy would raise "cost matrix is infeasible" */
+#define SA_STATUS_PAF_OOB 16           /* a PAF line sample fell outside the PAF tensor (TF-CPU raises) */
+
+typedef void* sa_stream_t;
+
+int sa_abi_version(void);
+const char* sa_last_error(void);
+/* HOST out-params. `arch` receives e.g. "gfx950". */
+int sa_device_info(int device, int* n_cu, int* lds_bytes, int* wave_size, char* arch, int arch_len);
+
+/* ------------------------------------------------------------------------------------------------
+ * Peak finding -- replaces sleap/nn/peak_finding.py
+ * ---------------------------------------------------------------------------------------------- */
+
+#define SA_REFINE_NONE 0
+#define SA_REFINE_INTEGRAL 1 /* find_local_peaks(refinement="integral")  peak_finding.py:451-532 */
+#define SA_REFINE_LOCAL 2    /* find_local_peaks(refinement="local")     peak_finding.py:78-132 */
+#define SA_REFINE_OFFSETS 3  /* find_local_peaks_with_offsets            peak_finding.py:646-707 */
+
+size_t sa_find_local_peaks_workspace(int B, int max_peaks);
+
+/* find_local_peaks_rough (peak_finding.py:249-308: tf.nn.dilation2d NMS + tf.where + gather_nd)
+ * followed by the refinement of find_local_peaks / find_local_peaks_with_offsets
+ * (crop_bboxes -> tf.image.crop_and_resize, integral_regression / find_offsets_local_direction).
+ *
+ *   cms      [B,H,W,C] f32          offsets [B,H,W,2C] f32 or NULL
+ *   peak_xy  [B,max_peaks,2] f32  = (rough + offset) * xy_scale, order row-major (y,x,c) per frame
+ *   peak_val [B,max_peaks] f32      peak_chan [B,max_peaks] i32      peak_count [B] i32
+ *   status   [B] i32 (bits OR-ed in; caller zeroes)
+ * `xy_scale` = 1 reproduces the module function (grid units); BottomUpInferenceLayer.find_peaks
+ * (inference.py:2892-2936) passes cm_output_stride. */
+int sa_find_local_peaks(const float* cms, const float* offsets, int B, int H, int W, int C,
+                        float threshold, int refinement, int patch_size, float xy_scale,
+                        int max_peaks, float* peak_xy, float* peak_val, int32_t* peak_chan,
+                        int32_t* peak_count, int32_t* status, void* workspace, size_t ws_bytes,
+                        sa_stream_t stream);
+
+/* find_global_peaks_rough + find_global_peaks / find_global_peaks_with_offsets
+ * (peak_finding.py:193-246, 337-420, 566-643). Row and column argmax are taken independently.
+ *   peak_xy [B,C,2] f32 (NaN below threshold), peak_val [B,C] f32 */
+int sa_find_global_peaks(const float* cms, const float* offsets, int B, int H, int W, int C,
+                         float threshold, int refinement, int patch_size, float xy_scale,
+                         float* peak_xy, float* peak_val, sa_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * PAF grouping -- replaces sleap/nn/paf_grouping.py
+ * ---------------------------------------------------------------------------------------------- */
+
+/* get_connection_candidates + make_line_subs + get_paf_lines + score_paf_lines
+ * (paf_grouping.py:82-142, 145-275, 325-403; batch loop :406-550).
+ *
+ *   pafs [B,Hp,Wp,2E] f32;  peaks as produced by sa_find_local_peaks (image pixels)
+ *   edges [E,2] i32 (src node, dst node)
+ *   node_count [B,N] i32; node_peaks [B,N,max_node_peaks] i32 (index into the frame's peak list)
+ *   line_scores [B,E,max_node_peaks,max_node_peaks] f32 -- entry [k][s][d] is the candidate
+ *     (s-th peak of edge k's src node, d-th peak of its dst node); unused entries untouched
+ * `max_edge_length` is max_edge_length_ratio * max(Hp,Wp,2E) * pafs_stride, computed by the host
+ * exactly as paf_grouping.py:469-473. */
+int sa_paf_score(const float* pafs, int B, int Hp, int Wp, int E, const float* peak_xy,
+                 const int32_t* peak_chan, const int32_t* peak_count, int max_peaks,
+                 const int32_t* edges, int N, int n_points, float pafs_stride,
+                 float max_edge_length, float dist_penalty_weight, int max_node_peaks,
+                 int32_t* node_count, int32_t* node_peaks, float* line_scores, int32_t* status,
+                 sa_stream_t stream);
+
+/* match_candidates_sample (paf_grouping.py:553-670) with the Hungarian solve of
+ * sleap/nn/utils.py:79-98 (scipy.optimize.linear_sum_assignment, restated in csrc/lsa.h).
+ *   match_dst [B,E,max_node_peaks] i32: for src peak s of edge k the matched dst peak or -1
+ *   match_score [B,E,max_node_peaks] f32 */
+int sa_paf_match(const float* line_scores, const int32_t* node_count, const int32_t* edges, int B,
+                 int E, int N, int max_node_peaks, int32_t* match_dst, float* match_score,
+                 int32_t* status, sa_stream_t stream);
+
+/* group_instances_sample = assign_connections_to_instances + make_predicted_instances
+ * (paf_grouping.py:984-1112, 799-914, 917-981).
+ *   sorted_edge_inds [n_sorted] i32: PAFScorer.sorted_edge_inds (toposort_edges :1293-1315)
+ *   instance_peaks [B,max_instances,N,2] f32 NaN-padded; instance_peak_vals [B,max_instances,N];
+ *   instance_scores [B,max_instances]; n_instances [B] i32 */
+int sa_paf_group(const float* peak_xy, const float* peak_val, const int32_t* node_count,
+                 const int32_t* node_peaks, int max_peaks, const int32_t* match_dst,
+                 const float* match_score, const int32_t* edges, const int32_t* sorted_edge_inds,
+                 int n_sorted, int B, int E, int N, int max_node_peaks, float min_line_scores,
+                 int min_instance_peaks, int max_instances, float* instance_peaks,
+                 float* instance_peak_vals, float* instance_scores, int32_t* n_instances,
+                 int32_t* status, sa_stream_t stream);
+
+/* HOST-side Hungarian solve (same code as the device path; for tests / tooling).
+ * cost [nr,nc] f64 row-major; row_ind/col_ind sized min(nr,nc). Returns #pairs or -1 if infeasible. */
+int sa_lsa_host(const double* cost, int nr, int nc, int64_t* row_ind, int64_t* col_ind);
+
+/* ------------------------------------------------------------------------------------------------
+ * Network layers -- replace the TensorFlow/cuDNN ops behind the Keras graph built by
+ * sleap/nn/architectures/{encoder_decoder,unet,hourglass}.py and sleap/nn/heads.py
+ * ---------------------------------------------------------------------------------------------- */
+
+/* InferenceLayer.preprocess (inference.py:940-967: ensure_float = x * 1/255) fused with the first
+ * Conv2D(k3, same)+bias+ReLU of the encoder (encoder_decoder.py:117-131) for Cin in {1,3}.
+ *   src [B,H,W,Cin] u8 (src_is_u8=1, scaled by 1/255) or f32;  w [3][3][Cin][CoutP] f32;  bias [CoutP] f32
+ *   dst [B,H,W,CoutP] bf16 */
+int sa_stem_conv3x3(const void* src, int src_is_u8, int B, int H, int W, int Cin, const float* w,
+                    const float* bias, int CoutP, int relu, void* dst, sa_stream_t stream);
+
+#define SA_SRC1_NONE 0
+#define SA_SRC1_DIRECT 1     /* Concatenate([src0, src1]) (encoder_decoder.py:360-362) */
+#define SA_SRC1_UPSAMPLE2X 2 /* Concatenate([src0, UpSampling2D(2, bilinear)(src1)]) (:335-339) */
+#define SA_SRC0_POOL2X 4     /* flag OR-ed in: src0 is read through MaxPool2D(2, s2) (:109-114) */
+
+/* Conv2D(k3, s1, same) + bias + optional ReLU on bf16 NHWC activations as an implicit GEMM on
+ * MFMA (v_mfma_f32_32x32x16_bf16, fp32 accumulate).
+ *   src0 [B,H0,W0,C0P] bf16 (H0=H, or 2H when SA_SRC0_POOL2X), src1 [B,H1,W1,C1P] bf16 or NULL
+ *   w packed by sa_pack_conv3x3_weights: [CoutP/32][9*(C0P+C1P)/16][32][16] bf16;  bias [CoutP] f32
+ *   dst [B,H,W,CoutP] bf16 */
+int sa_conv3x3_bf16(const void* src0, int C0P, const void* src1, int C1P, int mode, const void* w,
+                    const float* bias, int CoutP, int relu, int B, int H, int W, void* dst,
+                    sa_stream_t stream);
+
+/* HOST helper: Keras Conv2D kernel (3,3,Cin,Cout) f32 -> the packed bf16 layout above. The input
+ * channel axis is the concatenation [C0 | C1]; each part is zero-padded to C0P / C1P. */
+int sa_pack_conv3x3_weights(const float* keras_kernel, int C0, int C0P, int C1, int C1P, int Cout,
+                            int CoutP, uint16_t* packed);
+size_t sa_conv3x3_packed_elems(int C0P, int C1P, int CoutP);
+
+/* Conv2DTranspose(k3, s2, same) + bias + optional ReLU (encoder_decoder.py:304-310; out = 2n, full
+ * transposed conv cropped at the end).  w [3][3][CoutP][CinP] bf16 (Keras layout, padded) */
+int sa_convt3x3s2_bf16(const void* src, int CinP, const void* w, const float* bias, int CoutP,
+                       int relu, int B, int H, int W, void* dst, sa_stream_t stream);
+
+/* MaxPooling2D(2, s2, same) on even sizes; UpSampling2D(2, "bilinear"|"nearest") */
+int sa_maxpool2x2_bf16(const void* src, int B, int H, int W, int CP, void* dst, sa_stream_t stream);
+int sa_upsample2x_bf16(const void* src, int B, int H, int W, int CP, int bilinear, void* dst,
+                       sa_stream_t stream);
+
+/* Head.make_head: Conv2D(k1, linear) (heads.py:42-62).  w [Cout][CinP] f32, dst [B,H,W,Cout] f32 */
+int sa_conv1x1_head(const void* src, int CinP, const float* w, const float* bias, int Cout, int B,
+                    int H, int W, float* dst, sa_stream_t stream);
+
+/* dtype plumbing: f32 NHWC [.., C] <-> bf16 NHWC [.., CP] (zero padded) */
+int sa_f32_to_bf16_padded(const float* src, int n_pix, int C, int CP, void* dst, sa_stream_t stream);
+int sa_bf16_to_f32(const void* src, int n_pix, int CP, int C, float* dst, sa_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SLEAP_AMD_H */

@@ -1,0 +1,157 @@
+"""Thin Python wrappers over the C ABI: torch is used ONLY for device memory and streams.
+
+Every function takes/returns torch CUDA tensors (contiguous) and enqueues work on the current
+torch stream. Shapes and meanings follow include/sleap_amd.h.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import REFINE, check
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _dev(t_or_dev=None):
+    if isinstance(t_or_dev, torch.Tensor):
+        return t_or_dev.device
+    return torch.device("cuda", torch.cuda.current_device()) if t_or_dev is None else torch.device(t_or_dev)
+
+
+def require_cuda():
+    if not torch.cuda.is_available():
+        raise RuntimeError("sleap_amd needs a ROCm GPU (gfx950); no CPU fallback exists")
+
+
+def to_cuda_f32(x):
+    require_cuda()
+    if isinstance(x, torch.Tensor):
+        return x.to(device="cuda", dtype=torch.float32).contiguous()
+    return torch.from_numpy(np.ascontiguousarray(np.asarray(x, dtype=np.float32))).cuda()
+
+
+def device_info(device=0):
+    n_cu, lds, wave = C.c_int(), C.c_int(), C.c_int()
+    arch = C.create_string_buffer(64)
+    check(_lib.lib().sa_device_info(device, C.byref(n_cu), C.byref(lds), C.byref(wave), arch, 64), "sa_device_info")
+    return {"n_cu": n_cu.value, "lds_bytes": lds.value, "wave_size": wave.value, "arch": arch.value.decode()}
+
+
+# --------------------------------------------------------------------------------------------------
+# peak finding
+# --------------------------------------------------------------------------------------------------
+def find_local_peaks(cms, offsets=None, threshold=0.2, refinement=None, patch_size=5, xy_scale=1.0,
+                     max_peaks=512, status=None):
+    """-> peak_xy [B,P,2], peak_val [B,P], peak_chan [B,P] i32, peak_count [B] i32, status [B] i32."""
+    B, H, W, Cc = cms.shape
+    dev = cms.device
+    peak_xy = torch.empty((B, max_peaks, 2), dtype=torch.float32, device=dev)
+    peak_val = torch.empty((B, max_peaks), dtype=torch.float32, device=dev)
+    peak_chan = torch.empty((B, max_peaks), dtype=torch.int32, device=dev)
+    peak_count = torch.empty((B,), dtype=torch.int32, device=dev)
+    if status is None:
+        status = torch.zeros((B,), dtype=torch.int32, device=dev)
+    h = _lib.lib()
+    ws_bytes = h.sa_find_local_peaks_workspace(B, max_peaks)
+    ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
+    mode = REFINE["offsets"] if offsets is not None else REFINE[refinement]
+    check(
+        h.sa_find_local_peaks(_ptr(cms), _ptr(offsets), B, H, W, Cc, float(threshold), mode, int(patch_size),
+                              float(xy_scale), int(max_peaks), _ptr(peak_xy), _ptr(peak_val), _ptr(peak_chan),
+                              _ptr(peak_count), _ptr(status), _ptr(ws), ws_bytes, _stream()),
+        "sa_find_local_peaks",
+    )
+    return peak_xy, peak_val, peak_chan, peak_count, status
+
+
+def find_global_peaks(cms, offsets=None, threshold=0.2, refinement=None, patch_size=5, xy_scale=1.0):
+    """-> peak_xy [B,C,2] (NaN below threshold), peak_val [B,C]."""
+    B, H, W, Cc = cms.shape
+    peak_xy = torch.empty((B, Cc, 2), dtype=torch.float32, device=cms.device)
+    peak_val = torch.empty((B, Cc), dtype=torch.float32, device=cms.device)
+    mode = REFINE["offsets"] if offsets is not None else REFINE[refinement]
+    check(
+        _lib.lib().sa_find_global_peaks(_ptr(cms), _ptr(offsets), B, H, W, Cc, float(threshold), mode,
+                                        int(patch_size), float(xy_scale), _ptr(peak_xy), _ptr(peak_val), _stream()),
+        "sa_find_global_peaks",
+    )
+    return peak_xy, peak_val
+
+
+# --------------------------------------------------------------------------------------------------
+# PAF grouping
+# --------------------------------------------------------------------------------------------------
+def paf_score(pafs, peak_xy, peak_chan, peak_count, edges, n_nodes, n_points, pafs_stride, max_edge_length,
+              dist_penalty_weight, max_node_peaks, status):
+    B, Hp, Wp, C2 = pafs.shape
+    E = C2 // 2
+    dev = pafs.device
+    P = peak_xy.shape[1]
+    node_count = torch.empty((B, n_nodes), dtype=torch.int32, device=dev)
+    node_peaks = torch.empty((B, n_nodes, max_node_peaks), dtype=torch.int32, device=dev)
+    line_scores = torch.full((B, E, max_node_peaks, max_node_peaks), float("nan"), dtype=torch.float32, device=dev)
+    check(
+        _lib.lib().sa_paf_score(_ptr(pafs), B, Hp, Wp, E, _ptr(peak_xy), _ptr(peak_chan), _ptr(peak_count), P,
+                                _ptr(edges), n_nodes, int(n_points), float(pafs_stride), float(max_edge_length),
+                                float(dist_penalty_weight), int(max_node_peaks), _ptr(node_count),
+                                _ptr(node_peaks), _ptr(line_scores), _ptr(status), _stream()),
+        "sa_paf_score",
+    )
+    return node_count, node_peaks, line_scores
+
+
+def paf_match(line_scores, node_count, edges, status):
+    B, E, NP, _ = line_scores.shape
+    N = node_count.shape[1]
+    dev = line_scores.device
+    match_dst = torch.empty((B, E, NP), dtype=torch.int32, device=dev)
+    match_score = torch.empty((B, E, NP), dtype=torch.float32, device=dev)
+    check(
+        _lib.lib().sa_paf_match(_ptr(line_scores), _ptr(node_count), _ptr(edges), B, E, N, NP, _ptr(match_dst),
+                                _ptr(match_score), _ptr(status), _stream()),
+        "sa_paf_match",
+    )
+    return match_dst, match_score
+
+
+def paf_group(peak_xy, peak_val, node_count, node_peaks, match_dst, match_score, edges, sorted_edge_inds,
+              min_line_scores, min_instance_peaks, max_instances, status):
+    B, N, NP = node_peaks.shape
+    E = match_dst.shape[1]
+    P = peak_xy.shape[1]
+    dev = peak_xy.device
+    inst = torch.empty((B, max_instances, N, 2), dtype=torch.float32, device=dev)
+    vals = torch.empty((B, max_instances, N), dtype=torch.float32, device=dev)
+    scores = torch.empty((B, max_instances), dtype=torch.float32, device=dev)
+    n_inst = torch.empty((B,), dtype=torch.int32, device=dev)
+    check(
+        _lib.lib().sa_paf_group(_ptr(peak_xy), _ptr(peak_val), _ptr(node_count), _ptr(node_peaks), P,
+                                _ptr(match_dst), _ptr(match_score), _ptr(edges), _ptr(sorted_edge_inds),
+                                int(sorted_edge_inds.numel()), B, E, N, NP, float(min_line_scores),
+                                int(min_instance_peaks), int(max_instances), _ptr(inst), _ptr(vals), _ptr(scores),
+                                _ptr(n_inst), _ptr(status), _stream()),
+        "sa_paf_group",
+    )
+    return inst, vals, scores, n_inst
+
+
+def lsa_host(cost):
+    """Host Hungarian solve with the library's code (scipy.optimize.linear_sum_assignment semantics)."""
+    cost = np.ascontiguousarray(np.asarray(cost, dtype=np.float64))
+    nr, nc = cost.shape
+    n = min(nr, nc)
+    rows = np.zeros((max(n, 1),), np.int64)
+    cols = np.zeros((max(n, 1),), np.int64)
+    rc = _lib.lib().sa_lsa_host(cost.ctypes.data_as(C.c_void_p), nr, nc, rows.ctypes.data_as(C.c_void_p),
+                                cols.ctypes.data_as(C.c_void_p))
+    if rc < 0:
+        raise ValueError("cost matrix is infeasible")
+    return rows[:rc], cols[:rc]
