@@ -1,0 +1,214 @@
+#!/usr/bin/env python
+"""Benchmark of the bottom-up inference hot path on MI355X (BASELINE.json metric:
+"frames/sec at 1024x1024 bottom-up (13 nodes)").
+
+    python bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[3]): bottom-up UNet + PAFs, 1024x1024x1 uint8 frames, 13 nodes / 12
+edges (flies13), 4 animals per frame; architecture of training profile baseline_medium_rf.bottomup with
+seeded random weights and calibrated heads (sleap_amd/benchmark_model.py); `--batch` frames per GPU per
+step (default 64), frame-sharded over the GPUs (weak scaling), results gathered with one all-gather.
+
+A step = preprocessing (u8 -> float fused into the first conv) -> UNet forward -> local peaks with
+integral refinement -> PAF scoring -> Hungarian matching -> instance assembly -> packed fixed-shape
+results (all-gathered over ranks when N > 1), on frames already resident in HBM.
+
+Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
+  roofline      conv3x3 MFMA kernel family: algorithmic TFLOP/s (2*H*W*Cin*Cout*9 over its launches) over
+                its HIP-event-measured time inside this process, vs the 2.5 PFLOP/s dense bf16 MFMA peak
+  cpu_baseline  the CPU oracle (torch-CPU fp32 convs + NumPy/SciPy post-processing; "port") timed on the
+                host cores over a bounded sample of the same workload (N=1 only)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0  # dense, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=64, help="frames per GPU per step")
+    ap.add_argument("--size", type=int, default=1024)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-seconds", type=float, default=20.0)
+    ap.add_argument("--layers", action="store_true", help="also print the per-layer table to stderr")
+    return ap.parse_args()
+
+
+def cpu_baseline(mc, weights, scorer_args, frames_u8, budget_s):
+    """Times the CPU oracle on a bounded sample of the same frames (all host cores for the convs)."""
+    from oracle import paf_grouping as opg
+    from oracle import peak_finding as opf
+    from oracle.keras_graph import KerasGraph, preprocess
+
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    g = KerasGraph(mc, weights)
+    scorer = opg.PAFScorer(scorer_args["nodes"], scorer_args["edges"], scorer_args["stride"], oob="zero")
+
+    def run(batch):
+        cms, pafs = g(preprocess(batch))[:2]
+        pts, vals, si, ci = opf.find_local_peaks(cms, 0.2, "integral", 5)
+        pts = pts * np.float32(4)
+        B = batch.shape[0]
+        return scorer.predict(pafs, [pts[si == b] for b in range(B)], [vals[si == b] for b in range(B)],
+                              [ci[si == b] for b in range(B)])
+
+    t0 = time.time()
+    run(frames_u8[:1])  # warm-up (thread pools, allocator)
+    t1 = time.time()
+    per = max(t1 - t0, 1e-3)
+    n = int(max(1, min(len(frames_u8), budget_s / per)))
+    t2 = time.time()
+    run(frames_u8[:n])
+    dt = time.time() - t2
+    return {"value": n / dt, "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": f"{n} frame(s) of the same 1024x1024 workload, one batch, after a 1-frame warm-up; "
+                      f"torch-CPU fp32 convs ({cores} threads) + NumPy/SciPy post-processing"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
+    torch.cuda.set_device(local_rank)
+    import torch.distributed as dist
+
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+
+    from sleap_amd import parallel
+    from sleap_amd.benchmark_model import build_benchmark_predictor
+    from sleap_amd.synth import FLIES13_EDGES, FLIES13_NODES, render_frames
+
+    H = W = args.size
+    B = args.batch
+    pred, mc, weights = build_benchmark_predictor(H, W, batch_size=B, seed=0)
+    layer = pred.inference_model.bottomup_layer
+    net = layer.keras_model
+    scorer = layer.paf_scorer
+    n_unique = min(B, 8)
+    frames_np, _ = render_frames(n_unique, H, W, n_animals=4, seed=100 + rank)
+    frames = torch.from_numpy(frames_np).cuda()
+    frames = frames.repeat((B + n_unique - 1) // n_unique, 1, 1, 1)[:B].contiguous()  # resident in HBM
+    width = parallel.packed_width(scorer.max_instances, scorer.n_nodes)
+    host_out = torch.empty((world * B, width), dtype=torch.float32).pin_memory()
+    gathered = torch.empty((world * B, width), dtype=torch.float32, device="cuda")
+
+    def step():
+        outs = pred.inference_model.call(frames)
+        packed = parallel.pack_results(outs)
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, packed)
+            host_out.copy_(gathered, non_blocking=True)
+        else:
+            host_out.copy_(packed, non_blocking=True)
+        return outs
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    res = parallel.unpack_results(host_out[:B].clone(), scorer.max_instances, scorer.n_nodes)
+    status_bits = int(np.bitwise_or.reduce(res["status"].numpy().astype(np.int64)))
+    mean_instances = float(res["n_valid"].float().mean())
+
+    out = None
+    if rank == 0:
+        # ---- instrumented pass: per-op HIP events on the launch stream (outside the timed region)
+        descs = net.op_descriptions(H, W)
+        acc = np.zeros(len(descs))
+        reps = 3
+        for _ in range(reps):
+            prof = []
+            net.forward(layer.preprocess(frames), profile=prof)
+            torch.cuda.synchronize()
+            acc += np.array([a.elapsed_time(b) for a, b in prof])
+        acc /= reps  # ms per launch
+        conv_ms = sum(ms for (k, _, _), ms in zip(descs, acc) if k == "conv")
+        conv_fl = sum(f for (k, _, f) in descs if k == "conv") * B
+        n_conv = sum(1 for (k, _, _) in descs if k == "conv")
+        all_ms = float(acc.sum())
+        # post-processing time
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        cms, pafs, offs = layer.forward_pass(frames)
+        torch.cuda.synchronize()
+        e0.record()
+        pk = layer.find_peaks(cms, offs)
+        scorer.predict_padded(pafs, *pk)
+        e1.record()
+        torch.cuda.synchronize()
+        post_ms = e0.elapsed_time(e1)
+        mean_peaks = float(pk[3].float().mean())
+        achieved = conv_fl / (conv_ms * 1e-3) / 1e12
+        roofline = {
+            "kernel": "conv3x3_mfma_kernel (all launches of one step)", "bound": "mfma", "achieved": round(achieved, 2),
+            "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
+            "traffic": None,
+            "launches_per_step": n_conv, "avg_launch_ms": round(conv_ms / n_conv, 4),
+            "algorithmic_gflop_per_frame": round(conv_fl / B / 1e9, 2),
+            "network_ms_per_step": round(all_ms, 3), "postproc_ms_per_step": round(post_ms, 3),
+        }
+        if args.layers:
+            for (k, nm, f), ms in zip(descs, acc):
+                tf = f * B / (ms * 1e-3) / 1e12 if ms > 0 else 0
+                print(f"{nm:44s} {ms:8.3f} ms {tf:8.1f} TFLOP/s", file=sys.stderr)
+        fps = world * B * args.steps / dt
+        out = {
+            "metric": "frames/sec at 1024x1024 bottom-up (13 nodes)", "value": round(fps, 2), "unit": "frames/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[3]: bottom-up UNet(baseline_medium_rf: f16 r2 s32->4 bilinear)"
+                                   f"+PAFs, {H}x{W}x1 u8, 13 nodes/12 edges, 4 animals, random-init weights with "
+                                   "calibrated heads", "frames_per_gpu_per_step": B, "global_batch": B * world,
+                       "parallelism": f"frame-sharded dp{world}, one all-gather of packed results per step",
+                       "peak_threshold": 0.2, "refinement": "integral", "mean_peaks_per_frame": round(mean_peaks, 1),
+                       "mean_instances_per_frame": round(mean_instances, 2), "status_bits": status_bits},
+            "roofline": roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(mc, weights, {"nodes": FLIES13_NODES, "edges": FLIES13_EDGES, "stride": 8},
+                                               frames_np, args.cpu_baseline_seconds)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

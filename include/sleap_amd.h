@@ -148,7 +148,8 @@ int sa_stem_conv3x3(const void* src, int src_is_u8, int B, int H, int W, int Cin
 /* Conv2D(k3, s1, same) + bias + optional ReLU on bf16 NHWC activations as an implicit GEMM on
  * MFMA (v_mfma_f32_32x32x16_bf16, fp32 accumulate).
  *   src0 [B,H0,W0,C0P] bf16 (H0=H, or 2H when SA_SRC0_POOL2X), src1 [B,H1,W1,C1P] bf16 or NULL
- *   w packed by sa_pack_conv3x3_weights: [CoutP/32][9*(C0P+C1P)/16][32][16] bf16;  bias [CoutP] f32
+ *   w packed by sa_pack_conv3x3_weights: [ceil(CoutP/32)][(C0P+C1P)/16][9 taps][64 lanes][8] bf16 (MFMA
+ *   A-fragment order);  bias [CoutP] f32
  *   dst [B,H,W,CoutP] bf16 */
 int sa_conv3x3_bf16(const void* src0, int C0P, const void* src1, int C1P, int mode, const void* w,
                     const float* bias, int CoutP, int relu, int B, int H, int W, void* dst,
@@ -170,9 +171,10 @@ int sa_maxpool2x2_bf16(const void* src, int B, int H, int W, int CP, void* dst, 
 int sa_upsample2x_bf16(const void* src, int B, int H, int W, int CP, int bilinear, void* dst,
                        sa_stream_t stream);
 
-/* Head.make_head: Conv2D(k1, linear) (heads.py:42-62).  w [Cout][CinP] f32, dst [B,H,W,Cout] f32 */
-int sa_conv1x1_head(const void* src, int CinP, const float* w, const float* bias, int Cout, int B,
-                    int H, int W, float* dst, sa_stream_t stream);
+/* Head.make_head: Conv2D(k1, activation) (heads.py:42-62).  w [Cout][CinP] f32, dst [B,H,W,Cout] f32
+ * act: 0 linear (all pose heads), 1 sigmoid (ClassMapsHead; identity heads are otherwise out of scope) */
+int sa_conv1x1_head(const void* src, int CinP, const float* w, const float* bias, int Cout, int act,
+                    int B, int H, int W, float* dst, sa_stream_t stream);
 
 /* dtype plumbing: f32 NHWC [.., C] <-> bf16 NHWC [.., CP] (zero padded) */
 int sa_f32_to_bf16_padded(const float* src, int n_pix, int C, int CP, void* dst, sa_stream_t stream);

@@ -43,7 +43,7 @@ SIGNATURES = {
     "sa_convt3x3s2_bf16": (_i, [_p, _i, _p, _p, _i, _i, _i, _i, _i, _p, _p]),
     "sa_maxpool2x2_bf16": (_i, [_p, _i, _i, _i, _i, _p, _p]),
     "sa_upsample2x_bf16": (_i, [_p, _i, _i, _i, _i, _i, _p, _p]),
-    "sa_conv1x1_head": (_i, [_p, _i, _p, _p, _i, _i, _i, _i, _p, _p]),
+    "sa_conv1x1_head": (_i, [_p, _i, _p, _p, _i, _i, _i, _i, _i, _p, _p]),
     "sa_f32_to_bf16_padded": (_i, [_p, _i, _i, _i, _p, _p]),
     "sa_bf16_to_f32": (_i, [_p, _i, _i, _i, _p, _p]),
 }
@@ -61,6 +61,9 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
+    # torch ships its own libamdhip64; it must be the first (and only) HIP runtime in the process, otherwise
+    # device pointers handed over by torch belong to a different runtime than the one launching our kernels.
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         try:
             from . import build as _build

@@ -1,0 +1,90 @@
+"""Random-weight benchmark models of the reference's shipped training profiles.
+
+No trained 1024x1024 checkpoints exist offline, so benchmarks use the architecture of
+`sleap/training_profiles/baseline_medium_rf.bottomup.json` (UNet filters 16, rate 2, max_stride 32,
+output_stride 4, bilinear upsampling; confmaps @ stride 4, PAFs @ stride 8) with the 13-node / 12-edge
+`flies13` skeleton and seeded He-normal weights. Random heads emit noise, which would leave peak finding
+and grouping idle (or overflowing), so the two 1x1 heads are affinely calibrated on a few synthetic frames
+such that every confidence-map channel has about `n_animals` local maxima above the 0.2 threshold and PAF
+values have unit-order magnitude: post-processing then runs on realistic peak / candidate counts.
+"""
+import numpy as np
+import torch
+
+from .nn.architectures import build_unet_model_config, he_normal_weights
+from .nn.engine import DeviceNetwork
+from .nn.inference import BottomUpPredictor
+from .synth import FLIES13_EDGES, FLIES13_NODES, render_frames
+
+
+def medium_rf_bottomup_config(nodes=FLIES13_NODES, edges=FLIES13_EDGES, filters=16, filters_rate=2.0, max_stride=32,
+                              output_stride=4):
+    """The fields of training_config.json the inference path reads, baseline_medium_rf values."""
+    return {
+        "data": {"preprocessing": {"ensure_rgb": False, "ensure_grayscale": False, "input_scaling": 1.0,
+                                   "pad_to_stride": None, "resize_and_pad_to_target": True,
+                                   "target_height": None, "target_width": None},
+                 "labels": {"skeletons": []}},
+        "model": {"backbone": {"leap": None, "unet": {"stem_stride": None, "max_stride": max_stride,
+                                                      "output_stride": output_stride, "filters": filters,
+                                                      "filters_rate": filters_rate, "middle_block": True,
+                                                      "up_interpolate": True, "stacks": 1},
+                               "hourglass": None, "resnet": None, "pretrained_encoder": None},
+                  "heads": {"single_instance": None, "centroid": None, "centered_instance": None,
+                            "multi_instance": {"confmaps": {"part_names": list(nodes), "sigma": 2.5, "output_stride": 4,
+                                                            "loss_weight": 1.0, "offset_refinement": False},
+                                               "pafs": {"edges": [list(e) for e in edges], "sigma": 75.0,
+                                                        "output_stride": 8, "loss_weight": 1.0}},
+                            "multi_class_bottomup": None, "multi_class_topdown": None}},
+    }
+
+
+def build_benchmark_graph(height, width, cfg=None, seed=0):
+    cfg = cfg or medium_rf_bottomup_config()
+    u = cfg["model"]["backbone"]["unet"]
+    mi = cfg["model"]["heads"]["multi_instance"]
+    mc, shapes = build_unet_model_config(
+        (height, width, 1), u["filters"], u["filters_rate"], u["max_stride"], u["output_stride"], u["middle_block"],
+        u["up_interpolate"], None,
+        heads=[("MultiInstanceConfmapsHead", len(mi["confmaps"]["part_names"]), mi["confmaps"]["output_stride"]),
+               ("PartAffinityFieldsHead", 2 * len(mi["pafs"]["edges"]), mi["pafs"]["output_stride"])])
+    return cfg, mc, he_normal_weights(shapes, seed)
+
+
+def calibrate_heads(net: DeviceNetwork, frames_u8: torch.Tensor, n_animals=4, cm_index=0, paf_index=1, weights=None):
+    """Affine-rescale the random heads (see module docstring). Calibration only; not part of any timed region.
+    If `weights` is given, the calibrated head kernels/biases are written back so that the same model can be
+    evaluated elsewhere (e.g. by the CPU oracle)."""
+    outs = net.forward(frames_u8)
+    cms = outs[cm_index].clone()
+    pafs = outs[paf_index].clone()
+    B = cms.shape[0]
+    x = cms.permute(0, 3, 1, 2)
+    is_max = (torch.nn.functional.max_pool2d(x, 3, 1, 1) == x)
+    scale, shift = [], []
+    for c in range(cms.shape[3]):
+        v = x[:, c][is_max[:, c]]
+        k = max(min(n_animals * B, v.numel() // 2), 1)
+        top = torch.topk(v, 2 * k).values
+        vk, v2k = float(top[k - 1]), float(top[2 * k - 1])  # k-th largest local maximum -> 0.3, 2k-th -> 0.1
+        a = 0.2 / max(vk - v2k, 1e-6)
+        scale.append(a)
+        shift.append(0.3 - a * vk)
+    net.rescale_head(cm_index, scale, shift)
+    ps = float(pafs.std())
+    net.rescale_head(paf_index, [0.5 / max(ps, 1e-6)] * pafs.shape[3], [0.0] * pafs.shape[3])
+    if weights is not None:
+        for idx in (cm_index, paf_index):
+            k, b = net.export_head(idx)
+            name = net.output_names[idx]
+            weights[f"{name}/kernel"], weights[f"{name}/bias"] = k, b
+
+
+def build_benchmark_predictor(height=1024, width=1024, batch_size=64, n_animals=4, seed=0, calib_frames=2):
+    """-> (BottomUpPredictor on the current CUDA device, keras-style model_config, weights dict)."""
+    cfg, mc, weights = build_benchmark_graph(height, width, seed=seed)
+    net = DeviceNetwork(mc, weights)
+    frames, _ = render_frames(calib_frames, height, width, n_animals, seed=1234)
+    calibrate_heads(net, torch.from_numpy(frames).cuda(), n_animals, weights=weights)
+    pred = BottomUpPredictor(bottomup_config=cfg, bottomup_model=net, batch_size=batch_size)
+    return pred, mc, weights

@@ -1,0 +1,48 @@
+// bf16 helpers shared by the network kernels (device side).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace sa {
+
+typedef __attribute__((ext_vector_type(8))) unsigned short bf16x8_t;  // 16 B = 8 bf16 channels
+typedef __attribute__((ext_vector_type(4))) unsigned short bf16x4_t;
+
+// round-to-nearest-even float -> bf16 (NaN kept quiet)
+__host__ __device__ inline uint16_t f2bf(float f) {
+  union { float f; uint32_t u; } v;
+  v.f = f;
+  if ((v.u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((v.u >> 16) | 0x40);
+  const uint32_t lsb = (v.u >> 16) & 1u;
+  return (uint16_t)((v.u + 0x7fffu + lsb) >> 16);
+}
+
+__host__ __device__ inline float bf2f(uint16_t h) {
+  union { float f; uint32_t u; } v;
+  v.u = ((uint32_t)h) << 16;
+  return v.f;
+}
+
+// UpSampling2D(2, bilinear) == tf.image.resize half-pixel centres: output index o reads source
+// coordinate o/2 - 0.25 -> taps (i0, i1) with weight w1 on i1, edge-clamped.
+__device__ __forceinline__ void up2_taps(int o, int n, int& i0, int& i1, float& w1) {
+  const int i = o >> 1;
+  if (o & 1) {
+    i0 = i;
+    i1 = min(i + 1, n - 1);
+    w1 = 0.25f;
+  } else {
+    i0 = max(i - 1, 0);
+    i1 = i;
+    w1 = 0.75f;
+  }
+}
+
+__device__ __forceinline__ float up2_lerp(float tl, float tr, float bl, float br, float wy, float wx) {
+  const float t = tl + (tr - tl) * wx;
+  const float b = bl + (br - bl) * wx;
+  return t + (b - t) * wy;
+}
+
+}  // namespace sa

@@ -1,0 +1,302 @@
+// 3x3 stride-1 SAME convolution on bf16 NHWC activations as an implicit GEMM on the CDNA4 matrix
+// cores (v_mfma_f32_32x32x16_bf16, fp32 accumulate), with the surrounding Keras layers fused in:
+//   - bias + ReLU epilogue                       (encoder_decoder.py:117-131 Conv2D -> Activation)
+//   - MaxPool2D(2,s2) folded into the tile load  (encoder_decoder.py:109-114 pool_before_convs)
+//   - Concatenate([skip, x]) as a two-source K loop, with UpSampling2D(2, bilinear) of x folded
+//     into the tile load                         (encoder_decoder.py:335-339, 360-362)
+//
+// GEMM view: M = output channels (weights are the MFMA A operand), N = pixels of a 32-wide row
+// segment (B operand), K = 9 taps x input channels. A workgroup (4 waves) owns a TH x 32 pixel tile
+// for MT*32 output channels; the (TH+2) x 34 input halo tile of one CK-channel chunk is staged in
+// LDS once and re-read by all 9 taps with shifted addresses (no im2col materialisation); each wave
+// keeps R rows x MT cout-tiles of 32x32 fp32 accumulators in registers.
+//
+// LDS layout: pixel stride CK*2+16 bytes -> the 16 lanes of every ds_read_b128 service group hit 16
+// distinct 16-byte slots (stride/16 is odd), so B-fragment reads are bank-conflict free; packed
+// weights are stored lane-linear so A-fragment reads are consecutive 16 B per lane.
+#include <cstdint>
+#include <vector>
+
+#include "bf16.h"
+#include "sa_common.h"
+
+namespace {
+
+using sa::bf16x8_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 mfma_bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+struct ConvParams {
+  const uint16_t* src0;
+  const uint16_t* src1;
+  const uint16_t* w;  // packed [CoutP32/32][CinP/16][9][64][8]
+  const float* bias;  // [CoutP]
+  uint16_t* dst;
+  int C0P, C1P, CoutP;
+  int B, H, W;  // output size
+  int relu;
+  int tiles_x, tiles_y, co_tiles;
+};
+
+__device__ __forceinline__ bf16x8_t zero8() {
+  bf16x8_t z = {0, 0, 0, 0, 0, 0, 0, 0};
+  return z;
+}
+
+__device__ __forceinline__ bf16x8_t max8(bf16x8_t a, bf16x8_t b) {
+  bf16x8_t o;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) o[j] = (sa::bf2f(a[j]) >= sa::bf2f(b[j])) ? a[j] : b[j];
+  return o;
+}
+
+// MODE bits: 1 = src1 direct, 2 = src1 upsampled x2 (bilinear), 4 = src0 read through 2x2 max-pool
+template <int MT, int R, int CK, int MODE>
+__global__ void __launch_bounds__(256)
+conv3x3_mfma_kernel(const ConvParams p) {
+  constexpr int TH = 4 * R, TW = 32, PH = TH + 2, PW = TW + 2;
+  constexpr int PIX = CK * 2 + 16;  // LDS bytes per pixel
+  constexpr int IN_BYTES = PH * PW * PIX;
+  constexpr int KK = CK / 16;
+  constexpr int W_BYTES = MT * KK * 9 * 1024;
+  constexpr int PARTS = CK / 8;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* in_tile = smem;
+  unsigned char* w_tile = smem + IN_BYTES;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int bid = blockIdx.x;
+  const int co_t = bid % p.co_tiles;
+  bid /= p.co_tiles;
+  const int tx_i = bid % p.tiles_x;
+  bid /= p.tiles_x;
+  const int ty_i = bid % p.tiles_y;
+  const int b = bid / p.tiles_y;
+  const int x0 = tx_i * TW, y0 = ty_i * TH;
+  const int H = p.H, W = p.W;
+  const int CinP = p.C0P + p.C1P;
+  const int K16 = CinP / 16;
+  const int co32_0 = co_t * MT;
+  const int co32_n = (p.CoutP + 31) / 32;
+
+  f32x16 acc[MT][R];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[m][r][i] = 0.0f;
+
+  const int n_chunks = CinP / CK;
+  for (int chunk = 0; chunk < n_chunks; ++chunk) {
+    __syncthreads();
+    // ---------------- stage the input halo tile of this channel chunk
+    const int c_lo = chunk * CK;
+    const bool from1 = (MODE & 3) && (c_lo >= p.C0P);
+    for (int piece = tid; piece < PH * PW * PARTS; piece += 256) {
+      const int part = piece % PARTS;
+      const int pix = piece / PARTS;
+      const int tx = pix % PW, ty = pix / PW;
+      const int gy = y0 + ty - 1, gx = x0 + tx - 1;
+      bf16x8_t v = zero8();
+      if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
+        if (!from1) {
+          const int c = c_lo + part * 8;
+          if (MODE & 4) {
+            const int Ws = 2 * W;
+            const uint16_t* s = p.src0 + (((size_t)b * 2 * H + 2 * gy) * Ws + 2 * gx) * p.C0P + c;
+            const bf16x8_t a = *reinterpret_cast<const bf16x8_t*>(s);
+            const bf16x8_t a1 = *reinterpret_cast<const bf16x8_t*>(s + p.C0P);
+            const bf16x8_t a2 = *reinterpret_cast<const bf16x8_t*>(s + (size_t)Ws * p.C0P);
+            const bf16x8_t a3 = *reinterpret_cast<const bf16x8_t*>(s + (size_t)Ws * p.C0P + p.C0P);
+            v = max8(max8(a, a1), max8(a2, a3));
+          } else {
+            v = *reinterpret_cast<const bf16x8_t*>(p.src0 + (((size_t)b * H + gy) * W + gx) * p.C0P + c);
+          }
+        } else {
+          const int c = c_lo - p.C0P + part * 8;
+          if (MODE & 2) {
+            const int Hs = H / 2, Ws = W / 2;
+            int yA, yB, xA, xB;
+            float wy, wx;
+            sa::up2_taps(gy, Hs, yA, yB, wy);
+            sa::up2_taps(gx, Ws, xA, xB, wx);
+            const uint16_t* base = p.src1 + (size_t)b * Hs * Ws * p.C1P + c;
+            const bf16x8_t tl = *reinterpret_cast<const bf16x8_t*>(base + ((size_t)yA * Ws + xA) * p.C1P);
+            const bf16x8_t tr = *reinterpret_cast<const bf16x8_t*>(base + ((size_t)yA * Ws + xB) * p.C1P);
+            const bf16x8_t bl = *reinterpret_cast<const bf16x8_t*>(base + ((size_t)yB * Ws + xA) * p.C1P);
+            const bf16x8_t br = *reinterpret_cast<const bf16x8_t*>(base + ((size_t)yB * Ws + xB) * p.C1P);
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+              v[j] = sa::f2bf(sa::up2_lerp(sa::bf2f(tl[j]), sa::bf2f(tr[j]), sa::bf2f(bl[j]), sa::bf2f(br[j]), wy, wx));
+          } else {
+            v = *reinterpret_cast<const bf16x8_t*>(p.src1 + (((size_t)b * H + gy) * W + gx) * p.C1P + c);
+          }
+        }
+      }
+      *reinterpret_cast<bf16x8_t*>(in_tile + pix * PIX + part * 16) = v;
+    }
+    // ---------------- stage the packed weights of this chunk (lane-linear 16 B pieces)
+    for (int i = tid; i < W_BYTES / 16; i += 256) {
+      const int m = i / (KK * 9 * 64);
+      const int rest = i % (KK * 9 * 64);
+      const int co32 = co32_0 + m;
+      bf16x8_t v = zero8();
+      if (co32 < co32_n)
+        v = *reinterpret_cast<const bf16x8_t*>(p.w + (((size_t)co32 * K16 + chunk * KK) * 9 * 64 + rest) * 8);
+      *reinterpret_cast<bf16x8_t*>(w_tile + (size_t)i * 16) = v;
+    }
+    __syncthreads();
+    // ---------------- 9 taps x KK k-steps of MFMA
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int dy = tap / 3, dx = tap % 3;
+#pragma unroll
+      for (int kk = 0; kk < KK; ++kk) {
+        mfma_bf16x8 a[MT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+          a[m] = *reinterpret_cast<const mfma_bf16x8*>(w_tile + ((m * KK + kk) * 9 + tap) * 1024 + lane * 16);
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          const int row = wave * R + r;
+          const int pix = (row + dy) * PW + (lane & 31) + dx;
+          const mfma_bf16x8 bv =
+              *reinterpret_cast<const mfma_bf16x8*>(in_tile + pix * PIX + kk * 32 + (lane >> 5) * 16);
+#pragma unroll
+          for (int m = 0; m < MT; ++m)
+            acc[m][r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m], bv, acc[m][r], 0, 0, 0);
+        }
+      }
+    }
+  }
+
+  // ---------------- epilogue: bias + ReLU, bf16 pack, 8-byte stores (4 consecutive couts per group)
+  const int gx = x0 + (lane & 31);
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+    const int co_base = (co32_0 + m) * 32 + 4 * (lane >> 5);
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int gy = y0 + wave * R + r;
+      if (gy >= H || gx >= W) continue;
+      uint16_t* out = p.dst + (((size_t)b * H + gy) * W + gx) * p.CoutP;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int co = co_base + 8 * g;
+        if (co >= p.CoutP) continue;
+        const float4 bq = *reinterpret_cast<const float4*>(p.bias + co);
+        const float bb[4] = {bq.x, bq.y, bq.z, bq.w};
+        sa::bf16x4_t o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float v = acc[m][r][4 * g + j] + bb[j];
+          if (p.relu) v = fmaxf(v, 0.0f);
+          o[j] = sa::f2bf(v);
+        }
+        *reinterpret_cast<sa::bf16x4_t*>(out + co) = o;
+      }
+    }
+  }
+}
+
+template <int MT, int R, int CK, int MODE>
+int launch(const ConvParams& p, hipStream_t st) {
+  constexpr int TH = 4 * R;
+  constexpr size_t lds = (size_t)(TH + 2) * 34 * (CK * 2 + 16) + (size_t)MT * (CK / 16) * 9 * 1024;
+  ConvParams q = p;
+  q.tiles_x = (p.W + 31) / 32;
+  q.tiles_y = (p.H + TH - 1) / TH;
+  const int co32_n = (p.CoutP + 31) / 32;
+  q.co_tiles = (co32_n + MT - 1) / MT;
+  const size_t nblk = (size_t)q.tiles_x * q.tiles_y * q.co_tiles * p.B;
+  if (nblk > 0x7fffffffull) return sa::fail(SA_ERR_INVALID_ARG, "sa_conv3x3_bf16: grid too large");
+  static bool attr_set = false;
+  if (!attr_set && lds > 64 * 1024) {
+    SA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_mfma_kernel<MT, R, CK, MODE>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((conv3x3_mfma_kernel<MT, R, CK, MODE>), dim3((unsigned)nblk), dim3(256), lds, st, q);
+  SA_LAUNCH_CHECK();
+  return SA_OK;
+}
+
+template <int MT, int R, int CK>
+int launch_mode(const ConvParams& p, int mode, hipStream_t st) {
+  switch (mode) {
+    case 0: return launch<MT, R, CK, 0>(p, st);
+    case 1: return launch<MT, R, CK, 1>(p, st);
+    case 2: return launch<MT, R, CK, 2>(p, st);
+    case 4: return launch<MT, R, CK, 4>(p, st);
+    default: return sa::fail(SA_ERR_UNSUPPORTED, "sa_conv3x3_bf16: unsupported mode %d", mode);
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t sa_conv3x3_packed_elems(int C0P, int C1P, int CoutP) {
+  const size_t co32 = (CoutP + 31) / 32, k16 = (size_t)(C0P + C1P) / 16;
+  return co32 * k16 * 9 * 64 * 8;
+}
+
+int sa_pack_conv3x3_weights(const float* kk, int C0, int C0P, int C1, int C1P, int Cout, int CoutP,
+                            uint16_t* packed) {
+  SA_REQUIRE(C0P % 16 == 0 && C1P % 16 == 0 && C0 <= C0P && C1 <= C1P && Cout <= CoutP && CoutP % 16 == 0,
+             "sa_pack_conv3x3_weights: channel counts must be padded to multiples of 16");
+  const int Cin = C0 + C1, CinP = C0P + C1P, K16 = CinP / 16, co32_n = (CoutP + 31) / 32;
+  for (int co32 = 0; co32 < co32_n; ++co32)
+    for (int k16 = 0; k16 < K16; ++k16)
+      for (int tap = 0; tap < 9; ++tap)
+        for (int lane = 0; lane < 64; ++lane)
+          for (int j = 0; j < 8; ++j) {
+            const int co = co32 * 32 + (lane & 31);
+            const int cp = k16 * 16 + (lane >> 5) * 8 + j;  // padded concat channel
+            int ci = -1;                                     // Keras input channel
+            if (cp < C0P) {
+              if (cp < C0) ci = cp;
+            } else if (cp - C0P < C1) {
+              ci = C0 + (cp - C0P);
+            }
+            float v = 0.0f;
+            if (co < Cout && ci >= 0) v = kk[((size_t)tap * Cin + ci) * Cout + co];  // (kh,kw,Cin,Cout)
+            packed[((((size_t)co32 * K16 + k16) * 9 + tap) * 64 + lane) * 8 + j] = sa::f2bf(v);
+          }
+  return SA_OK;
+}
+
+int sa_conv3x3_bf16(const void* src0, int C0P, const void* src1, int C1P, int mode, const void* w,
+                    const float* bias, int CoutP, int relu, int B, int H, int W, void* dst,
+                    sa_stream_t stream) {
+  SA_REQUIRE(src0 && w && bias && dst, "sa_conv3x3_bf16: NULL pointer");
+  SA_REQUIRE(C0P > 0 && C0P % 16 == 0 && C1P % 16 == 0 && CoutP > 0 && CoutP % 16 == 0,
+             "sa_conv3x3_bf16: channels must be padded to multiples of 16 (C0P=%d C1P=%d CoutP=%d)", C0P, C1P, CoutP);
+  SA_REQUIRE(B > 0 && H > 0 && W > 0, "sa_conv3x3_bf16: bad shape");
+  SA_REQUIRE((mode & 3) == 0 || (src1 && C1P > 0), "sa_conv3x3_bf16: mode needs src1");
+  SA_REQUIRE((mode & 3) != 0 || C1P == 0, "sa_conv3x3_bf16: C1P given without a src1 mode");
+  SA_REQUIRE(!(mode & 2) || (H % 2 == 0 && W % 2 == 0), "sa_conv3x3_bf16: upsample mode needs even H, W");
+  ConvParams p;
+  p.src0 = (const uint16_t*)src0;
+  p.src1 = (const uint16_t*)src1;
+  p.w = (const uint16_t*)w;
+  p.bias = bias;
+  p.dst = (uint16_t*)dst;
+  p.C0P = C0P;
+  p.C1P = C1P;
+  p.CoutP = CoutP;
+  p.B = B;
+  p.H = H;
+  p.W = W;
+  p.relu = relu;
+  hipStream_t st = (hipStream_t)stream;
+  const bool ck32 = (C0P % 32 == 0) && (C1P % 32 == 0);
+  const int co32_n = (CoutP + 31) / 32;
+  if (co32_n >= 2) {
+    return ck32 ? launch_mode<2, 4, 32>(p, mode, st) : launch_mode<2, 4, 16>(p, mode, st);
+  }
+  return ck32 ? launch_mode<1, 4, 32>(p, mode, st) : launch_mode<1, 4, 16>(p, mode, st);
+}
+
+}  // extern "C"

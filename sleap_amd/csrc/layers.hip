@@ -1,0 +1,322 @@
+// Bandwidth-bound network layers on bf16 NHWC activations for gfx950: the u8->f32 normalising stem
+// convolution, 2x2 max-pool, x2 upsampling, the 1x1 linear heads, the (fixture-only) 3x3 stride-2
+// transposed convolution and dtype plumbing. The MFMA 3x3 convolution lives in conv3x3.hip.
+//
+// All kernels move 16 B per lane (8 bf16 channels) so that a wave touches whole 1 KiB lines.
+#include <cstdint>
+
+#include "bf16.h"
+#include "sa_common.h"
+
+namespace {
+
+using sa::bf16x8_t;
+
+// ------------------------------------------------------------------------------------------------
+// stem: ensure_float (x * 1/255, normalization.py:34-49) + Conv2D(k3,same) + bias + ReLU, Cin in {1,3}
+// thread = (pixel, group of 8 output channels); fp32 arithmetic, bf16 store.
+// ------------------------------------------------------------------------------------------------
+template <int CIN, bool U8>
+__global__ void __launch_bounds__(256)
+stem_conv3x3_kernel(const void* __restrict__ src_, int B, int H, int W, const float* __restrict__ w,
+                    const float* __restrict__ bias, int CoutP, int relu, uint16_t* __restrict__ dst) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  float* sw = reinterpret_cast<float*>(smem_raw);  // [9*CIN][CoutP] + bias[CoutP]
+  const int nw = 9 * CIN * CoutP;
+  for (int i = threadIdx.x; i < nw + CoutP; i += blockDim.x) sw[i] = (i < nw) ? w[i] : bias[i - nw];
+  __syncthreads();
+  const int groups = CoutP / 8;
+  const size_t total = (size_t)B * H * W * groups;
+  for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
+    const int g = (int)(t % groups);
+    const size_t p = t / groups;
+    const int x = (int)(p % W);
+    const int y = (int)((p / W) % H);
+    const size_t b = p / ((size_t)W * H);
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = sw[nw + g * 8 + j];
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+      const int yy = y + dy - 1;
+      if (yy < 0 || yy >= H) continue;
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) {
+        const int xx = x + dx - 1;
+        if (xx < 0 || xx >= W) continue;
+        const size_t si = ((b * H + yy) * W + xx) * CIN;
+#pragma unroll
+        for (int c = 0; c < CIN; ++c) {
+          float v;
+          if (U8)
+            v = (float)reinterpret_cast<const uint8_t*>(src_)[si + c] * (1.0f / 255.0f);
+          else
+            v = reinterpret_cast<const float*>(src_)[si + c];
+          const float* wr = sw + ((dy * 3 + dx) * CIN + c) * CoutP + g * 8;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) acc[j] = fmaf(v, wr[j], acc[j]);
+        }
+      }
+    }
+    bf16x8_t o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = sa::f2bf(relu ? fmaxf(acc[j], 0.0f) : acc[j]);
+    *reinterpret_cast<bf16x8_t*>(dst + p * CoutP + g * 8) = o;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// MaxPooling2D(2, s2) on even sizes
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+maxpool2x2_kernel(const uint16_t* __restrict__ src, int B, int H, int W, int CP, uint16_t* __restrict__ dst) {
+  const int Ho = H / 2, Wo = W / 2, groups = CP / 8;
+  const size_t total = (size_t)B * Ho * Wo * groups;
+  for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
+    const int g = (int)(t % groups);
+    const size_t p = t / groups;
+    const int x = (int)(p % Wo);
+    const int y = (int)((p / Wo) % Ho);
+    const size_t b = p / ((size_t)Wo * Ho);
+    const uint16_t* s = src + ((b * H + 2 * y) * W + 2 * x) * CP + g * 8;
+    const bf16x8_t a = *reinterpret_cast<const bf16x8_t*>(s);
+    const bf16x8_t c = *reinterpret_cast<const bf16x8_t*>(s + CP);
+    const bf16x8_t d = *reinterpret_cast<const bf16x8_t*>(s + (size_t)W * CP);
+    const bf16x8_t e = *reinterpret_cast<const bf16x8_t*>(s + (size_t)W * CP + CP);
+    bf16x8_t o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      o[j] = sa::f2bf(fmaxf(fmaxf(sa::bf2f(a[j]), sa::bf2f(c[j])), fmaxf(sa::bf2f(d[j]), sa::bf2f(e[j]))));
+    *reinterpret_cast<bf16x8_t*>(dst + p * CP + g * 8) = o;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// UpSampling2D(2): bilinear = half-pixel centres (tf.image.resize, align_corners=False): for output
+// index o the source coordinate is (o + 0.5)/2 - 0.5, i.e. weights (0.25, 0.75) with edge clamping.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+upsample2x_kernel(const uint16_t* __restrict__ src, int B, int H, int W, int CP, int bilinear,
+                  uint16_t* __restrict__ dst) {
+  const int Ho = 2 * H, Wo = 2 * W, groups = CP / 8;
+  const size_t total = (size_t)B * Ho * Wo * groups;
+  for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
+    const int g = (int)(t % groups);
+    const size_t p = t / groups;
+    const int x = (int)(p % Wo);
+    const int y = (int)((p / Wo) % Ho);
+    const size_t b = p / ((size_t)Wo * Ho);
+    bf16x8_t o;
+    if (!bilinear) {
+      o = *reinterpret_cast<const bf16x8_t*>(src + ((b * H + y / 2) * W + x / 2) * CP + g * 8);
+    } else {
+      int y0, y1, x0, x1;
+      float wy, wx;
+      sa::up2_taps(y, H, y0, y1, wy);
+      sa::up2_taps(x, W, x0, x1, wx);
+      const uint16_t* base = src + b * H * W * (size_t)CP + g * 8;
+      const bf16x8_t a = *reinterpret_cast<const bf16x8_t*>(base + ((size_t)y0 * W + x0) * CP);
+      const bf16x8_t c = *reinterpret_cast<const bf16x8_t*>(base + ((size_t)y0 * W + x1) * CP);
+      const bf16x8_t d = *reinterpret_cast<const bf16x8_t*>(base + ((size_t)y1 * W + x0) * CP);
+      const bf16x8_t e = *reinterpret_cast<const bf16x8_t*>(base + ((size_t)y1 * W + x1) * CP);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = sa::f2bf(sa::up2_lerp(sa::bf2f(a[j]), sa::bf2f(c[j]), sa::bf2f(d[j]), sa::bf2f(e[j]), wy, wx));
+    }
+    *reinterpret_cast<bf16x8_t*>(dst + p * CP + g * 8) = o;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// 1x1 linear head (heads.py:42-62): bf16 features x f32 weights -> f32 maps with exact channel count.
+// thread = pixel; weights [Cout][CinP] staged in LDS (broadcast reads).
+// ------------------------------------------------------------------------------------------------
+template <int CO>  // couts handled per pass
+__global__ void __launch_bounds__(256)
+conv1x1_head_kernel(const uint16_t* __restrict__ src, int CinP, const float* __restrict__ w,
+                    const float* __restrict__ bias, int Cout, int act, size_t n_pix, float* __restrict__ dst) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  float* sw = reinterpret_cast<float*>(smem_raw);  // [CoutR][CinP], CoutR = Cout rounded up to CO
+  const int CoutR = (Cout + CO - 1) / CO * CO;
+  for (int i = threadIdx.x; i < CoutR * CinP; i += blockDim.x) sw[i] = (i < Cout * CinP) ? w[i] : 0.0f;
+  __syncthreads();
+  for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < n_pix; p += (size_t)gridDim.x * blockDim.x) {
+    const uint16_t* s = src + p * CinP;
+    for (int c0 = 0; c0 < Cout; c0 += CO) {
+      float acc[CO];
+#pragma unroll
+      for (int j = 0; j < CO; ++j) acc[j] = 0.0f;
+      for (int k = 0; k < CinP; k += 8) {
+        const bf16x8_t v = *reinterpret_cast<const bf16x8_t*>(s + k);
+        float f[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) f[i] = sa::bf2f(v[i]);
+#pragma unroll
+        for (int j = 0; j < CO; ++j) {
+          const float* wr = sw + (c0 + j) * CinP + k;
+#pragma unroll
+          for (int i = 0; i < 8; ++i) acc[j] = fmaf(f[i], wr[i], acc[j]);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < CO; ++j)
+        if (c0 + j < Cout) {
+          float v = acc[j] + bias[c0 + j];
+          if (act == 1) v = 1.0f / (1.0f + __expf(-v));
+          dst[p * Cout + c0 + j] = v;
+        }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Conv2DTranspose(k3, s2, same): out[y][x] = sum_{2i+ky=y, 2j+kx=x} in[i][j] . w[ky][kx], output 2H x 2W
+// (full transposed conv cropped at the end). Direct kernel: only the reference's small fixture
+// models use transposed convolutions (training profiles ship with up_interpolate=true).
+// thread = (output pixel, cout); w [3][3][CoutP][CinP] bf16.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+convt3x3s2_kernel(const uint16_t* __restrict__ src, int CinP, const uint16_t* __restrict__ w,
+                  const float* __restrict__ bias, int CoutP, int relu, int B, int H, int W,
+                  uint16_t* __restrict__ dst) {
+  const int Ho = 2 * H, Wo = 2 * W;
+  const size_t total = (size_t)B * Ho * Wo * CoutP;
+  for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
+    const int co = (int)(t % CoutP);
+    const size_t p = t / CoutP;
+    const int x = (int)(p % Wo);
+    const int y = (int)((p / Wo) % Ho);
+    const size_t b = p / ((size_t)Wo * Ho);
+    float acc = bias[co];
+    for (int ky = (y & 1); ky < 3; ky += 2) {
+      const int i = (y - ky) / 2;
+      if (i < 0 || i >= H) continue;
+      for (int kx = (x & 1); kx < 3; kx += 2) {
+        const int j = (x - kx) / 2;
+        if (j < 0 || j >= W) continue;
+        const uint16_t* s = src + ((b * H + i) * W + j) * CinP;
+        const uint16_t* wr = w + ((size_t)(ky * 3 + kx) * CoutP + co) * CinP;
+        for (int k = 0; k < CinP; k += 8) {
+          const bf16x8_t a = *reinterpret_cast<const bf16x8_t*>(s + k);
+          const bf16x8_t q = *reinterpret_cast<const bf16x8_t*>(wr + k);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) acc = fmaf(sa::bf2f(a[e]), sa::bf2f(q[e]), acc);
+        }
+      }
+    }
+    dst[t] = sa::f2bf(relu ? fmaxf(acc, 0.0f) : acc);
+  }
+}
+
+__global__ void f32_to_bf16_padded_kernel(const float* __restrict__ src, size_t n_pix, int C, int CP,
+                                          uint16_t* __restrict__ dst) {
+  const size_t total = n_pix * CP;
+  for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(t % CP);
+    const size_t p = t / CP;
+    dst[t] = (c < C) ? sa::f2bf(src[p * C + c]) : (uint16_t)0;
+  }
+}
+
+__global__ void bf16_to_f32_kernel(const uint16_t* __restrict__ src, size_t n_pix, int CP, int C,
+                                   float* __restrict__ dst) {
+  const size_t total = n_pix * C;
+  for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(t % C);
+    const size_t p = t / C;
+    dst[t] = sa::bf2f(src[p * CP + c]);
+  }
+}
+
+inline int grid_for(size_t total, int block = 256, int cap = 256 * 16) {
+  size_t g = (total + block - 1) / block;
+  if (g > (size_t)cap) g = cap;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+}  // namespace
+
+extern "C" {
+
+int sa_stem_conv3x3(const void* src, int src_is_u8, int B, int H, int W, int Cin, const float* w,
+                    const float* bias, int CoutP, int relu, void* dst, sa_stream_t stream) {
+  SA_REQUIRE(Cin == 1 || Cin == 3, "sa_stem_conv3x3: Cin must be 1 or 3, got %d", Cin);
+  SA_REQUIRE(CoutP > 0 && CoutP % 8 == 0 && CoutP <= 256, "sa_stem_conv3x3: CoutP must be a multiple of 8 (<=256)");
+  SA_REQUIRE(B > 0 && H > 0 && W > 0, "sa_stem_conv3x3: bad shape");
+  const size_t total = (size_t)B * H * W * (CoutP / 8);
+  const size_t lds = sizeof(float) * (size_t)(9 * Cin + 1) * CoutP;
+  const dim3 g(grid_for(total)), blk(256);
+  hipStream_t st = (hipStream_t)stream;
+  uint16_t* d = (uint16_t*)dst;
+#define SA_STEM(CIN, U8) \
+  hipLaunchKernelGGL((stem_conv3x3_kernel<CIN, U8>), g, blk, lds, st, src, B, H, W, w, bias, CoutP, relu, d)
+  if (Cin == 1 && src_is_u8) SA_STEM(1, true);
+  else if (Cin == 1) SA_STEM(1, false);
+  else if (src_is_u8) SA_STEM(3, true);
+  else SA_STEM(3, false);
+#undef SA_STEM
+  SA_LAUNCH_CHECK();
+  return SA_OK;
+}
+
+int sa_maxpool2x2_bf16(const void* src, int B, int H, int W, int CP, void* dst, sa_stream_t stream) {
+  SA_REQUIRE(H % 2 == 0 && W % 2 == 0 && CP % 8 == 0, "sa_maxpool2x2_bf16: needs even H,W and CP%%8==0");
+  const size_t total = (size_t)B * (H / 2) * (W / 2) * (CP / 8);
+  hipLaunchKernelGGL(maxpool2x2_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
+                     (const uint16_t*)src, B, H, W, CP, (uint16_t*)dst);
+  SA_LAUNCH_CHECK();
+  return SA_OK;
+}
+
+int sa_upsample2x_bf16(const void* src, int B, int H, int W, int CP, int bilinear, void* dst,
+                       sa_stream_t stream) {
+  SA_REQUIRE(CP % 8 == 0, "sa_upsample2x_bf16: CP%%8 != 0");
+  const size_t total = (size_t)B * 4 * H * W * (CP / 8);
+  hipLaunchKernelGGL(upsample2x_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
+                     (const uint16_t*)src, B, H, W, CP, bilinear, (uint16_t*)dst);
+  SA_LAUNCH_CHECK();
+  return SA_OK;
+}
+
+int sa_conv1x1_head(const void* src, int CinP, const float* w, const float* bias, int Cout, int act,
+                    int B, int H, int W, float* dst, sa_stream_t stream) {
+  SA_REQUIRE(CinP % 8 == 0 && Cout > 0, "sa_conv1x1_head: CinP%%8 != 0 or Cout <= 0");
+  SA_REQUIRE(act == 0 || act == 1, "sa_conv1x1_head: act must be 0 (linear) or 1 (sigmoid)");
+  constexpr int CO = 8;
+  const int CoutR = (Cout + CO - 1) / CO * CO;
+  const size_t lds = sizeof(float) * (size_t)CoutR * CinP;
+  SA_REQUIRE(lds <= 64 * 1024, "sa_conv1x1_head: weights (%zu B) exceed the LDS budget", lds);
+  const size_t n_pix = (size_t)B * H * W;
+  hipLaunchKernelGGL((conv1x1_head_kernel<CO>), dim3(grid_for(n_pix)), dim3(256), lds, (hipStream_t)stream,
+                     (const uint16_t*)src, CinP, w, bias, Cout, act, n_pix, dst);
+  SA_LAUNCH_CHECK();
+  return SA_OK;
+}
+
+int sa_convt3x3s2_bf16(const void* src, int CinP, const void* w, const float* bias, int CoutP,
+                       int relu, int B, int H, int W, void* dst, sa_stream_t stream) {
+  SA_REQUIRE(CinP % 8 == 0 && CoutP % 8 == 0, "sa_convt3x3s2_bf16: channel padding");
+  const size_t total = (size_t)B * 4 * H * W * CoutP;
+  hipLaunchKernelGGL(convt3x3s2_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
+                     (const uint16_t*)src, CinP, (const uint16_t*)w, bias, CoutP, relu, B, H, W, (uint16_t*)dst);
+  SA_LAUNCH_CHECK();
+  return SA_OK;
+}
+
+int sa_f32_to_bf16_padded(const float* src, int n_pix, int C, int CP, void* dst, sa_stream_t stream) {
+  SA_REQUIRE(CP >= C && C > 0, "sa_f32_to_bf16_padded: CP < C");
+  hipLaunchKernelGGL(f32_to_bf16_padded_kernel, dim3(grid_for((size_t)n_pix * CP)), dim3(256), 0,
+                     (hipStream_t)stream, src, (size_t)n_pix, C, CP, (uint16_t*)dst);
+  SA_LAUNCH_CHECK();
+  return SA_OK;
+}
+
+int sa_bf16_to_f32(const void* src, int n_pix, int CP, int C, float* dst, sa_stream_t stream) {
+  SA_REQUIRE(CP >= C && C > 0, "sa_bf16_to_f32: CP < C");
+  hipLaunchKernelGGL(bf16_to_f32_kernel, dim3(grid_for((size_t)n_pix * C)), dim3(256), 0, (hipStream_t)stream,
+                     (const uint16_t*)src, (size_t)n_pix, CP, C, dst);
+  SA_LAUNCH_CHECK();
+  return SA_OK;
+}
+
+}  // extern "C"

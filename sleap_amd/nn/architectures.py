@@ -1,0 +1,161 @@
+"""Builds the Keras functional-graph description of SLEAP's UNet backbones + heads.
+
+Mirrors, as plain data (layer list with the reference's layer names and wiring), what the reference
+builds with Keras objects:
+    sleap/nn/architectures/unet.py:46-278             UNet (stem / encoder / decoder stacks, from_config)
+    sleap/nn/architectures/encoder_decoder.py:57-676  SimpleConvBlock, SimpleUpsamplingBlock, make_backbone
+    sleap/nn/heads.py:42-62                           Head.make_head (1x1 linear Conv2D named after the head class)
+    sleap/nn/model.py:312-364                         Model.make_model (heads attach at matching stride)
+The result has the same schema as `json.loads(h5.attrs["model_config"])` so the engine, the
+oracle and a real `best_model.h5` all go through one code path. Used for randomly initialised
+benchmark models (there are no trained 1024x1024 checkpoints offline).
+"""
+import math
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+
+class _G:
+    def __init__(self):
+        self.layers = []
+
+    def add(self, class_name, name, config, inputs):
+        cfg = dict(config)
+        cfg["name"] = name
+        self.layers.append({
+            "class_name": class_name, "name": name, "config": cfg,
+            "inbound_nodes": [[[i, 0, 0, {}] for i in inputs]] if inputs else [],
+        })
+        return name
+
+
+def _conv(g, x, name, filters, k=3, activation="linear"):
+    return g.add("Conv2D", name, {"filters": int(filters), "kernel_size": [k, k], "strides": [1, 1], "padding": "same",
+                                  "activation": activation, "use_bias": True, "dilation_rate": [1, 1]}, [x])
+
+
+def _relu(g, x, name):
+    return g.add("Activation", name, {"activation": "relu"}, [x])
+
+
+def build_unet_model_config(input_shape: Tuple[int, int, int], filters: int = 16, filters_rate: float = 2.0,
+                            max_stride: int = 32, output_stride: int = 4, middle_block: bool = True,
+                            up_interpolate: bool = True, stem_stride: Optional[int] = None,
+                            heads: Sequence[Tuple[str, int, int]] = ()) -> Tuple[dict, Dict[str, tuple]]:
+    """`heads` = [(head_class_name, channels, output_stride), ...] in model-output order.
+
+    Returns (model_config, weight_shapes) where weight_shapes maps "<layer>/kernel|bias" to shapes.
+    """
+    if stem_stride is not None:
+        raise NotImplementedError("UNet stem blocks (stem_stride) are not implemented")
+    convs_per_block, kernel = 2, 3  # UNet.from_config fixes these (unet.py:266-278)
+    down_blocks = int(math.log2(max_stride))
+    up_blocks = int(math.log2(max_stride / output_stride))
+    g = _G()
+    shapes = {}
+    x = g.add("InputLayer", "input", {"batch_input_shape": [None, input_shape[0], input_shape[1], input_shape[2]]}, [])
+    cur_c = input_shape[2]
+
+    def conv(x, name, f, cin, k=3):
+        shapes[f"{name}/kernel"] = (k, k, cin, int(f))
+        shapes[f"{name}/bias"] = (int(f),)
+        return _conv(g, x, name, f, k)
+
+    # ---- encoder (unet.py:136-205; SimpleConvBlock.make_block encoder_decoder.py:92-144)
+    prefix = "stack0_enc"
+    skips = {}  # stride -> (tensor name, channels)
+    stride = 1
+    for block in range(down_blocks):
+        f = int(filters * (filters_rate ** block))
+        if block > 0:
+            x = g.add("MaxPooling2D", f"{prefix}{block}_pool", {"pool_size": [2, 2], "strides": [2, 2], "padding": "same"}, [x])
+            stride *= 2
+        for i in range(convs_per_block):
+            x = conv(x, f"{prefix}{block}_conv{i}", f, cur_c)
+            cur_c = f
+            x = _relu(g, x, f"{prefix}{block}_act{i}_relu")
+        skips[stride] = (x, cur_c)
+    x = g.add("MaxPooling2D", f"{prefix}{down_blocks}_last_pool", {"pool_size": [2, 2], "strides": [2, 2], "padding": "same"}, [x])
+    stride *= 2
+    bi = down_blocks + 1
+    if middle_block:
+        f = int(filters * (filters_rate ** down_blocks))
+        if convs_per_block > 1:
+            name = f"{prefix}{bi}_middle_expand"
+            x = conv(x, f"{name}_conv0", f, cur_c)
+            cur_c = f
+            x = _relu(g, x, f"{name}_act0_relu")
+            bi += 1
+        name = f"{prefix}{bi}_middle_contract"
+        x = conv(x, f"{name}_conv0", f, cur_c)
+        cur_c = f
+        x = _relu(g, x, f"{name}_act0_relu")
+    # ---- decoder (unet.py:207-247; SimpleUpsamplingBlock.make_block encoder_decoder.py:275-399)
+    mids = {stride: (x, cur_c)}
+    for block in range(up_blocks):
+        f = int(filters * (filters_rate ** (down_blocks - 1 - block)))
+        nxt = stride // 2
+        name = f"stack0_dec{block}_s{stride}_to_s{nxt}"
+        if up_interpolate:
+            x = g.add("UpSampling2D", f"{name}_interp_bilinear", {"size": [2, 2], "interpolation": "bilinear"}, [x])
+        else:
+            shapes[f"{name}_trans_conv/kernel"] = (kernel, kernel, int(f), cur_c)
+            shapes[f"{name}_trans_conv/bias"] = (int(f),)
+            x = g.add("Conv2DTranspose", f"{name}_trans_conv",
+                      {"filters": int(f), "kernel_size": [3, 3], "strides": [2, 2], "padding": "same",
+                       "activation": "linear", "use_bias": True, "dilation_rate": [1, 1], "output_padding": None}, [x])
+            cur_c = f
+            x = _relu(g, x, f"{name}_trans_conv_act_relu")
+        if nxt in skips:
+            sk, sc = skips[nxt]
+            x = g.add("Concatenate", f"{name}_skip_concat", {"axis": -1}, [sk, x])
+            cur_c += sc
+        for i in range(convs_per_block):
+            x = conv(x, f"{name}_refine_conv{i}", f, cur_c)
+            cur_c = f
+            x = _relu(g, x, f"{name}_refine_conv{i}_act_relu")
+        stride = nxt
+        mids[stride] = (x, cur_c)
+    # ---- heads (model.py:336-359): main output if strides match, else the decoder feature of that stride
+    outs = []
+    for head_name, channels, hs in heads:
+        if hs not in mids:
+            raise ValueError(f"Could not find a feature activation for output at stride {hs}.")
+        src, sc = mids[hs]
+        shapes[f"{head_name}/kernel"] = (1, 1, sc, int(channels))
+        shapes[f"{head_name}/bias"] = (int(channels),)
+        outs.append(_conv(g, src, head_name, channels, k=1))
+    cfg = {"class_name": "Functional",
+           "config": {"name": "model", "layers": g.layers, "input_layers": [["input", 0, 0]],
+                      "output_layers": [[o, 0, 0] for o in outs]}}
+    return cfg, shapes
+
+
+def he_normal_weights(shapes: Dict[str, tuple], seed: int = 0) -> Dict[str, np.ndarray]:
+    """Deterministic He-normal kernels / small biases (random-init weights for benchmarking)."""
+    rng = np.random.default_rng(seed)
+    w = {}
+    for k in sorted(shapes):
+        s = shapes[k]
+        if k.endswith("/kernel"):
+            fan_in = s[0] * s[1] * (s[3] if "trans_conv" in k else s[2])
+            w[k] = (rng.standard_normal(s) * math.sqrt(2.0 / fan_in)).astype(np.float32)
+        else:
+            w[k] = (rng.standard_normal(s) * 0.01).astype(np.float32)
+    return w
+
+
+def unet_from_training_config(cfg: dict, input_shape, n_nodes=None, n_edges=None):
+    """Model.from_config + make_model for a `multi_instance` (bottom-up) training config dict."""
+    u = cfg["model"]["backbone"]["unet"]
+    mi = cfg["model"]["heads"]["multi_instance"]
+    nodes = mi["confmaps"].get("part_names") or [None] * n_nodes
+    edges = mi["pafs"].get("edges") or [None] * n_edges
+    heads = [("MultiInstanceConfmapsHead", len(nodes), mi["confmaps"]["output_stride"]),
+             ("PartAffinityFieldsHead", 2 * len(edges), mi["pafs"]["output_stride"])]
+    if mi["confmaps"].get("offset_refinement"):
+        heads.append(("OffsetRefinementHead", 2 * len(nodes), mi["confmaps"]["output_stride"]))
+    return build_unet_model_config(input_shape, u["filters"], u["filters_rate"], u["max_stride"], u["output_stride"],
+                                   u.get("middle_block", True), u.get("up_interpolate", True), u.get("stem_stride"),
+                                   heads)

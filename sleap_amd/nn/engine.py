@@ -1,0 +1,387 @@
+"""Executes a SLEAP Keras functional graph (the content of `best_model.h5`) on MI355X.
+
+Stands in for `tf.keras.models.load_model(...)` + `keras_model(imgs)` of the reference
+(sleap/nn/inference.py:3207, 2864-2890). The graph is compiled once into a flat plan of fused HIP
+launches (include/sleap_amd.h):
+
+    Conv2D(k3)+bias+Activation(relu)                      -> sa_conv3x3_bf16 (MFMA implicit GEMM)
+    MaxPooling2D(2) feeding a Conv2D                       -> folded into that conv's tile load
+    Concatenate([skip, UpSampling2D(2,bilinear)(x)])+Conv  -> two-source K loop, upsample-on-load
+    InputLayer(+ensure_float) + first Conv2D               -> sa_stem_conv3x3 (u8 in, bf16 out)
+    1x1 linear head convs                                  -> sa_conv1x1_head (f32 out)
+    Conv2DTranspose(k3,s2)+Activation                      -> sa_convt3x3s2_bf16
+
+Activations are bf16 NHWC with channels padded to a multiple of 16; accumulation is fp32.
+torch is used for device memory only.
+"""
+import ctypes as C
+import json
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch
+
+from .. import _lib
+from .._lib import check
+from ..ops import _ptr, _stream, require_cuda
+
+
+def _pad16(c):
+    return (c + 15) // 16 * 16
+
+
+class _T:
+    """A (possibly virtual) activation tensor in the plan."""
+
+    def __init__(self, kind, c, scale_num=1, scale_den=1, buf=None, parts=None, src=None, interp=None):
+        self.kind = kind  # "input" | "real" | "pool" | "up" | "concat" | "f32out"
+        self.c = c  # logical channels
+        self.cp = _pad16(c)
+        self.num, self.den = scale_num, scale_den  # spatial size = in_size * num / den
+        self.buf = buf  # plan buffer id for real tensors
+        self.parts = parts  # concat: list of _T
+        self.src = src  # pool/up: source _T
+        self.interp = interp
+
+
+class DeviceNetwork:
+    def __init__(self, model_config: dict, weights: Dict[str, np.ndarray], device=None):
+        require_cuda()
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        cfg = model_config["config"]
+        self.layers = cfg["layers"]
+        self.input_name = cfg["input_layers"][0][0]
+        self.output_names = [l[0] for l in cfg["output_layers"]]
+        self.weights = weights
+        self.in_channels = None
+        for l in self.layers:
+            if l["class_name"] == "InputLayer":
+                self.in_channels = l["config"]["batch_input_shape"][-1]
+        self._compile()
+        self._buffers = {}
+
+    # ------------------------------------------------------------------ compile
+    def _consumers(self):
+        cons = {}
+        for l in self.layers:
+            for node in l["inbound_nodes"][:1]:
+                for inp in node:
+                    cons.setdefault(inp[0], []).append(l["name"])
+        return cons
+
+    def _compile(self):
+        dev = self.device
+        cons = self._consumers()
+        by_name = {l["name"]: l for l in self.layers}
+        t: Dict[str, _T] = {}
+        plan = []
+        n_buf = [0]
+        self.buf_meta = {}  # id -> (cp, num, den, dtype)
+        skip = set()  # layers fused into a predecessor
+
+        def new_buf(c_alloc, num, den, dtype):
+            i = n_buf[0]
+            n_buf[0] += 1
+            self.buf_meta[i] = (c_alloc, num, den, dtype)
+            return i
+
+        def materialize(v: _T) -> _T:
+            """Return a real bf16 tensor for v, emitting standalone kernels if needed."""
+            if v.kind == "real":
+                return v
+            if v.kind == "pool":
+                s = materialize(v.src)
+                o = _T("real", v.c, v.num, v.den, buf=new_buf(v.cp, v.num, v.den, "bf16"))
+                plan.append(("pool", s, o))
+                return o
+            if v.kind == "up":
+                s = materialize(v.src)
+                o = _T("real", v.c, v.num, v.den, buf=new_buf(v.cp, v.num, v.den, "bf16"))
+                plan.append(("up", s, o, 1 if v.interp == "bilinear" else 0))
+                return o
+            raise NotImplementedError(f"cannot materialize tensor kind {v.kind}")
+
+        def upload_f32(a):
+            return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev)
+
+        def padded_bias(name, cout, coutp, use_bias=True):
+            b = np.zeros((coutp,), np.float32)
+            if use_bias and f"{name}/bias" in self.weights:
+                b[:cout] = self.weights[f"{name}/bias"]
+            return upload_f32(b)
+
+        def conv_activation(l):
+            """Fuse a following Activation(relu) layer if it is the conv's only consumer."""
+            name, act = l["name"], l["config"].get("activation", "linear")
+            out_name = name
+            c = cons.get(name, [])
+            if act == "linear" and len(c) == 1 and by_name[c[0]]["class_name"] == "Activation" \
+                    and name not in self.output_names:
+                a = by_name[c[0]]["config"]["activation"]
+                if a in ("relu", "linear"):
+                    act = a
+                    out_name = c[0]
+                    skip.add(c[0])
+            if act not in ("relu", "linear"):
+                raise NotImplementedError(f"activation {act} on {name}")
+            return out_name, 1 if act == "relu" else 0
+
+        for l in self.layers:
+            cn, name, c = l["class_name"], l["name"], l["config"]
+            if name in skip:
+                continue
+            if cn == "InputLayer":
+                t[name] = _T("input", c["batch_input_shape"][-1])
+                continue
+            ins = [t[n[0]] for n in l["inbound_nodes"][0]]
+            if cn == "Conv2D":
+                k = tuple(c["kernel_size"])
+                if tuple(c["strides"]) != (1, 1) or c["padding"] != "same" or tuple(c.get("dilation_rate", (1, 1))) != (1, 1):
+                    raise NotImplementedError(f"Conv2D {name}: only stride 1 / same / no dilation is implemented")
+                kern = np.asarray(self.weights[f"{name}/kernel"], np.float32)
+                cin, cout = kern.shape[2], kern.shape[3]
+                x = ins[0]
+                if k == (1, 1) and name in self.output_names:
+                    act = {"linear": 0, "sigmoid": 1}.get(c.get("activation", "linear"))
+                    if act is None:
+                        raise NotImplementedError(f"head {name}: activation {c.get('activation')}")
+                    s = materialize(x)
+                    w = np.zeros((cout, s.cp), np.float32)
+                    w[:, :cin] = kern[0, 0].T
+                    bias = np.zeros((cout,), np.float32)
+                    if c.get("use_bias", True):
+                        bias[:] = self.weights[f"{name}/bias"]
+                    o = _T("f32out", cout, s.num, s.den, buf=new_buf(cout, s.num, s.den, "f32"))
+                    plan.append(("head", s, o, upload_f32(w), upload_f32(bias), act))
+                    t[name] = o
+                    continue
+                if k != (3, 3):
+                    raise NotImplementedError(f"Conv2D {name}: kernel {k} not implemented")
+                out_name, relu = conv_activation(l)
+                coutp = _pad16(cout)
+                bias = padded_bias(name, cout, coutp, c.get("use_bias", True))
+                o = _T("real", cout, x.num, x.den, buf=new_buf(coutp, x.num, x.den, "bf16"))
+                if x.kind == "input":
+                    if cin not in (1, 3):
+                        raise NotImplementedError("stem conv needs 1 or 3 input channels")
+                    w = np.zeros((3, 3, cin, coutp), np.float32)
+                    w[..., :cout] = kern
+                    plan.append(("stem", o, upload_f32(w), bias, cin, relu))
+                else:
+                    mode, s0, s1 = _lib.SRC1_NONE, None, None
+                    if x.kind == "concat":
+                        if len(x.parts) != 2:
+                            raise NotImplementedError("Concatenate with != 2 inputs")
+                        s0 = materialize(x.parts[0])
+                        p1 = x.parts[1]
+                        if p1.kind == "up" and p1.interp == "bilinear":
+                            s1, mode = materialize(p1.src), _lib.SRC1_UPSAMPLE2X
+                        else:
+                            s1, mode = materialize(p1), _lib.SRC1_DIRECT
+                    elif x.kind == "pool":
+                        s0, mode = materialize(x.src), _lib.SRC0_POOL2X
+                    else:
+                        s0 = materialize(x)
+                    c0, c1 = s0.c, (s1.c if s1 is not None else 0)
+                    assert c0 + c1 == cin, (name, c0, c1, cin)
+                    c0p, c1p = s0.cp, (s1.cp if s1 is not None else 0)
+                    h = _lib.lib()
+                    n = h.sa_conv3x3_packed_elems(c0p, c1p, coutp)
+                    packed = np.zeros((n,), np.uint16)
+                    kc = np.ascontiguousarray(kern)
+                    check(h.sa_pack_conv3x3_weights(kc.ctypes.data_as(C.c_void_p), c0, c0p, c1, c1p, cout, coutp,
+                                                    packed.ctypes.data_as(C.c_void_p)), "sa_pack_conv3x3_weights")
+                    wdev = torch.from_numpy(packed.view(np.int16)).to(dev)
+                    plan.append(("conv", s0, s1, mode, wdev, bias, o, relu))
+                t[out_name] = o
+                t[name] = o
+            elif cn == "Conv2DTranspose":
+                if tuple(c["kernel_size"]) != (3, 3) or tuple(c["strides"]) != (2, 2) or c["padding"] != "same":
+                    raise NotImplementedError(f"Conv2DTranspose {name}: only k3 s2 same is implemented")
+                kern = np.asarray(self.weights[f"{name}/kernel"], np.float32)  # (kh, kw, Cout, Cin)
+                cout, cin = kern.shape[2], kern.shape[3]
+                s = materialize(ins[0])
+                out_name, relu = conv_activation(l)
+                coutp = _pad16(cout)
+                w = np.zeros((3, 3, coutp, s.cp), np.float32)
+                w[:, :, :cout, :cin] = kern
+                wb = torch.from_numpy(w).to(dev).to(torch.bfloat16).contiguous()
+                bias = padded_bias(name, cout, coutp, c.get("use_bias", True))
+                o = _T("real", cout, s.num * 2, s.den, buf=new_buf(coutp, s.num * 2, s.den, "bf16"))
+                plan.append(("convt", s, wb, bias, o, relu))
+                t[out_name] = o
+                t[name] = o
+            elif cn == "Activation":
+                raise NotImplementedError(f"standalone Activation {name} (not fused into a conv)")
+            elif cn == "MaxPooling2D":
+                if tuple(c["pool_size"]) != (2, 2) or tuple(c["strides"]) != (2, 2):
+                    raise NotImplementedError(f"MaxPooling2D {name}: only 2x2 s2 is implemented")
+                x = ins[0]
+                t[name] = _T("pool", x.c, x.num, x.den * 2, src=x)
+            elif cn == "UpSampling2D":
+                if tuple(c["size"]) != (2, 2):
+                    raise NotImplementedError(f"UpSampling2D {name}: only x2 is implemented")
+                x = ins[0]
+                t[name] = _T("up", x.c, x.num * 2, x.den, src=x, interp=c.get("interpolation", "nearest"))
+            elif cn == "Concatenate":
+                t[name] = _T("concat", sum(i.c for i in ins), ins[0].num, ins[0].den, parts=ins)
+            else:
+                raise NotImplementedError(f"Keras layer {cn} ({name}) is not implemented in the HIP engine")
+        self.plan = plan
+        self.outputs = []
+        for n in self.output_names:
+            o = t[n]
+            if o.kind != "f32out":
+                raise NotImplementedError(f"model output {n} is not a 1x1 linear head")
+            self.outputs.append(o)
+        self.n_buf = n_buf[0]
+        # reduce fractions for stride bookkeeping
+        self.max_stride = max(den // max(num, 1) for (_, num, den, _) in self.buf_meta.values())
+
+    def output_strides(self):
+        return [o.den // o.num for o in self.outputs]
+
+    # ------------------------------------------------------------------ run
+    def _get_buffers(self, B, H, W):
+        key = (B, H, W)
+        if key not in self._buffers:
+            bufs = {}
+            for i, (c_alloc, num, den, dt) in self.buf_meta.items():
+                h, w = H * num // den, W * num // den
+                dtype = torch.bfloat16 if dt == "bf16" else torch.float32
+                bufs[i] = torch.empty((B, h, w, c_alloc), dtype=dtype, device=self.device)
+            self._buffers = {key: bufs}  # keep one shape resident
+        return self._buffers[key]
+
+    def rescale_head(self, output_index: int, scale, shift):
+        """out' = scale[c] * out + shift[c] folded into the 1x1 head's weights (used to calibrate random heads)."""
+        target = self.outputs[output_index]
+        for op in self.plan:
+            if op[0] == "head" and op[2] is target:
+                w, b = op[3], op[4]
+                sc = torch.as_tensor(scale, dtype=torch.float32, device=w.device).reshape(-1)
+                sh = torch.as_tensor(shift, dtype=torch.float32, device=w.device).reshape(-1)
+                w.mul_(sc[:, None])
+                b.mul_(sc).add_(sh)
+                return
+        raise KeyError(output_index)
+
+    def export_head(self, output_index: int):
+        """-> (kernel (1,1,Cin,Cout) float32, bias (Cout,)) of the 1x1 head as currently held on the device."""
+        target = self.outputs[output_index]
+        for op in self.plan:
+            if op[0] == "head" and op[2] is target:
+                s, w, b = op[1], op[3].cpu().numpy(), op[4].cpu().numpy()
+                return np.ascontiguousarray(w[:, : s.c].T)[None, None], b.copy()
+        raise KeyError(output_index)
+
+    def op_descriptions(self, H, W):
+        """[(kind, name-ish, algorithmic FLOPs per frame)] in plan order."""
+        out = []
+        for op in self.plan:
+            k = op[0]
+            if k == "stem":
+                o, cin = op[1], op[4]
+                f = 2 * (H * o.num // o.den) * (W * o.num // o.den) * cin * o.c * 9
+                out.append((k, f"stem {cin}->{o.c} @{H * o.num // o.den}", f))
+            elif k == "conv":
+                s0, s1, o = op[1], op[2], op[6]
+                cin = s0.c + (s1.c if s1 is not None else 0)
+                f = 2 * (H * o.num // o.den) * (W * o.num // o.den) * cin * o.c * 9
+                out.append((k, f"conv3x3 {cin}->{o.c} @{H * o.num // o.den} mode{op[3]}", f))
+            elif k == "head":
+                s, o = op[1], op[2]
+                out.append((k, f"head {s.c}->{o.c} @{H * s.num // s.den}", 2 * (H * s.num // s.den) * (W * s.num // s.den) * s.c * o.c))
+            elif k == "convt":
+                s, o = op[1], op[4]
+                out.append((k, f"convT {s.c}->{o.c} @{H * s.num // s.den}", 2 * (H * s.num // s.den) * (W * s.num // s.den) * s.c * o.c * 9))
+            else:
+                out.append((k, k, 0))
+        return out
+
+    def forward(self, imgs: torch.Tensor, profile: Optional[list] = None) -> List[torch.Tensor]:
+        """imgs: (B, H, W, C) uint8 or float32 CUDA tensor, H and W multiples of the max stride.
+        Returns the model outputs (float32, NHWC) in `output_names` order. The returned tensors are
+        views of cached buffers that the next call overwrites."""
+        assert imgs.is_cuda and imgs.is_contiguous()
+        B, H, W, Cin = imgs.shape
+        if H % self.max_stride or W % self.max_stride:
+            raise ValueError(f"input size {(H, W)} must be a multiple of the model stride {self.max_stride}")
+        bufs = self._get_buffers(B, H, W)
+        h = _lib.lib()
+        st = _stream()
+
+        def hw(tt):
+            return H * tt.num // tt.den, W * tt.num // tt.den
+
+        for op in self.plan:
+            kind = op[0]
+            if profile is not None:
+                ev0 = torch.cuda.Event(enable_timing=True)
+                ev1 = torch.cuda.Event(enable_timing=True)
+                ev0.record()
+                profile.append((ev0, ev1))
+            if kind == "stem":
+                _, o, w, bias, cin, relu = op
+                if cin != Cin:
+                    raise ValueError(f"model expects {cin} input channels, got {Cin}")
+                is_u8 = 1 if imgs.dtype == torch.uint8 else 0
+                if not is_u8 and imgs.dtype != torch.float32:
+                    raise ValueError("images must be uint8 or float32")
+                check(h.sa_stem_conv3x3(_ptr(imgs), is_u8, B, H, W, cin, _ptr(w), _ptr(bias), o.cp, relu,
+                                        _ptr(bufs[o.buf]), st), "sa_stem_conv3x3")
+            elif kind == "conv":
+                _, s0, s1, mode, w, bias, o, relu = op
+                oh, ow = hw(o)
+                check(h.sa_conv3x3_bf16(_ptr(bufs[s0.buf]), s0.cp, _ptr(bufs[s1.buf]) if s1 is not None else None,
+                                        s1.cp if s1 is not None else 0, mode, _ptr(w), _ptr(bias), o.cp, relu, B, oh, ow,
+                                        _ptr(bufs[o.buf]), st), "sa_conv3x3_bf16")
+            elif kind == "head":
+                _, s, o, w, bias, act = op
+                sh, sw = hw(s)
+                check(h.sa_conv1x1_head(_ptr(bufs[s.buf]), s.cp, _ptr(w), _ptr(bias), o.c, act, B, sh, sw,
+                                        _ptr(bufs[o.buf]), st), "sa_conv1x1_head")
+            elif kind == "pool":
+                _, s, o = op
+                sh, sw = hw(s)
+                check(h.sa_maxpool2x2_bf16(_ptr(bufs[s.buf]), B, sh, sw, s.cp, _ptr(bufs[o.buf]), st), "sa_maxpool2x2_bf16")
+            elif kind == "up":
+                _, s, o, bil = op
+                sh, sw = hw(s)
+                check(h.sa_upsample2x_bf16(_ptr(bufs[s.buf]), B, sh, sw, s.cp, bil, _ptr(bufs[o.buf]), st), "sa_upsample2x_bf16")
+            elif kind == "convt":
+                _, s, w, bias, o, relu = op
+                sh, sw = hw(s)
+                check(h.sa_convt3x3s2_bf16(_ptr(bufs[s.buf]), s.cp, _ptr(w), _ptr(bias), o.cp, relu, B, sh, sw,
+                                           _ptr(bufs[o.buf]), st), "sa_convt3x3s2_bf16")
+            else:
+                raise AssertionError(kind)
+            if profile is not None:
+                ev1.record()
+        return [bufs[o.buf] for o in self.outputs]
+
+    def conv_flops(self, H, W):
+        """2*H*W*Cin*Cout*k*k over all convs for ONE frame (logical channels)."""
+        total = 0
+        for op in self.plan:
+            if op[0] == "stem":
+                o, cin = op[1], op[4]
+                total += 2 * (H * o.num // o.den) * (W * o.num // o.den) * cin * o.c * 9
+            elif op[0] == "conv":
+                s0, s1, o = op[1], op[2], op[6]
+                cin = s0.c + (s1.c if s1 is not None else 0)
+                total += 2 * (H * o.num // o.den) * (W * o.num // o.den) * cin * o.c * 9
+            elif op[0] == "head":
+                s, o = op[1], op[2]
+                total += 2 * (H * s.num // s.den) * (W * s.num // s.den) * s.c * o.c
+            elif op[0] == "convt":
+                s, o = op[1], op[4]
+                total += 2 * (H * s.num // s.den) * (W * s.num // s.den) * s.c * o.c * 9
+        return total
+
+
+def load_keras_npz(path):
+    """Read a model extracted by tools/h5_extract.py -> (model_config, weights)."""
+    z = np.load(path)
+    cfg = json.loads(bytes(z["__model_config__"]).decode("utf-8"))
+    return cfg, {k: z[k] for k in z.files if k != "__model_config__"}

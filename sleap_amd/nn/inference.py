@@ -1,0 +1,532 @@
+"""Bottom-up inference with the reference's `sleap.nn.inference` surface, running on MI355X.
+
+Mirrors (names, arguments, defaults, output dictionary keys, error behaviour):
+    InferenceLayer            sleap/nn/inference.py:897-978
+    InferenceModel            :981-1171   (predict / predict_on_batch; NaN-padded "unragged" outputs + n_valid)
+    get_model_output_stride   :1174-1201
+    find_head                 :1204-1226
+    BottomUpInferenceLayer    :2737-3003
+    BottomUpInferenceModel    :3006-3052
+    Predictor                 :158-591    (from_model_paths, predict, _predict_generator)
+    BottomUpPredictor         :3055-3348
+    load_model                :4865-5004
+
+The network runs through `engine.DeviceNetwork`, peaks and grouping through the HIP kernels behind
+`ops`; a batch never leaves the device until the final, single D2H copy of the fixed-shape result.
+With `torch.distributed` initialised, `BottomUpPredictor.predict` shards every global batch by
+contiguous frame ranges and gathers the packed results with ONE all-gather (RCCL) per batch.
+"""
+import json
+import os
+import time
+import zipfile
+import tempfile
+from typing import Dict, Iterator, List, Optional, Union
+
+import numpy as np
+import torch
+
+from .. import _lib, ops, parallel
+from . import model_io
+from .engine import DeviceNetwork
+from .paf_grouping import GroupingOverflowError, PAFScorer
+
+
+def find_head(model, name: str) -> Optional[int]:
+    """inference.py:1204-1226 -- index of the first output whose name CONTAINS `name`."""
+    for i, head_name in enumerate(model.output_names):
+        if name in head_name:
+            return i
+    return None
+
+
+def get_model_output_stride(model, input_ind: int = 0, output_ind: int = -1) -> int:
+    """inference.py:1174-1201 -- input size / output size of the given output."""
+    return int(model.output_strides()[output_ind])
+
+
+def _as_device_images(data) -> torch.Tensor:
+    if isinstance(data, dict):
+        data = data["image"]
+    if isinstance(data, torch.Tensor):
+        t = data
+    else:
+        t = torch.from_numpy(np.ascontiguousarray(data))
+    if t.ndim == 3:
+        t = t[None]
+    if t.ndim != 4:
+        raise ValueError(f"images must have shape (samples, height, width, channels), got {tuple(t.shape)}")
+    ops.require_cuda()
+    if t.dtype not in (torch.uint8, torch.float32):
+        t = t.to(torch.float32)
+    return t.cuda(non_blocking=True).contiguous()
+
+
+class InferenceLayer:
+    """Wraps the network with the reference's preprocessing (inference.py:897-978).
+
+    Attributes: keras_model (a `DeviceNetwork`), input_scale, pad_to_stride, ensure_grayscale
+    (None = infer from the model's input channels), ensure_float.
+    """
+
+    def __init__(self, keras_model: DeviceNetwork, input_scale: float = 1.0, pad_to_stride: int = 1,
+                 ensure_grayscale: Optional[bool] = None, ensure_float: bool = True, **kwargs):
+        self.keras_model = keras_model
+        self.input_scale = input_scale
+        self.pad_to_stride = pad_to_stride
+        if ensure_grayscale is None:
+            ensure_grayscale = keras_model.in_channels == 1
+        self.ensure_grayscale = ensure_grayscale
+        self.ensure_float = ensure_float
+
+    def preprocess(self, imgs, resize_img: bool = True) -> torch.Tensor:
+        """inference.py:940-967: grayscale|rgb -> float -> resize -> pad (bottom/right zeros).
+
+        uint8 batches that need no resize stay uint8: the `* 1/255` of ensure_float
+        (normalization.py:49) is fused into the first convolution's load (sa_stem_conv3x3).
+        """
+        x = _as_device_images(imgs)
+        if self.ensure_grayscale:
+            x = _ensure_grayscale(x)
+        else:
+            x = _ensure_rgb(x)
+        if resize_img and self.input_scale != 1.0:
+            if self.ensure_float and x.dtype == torch.uint8:
+                x = x.to(torch.float32) * np.float32(1.0 / 255.0)
+            x = _resize_image(x, self.input_scale)
+        if self.pad_to_stride > 1:
+            x = _pad_to_stride(x, self.pad_to_stride)
+        return x
+
+    def call(self, data):
+        return self.keras_model.forward(self.preprocess(data))
+
+    __call__ = call
+
+
+def _ensure_grayscale(x):
+    """normalization.py:81-96 (tf.image.rgb_to_grayscale; integer images round-trip through float)."""
+    if x.shape[-1] == 1:
+        return x
+    w = torch.tensor([0.2989, 0.5870, 0.1140], dtype=torch.float32, device=x.device)
+    if x.dtype == torch.uint8:
+        g = ((x.to(torch.float32) * np.float32(1.0 / 255.0)) * w).sum(dim=-1, keepdim=True)
+        return (g * np.float32(255.5)).to(torch.uint8).contiguous()
+    return (x * w).sum(dim=-1, keepdim=True).contiguous()
+
+
+def _ensure_rgb(x):
+    """normalization.py:99-114."""
+    if x.shape[-1] == 1:
+        return x.expand(-1, -1, -1, 3).contiguous()
+    return x
+
+
+def _resize_image(x, scale):
+    """resizing.py:71-105: bilinear, half-pixel centres, no antialias; size = int(dim * scale)."""
+    H, W = x.shape[1], x.shape[2]
+    nh, nw = int(H * scale), int(W * scale)
+    y = torch.nn.functional.interpolate(x.to(torch.float32).permute(0, 3, 1, 2), size=(nh, nw), mode="bilinear",
+                                        align_corners=False, antialias=False).permute(0, 2, 3, 1)
+    if x.dtype == torch.uint8:
+        return y.to(torch.uint8).contiguous()
+    return y.contiguous()
+
+
+def _pad_to_stride(x, max_stride):
+    """resizing.py:34-68."""
+    B, H, W, Cc = x.shape
+    ph = (max_stride - H % max_stride) % max_stride
+    pw = (max_stride - W % max_stride) % max_stride
+    if ph == 0 and pw == 0:
+        return x
+    out = torch.zeros((B, H + ph, W + pw, Cc), dtype=x.dtype, device=x.device)
+    out[:, :H, :W] = x
+    return out
+
+
+class InferenceModel:
+    """inference.py:981-1171 -- input handling and "unragging" shared by all inference models."""
+
+    def call(self, example):  # overridden
+        raise NotImplementedError
+
+    def __call__(self, example):
+        return self.call(example)
+
+    @staticmethod
+    def _unrag(outs: Dict[str, torch.Tensor], numpy: bool):
+        """unrag_example (data/utils.py:118-146): crop the instance axis to the batch's bounding shape,
+        add `n_valid` (row lengths of the first ragged output, inference.py:1083-1088)."""
+        if not numpy:
+            return outs
+        n_valid = outs["n_valid"].cpu().numpy()
+        bound = int(n_valid.max()) if n_valid.size else 0
+        res = {}
+        for k, v in outs.items():
+            if k in ("instance_peaks", "instance_peak_vals", "instance_scores"):
+                res[k] = v[:, :bound].cpu().numpy()
+            elif isinstance(v, torch.Tensor):
+                res[k] = v.cpu().numpy()
+            else:
+                res[k] = v
+        res["n_valid"] = n_valid.astype(np.int64)
+        return res
+
+    def predict_on_batch(self, data, numpy: bool = False, **kwargs):
+        """inference.py:1047-1090."""
+        outs = self.call(data)
+        if numpy:
+            self._check_status(outs)
+        return self._unrag(outs, numpy)
+
+    def predict(self, data, numpy: bool = True, batch_size: int = 4, **kwargs):
+        """inference.py:989-1045 -- `data`: array/tensor (samples, H, W, C) or dict with key "image"."""
+        imgs = data["image"] if isinstance(data, dict) else data
+        n = len(imgs)
+        parts = []
+        for i in range(0, n, batch_size):
+            o = self.call(imgs[i : i + batch_size])
+            self._check_status(o)
+            parts.append({k: (v.clone() if isinstance(v, torch.Tensor) else v) for k, v in o.items()})
+        outs = {k: torch.cat([p[k] for p in parts], dim=0) for k in parts[0] if isinstance(parts[0][k], torch.Tensor)}
+        return self._unrag(outs, numpy)
+
+    def _check_status(self, outs):
+        st = outs.get("status")
+        if st is None:
+            return
+        bits = 0
+        for v in st.tolist():
+            bits |= int(v)
+        if bits & _lib.STATUS_LSA_INFEASIBLE:
+            raise ValueError("cost matrix is infeasible")  # what scipy raises inside the reference
+        if bits & (_lib.STATUS_PEAK_OVERFLOW | _lib.STATUS_NODE_PEAK_OVERFLOW | _lib.STATUS_INSTANCE_OVERFLOW):
+            raise GroupingOverflowError(
+                f"fixed-shape result buffers overflowed (status bits {bits}): raise max_peaks / "
+                "paf_scorer.max_node_peaks / paf_scorer.max_instances")
+
+
+class BottomUpInferenceLayer(InferenceLayer):
+    """inference.py:2737-3003. Same constructor arguments and mutable attributes as the reference.
+
+    New, device-buffer related: `max_peaks` (local peaks per frame held on the device).
+    """
+
+    def __init__(self, keras_model: DeviceNetwork, paf_scorer: PAFScorer, input_scale: float = 1.0,
+                 pad_to_stride: int = 1, cm_output_stride: Optional[int] = None,
+                 paf_output_stride: Optional[int] = None, peak_threshold: float = 0.2,
+                 refinement: Optional[str] = "local", integral_patch_size: int = 5, return_confmaps: bool = False,
+                 return_pafs: bool = False, return_paf_graph: bool = False, confmaps_ind: Optional[int] = None,
+                 pafs_ind: Optional[int] = None, offsets_ind: Optional[int] = None, max_peaks: int = 512, **kwargs):
+        super().__init__(keras_model=keras_model, input_scale=input_scale, pad_to_stride=pad_to_stride, **kwargs)
+        self.paf_scorer = paf_scorer
+        self.confmaps_ind = confmaps_ind
+        self.pafs_ind = pafs_ind
+        self.offsets_ind = offsets_ind
+        if self.confmaps_ind is None:
+            self.confmaps_ind = find_head(self.keras_model, "MultiInstanceConfmapsHead")
+        if self.confmaps_ind is None:
+            raise ValueError("Index of the confidence maps output tensor must be specified if not "
+                             "named 'MultiInstanceConfmapsHead'.")
+        if self.pafs_ind is None:
+            self.pafs_ind = find_head(self.keras_model, "PartAffinityFieldsHead")
+        if self.pafs_ind is None:
+            raise ValueError("Index of the part affinity fields output tensor must be specified if "
+                             "not named 'PartAffinityFieldsHead'.")
+        if self.offsets_ind is None:
+            self.offsets_ind = find_head(self.keras_model, "OffsetRefinementHead")
+        if cm_output_stride is None:
+            cm_output_stride = get_model_output_stride(self.keras_model, output_ind=self.confmaps_ind)
+        self.cm_output_stride = cm_output_stride
+        if paf_output_stride is None:
+            paf_output_stride = get_model_output_stride(self.keras_model, output_ind=self.pafs_ind)
+        self.paf_output_stride = paf_output_stride
+        self.peak_threshold = peak_threshold
+        self.refinement = refinement
+        self.integral_patch_size = integral_patch_size
+        self.return_confmaps = return_confmaps
+        self.return_pafs = return_pafs
+        self.return_paf_graph = return_paf_graph
+        self.max_peaks = max_peaks
+
+    def forward_pass(self, data):
+        """inference.py:2864-2890 -> (cms, pafs, offsets|None), float32 NHWC device tensors."""
+        imgs = self.preprocess(data)
+        preds = self.keras_model.forward(imgs)
+        offsets = preds[self.offsets_ind] if self.offsets_ind is not None else None
+        return preds[self.confmaps_ind], preds[self.pafs_ind], offsets
+
+    def find_peaks(self, cms, offsets, status=None):
+        """inference.py:2892-2936 in padded form: (peak_xy [B,P,2] image px, peak_val, peak_chan, peak_count, status).
+
+        `peaks * cm_output_stride` (:2921) is applied inside the kernel as a separate fp32 multiply."""
+        refinement = self.refinement if self.refinement in ("integral", "local") else None
+        return ops.find_local_peaks(cms, offsets, self.peak_threshold, refinement, self.integral_patch_size,
+                                    float(self.cm_output_stride), self.max_peaks, status)
+
+    def call(self, data):
+        """inference.py:2938-3003. Returns fixed-shape device tensors:
+        instance_peaks (B, I, N, 2), instance_peak_vals (B, I, N), instance_scores (B, I) NaN-padded along I,
+        n_valid (B,), status (B,) [+ confmaps, part_affinity_fields, paf graph tables if requested]."""
+        cms, pafs, offsets = self.forward_pass(data)
+        peak_xy, peak_val, peak_chan, peak_count, status = self.find_peaks(cms, offsets)
+        res = self.paf_scorer.predict_padded(pafs, peak_xy, peak_val, peak_chan, peak_count, status,
+                                             return_graph=self.return_paf_graph)
+        inst, vals, scores, n_inst = res[0], res[1], res[2], res[3]
+        if self.input_scale != 1.0:
+            inst = (inst / np.float32(self.input_scale)) + np.float32(0.5)  # :2980-2984
+        out = {"instance_peaks": inst, "instance_peak_vals": vals, "instance_scores": scores, "n_valid": n_inst,
+               "status": status}
+        if self.return_confmaps:
+            out["confmaps"] = cms
+        if self.return_pafs:
+            out["part_affinity_fields"] = pafs
+        if self.return_paf_graph:
+            out["peaks"], out["peak_vals"], out["peak_channel_inds"], out["peak_count"] = peak_xy, peak_val, peak_chan, peak_count
+            node_count, node_peaks, line_scores, match_dst, match_score = res[5]
+            out["paf_node_count"], out["paf_node_peaks"], out["line_scores"] = node_count, node_peaks, line_scores
+        return out
+
+    __call__ = call
+
+
+class BottomUpInferenceModel(InferenceModel):
+    """inference.py:3006-3052."""
+
+    def __init__(self, bottomup_layer: BottomUpInferenceLayer, **kwargs):
+        self.bottomup_layer = bottomup_layer
+
+    def call(self, example):
+        if isinstance(example, dict):
+            example = example["image"]
+        return self.bottomup_layer(example)
+
+
+# ----------------------------------------------------------------------------------------------------
+# Predictors
+# ----------------------------------------------------------------------------------------------------
+class Predictor:
+    """inference.py:158-591 (the parts on the bottom-up path)."""
+
+    verbosity = "none"
+    report_rate = 2.0
+    model_paths: List[str] = []
+
+    @classmethod
+    def from_model_paths(cls, model_paths, peak_threshold: float = 0.2, integral_refinement: bool = True,
+                         integral_patch_size: int = 5, batch_size: int = 4, resize_input_layer: bool = True,
+                         max_instances: Optional[int] = None) -> "Predictor":
+        """inference.py:176-311: dispatch on `model.heads` (only `multi_instance` is implemented)."""
+        if isinstance(model_paths, str):
+            model_paths = [model_paths]
+        model_configs = [model_io.load_training_config(p) for p in model_paths]
+        model_paths = [model_io.model_dir(p) for p in model_paths]
+        model_types = [model_io.head_type(c) for c in model_configs]
+        if "multi_instance" in model_types:
+            i = model_types.index("multi_instance")
+            predictor = BottomUpPredictor.from_trained_models(
+                model_paths[i], peak_threshold=peak_threshold, integral_refinement=integral_refinement,
+                integral_patch_size=integral_patch_size, batch_size=batch_size,
+                resize_input_layer=resize_input_layer, max_instances=max_instances)
+        else:
+            raise ValueError("Could not create predictor from model paths:" + "\n".join(model_paths)
+                             + f"\n(model types {model_types}: only bottom-up 'multi_instance' models run on this path)")
+        predictor.model_paths = model_paths
+        return predictor
+
+    @property
+    def is_grayscale(self) -> bool:
+        return self.inference_model.bottomup_layer.keras_model.in_channels == 1
+
+
+class BottomUpPredictor(Predictor):
+    """inference.py:3055-3348. Same fields and defaults as the reference's attrs class."""
+
+    def __init__(self, bottomup_config: dict, bottomup_model: DeviceNetwork, inference_model=None, pipeline=None,
+                 tracker=None, peak_threshold: float = 0.2, batch_size: int = 4, integral_refinement: bool = True,
+                 integral_patch_size: int = 5, max_edge_length_ratio: float = 0.25, dist_penalty_weight: float = 1.0,
+                 paf_line_points: int = 10, min_line_scores: float = 0.25, max_instances: Optional[int] = None,
+                 verbosity: str = "none", report_rate: float = 2.0, model_paths=None):
+        self.bottomup_config = bottomup_config
+        self.bottomup_model = bottomup_model
+        self.inference_model = inference_model
+        self.pipeline = pipeline
+        self.tracker = tracker
+        self.peak_threshold = peak_threshold
+        self.batch_size = batch_size
+        self.integral_refinement = integral_refinement
+        self.integral_patch_size = integral_patch_size
+        self.max_edge_length_ratio = max_edge_length_ratio
+        self.dist_penalty_weight = dist_penalty_weight
+        self.paf_line_points = paf_line_points
+        self.min_line_scores = min_line_scores
+        self.max_instances = max_instances
+        self.verbosity = verbosity
+        self.report_rate = report_rate
+        self.model_paths = model_paths or []
+        self._initialize_inference_model()
+
+    def _initialize_inference_model(self):
+        """inference.py:3119-3140."""
+        cfg = self.bottomup_config
+        mi = cfg["model"]["heads"]["multi_instance"]
+        pre = cfg["data"]["preprocessing"]
+        self.inference_model = BottomUpInferenceModel(
+            BottomUpInferenceLayer(
+                keras_model=self.bottomup_model,
+                paf_scorer=PAFScorer.from_config(
+                    mi, max_edge_length_ratio=self.max_edge_length_ratio,
+                    dist_penalty_weight=self.dist_penalty_weight, n_points=self.paf_line_points,
+                    min_instance_peaks=0, min_line_scores=self.min_line_scores),
+                input_scale=pre.get("input_scaling", 1.0),
+                pad_to_stride=model_io.maximum_stride(cfg),
+                peak_threshold=self.peak_threshold,
+                refinement="integral" if self.integral_refinement else "local",
+                integral_patch_size=self.integral_patch_size,
+                cm_output_stride=mi["confmaps"]["output_stride"],
+                paf_output_stride=mi["pafs"]["output_stride"],
+            ))
+
+    @property
+    def data_config(self):
+        return self.bottomup_config["data"]
+
+    @classmethod
+    def from_trained_models(cls, model_path: str, batch_size: int = 4, peak_threshold: float = 0.2,
+                            integral_refinement: bool = True, integral_patch_size: int = 5,
+                            max_edge_length_ratio: float = 0.25, dist_penalty_weight: float = 1.0,
+                            paf_line_points: int = 10, min_line_scores: float = 0.25,
+                            resize_input_layer: bool = True, max_instances: Optional[int] = None) -> "BottomUpPredictor":
+        """inference.py:3152-3228: reads `<dir>/training_config.json` + `<dir>/best_model.h5`.
+        (`resize_input_layer` is accepted for compatibility: the engine is fully convolutional.)"""
+        cfg = model_io.load_training_config(model_path)
+        mc, weights = model_io.load_keras_model(model_io.model_dir(model_path))
+        net = DeviceNetwork(mc, weights)
+        obj = cls(bottomup_config=cfg, bottomup_model=net, peak_threshold=peak_threshold, batch_size=batch_size,
+                  integral_refinement=integral_refinement, integral_patch_size=integral_patch_size,
+                  max_edge_length_ratio=max_edge_length_ratio, dist_penalty_weight=dist_penalty_weight,
+                  paf_line_points=paf_line_points, min_line_scores=min_line_scores, max_instances=max_instances)
+        obj.model_paths = [model_io.model_dir(model_path)]
+        return obj
+
+    # ------------------------------------------------------------------ prediction
+    def _frames_of(self, data):
+        if isinstance(data, np.ndarray) or isinstance(data, torch.Tensor):
+            if data.ndim == 3:
+                data = data[None]
+            return data
+        if hasattr(data, "__len__") and hasattr(data, "__getitem__"):
+            return data  # video-like: data[i:j] -> (n, H, W, C)
+        raise TypeError(f"unsupported data type for predict(): {type(data)}")
+
+    def _predict_generator(self, data) -> Iterator[Dict[str, np.ndarray]]:
+        """inference.py:377-494: one dict per (global) batch, NumPy values, coordinates in image pixels.
+
+        Under torch.distributed each rank runs the network on its contiguous slice of the batch and one
+        all-gather assembles the batch on every rank (parallel.gather_batch_results)."""
+        frames = self._frames_of(data)
+        n = len(frames)
+        layer = self.inference_model.bottomup_layer
+        rank, world = parallel.rank_world()
+        t0 = time.time()
+        n_done = 0
+        last_report = t0
+        for i0 in range(0, n, self.batch_size):
+            i1 = min(i0 + self.batch_size, n)
+            lo, hi = parallel.shard_range(i0, i1, rank, world)
+            batch = frames[lo:hi]
+            if isinstance(batch, list):
+                batch = np.stack(batch)
+            if hi > lo:
+                outs = self.inference_model.call(batch)
+                packed = parallel.pack_results(outs)
+            else:
+                packed = None
+            packed = parallel.gather_batch_results(packed, i1 - i0, layer.paf_scorer.max_instances,
+                                                   layer.paf_scorer.n_nodes, world, device=layer.keras_model.device)
+            res = parallel.unpack_results(packed, layer.paf_scorer.max_instances, layer.paf_scorer.n_nodes)
+            self.inference_model._check_status(res)
+            ex = InferenceModel._unrag(res, numpy=True)
+            ex.pop("status", None)
+            ex["video_ind"] = np.zeros((i1 - i0,), np.int64)
+            ex["frame_ind"] = np.arange(i0, i1, dtype=np.int64)
+            ex["scale"] = np.ones((i1 - i0, 2), np.float32)
+            if world == 1:
+                ex["image"] = batch if isinstance(batch, np.ndarray) else np.asarray(batch)
+            n_done += i1 - i0
+            now = time.time()
+            if self.verbosity == "json" and (now - last_report) >= 1.0 / max(self.report_rate, 1e-6) and rank == 0:
+                el = now - t0
+                print(json.dumps({"n_processed": n_done, "n_total": n, "elapsed": el, "rate": n_done / max(el, 1e-9),
+                                  "eta": (n - n_done) / max(n_done / max(el, 1e-9), 1e-9)}), flush=True)
+                last_report = now
+            yield ex
+
+    def predict(self, data, make_labels: bool = True):
+        """inference.py:496-531. `make_labels=False` -> list of per-batch dicts of NumPy arrays
+        (`instance_peaks (b, Imax, N, 2)` NaN-padded, `instance_peak_vals`, `instance_scores`, `n_valid`,
+        `video_ind`, `frame_ind`, ...). `make_labels=True` builds `sleap.Labels` with the UNMODIFIED
+        reference classes and therefore needs the `sleap` package importable."""
+        gen = self._predict_generator(data)
+        if make_labels:
+            return self._make_labeled_frames_from_generator(gen, data)
+        return list(gen)
+
+    def _make_labeled_frames_from_generator(self, generator, data):
+        """inference.py:3230-3348 -- hands arrays to sleap's own result containers."""
+        try:
+            import sleap  # noqa: F401  (out of scope for this package: the reference's containers are used as-is)
+        except Exception as e:  # noqa: BLE001
+            raise ImportError("predict(make_labels=True) builds sleap.Labels with the reference's own classes; "
+                              "install `sleap` or call predict(data, make_labels=False)") from e
+        skeleton = sleap.Skeleton.from_names_and_edge_inds(  # pragma: no cover (needs sleap)
+            self.inference_model.bottomup_layer.paf_scorer.part_names,
+            self.inference_model.bottomup_layer.paf_scorer.edge_inds)
+        video = data if isinstance(data, sleap.Video) else sleap.Video.from_numpy(np.asarray(data))
+        lfs = []
+        for ex in generator:  # pragma: no cover
+            for fi, pts, conf, sc, nv in zip(ex["frame_ind"], ex["instance_peaks"], ex["instance_peak_vals"],
+                                             ex["instance_scores"], ex["n_valid"]):
+                insts = []
+                for p, c, s in zip(pts[:nv], conf[:nv], sc[:nv]):
+                    if np.isnan(p).all():
+                        continue
+                    insts.append(sleap.PredictedInstance.from_numpy(points=p, point_confidences=c,
+                                                                    instance_score=s, skeleton=skeleton))
+                if self.max_instances is not None and len(insts) > self.max_instances:
+                    insts = sorted(insts, key=lambda x: x.score, reverse=True)[: self.max_instances]
+                if self.tracker:
+                    insts = self.tracker.track(untracked_instances=insts, img=None, t=int(fi))
+                lfs.append(sleap.LabeledFrame(video=video, frame_idx=int(fi), instances=insts))
+        return sleap.Labels(lfs)  # pragma: no cover
+
+
+def load_model(model_path: Union[str, List[str]], batch_size: int = 4, peak_threshold: float = 0.2,
+               refinement: str = "integral", tracker: Optional[str] = None, tracker_window: int = 5,
+               tracker_max_instances: Optional[int] = None, disable_gpu_preallocation: bool = True,
+               progress_reporting: str = "rich", resize_input_layer: bool = True,
+               max_instances: Optional[int] = None) -> Predictor:
+    """inference.py:4865-5004: accepts model folders, `training_config.json` paths or `.zip` archives."""
+    if isinstance(model_path, str):
+        model_paths = [model_path]
+    else:
+        model_paths = list(model_path)
+    resolved = []
+    for mp in model_paths:
+        if mp.endswith(".zip"):
+            tmp = tempfile.mkdtemp()
+            with zipfile.ZipFile(mp) as z:
+                z.extractall(tmp)
+            found = [r for r, _, f in os.walk(tmp) if "training_config.json" in f]
+            resolved.extend(found)
+        else:
+            resolved.append(mp)
+    if tracker is not None:
+        raise NotImplementedError("tracking (sleap.nn.tracking) is outside this package's hot path; pass the "
+                                  "reference's own Tracker through predictor.tracker")
+    predictor = Predictor.from_model_paths(resolved, peak_threshold=peak_threshold,
+                                           integral_refinement=refinement == "integral", batch_size=batch_size,
+                                           resize_input_layer=resize_input_layer, max_instances=max_instances)
+    predictor.verbosity = progress_reporting if progress_reporting in ("json", "none") else "none"
+    return predictor

@@ -1,0 +1,54 @@
+"""Seeded synthetic 13-node fly video for benchmarks and smoke tests (no datasets are reachable offline).
+
+Skeleton = sleap/skeletons/flies13.json (13 nodes / 12 edges); generator spec from SURVEY.md §8(d):
+random similarity transforms of a template pose, centres kept `margin` px inside the frame and at
+least `min_sep` px apart.
+"""
+import numpy as np
+
+FLIES13_NODES = ["head", "thorax", "abdomen", "wingL", "wingR", "forelegL", "forelegR", "midlegL", "midlegR",
+                 "hindlegL", "hindlegR", "eyeL", "eyeR"]
+FLIES13_EDGES = [("thorax", "head"), ("thorax", "abdomen"), ("thorax", "wingL"), ("thorax", "wingR"),
+                 ("thorax", "forelegL"), ("thorax", "forelegR"), ("thorax", "midlegL"), ("thorax", "midlegR"),
+                 ("thorax", "hindlegL"), ("thorax", "hindlegR"), ("head", "eyeL"), ("head", "eyeR")]
+_TEMPLATE = np.array([[0.45, 0.0], [0.0, 0.0], [-0.55, 0.0], [-0.35, 0.30], [-0.35, -0.30], [0.35, 0.35], [0.35, -0.35],
+                      [0.05, 0.45], [0.05, -0.45], [-0.30, 0.50], [-0.30, -0.50], [0.55, 0.12], [0.55, -0.12]], np.float32)
+
+
+def random_instances(rng, n_animals, height, width, body=(80.0, 120.0), margin=128.0, min_sep=64.0, jitter=2.0):
+    centres, out, tries = [], [], 0
+    while len(out) < n_animals and tries < 10000:
+        tries += 1
+        c = rng.uniform([margin, margin], [width - margin, height - margin])
+        if any(np.hypot(*(c - o)) < min_sep for o in centres):
+            continue
+        th, s = rng.uniform(0, 2 * np.pi), rng.uniform(*body)
+        R = np.array([[np.cos(th), -np.sin(th)], [np.sin(th), np.cos(th)]])
+        out.append(((_TEMPLATE * s) @ R.T + c + rng.normal(0, jitter, _TEMPLATE.shape)).astype(np.float32))
+        centres.append(c)
+    return np.stack(out) if out else np.zeros((0, 13, 2), np.float32)
+
+
+def render_frames(n_frames, height, width, n_animals=4, seed=0):
+    """-> (frames uint8 (T, H, W, 1), instances list of (A, 13, 2)). Dark blobs on a noisy light background."""
+    rng = np.random.default_rng(seed)
+    frames = np.empty((n_frames, height, width, 1), np.uint8)
+    insts = []
+    r = 10
+    yy, xx = np.mgrid[-r : r + 1, -r : r + 1].astype(np.float32)
+    for t in range(n_frames):
+        inst = random_instances(rng, n_animals, height, width, margin=min(128.0, min(height, width) / 4))
+        insts.append(inst)
+        small = rng.normal(0, 1, (height // 16 + 1, width // 16 + 1)).astype(np.float32)
+        img = 170 + 12 * np.kron(small, np.ones((16, 16), np.float32))[:height, :width]
+        img += rng.normal(0, 4, (height, width)).astype(np.float32)
+        for a in inst:
+            for k, p in enumerate(a):
+                cx, cy = int(round(float(p[0]))), int(round(float(p[1])))
+                x0, x1, y0, y1 = max(cx - r, 0), min(cx + r + 1, width), max(cy - r, 0), min(cy + r + 1, height)
+                if x1 <= x0 or y1 <= y0:
+                    continue
+                blob = np.exp(-((xx + cx - p[0]) ** 2 + (yy + cy - p[1]) ** 2) / (2 * 3.0 ** 2))
+                img[y0:y1, x0:x1] -= (70 + 5 * k) * blob[y0 - cy + r : y1 - cy + r, x0 - cx + r : x1 - cx + r]
+        frames[t, :, :, 0] = np.clip(img, 0, 255).astype(np.uint8)
+    return frames, insts

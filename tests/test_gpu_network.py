@@ -1,0 +1,215 @@
+"""Network-layer kernels vs a plain torch fp32 reference of the same op (on the same bf16-rounded
+operands), and whole-graph parity vs the fp32 CPU oracle (oracle/keras_graph.py).
+
+Tolerances: a bf16 store has 8 mantissa bits (rel. 2^-9 rounding error); layer tests compare against
+the fp32 result of identical bf16 inputs, so only accumulation order and the final rounding differ:
+|delta| <= 1e-2 * max|ref| is generous. Whole-network tolerance is stated in the test.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+MODELS = os.path.join(os.path.dirname(__file__), "golden", "models")
+
+
+def _bf(x):
+    return x.to(torch.bfloat16).to(torch.float32)
+
+
+def _ref_conv(x_nhwc, k_keras, bias, relu):
+    y = F.conv2d(x_nhwc.permute(0, 3, 1, 2), k_keras.permute(3, 2, 0, 1), bias, padding=1)
+    if relu:
+        y = torch.relu(y)
+    return y.permute(0, 2, 3, 1)
+
+
+CONV_CASES = [
+    # (B, H, W, C0, C1, Cout, mode)  mode: 0 none, 1 concat, 2 concat+upsample, 4 pool
+    (2, 16, 32, 16, 0, 16, 0),
+    (1, 37, 45, 32, 0, 64, 0),  # ragged tiles
+    (1, 20, 70, 24, 0, 36, 0),  # channel padding (24->32, 36->48), CK=16 path
+    (2, 32, 32, 64, 0, 128, 0),  # two cout tiles per WG + cout grid
+    (1, 16, 16, 256, 0, 96, 0),
+    (1, 24, 40, 32, 32, 32, 1),
+    (1, 24, 40, 36, 54, 36, 1),
+    (2, 32, 64, 64, 128, 64, 2),
+    (1, 16, 32, 24, 36, 24, 2),
+    (1, 32, 32, 16, 0, 32, 4),
+    (2, 18, 34, 48, 0, 16, 4),
+]
+
+
+@pytest.mark.parametrize("B,H,W,C0,C1,Cout,mode", CONV_CASES)
+def test_conv3x3_vs_torch(B, H, W, C0, C1, Cout, mode):
+    from sleap_amd import ops
+
+    g = torch.Generator(device="cpu").manual_seed(B * 1000 + H * 10 + C0 + C1 + Cout + mode)
+    k = torch.randn((3, 3, C0 + C1, Cout), generator=g) * (2.0 / (9 * (C0 + C1))) ** 0.5
+    bias = torch.randn((Cout,), generator=g) * 0.1
+    if mode == 4:
+        x0 = torch.randn((B, 2 * H, 2 * W, C0), generator=g)
+    else:
+        x0 = torch.randn((B, H, W, C0), generator=g)
+    x1 = None
+    if mode == 1:
+        x1 = torch.randn((B, H, W, C1), generator=g)
+    elif mode == 2:
+        x1 = torch.randn((B, H // 2, W // 2, C1), generator=g)
+    # reference on bf16-rounded operands
+    r0 = _bf(x0)
+    if mode == 4:
+        r0 = F.max_pool2d(r0.permute(0, 3, 1, 2), 2).permute(0, 2, 3, 1)
+    rin = r0
+    if x1 is not None:
+        r1 = _bf(x1)
+        if mode == 2:
+            r1 = _bf(F.interpolate(r1.permute(0, 3, 1, 2), scale_factor=2.0, mode="bilinear", align_corners=False)
+                     .permute(0, 2, 3, 1))
+        rin = torch.cat([r0, r1], dim=-1)
+    ref = _ref_conv(rin, _bf(k), bias, True)
+    # device
+    d0 = ops.to_bf16_padded(x0.cuda().contiguous())
+    d1 = ops.to_bf16_padded(x1.cuda().contiguous()) if x1 is not None else None
+    pw = ops.pack_conv3x3_weights(k.numpy(), C0, C1)
+    coutp = ops.pad16(Cout)
+    bp = torch.zeros((coutp,), dtype=torch.float32)
+    bp[:Cout] = bias
+    out = ops.conv3x3(d0, d1, mode, pw, bp.cuda(), coutp, True, (H, W))
+    got = ops.from_bf16(out, Cout).cpu()
+    pad = out.float()[..., Cout:]
+    assert float(pad.abs().max()) == 0.0 if pad.numel() else True
+    scale = float(ref.abs().max())
+    assert float((got - ref).abs().max()) <= 1e-2 * scale, (float((got - ref).abs().max()), scale)
+
+
+def test_conv3x3_identity_asymmetric():
+    """Delta kernel with an asymmetric tap: catches transposed MFMA operand/accumulator layouts."""
+    from sleap_amd import ops
+
+    C = 32
+    k = torch.zeros((3, 3, C, C))
+    for c in range(C):
+        k[0, 2, c, (c + 5) % C] = 1.0  # out[y,x,(c+5)%C] = in[y-1,x+1,c]
+    x = torch.randn((1, 8, 40, C))
+    d0 = ops.to_bf16_padded(x.cuda())
+    out = ops.conv3x3(d0, None, 0, ops.pack_conv3x3_weights(k.numpy(), C), torch.zeros(C).cuda(), C, False, (8, 40))
+    got = ops.from_bf16(out, C).cpu()
+    ref = torch.zeros_like(x)
+    xs = _bf(x)
+    ref[:, 1:, :-1, :] = xs[:, :-1, 1:, :]
+    ref = ref[..., [(c - 5) % C for c in range(C)]]
+    assert torch.equal(got, ref)
+
+
+def _close(got, ref, rel, abs_=0.0):
+    err = float((got - ref).abs().max())
+    lim = rel * float(ref.abs().max()) + abs_
+    assert err <= lim, f"max|delta|={err:.4g} > {lim:.4g}"
+
+
+def test_small_layers_vs_torch():
+    from sleap_amd import _lib, ops
+    from sleap_amd.ops import _ptr, _stream, check
+
+    h = _lib.lib()
+    g = torch.Generator().manual_seed(0)
+    # stem u8 (device tensors are kept alive in named variables until the result is read back)
+    img = torch.randint(0, 256, (2, 20, 36, 1), generator=g, dtype=torch.uint8)
+    k = torch.randn((3, 3, 1, 16), generator=g)
+    b = torch.randn((16,), generator=g)
+    d_img, d_k, d_b = img.cuda(), k.cuda().contiguous(), b.cuda()
+    out = torch.empty((2, 20, 36, 16), dtype=torch.bfloat16, device="cuda")
+    check(h.sa_stem_conv3x3(_ptr(d_img), 1, 2, 20, 36, 1, _ptr(d_k), _ptr(d_b), 16, 1, _ptr(out), _stream()), "stem")
+    _close(out.float().cpu(), _ref_conv(img.float() * np.float32(1 / 255), k, b, True), 1e-2)
+    # stem f32 rgb
+    imgf = torch.rand((1, 12, 12, 3), generator=g)
+    k3 = torch.randn((3, 3, 3, 8), generator=g)
+    b3 = torch.randn((8,), generator=g)
+    d_img, d_k, d_b = imgf.cuda(), k3.cuda().contiguous(), b3.cuda()
+    out = torch.empty((1, 12, 12, 8), dtype=torch.bfloat16, device="cuda")
+    check(h.sa_stem_conv3x3(_ptr(d_img), 0, 1, 12, 12, 3, _ptr(d_k), _ptr(d_b), 8, 0, _ptr(out), _stream()), "stem")
+    _close(out.float().cpu(), _ref_conv(imgf, k3, b3, False), 1e-2)
+    # pool / upsample
+    x = torch.randn((2, 12, 20, 32), generator=g)
+    xd = ops.to_bf16_padded(x.cuda())
+    o = torch.empty((2, 6, 10, 32), dtype=torch.bfloat16, device="cuda")
+    check(h.sa_maxpool2x2_bf16(_ptr(xd), 2, 12, 20, 32, _ptr(o), _stream()), "pool")
+    ref = F.max_pool2d(_bf(x).permute(0, 3, 1, 2), 2).permute(0, 2, 3, 1)
+    assert torch.equal(o.float().cpu(), ref)
+    for bil, modeN in ((1, "bilinear"), (0, "nearest")):
+        o = torch.empty((2, 24, 40, 32), dtype=torch.bfloat16, device="cuda")
+        check(h.sa_upsample2x_bf16(_ptr(xd), 2, 12, 20, 32, bil, _ptr(o), _stream()), "up")
+        kw = dict(align_corners=False) if bil else {}
+        ref = F.interpolate(_bf(x).permute(0, 3, 1, 2), scale_factor=2.0, mode=modeN, **kw).permute(0, 2, 3, 1)
+        _close(o.float().cpu(), ref, 0.0, 2e-2)
+    # 1x1 head
+    wk = torch.randn((13, 32), generator=g)
+    bk = torch.randn((13,), generator=g)
+    d_w, d_b = wk.cuda(), bk.cuda()
+    o = torch.empty((2, 12, 20, 13), dtype=torch.float32, device="cuda")
+    check(h.sa_conv1x1_head(_ptr(xd), 32, _ptr(d_w), _ptr(d_b), 13, 0, 2, 12, 20, _ptr(o), _stream()), "head")
+    _close(o.cpu(), _bf(x) @ wk.T + bk, 1e-4, 1e-5)
+    # transposed conv k3 s2 same == full transposed conv cropped at the end
+    kt = torch.randn((3, 3, 16, 32), generator=g) * 0.1  # (kh, kw, Cout, Cin)
+    bt = torch.randn((16,), generator=g)
+    d_w, d_b = kt.cuda().to(torch.bfloat16).contiguous(), bt.cuda()
+    o = torch.empty((2, 24, 40, 16), dtype=torch.bfloat16, device="cuda")
+    check(h.sa_convt3x3s2_bf16(_ptr(xd), 32, _ptr(d_w), _ptr(d_b), 16, 1, 2, 12, 20, _ptr(o), _stream()), "convt")
+    ref = F.conv_transpose2d(_bf(x).permute(0, 3, 1, 2), _bf(kt).permute(3, 2, 0, 1), None, stride=2)[:, :, :24, :40]
+    ref = torch.relu(ref + bt.view(1, -1, 1, 1)).permute(0, 2, 3, 1)
+    _close(o.float().cpu(), ref, 1e-2)
+
+
+def _run_graph_parity(cfg, weights, x_u8, tol_rel):
+    from oracle.keras_graph import KerasGraph, ensure_float
+    from sleap_amd.nn.engine import DeviceNetwork
+
+    net = DeviceNetwork(cfg, weights)
+    outs = net.forward(torch.from_numpy(x_u8).cuda())
+    ref = KerasGraph(cfg, weights)(ensure_float(x_u8))
+    assert len(outs) == len(ref)
+    worst = 0.0
+    for o, r in zip(outs, ref):
+        o = o.cpu().numpy()
+        assert o.shape == r.shape
+        err = np.abs(o - r).max() / max(np.abs(r).max(), 1e-6)
+        worst = max(worst, err)
+    assert worst <= tol_rel, worst
+    return worst
+
+
+def test_fixture_bottomup_network_vs_oracle():
+    """Trained fixture (Conv2DTranspose decoder, 3 heads). bf16 activations through 17 layers:
+    max |delta| / max|ref| per head <= 3e-2."""
+    from sleap_amd.nn.engine import load_keras_npz
+
+    cfg, w = load_keras_npz(os.path.join(MODELS, "minimal_instance.UNet.bottomup", "best_model.npz"))
+    rng = np.random.default_rng(0)
+    x = rng.integers(0, 256, (2, 96, 128, 1), dtype=np.uint8)
+    _run_graph_parity(cfg, w, x, 3e-2)
+
+
+def test_fixture_bilinear_network_vs_oracle():
+    from sleap_amd.nn.engine import load_keras_npz
+
+    cfg, w = load_keras_npz(os.path.join(MODELS, "min_tracks_2node.UNet.bottomup_multiclass", "best_model.npz"))
+    rng = np.random.default_rng(1)
+    x = rng.integers(0, 256, (1, 64, 96, 1), dtype=np.uint8)
+    _run_graph_parity(cfg, w, x, 3e-2)
+
+
+def test_random_benchmark_unet_vs_oracle():
+    """baseline_medium_rf.bottomup topology (f16 r2 s32->4, bilinear) with He-normal weights at 128x160."""
+    from sleap_amd.nn.architectures import build_unet_model_config, he_normal_weights
+
+    cfg, shapes = build_unet_model_config((128, 160, 1), 16, 2, 32, 4, True, True,
+                                          heads=[("MultiInstanceConfmapsHead", 13, 4), ("PartAffinityFieldsHead", 24, 8)])
+    w = he_normal_weights(shapes, seed=1)
+    rng = np.random.default_rng(2)
+    x = rng.integers(0, 256, (2, 128, 160, 1), dtype=np.uint8)
+    _run_graph_parity(cfg, w, x, 3e-2)
