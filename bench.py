@@ -53,7 +53,9 @@ def cpu_baseline(mc, weights, scorer_args, frames_u8, budget_s):
     from oracle import peak_finding as opf
     from oracle.keras_graph import KerasGraph, preprocess
 
-    cores = os.cpu_count() or 1
+    # torch-CPU convolutions stop scaling (and collapse at 256 threads) on the 2x64-core EPYC host of the GPU box:
+    # measured 0.22 s/frame at 16-32 threads, 0.40 s at 64, 0.73 s at 128, 17.5 s at 256 (tools/cpu_probe.py).
+    cores = min(os.cpu_count() or 1, 32)
     torch.set_num_threads(cores)
     g = KerasGraph(mc, weights)
     scorer = opg.PAFScorer(scorer_args["nodes"], scorer_args["edges"], scorer_args["stride"], oob="zero")

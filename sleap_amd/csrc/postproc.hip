@@ -17,7 +17,7 @@
 
 namespace {
 
-constexpr int MAXNP = 64;  // compile-time cap on max_node_peaks (peaks of one node type per frame)
+constexpr int MAXNP = 128;  // compile-time cap on max_node_peaks (peaks of one node type per frame)
 constexpr int MAXNODES = 64;
 
 // ------------------------------------------------------------------------------------------------

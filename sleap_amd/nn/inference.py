@@ -173,11 +173,52 @@ class InferenceModel:
         res["n_valid"] = n_valid.astype(np.int64)
         return res
 
+    # hard limits of the device kernels (csrc/postproc.hip: MAXNP; sa_find_local_peaks: max_peaks <= 16384)
+    _HARD_MAX_PEAKS = 16384
+    _HARD_MAX_NODE_PEAKS = 128
+    _HARD_MAX_INSTANCES = 1024
+
+    def call_checked(self, data):
+        """`call` + inspection of the per-frame status words (one tiny D2H copy). The reference's ragged tensors
+        have no capacity limits, so on an overflow of the fixed-shape device buffers the caps are doubled (they
+        stay grown for later batches) and the batch is re-run; scipy's "infeasible" error is re-raised."""
+        while True:
+            outs = self.call(data)
+            bits = 0
+            for v in outs["status"].tolist():
+                bits |= int(v)
+            if bits & _lib.STATUS_LSA_INFEASIBLE:
+                raise ValueError("cost matrix is infeasible")  # what scipy raises inside the reference
+            over = bits & (_lib.STATUS_PEAK_OVERFLOW | _lib.STATUS_NODE_PEAK_OVERFLOW | _lib.STATUS_INSTANCE_OVERFLOW)
+            if not over:
+                return outs
+            if not self._grow_caps(over):
+                raise GroupingOverflowError(
+                    f"a frame exceeds the hard capacity of the device buffers (status bits {bits}): "
+                    f"> {self._HARD_MAX_PEAKS} peaks, > {self._HARD_MAX_NODE_PEAKS} peaks of one node type or "
+                    f"> {self._HARD_MAX_INSTANCES} instances")
+
+    def _grow_caps(self, over) -> bool:
+        layer = getattr(self, "bottomup_layer", None)
+        if layer is None:
+            return False
+        sc = layer.paf_scorer
+        grown = False
+        if over & _lib.STATUS_PEAK_OVERFLOW and layer.max_peaks < self._HARD_MAX_PEAKS:
+            layer.max_peaks = min(layer.max_peaks * 2, self._HARD_MAX_PEAKS)
+            grown = True
+        if over & _lib.STATUS_NODE_PEAK_OVERFLOW and sc.max_node_peaks < self._HARD_MAX_NODE_PEAKS:
+            sc.max_node_peaks = min(sc.max_node_peaks * 2, self._HARD_MAX_NODE_PEAKS)
+            grown = True
+        if over & _lib.STATUS_INSTANCE_OVERFLOW and sc.max_instances < self._HARD_MAX_INSTANCES:
+            sc.max_instances = min(sc.max_instances * 2, self._HARD_MAX_INSTANCES)
+            grown = True
+        return grown
+
     def predict_on_batch(self, data, numpy: bool = False, **kwargs):
-        """inference.py:1047-1090."""
-        outs = self.call(data)
-        if numpy:
-            self._check_status(outs)
+        """inference.py:1047-1090. numpy=False returns device tensors without synchronising (check
+        `status` yourself or use `call_checked`)."""
+        outs = self.call_checked(data) if numpy else self.call(data)
         return self._unrag(outs, numpy)
 
     def predict(self, data, numpy: bool = True, batch_size: int = 4, **kwargs):
@@ -186,25 +227,19 @@ class InferenceModel:
         n = len(imgs)
         parts = []
         for i in range(0, n, batch_size):
-            o = self.call(imgs[i : i + batch_size])
-            self._check_status(o)
+            o = self.call_checked(imgs[i : i + batch_size])
             parts.append({k: (v.clone() if isinstance(v, torch.Tensor) else v) for k, v in o.items()})
-        outs = {k: torch.cat([p[k] for p in parts], dim=0) for k in parts[0] if isinstance(parts[0][k], torch.Tensor)}
+        imax = max(p["instance_scores"].shape[1] for p in parts)  # caps may have grown between batches
+        for p in parts:
+            for k in ("instance_peaks", "instance_peak_vals", "instance_scores"):
+                v = p[k]
+                if v.shape[1] < imax:
+                    pad = torch.full((v.shape[0], imax - v.shape[1]) + tuple(v.shape[2:]), float("nan"),
+                                     dtype=v.dtype, device=v.device)
+                    p[k] = torch.cat([v, pad], dim=1)
+        keys = ("instance_peaks", "instance_peak_vals", "instance_scores", "n_valid", "status")
+        outs = {k: torch.cat([p[k] for p in parts], dim=0) for k in keys}
         return self._unrag(outs, numpy)
-
-    def _check_status(self, outs):
-        st = outs.get("status")
-        if st is None:
-            return
-        bits = 0
-        for v in st.tolist():
-            bits |= int(v)
-        if bits & _lib.STATUS_LSA_INFEASIBLE:
-            raise ValueError("cost matrix is infeasible")  # what scipy raises inside the reference
-        if bits & (_lib.STATUS_PEAK_OVERFLOW | _lib.STATUS_NODE_PEAK_OVERFLOW | _lib.STATUS_INSTANCE_OVERFLOW):
-            raise GroupingOverflowError(
-                f"fixed-shape result buffers overflowed (status bits {bits}): raise max_peaks / "
-                "paf_scorer.max_node_peaks / paf_scorer.max_instances")
 
 
 class BottomUpInferenceLayer(InferenceLayer):
@@ -429,6 +464,7 @@ class BottomUpPredictor(Predictor):
         n = len(frames)
         layer = self.inference_model.bottomup_layer
         rank, world = parallel.rank_world()
+        i_gather = layer.paf_scorer.max_instances  # instance capacity of the gathered buffer, equal on all ranks
         t0 = time.time()
         n_done = 0
         last_report = t0
@@ -439,14 +475,24 @@ class BottomUpPredictor(Predictor):
             if isinstance(batch, list):
                 batch = np.stack(batch)
             if hi > lo:
-                outs = self.inference_model.call(batch)
+                outs = self.inference_model.call_checked(batch)
+                if world > 1 and outs["instance_scores"].shape[1] != i_gather:
+                    # this rank's caps grew; the collective needs one width on every rank
+                    if int(outs["n_valid"].max().item()) > i_gather:
+                        raise GroupingOverflowError(
+                            f"a frame has more than max_instances={i_gather} instances; under torch.distributed "
+                            "construct the PAFScorer with a larger max_instances on every rank")
+                    outs = dict(outs)
+                    for k in ("instance_peaks", "instance_peak_vals", "instance_scores"):
+                        outs[k] = outs[k][:, :i_gather].contiguous()
+                elif world == 1:
+                    i_gather = outs["instance_scores"].shape[1]
                 packed = parallel.pack_results(outs)
             else:
                 packed = None
-            packed = parallel.gather_batch_results(packed, i1 - i0, layer.paf_scorer.max_instances,
-                                                   layer.paf_scorer.n_nodes, world, device=layer.keras_model.device)
-            res = parallel.unpack_results(packed, layer.paf_scorer.max_instances, layer.paf_scorer.n_nodes)
-            self.inference_model._check_status(res)
+            packed = parallel.gather_batch_results(packed, i1 - i0, i_gather, layer.paf_scorer.n_nodes, world,
+                                                   device=layer.keras_model.device)
+            res = parallel.unpack_results(packed, i_gather, layer.paf_scorer.n_nodes)
             ex = InferenceModel._unrag(res, numpy=True)
             ex.pop("status", None)
             ex["video_ind"] = np.zeros((i1 - i0,), np.int64)

@@ -1,0 +1,139 @@
+"""The reference-shaped inference API end to end on the GPU (reference: tests/nn/test_inference.py:399-497
+preprocess cases, :533-539 find_head, :769-806 bottom-up predictor)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+from numpy.testing import assert_allclose, assert_array_equal
+
+from oracle import paf_grouping as opg
+from oracle import peak_finding as opf
+from oracle.keras_graph import preprocess as oracle_preprocess
+
+pytestmark = pytest.mark.gpu
+
+MODEL_DIR = os.path.join(os.path.dirname(__file__), "golden", "models", "minimal_instance.UNet.bottomup")
+
+
+@pytest.fixture(scope="module")
+def frames():
+    from sleap_amd.synth import render_frames
+
+    return render_frames(5, 384, 384, n_animals=2, seed=11)[0]
+
+
+@pytest.fixture(scope="module")
+def predictor(frames):
+    from sleap_amd.nn.inference import load_model
+
+    p = load_model(MODEL_DIR, batch_size=2, progress_reporting="none")
+    # The fixture was trained on real fly video; on synthetic frames its confidence maps are noisy. Pick the
+    # peak threshold that leaves a realistic number of peaks (<= ~12 per node type and frame).
+    layer = p.inference_model.bottomup_layer
+    cms = layer.forward_pass(frames)[0].cpu().numpy()
+    mask = opf.nms_mask(cms, -np.inf)
+    vals = np.sort(cms[mask])[::-1]
+    layer.peak_threshold = float(vals[min(len(vals) - 1, 12 * cms.shape[0] * cms.shape[3])])
+    assert layer.refinement == "integral" and layer.input_scale == 1.0
+    return p
+
+
+
+
+def test_load_model_wires_the_reference_attribute_paths(predictor):
+    from sleap_amd.nn.inference import BottomUpPredictor, find_head
+
+    assert isinstance(predictor, BottomUpPredictor)
+    layer = predictor.inference_model.bottomup_layer
+    # CLI mutates these paths (inference.py:5525-5531)
+    assert layer.paf_scorer.max_edge_length_ratio == 0.25 and layer.paf_scorer.dist_penalty_weight == 1.0
+    assert layer.paf_scorer.n_points == 10 and layer.paf_scorer.min_line_scores == 0.25
+    assert layer.paf_scorer.part_names == ["A", "B"] and layer.paf_scorer.edge_inds == [(0, 1)]
+    assert layer.cm_output_stride == 2 and layer.paf_output_stride == 4 and layer.pad_to_stride == 8
+    assert layer.refinement == "integral" and layer.input_scale == 1.0
+    net = layer.keras_model
+    assert net.output_names == ["MultiInstanceConfmapsHead_0", "PartAffinityFieldsHead_0", "OffsetRefinementHead_0"]
+    assert find_head(net, "MultiInstanceConfmapsHead") == 0 and find_head(net, "PartAffinityFieldsHead") == 1
+    assert find_head(net, "OffsetRefinementHead") == 2 and find_head(net, "CentroidConfmapsHead") is None
+    assert layer.offsets_ind == 2  # the fixture has a learned-offset head -> find_local_peaks_with_offsets path
+    assert predictor.is_grayscale
+
+
+def test_predict_matches_oracle_postprocessing(predictor, frames):
+    layer = predictor.inference_model.bottomup_layer
+    outs = predictor.predict(frames, make_labels=False)
+    assert len(outs) == 3  # batches of 2, 2, 1
+    for k in ("instance_peaks", "instance_peak_vals", "instance_scores", "n_valid", "video_ind", "frame_ind", "image"):
+        assert k in outs[0]
+    assert outs[0]["instance_peaks"].dtype == np.float32 and outs[0]["instance_peaks"].shape[2:] == (2, 2)
+    assert_array_equal(np.concatenate([o["frame_ind"] for o in outs]), np.arange(5))
+    # oracle post-processing on the device network outputs
+    cms, pafs, offs = layer.forward_pass(frames)
+    cms, pafs, offs = cms.cpu().numpy(), pafs.cpu().numpy(), offs.cpu().numpy()
+    pts, vals, si, ci = opf.find_local_peaks_with_offsets(cms, offs, layer.peak_threshold)
+    pts = pts * np.float32(2)
+    sc = opg.PAFScorer(["A", "B"], [("A", "B")], 4, oob="zero")
+    B = 5
+    o = sc.predict(pafs, [pts[si == b] for b in range(B)], [vals[si == b] for b in range(B)], [ci[si == b] for b in range(B)])
+    got_n = np.concatenate([x["n_valid"] for x in outs])
+    assert_array_equal(got_n, [len(x) for x in o[0]])
+    for b in range(B):
+        ob = outs[b // 2]
+        i = b % 2
+        n = got_n[b]
+        assert_allclose(ob["instance_peaks"][i, :n], o[0][b], atol=1e-4, equal_nan=True)
+        assert_allclose(ob["instance_scores"][i, :n], o[2][b], atol=1e-5)
+        assert np.isnan(ob["instance_peaks"][i, n:]).all()
+
+
+def test_thresholds_disable_everything(predictor, frames):  # ref tests/nn/test_inference.py:795-806
+    layer = predictor.inference_model.bottomup_layer
+    old = layer.paf_scorer.min_line_scores
+    layer.paf_scorer.min_line_scores = 1.1e9
+    try:
+        outs = predictor.predict(frames[:2], make_labels=False)
+        assert int(outs[0]["n_valid"].sum()) == 0 and outs[0]["instance_peaks"].shape[1] == 0
+    finally:
+        layer.paf_scorer.min_line_scores = old
+    old = layer.peak_threshold
+    layer.peak_threshold = 1e9
+    try:
+        outs = predictor.predict(frames[:2], make_labels=False)
+        assert int(outs[0]["n_valid"].sum()) == 0
+    finally:
+        layer.peak_threshold = old
+
+
+def test_inference_model_predict_and_on_batch(predictor, frames):
+    im = predictor.inference_model
+    a = im.predict(frames[:3], numpy=True, batch_size=2)
+    b = im.predict_on_batch(frames[:3], numpy=True)
+    assert set(("instance_peaks", "instance_peak_vals", "instance_scores", "n_valid")) <= set(a)
+    assert_array_equal(a["n_valid"], b["n_valid"])
+    assert_allclose(a["instance_peaks"], b["instance_peaks"], equal_nan=True)
+    c = im.predict_on_batch({"image": frames[:3]}, numpy=False)
+    assert isinstance(c["instance_peaks"], torch.Tensor) and c["instance_peaks"].is_cuda
+
+
+@pytest.mark.parametrize("shape,dtype,scale,stride", [
+    ((2, 30, 45, 1), np.uint8, 1.0, 16), ((1, 64, 64, 1), np.uint8, 0.5, 8), ((1, 33, 20, 1), np.float32, 1.0, 1),
+    ((2, 16, 16, 3), np.uint8, 1.0, 1), ((1, 40, 24, 3), np.uint8, 0.5, 16),
+])
+def test_preprocess_matches_oracle(shape, dtype, scale, stride):  # ref :399-497
+    from oracle.keras_graph import ensure_float
+    from sleap_amd.nn.inference import InferenceLayer
+
+    class FakeNet:
+        in_channels = 1
+
+    rng = np.random.default_rng(0)
+    x = (rng.random(shape) * (255 if dtype == np.uint8 else 1)).astype(dtype)
+    layer = InferenceLayer(FakeNet(), input_scale=scale, pad_to_stride=stride)
+    got = layer.preprocess(x)
+    want = oracle_preprocess(x, input_scale=scale, pad_stride=stride, ensure_gray=True)
+    g = got.cpu().numpy()
+    if g.dtype == np.uint8:  # uint8 survives when no float op was needed: the 1/255 is fused into the stem conv
+        g = ensure_float(g)
+    assert g.shape == want.shape
+    assert_allclose(g, want, atol=1.0 / 255 + 1e-6 if scale != 1.0 or shape[-1] == 3 else 0)
