@@ -150,9 +150,10 @@ int sa_stem_conv3x3(const void* src, int src_is_u8, int B, int H, int W, int Cin
  *   src0 [B,H0,W0,C0P] bf16 (H0=H, or 2H when SA_SRC0_POOL2X), src1 [B,H1,W1,C1P] bf16 or NULL
  *   w packed by sa_pack_conv3x3_weights: [ceil(CoutP/32)][(C0P+C1P)/16][9 taps][64 lanes][8] bf16 (MFMA
  *   A-fragment order);  bias [CoutP] f32
- *   dst [B,H,W,CoutP] bf16 */
+ *   dst [B,H,W,CoutP] bf16 and/or dst_pool [B,H/2,W/2,CoutP] bf16 = MaxPool2D(2,s2) of the same output fused
+ *   into the epilogue (either may be NULL; dst_pool only with mode NONE/DIRECT) */
 int sa_conv3x3_bf16(const void* src0, int C0P, const void* src1, int C1P, int mode, const void* w,
-                    const float* bias, int CoutP, int relu, int B, int H, int W, void* dst,
+                    const float* bias, int CoutP, int relu, int B, int H, int W, void* dst, void* dst_pool,
                     sa_stream_t stream);
 
 /* HOST helper: Keras Conv2D kernel (3,3,Cin,Cout) f32 -> the packed bf16 layout above. The input

@@ -37,7 +37,7 @@ SIGNATURES = {
     "sa_paf_group": (_i, [_p, _p, _p, _p, _i, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _i, _i, _p, _p, _p, _p, _p, _p]),
     "sa_lsa_host": (_i, [_p, _i, _i, _p, _p]),
     "sa_stem_conv3x3": (_i, [_p, _i, _i, _i, _i, _i, _p, _p, _i, _i, _p, _p]),
-    "sa_conv3x3_bf16": (_i, [_p, _i, _p, _i, _i, _p, _p, _i, _i, _i, _i, _i, _p, _p]),
+    "sa_conv3x3_bf16": (_i, [_p, _i, _p, _i, _i, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p]),
     "sa_pack_conv3x3_weights": (_i, [_p, _i, _i, _i, _i, _i, _i, _p]),
     "sa_conv3x3_packed_elems": (_sz, [_i, _i, _i]),
     "sa_convt3x3s2_bf16": (_i, [_p, _i, _p, _p, _i, _i, _i, _i, _i, _p, _p]),

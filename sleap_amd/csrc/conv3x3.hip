@@ -200,6 +200,250 @@ conv3x3_mfma_kernel(const ConvParams p) {
   }
 }
 
+// ================================================================================================
+// v2: asynchronous-DMA pipeline (global_load_lds), double-buffered LDS, dense XOR-swizzled tile.
+//
+// Sources: src0 (+ optional src1 = Concatenate([src0, src1]), same resolution). Per CK-channel chunk the
+// (18 x 34)-pixel halo tile and the MT*(CK/16)*9 KiB packed weight slab are copied HBM/L2 -> LDS by
+// global_load_lds_dwordx4 (16 B per lane, no VGPR round trip) into the buffer NOT being computed on, so
+// the copy of chunk c+1 overlaps the 9-tap MFMA loop of chunk c; one barrier per chunk.
+// A DMA writes LDS lane-linearly (base + lane*16), so bank-conflict avoidance cannot use padding: the
+// tile is dense ([pixel][CK] bf16) and the 16-byte piece q of pixel p is stored at slot q ^ swz(p)
+// (swz = (p>>2)&3 for CK=32, (p>>3)&1 for CK=16) by permuting the per-lane SOURCE address; B-fragment
+// reads apply the same XOR. Any 16 pixels that are distinct mod 16 -- which the lane groups of
+// ds_read_b128 always are here -- then hit 16 distinct 16-byte slots. Out-of-image halo pixels read a
+// zero page. Epilogue: bias + ReLU, optional full-resolution store, optional fused MaxPool2D(2) store
+// (rows pair inside the wave, columns pair across lanes l, l^1).
+// ================================================================================================
+struct ConvParams2 {
+  const uint16_t* src0;
+  const uint16_t* src1;
+  const uint16_t* w;
+  const float* bias;
+  uint16_t* dst;       // [B,H,W,CoutP] or nullptr
+  uint16_t* dst_pool;  // [B,H/2,W/2,CoutP] or nullptr
+  const uint16_t* zeros;
+  int C0P, C1P, CoutP;
+  int B, H, W;
+  int relu;
+  int tiles_x, tiles_y, co_tiles;
+};
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+template <int CK>
+__device__ __forceinline__ int swz(int p) {
+  return (CK == 32) ? ((p >> 2) & 3) : ((p >> 3) & 1);
+}
+
+// MT: 32-cout tiles per workgroup; CK: channels per chunk; R: rows per wave (tile = 4R x 32 pixels);
+// NBUF: LDS stages (2 = copy of chunk c+1 overlaps the MFMAs of chunk c; 1 for single-chunk layers, which are
+// HBM-bound and rely on many small resident workgroups per CU instead).
+template <int MT, int CK, int R, int NBUF>
+__global__ void __launch_bounds__(256)
+conv3x3_dma_kernel(const ConvParams2 p) {
+  constexpr int TH = 4 * R, TW = 32, PH = TH + 2, PW = TW + 2;
+  constexpr int PIXB = CK * 2;
+  constexpr int N_IN = (PH * PW * PIXB + 1023) / 1024;
+  constexpr int IN_BYTES = N_IN * 1024;
+  constexpr int KK = CK / 16;
+  constexpr int N_W = MT * KK * 9;
+  constexpr int W_BYTES = N_W * 1024;
+  constexpr int STAGE = IN_BYTES + W_BYTES;
+  constexpr int N_DMA = N_IN + N_W;
+  constexpr int PER_WAVE = (N_DMA + 3) / 4;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int bid = blockIdx.x;
+  const int co_t = bid % p.co_tiles;
+  bid /= p.co_tiles;
+  const int tx_i = bid % p.tiles_x;
+  bid /= p.tiles_x;
+  const int ty_i = bid % p.tiles_y;
+  const int b = bid / p.tiles_y;
+  const int x0 = tx_i * TW, y0 = ty_i * TH;
+  const int H = p.H, W = p.W;
+  const int CinP = p.C0P + p.C1P;
+  const int K16 = CinP / 16;
+  const int co32_0 = co_t * MT;
+  const int co32_n = (p.CoutP + 31) / 32;
+
+  // ---- per-lane DMA descriptors (identical for every chunk)
+  int pix_n[PER_WAVE];  // input: global pixel index or -1 (zero page); weights: cout tile or -1
+  int q8[PER_WAVE];
+#pragma unroll
+  for (int j = 0; j < PER_WAVE; ++j) {
+    const int i = j * 4 + wave;
+    pix_n[j] = -1;
+    q8[j] = 0;
+    if (i < N_IN) {
+      const int o = i * 1024 + lane * 16;
+      const int pl = o / PIXB, s = (o % PIXB) / 16;
+      if (pl < PH * PW) {
+        const int ty = pl / PW, tx = pl % PW;
+        const int gy = y0 + ty - 1, gx = x0 + tx - 1;
+        if (gy >= 0 && gy < H && gx >= 0 && gx < W) pix_n[j] = (b * H + gy) * W + gx;
+        q8[j] = (s ^ swz<CK>(pl)) * 8;
+      }
+    } else if (i < N_DMA) {
+      const int k = i - N_IN;
+      const int m = k / (KK * 9), rest = k % (KK * 9);
+      if (co32_0 + m < co32_n) {
+        pix_n[j] = m;
+        q8[j] = (rest * 64 + lane) * 8;  // element offset inside the [KK][9][64][8] slab
+      }
+    }
+  }
+
+  auto issue = [&](int chunk, int buf) {
+    const int c_lo = chunk * CK;
+    const bool from1 = c_lo >= p.C0P;
+    const uint16_t* base = from1 ? p.src1 : p.src0;
+    const int CxP = from1 ? p.C1P : p.C0P;
+    const int cc = from1 ? c_lo - p.C0P : c_lo;
+    unsigned char* stage = smem + buf * STAGE;
+#pragma unroll
+    for (int j = 0; j < PER_WAVE; ++j) {
+      const int i = j * 4 + wave;
+      if (i < N_IN) {
+        const uint16_t* src = (pix_n[j] >= 0) ? base + (size_t)pix_n[j] * CxP + cc + q8[j] : p.zeros + (lane & 3) * 8;
+        __builtin_amdgcn_global_load_lds(src, (lds_ptr_t)(stage + i * 1024), 16, 0, 0);
+      } else if (i < N_DMA) {
+        const uint16_t* src = (pix_n[j] >= 0)
+                                  ? p.w + ((size_t)(co32_0 + pix_n[j]) * K16 + chunk * KK) * (9 * 64 * 8) + q8[j]
+                                  : p.zeros + (lane & 3) * 8;
+        __builtin_amdgcn_global_load_lds(src, (lds_ptr_t)(stage + i * 1024), 16, 0, 0);
+      }
+    }
+  };
+
+  f32x16 acc[MT][R];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[m][r][i] = 0.0f;
+
+  const int n_chunks = CinP / CK;
+  issue(0, 0);
+  int buf = 0;
+  const int half = lane >> 5, lx = lane & 31;
+  for (int chunk = 0; chunk < n_chunks; ++chunk) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (NBUF == 2 && chunk + 1 < n_chunks) issue(chunk + 1, buf ^ 1);
+    const unsigned char* in_tile = smem + buf * STAGE;
+    const unsigned char* w_tile = in_tile + IN_BYTES;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int dy = tap / 3, dx = tap % 3;
+#pragma unroll
+      for (int kk = 0; kk < KK; ++kk) {
+        mfma_bf16x8 a[MT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+          a[m] = *reinterpret_cast<const mfma_bf16x8*>(w_tile + ((m * KK + kk) * 9 + tap) * 1024 + lane * 16);
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          const int pl = (wave * R + r + dy) * PW + lx + dx;
+          const int slot = (kk * 2 + half) ^ swz<CK>(pl);
+          const mfma_bf16x8 bv = *reinterpret_cast<const mfma_bf16x8*>(in_tile + pl * PIXB + slot * 16);
+#pragma unroll
+          for (int m = 0; m < MT; ++m)
+            acc[m][r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m], bv, acc[m][r], 0, 0, 0);
+        }
+      }
+    }
+    if (NBUF == 2) {
+      buf ^= 1;
+    } else if (chunk + 1 < n_chunks) {  // single stage: refill after everyone finished reading it
+      __syncthreads();
+      issue(chunk + 1, 0);
+    }
+  }
+
+  // ---- epilogue
+  const int gx = x0 + lx;
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+    const int co_base = (co32_0 + m) * 32 + 4 * half;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int co = co_base + 8 * g;
+      if (co >= p.CoutP) continue;
+      const float4 bq = *reinterpret_cast<const float4*>(p.bias + co);
+      const float bb[4] = {bq.x, bq.y, bq.z, bq.w};
+      float v[R][4];
+#pragma unroll
+      for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float t = acc[m][r][4 * g + j] + bb[j];
+          v[r][j] = p.relu ? fmaxf(t, 0.0f) : t;
+        }
+      if (p.dst) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          const int gy = y0 + wave * R + r;
+          if (gy < H && gx < W) {
+            sa::bf16x4_t o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = sa::f2bf(v[r][j]);
+            *reinterpret_cast<sa::bf16x4_t*>(p.dst + (((size_t)b * H + gy) * W + gx) * p.CoutP + co) = o;
+          }
+        }
+      }
+      if (p.dst_pool) {
+#pragma unroll
+        for (int r = 0; r < R; r += 2) {
+          sa::bf16x4_t o;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            float t = fmaxf(v[r][j], v[r + 1][j]);
+            t = fmaxf(t, __shfl_xor(t, 1));
+            o[j] = sa::f2bf(t);
+          }
+          const int gy = y0 + wave * R + r;
+          if (!(lane & 1) && gy < H && gx < W)
+            *reinterpret_cast<sa::bf16x4_t*>(p.dst_pool + (((size_t)b * (H / 2) + gy / 2) * (W / 2) + gx / 2) * p.CoutP + co) = o;
+        }
+      }
+    }
+  }
+}
+
+template <int MT, int CK, int R, int NBUF>
+int launch2(const ConvParams2& p, hipStream_t st) {
+  constexpr int N_IN = ((4 * R + 2) * 34 * CK * 2 + 1023) / 1024;
+  constexpr size_t lds = NBUF * ((size_t)N_IN * 1024 + (size_t)MT * (CK / 16) * 9 * 1024);
+  ConvParams2 q = p;
+  q.tiles_x = (p.W + 31) / 32;
+  q.tiles_y = (p.H + 4 * R - 1) / (4 * R);
+  const int co32_n = (p.CoutP + 31) / 32;
+  q.co_tiles = (co32_n + MT - 1) / MT;
+  const size_t nblk = (size_t)q.tiles_x * q.tiles_y * q.co_tiles * p.B;
+  if (nblk > 0x7fffffffull) return sa::fail(SA_ERR_INVALID_ARG, "sa_conv3x3_bf16: grid too large");
+  static bool attr_set = false;
+  if (!attr_set && lds > 64 * 1024) {
+    SA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_dma_kernel<MT, CK, R, NBUF>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((conv3x3_dma_kernel<MT, CK, R, NBUF>), dim3((unsigned)nblk), dim3(256), lds, st, q);
+  SA_LAUNCH_CHECK();
+  return SA_OK;
+}
+
+template <int MT, int CK>
+int launch2_pick(const ConvParams2& p, hipStream_t st) {
+  // single-chunk layers (Cin <= CK) are HBM-bound: small single-stage tiles, many workgroups per CU
+  if ((p.C0P + p.C1P) == CK) return launch2<MT, CK, 2, 1>(p, st);
+  return launch2<MT, CK, 4, 2>(p, st);
+}
+
 template <int MT, int R, int CK, int MODE>
 int launch(const ConvParams& p, hipStream_t st) {
   constexpr int TH = 4 * R;
@@ -268,9 +512,9 @@ int sa_pack_conv3x3_weights(const float* kk, int C0, int C0P, int C1, int C1P, i
 }
 
 int sa_conv3x3_bf16(const void* src0, int C0P, const void* src1, int C1P, int mode, const void* w,
-                    const float* bias, int CoutP, int relu, int B, int H, int W, void* dst,
+                    const float* bias, int CoutP, int relu, int B, int H, int W, void* dst, void* dst_pool,
                     sa_stream_t stream) {
-  SA_REQUIRE(src0 && w && bias && dst, "sa_conv3x3_bf16: NULL pointer");
+  SA_REQUIRE(src0 && w && bias && (dst || dst_pool), "sa_conv3x3_bf16: NULL pointer");
   SA_REQUIRE(C0P > 0 && C0P % 16 == 0 && C1P % 16 == 0 && CoutP > 0 && CoutP % 16 == 0,
              "sa_conv3x3_bf16: channels must be padded to multiples of 16 (C0P=%d C1P=%d CoutP=%d)", C0P, C1P, CoutP);
   SA_REQUIRE(B > 0 && H > 0 && W > 0, "sa_conv3x3_bf16: bad shape");
@@ -293,10 +537,40 @@ int sa_conv3x3_bf16(const void* src0, int C0P, const void* src1, int C1P, int mo
   hipStream_t st = (hipStream_t)stream;
   const bool ck32 = (C0P % 32 == 0) && (C1P % 32 == 0);
   const int co32_n = (CoutP + 31) / 32;
-  if (co32_n >= 2) {
-    return ck32 ? launch_mode<2, 4, 32>(p, mode, st) : launch_mode<2, 4, 16>(p, mode, st);
+  const int src_mode = mode & 7;
+  if (src_mode == SA_SRC1_NONE || src_mode == SA_SRC1_DIRECT) {
+    // v2 DMA pipeline; the pooled output (SA_DST_POOL2X) is only implemented here
+    static const uint16_t* zeros = nullptr;
+    if (!zeros) {
+      void* z = nullptr;
+      SA_HIP_CHECK(hipMalloc(&z, 256));
+      SA_HIP_CHECK(hipMemset(z, 0, 256));
+      zeros = (const uint16_t*)z;
+    }
+    SA_REQUIRE(!dst_pool || (H % 2 == 0 && W % 2 == 0), "sa_conv3x3_bf16: pooled output needs even H, W");
+    ConvParams2 q;
+    q.src0 = p.src0;
+    q.src1 = p.src1;
+    q.w = p.w;
+    q.bias = bias;
+    q.dst = (uint16_t*)dst;
+    q.dst_pool = (uint16_t*)dst_pool;
+    q.zeros = zeros;
+    q.C0P = C0P;
+    q.C1P = C1P;
+    q.CoutP = CoutP;
+    q.B = B;
+    q.H = H;
+    q.W = W;
+    q.relu = relu;
+    if (co32_n >= 2) return ck32 ? launch2_pick<2, 32>(q, st) : launch2_pick<2, 16>(q, st);
+    return ck32 ? launch2_pick<1, 32>(q, st) : launch2_pick<1, 16>(q, st);
   }
-  return ck32 ? launch_mode<1, 4, 32>(p, mode, st) : launch_mode<1, 4, 16>(p, mode, st);
+  SA_REQUIRE(dst && !dst_pool, "sa_conv3x3_bf16: pooled output is not available with pool/upsample source modes");
+  if (co32_n >= 2) {
+    return ck32 ? launch_mode<2, 4, 32>(p, src_mode, st) : launch_mode<2, 4, 16>(p, src_mode, st);
+  }
+  return ck32 ? launch_mode<1, 4, 32>(p, src_mode, st) : launch_mode<1, 4, 16>(p, src_mode, st);
 }
 
 }  // extern "C"

@@ -45,8 +45,12 @@ class _T:
 
 
 class DeviceNetwork:
-    def __init__(self, model_config: dict, weights: Dict[str, np.ndarray], device=None):
+    def __init__(self, model_config: dict, weights: Dict[str, np.ndarray], device=None, fuse_upsample: bool = False):
+        """`fuse_upsample=True` folds UpSampling2D(bilinear) into the consuming conv's tile load (register-staged
+        v1 kernel); the default materialises the upsampled tensor with the bandwidth-bound standalone kernel and
+        feeds the asynchronous-DMA conv kernel (faster overall, measured in profiles/)."""
         require_cuda()
+        self.fuse_upsample = fuse_upsample
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         cfg = model_config["config"]
         self.layers = cfg["layers"]
@@ -78,6 +82,7 @@ class DeviceNetwork:
         n_buf = [0]
         self.buf_meta = {}  # id -> (cp, num, den, dtype)
         skip = set()  # layers fused into a predecessor
+        pooled_of: Dict[str, _T] = {}  # MaxPooling2D layer name -> pooled tensor written by the producing conv
 
         def new_buf(c_alloc, num, den, dtype):
             i = n_buf[0]
@@ -160,12 +165,19 @@ class DeviceNetwork:
                 out_name, relu = conv_activation(l)
                 coutp = _pad16(cout)
                 bias = padded_bias(name, cout, coutp, c.get("use_bias", True))
-                o = _T("real", cout, x.num, x.den, buf=new_buf(coutp, x.num, x.den, "bf16"))
+                # consumers: MaxPooling2D(2) consumers are served by a pooled copy written by this conv's epilogue
+                consumers = [by_name[n] for n in cons.get(out_name, [])]
+                pools = [q for q in consumers if q["class_name"] == "MaxPooling2D"
+                         and tuple(q["config"]["pool_size"]) == (2, 2) and tuple(q["config"]["strides"]) == (2, 2)]
+                need_full = (len(pools) != len(consumers)) or out_name in self.output_names or not consumers
+                o = _T("real", cout, x.num, x.den)  # its buffer is allocated below, only if someone reads it
+                o_pool = None
                 if x.kind == "input":
                     if cin not in (1, 3):
                         raise NotImplementedError("stem conv needs 1 or 3 input channels")
                     w = np.zeros((3, 3, cin, coutp), np.float32)
                     w[..., :cout] = kern
+                    o.buf = new_buf(coutp, x.num, x.den, "bf16")
                     plan.append(("stem", o, upload_f32(w), bias, cin, relu))
                 else:
                     mode, s0, s1 = _lib.SRC1_NONE, None, None
@@ -174,7 +186,7 @@ class DeviceNetwork:
                             raise NotImplementedError("Concatenate with != 2 inputs")
                         s0 = materialize(x.parts[0])
                         p1 = x.parts[1]
-                        if p1.kind == "up" and p1.interp == "bilinear":
+                        if p1.kind == "up" and p1.interp == "bilinear" and self.fuse_upsample:
                             s1, mode = materialize(p1.src), _lib.SRC1_UPSAMPLE2X
                         else:
                             s1, mode = materialize(p1), _lib.SRC1_DIRECT
@@ -182,6 +194,14 @@ class DeviceNetwork:
                         s0, mode = materialize(x.src), _lib.SRC0_POOL2X
                     else:
                         s0 = materialize(x)
+                    if pools and mode in (_lib.SRC1_NONE, _lib.SRC1_DIRECT):
+                        o_pool = _T("real", cout, x.num, x.den * 2, buf=new_buf(coutp, x.num, x.den * 2, "bf16"))
+                        for q in pools:
+                            pooled_of[q["name"]] = o_pool
+                    else:
+                        need_full = True
+                    if need_full:
+                        o.buf = new_buf(coutp, x.num, x.den, "bf16")
                     c0, c1 = s0.c, (s1.c if s1 is not None else 0)
                     assert c0 + c1 == cin, (name, c0, c1, cin)
                     c0p, c1p = s0.cp, (s1.cp if s1 is not None else 0)
@@ -192,7 +212,7 @@ class DeviceNetwork:
                     check(h.sa_pack_conv3x3_weights(kc.ctypes.data_as(C.c_void_p), c0, c0p, c1, c1p, cout, coutp,
                                                     packed.ctypes.data_as(C.c_void_p)), "sa_pack_conv3x3_weights")
                     wdev = torch.from_numpy(packed.view(np.int16)).to(dev)
-                    plan.append(("conv", s0, s1, mode, wdev, bias, o, relu))
+                    plan.append(("conv", s0, s1, mode, wdev, bias, o, relu, o_pool, need_full))
                 t[out_name] = o
                 t[name] = o
             elif cn == "Conv2DTranspose":
@@ -217,7 +237,7 @@ class DeviceNetwork:
                 if tuple(c["pool_size"]) != (2, 2) or tuple(c["strides"]) != (2, 2):
                     raise NotImplementedError(f"MaxPooling2D {name}: only 2x2 s2 is implemented")
                 x = ins[0]
-                t[name] = _T("pool", x.c, x.num, x.den * 2, src=x)
+                t[name] = pooled_of[name] if name in pooled_of else _T("pool", x.c, x.num, x.den * 2, src=x)
             elif cn == "UpSampling2D":
                 if tuple(c["size"]) != (2, 2):
                     raise NotImplementedError(f"UpSampling2D {name}: only x2 is implemented")
@@ -331,11 +351,12 @@ class DeviceNetwork:
                 check(h.sa_stem_conv3x3(_ptr(imgs), is_u8, B, H, W, cin, _ptr(w), _ptr(bias), o.cp, relu,
                                         _ptr(bufs[o.buf]), st), "sa_stem_conv3x3")
             elif kind == "conv":
-                _, s0, s1, mode, w, bias, o, relu = op
+                _, s0, s1, mode, w, bias, o, relu, o_pool, need_full = op
                 oh, ow = hw(o)
                 check(h.sa_conv3x3_bf16(_ptr(bufs[s0.buf]), s0.cp, _ptr(bufs[s1.buf]) if s1 is not None else None,
                                         s1.cp if s1 is not None else 0, mode, _ptr(w), _ptr(bias), o.cp, relu, B, oh, ow,
-                                        _ptr(bufs[o.buf]), st), "sa_conv3x3_bf16")
+                                        _ptr(bufs[o.buf]) if need_full else None,
+                                        _ptr(bufs[o_pool.buf]) if o_pool is not None else None, st), "sa_conv3x3_bf16")
             elif kind == "head":
                 _, s, o, w, bias, act = op
                 sh, sw = hw(s)

@@ -192,11 +192,14 @@ def pack_conv3x3_weights(kernel, c0, c1=0):
     return torch.from_numpy(packed.view(np.int16)).cuda()
 
 
-def conv3x3(src0, src1, mode, packed_w, bias_padded, coutp, relu, out_hw):
+def conv3x3(src0, src1, mode, packed_w, bias_padded, coutp, relu, out_hw, full=True, pooled=False):
     B = src0.shape[0]
     H, W = out_hw
-    out = torch.empty((B, H, W, coutp), dtype=torch.bfloat16, device=src0.device)
+    out = torch.empty((B, H, W, coutp), dtype=torch.bfloat16, device=src0.device) if full else None
+    outp = torch.empty((B, H // 2, W // 2, coutp), dtype=torch.bfloat16, device=src0.device) if pooled else None
     check(_lib.lib().sa_conv3x3_bf16(_ptr(src0), src0.shape[3], _ptr(src1), src1.shape[3] if src1 is not None else 0,
                                      mode, _ptr(packed_w), _ptr(bias_padded), coutp, int(relu), B, H, W, _ptr(out),
-                                     _stream()), "sa_conv3x3_bf16")
-    return out
+                                     _ptr(outp), _stream()), "sa_conv3x3_bf16")
+    if full and pooled:
+        return out, outp
+    return outp if pooled else out

@@ -79,7 +79,15 @@ def test_conv3x3_vs_torch(B, H, W, C0, C1, Cout, mode):
     coutp = ops.pad16(Cout)
     bp = torch.zeros((coutp,), dtype=torch.float32)
     bp[:Cout] = bias
-    out = ops.conv3x3(d0, d1, mode, pw, bp.cuda(), coutp, True, (H, W))
+    pooled = mode in (0, 1) and H % 2 == 0 and W % 2 == 0
+    out = ops.conv3x3(d0, d1, mode, pw, bp.cuda(), coutp, True, (H, W), full=True, pooled=pooled)
+    if pooled:
+        out, outp = out
+        # fused MaxPool2D(2) epilogue == pooling the stored full-resolution output, exactly
+        want = F.max_pool2d(out.float().permute(0, 3, 1, 2), 2).permute(0, 2, 3, 1)
+        assert torch.equal(outp.float(), want)
+        only = ops.conv3x3(d0, d1, mode, pw, bp.cuda(), coutp, True, (H, W), full=False, pooled=True)
+        assert torch.equal(only.float(), want)
     got = ops.from_bf16(out, Cout).cpu()
     pad = out.float()[..., Cout:]
     assert float(pad.abs().max()) == 0.0 if pad.numel() else True
@@ -254,8 +262,11 @@ def test_layerwise_vs_bf16_emulating_oracle():
         name = conv_layers[i]
         i += 1
         o = op[1] if op[0] == "stem" else op[6]
-        d = bufs[o.buf].float().cpu().numpy()[..., : o.c]
         r = ref[acts.get(name, name)]
+        if o.buf is None:  # only the fused max-pooled copy of this layer is stored
+            o = op[8]
+            r = r.reshape(r.shape[0], r.shape[1] // 2, 2, r.shape[2] // 2, 2, r.shape[3]).max(axis=(2, 4))
+        d = bufs[o.buf].float().cpu().numpy()[..., : o.c]
         scale = np.abs(r).max()
         err = np.abs(d - r).max() / scale
         assert err <= 2.0 ** -6, (name, err)
