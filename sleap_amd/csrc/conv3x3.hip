@@ -236,13 +236,19 @@ __device__ __forceinline__ int swz(int p) {
   return (CK == 32) ? ((p >> 2) & 3) : ((p >> 3) & 1);
 }
 
-// MT: 32-cout tiles per workgroup; CK: channels per chunk; R: rows per wave (tile = 4R x 32 pixels);
-// NBUF: LDS stages (2 = copy of chunk c+1 overlaps the MFMAs of chunk c; 1 for single-chunk layers, which are
-// HBM-bound and rely on many small resident workgroups per CU instead).
-template <int MT, int CK, int R, int NBUF>
-__global__ void __launch_bounds__(256)
+// MT: 32-cout tiles per workgroup; CK: channels per chunk; NW: waves per workgroup; R: rows per wave
+// (tile = NW*R x 32 pixels); NBUF: LDS stages (2 = the copy of chunk c+1 overlaps the MFMAs of chunk c).
+//   compute-bound (multi-chunk) layers: NW=8, R=2, NBUF=2 -> two waves per SIMD hide each other's LDS latency
+//   single-chunk layers (Cin <= CK, HBM-bound): NW=4, R=2, NBUF=1 -> small footprint, many workgroups per CU
+// Copies are buffer_load_dwordx4 ... lds (raw buffer descriptor per frame): the per-lane byte offset of a halo
+// pixel that lies outside the image is set beyond num_records, for which the hardware writes zeros to LDS
+// (verified by tools/probes/buffer_lds_oob.hip) -- SAME padding costs nothing; the chunk's channel offset and
+// the weight-slab offset travel in the scalar offset, so issuing a copy is one SALU add + one VMEM instruction.
+template <int MT, int CK, int NW, int R, int NBUF>
+__global__ void __launch_bounds__(NW * 64)
 conv3x3_dma_kernel(const ConvParams2 p) {
-  constexpr int TH = 4 * R, TW = 32, PH = TH + 2, PW = TW + 2;
+#if defined(__HIP_DEVICE_COMPILE__)  // the body uses device-only types (buffer resources); the host pass only needs the stub
+  constexpr int TH = NW * R, TW = 32, PH = TH + 2, PW = TW + 2;
   constexpr int PIXB = CK * 2;
   constexpr int N_IN = (PH * PW * PIXB + 1023) / 1024;
   constexpr int IN_BYTES = N_IN * 1024;
@@ -250,13 +256,20 @@ conv3x3_dma_kernel(const ConvParams2 p) {
   constexpr int N_W = MT * KK * 9;
   constexpr int W_BYTES = N_W * 1024;
   constexpr int STAGE = IN_BYTES + W_BYTES;
-  constexpr int N_DMA = N_IN + N_W;
-  constexpr int PER_WAVE = (N_DMA + 3) / 4;
+  constexpr int IN_PER_WAVE = (N_IN + NW - 1) / NW;
+  constexpr int W_PER_WAVE = (N_W + NW - 1) / NW;
+  constexpr unsigned OOB = 0xFFFFFF00u;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  int bid = blockIdx.x;
+  // XCD-aware block order: hardware places block i on XCD i % 8; give every XCD a contiguous range of logical
+  // tiles so that the cout tiles / neighbouring spatial tiles that re-read the same input share one L2.
+  int bid;
+  {
+    const int nblk = gridDim.x, q = nblk >> 3, r = nblk & 7, xcd = blockIdx.x & 7, k = blockIdx.x >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+  }
   const int co_t = bid % p.co_tiles;
   bid /= p.co_tiles;
   const int tx_i = bid % p.tiles_x;
@@ -270,51 +283,56 @@ conv3x3_dma_kernel(const ConvParams2 p) {
   const int co32_0 = co_t * MT;
   const int co32_n = (p.CoutP + 31) / 32;
 
-  // ---- per-lane DMA descriptors (identical for every chunk)
-  int pix_n[PER_WAVE];  // input: global pixel index or -1 (zero page); weights: cout tile or -1
-  int q8[PER_WAVE];
+  // ---- buffer descriptors (wave-uniform): one frame of each source, the packed weights
+  const size_t f0 = (size_t)H * W * p.C0P * 2, f1 = (size_t)H * W * p.C1P * 2;
+  const __amdgpu_buffer_rsrc_t rs0 =
+      __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<const unsigned char*>(p.src0) + b * f0), 0, (int)f0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(p.C1P ? reinterpret_cast<const unsigned char*>(p.src1) + b * f1 : reinterpret_cast<const unsigned char*>(p.src0)), 0,
+      (int)f1, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)p.w, 0, (int)((size_t)co32_n * K16 * 9 * 1024), 0x00020000);
+
+  // ---- per-lane byte offsets of this wave's input copies inside a frame (same for every chunk)
+  unsigned voff0[IN_PER_WAVE], voff1[IN_PER_WAVE];
 #pragma unroll
-  for (int j = 0; j < PER_WAVE; ++j) {
-    const int i = j * 4 + wave;
-    pix_n[j] = -1;
-    q8[j] = 0;
-    if (i < N_IN) {
-      const int o = i * 1024 + lane * 16;
-      const int pl = o / PIXB, s = (o % PIXB) / 16;
-      if (pl < PH * PW) {
-        const int ty = pl / PW, tx = pl % PW;
-        const int gy = y0 + ty - 1, gx = x0 + tx - 1;
-        if (gy >= 0 && gy < H && gx >= 0 && gx < W) pix_n[j] = (b * H + gy) * W + gx;
-        q8[j] = (s ^ swz<CK>(pl)) * 8;
-      }
-    } else if (i < N_DMA) {
-      const int k = i - N_IN;
-      const int m = k / (KK * 9), rest = k % (KK * 9);
-      if (co32_0 + m < co32_n) {
-        pix_n[j] = m;
-        q8[j] = (rest * 64 + lane) * 8;  // element offset inside the [KK][9][64][8] slab
-      }
-    }
+  for (int j = 0; j < IN_PER_WAVE; ++j) {
+    const int i = j * NW + wave;
+    const int o = i * 1024 + lane * 16;
+    const int pl = o / PIXB, s = (o % PIXB) / 16;
+    const int ty = pl / PW, tx = pl - ty * PW;
+    const int gy = y0 + ty - 1, gx = x0 + tx - 1;
+    const bool ok = (i < N_IN) && (pl < PH * PW) && gy >= 0 && gy < H && gx >= 0 && gx < W;
+    const unsigned pix = (unsigned)(gy * W + gx);
+    const unsigned q16 = (unsigned)((s ^ swz<CK>(pl)) * 16);
+    voff0[j] = ok ? pix * (unsigned)(p.C0P * 2) + q16 : OOB;
+    voff1[j] = ok ? pix * (unsigned)(p.C1P * 2) + q16 : OOB;
   }
+  const unsigned wv = (unsigned)lane * 16;
 
   auto issue = [&](int chunk, int buf) {
     const int c_lo = chunk * CK;
     const bool from1 = c_lo >= p.C0P;
-    const uint16_t* base = from1 ? p.src1 : p.src0;
-    const int CxP = from1 ? p.C1P : p.C0P;
-    const int cc = from1 ? c_lo - p.C0P : c_lo;
+    const int cc2 = (from1 ? c_lo - p.C0P : c_lo) * 2;
     unsigned char* stage = smem + buf * STAGE;
 #pragma unroll
-    for (int j = 0; j < PER_WAVE; ++j) {
-      const int i = j * 4 + wave;
+    for (int j = 0; j < IN_PER_WAVE; ++j) {
+      const int i = j * NW + wave;
       if (i < N_IN) {
-        const uint16_t* src = (pix_n[j] >= 0) ? base + (size_t)pix_n[j] * CxP + cc + q8[j] : p.zeros + (lane & 3) * 8;
-        __builtin_amdgcn_global_load_lds(src, (lds_ptr_t)(stage + i * 1024), 16, 0, 0);
-      } else if (i < N_DMA) {
-        const uint16_t* src = (pix_n[j] >= 0)
-                                  ? p.w + ((size_t)(co32_0 + pix_n[j]) * K16 + chunk * KK) * (9 * 64 * 8) + q8[j]
-                                  : p.zeros + (lane & 3) * 8;
-        __builtin_amdgcn_global_load_lds(src, (lds_ptr_t)(stage + i * 1024), 16, 0, 0);
+        if (from1)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, (lds_ptr_t)(stage + i * 1024), 16, voff1[j], cc2, 0, 0);
+        else
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, (lds_ptr_t)(stage + i * 1024), 16, voff0[j], cc2, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < W_PER_WAVE; ++j) {
+      const int k = j * NW + wave;  // (m, kk, tap) slab index
+      if (k < N_W) {
+        const int m = k / (KK * 9), rest = k - m * (KK * 9);
+        // cout tiles beyond CoutP read out of range -> zeros
+        const int soff = (co32_0 + m < co32_n) ? (((co32_0 + m) * K16 + chunk * KK) * 9 + rest) * 1024 : (int)0x7FFFF000;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_ptr_t)(stage + IN_BYTES + k * 1024), 16, wv, soff, 0, 0);
       }
     }
   };
@@ -413,26 +431,30 @@ conv3x3_dma_kernel(const ConvParams2 p) {
       }
     }
   }
+#endif
 }
 
-template <int MT, int CK, int R, int NBUF>
+template <int MT, int CK, int NW, int R, int NBUF>
 int launch2(const ConvParams2& p, hipStream_t st) {
-  constexpr int N_IN = ((4 * R + 2) * 34 * CK * 2 + 1023) / 1024;
+  constexpr int TH = NW * R;
+  constexpr int N_IN = ((TH + 2) * 34 * CK * 2 + 1023) / 1024;
   constexpr size_t lds = NBUF * ((size_t)N_IN * 1024 + (size_t)MT * (CK / 16) * 9 * 1024);
   ConvParams2 q = p;
   q.tiles_x = (p.W + 31) / 32;
-  q.tiles_y = (p.H + 4 * R - 1) / (4 * R);
+  q.tiles_y = (p.H + TH - 1) / TH;
   const int co32_n = (p.CoutP + 31) / 32;
   q.co_tiles = (co32_n + MT - 1) / MT;
   const size_t nblk = (size_t)q.tiles_x * q.tiles_y * q.co_tiles * p.B;
   if (nblk > 0x7fffffffull) return sa::fail(SA_ERR_INVALID_ARG, "sa_conv3x3_bf16: grid too large");
+  if ((size_t)p.H * p.W * (p.C0P > p.C1P ? p.C0P : p.C1P) * 2 >= 0xFFFFFF00ull)
+    return sa::fail(SA_ERR_UNSUPPORTED, "sa_conv3x3_bf16: one frame must be smaller than 4 GiB");
   static bool attr_set = false;
   if (!attr_set && lds > 64 * 1024) {
-    SA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_dma_kernel<MT, CK, R, NBUF>),
+    SA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_dma_kernel<MT, CK, NW, R, NBUF>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv3x3_dma_kernel<MT, CK, R, NBUF>), dim3((unsigned)nblk), dim3(256), lds, st, q);
+  hipLaunchKernelGGL((conv3x3_dma_kernel<MT, CK, NW, R, NBUF>), dim3((unsigned)nblk), dim3(NW * 64), lds, st, q);
   SA_LAUNCH_CHECK();
   return SA_OK;
 }
@@ -440,8 +462,8 @@ int launch2(const ConvParams2& p, hipStream_t st) {
 template <int MT, int CK>
 int launch2_pick(const ConvParams2& p, hipStream_t st) {
   // single-chunk layers (Cin <= CK) are HBM-bound: small single-stage tiles, many workgroups per CU
-  if ((p.C0P + p.C1P) == CK) return launch2<MT, CK, 2, 1>(p, st);
-  return launch2<MT, CK, 4, 2>(p, st);
+  if ((p.C0P + p.C1P) == CK) return launch2<MT, CK, 4, 2, 1>(p, st);
+  return launch2<MT, CK, 8, 2, 2>(p, st);
 }
 
 template <int MT, int R, int CK, int MODE>
