@@ -156,6 +156,16 @@ int sa_conv3x3_bf16(const void* src0, int C0P, const void* src1, int C1P, int mo
                     const float* bias, int CoutP, int relu, int B, int H, int W, void* dst, void* dst_pool,
                     sa_stream_t stream);
 
+/* Same convolution with up to two 1x1 heads (Head.make_head, heads.py:42-62) fused into the epilogue and
+ * computed from the fp32 accumulators (no bf16 rounding of the features the heads see). Needs CoutP <= 64 and
+ * mode NONE/DIRECT. HOST arrays of length n_heads: head_w[i] -> device [head_c[i]][CoutP] f32, head_b[i] -> device
+ * [head_c[i]] f32, head_c[i] <= 32, head_act[i] (0 linear, 1 sigmoid), head_dst[i] -> device [B,H,W,head_c[i]] f32.
+ * dst (bf16 features) may be NULL when only the heads consume this layer. */
+int sa_conv3x3_heads_bf16(const void* src0, int C0P, const void* src1, int C1P, int mode, const void* w,
+                          const float* bias, int CoutP, int relu, int B, int H, int W, void* dst, int n_heads,
+                          const float* const* head_w, const float* const* head_b, const int* head_c,
+                          const int* head_act, float* const* head_dst, sa_stream_t stream);
+
 /* HOST helper: Keras Conv2D kernel (3,3,Cin,Cout) f32 -> the packed bf16 layout above. The input
  * channel axis is the concatenation [C0 | C1]; each part is zero-padded to C0P / C1P. */
 int sa_pack_conv3x3_weights(const float* keras_kernel, int C0, int C0P, int C1, int C1P, int Cout,

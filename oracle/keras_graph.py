@@ -51,13 +51,15 @@ def _act(x, name):
 class KerasGraph:
     """Executes the layer list of a Keras `Functional` model config in NCHW torch tensors."""
 
-    def __init__(self, model_config, weights, emulate_bf16=False):
+    def __init__(self, model_config, weights, emulate_bf16=False, fp32_input_heads=()):
         """`emulate_bf16=True` rounds weights/activations to bfloat16 at exactly the points where the HIP engine
         stores bf16 (conv / transposed-conv / upsample outputs, 3x3 conv weights except the fp32 stem; heads
         keep fp32 weights and outputs), with fp32 accumulation in between. It separates "the kernels compute what
         they claim" (tight tolerance against this mode) from "bf16 storage is accurate enough" (loose tolerance
         against the fp32 mode)."""
         self.emulate_bf16 = emulate_bf16
+        # heads the engine computes from the un-rounded fp32 accumulators of the producing conv (fused epilogue)
+        self.fp32_input_heads = set(fp32_input_heads)
         cfg = model_config["config"]
         self.layers = cfg["layers"]
         self.input_names = [l[0] for l in cfg["input_layers"]]
@@ -77,14 +79,23 @@ class KerasGraph:
         """x_nhwc: (B, H, W, C) float32 array/tensor -> list of NHWC float32 numpy outputs."""
         x = torch.as_tensor(np.asarray(x_nhwc), dtype=torch.float32).permute(0, 3, 1, 2).contiguous()
         t = {}
+        u = {}  # un-rounded twins of conv (+activation) outputs in emulate_bf16 mode
         self._x_in = x
         for l in self.layers:
             cn, name, c = l["class_name"], l["name"], l["config"]
             if cn == "InputLayer":
                 t[name] = x
                 continue
-            ins = [t[n[0]] for n in l["inbound_nodes"][0]]
+            src = [n[0] for n in l["inbound_nodes"][0]]
+            ins = [t[n] for n in src]
+            if self.emulate_bf16 and name in self.fp32_input_heads and src[0] in u:
+                ins = [u[src[0]]]
             t[name] = self._layer(cn, name, c, ins)
+            if self.emulate_bf16:
+                if cn == "Conv2D":
+                    u[name] = self._layer_fp32(cn, name, c, ins)
+                elif cn == "Activation" and src[0] in u:
+                    u[name] = _act(u[src[0]], c["activation"])
         outs = [t[n].permute(0, 2, 3, 1).contiguous().numpy() for n in self.output_names]
         if return_all:
             return outs, {k: v.permute(0, 2, 3, 1).contiguous().numpy() for k, v in t.items()}

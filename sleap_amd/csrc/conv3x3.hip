@@ -227,6 +227,13 @@ struct ConvParams2 {
   int B, H, W;
   int relu;
   int tiles_x, tiles_y, co_tiles;
+  // fused 1x1 heads (Head.make_head, heads.py:42-62) computed from the fp32 accumulators of this conv
+  int n_heads;
+  const float* head_w[2];  // [NH][CoutP] f32
+  const float* head_b[2];  // [NH]
+  float* head_dst[2];      // [B,H,W,NH] f32
+  int head_c[2];           // NH <= 32
+  int head_act[2];         // 0 linear, 1 sigmoid
 };
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -244,7 +251,7 @@ __device__ __forceinline__ int swz(int p) {
 // pixel that lies outside the image is set beyond num_records, for which the hardware writes zeros to LDS
 // (verified by tools/probes/buffer_lds_oob.hip) -- SAME padding costs nothing; the chunk's channel offset and
 // the weight-slab offset travel in the scalar offset, so issuing a copy is one SALU add + one VMEM instruction.
-template <int MT, int CK, int NW, int R, int NBUF>
+template <int MT, int CK, int NW, int R, int NBUF, bool HEADS>
 __global__ void __launch_bounds__(NW * 64)
 conv3x3_dma_kernel(const ConvParams2 p) {
 #if defined(__HIP_DEVICE_COMPILE__)  // the body uses device-only types (buffer resources); the host pass only needs the stub
@@ -431,10 +438,69 @@ conv3x3_dma_kernel(const ConvParams2 p) {
       }
     }
   }
+
+  // ---- fused 1x1 heads: out[n] = act(b[n] + sum_co relu(conv)[co] * Wh[n][co]) from the UN-ROUNDED fp32 values.
+  // This workgroup holds all CoutP (<= MT*32) channels of its pixels: every lane owns 16*MT channels of pixel
+  // (row r, column lx); the partner lane (lane ^ 32) owns the other half.
+  if constexpr (HEADS) {
+    float* wh = reinterpret_cast<float*>(smem);
+    for (int hd = 0; hd < p.n_heads; ++hd) {
+      const int NH = p.head_c[hd];
+      __syncthreads();  // main-loop LDS reads (or the previous head) are done
+      for (int i = tid; i < NH * p.CoutP; i += NW * 64) wh[i] = p.head_w[hd][i];
+      __syncthreads();
+      float hacc[R][32];
+#pragma unroll
+      for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int n = 0; n < 32; ++n) hacc[r][n] = 0.0f;
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int co = (co32_0 + m) * 32 + 4 * half + 8 * g;
+          if (co >= p.CoutP) continue;
+          const float4 bq = *reinterpret_cast<const float4*>(p.bias + co);
+          const float bb[4] = {bq.x, bq.y, bq.z, bq.w};
+          float v[R][4];
+#pragma unroll
+          for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              float t = acc[m][r][4 * g + j] + bb[j];
+              v[r][j] = p.relu ? fmaxf(t, 0.0f) : t;
+            }
+#pragma unroll
+          for (int n = 0; n < 32; ++n) {
+            if (n < NH) {
+              const float4 wq = *reinterpret_cast<const float4*>(wh + n * p.CoutP + co);
+#pragma unroll
+              for (int r = 0; r < R; ++r)
+                hacc[r][n] = fmaf(v[r][3], wq.w, fmaf(v[r][2], wq.z, fmaf(v[r][1], wq.y, fmaf(v[r][0], wq.x, hacc[r][n]))));
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const int gy = y0 + wave * R + r;
+        float* out = p.head_dst[hd] + (((size_t)b * H + gy) * W + gx) * NH;
+#pragma unroll
+        for (int n = 0; n < 32; ++n) {
+          if (n < NH) {
+            float t = hacc[r][n] + __shfl_xor(hacc[r][n], 32);
+            t += p.head_b[hd][n];
+            if (p.head_act[hd] == 1) t = 1.0f / (1.0f + __expf(-t));
+            if (half == 0 && gy < H && gx < W) out[n] = t;
+          }
+        }
+      }
+    }
+  }
 #endif
 }
 
-template <int MT, int CK, int NW, int R, int NBUF>
+template <int MT, int CK, int NW, int R, int NBUF, bool HEADS>
 int launch2(const ConvParams2& p, hipStream_t st) {
   constexpr int TH = NW * R;
   constexpr int N_IN = ((TH + 2) * 34 * CK * 2 + 1023) / 1024;
@@ -450,20 +516,27 @@ int launch2(const ConvParams2& p, hipStream_t st) {
     return sa::fail(SA_ERR_UNSUPPORTED, "sa_conv3x3_bf16: one frame must be smaller than 4 GiB");
   static bool attr_set = false;
   if (!attr_set && lds > 64 * 1024) {
-    SA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_dma_kernel<MT, CK, NW, R, NBUF>),
+    SA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_dma_kernel<MT, CK, NW, R, NBUF, HEADS>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv3x3_dma_kernel<MT, CK, NW, R, NBUF>), dim3((unsigned)nblk), dim3(NW * 64), lds, st, q);
+  if (HEADS) {
+    if (q.co_tiles != 1) return sa::fail(SA_ERR_UNSUPPORTED, "fused heads need all output channels in one workgroup (CoutP <= %d)", MT * 32);
+    for (int hd = 0; hd < p.n_heads; ++hd)
+      if ((size_t)p.head_c[hd] * p.CoutP * 4 > lds || p.head_c[hd] > 32 || p.head_c[hd] < 1)
+        return sa::fail(SA_ERR_UNSUPPORTED, "fused head %d: %d channels not supported", hd, p.head_c[hd]);
+  }
+  hipLaunchKernelGGL((conv3x3_dma_kernel<MT, CK, NW, R, NBUF, HEADS>), dim3((unsigned)nblk), dim3(NW * 64), lds, st, q);
   SA_LAUNCH_CHECK();
   return SA_OK;
 }
 
 template <int MT, int CK>
 int launch2_pick(const ConvParams2& p, hipStream_t st) {
+  if (p.n_heads > 0) return launch2<MT, CK, 8, 2, 2, true>(p, st);
   // single-chunk layers (Cin <= CK) are HBM-bound: small single-stage tiles, many workgroups per CU
-  if ((p.C0P + p.C1P) == CK) return launch2<MT, CK, 4, 2, 1>(p, st);
-  return launch2<MT, CK, 8, 2, 2>(p, st);
+  if ((p.C0P + p.C1P) == CK) return launch2<MT, CK, 4, 2, 1, false>(p, st);
+  return launch2<MT, CK, 8, 2, 2, false>(p, st);
 }
 
 template <int MT, int R, int CK, int MODE>
@@ -501,42 +574,12 @@ int launch_mode(const ConvParams& p, int mode, hipStream_t st) {
 
 }  // namespace
 
-extern "C" {
-
-size_t sa_conv3x3_packed_elems(int C0P, int C1P, int CoutP) {
-  const size_t co32 = (CoutP + 31) / 32, k16 = (size_t)(C0P + C1P) / 16;
-  return co32 * k16 * 9 * 64 * 8;
-}
-
-int sa_pack_conv3x3_weights(const float* kk, int C0, int C0P, int C1, int C1P, int Cout, int CoutP,
-                            uint16_t* packed) {
-  SA_REQUIRE(C0P % 16 == 0 && C1P % 16 == 0 && C0 <= C0P && C1 <= C1P && Cout <= CoutP && CoutP % 16 == 0,
-             "sa_pack_conv3x3_weights: channel counts must be padded to multiples of 16");
-  const int Cin = C0 + C1, CinP = C0P + C1P, K16 = CinP / 16, co32_n = (CoutP + 31) / 32;
-  for (int co32 = 0; co32 < co32_n; ++co32)
-    for (int k16 = 0; k16 < K16; ++k16)
-      for (int tap = 0; tap < 9; ++tap)
-        for (int lane = 0; lane < 64; ++lane)
-          for (int j = 0; j < 8; ++j) {
-            const int co = co32 * 32 + (lane & 31);
-            const int cp = k16 * 16 + (lane >> 5) * 8 + j;  // padded concat channel
-            int ci = -1;                                     // Keras input channel
-            if (cp < C0P) {
-              if (cp < C0) ci = cp;
-            } else if (cp - C0P < C1) {
-              ci = C0 + (cp - C0P);
-            }
-            float v = 0.0f;
-            if (co < Cout && ci >= 0) v = kk[((size_t)tap * Cin + ci) * Cout + co];  // (kh,kw,Cin,Cout)
-            packed[((((size_t)co32 * K16 + k16) * 9 + tap) * 64 + lane) * 8 + j] = sa::f2bf(v);
-          }
-  return SA_OK;
-}
-
-int sa_conv3x3_bf16(const void* src0, int C0P, const void* src1, int C1P, int mode, const void* w,
-                    const float* bias, int CoutP, int relu, int B, int H, int W, void* dst, void* dst_pool,
-                    sa_stream_t stream) {
-  SA_REQUIRE(src0 && w && bias && (dst || dst_pool), "sa_conv3x3_bf16: NULL pointer");
+static int conv3x3_impl(const void* src0, int C0P, const void* src1, int C1P, int mode, const void* w,
+                        const float* bias, int CoutP, int relu, int B, int H, int W, void* dst, void* dst_pool,
+                        int n_heads, const float* const* head_w, const float* const* head_b, const int* head_c,
+                        const int* head_act, float* const* head_dst, sa_stream_t stream) {
+  SA_REQUIRE(src0 && w && bias && (dst || dst_pool || n_heads > 0), "sa_conv3x3_bf16: NULL pointer");
+  SA_REQUIRE(n_heads >= 0 && n_heads <= 2, "sa_conv3x3_bf16: at most 2 fused heads");
   SA_REQUIRE(C0P > 0 && C0P % 16 == 0 && C1P % 16 == 0 && CoutP > 0 && CoutP % 16 == 0,
              "sa_conv3x3_bf16: channels must be padded to multiples of 16 (C0P=%d C1P=%d CoutP=%d)", C0P, C1P, CoutP);
   SA_REQUIRE(B > 0 && H > 0 && W > 0, "sa_conv3x3_bf16: bad shape");
@@ -585,14 +628,72 @@ int sa_conv3x3_bf16(const void* src0, int C0P, const void* src1, int C1P, int mo
     q.H = H;
     q.W = W;
     q.relu = relu;
+    q.n_heads = n_heads;
+    for (int hd = 0; hd < n_heads; ++hd) {
+      q.head_w[hd] = head_w[hd];
+      q.head_b[hd] = head_b[hd];
+      q.head_c[hd] = head_c[hd];
+      q.head_act[hd] = head_act[hd];
+      q.head_dst[hd] = head_dst[hd];
+    }
     if (co32_n >= 2) return ck32 ? launch2_pick<2, 32>(q, st) : launch2_pick<2, 16>(q, st);
     return ck32 ? launch2_pick<1, 32>(q, st) : launch2_pick<1, 16>(q, st);
   }
-  SA_REQUIRE(dst && !dst_pool, "sa_conv3x3_bf16: pooled output is not available with pool/upsample source modes");
+  SA_REQUIRE(dst && !dst_pool && n_heads == 0,
+             "sa_conv3x3_bf16: pooled output / fused heads are not available with pool/upsample source modes");
   if (co32_n >= 2) {
     return ck32 ? launch_mode<2, 4, 32>(p, src_mode, st) : launch_mode<2, 4, 16>(p, src_mode, st);
   }
   return ck32 ? launch_mode<1, 4, 32>(p, src_mode, st) : launch_mode<1, 4, 16>(p, src_mode, st);
+}
+
+
+extern "C" {
+
+size_t sa_conv3x3_packed_elems(int C0P, int C1P, int CoutP) {
+  const size_t co32 = (CoutP + 31) / 32, k16 = (size_t)(C0P + C1P) / 16;
+  return co32 * k16 * 9 * 64 * 8;
+}
+
+int sa_pack_conv3x3_weights(const float* kk, int C0, int C0P, int C1, int C1P, int Cout, int CoutP,
+                            uint16_t* packed) {
+  SA_REQUIRE(C0P % 16 == 0 && C1P % 16 == 0 && C0 <= C0P && C1 <= C1P && Cout <= CoutP && CoutP % 16 == 0,
+             "sa_pack_conv3x3_weights: channel counts must be padded to multiples of 16");
+  const int Cin = C0 + C1, CinP = C0P + C1P, K16 = CinP / 16, co32_n = (CoutP + 31) / 32;
+  for (int co32 = 0; co32 < co32_n; ++co32)
+    for (int k16 = 0; k16 < K16; ++k16)
+      for (int tap = 0; tap < 9; ++tap)
+        for (int lane = 0; lane < 64; ++lane)
+          for (int j = 0; j < 8; ++j) {
+            const int co = co32 * 32 + (lane & 31);
+            const int cp = k16 * 16 + (lane >> 5) * 8 + j;  // padded concat channel
+            int ci = -1;                                     // Keras input channel
+            if (cp < C0P) {
+              if (cp < C0) ci = cp;
+            } else if (cp - C0P < C1) {
+              ci = C0 + (cp - C0P);
+            }
+            float v = 0.0f;
+            if (co < Cout && ci >= 0) v = kk[((size_t)tap * Cin + ci) * Cout + co];  // (kh,kw,Cin,Cout)
+            packed[((((size_t)co32 * K16 + k16) * 9 + tap) * 64 + lane) * 8 + j] = sa::f2bf(v);
+          }
+  return SA_OK;
+}
+
+int sa_conv3x3_bf16(const void* src0, int C0P, const void* src1, int C1P, int mode, const void* w,
+                    const float* bias, int CoutP, int relu, int B, int H, int W, void* dst, void* dst_pool,
+                    sa_stream_t stream) {
+  return conv3x3_impl(src0, C0P, src1, C1P, mode, w, bias, CoutP, relu, B, H, W, dst, dst_pool, 0, nullptr, nullptr,
+                      nullptr, nullptr, nullptr, stream);
+}
+
+int sa_conv3x3_heads_bf16(const void* src0, int C0P, const void* src1, int C1P, int mode, const void* w,
+                          const float* bias, int CoutP, int relu, int B, int H, int W, void* dst, int n_heads,
+                          const float* const* head_w, const float* const* head_b, const int* head_c,
+                          const int* head_act, float* const* head_dst, sa_stream_t stream) {
+  SA_REQUIRE(n_heads >= 1 && head_w && head_b && head_c && head_act && head_dst, "sa_conv3x3_heads_bf16: bad head arguments");
+  return conv3x3_impl(src0, C0P, src1, C1P, mode, w, bias, CoutP, relu, B, H, W, dst, nullptr, n_heads, head_w, head_b,
+                      head_c, head_act, head_dst, stream);
 }
 
 }  // extern "C"

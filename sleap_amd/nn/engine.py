@@ -45,12 +45,14 @@ class _T:
 
 
 class DeviceNetwork:
-    def __init__(self, model_config: dict, weights: Dict[str, np.ndarray], device=None, fuse_upsample: bool = False):
+    def __init__(self, model_config: dict, weights: Dict[str, np.ndarray], device=None, fuse_upsample: bool = False,
+                 fuse_heads: bool = True):
         """`fuse_upsample=True` folds UpSampling2D(bilinear) into the consuming conv's tile load (register-staged
         v1 kernel); the default materialises the upsampled tensor with the bandwidth-bound standalone kernel and
         feeds the asynchronous-DMA conv kernel (faster overall, measured in profiles/)."""
         require_cuda()
         self.fuse_upsample = fuse_upsample
+        self.fuse_heads = fuse_heads
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         cfg = model_config["config"]
         self.layers = cfg["layers"]
@@ -212,7 +214,7 @@ class DeviceNetwork:
                     check(h.sa_pack_conv3x3_weights(kc.ctypes.data_as(C.c_void_p), c0, c0p, c1, c1p, cout, coutp,
                                                     packed.ctypes.data_as(C.c_void_p)), "sa_pack_conv3x3_weights")
                     wdev = torch.from_numpy(packed.view(np.int16)).to(dev)
-                    plan.append(("conv", s0, s1, mode, wdev, bias, o, relu, o_pool, need_full))
+                    plan.append(["conv", s0, s1, mode, wdev, bias, o, relu, o_pool, need_full, []])
                 t[out_name] = o
                 t[name] = o
             elif cn == "Conv2DTranspose":
@@ -247,7 +249,7 @@ class DeviceNetwork:
                 t[name] = _T("concat", sum(i.c for i in ins), ins[0].num, ins[0].den, parts=ins)
             else:
                 raise NotImplementedError(f"Keras layer {cn} ({name}) is not implemented in the HIP engine")
-        self.plan = plan
+        self.plan = self._fuse_heads(plan) if self.fuse_heads else plan
         self.outputs = []
         for n in self.output_names:
             o = t[n]
@@ -257,6 +259,39 @@ class DeviceNetwork:
         self.n_buf = n_buf[0]
         # reduce fractions for stride bookkeeping
         self.max_stride = max(den // max(num, 1) for (_, num, den, _) in self.buf_meta.values())
+
+    @staticmethod
+    def _reads(op):
+        k = op[0]
+        if k == "conv":
+            return [t for t in (op[1], op[2]) if t is not None]
+        if k in ("head", "pool", "up", "convt"):
+            return [op[1]]
+        return []
+
+    def _fuse_heads(self, plan):
+        """Move 1x1 heads into the epilogue of the conv that produces their input (<= 2 heads, <= 32 channels each,
+        producer with <= 64 padded output channels on the DMA path). If the heads were the only readers the bf16
+        feature tensor is never written."""
+        convs = {id(op[6]): op for op in plan if op[0] == "conv"}
+        out = []
+        for op in plan:
+            if op[0] == "head":
+                prod = convs.get(id(op[1]))
+                if (prod is not None and prod[3] in (_lib.SRC1_NONE, _lib.SRC1_DIRECT) and prod[6].cp <= 64
+                        and len(prod[10]) < 2 and op[2].c <= 32):
+                    prod[10].append(op)
+                    continue
+            out.append(op)
+        for op in out:
+            if op[0] == "conv" and op[10]:
+                o = op[6]
+                readers = sum(1 for q in out for t in self._reads(q) if t is o)
+                if readers == 0:
+                    op[9] = False  # need_full
+                    self.buf_meta.pop(o.buf, None)
+                    o.buf = None
+        return out
 
     def output_strides(self):
         return [o.den // o.num for o in self.outputs]
@@ -276,7 +311,7 @@ class DeviceNetwork:
     def rescale_head(self, output_index: int, scale, shift):
         """out' = scale[c] * out + shift[c] folded into the 1x1 head's weights (used to calibrate random heads)."""
         target = self.outputs[output_index]
-        for op in self.plan:
+        for op in self._all_heads():
             if op[0] == "head" and op[2] is target:
                 w, b = op[3], op[4]
                 sc = torch.as_tensor(scale, dtype=torch.float32, device=w.device).reshape(-1)
@@ -286,10 +321,27 @@ class DeviceNetwork:
                 return
         raise KeyError(output_index)
 
+    def fused_head_names(self):
+        """Output layer names whose 1x1 head is computed inside the producing conv's epilogue (from fp32 values)."""
+        names = []
+        for op in self.plan:
+            if op[0] == "conv":
+                for hd in op[10]:
+                    names.append(self.output_names[[id(o) for o in self.outputs].index(id(hd[2]))])
+        return names
+
+    def _all_heads(self):
+        for op in self.plan:
+            if op[0] == "head":
+                yield op
+            elif op[0] == "conv":
+                for hd in op[10]:
+                    yield hd
+
     def export_head(self, output_index: int):
         """-> (kernel (1,1,Cin,Cout) float32, bias (Cout,)) of the 1x1 head as currently held on the device."""
         target = self.outputs[output_index]
-        for op in self.plan:
+        for op in self._all_heads():
             if op[0] == "head" and op[2] is target:
                 s, w, b = op[1], op[3].cpu().numpy(), op[4].cpu().numpy()
                 return np.ascontiguousarray(w[:, : s.c].T)[None, None], b.copy()
@@ -308,7 +360,10 @@ class DeviceNetwork:
                 s0, s1, o = op[1], op[2], op[6]
                 cin = s0.c + (s1.c if s1 is not None else 0)
                 f = 2 * (H * o.num // o.den) * (W * o.num // o.den) * cin * o.c * 9
-                out.append((k, f"conv3x3 {cin}->{o.c} @{H * o.num // o.den} mode{op[3]}", f))
+                nm = f"conv3x3 {cin}->{o.c} @{H * o.num // o.den} mode{op[3]}"
+                for hd in op[10]:
+                    nm += f" +head{hd[2].c}"
+                out.append((k, nm, f))
             elif k == "head":
                 s, o = op[1], op[2]
                 out.append((k, f"head {s.c}->{o.c} @{H * s.num // s.den}", 2 * (H * s.num // s.den) * (W * s.num // s.den) * s.c * o.c))
@@ -350,8 +405,24 @@ class DeviceNetwork:
                     raise ValueError("images must be uint8 or float32")
                 check(h.sa_stem_conv3x3(_ptr(imgs), is_u8, B, H, W, cin, _ptr(w), _ptr(bias), o.cp, relu,
                                         _ptr(bufs[o.buf]), st), "sa_stem_conv3x3")
+            elif kind == "conv" and op[10]:
+                _, s0, s1, mode, w, bias, o, relu, o_pool, need_full, heads = op
+                oh, ow = hw(o)
+                n = len(heads)
+                arr = (C.c_void_p * n)
+                hw_ = arr(*[hd[3].data_ptr() for hd in heads])
+                hb_ = arr(*[hd[4].data_ptr() for hd in heads])
+                hd_ = arr(*[bufs[hd[2].buf].data_ptr() for hd in heads])
+                hc_ = (C.c_int * n)(*[hd[2].c for hd in heads])
+                ha_ = (C.c_int * n)(*[hd[5] for hd in heads])
+                for hd in heads:  # the fused kernel indexes head weights with the producer's padded channel count
+                    assert hd[3].shape[1] == o.cp
+                check(h.sa_conv3x3_heads_bf16(_ptr(bufs[s0.buf]), s0.cp, _ptr(bufs[s1.buf]) if s1 is not None else None,
+                                              s1.cp if s1 is not None else 0, mode, _ptr(w), _ptr(bias), o.cp, relu, B, oh,
+                                              ow, _ptr(bufs[o.buf]) if need_full else None, n, hw_, hb_, hc_, ha_, hd_, st),
+                      "sa_conv3x3_heads_bf16")
             elif kind == "conv":
-                _, s0, s1, mode, w, bias, o, relu, o_pool, need_full = op
+                _, s0, s1, mode, w, bias, o, relu, o_pool, need_full, _heads = op
                 oh, ow = hw(o)
                 check(h.sa_conv3x3_bf16(_ptr(bufs[s0.buf]), s0.cp, _ptr(bufs[s1.buf]) if s1 is not None else None,
                                         s1.cp if s1 is not None else 0, mode, _ptr(w), _ptr(bias), o.cp, relu, B, oh, ow,
