@@ -636,6 +636,12 @@ static int conv3x3_impl(const void* src0, int C0P, const void* src1, int C1P, in
       q.head_act[hd] = head_act[hd];
       q.head_dst[hd] = head_dst[hd];
     }
+    if (n_heads > 0 && co32_n > 2) {
+      // heads need every output channel in one workgroup: 4 cout tiles (<= 128 channels), CK = 16 keeps two LDS
+      // stages within 160 KiB
+      SA_REQUIRE(co32_n <= 4, "sa_conv3x3_heads_bf16: fused heads support at most 128 output channels");
+      return launch2<4, 16, 8, 2, 2, true>(q, st);
+    }
     if (co32_n >= 2) return ck32 ? launch2_pick<2, 32>(q, st) : launch2_pick<2, 16>(q, st);
     return ck32 ? launch2_pick<1, 32>(q, st) : launch2_pick<1, 16>(q, st);
   }

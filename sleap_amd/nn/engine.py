@@ -271,14 +271,14 @@ class DeviceNetwork:
 
     def _fuse_heads(self, plan):
         """Move 1x1 heads into the epilogue of the conv that produces their input (<= 2 heads, <= 32 channels each,
-        producer with <= 64 padded output channels on the DMA path). If the heads were the only readers the bf16
+        producer with <= 128 padded output channels on the DMA path). If the heads were the only readers the bf16
         feature tensor is never written."""
         convs = {id(op[6]): op for op in plan if op[0] == "conv"}
         out = []
         for op in plan:
             if op[0] == "head":
                 prod = convs.get(id(op[1]))
-                if (prod is not None and prod[3] in (_lib.SRC1_NONE, _lib.SRC1_DIRECT) and prod[6].cp <= 64
+                if (prod is not None and prod[3] in (_lib.SRC1_NONE, _lib.SRC1_DIRECT) and prod[6].cp <= 128
                         and len(prod[10]) < 2 and op[2].c <= 32):
                     prod[10].append(op)
                     continue
