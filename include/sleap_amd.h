@@ -140,6 +140,16 @@ int sa_lsa_host(const double* cost, int nr, int nc, int64_t* row_ind, int64_t* c
 int sa_stem_conv3x3(const void* src, int src_is_u8, int B, int H, int W, int Cin, const float* w,
                     const float* bias, int CoutP, int relu, void* dst, sa_stream_t stream);
 
+/* The first TWO layers of the encoder in one kernel: sa_stem_conv3x3 computed on the VALU straight into the LDS
+ * tile of the following Conv2D(k3)+bias+ReLU (MFMA), whose output is stored at full resolution and/or max-pooled
+ * (encoder_decoder.py:109-131: conv, conv, then the next block's MaxPool2D). The full-resolution activation of
+ * the first conv (B*H*W*C0P bf16) never touches HBM.
+ *   src [B,H,W,Cin] u8|f32; w0 [3][3][Cin][C0P] f32, bias0 [C0P] f32 (C0P in {16,32});
+ *   w1 packed (sa_pack_conv3x3_weights with C0 = first conv's channels), bias1 [CoutP] f32, CoutP <= 64 */
+int sa_stem_conv3x3x2_bf16(const void* src, int src_is_u8, int B, int H, int W, int Cin, const float* w0,
+                           const float* bias0, int C0P, int relu0, const void* w1, const float* bias1, int CoutP,
+                           int relu1, void* dst, void* dst_pool, sa_stream_t stream);
+
 #define SA_SRC1_NONE 0
 #define SA_SRC1_DIRECT 1     /* Concatenate([src0, src1]) (encoder_decoder.py:360-362) */
 #define SA_SRC1_UPSAMPLE2X 2 /* Concatenate([src0, UpSampling2D(2, bilinear)(src1)]) (:335-339) */

@@ -9,14 +9,28 @@ namespace sa {
 typedef __attribute__((ext_vector_type(8))) unsigned short bf16x8_t;  // 16 B = 8 bf16 channels
 typedef __attribute__((ext_vector_type(4))) unsigned short bf16x4_t;
 
-// round-to-nearest-even float -> bf16 (NaN kept quiet)
+// round-to-nearest-even float -> bf16 (NaN kept quiet). Device code uses the hardware conversion
+// (v_cvt_pk_bf16_f32 on gfx950, same rounding); the host twin is used by the weight packer.
 __host__ __device__ inline uint16_t f2bf(float f) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_bit_cast(uint16_t, static_cast<__bf16>(f));
+#endif
   union { float f; uint32_t u; } v;
   v.f = f;
   if ((v.u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((v.u >> 16) | 0x40);
   const uint32_t lsb = (v.u >> 16) & 1u;
   return (uint16_t)((v.u + 0x7fffu + lsb) >> 16);
 }
+
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+// two floats -> packed bf16 pair (lo in bits 0..15) with ONE v_cvt_pk_bf16_f32
+__device__ __forceinline__ uint32_t f2bf2(float lo, float hi) {
+  f32x2_t v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
+}
+#endif
 
 __host__ __device__ inline float bf2f(uint16_t h) {
   union { float f; uint32_t u; } v;

@@ -234,6 +234,12 @@ struct ConvParams2 {
   float* head_dst[2];      // [B,H,W,NH] f32
   int head_c[2];           // NH <= 32
   int head_act[2];         // 0 linear, 1 sigmoid
+  // fused first layer (ensure_float + Conv2D(k3)+bias+ReLU on the raw image), computed on the VALU straight
+  // into the LDS tile that the MFMA loop reads; src0 is unused then
+  const void* stem_src;    // [B,H,W,CIN] u8 or f32
+  const float* stem_w;     // [3][3][CIN][C0P] f32
+  const float* stem_b;     // [C0P]
+  int stem_is_u8, stem_relu;
 };
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -251,7 +257,7 @@ __device__ __forceinline__ int swz(int p) {
 // pixel that lies outside the image is set beyond num_records, for which the hardware writes zeros to LDS
 // (verified by tools/probes/buffer_lds_oob.hip) -- SAME padding costs nothing; the chunk's channel offset and
 // the weight-slab offset travel in the scalar offset, so issuing a copy is one SALU add + one VMEM instruction.
-template <int MT, int CK, int NW, int R, int NBUF, bool HEADS>
+template <int MT, int CK, int NW, int R, int NBUF, bool HEADS, int STEM_CIN>
 __global__ void __launch_bounds__(NW * 64)
 conv3x3_dma_kernel(const ConvParams2 p) {
 #if defined(__HIP_DEVICE_COMPILE__)  // the body uses device-only types (buffer resources); the host pass only needs the stub
@@ -292,10 +298,11 @@ conv3x3_dma_kernel(const ConvParams2 p) {
 
   // ---- buffer descriptors (wave-uniform): one frame of each source, the packed weights
   const size_t f0 = (size_t)H * W * p.C0P * 2, f1 = (size_t)H * W * p.C1P * 2;
-  const __amdgpu_buffer_rsrc_t rs0 =
-      __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<const unsigned char*>(p.src0) + b * f0), 0, (int)f0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(STEM_CIN ? reinterpret_cast<const unsigned char*>(p.w) : reinterpret_cast<const unsigned char*>(p.src0) + b * f0), 0,
+      (int)f0, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)(p.C1P ? reinterpret_cast<const unsigned char*>(p.src1) + b * f1 : reinterpret_cast<const unsigned char*>(p.src0)), 0,
+      (void*)(p.C1P ? reinterpret_cast<const unsigned char*>(p.src1) + b * f1 : reinterpret_cast<const unsigned char*>(p.w)), 0,
       (int)f1, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(
       (void*)p.w, 0, (int)((size_t)co32_n * K16 * 9 * 1024), 0x00020000);
@@ -325,7 +332,7 @@ conv3x3_dma_kernel(const ConvParams2 p) {
 #pragma unroll
     for (int j = 0; j < IN_PER_WAVE; ++j) {
       const int i = j * NW + wave;
-      if (i < N_IN) {
+      if (STEM_CIN == 0 && i < N_IN) {
         if (from1)
           __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, (lds_ptr_t)(stage + i * 1024), 16, voff1[j], cc2, 0, 0);
         else
@@ -354,6 +361,154 @@ conv3x3_dma_kernel(const ConvParams2 p) {
 
   const int n_chunks = CinP / CK;
   issue(0, 0);
+  if constexpr (STEM_CIN > 0) {
+    // First conv on the raw image, written as bf16 straight into the swizzled LDS tile of the second conv.
+    // Halo pixels outside the image are ZERO (the second conv's SAME padding pads the first conv's OUTPUT); the
+    // raw tile itself is zero outside the image (the first conv's SAME padding).
+    constexpr int RW = PW + 2, RH = PH + 2, KT = 9 * STEM_CIN;
+    if (p.stem_is_u8) {
+      // uint8 path on the matrix cores: pixel values 0..255 are exact in bf16 (B operand); the fp32 weights times
+      // 1/255 (ensure_float, normalization.py:49) are split into three bf16 terms hi+mid+lo (A operands), which
+      // carries their full 24-bit mantissa, so three MFMAs per 16 taps give fp32-accurate products with fp32
+      // accumulation. K index = tap*CIN + c, zero padded to a multiple of 16.
+      constexpr int NK16 = (KT + 15) / 16;
+      uint16_t* rawh = reinterpret_cast<uint16_t*>(smem + NBUF * STAGE);
+      for (int i = tid; i < RH * RW * STEM_CIN; i += NW * 64) {
+        const int c = i % STEM_CIN, px = i / STEM_CIN;
+        const int ty = px / RW, tx = px - ty * RW;
+        const int gy = y0 + ty - 2, gx = x0 + tx - 2;
+        float v = 0.0f;
+        if (gy >= 0 && gy < H && gx >= 0 && gx < W)
+          v = (float)reinterpret_cast<const uint8_t*>(p.stem_src)[(((size_t)b * H + gy) * W + gx) * STEM_CIN + c];
+        rawh[i] = sa::f2bf(v);
+      }
+      const int hf = lane >> 5, l32 = lane & 31;
+      mfma_bf16x8 wa[NK16][3];
+#pragma unroll
+      for (int ks = 0; ks < NK16; ++ks) {
+        bf16x8_t t0, t1, t2;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int k = ks * 16 + hf * 8 + j;
+          float wv = 0.0f;
+          if (k < KT && l32 < CK) wv = p.stem_w[k * CK + l32] * (1.0f / 255.0f);
+          const uint16_t h0 = sa::f2bf(wv);
+          const float r1 = wv - sa::bf2f(h0);
+          const uint16_t h1 = sa::f2bf(r1);
+          const uint16_t h2 = sa::f2bf(r1 - sa::bf2f(h1));
+          t0[j] = h0;
+          t1[j] = h1;
+          t2[j] = h2;
+        }
+        wa[ks][0] = __builtin_bit_cast(mfma_bf16x8, t0);
+        wa[ks][1] = __builtin_bit_cast(mfma_bf16x8, t1);
+        wa[ks][2] = __builtin_bit_cast(mfma_bf16x8, t2);
+      }
+      __syncthreads();
+      constexpr int NG = (PH * PW + 31) / 32;
+      for (int g = wave; g < NG; g += NW) {
+        const int pl = g * 32 + l32;
+        const bool valid = pl < PH * PW;
+        const int plc = valid ? pl : 0;
+        const int ty = plc / PW, tx = plc - ty * PW;
+        f32x16 d;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) d[i] = 0.0f;
+#pragma unroll
+        for (int ks = 0; ks < NK16; ++ks) {
+          bf16x8_t bq;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const int k = ks * 16 + hf * 8 + j;
+            // k is lane dependent only through hf: resolve both halves at compile time
+            const int k0 = ks * 16 + j, k1 = ks * 16 + 8 + j;
+            uint16_t v0 = 0, v1 = 0;
+            if (k0 < KT) v0 = rawh[((ty + (k0 / STEM_CIN) / 3) * RW + tx + (k0 / STEM_CIN) % 3) * STEM_CIN + k0 % STEM_CIN];
+            if (k1 < KT) v1 = rawh[((ty + (k1 / STEM_CIN) / 3) * RW + tx + (k1 / STEM_CIN) % 3) * STEM_CIN + k1 % STEM_CIN];
+            bq[j] = hf ? v1 : v0;
+            (void)k;
+          }
+          const mfma_bf16x8 bf = __builtin_bit_cast(mfma_bf16x8, bq);
+#pragma unroll
+          for (int part = 0; part < 3; ++part) d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[ks][part], bf, d, 0, 0, 0);
+        }
+        const int gy = y0 + ty - 1, gx = x0 + tx - 1;
+        const bool in_img = valid && gy >= 0 && gy < H && gx >= 0 && gx < W;
+        // lane holds couts (reg&3) + 8*(reg>>2) + 4*hf of pixel pl; piece q (couts 8q..8q+7) = regs 4q..4q+3 of
+        // the hf=0 lane followed by the same regs of the hf=1 lane -> one exchange with the partner lane per pair
+        // of pieces, then every lane stores one 16-byte piece per pair.
+#pragma unroll
+        for (int qp = 0; qp < CK / 16; ++qp) {
+          unsigned pk[2][2];  // [piece in pair][dword]
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            const int q = 2 * qp + e;
+            uint16_t h4[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              float t = d[4 * q + j] + p.stem_b[8 * q + 4 * hf + j];
+              if (p.stem_relu) t = fmaxf(t, 0.0f);
+              h4[j] = in_img ? sa::f2bf(t) : (uint16_t)0;
+            }
+            pk[e][0] = (unsigned)h4[0] | ((unsigned)h4[1] << 16);
+            pk[e][1] = (unsigned)h4[2] | ((unsigned)h4[3] << 16);
+          }
+          // hf=0 keeps piece 2qp (sends its half of piece 2qp+1); hf=1 keeps piece 2qp+1
+          const unsigned s0 = hf ? pk[0][0] : pk[1][0], s1 = hf ? pk[0][1] : pk[1][1];
+          const unsigned r0 = __shfl_xor(s0, 32), r1 = __shfl_xor(s1, 32);
+          uint4 piece;
+          if (hf) {
+            piece = make_uint4(r0, r1, pk[1][0], pk[1][1]);
+          } else {
+            piece = make_uint4(pk[0][0], pk[0][1], r0, r1);
+          }
+          const int q = 2 * qp + hf;
+          if (valid) *reinterpret_cast<uint4*>(smem + pl * PIXB + (q ^ swz<CK>(pl)) * 16) = piece;
+        }
+      }
+    } else {
+      // float32 images: VALU path, same fp32 FMA order as stem_conv3x3_kernel (bit-identical activations)
+      float* raw = reinterpret_cast<float*>(smem + NBUF * STAGE);
+      float* w0 = raw + RH * RW * STEM_CIN;  // [9*CIN][CK] then bias [CK]
+      for (int i = tid; i < RH * RW * STEM_CIN; i += NW * 64) {
+        const int c = i % STEM_CIN, px = i / STEM_CIN;
+        const int ty = px / RW, tx = px - ty * RW;
+        const int gy = y0 + ty - 2, gx = x0 + tx - 2;
+        float v = 0.0f;
+        if (gy >= 0 && gy < H && gx >= 0 && gx < W)
+          v = reinterpret_cast<const float*>(p.stem_src)[(((size_t)b * H + gy) * W + gx) * STEM_CIN + c];
+        raw[i] = v;
+      }
+      for (int i = tid; i < (KT + 1) * CK; i += NW * 64) w0[i] = (i < KT * CK) ? p.stem_w[i] : p.stem_b[i - KT * CK];
+      __syncthreads();
+      constexpr int PIECES = CK / 8;
+      for (int it = tid; it < PH * PW * PIECES; it += NW * 64) {
+        const int pl = it / PIECES, q = it - pl * PIECES;
+        const int ty = pl / PW, tx = pl - ty * PW;
+        const int gy = y0 + ty - 1, gx = x0 + tx - 1;
+        bf16x8_t o = zero8();
+        if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
+          float a8[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) a8[j] = w0[KT * CK + q * 8 + j];
+#pragma unroll
+          for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+              for (int c = 0; c < STEM_CIN; ++c) {
+                const float v = raw[((ty + dy) * RW + tx + dx) * STEM_CIN + c];
+                const float* wr = w0 + ((dy * 3 + dx) * STEM_CIN + c) * CK + q * 8;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) a8[j] = fmaf(v, wr[j], a8[j]);
+              }
+#pragma unroll
+          for (int j = 0; j < 8; ++j) o[j] = sa::f2bf(p.stem_relu ? fmaxf(a8[j], 0.0f) : a8[j]);
+        }
+        *reinterpret_cast<bf16x8_t*>(smem + pl * PIXB + (q ^ swz<CK>(pl)) * 16) = o;
+      }
+    }
+  }
   int buf = 0;
   const int half = lane >> 5, lx = lane & 31;
   for (int chunk = 0; chunk < n_chunks; ++chunk) {
@@ -500,11 +655,12 @@ conv3x3_dma_kernel(const ConvParams2 p) {
 #endif
 }
 
-template <int MT, int CK, int NW, int R, int NBUF, bool HEADS>
+template <int MT, int CK, int NW, int R, int NBUF, bool HEADS, int STEM_CIN = 0>
 int launch2(const ConvParams2& p, hipStream_t st) {
   constexpr int TH = NW * R;
   constexpr int N_IN = ((TH + 2) * 34 * CK * 2 + 1023) / 1024;
-  constexpr size_t lds = NBUF * ((size_t)N_IN * 1024 + (size_t)MT * (CK / 16) * 9 * 1024);
+  constexpr size_t lds = NBUF * ((size_t)N_IN * 1024 + (size_t)MT * (CK / 16) * 9 * 1024) +
+                         (STEM_CIN ? ((size_t)(TH + 4) * 36 * STEM_CIN + (size_t)(9 * STEM_CIN + 1) * CK) * 4 : 0);
   ConvParams2 q = p;
   q.tiles_x = (p.W + 31) / 32;
   q.tiles_y = (p.H + TH - 1) / TH;
@@ -512,11 +668,11 @@ int launch2(const ConvParams2& p, hipStream_t st) {
   q.co_tiles = (co32_n + MT - 1) / MT;
   const size_t nblk = (size_t)q.tiles_x * q.tiles_y * q.co_tiles * p.B;
   if (nblk > 0x7fffffffull) return sa::fail(SA_ERR_INVALID_ARG, "sa_conv3x3_bf16: grid too large");
-  if ((size_t)p.H * p.W * (p.C0P > p.C1P ? p.C0P : p.C1P) * 2 >= 0xFFFFFF00ull)
+  if (!STEM_CIN && (size_t)p.H * p.W * (p.C0P > p.C1P ? p.C0P : p.C1P) * 2 >= 0xFFFFFF00ull)
     return sa::fail(SA_ERR_UNSUPPORTED, "sa_conv3x3_bf16: one frame must be smaller than 4 GiB");
   static bool attr_set = false;
   if (!attr_set && lds > 64 * 1024) {
-    SA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_dma_kernel<MT, CK, NW, R, NBUF, HEADS>),
+    SA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_dma_kernel<MT, CK, NW, R, NBUF, HEADS, STEM_CIN>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
@@ -526,7 +682,7 @@ int launch2(const ConvParams2& p, hipStream_t st) {
       if ((size_t)p.head_c[hd] * p.CoutP * 4 > lds || p.head_c[hd] > 32 || p.head_c[hd] < 1)
         return sa::fail(SA_ERR_UNSUPPORTED, "fused head %d: %d channels not supported", hd, p.head_c[hd]);
   }
-  hipLaunchKernelGGL((conv3x3_dma_kernel<MT, CK, NW, R, NBUF, HEADS>), dim3((unsigned)nblk), dim3(NW * 64), lds, st, q);
+  hipLaunchKernelGGL((conv3x3_dma_kernel<MT, CK, NW, R, NBUF, HEADS, STEM_CIN>), dim3((unsigned)nblk), dim3(NW * 64), lds, st, q);
   SA_LAUNCH_CHECK();
   return SA_OK;
 }
@@ -613,7 +769,7 @@ static int conv3x3_impl(const void* src0, int C0P, const void* src1, int C1P, in
       zeros = (const uint16_t*)z;
     }
     SA_REQUIRE(!dst_pool || (H % 2 == 0 && W % 2 == 0), "sa_conv3x3_bf16: pooled output needs even H, W");
-    ConvParams2 q;
+    ConvParams2 q = {};
     q.src0 = p.src0;
     q.src1 = p.src1;
     q.w = p.w;
@@ -691,6 +847,45 @@ int sa_conv3x3_bf16(const void* src0, int C0P, const void* src1, int C1P, int mo
                     sa_stream_t stream) {
   return conv3x3_impl(src0, C0P, src1, C1P, mode, w, bias, CoutP, relu, B, H, W, dst, dst_pool, 0, nullptr, nullptr,
                       nullptr, nullptr, nullptr, stream);
+}
+
+int sa_stem_conv3x3x2_bf16(const void* src, int src_is_u8, int B, int H, int W, int Cin, const float* w0,
+                           const float* bias0, int C0P, int relu0, const void* w1, const float* bias1, int CoutP,
+                           int relu1, void* dst, void* dst_pool, sa_stream_t stream) {
+  SA_REQUIRE(src && w0 && bias0 && w1 && bias1 && (dst || dst_pool), "sa_stem_conv3x3x2_bf16: NULL pointer");
+  SA_REQUIRE(Cin == 1 || Cin == 3, "sa_stem_conv3x3x2_bf16: Cin must be 1 or 3");
+  SA_REQUIRE(C0P == 16 || C0P == 32, "sa_stem_conv3x3x2_bf16: the first conv must have 16 or 32 (padded) output channels");
+  SA_REQUIRE(CoutP > 0 && CoutP % 16 == 0 && CoutP <= 64, "sa_stem_conv3x3x2_bf16: CoutP must be a multiple of 16, <= 64");
+  SA_REQUIRE(!dst_pool || (H % 2 == 0 && W % 2 == 0), "sa_stem_conv3x3x2_bf16: pooled output needs even H, W");
+  ConvParams2 q = {};
+  q.src0 = nullptr;
+  q.src1 = nullptr;
+  q.w = (const uint16_t*)w1;
+  q.bias = bias1;
+  q.dst = (uint16_t*)dst;
+  q.dst_pool = (uint16_t*)dst_pool;
+  q.zeros = nullptr;
+  q.C0P = C0P;
+  q.C1P = 0;
+  q.CoutP = CoutP;
+  q.B = B;
+  q.H = H;
+  q.W = W;
+  q.relu = relu1;
+  q.n_heads = 0;
+  q.stem_src = src;
+  q.stem_w = w0;
+  q.stem_b = bias0;
+  q.stem_is_u8 = src_is_u8;
+  q.stem_relu = relu0;
+  hipStream_t st = (hipStream_t)stream;
+  const bool two = CoutP > 32;
+  if (C0P == 16) {
+    if (Cin == 1) return two ? launch2<2, 16, 4, 2, 1, false, 1>(q, st) : launch2<1, 16, 4, 2, 1, false, 1>(q, st);
+    return two ? launch2<2, 16, 4, 2, 1, false, 3>(q, st) : launch2<1, 16, 4, 2, 1, false, 3>(q, st);
+  }
+  if (Cin == 1) return two ? launch2<2, 32, 4, 2, 1, false, 1>(q, st) : launch2<1, 32, 4, 2, 1, false, 1>(q, st);
+  return two ? launch2<2, 32, 4, 2, 1, false, 3>(q, st) : launch2<1, 32, 4, 2, 1, false, 3>(q, st);
 }
 
 int sa_conv3x3_heads_bf16(const void* src0, int C0P, const void* src1, int C1P, int mode, const void* w,

@@ -46,13 +46,14 @@ class _T:
 
 class DeviceNetwork:
     def __init__(self, model_config: dict, weights: Dict[str, np.ndarray], device=None, fuse_upsample: bool = False,
-                 fuse_heads: bool = True):
+                 fuse_heads: bool = True, fuse_stem: bool = True):
         """`fuse_upsample=True` folds UpSampling2D(bilinear) into the consuming conv's tile load (register-staged
         v1 kernel); the default materialises the upsampled tensor with the bandwidth-bound standalone kernel and
         feeds the asynchronous-DMA conv kernel (faster overall, measured in profiles/)."""
         require_cuda()
         self.fuse_upsample = fuse_upsample
         self.fuse_heads = fuse_heads
+        self.fuse_stem = fuse_stem
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         cfg = model_config["config"]
         self.layers = cfg["layers"]
@@ -249,7 +250,8 @@ class DeviceNetwork:
                 t[name] = _T("concat", sum(i.c for i in ins), ins[0].num, ins[0].den, parts=ins)
             else:
                 raise NotImplementedError(f"Keras layer {cn} ({name}) is not implemented in the HIP engine")
-        self.plan = self._fuse_heads(plan) if self.fuse_heads else plan
+        plan = self._fuse_heads(plan) if self.fuse_heads else plan
+        self.plan = self._fuse_stem(plan) if self.fuse_stem else plan
         self.outputs = []
         for n in self.output_names:
             o = t[n]
@@ -291,6 +293,26 @@ class DeviceNetwork:
                     op[9] = False  # need_full
                     self.buf_meta.pop(o.buf, None)
                     o.buf = None
+        return out
+
+    def _fuse_stem(self, plan):
+        """stem conv + the conv that follows it -> one launch (sa_stem_conv3x3x2_bf16) when the stem output has no
+        other reader, 16/32 padded channels, and the second conv has <= 64 output channels and no fused heads."""
+        out = list(plan)
+        for i, op in enumerate(out):
+            if op[0] != "stem":
+                continue
+            so = op[1]
+            readers = [q for q in out if any(t is so for t in self._reads(q))]
+            if len(readers) != 1 or readers[0][0] != "conv":
+                continue
+            cv = readers[0]
+            if cv[1] is not so or cv[2] is not None or cv[3] != _lib.SRC1_NONE or cv[10] or so.cp not in (16, 32) or cv[6].cp > 64:
+                continue
+            out[out.index(cv)] = ["stem2", op, cv]
+            out.remove(op)
+            self.buf_meta.pop(so.buf, None)
+            so.buf = None
         return out
 
     def output_strides(self):
@@ -352,7 +374,12 @@ class DeviceNetwork:
         out = []
         for op in self.plan:
             k = op[0]
-            if k == "stem":
+            if k == "stem2":
+                so, cin, o = op[1][1], op[1][4], op[2][6]
+                hh = H * o.num // o.den
+                f = 2 * hh * (W * o.num // o.den) * (cin * so.c + so.c * o.c) * 9
+                out.append(("conv", f"stem+conv3x3 {cin}->{so.c}->{o.c} @{hh}", f))
+            elif k == "stem":
                 o, cin = op[1], op[4]
                 f = 2 * (H * o.num // o.den) * (W * o.num // o.den) * cin * o.c * 9
                 out.append((k, f"stem {cin}->{o.c} @{H * o.num // o.den}", f))
@@ -396,7 +423,18 @@ class DeviceNetwork:
                 ev1 = torch.cuda.Event(enable_timing=True)
                 ev0.record()
                 profile.append((ev0, ev1))
-            if kind == "stem":
+            if kind == "stem2":
+                _, (_k, so, w0, b0, cin, relu0), (_c, _s0, _s1, _m, w1, b1, o, relu1, o_pool, need_full, _hd) = op
+                if cin != Cin:
+                    raise ValueError(f"model expects {cin} input channels, got {Cin}")
+                is_u8 = 1 if imgs.dtype == torch.uint8 else 0
+                if not is_u8 and imgs.dtype != torch.float32:
+                    raise ValueError("images must be uint8 or float32")
+                check(h.sa_stem_conv3x3x2_bf16(_ptr(imgs), is_u8, B, H, W, cin, _ptr(w0), _ptr(b0), so.cp, relu0, _ptr(w1),
+                                               _ptr(b1), o.cp, relu1, _ptr(bufs[o.buf]) if need_full else None,
+                                               _ptr(bufs[o_pool.buf]) if o_pool is not None else None, st),
+                      "sa_stem_conv3x3x2_bf16")
+            elif kind == "stem":
                 _, o, w, bias, cin, relu = op
                 if cin != Cin:
                     raise ValueError(f"model expects {cin} input channels, got {Cin}")
@@ -456,7 +494,10 @@ class DeviceNetwork:
         """2*H*W*Cin*Cout*k*k over all convs for ONE frame (logical channels)."""
         total = 0
         for op in self.plan:
-            if op[0] == "stem":
+            if op[0] == "stem2":
+                so, cin, o = op[1][1], op[1][4], op[2][6]
+                total += 2 * (H * o.num // o.den) * (W * o.num // o.den) * (cin * so.c + so.c * o.c) * 9
+            elif op[0] == "stem":
                 o, cin = op[1], op[4]
                 total += 2 * (H * o.num // o.den) * (W * o.num // o.den) * cin * o.c * 9
             elif op[0] == "conv":

@@ -256,11 +256,16 @@ def test_layerwise_vs_bf16_emulating_oracle():
     conv_layers = [l["name"] for l in cfg["config"]["layers"] if l["class_name"] == "Conv2D"]
     acts = {l["inbound_nodes"][0][0][0]: l["name"] for l in cfg["config"]["layers"] if l["class_name"] == "Activation"}
     i = 0
+    checked = 0
     for op in net.plan:
+        if op[0] == "stem2":  # fused first two convs: the first one's activation only ever lives in LDS
+            i += 1
+            op = op[2]
         if op[0] not in ("stem", "conv"):
             continue
         name = conv_layers[i]
         i += 1
+        checked += 1
         o = op[1] if op[0] == "stem" else op[6]
         r = ref[acts.get(name, name)]
         if o.buf is None and op[8] is None:
@@ -272,6 +277,25 @@ def test_layerwise_vs_bf16_emulating_oracle():
         scale = np.abs(r).max()
         err = np.abs(d - r).max() / scale
         assert err <= 2.0 ** -6, (name, err)
-        if i <= 2:
+        if checked <= 2:
             frac = (np.abs(d - r) > 1e-6 * scale).mean()
             assert frac < 2e-3 and err <= 2.0 ** -7 * 1.01, (name, frac, err)
+
+
+@pytest.mark.parametrize("fuse", [dict(fuse_stem=False), dict(fuse_heads=False), dict(fuse_upsample=True),
+                                  dict(fuse_stem=False, fuse_heads=False)])
+def test_fusion_variants_agree(fuse):
+    """Every fusion switch of the engine computes the same network up to bf16 rounding flips: the fused stem
+    evaluates the first conv on the matrix cores (3-term bf16 split of the fp32 weights, fp32-accurate), fused
+    heads see un-rounded features."""
+    from sleap_amd.nn.engine import DeviceNetwork
+
+    cfg, w = _benchmark_unet(96, 128)
+    x = torch.from_numpy(_fly_frames(2, 96, 128, 5)).cuda()
+    base = [o.clone() for o in DeviceNetwork(cfg, w).forward(x)]
+    other = [o.clone() for o in DeviceNetwork(cfg, w, **fuse).forward(x)]
+    for a, b in zip(base, other):
+        if False:
+            pass
+        else:
+            assert float((a - b).abs().max()) <= 2e-2 * float(a.abs().max())
