@@ -150,6 +150,16 @@ int sa_stem_conv3x3x2_bf16(const void* src, int src_is_u8, int B, int H, int W, 
                            const float* bias0, int C0P, int relu0, const void* w1, const float* bias1, int CoutP,
                            int relu1, void* dst, void* dst_pool, sa_stream_t stream);
 
+/* Specialisation of sa_stem_conv3x3x2_bf16 for uint8 images and <= 16 channels in both convs (the default
+ * `filters: 16` of SLEAP's UNet profiles) on v_mfma_f32_16x16x32_bf16, all weights register resident.
+ *   blob: device copy of the buffer filled by sa_stem16_pack (HOST helper: Keras conv0 (3,3,Cin,C0) and conv1
+ *   (3,3,C0,C1) f32 kernels + biases -> per-lane MFMA fragments; sa_stem16_blob_bytes() bytes). */
+int sa_stem16_u8_bf16(const void* src, int B, int H, int W, int Cin, const void* blob, int relu0, int relu1,
+                      void* dst, void* dst_pool, sa_stream_t stream);
+int sa_stem16_pack(const float* k0, const float* b0, int Cin, int C0, const float* k1, const float* b1, int C1,
+                   void* blob);
+size_t sa_stem16_blob_bytes(void);
+
 #define SA_SRC1_NONE 0
 #define SA_SRC1_DIRECT 1     /* Concatenate([src0, src1]) (encoder_decoder.py:360-362) */
 #define SA_SRC1_UPSAMPLE2X 2 /* Concatenate([src0, UpSampling2D(2, bilinear)(src1)]) (:335-339) */

@@ -39,6 +39,9 @@ SIGNATURES = {
     "sa_stem_conv3x3": (_i, [_p, _i, _i, _i, _i, _i, _p, _p, _i, _i, _p, _p]),
     "sa_conv3x3_bf16": (_i, [_p, _i, _p, _i, _i, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p]),
     "sa_stem_conv3x3x2_bf16": (_i, [_p, _i, _i, _i, _i, _i, _p, _p, _i, _i, _p, _p, _i, _i, _p, _p, _p]),
+    "sa_stem16_u8_bf16": (_i, [_p, _i, _i, _i, _i, _p, _i, _i, _p, _p, _p]),
+    "sa_stem16_pack": (_i, [_p, _p, _i, _i, _p, _p, _i, _p]),
+    "sa_stem16_blob_bytes": (_sz, []),
     "sa_conv3x3_heads_bf16": (_i, [_p, _i, _p, _i, _i, _p, _p, _i, _i, _i, _i, _i, _p, _i, _p, _p, _p, _p, _p, _p]),
     "sa_pack_conv3x3_weights": (_i, [_p, _i, _i, _i, _i, _i, _i, _p]),
     "sa_conv3x3_packed_elems": (_sz, [_i, _i, _i]),

@@ -20,6 +20,7 @@ SOURCES = [
     ("postproc.hip", ["-ffp-contract=off"]),
     ("layers.hip", []),
     ("conv3x3.hip", []),
+    ("stem16.hip", []),
 ]
 COMMON = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function"]
 

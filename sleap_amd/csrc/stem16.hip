@@ -1,0 +1,292 @@
+// The two full-resolution layers of SLEAP's UNet encoder for filters <= 16 in ONE kernel, on 16x16x32 MFMA:
+//   ensure_float (u8 * 1/255, normalization.py:49) -> Conv2D(k3, Cin in {1,3} -> C0<=16)+bias+ReLU
+//   -> Conv2D(k3, C0 -> C1<=16)+bias+ReLU -> [full-resolution store] and/or [MaxPool2D(2) store]
+// (encoder_decoder.py:109-131: block 0's two convs and block 1's leading max-pool).
+//
+// These layers carry 5 % of the network's FLOPs but would move ~40 % of its activation bytes if each stored its
+// output; here the first conv's activation lives only in LDS and, when the consumer is the next block's pool,
+// only the pooled quarter-size tensor is written.
+//
+// Why a dedicated kernel: with 16 output channels a 32x32x16 MFMA wastes half its rows; v_mfma_f32_16x16x32_bf16
+// (M = 16 channels, N = 16 pixels, K = 32) fits exactly: conv0's 9*Cin <= 27 taps are ONE K=32 step, conv1 packs
+// two taps x 16 channels per step (5 steps for 9 taps). All weights live in registers for the whole workgroup.
+//
+// conv0 precision: the B operand holds raw pixel values 0..255 (exact in bf16); the fp32 weights times 1/255 are
+// split into three bf16 terms (hi + mid + lo carries the full 24-bit mantissa), three MFMAs with fp32 accumulation.
+#include <cstdint>
+
+#include "bf16.h"
+#include "sa_common.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 mfma_bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+using sa::bf16x8_t;
+
+struct Stem16Params {
+  const uint8_t* src;   // [B,H,W,CIN] u8
+  const uint16_t* blob;  // sa_stem16_pack: wa[3][64][8] | wb[5][64][8] bf16 | bias0[16] | bias1[16] f32
+  uint16_t* dst;        // [B,H,W,16] bf16 or nullptr
+  uint16_t* dst_pool;   // [B,H/2,W/2,16] bf16 or nullptr
+  int B, H, W, relu0, relu1, tiles_x, tiles_y;
+};
+
+// tile: 16 rows x 32 columns of output per workgroup (4 waves x 4 rows)
+#define SA_STEM16_TH 16
+#define SA_STEM16_TW 32
+
+template <int CIN>
+__global__ void __launch_bounds__(256)
+stem16_kernel(const Stem16Params p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int TH = SA_STEM16_TH, TW = SA_STEM16_TW, PH = TH + 2, PW = TW + 2, RH = TH + 4, RW = TW + 4;
+  // LDS: raw image tile as bf16 [RH][RW][CIN]; conv0 activation tile [PH*PW pixels][16 ch] bf16, 32 B per pixel,
+  // the two 16-byte halves of pixel pl swapped when (pl >> 3) & 1 (bank spreading for the ds_read_b128 of conv1)
+  __shared__ __attribute__((aligned(16))) uint16_t raw[RH * RW * CIN + 8];
+  __shared__ __attribute__((aligned(16))) unsigned char act[PH * PW * 32];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n16 = lane & 15, kb = lane >> 4;
+  int bid = blockIdx.x;
+  const int tx_i = bid % p.tiles_x;
+  bid /= p.tiles_x;
+  const int ty_i = bid % p.tiles_y;
+  const int b = bid / p.tiles_y;
+  const int x0 = tx_i * TW, y0 = ty_i * TH;
+  const int H = p.H, W = p.W;
+
+  // ---- raw tile (zero outside the image = conv0's SAME padding), pixel values as bf16 (exact for 0..255)
+  if (CIN == 1 && (W & 3) == 0) {
+    // aligned dword loads: columns x0-4 .. x0+35 (10 dwords per row); raw column tx corresponds to gx = x0 + tx - 2
+    for (int i = tid; i < RH * 10; i += 256) {
+      const int ty = i / 10, dq = i - ty * 10;
+      const int gy = y0 + ty - 2, gx = x0 - 4 + dq * 4;
+      unsigned v = 0;
+      if (gy >= 0 && gy < H && gx >= 0 && gx < W)
+        v = *reinterpret_cast<const unsigned*>(p.src + ((size_t)b * H + gy) * W + gx);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int tx = dq * 4 + e - 2;
+        if (tx >= 0 && tx < RW) raw[ty * RW + tx] = sa::f2bf((float)((v >> (8 * e)) & 0xFF));
+      }
+    }
+  } else {
+    for (int i = tid; i < RH * RW * CIN; i += 256) {
+      const int c = i % CIN, px = i / CIN;
+      const int ty = px / RW, tx = px - ty * RW;
+      const int gy = y0 + ty - 2, gx = x0 + tx - 2;
+      float v = 0.0f;
+      if (gy >= 0 && gy < H && gx >= 0 && gx < W) v = (float)p.src[(((size_t)b * H + gy) * W + gx) * CIN + c];
+      raw[i] = sa::f2bf(v);
+    }
+  }
+  // ---- weights: MFMA A fragments packed per lane on the host (sa_stem16_pack), register resident
+  const uint4* blob4 = reinterpret_cast<const uint4*>(p.blob);
+  mfma_bf16x8 wa[3], wb[5];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) wa[i] = __builtin_bit_cast(mfma_bf16x8, blob4[i * 64 + lane]);
+#pragma unroll
+  for (int i = 0; i < 5; ++i) wb[i] = __builtin_bit_cast(mfma_bf16x8, blob4[(3 + i) * 64 + lane]);
+  const float* biases = reinterpret_cast<const float*>(p.blob + 8 * 64 * 8);
+  const float4 q0 = *reinterpret_cast<const float4*>(biases + kb * 4);  // D rows of this lane: couts kb*4 .. kb*4+3
+  const float4 q1 = *reinterpret_cast<const float4*>(biases + 16 + kb * 4);
+  const float bias0[4] = {q0.x, q0.y, q0.z, q0.w}, bias1[4] = {q1.x, q1.y, q1.z, q1.w};
+  __syncthreads();
+
+  // ---- conv0 on the (PH x PW) halo tile, 16 pixels per MFMA group
+  constexpr int NG0 = (PH * PW + 15) / 16;
+  for (int g = wave; g < NG0; g += 4) {
+    const int pl = g * 16 + n16;
+    const bool valid = pl < PH * PW;
+    const int plc = valid ? pl : 0;
+    const int ty = plc / PW, tx = plc - ty * PW;
+    bf16x8_t bq = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (CIN == 1) {
+      if (kb < 3) {
+        const uint16_t* r = raw + (ty + kb) * RW + tx;
+        bq[0] = r[0];
+        bq[1] = r[1];
+        bq[2] = r[2];
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int f = kb * 8 + j;  // flat tap*CIN + c
+        if (f < 9 * CIN) {
+          const int tap = f / CIN, c = f - tap * CIN;
+          bq[j] = raw[((ty + tap / 3) * RW + tx + tap % 3) * CIN + c];
+        }
+      }
+    }
+    const mfma_bf16x8 bf = __builtin_bit_cast(mfma_bf16x8, bq);
+    f32x4 d = {0.0f, 0.0f, 0.0f, 0.0f};
+    d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[0], bf, d, 0, 0, 0);
+    d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[1], bf, d, 0, 0, 0);
+    d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[2], bf, d, 0, 0, 0);
+    const int gy = y0 + ty - 1, gx = x0 + tx - 1;
+    const bool in_img = valid && gy >= 0 && gy < H && gx >= 0 && gx < W;  // outside: conv1's SAME padding = 0
+    float v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float t = d[j] + bias0[j];
+      if (p.relu0) t = fmaxf(t, 0.0f);
+      v[j] = in_img ? t : 0.0f;
+    }
+    if (valid) {
+      uint2 o;
+      o.x = sa::f2bf2(v[0], v[1]);
+      o.y = sa::f2bf2(v[2], v[3]);
+      const int piece = (kb >> 1) ^ ((pl >> 3) & 1);
+      *reinterpret_cast<uint2*>(act + pl * 32 + piece * 16 + (kb & 1) * 8) = o;
+    }
+  }
+  __syncthreads();
+
+  // ---- conv1: wave w owns rows 4w..4w+3, two 16-pixel groups per row
+  f32x4 acc[4][2];
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) acc[r][h] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+  for (int s = 0; s < 5; ++s) {
+    const int tap = 2 * s + (kb >> 1);
+    const int dy = tap < 9 ? tap / 3 : 0, dx = tap < 9 ? tap % 3 : 0;  // tap 9 (padding) reads any valid address
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int pl = (wave * 4 + r + dy) * PW + h * 16 + n16 + dx;
+        const int piece = (kb & 1) ^ ((pl >> 3) & 1);
+        const mfma_bf16x8 bv = *reinterpret_cast<const mfma_bf16x8*>(act + pl * 32 + piece * 16);
+        acc[r][h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[s], bv, acc[r][h], 0, 0, 0);
+      }
+  }
+
+  // ---- epilogue: lane holds couts kb*4..+3 of pixel (row, h*16 + n16)
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int gx = x0 + h * 16 + n16;
+    float v[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float t = acc[r][h][j] + bias1[j];
+        v[r][j] = p.relu1 ? fmaxf(t, 0.0f) : t;
+      }
+    if (p.dst) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int gy = y0 + wave * 4 + r;
+        if (gy < H && gx < W) {
+          uint2 o;
+          o.x = sa::f2bf2(v[r][0], v[r][1]);
+          o.y = sa::f2bf2(v[r][2], v[r][3]);
+          *reinterpret_cast<uint2*>(p.dst + (((size_t)b * H + gy) * W + gx) * 16 + kb * 4) = o;
+        }
+      }
+    }
+    if (p.dst_pool) {
+#pragma unroll
+      for (int r = 0; r < 4; r += 2) {
+        float t4[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float t = fmaxf(v[r][j], v[r + 1][j]);
+          t4[j] = fmaxf(t, __shfl_xor(t, 1));
+        }
+        const int gy = y0 + wave * 4 + r;
+        if (!(lane & 1) && gy < H && gx < W) {
+          uint2 o;
+          o.x = sa::f2bf2(t4[0], t4[1]);
+          o.y = sa::f2bf2(t4[2], t4[3]);
+          *reinterpret_cast<uint2*>(p.dst_pool + (((size_t)b * (H / 2) + gy / 2) * (W / 2) + gx / 2) * 16 + kb * 4) = o;
+        }
+      }
+    }
+  }
+#endif
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t sa_stem16_blob_bytes(void) { return 8 * 64 * 8 * 2 + 32 * 4; }
+
+// HOST: Keras kernels conv0 (3,3,Cin,C0) f32 / conv1 (3,3,C0,C1) f32 + biases -> the per-lane MFMA A-fragment blob:
+//   wa[3][64][8] bf16: conv0 weights * 1/255 split hi/mid/lo; lane l -> cout l&15, k = (l>>4)*8 + j
+//                      (Cin=1: k-block = kernel row, j = kernel column; Cin=3: k = tap*3 + c)
+//   wb[5][64][8] bf16: conv1, step s covers taps 2s (k-blocks 0,1 = channels 0-7, 8-15) and 2s+1 (k-blocks 2,3)
+//   bias0[16], bias1[16] f32
+int sa_stem16_pack(const float* k0, const float* b0, int Cin, int C0, const float* k1, const float* b1, int C1,
+                   void* blob) {
+  SA_REQUIRE((Cin == 1 || Cin == 3) && C0 >= 1 && C0 <= 16 && C1 >= 1 && C1 <= 16, "sa_stem16_pack: bad channel counts");
+  uint16_t* w = (uint16_t*)blob;
+  for (int l = 0; l < 64; ++l) {
+    const int m = l & 15, kb = l >> 4;
+    for (int j = 0; j < 8; ++j) {
+      const int k = kb * 8 + j;
+      int f = -1;
+      if (Cin == 1) {
+        if (kb < 3 && j < 3) f = kb * 3 + j;
+      } else if (k < 9 * Cin) {
+        f = k;
+      }
+      float wv = 0.0f;
+      if (f >= 0 && m < C0) wv = k0[(size_t)f * C0 + m] * (1.0f / 255.0f);
+      const uint16_t h0 = sa::f2bf(wv);
+      const float r1 = wv - sa::bf2f(h0);
+      const uint16_t h1 = sa::f2bf(r1);
+      w[(0 * 64 + l) * 8 + j] = h0;
+      w[(1 * 64 + l) * 8 + j] = h1;
+      w[(2 * 64 + l) * 8 + j] = sa::f2bf(r1 - sa::bf2f(h1));
+    }
+    for (int s = 0; s < 5; ++s) {
+      const int tap = 2 * s + (kb >> 1);
+      for (int j = 0; j < 8; ++j) {
+        const int ci = (kb & 1) * 8 + j;
+        float v = 0.0f;
+        if (tap < 9 && ci < C0 && m < C1) v = k1[((size_t)tap * C0 + ci) * C1 + m];
+        w[((3 + s) * 64 + l) * 8 + j] = sa::f2bf(v);
+      }
+    }
+  }
+  float* bb = reinterpret_cast<float*>(w + 8 * 64 * 8);
+  for (int i = 0; i < 16; ++i) {
+    bb[i] = i < C0 ? b0[i] : 0.0f;
+    bb[16 + i] = i < C1 ? b1[i] : 0.0f;
+  }
+  return SA_OK;
+}
+
+int sa_stem16_u8_bf16(const void* src, int B, int H, int W, int Cin, const void* blob, int relu0, int relu1,
+                      void* dst, void* dst_pool, sa_stream_t stream) {
+  SA_REQUIRE(src && blob && (dst || dst_pool), "sa_stem16_u8_bf16: NULL pointer");
+  SA_REQUIRE(Cin == 1 || Cin == 3, "sa_stem16_u8_bf16: Cin must be 1 or 3");
+  SA_REQUIRE(B > 0 && H > 0 && W > 0, "sa_stem16_u8_bf16: bad shape");
+  SA_REQUIRE(!dst_pool || (H % 2 == 0 && W % 2 == 0), "sa_stem16_u8_bf16: pooled output needs even H, W");
+  Stem16Params p;
+  p.src = (const uint8_t*)src;
+  p.blob = (const uint16_t*)blob;
+  p.dst = (uint16_t*)dst;
+  p.dst_pool = (uint16_t*)dst_pool;
+  p.B = B;
+  p.H = H;
+  p.W = W;
+  p.relu0 = relu0;
+  p.relu1 = relu1;
+  p.tiles_x = (W + SA_STEM16_TW - 1) / SA_STEM16_TW;
+  p.tiles_y = (H + SA_STEM16_TH - 1) / SA_STEM16_TH;
+  const size_t nblk = (size_t)p.tiles_x * p.tiles_y * B;
+  if (nblk > 0x7fffffffull) return sa::fail(SA_ERR_INVALID_ARG, "sa_stem16_u8_bf16: grid too large");
+  if (Cin == 1)
+    hipLaunchKernelGGL((stem16_kernel<1>), dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, p);
+  else
+    hipLaunchKernelGGL((stem16_kernel<3>), dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, p);
+  SA_LAUNCH_CHECK();
+  return SA_OK;
+}
+
+}  // extern "C"

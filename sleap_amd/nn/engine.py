@@ -46,7 +46,7 @@ class _T:
 
 class DeviceNetwork:
     def __init__(self, model_config: dict, weights: Dict[str, np.ndarray], device=None, fuse_upsample: bool = False,
-                 fuse_heads: bool = True, fuse_stem: bool = True):
+                 fuse_heads: bool = True, fuse_stem: bool = True, use_stem16: bool = True):
         """`fuse_upsample=True` folds UpSampling2D(bilinear) into the consuming conv's tile load (register-staged
         v1 kernel); the default materialises the upsampled tensor with the bandwidth-bound standalone kernel and
         feeds the asynchronous-DMA conv kernel (faster overall, measured in profiles/)."""
@@ -54,6 +54,7 @@ class DeviceNetwork:
         self.fuse_upsample = fuse_upsample
         self.fuse_heads = fuse_heads
         self.fuse_stem = fuse_stem
+        self.use_stem16 = use_stem16
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         cfg = model_config["config"]
         self.layers = cfg["layers"]
@@ -181,7 +182,7 @@ class DeviceNetwork:
                     w = np.zeros((3, 3, cin, coutp), np.float32)
                     w[..., :cout] = kern
                     o.buf = new_buf(coutp, x.num, x.den, "bf16")
-                    plan.append(("stem", o, upload_f32(w), bias, cin, relu))
+                    plan.append(("stem", o, upload_f32(w), bias, cin, relu, name))
                 else:
                     mode, s0, s1 = _lib.SRC1_NONE, None, None
                     if x.kind == "concat":
@@ -215,7 +216,7 @@ class DeviceNetwork:
                     check(h.sa_pack_conv3x3_weights(kc.ctypes.data_as(C.c_void_p), c0, c0p, c1, c1p, cout, coutp,
                                                     packed.ctypes.data_as(C.c_void_p)), "sa_pack_conv3x3_weights")
                     wdev = torch.from_numpy(packed.view(np.int16)).to(dev)
-                    plan.append(["conv", s0, s1, mode, wdev, bias, o, relu, o_pool, need_full, []])
+                    plan.append(["conv", s0, s1, mode, wdev, bias, o, relu, o_pool, need_full, [], name])
                 t[out_name] = o
                 t[name] = o
             elif cn == "Conv2DTranspose":
@@ -309,7 +310,19 @@ class DeviceNetwork:
             cv = readers[0]
             if cv[1] is not so or cv[2] is not None or cv[3] != _lib.SRC1_NONE or cv[10] or so.cp not in (16, 32) or cv[6].cp > 64:
                 continue
-            out[out.index(cv)] = ["stem2", op, cv]
+            w1_16 = None
+            if so.cp == 16 and cv[6].cp == 16:  # register-resident 16x16x32 MFMA specialisation (uint8 input)
+                h = _lib.lib()
+                k0 = np.ascontiguousarray(self.weights[op[6] + "/kernel"], dtype=np.float32)
+                k1 = np.ascontiguousarray(self.weights[cv[11] + "/kernel"], dtype=np.float32)
+                b0 = np.ascontiguousarray(self.weights.get(op[6] + "/bias", np.zeros(k0.shape[3])), dtype=np.float32)
+                b1 = np.ascontiguousarray(self.weights.get(cv[11] + "/bias", np.zeros(k1.shape[3])), dtype=np.float32)
+                blob = np.zeros((h.sa_stem16_blob_bytes(),), np.uint8)
+                vp = lambda a: a.ctypes.data_as(C.c_void_p)
+                check(h.sa_stem16_pack(vp(k0), vp(b0), k0.shape[2], k0.shape[3], vp(k1), vp(b1), k1.shape[3], vp(blob)),
+                      "sa_stem16_pack")
+                w1_16 = torch.from_numpy(blob).to(self.device)
+            out[out.index(cv)] = ["stem2", op, cv, w1_16]
             out.remove(op)
             self.buf_meta.pop(so.buf, None)
             so.buf = None
@@ -424,18 +437,25 @@ class DeviceNetwork:
                 ev0.record()
                 profile.append((ev0, ev1))
             if kind == "stem2":
-                _, (_k, so, w0, b0, cin, relu0), (_c, _s0, _s1, _m, w1, b1, o, relu1, o_pool, need_full, _hd) = op
+                _, (_k, so, w0, b0, cin, relu0, _n0), (_c, _s0, _s1, _m, w1, b1, o, relu1, o_pool, need_full, _hd, _nm), w1_16 = op
                 if cin != Cin:
                     raise ValueError(f"model expects {cin} input channels, got {Cin}")
                 is_u8 = 1 if imgs.dtype == torch.uint8 else 0
                 if not is_u8 and imgs.dtype != torch.float32:
                     raise ValueError("images must be uint8 or float32")
-                check(h.sa_stem_conv3x3x2_bf16(_ptr(imgs), is_u8, B, H, W, cin, _ptr(w0), _ptr(b0), so.cp, relu0, _ptr(w1),
-                                               _ptr(b1), o.cp, relu1, _ptr(bufs[o.buf]) if need_full else None,
-                                               _ptr(bufs[o_pool.buf]) if o_pool is not None else None, st),
-                      "sa_stem_conv3x3x2_bf16")
+                if is_u8 and w1_16 is not None and self.use_stem16:
+                    check(h.sa_stem16_u8_bf16(_ptr(imgs), B, H, W, cin, _ptr(w1_16), relu0, relu1,
+                                              _ptr(bufs[o.buf]) if need_full else None,
+                                              _ptr(bufs[o_pool.buf]) if o_pool is not None else None, st),
+                          "sa_stem16_u8_bf16")
+                else:
+                    check(h.sa_stem_conv3x3x2_bf16(_ptr(imgs), is_u8, B, H, W, cin, _ptr(w0), _ptr(b0), so.cp, relu0,
+                                                   _ptr(w1), _ptr(b1), o.cp, relu1,
+                                                   _ptr(bufs[o.buf]) if need_full else None,
+                                                   _ptr(bufs[o_pool.buf]) if o_pool is not None else None, st),
+                          "sa_stem_conv3x3x2_bf16")
             elif kind == "stem":
-                _, o, w, bias, cin, relu = op
+                _, o, w, bias, cin, relu, _n0 = op
                 if cin != Cin:
                     raise ValueError(f"model expects {cin} input channels, got {Cin}")
                 is_u8 = 1 if imgs.dtype == torch.uint8 else 0
@@ -444,7 +464,7 @@ class DeviceNetwork:
                 check(h.sa_stem_conv3x3(_ptr(imgs), is_u8, B, H, W, cin, _ptr(w), _ptr(bias), o.cp, relu,
                                         _ptr(bufs[o.buf]), st), "sa_stem_conv3x3")
             elif kind == "conv" and op[10]:
-                _, s0, s1, mode, w, bias, o, relu, o_pool, need_full, heads = op
+                _, s0, s1, mode, w, bias, o, relu, o_pool, need_full, heads, _nm = op
                 oh, ow = hw(o)
                 n = len(heads)
                 arr = (C.c_void_p * n)
@@ -460,7 +480,7 @@ class DeviceNetwork:
                                               ow, _ptr(bufs[o.buf]) if need_full else None, n, hw_, hb_, hc_, ha_, hd_, st),
                       "sa_conv3x3_heads_bf16")
             elif kind == "conv":
-                _, s0, s1, mode, w, bias, o, relu, o_pool, need_full, _heads = op
+                _, s0, s1, mode, w, bias, o, relu, o_pool, need_full, _heads, _nm = op
                 oh, ow = hw(o)
                 check(h.sa_conv3x3_bf16(_ptr(bufs[s0.buf]), s0.cp, _ptr(bufs[s1.buf]) if s1 is not None else None,
                                         s1.cp if s1 is not None else 0, mode, _ptr(w), _ptr(bias), o.cp, relu, B, oh, ow,

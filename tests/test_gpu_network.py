@@ -282,7 +282,7 @@ def test_layerwise_vs_bf16_emulating_oracle():
             assert frac < 2e-3 and err <= 2.0 ** -7 * 1.01, (name, frac, err)
 
 
-@pytest.mark.parametrize("fuse", [dict(fuse_stem=False), dict(fuse_heads=False), dict(fuse_upsample=True),
+@pytest.mark.parametrize("fuse", [dict(fuse_stem=False), dict(use_stem16=False), dict(fuse_heads=False), dict(fuse_upsample=True),
                                   dict(fuse_stem=False, fuse_heads=False)])
 def test_fusion_variants_agree(fuse):
     """Every fusion switch of the engine computes the same network up to bf16 rounding flips: the fused stem
