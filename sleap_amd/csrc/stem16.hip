@@ -41,10 +41,12 @@ __global__ void __launch_bounds__(256)
 stem16_kernel(const Stem16Params p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int TH = SA_STEM16_TH, TW = SA_STEM16_TW, PH = TH + 2, PW = TW + 2, RH = TH + 4, RW = TW + 4;
-  // LDS: raw image tile as bf16 [RH][RW][CIN]; conv0 activation tile [PH*PW pixels][16 ch] bf16, 32 B per pixel,
-  // the two 16-byte halves of pixel pl swapped when (pl >> 3) & 1 (bank spreading for the ds_read_b128 of conv1)
+  // LDS: raw image tile as bf16 [RH][RW][CIN]; conv0 activation tile [PH*PW pixels][16 ch] bf16 with a pixel
+  // stride of 48 B (32 B data + 16 B pad): 3 sixteen-byte slots per pixel is odd, so the 16 pixels of a
+  // ds_read_b128 lane group fall on 16 distinct slots (conflict-free) and addresses stay base + immediate.
+  constexpr int APIX = 48;
   __shared__ __attribute__((aligned(16))) uint16_t raw[RH * RW * CIN + 8];
-  __shared__ __attribute__((aligned(16))) unsigned char act[PH * PW * 32];
+  __shared__ __attribute__((aligned(16))) unsigned char act[PH * PW * APIX];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n16 = lane & 15, kb = lane >> 4;
   int bid = blockIdx.x;
@@ -136,8 +138,7 @@ stem16_kernel(const Stem16Params p) {
       uint2 o;
       o.x = sa::f2bf2(v[0], v[1]);
       o.y = sa::f2bf2(v[2], v[3]);
-      const int piece = (kb >> 1) ^ ((pl >> 3) & 1);
-      *reinterpret_cast<uint2*>(act + pl * 32 + piece * 16 + (kb & 1) * 8) = o;
+      *reinterpret_cast<uint2*>(act + pl * APIX + kb * 8) = o;
     }
   }
   __syncthreads();
@@ -157,8 +158,7 @@ stem16_kernel(const Stem16Params p) {
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         const int pl = (wave * 4 + r + dy) * PW + h * 16 + n16 + dx;
-        const int piece = (kb & 1) ^ ((pl >> 3) & 1);
-        const mfma_bf16x8 bv = *reinterpret_cast<const mfma_bf16x8*>(act + pl * 32 + piece * 16);
+        const mfma_bf16x8 bv = *reinterpret_cast<const mfma_bf16x8*>(act + pl * APIX + (kb & 1) * 16);
         acc[r][h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[s], bv, acc[r][h], 0, 0, 0);
       }
   }
