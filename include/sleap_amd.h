@@ -109,7 +109,10 @@ int sa_paf_score(const float* pafs, int B, int Hp, int Wp, int E, const float* p
  *   match_score [B,E,max_node_peaks] f32 */
 int sa_paf_match(const float* line_scores, const int32_t* node_count, const int32_t* edges, int B,
                  int E, int N, int max_node_peaks, int32_t* match_dst, float* match_score,
-                 int32_t* status, sa_stream_t stream);
+                 int32_t* status, void* workspace, size_t ws_bytes, sa_stream_t stream);
+
+/* Bytes of device workspace sa_paf_match / sa_paf_group need (one buffer may serve both, sequentially). */
+size_t sa_paf_workspace(int B, int E, int N, int max_node_peaks);
 
 /* group_instances_sample = assign_connections_to_instances + make_predicted_instances
  * (paf_grouping.py:984-1112, 799-914, 917-981).
@@ -122,7 +125,7 @@ int sa_paf_group(const float* peak_xy, const float* peak_val, const int32_t* nod
                  int n_sorted, int B, int E, int N, int max_node_peaks, float min_line_scores,
                  int min_instance_peaks, int max_instances, float* instance_peaks,
                  float* instance_peak_vals, float* instance_scores, int32_t* n_instances,
-                 int32_t* status, sa_stream_t stream);
+                 int32_t* status, void* workspace, size_t ws_bytes, sa_stream_t stream);
 
 /* HOST-side Hungarian solve (same code as the device path; for tests / tooling).
  * cost [nr,nc] f64 row-major; row_ind/col_ind sized min(nr,nc). Returns #pairs or -1 if infeasible. */

@@ -19,17 +19,32 @@
 
 namespace sa {
 
-template <int MAXN>
+// Work arrays live wherever the caller puts them (host heap, device global workspace): the problem size is a
+// run-time value, the reference's ragged tensors have no upper bound on it.
 struct LsaWork {
-  double u[MAXN], v[MAXN], sp[MAXN];
-  int path[MAXN], col4row[MAXN], row4col[MAXN], remaining[MAXN];
-  bool SR[MAXN], SC[MAXN];
+  double *u, *v, *sp;
+  int *path, *col4row, *row4col, *remaining;
+  unsigned char *SR, *SC;
+  // bytes needed for an n x n (or smaller) problem, 8-byte aligned
+  SA_HD static inline unsigned long bytes(int n) { return (unsigned long)n * (3 * 8 + 4 * 4 + 2) + 16; }
+  SA_HD inline void bind(void* mem, int n) {
+    unsigned char* p = (unsigned char*)mem;
+    u = (double*)p;
+    v = u + n;
+    sp = v + n;
+    path = (int*)(sp + n);
+    col4row = path + n;
+    row4col = col4row + n;
+    remaining = row4col + n;
+    SR = (unsigned char*)(remaining + n);
+    SC = SR + n;
+  }
 };
 
 // cost(i, j) accessor returns the (possibly transposed) cost as double.
 // Solves for nr <= nc (caller transposes). Returns false if infeasible.
-template <int MAXN, typename CostFn>
-SA_HD inline bool lsa_solve(int nr, int nc, CostFn cost, LsaWork<MAXN>& w) {
+template <typename CostFn>
+SA_HD inline bool lsa_solve(int nr, int nc, CostFn cost, LsaWork& w) {
   const double INF = __builtin_huge_val();
   for (int i = 0; i < nr; ++i) {
     w.u[i] = 0.0;

@@ -11,13 +11,14 @@
 // TensorFlow CPU kernels the reference lowers to; this file is also compiled with
 // -ffp-contract=off.
 #include <cstdint>
+#include <vector>
 
 #include "lsa.h"
 #include "sa_common.h"
 
 namespace {
 
-constexpr int MAXNP = 128;  // compile-time cap on max_node_peaks (peaks of one node type per frame)
+constexpr int MAXNP = 512;  // cap on max_node_peaks (peaks of one node type per frame); bounds table sizes only
 constexpr int MAXNODES = 64;
 
 // ------------------------------------------------------------------------------------------------
@@ -409,7 +410,7 @@ __global__ void __launch_bounds__(64)
 paf_match_kernel(const float* __restrict__ line_scores, const int32_t* __restrict__ node_count,
                  const int32_t* __restrict__ edges, int B, int E, int N, int NP,
                  int32_t* __restrict__ match_dst, float* __restrict__ match_score,
-                 int32_t* __restrict__ status) {
+                 int32_t* __restrict__ status, unsigned char* __restrict__ workspace) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= B * E) return;
   const int b = t / E, k = t % E;
@@ -431,11 +432,12 @@ paf_match_kernel(const float* __restrict__ line_scores, const int32_t* __restric
         atomicOr(&status[b], SA_STATUS_LSA_INFEASIBLE);
         return;
       }
-  sa::LsaWork<MAXNP> w;
+  sa::LsaWork w;
+  w.bind(workspace + (size_t)t * sa::LsaWork::bytes(NP), NP);
   const bool tr = n_dst < n_src;
   CostView cv{sc, NP, tr};
   const int nr = tr ? n_dst : n_src, nc = tr ? n_src : n_dst;
-  if (!sa::lsa_solve<MAXNP>(nr, nc, cv, w)) {
+  if (!sa::lsa_solve(nr, nc, cv, w)) {
     atomicOr(&status[b], SA_STATUS_LSA_INFEASIBLE);
     return;
   }
@@ -459,9 +461,11 @@ paf_group_kernel(const float* __restrict__ peak_xy, const float* __restrict__ pe
                  float min_line_scores, int min_instance_peaks, int max_instances,
                  float* __restrict__ instance_peaks, float* __restrict__ instance_peak_vals,
                  float* __restrict__ instance_scores, int32_t* __restrict__ n_instances,
-                 int32_t* __restrict__ status) {
+                 int32_t* __restrict__ status, int32_t* __restrict__ workspace) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  int32_t* assign = reinterpret_cast<int32_t*>(smem_raw);  // [N*NP] instance id or -1
+  // tables live in LDS when they fit, otherwise in the caller's global workspace (3*N*NP+1 ints per frame)
+  int32_t* assign = workspace ? workspace + (size_t)blockIdx.x * (3 * (size_t)N * NP + 1)
+                              : reinterpret_cast<int32_t*>(smem_raw);  // [N*NP] instance id or -1
   int32_t* order = assign + N * NP;                        // [N*NP] peak ids in dict-insertion order
   int32_t* remap = order + N * NP;                         // [N*NP + 1] id -> contiguous index
   const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
@@ -662,6 +666,7 @@ int sa_paf_score(const float* pafs, int B, int Hp, int Wp, int E, const float* p
   SA_REQUIRE(max_node_peaks > 0 && max_node_peaks <= MAXNP, "sa_paf_score: max_node_peaks must be in [1,%d]", MAXNP);
   SA_REQUIRE(n_points >= 1, "sa_paf_score: n_points must be >= 1");
   const size_t lds = sizeof(int32_t) * ((size_t)N + (size_t)N * max_node_peaks);
+  SA_REQUIRE(lds <= 64 * 1024, "sa_paf_score: N * max_node_peaks too large for the LDS node tables");
   hipLaunchKernelGGL(paf_score_kernel, dim3(B), dim3(256), lds, (hipStream_t)stream, pafs, Hp, Wp, E,
                      peak_xy, peak_chan, peak_count, max_peaks, edges, N, n_points, pafs_stride,
                      max_edge_length, dist_penalty_weight, max_node_peaks, node_count, node_peaks,
@@ -670,14 +675,23 @@ int sa_paf_score(const float* pafs, int B, int Hp, int Wp, int E, const float* p
   return SA_OK;
 }
 
+size_t sa_paf_workspace(int B, int E, int N, int max_node_peaks) {
+  const size_t match = (size_t)B * E * sa::LsaWork::bytes(max_node_peaks);
+  const size_t group = (size_t)B * (3 * (size_t)N * max_node_peaks + 1) * sizeof(int32_t);
+  return (match > group ? match : group) + 64;
+}
+
 int sa_paf_match(const float* line_scores, const int32_t* node_count, const int32_t* edges, int B,
                  int E, int N, int max_node_peaks, int32_t* match_dst, float* match_score,
-                 int32_t* status, sa_stream_t stream) {
+                 int32_t* status, void* workspace, size_t ws_bytes, sa_stream_t stream) {
   SA_REQUIRE(max_node_peaks > 0 && max_node_peaks <= MAXNP, "sa_paf_match: max_node_peaks must be in [1,%d]", MAXNP);
   if (B * E == 0) return SA_OK;
+  if (!workspace || ws_bytes < (size_t)B * E * sa::LsaWork::bytes(max_node_peaks))
+    return sa::fail(SA_ERR_WORKSPACE, "sa_paf_match: workspace too small (see sa_paf_workspace)");
   const int nb = (B * E + 63) / 64;
   hipLaunchKernelGGL(paf_match_kernel, dim3(nb), dim3(64), 0, (hipStream_t)stream, line_scores,
-                     node_count, edges, B, E, N, max_node_peaks, match_dst, match_score, status);
+                     node_count, edges, B, E, N, max_node_peaks, match_dst, match_score, status,
+                     (unsigned char*)workspace);
   SA_LAUNCH_CHECK();
   return SA_OK;
 }
@@ -688,15 +702,22 @@ int sa_paf_group(const float* peak_xy, const float* peak_val, const int32_t* nod
                  int n_sorted, int B, int E, int N, int max_node_peaks, float min_line_scores,
                  int min_instance_peaks, int max_instances, float* instance_peaks,
                  float* instance_peak_vals, float* instance_scores, int32_t* n_instances,
-                 int32_t* status, sa_stream_t stream) {
+                 int32_t* status, void* workspace, size_t ws_bytes, sa_stream_t stream) {
   SA_REQUIRE(N > 0 && N <= MAXNODES && max_node_peaks > 0 && max_node_peaks <= MAXNP, "sa_paf_group: bad N/max_node_peaks");
   SA_REQUIRE(max_instances > 0, "sa_paf_group: max_instances must be > 0");
   const size_t nn = (size_t)N * max_node_peaks;
-  const size_t lds = sizeof(int32_t) * (3 * nn + 1);
+  size_t lds = sizeof(int32_t) * (3 * nn + 1);
+  int32_t* ws = nullptr;
+  if (lds > 48 * 1024) {  // tables too large for LDS: use the global workspace
+    if (!workspace || ws_bytes < (size_t)B * lds)
+      return sa::fail(SA_ERR_WORKSPACE, "sa_paf_group: workspace too small (see sa_paf_workspace)");
+    ws = (int32_t*)workspace;
+    lds = 0;
+  }
   hipLaunchKernelGGL(paf_group_kernel, dim3(B), dim3(64), lds, (hipStream_t)stream, peak_xy, peak_val,
                      node_count, node_peaks, max_peaks, match_dst, match_score, edges, sorted_edge_inds,
                      n_sorted, E, N, max_node_peaks, min_line_scores, min_instance_peaks, max_instances,
-                     instance_peaks, instance_peak_vals, instance_scores, n_instances, status);
+                     instance_peaks, instance_peak_vals, instance_scores, n_instances, status, ws);
   SA_LAUNCH_CHECK();
   return SA_OK;
 }
@@ -706,12 +727,15 @@ int sa_lsa_host(const double* cost, int nr, int nc, int64_t* row_ind, int64_t* c
   if (nr > 4096 || nc > 4096) return sa::fail(SA_ERR_INVALID_ARG, "sa_lsa_host: matrix too large");
   for (long i = 0; i < (long)nr * nc; ++i)
     if (cost[i] != cost[i] || cost[i] == -__builtin_huge_val()) return -1;
-  static thread_local sa::LsaWork<4096>* w = nullptr;
-  if (!w) w = new sa::LsaWork<4096>();
+  const int nmax = nr > nc ? nr : nc;
+  std::vector<unsigned char> mem(sa::LsaWork::bytes(nmax));
+  sa::LsaWork wk;
+  wk.bind(mem.data(), nmax);
+  sa::LsaWork* w = &wk;
   const bool tr = nc < nr;
   const int R = tr ? nc : nr, Cn = tr ? nr : nc;
   auto cf = [=](int i, int j) { return tr ? cost[(size_t)j * nc + i] : cost[(size_t)i * nc + j]; };
-  if (!sa::lsa_solve<4096>(R, Cn, cf, *w)) return -1;
+  if (!sa::lsa_solve(R, Cn, cf, *w)) return -1;
   if (!tr) {
     for (int i = 0; i < R; ++i) {
       row_ind[i] = i;

@@ -175,7 +175,7 @@ class InferenceModel:
 
     # hard limits of the device kernels (csrc/postproc.hip: MAXNP; sa_find_local_peaks: max_peaks <= 16384)
     _HARD_MAX_PEAKS = 16384
-    _HARD_MAX_NODE_PEAKS = 128
+    _HARD_MAX_NODE_PEAKS = 512
     _HARD_MAX_INSTANCES = 1024
 
     def call_checked(self, data):

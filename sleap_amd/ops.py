@@ -114,12 +114,26 @@ def paf_match(line_scores, node_count, edges, status):
     dev = line_scores.device
     match_dst = torch.empty((B, E, NP), dtype=torch.int32, device=dev)
     match_score = torch.empty((B, E, NP), dtype=torch.float32, device=dev)
+    ws = _paf_workspace(B, E, N, NP, dev)
     check(
         _lib.lib().sa_paf_match(_ptr(line_scores), _ptr(node_count), _ptr(edges), B, E, N, NP, _ptr(match_dst),
-                                _ptr(match_score), _ptr(status), _stream()),
+                                _ptr(match_score), _ptr(status), _ptr(ws), ws.numel(), _stream()),
         "sa_paf_match",
     )
     return match_dst, match_score
+
+
+_WS_CACHE = {}
+
+
+def _paf_workspace(B, E, N, NP, dev):
+    """One cached workspace per (shape, device): match and group run back to back on the same stream."""
+    key = (B, E, N, NP, str(dev))
+    if key not in _WS_CACHE:
+        if len(_WS_CACHE) > 8:
+            _WS_CACHE.clear()
+        _WS_CACHE[key] = torch.empty((_lib.lib().sa_paf_workspace(B, E, N, NP),), dtype=torch.uint8, device=dev)
+    return _WS_CACHE[key]
 
 
 def paf_group(peak_xy, peak_val, node_count, node_peaks, match_dst, match_score, edges, sorted_edge_inds,
@@ -132,12 +146,13 @@ def paf_group(peak_xy, peak_val, node_count, node_peaks, match_dst, match_score,
     vals = torch.empty((B, max_instances, N), dtype=torch.float32, device=dev)
     scores = torch.empty((B, max_instances), dtype=torch.float32, device=dev)
     n_inst = torch.empty((B,), dtype=torch.int32, device=dev)
+    ws = _paf_workspace(B, E, N, NP, dev)
     check(
         _lib.lib().sa_paf_group(_ptr(peak_xy), _ptr(peak_val), _ptr(node_count), _ptr(node_peaks), P,
                                 _ptr(match_dst), _ptr(match_score), _ptr(edges), _ptr(sorted_edge_inds),
                                 int(sorted_edge_inds.numel()), B, E, N, NP, float(min_line_scores),
                                 int(min_instance_peaks), int(max_instances), _ptr(inst), _ptr(vals), _ptr(scores),
-                                _ptr(n_inst), _ptr(status), _stream()),
+                                _ptr(n_inst), _ptr(status), _ptr(ws), ws.numel(), _stream()),
         "sa_paf_group",
     )
     return inst, vals, scores, n_inst

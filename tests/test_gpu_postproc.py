@@ -274,3 +274,26 @@ def test_matching_random_vs_scipy(pg):
         assert_array_equal(g[1][b], o[1][b])
         assert_array_equal(g[2][b], o[2][b])
         assert_array_equal(g[3][b], o[3][b])
+
+
+def test_hundreds_of_peaks_per_node_type(pf, pg):
+    """No fixed small cap: ~200 peaks per node type (tables in the global workspace instead of LDS/registers)."""
+    from sleap_amd import ops
+
+    rng = np.random.default_rng(9)
+    cms = rng.random((1, 64, 64, 3)).astype(np.float32)
+    pafs = rng.normal(0, 1, (1, 32, 32, 4)).astype(np.float32)
+    nodes, edges = ["a", "b", "c"], [("a", "b"), ("b", "c")]
+    o_pts, o_vals, o_si, o_ci = opf.find_local_peaks(cms, 0.93, "integral", 5)
+    assert 150 < np.bincount(o_ci).max() <= 512
+    o_pts = o_pts * np.float32(2)
+    osc = opg.PAFScorer(nodes, edges, 2, oob="zero")
+    o = osc.predict(pafs, [o_pts], [o_vals], [o_ci])
+    sc = pg.PAFScorer(nodes, edges, 2, max_node_peaks=512, max_instances=1024)
+    pxy, pval, pch, pcnt, st = ops.find_local_peaks(ops.to_cuda_f32(cms), None, 0.93, "integral", 5, 2.0, 2048)
+    inst, ivals, iscores, n_inst, st = sc.predict_padded(ops.to_cuda_f32(pafs), pxy, pval, pch, pcnt, st)
+    assert int(st.max().item()) & ~16 == 0
+    n = int(n_inst[0].item())
+    assert n == o[0][0].shape[0] and n > 50
+    assert_allclose(_n(inst)[0, :n], o[0][0], atol=1e-4, equal_nan=True)
+    assert_allclose(_n(iscores)[0, :n], o[2][0], atol=1e-4)
