@@ -82,6 +82,13 @@ int sa_find_global_peaks(const float* cms, const float* offsets, int B, int H, i
                          float threshold, int refinement, int patch_size, float xy_scale,
                          float* peak_xy, float* peak_val, sa_stream_t stream);
 
+/* crop_bboxes (peak_finding.py:135-190) for the top-down path (CentroidCrop, inference.py:1919-1929):
+ * tf.image.crop_and_resize(bilinear, extrapolation 0) of `crop` x `crop` boxes centred on fractional (x, y)
+ * centres (make_centered_bboxes, instance_cropping.py:124-166), cast back to the image dtype.
+ *   images [B,H,W,C] u8|f32; centres_xy [n,2] f32; sample_inds [n] i32; out [n,crop,crop,C] same dtype */
+int sa_crop_and_resize(const void* images, int is_u8, int H, int W, int C, const float* centres_xy,
+                       const int32_t* sample_inds, int n, int crop, void* out, sa_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * PAF grouping -- replaces sleap/nn/paf_grouping.py
  * ---------------------------------------------------------------------------------------------- */
@@ -209,6 +216,11 @@ int sa_upsample2x_bf16(const void* src, int B, int H, int W, int CP, int bilinea
  * act: 0 linear (all pose heads), 1 sigmoid (ClassMapsHead; identity heads are otherwise out of scope) */
 int sa_conv1x1_head(const void* src, int CinP, const float* w, const float* bias, int Cout, int act,
                     int B, int H, int W, float* dst, sa_stream_t stream);
+
+/* resize_image (data/resizing.py:71-105): tf.image.resize bilinear, half-pixel centres, no antialias, on the float
+ * image (InferenceLayer.preprocess applies ensure_float first). src [B,H,W,C] f32 -> dst [B,Ho,Wo,C] f32 */
+int sa_resize_bilinear_f32(const float* src, int B, int H, int W, int C, int Ho, int Wo, float* dst,
+                           sa_stream_t stream);
 
 /* dtype plumbing: f32 NHWC [.., C] <-> bf16 NHWC [.., CP] (zero padded) */
 int sa_f32_to_bf16_padded(const float* src, int n_pix, int C, int CP, void* dst, sa_stream_t stream);

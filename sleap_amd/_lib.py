@@ -32,6 +32,7 @@ SIGNATURES = {
     "sa_find_local_peaks_workspace": (_sz, [_i, _i]),
     "sa_find_local_peaks": (_i, [_p, _p, _i, _i, _i, _i, _f, _i, _i, _f, _i, _p, _p, _p, _p, _p, _p, _sz, _p]),
     "sa_find_global_peaks": (_i, [_p, _p, _i, _i, _i, _i, _f, _i, _i, _f, _p, _p, _p]),
+    "sa_crop_and_resize": (_i, [_p, _i, _i, _i, _i, _p, _p, _i, _i, _p, _p]),
     "sa_paf_score": (_i, [_p, _i, _i, _i, _i, _p, _p, _p, _i, _p, _i, _i, _f, _f, _f, _i, _p, _p, _p, _p, _p]),
     "sa_paf_match": (_i, [_p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _sz, _p]),
     "sa_paf_workspace": (_sz, [_i, _i, _i, _i]),
@@ -50,6 +51,7 @@ SIGNATURES = {
     "sa_maxpool2x2_bf16": (_i, [_p, _i, _i, _i, _i, _p, _p]),
     "sa_upsample2x_bf16": (_i, [_p, _i, _i, _i, _i, _i, _p, _p]),
     "sa_conv1x1_head": (_i, [_p, _i, _p, _p, _i, _i, _i, _i, _i, _p, _p]),
+    "sa_resize_bilinear_f32": (_i, [_p, _i, _i, _i, _i, _i, _i, _p, _p]),
     "sa_f32_to_bf16_padded": (_i, [_p, _i, _i, _i, _p, _p]),
     "sa_bf16_to_f32": (_i, [_p, _i, _i, _i, _p, _p]),
 }

@@ -207,6 +207,33 @@ convt3x3s2_kernel(const uint16_t* __restrict__ src, int CinP, const uint16_t* __
   }
 }
 
+// tf.image.resize(method="bilinear", antialias=False) with half-pixel centres (resizing.py:97-103):
+// src = (dst + 0.5) * in/out - 0.5; taps clamp to the image; value = top + (bottom - top) * ylerp.
+__global__ void __launch_bounds__(256)
+resize_bilinear_f32_kernel(const float* __restrict__ src, int B, int H, int W, int C, int Ho, int Wo,
+                           float* __restrict__ dst) {
+  const float sy = (float)H / (float)Ho, sx = (float)W / (float)Wo;
+  const size_t total = (size_t)B * Ho * Wo * C;
+  for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(t % C);
+    size_t p = t / C;
+    const int x = (int)(p % Wo);
+    p /= Wo;
+    const int y = (int)(p % Ho);
+    const size_t b = p / Ho;
+    const float fy = ((float)y + 0.5f) * sy - 0.5f, fx = ((float)x + 0.5f) * sx - 0.5f;
+    const float fly = floorf(fy), flx = floorf(fx);
+    const int y0 = max((int)fly, 0), y1 = min((int)ceilf(fy), H - 1);
+    const int x0 = max((int)flx, 0), x1 = min((int)ceilf(fx), W - 1);
+    const float ly = fy - fly, lx = fx - flx;
+    const float* im = src + b * H * W * C + c;
+    const float tl = im[((size_t)y0 * W + x0) * C], tr = im[((size_t)y0 * W + x1) * C];
+    const float bl = im[((size_t)y1 * W + x0) * C], br = im[((size_t)y1 * W + x1) * C];
+    const float top = tl + (tr - tl) * lx, bot = bl + (br - bl) * lx;
+    dst[t] = top + (bot - top) * ly;
+  }
+}
+
 __global__ void f32_to_bf16_padded_kernel(const float* __restrict__ src, size_t n_pix, int C, int CP,
                                           uint16_t* __restrict__ dst) {
   const size_t total = n_pix * CP;
@@ -299,6 +326,15 @@ int sa_convt3x3s2_bf16(const void* src, int CinP, const void* w, const float* bi
   const size_t total = (size_t)B * 4 * H * W * CoutP;
   hipLaunchKernelGGL(convt3x3s2_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
                      (const uint16_t*)src, CinP, (const uint16_t*)w, bias, CoutP, relu, B, H, W, (uint16_t*)dst);
+  SA_LAUNCH_CHECK();
+  return SA_OK;
+}
+
+int sa_resize_bilinear_f32(const float* src, int B, int H, int W, int C, int Ho, int Wo, float* dst,
+                           sa_stream_t stream) {
+  SA_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && Ho > 0 && Wo > 0, "sa_resize_bilinear_f32: bad shape");
+  hipLaunchKernelGGL(resize_bilinear_f32_kernel, dim3(grid_for((size_t)B * Ho * Wo * C)), dim3(256), 0,
+                     (hipStream_t)stream, src, B, H, W, C, Ho, Wo, dst);
   SA_LAUNCH_CHECK();
   return SA_OK;
 }

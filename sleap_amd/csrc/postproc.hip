@@ -295,6 +295,66 @@ global_peaks_kernel(const float* __restrict__ cms, const float* __restrict__ off
 }
 
 // ------------------------------------------------------------------------------------------------
+// Instance crops for the top-down path: crop_bboxes (peak_finding.py:135-190) = tf.image.crop_and_resize
+// (bilinear, extrapolation 0) of crop x crop boxes centred on FRACTIONAL centroids
+// (make_centered_bboxes, instance_cropping.py:124-166), result cast back to the image dtype.
+// Same float32 op sequence as the TF CPU kernel (normalised boxes, scale, floor/ceil/lerp).
+// ------------------------------------------------------------------------------------------------
+struct CropCoord {
+  int lo, hi;
+  float lerp;
+  bool ok;
+};
+
+__device__ __forceinline__ CropCoord crop_coord(float centre, int k, int i, int size) {
+  const float b1 = __fadd_rn(centre, __fmul_rn((float)(-k + 1), 0.5f));
+  const float b2 = __fadd_rn(centre, __fmul_rn((float)(k - 1), 0.5f));
+  const float sm1 = __fsub_rn((float)size, 1.0f);
+  const float n1 = __fdiv_rn(b1, sm1), n2 = __fdiv_rn(b2, sm1);
+  float in;
+  if (k > 1) {
+    const float scale = __fdiv_rn(__fmul_rn(__fsub_rn(n2, n1), sm1), (float)(k - 1));
+    in = __fadd_rn(__fmul_rn(n1, sm1), __fmul_rn((float)i, scale));
+  } else {
+    in = __fmul_rn(__fmul_rn(0.5f, __fadd_rn(n1, n2)), sm1);
+  }
+  CropCoord a;
+  a.ok = !(in < 0.0f || in > sm1);  // NaN centroids compare false twice -> "ok", handled by the caller's mask
+  const float fl = floorf(in), ce = ceilf(in);
+  a.lerp = __fsub_rn(in, fl);
+  a.lo = min(max((int)fl, 0), size - 1);
+  a.hi = min(max((int)ce, 0), size - 1);
+  return a;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+crop_and_resize_kernel(const T* __restrict__ images, int H, int W, int C, const float* __restrict__ centres_xy,
+                       const int32_t* __restrict__ sample_inds, int n, int crop, T* __restrict__ out) {
+  const size_t total = (size_t)n * crop * crop;
+  for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
+    const int xx = (int)(t % crop);
+    const int yy = (int)((t / crop) % crop);
+    const int i = (int)(t / ((size_t)crop * crop));
+    const float cx = centres_xy[2 * i], cy = centres_xy[2 * i + 1];
+    const CropCoord ay = crop_coord(cy, crop, yy, H), ax = crop_coord(cx, crop, xx, W);
+    const T* img = images + (size_t)sample_inds[i] * H * W * C;
+    T* o = out + t * C;
+    for (int c = 0; c < C; ++c) {
+      float v = 0.0f;
+      if (ay.ok && ax.ok) {
+        const float tl = (float)img[((size_t)ay.lo * W + ax.lo) * C + c], tr = (float)img[((size_t)ay.lo * W + ax.hi) * C + c];
+        const float bl = (float)img[((size_t)ay.hi * W + ax.lo) * C + c], br = (float)img[((size_t)ay.hi * W + ax.hi) * C + c];
+        const float top = __fadd_rn(tl, __fmul_rn(__fsub_rn(tr, tl), ax.lerp));
+        const float bot = __fadd_rn(bl, __fmul_rn(__fsub_rn(br, bl), ax.lerp));
+        v = __fadd_rn(top, __fmul_rn(__fsub_rn(bot, top), ay.lerp));
+      }
+      o[c] = (T)v;  // tf.cast(crops, images.dtype): truncation for uint8
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // PAF scoring
 // ------------------------------------------------------------------------------------------------
 
@@ -652,6 +712,23 @@ int sa_find_global_peaks(const float* cms, const float* offsets, int B, int H, i
   SA_REQUIRE(refinement != SA_REFINE_OFFSETS || offsets, "sa_find_global_peaks: offsets is NULL");
   hipLaunchKernelGGL(global_peaks_kernel, dim3(C, B), dim3(256), 0, (hipStream_t)stream, cms, offsets,
                      H, W, C, threshold, refinement, patch_size, xy_scale, peak_xy, peak_val);
+  SA_LAUNCH_CHECK();
+  return SA_OK;
+}
+
+int sa_crop_and_resize(const void* images, int is_u8, int H, int W, int C, const float* centres_xy,
+                       const int32_t* sample_inds, int n, int crop, void* out, sa_stream_t stream) {
+  SA_REQUIRE(H > 1 && W > 1 && C > 0 && crop > 0 && n >= 0, "sa_crop_and_resize: bad shape");
+  if (n == 0) return SA_OK;
+  const size_t total = (size_t)n * crop * crop;
+  int g = (int)((total + 255) / 256);
+  if (g > 4096) g = 4096;
+  if (is_u8)
+    hipLaunchKernelGGL((crop_and_resize_kernel<uint8_t>), dim3(g), dim3(256), 0, (hipStream_t)stream,
+                       (const uint8_t*)images, H, W, C, centres_xy, sample_inds, n, crop, (uint8_t*)out);
+  else
+    hipLaunchKernelGGL((crop_and_resize_kernel<float>), dim3(g), dim3(256), 0, (hipStream_t)stream,
+                       (const float*)images, H, W, C, centres_xy, sample_inds, n, crop, (float*)out);
   SA_LAUNCH_CHECK();
   return SA_OK;
 }

@@ -124,13 +124,15 @@ def _ensure_rgb(x):
 
 def _resize_image(x, scale):
     """resizing.py:71-105: bilinear, half-pixel centres, no antialias; size = int(dim * scale)."""
-    H, W = x.shape[1], x.shape[2]
+    B, H, W, Cc = x.shape
     nh, nw = int(H * scale), int(W * scale)
-    y = torch.nn.functional.interpolate(x.to(torch.float32).permute(0, 3, 1, 2), size=(nh, nw), mode="bilinear",
-                                        align_corners=False, antialias=False).permute(0, 2, 3, 1)
-    if x.dtype == torch.uint8:
-        return y.to(torch.uint8).contiguous()
-    return y.contiguous()
+    xf = x.to(torch.float32).contiguous()
+    y = torch.empty((B, nh, nw, Cc), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().sa_resize_bilinear_f32(ops._ptr(xf), B, H, W, Cc, nh, nw, ops._ptr(y), ops._stream()),
+               "sa_resize_bilinear_f32")
+    if x.dtype == torch.uint8:  # tf.cast back to the input dtype truncates
+        return y.to(torch.uint8)
+    return y
 
 
 def _pad_to_stride(x, max_stride):
@@ -339,6 +341,268 @@ class BottomUpInferenceModel(InferenceModel):
 
 
 # ----------------------------------------------------------------------------------------------------
+# Single-instance and top-down layers
+# ----------------------------------------------------------------------------------------------------
+def _heads(net, confmaps_name, confmaps_ind, offsets_ind):
+    if confmaps_ind is None:
+        confmaps_ind = find_head(net, confmaps_name)
+    if confmaps_ind is None:
+        raise ValueError(f"Index of the confidence maps output tensor must be specified if not named '{confmaps_name}'.")
+    if offsets_ind is None:
+        offsets_ind = find_head(net, "OffsetRefinementHead")
+    return confmaps_ind, offsets_ind
+
+
+def _pad_ragged(flat, sample_inds, n_samples, fill=float("nan")):
+    """flat (n, ...) + sample index per row (sample-major order) -> (B, Imax, ...) padded tensor, counts (B,)."""
+    counts = torch.bincount(sample_inds.to(torch.int64), minlength=n_samples)
+    imax = int(counts.max().item()) if flat.shape[0] else 0
+    out = torch.full((n_samples, imax) + tuple(flat.shape[1:]), fill, dtype=flat.dtype, device=flat.device)
+    if flat.shape[0]:
+        start = torch.cumsum(counts, 0) - counts
+        pos = torch.arange(flat.shape[0], device=flat.device) - start[sample_inds.to(torch.int64)]
+        out[sample_inds.to(torch.int64), pos] = flat
+    return out, counts.to(torch.int32)
+
+
+class SingleInstanceInferenceLayer(InferenceLayer):
+    """inference.py:1229-1380: network -> global peak per channel -> (B, 1, N, 2)."""
+
+    def __init__(self, keras_model, input_scale: float = 1.0, pad_to_stride: int = 1, output_stride: Optional[int] = None,
+                 peak_threshold: float = 0.2, refinement: Optional[str] = "local", integral_patch_size: int = 5,
+                 return_confmaps: bool = False, confmaps_ind: Optional[int] = None, offsets_ind: Optional[int] = None,
+                 **kwargs):
+        super().__init__(keras_model=keras_model, input_scale=input_scale, pad_to_stride=pad_to_stride, **kwargs)
+        self.confmaps_ind, self.offsets_ind = _heads(keras_model, "SingleInstanceConfmapsHead", confmaps_ind, offsets_ind)
+        if output_stride is None:
+            output_stride = get_model_output_stride(keras_model, output_ind=self.confmaps_ind)
+        self.output_stride = output_stride
+        self.peak_threshold = peak_threshold
+        self.refinement = refinement
+        self.integral_patch_size = integral_patch_size
+        self.return_confmaps = return_confmaps
+
+    def call(self, data):
+        imgs = self.preprocess(data)
+        preds = self.keras_model.forward(imgs)
+        cms = preds[self.confmaps_ind]
+        offsets = preds[self.offsets_ind] if self.offsets_ind is not None else None
+        refinement = self.refinement if self.refinement in ("integral", "local") else None
+        peaks, vals = ops.find_global_peaks(cms, offsets, self.peak_threshold, refinement, self.integral_patch_size,
+                                            float(self.output_stride))
+        if self.input_scale != 1.0:
+            peaks = (peaks / np.float32(self.input_scale)) + np.float32(0.5)
+        out = {"instance_peaks": peaks[:, None], "instance_peak_vals": vals[:, None]}
+        if self.return_confmaps:
+            out["confmaps"] = cms
+        return out
+
+    __call__ = call
+
+
+class SingleInstanceInferenceModel(InferenceModel):
+    """inference.py:1383-1412."""
+
+    def __init__(self, single_instance_layer, **kwargs):
+        self.single_instance_layer = single_instance_layer
+
+    def call(self, example):
+        return self.single_instance_layer(example)
+
+    def call_checked(self, data):
+        return self.call(data)
+
+    def predict(self, data, numpy: bool = True, batch_size: int = 4, **kwargs):
+        imgs = data["image"] if isinstance(data, dict) else data
+        parts = [self.call(imgs[i : i + batch_size]) for i in range(0, len(imgs), batch_size)]
+        outs = {k: torch.cat([p[k].clone() for p in parts], dim=0) for k in parts[0]}
+        return {k: v.cpu().numpy() for k, v in outs.items()} if numpy else outs
+
+    def predict_on_batch(self, data, numpy: bool = False, **kwargs):
+        outs = self.call(data)
+        return {k: v.cpu().numpy() for k, v in outs.items()} if numpy else outs
+
+
+class CentroidCrop(InferenceLayer):
+    """inference.py:1638-1966: centroid network -> local peaks -> crops of the UN-preprocessed full image."""
+
+    def __init__(self, keras_model, crop_size: int, input_scale: float = 1.0, pad_to_stride: int = 1,
+                 output_stride: Optional[int] = None, peak_threshold: float = 0.2, refinement: Optional[str] = "local",
+                 integral_patch_size: int = 5, return_confmaps: bool = False, confmaps_ind: Optional[int] = None,
+                 offsets_ind: Optional[int] = None, return_crops: bool = True, max_instances: Optional[int] = None,
+                 precrop_resize: float = 1.0, max_peaks: int = 512, **kwargs):
+        super().__init__(keras_model=keras_model, input_scale=input_scale, pad_to_stride=pad_to_stride, **kwargs)
+        self.crop_size = crop_size
+        self.confmaps_ind, self.offsets_ind = _heads(keras_model, "CentroidConfmapsHead", confmaps_ind, offsets_ind)
+        if output_stride is None:
+            output_stride = get_model_output_stride(keras_model, output_ind=self.confmaps_ind)
+        self.output_stride = output_stride
+        self.peak_threshold = peak_threshold
+        self.refinement = refinement
+        self.integral_patch_size = integral_patch_size
+        self.return_confmaps = return_confmaps
+        self.return_crops = return_crops
+        self.max_instances = max_instances
+        self.precrop_resize = precrop_resize
+        self.max_peaks = max_peaks
+
+    def call(self, inputs):
+        full_imgs = _as_device_images(inputs)
+        imgs = self.preprocess(full_imgs)
+        out = self.keras_model.forward(imgs)
+        cms = out[self.confmaps_ind]
+        offsets = out[self.offsets_ind] if self.offsets_ind is not None else None
+        B = cms.shape[0]
+        refinement = self.refinement if self.refinement in ("integral", "local") else None
+        while True:
+            pxy, pval, pch, pcnt, status = ops.find_local_peaks(cms, offsets, self.peak_threshold, refinement,
+                                                                self.integral_patch_size, float(self.output_stride),
+                                                                self.max_peaks)
+            if not (int(status.max().item()) & _lib.STATUS_PEAK_OVERFLOW) or self.max_peaks >= 16384:
+                break
+            self.max_peaks *= 2
+        P = pval.shape[1]
+        mask = torch.arange(P, device=pval.device)[None, :] < pcnt[:, None]
+        sample_inds = torch.arange(B, device=pval.device, dtype=torch.int32)[:, None].expand(B, P)[mask]
+        pts, vals = pxy[mask], pval[mask]
+        if self.input_scale != 1.0:
+            pts = (pts / np.float32(self.input_scale)) + np.float32(0.5)
+        if self.precrop_resize != 1.0:
+            full_imgs = _resize_image(full_imgs, self.precrop_resize)
+            pts = pts * np.float32(self.precrop_resize)
+        if pts.shape[0] > 0 and self.max_instances is not None:
+            keep = []
+            for b in range(B):  # tf.math.top_k per sample (:1850-1916)
+                sel = torch.nonzero(sample_inds == b).reshape(-1)
+                if self.max_instances < sel.numel():
+                    order = torch.sort(vals[sel], descending=True, stable=True).indices[: self.max_instances]
+                    sel = sel[order]
+                keep.append(sel)
+            keep = torch.cat(keep)
+            pts, vals, sample_inds = pts[keep], vals[keep], sample_inds[keep]
+        crop_offsets = pts - np.float32(self.crop_size / 2)
+        crops = ops.crop_and_resize(full_imgs, pts, sample_inds, self.crop_size)
+        outputs = dict(centroids=pts, centroid_vals=vals, crop_sample_inds=sample_inds, samples=B)
+        if self.return_confmaps:
+            outputs["centroid_confmaps"] = cms
+        if self.return_crops:
+            outputs["crops"] = crops
+            outputs["crop_offsets"] = crop_offsets
+        return outputs
+
+    __call__ = call
+
+
+class FindInstancePeaks(InferenceLayer):
+    """inference.py:1969-2200: centered-instance network on crops -> global peak per channel, shifted by the crop
+    offsets back into full-image coordinates."""
+
+    def __init__(self, keras_model, input_scale: float = 1.0, output_stride: Optional[int] = None,
+                 peak_threshold: float = 0.2, refinement: Optional[str] = "local", integral_patch_size: int = 5,
+                 return_confmaps: bool = False, confmaps_ind: Optional[int] = None, offsets_ind: Optional[int] = None,
+                 resize_input_image: bool = True, **kwargs):
+        super().__init__(keras_model=keras_model, input_scale=input_scale, pad_to_stride=1, **kwargs)
+        self.confmaps_ind, self.offsets_ind = _heads(keras_model, "CenteredInstanceConfmapsHead", confmaps_ind, offsets_ind)
+        if output_stride is None:
+            output_stride = get_model_output_stride(keras_model, output_ind=self.confmaps_ind)
+        self.output_stride = output_stride
+        self.peak_threshold = peak_threshold
+        self.refinement = refinement
+        self.integral_patch_size = integral_patch_size
+        self.return_confmaps = return_confmaps
+        self.resize_input_image = resize_input_image
+
+    def call(self, inputs):
+        if isinstance(inputs, dict):
+            crops = inputs["crops"]
+        else:
+            crops, inputs = inputs, {}
+        crops = _as_device_images(crops) if not isinstance(crops, torch.Tensor) or not crops.is_cuda else crops
+        n = crops.shape[0]
+        if "crop_sample_inds" in inputs:
+            samples, crop_sample_inds = inputs["samples"], inputs["crop_sample_inds"]
+        else:
+            samples, crop_sample_inds = n, torch.arange(n, dtype=torch.int32, device=crops.device)
+        n_nodes = self.keras_model.outputs[self.confmaps_ind].c
+        if n == 0:
+            peak_points = torch.zeros((0, n_nodes, 2), dtype=torch.float32, device=crops.device)
+            peak_vals = torch.zeros((0, n_nodes), dtype=torch.float32, device=crops.device)
+        else:
+            x = self.preprocess(crops, resize_img=self.resize_input_image)
+            out = self.keras_model.forward(x)
+            cms = out[self.confmaps_ind]
+            offsets = out[self.offsets_ind] if self.offsets_ind is not None else None
+            refinement = self.refinement if self.refinement in ("integral", "local") else None
+            peak_points, peak_vals = ops.find_global_peaks(cms, offsets, self.peak_threshold, refinement,
+                                                           self.integral_patch_size, float(self.output_stride))
+            if self.input_scale != 1.0:
+                peak_points = (peak_points / np.float32(self.input_scale)) + np.float32(0.5)
+            if "crop_offsets" in inputs:
+                peak_points = peak_points + (inputs["crop_offsets"][:, None, :] / np.float32(self.input_scale))
+        peaks, counts = _pad_ragged(peak_points, crop_sample_inds, samples)
+        vals, _ = _pad_ragged(peak_vals, crop_sample_inds, samples)
+        outputs = {"instance_peaks": peaks, "instance_peak_vals": vals, "n_valid": counts}
+        if "centroids" in inputs:
+            outputs["centroids"], _ = _pad_ragged(inputs["centroids"], crop_sample_inds, samples)
+            outputs["centroid_vals"], _ = _pad_ragged(inputs["centroid_vals"], crop_sample_inds, samples)
+        if "centroid_confmaps" in inputs:
+            outputs["centroid_confmaps"] = inputs["centroid_confmaps"]
+        return outputs
+
+    __call__ = call
+
+
+class TopDownInferenceModel(InferenceModel):
+    """inference.py:2246-2311."""
+
+    def __init__(self, centroid_crop: CentroidCrop, instance_peaks: FindInstancePeaks, **kwargs):
+        self.centroid_crop = centroid_crop
+        self.instance_peaks = instance_peaks
+
+    def call(self, example):
+        return self.instance_peaks(self.centroid_crop(example))
+
+    def call_checked(self, data):
+        return self.call(data)
+
+    @staticmethod
+    def _to_numpy(outs):
+        return {k: (v.cpu().numpy() if isinstance(v, torch.Tensor) else v) for k, v in outs.items()}
+
+    def predict_on_batch(self, data, numpy: bool = False, **kwargs):
+        outs = self.call(data)
+        if not numpy:
+            return outs
+        res = self._to_numpy(outs)
+        res["n_valid"] = res["n_valid"].astype(np.int64)
+        return res
+
+    def predict(self, data, numpy: bool = True, batch_size: int = 4, **kwargs):
+        imgs = data["image"] if isinstance(data, dict) else data
+        parts = [self.call(imgs[i : i + batch_size]) for i in range(0, len(imgs), batch_size)]
+        imax = max(p["instance_peaks"].shape[1] for p in parts)
+        keys = [k for k in ("instance_peaks", "instance_peak_vals", "centroids", "centroid_vals") if k in parts[0]]
+        outs = {}
+        for k in keys:
+            padded = []
+            for p in parts:
+                v = p[k]
+                if v.shape[1] < imax:
+                    pad = torch.full((v.shape[0], imax - v.shape[1]) + tuple(v.shape[2:]), float("nan"), dtype=v.dtype,
+                                     device=v.device)
+                    v = torch.cat([v, pad], dim=1)
+                padded.append(v)
+            outs[k] = torch.cat(padded, dim=0)
+        outs["n_valid"] = torch.cat([p["n_valid"] for p in parts], dim=0)
+        return self.predict_on_batch_to_numpy(outs) if numpy else outs
+
+    def predict_on_batch_to_numpy(self, outs):
+        res = self._to_numpy(outs)
+        res["n_valid"] = res["n_valid"].astype(np.int64)
+        return res
+
+
+# ----------------------------------------------------------------------------------------------------
 # Predictors
 # ----------------------------------------------------------------------------------------------------
 class Predictor:
@@ -358,7 +622,19 @@ class Predictor:
         model_configs = [model_io.load_training_config(p) for p in model_paths]
         model_paths = [model_io.model_dir(p) for p in model_paths]
         model_types = [model_io.head_type(c) for c in model_configs]
-        if "multi_instance" in model_types:
+        if "single_instance" in model_types:
+            predictor = SingleInstancePredictor.from_trained_models(
+                model_paths[model_types.index("single_instance")], peak_threshold=peak_threshold,
+                integral_refinement=integral_refinement, integral_patch_size=integral_patch_size,
+                batch_size=batch_size, resize_input_layer=resize_input_layer)
+        elif "centroid" in model_types and "centered_instance" in model_types:
+            predictor = TopDownPredictor.from_trained_models(
+                centroid_model_path=model_paths[model_types.index("centroid")],
+                confmap_model_path=model_paths[model_types.index("centered_instance")],
+                peak_threshold=peak_threshold, integral_refinement=integral_refinement,
+                integral_patch_size=integral_patch_size, batch_size=batch_size,
+                resize_input_layer=resize_input_layer, max_instances=max_instances)
+        elif "multi_instance" in model_types:
             i = model_types.index("multi_instance")
             predictor = BottomUpPredictor.from_trained_models(
                 model_paths[i], peak_threshold=peak_threshold, integral_refinement=integral_refinement,
@@ -366,13 +642,187 @@ class Predictor:
                 resize_input_layer=resize_input_layer, max_instances=max_instances)
         else:
             raise ValueError("Could not create predictor from model paths:" + "\n".join(model_paths)
-                             + f"\n(model types {model_types}: only bottom-up 'multi_instance' models run on this path)")
+                             + f"\n(model types {model_types}: implemented are single_instance, centroid + "
+                               "centered_instance (top-down) and multi_instance (bottom-up); ground-truth-centroid "
+                               "variants, multi-class and MoveNet models are out of scope)")
         predictor.model_paths = model_paths
         return predictor
 
     @property
     def is_grayscale(self) -> bool:
-        return self.inference_model.bottomup_layer.keras_model.in_channels == 1
+        return self._input_network().in_channels == 1
+
+    def _input_network(self):
+        return self.inference_model.bottomup_layer.keras_model
+
+    # -- generic batch loop (single-instance / top-down); BottomUpPredictor overrides it with the packed all-gather
+    def _frames_of(self, data):
+        if isinstance(data, (np.ndarray, torch.Tensor)):
+            return data[None] if data.ndim == 3 else data
+        if hasattr(data, "__len__") and hasattr(data, "__getitem__"):
+            return data
+        raise TypeError(f"unsupported data type for predict(): {type(data)}")
+
+    def _predict_generator(self, data):
+        """inference.py:377-494. Under torch.distributed each rank predicts its contiguous slice of the batch and
+        the (small, ragged) NumPy results are exchanged with one all_gather_object."""
+        import torch.distributed as dist
+
+        frames = self._frames_of(data)
+        n = len(frames)
+        rank, world = parallel.rank_world()
+        for i0 in range(0, n, self.batch_size):
+            i1 = min(i0 + self.batch_size, n)
+            lo, hi = parallel.shard_range(i0, i1, rank, world)
+            ex = self.inference_model.predict_on_batch(frames[lo:hi], numpy=True) if hi > lo else None
+            if world > 1:
+                parts = [None] * world
+                dist.all_gather_object(parts, ex)
+                parts = [p for p in parts if p is not None]
+                imax = max(p["instance_peaks"].shape[1] for p in parts)
+                ex = {}
+                for k in parts[0]:
+                    vs = []
+                    for p in parts:
+                        v = p[k]
+                        if v.ndim >= 2 and k != "n_valid" and v.shape[1] < imax:
+                            pad = np.full((v.shape[0], imax - v.shape[1]) + v.shape[2:], np.nan, v.dtype)
+                            v = np.concatenate([v, pad], axis=1)
+                        vs.append(v)
+                    ex[k] = np.concatenate(vs, axis=0)
+            ex["video_ind"] = np.zeros((i1 - i0,), np.int64)
+            ex["frame_ind"] = np.arange(i0, i1, dtype=np.int64)
+            ex["scale"] = np.ones((i1 - i0, 2), np.float32)
+            yield ex
+
+    def predict(self, data, make_labels: bool = True):
+        """inference.py:496-531 (see BottomUpPredictor.predict for the output contract)."""
+        if make_labels:
+            raise ImportError("predict(make_labels=True) builds sleap.Labels with the reference's own classes, which is "
+                              "only wired up for the bottom-up predictor here; call predict(data, make_labels=False)")
+        return list(self._predict_generator(data))
+
+
+class SingleInstancePredictor(Predictor):
+    """inference.py:1415-1635."""
+
+    def __init__(self, confmap_config: dict, confmap_model: DeviceNetwork, inference_model=None, peak_threshold: float = 0.2,
+                 integral_refinement: bool = True, integral_patch_size: int = 5, batch_size: int = 4,
+                 verbosity: str = "none", report_rate: float = 2.0, model_paths=None):
+        self.confmap_config = confmap_config
+        self.confmap_model = confmap_model
+        self.peak_threshold = peak_threshold
+        self.integral_refinement = integral_refinement
+        self.integral_patch_size = integral_patch_size
+        self.batch_size = batch_size
+        self.verbosity, self.report_rate, self.model_paths = verbosity, report_rate, model_paths or []
+        self.tracker = None
+        self._initialize_inference_model()
+
+    def _initialize_inference_model(self):
+        """inference.py:1456-1468."""
+        cfg = self.confmap_config
+        self.inference_model = SingleInstanceInferenceModel(
+            SingleInstanceInferenceLayer(
+                keras_model=self.confmap_model,
+                input_scale=cfg["data"]["preprocessing"].get("input_scaling", 1.0),
+                pad_to_stride=model_io.maximum_stride(cfg),
+                peak_threshold=self.peak_threshold,
+                refinement="integral" if self.integral_refinement else "local",
+                integral_patch_size=self.integral_patch_size,
+                output_stride=cfg["model"]["heads"]["single_instance"]["output_stride"]))
+
+    def _input_network(self):
+        return self.confmap_model
+
+    @property
+    def data_config(self):
+        return self.confmap_config["data"]
+
+    @classmethod
+    def from_trained_models(cls, model_path: str, peak_threshold: float = 0.2, integral_refinement: bool = True,
+                            integral_patch_size: int = 5, batch_size: int = 4, resize_input_layer: bool = True):
+        """inference.py:1479-1529."""
+        cfg = model_io.load_training_config(model_path)
+        mc, weights = model_io.load_keras_model(model_io.model_dir(model_path))
+        obj = cls(confmap_config=cfg, confmap_model=DeviceNetwork(mc, weights), peak_threshold=peak_threshold,
+                  integral_refinement=integral_refinement, integral_patch_size=integral_patch_size, batch_size=batch_size)
+        obj.model_paths = [model_io.model_dir(model_path)]
+        return obj
+
+
+class TopDownPredictor(Predictor):
+    """inference.py:2314-2734 (both models given; ground-truth centroid / peak variants are out of scope)."""
+
+    def __init__(self, centroid_config: dict, centroid_model: DeviceNetwork, confmap_config: dict,
+                 confmap_model: DeviceNetwork, inference_model=None, peak_threshold: float = 0.2, batch_size: int = 4,
+                 integral_refinement: bool = True, integral_patch_size: int = 5, max_instances: Optional[int] = None,
+                 verbosity: str = "none", report_rate: float = 2.0, model_paths=None):
+        self.centroid_config, self.centroid_model = centroid_config, centroid_model
+        self.confmap_config, self.confmap_model = confmap_config, confmap_model
+        self.peak_threshold = peak_threshold
+        self.batch_size = batch_size
+        self.integral_refinement = integral_refinement
+        self.integral_patch_size = integral_patch_size
+        self.max_instances = max_instances
+        self.verbosity, self.report_rate, self.model_paths = verbosity, report_rate, model_paths or []
+        self.tracker = None
+        self._initialize_inference_model()
+
+    def _initialize_inference_model(self):
+        """inference.py:2373-2424."""
+        ccfg, icfg = self.centroid_config, self.confmap_config
+        pad = ccfg["data"]["preprocessing"].get("pad_to_stride") or model_io.maximum_stride(ccfg)
+        centroid_crop_layer = CentroidCrop(
+            keras_model=self.centroid_model,
+            crop_size=icfg["data"]["instance_cropping"]["crop_size"],
+            input_scale=ccfg["data"]["preprocessing"].get("input_scaling", 1.0),
+            precrop_resize=1.0,
+            pad_to_stride=pad,
+            output_stride=ccfg["model"]["heads"]["centroid"]["output_stride"],
+            peak_threshold=self.peak_threshold,
+            refinement="integral" if self.integral_refinement else "local",
+            integral_patch_size=self.integral_patch_size,
+            return_confmaps=False,
+            max_instances=self.max_instances)
+        instance_peaks_layer = FindInstancePeaks(
+            keras_model=self.confmap_model,
+            input_scale=icfg["data"]["preprocessing"].get("input_scaling", 1.0),
+            peak_threshold=self.peak_threshold,
+            output_stride=icfg["model"]["heads"]["centered_instance"]["output_stride"],
+            refinement="integral" if self.integral_refinement else "local",
+            integral_patch_size=self.integral_patch_size,
+            return_confmaps=False,
+            resize_input_image=False)
+        centroid_crop_layer.precrop_resize = icfg["data"]["preprocessing"].get("input_scaling", 1.0)
+        self.inference_model = TopDownInferenceModel(centroid_crop=centroid_crop_layer, instance_peaks=instance_peaks_layer)
+
+    def _input_network(self):
+        return self.centroid_model
+
+    @property
+    def data_config(self):
+        return self.centroid_config["data"]
+
+    @classmethod
+    def from_trained_models(cls, centroid_model_path: Optional[str] = None, confmap_model_path: Optional[str] = None,
+                            batch_size: int = 4, peak_threshold: float = 0.2, integral_refinement: bool = True,
+                            integral_patch_size: int = 5, resize_input_layer: bool = True,
+                            max_instances: Optional[int] = None):
+        """inference.py:2447-2540."""
+        if centroid_model_path is None or confmap_model_path is None:
+            raise ValueError("Both a centroid and a centered-instance model are required: predicting from ground truth "
+                             "centroids / peaks (CentroidCropGroundTruth, FindInstancePeaksGroundTruth) is out of scope.")
+        nets, cfgs = [], []
+        for mp in (centroid_model_path, confmap_model_path):
+            cfgs.append(model_io.load_training_config(mp))
+            mc, weights = model_io.load_keras_model(model_io.model_dir(mp))
+            nets.append(DeviceNetwork(mc, weights))
+        obj = cls(centroid_config=cfgs[0], centroid_model=nets[0], confmap_config=cfgs[1], confmap_model=nets[1],
+                  peak_threshold=peak_threshold, batch_size=batch_size, integral_refinement=integral_refinement,
+                  integral_patch_size=integral_patch_size, max_instances=max_instances)
+        obj.model_paths = [model_io.model_dir(centroid_model_path), model_io.model_dir(confmap_model_path)]
+        return obj
 
 
 class BottomUpPredictor(Predictor):

@@ -86,6 +86,22 @@ def find_global_peaks(cms, offsets=None, threshold=0.2, refinement=None, patch_s
     return peak_xy, peak_val
 
 
+def crop_and_resize(images, centres_xy, sample_inds, crop_size):
+    """-> crops (n, crop, crop, C) of the images' dtype (uint8 or float32) centred on fractional (x, y) centres."""
+    B, H, W, Cc = images.shape
+    n = centres_xy.shape[0]
+    out = torch.empty((n, crop_size, crop_size, Cc), dtype=images.dtype, device=images.device)
+    if n:
+        is_u8 = 1 if images.dtype == torch.uint8 else 0
+        if not is_u8 and images.dtype != torch.float32:
+            raise ValueError("crop_and_resize: images must be uint8 or float32")
+        centres_xy = centres_xy.to(torch.float32).contiguous()
+        sample_inds = sample_inds.to(torch.int32).contiguous()
+        check(_lib.lib().sa_crop_and_resize(_ptr(images), is_u8, H, W, Cc, _ptr(centres_xy), _ptr(sample_inds), n,
+                                            int(crop_size), _ptr(out), _stream()), "sa_crop_and_resize")
+    return out
+
+
 # --------------------------------------------------------------------------------------------------
 # PAF grouping
 # --------------------------------------------------------------------------------------------------
