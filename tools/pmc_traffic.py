@@ -1,0 +1,44 @@
+"""HBM traffic of the conv kernel family from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) over bench.py.
+FETCH_SIZE is doubled (gfx950 reports half the bytes of wide coalesced reads, MI355X_MICROARCH.md §HBM).
+
+    python tools/pmc_traffic.py <fetch counter_collection.csv> <write counter_collection.csv> <n B=64 forwards>
+"""
+import csv
+import re
+import sys
+from collections import defaultdict
+
+PAT = re.compile(r"(conv3x3_dma_kernel<[^>]*>|stem16_kernel<\d>|upsample2x_kernel)")
+
+
+def load(path, counter):
+    a = defaultdict(list)
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] != counter:
+            continue
+        m = PAT.search(r["Kernel_Name"])
+        if m:
+            a[(m.group(1), int(r["Grid_Size"]))].append(float(r["Counter_Value"]))
+    return a
+
+
+def main(fetch_csv, write_csv, n_fwd):
+    f, w = load(fetch_csv, "FETCH_SIZE"), load(write_csv, "WRITE_SIZE")
+    print("| kernel | grid | launches | FETCH_SIZE x2 [MB/launch] | WRITE_SIZE [MB/launch] |")
+    print("|---|---|---|---|---|")
+    tf = tw = 0.0
+    for key in sorted(f, key=lambda k: -sum(f[k])):
+        fv = sum(f[key]) / len(f[key]) / 1024 * 2
+        wv = sum(w.get(key, [0])) / max(len(w.get(key, [1])), 1) / 1024
+        print(f"| `{key[0]}` | {key[1]} | {len(f[key])} | {fv:.1f} | {wv:.1f} |")
+        if "upsample" not in key[0]:
+            tf += sum(f[key]) / 1024 * 2
+            tw += sum(w.get(key, [0])) / 1024
+    print(f"\nconv family (conv3x3_dma_kernel + stem16_kernel), all launches of the run: FETCH x2 {tf / 1024:.2f} GB, "
+          f"WRITE {tw / 1024:.2f} GB over {n_fwd} forward passes of 64 frames (+1 calibration pass of 2 frames)")
+    print(f"-> per step (17 launches, 64 frames): {(tf + tw) / 1024 / n_fwd:.2f} GB = "
+          f"{(tf + tw) / n_fwd / 64:.0f} MB/frame; algorithmic minimum of the fused plan: 190 MB/frame (DESIGN.md §3)")
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], sys.argv[2], int(sys.argv[3]))
