@@ -179,7 +179,7 @@ def main():
         mean_peaks = float(pk[3].float().mean())
         achieved = conv_fl / (conv_ms * 1e-3) / 1e12
         roofline = {
-            "kernel": "conv3x3_mfma_kernel (all launches of one step)", "bound": "mfma", "achieved": round(achieved, 2),
+            "kernel": "conv3x3_dma_kernel + stem16_kernel (the 17 MFMA conv launches of one step)", "bound": "mfma", "achieved": round(achieved, 2),
             "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
             "traffic": (MEASURED_CONV_TRAFFIC_BYTES_PER_STEP if (B == 64 and H == 1024 and W == 1024) else None),
             "traffic_unit": "HBM bytes per step over the kernel family's launches (rocprofv3 PMC, profiles/r01_pmc_hbm_traffic.md)",

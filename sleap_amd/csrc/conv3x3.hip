@@ -545,51 +545,75 @@ conv3x3_dma_kernel(const ConvParams2 p) {
     }
   }
 
-  // ---- epilogue
+  // ---- epilogue: bias + ReLU, bf16 pack. A lane holds channels {0-3, 8-11, 16-19, 24-27} + 4*half of its pixel;
+  // exchanging one 8-byte group with the partner lane (lane ^ 32) per pair of groups gives every lane 8 CONSECUTIVE
+  // channels, i.e. one 16-byte store per pair instead of two 8-byte stores (fewer store instructions, full 64-byte
+  // runs per pixel instead of interleaved partial writes).
   const int gx = x0 + lx;
 #pragma unroll
   for (int m = 0; m < MT; ++m) {
-    const int co_base = (co32_0 + m) * 32 + 4 * half;
+    const int cobase = (co32_0 + m) * 32;
+    if (cobase >= p.CoutP) continue;
+    float bb[4][4];
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      const int co = co_base + 8 * g;
-      if (co >= p.CoutP) continue;
-      const float4 bq = *reinterpret_cast<const float4*>(p.bias + co);
-      const float bb[4] = {bq.x, bq.y, bq.z, bq.w};
-      float v[R][4];
+      const int co = cobase + 8 * g + 4 * half;
+      float4 bq = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      if (co < p.CoutP) bq = *reinterpret_cast<const float4*>(p.bias + co);
+      bb[g][0] = bq.x;
+      bb[g][1] = bq.y;
+      bb[g][2] = bq.z;
+      bb[g][3] = bq.w;
+    }
+    auto act = [&](int r, int g, int j) {
+      const float t = acc[m][r][4 * g + j] + bb[g][j];
+      return p.relu ? fmaxf(t, 0.0f) : t;
+    };
+    auto store_pieces = [&](uint16_t* row_ptr, bool ok, const uint2 (&pk)[4]) {
 #pragma unroll
-      for (int r = 0; r < R; ++r)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          float t = acc[m][r][4 * g + j] + bb[j];
-          v[r][j] = p.relu ? fmaxf(t, 0.0f) : t;
-        }
-      if (p.dst) {
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-          const int gy = y0 + wave * R + r;
-          if (gy < H && gx < W) {
-            sa::bf16x4_t o;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) o[j] = sa::f2bf(v[r][j]);
-            *reinterpret_cast<sa::bf16x4_t*>(p.dst + (((size_t)b * H + gy) * W + gx) * p.CoutP + co) = o;
-          }
-        }
+      for (int pr = 0; pr < 2; ++pr) {
+        const uint2 send = half ? pk[2 * pr] : pk[2 * pr + 1];
+        uint2 recv;
+        recv.x = __shfl_xor(send.x, 32);
+        recv.y = __shfl_xor(send.y, 32);
+        const uint4 piece = half ? make_uint4(recv.x, recv.y, pk[2 * pr + 1].x, pk[2 * pr + 1].y)
+                                 : make_uint4(pk[2 * pr].x, pk[2 * pr].y, recv.x, recv.y);
+        const int co = cobase + 16 * pr + 8 * half;
+        if (ok && co < p.CoutP) *reinterpret_cast<uint4*>(row_ptr + co) = piece;
       }
-      if (p.dst_pool) {
+    };
+    if (p.dst) {
 #pragma unroll
-        for (int r = 0; r < R; r += 2) {
-          sa::bf16x4_t o;
+      for (int r = 0; r < R; ++r) {
+        const int gy = y0 + wave * R + r;
+        uint2 pk[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          pk[g].x = sa::f2bf2(act(r, g, 0), act(r, g, 1));
+          pk[g].y = sa::f2bf2(act(r, g, 2), act(r, g, 3));
+        }
+        const bool ok = gy < H && gx < W;
+        store_pieces(p.dst + (((size_t)b * H + (ok ? gy : 0)) * W + (ok ? gx : 0)) * p.CoutP, ok, pk);
+      }
+    }
+    if (p.dst_pool) {
+#pragma unroll
+      for (int r = 0; r < R; r += 2) {
+        const int gy = y0 + wave * R + r;
+        uint2 pk[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          float t4[4];
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
-            float t = fmaxf(v[r][j], v[r + 1][j]);
-            t = fmaxf(t, __shfl_xor(t, 1));
-            o[j] = sa::f2bf(t);
+            const float t = fmaxf(act(r, g, j), act(r + 1, g, j));
+            t4[j] = fmaxf(t, __shfl_xor(t, 1));
           }
-          const int gy = y0 + wave * R + r;
-          if (!(lane & 1) && gy < H && gx < W)
-            *reinterpret_cast<sa::bf16x4_t*>(p.dst_pool + (((size_t)b * (H / 2) + gy / 2) * (W / 2) + gx / 2) * p.CoutP + co) = o;
+          pk[g].x = sa::f2bf2(t4[0], t4[1]);
+          pk[g].y = sa::f2bf2(t4[2], t4[3]);
         }
+        const bool ok = !(lane & 1) && gy < H && gx < W;
+        store_pieces(p.dst_pool + (((size_t)b * (H / 2) + (ok ? gy / 2 : 0)) * (W / 2) + (ok ? gx / 2 : 0)) * p.CoutP, ok, pk);
       }
     }
   }
