@@ -186,6 +186,18 @@ int sa_conv3x3_bf16(const void* src0, int C0P, const void* src1, int C1P, int mo
                     const float* bias, int CoutP, int relu, int B, int H, int W, void* dst, void* dst_pool,
                     sa_stream_t stream);
 
+/* Same convolution with the extended epilogue the hourglass / ResNet graphs need:
+ *   v = acc + bias; if relu: v = max(v, 0);
+ *   if post_scale: v = v * post_scale[c] + post_shift[c]     (BatchNormalization AFTER the activation, hourglass.py:36-45)
+ *   if residual:   v += residual[pixel][c]                   (Add layer; res_mode 1: residual is [B,H/2,W/2,CoutP] and is
+ *                                                             read with UpSampling2D(2,"nearest"), hourglass.py:183-191)
+ *   if relu_last:  v = max(v, 0)                             (ResNet: relu(bn(conv) + shortcut), resnet.py:168-253)
+ * post_scale/post_shift [CoutP] f32 or NULL, residual bf16 or NULL. mode NONE/DIRECT only. */
+int sa_conv3x3_ex_bf16(const void* src0, int C0P, const void* src1, int C1P, int mode, const void* w,
+                       const float* bias, int CoutP, int relu, int B, int H, int W, void* dst, void* dst_pool,
+                       const float* post_scale, const float* post_shift, const void* residual, int res_mode,
+                       int relu_last, sa_stream_t stream);
+
 /* Same convolution with up to two 1x1 heads (Head.make_head, heads.py:42-62) fused into the epilogue and
  * computed from the fp32 accumulators (no bf16 rounding of the features the heads see). Needs CoutP <= 64 and
  * mode NONE/DIRECT. HOST arrays of length n_heads: head_w[i] -> device [head_c[i]][CoutP] f32, head_b[i] -> device
@@ -206,6 +218,19 @@ size_t sa_conv3x3_packed_elems(int C0P, int C1P, int CoutP);
  * transposed conv cropped at the end).  w [3][3][CoutP][CinP] bf16 (Keras layout, padded) */
 int sa_convt3x3s2_bf16(const void* src, int CinP, const void* w, const float* bias, int CoutP,
                        int relu, int B, int H, int W, void* dst, sa_stream_t stream);
+
+/* First-layer convolution of any kernel size / stride on the raw image with explicit TF SAME pads, e.g. the
+ * hourglass stem Conv2D(k7, s2, same)+ReLU+BatchNormalization (hourglass.py:75-85). ensure_float fused for u8.
+ *   src [B,H,W,Cin] u8|f32; w [kh][kw][Cin][CoutP] f32; post_scale/post_shift [CoutP] or NULL (BN after ReLU);
+ *   dst [B,Ho,Wo,CoutP] bf16 */
+int sa_image_conv_bf16(const void* src, int src_is_u8, int B, int H, int W, int Cin, int kh, int kw, int stride,
+                       int pad_top, int pad_left, int Ho, int Wo, const float* w, const float* bias, int CoutP, int relu,
+                       const float* post_scale, const float* post_shift, void* dst, sa_stream_t stream);
+
+/* Add layer (hourglass.py:190, resnet.py:249): dst = a + b [+ ReLU]; b may be [B,H/2,W/2,CP] read with
+ * UpSampling2D(2, "nearest") (b_half_res = 1). Used when the addition can not be folded into a conv epilogue. */
+int sa_add_bf16(const void* a, const void* b, int B, int H, int W, int CP, int b_half_res, int relu, void* dst,
+                sa_stream_t stream);
 
 /* MaxPooling2D(2, s2, same) on even sizes; UpSampling2D(2, "bilinear"|"nearest") */
 int sa_maxpool2x2_bf16(const void* src, int B, int H, int W, int CP, void* dst, sa_stream_t stream);

@@ -51,13 +51,17 @@ def _act(x, name):
 class KerasGraph:
     """Executes the layer list of a Keras `Functional` model config in NCHW torch tensors."""
 
-    def __init__(self, model_config, weights, emulate_bf16=False, fp32_input_heads=()):
+    def __init__(self, model_config, weights, emulate_bf16=False, fp32_input_heads=(), round_layers=None):
         """`emulate_bf16=True` rounds weights/activations to bfloat16 at exactly the points where the HIP engine
         stores bf16 (conv / transposed-conv / upsample outputs, 3x3 conv weights except the fp32 stem; heads
         keep fp32 weights and outputs), with fp32 accumulation in between. It separates "the kernels compute what
         they claim" (tight tolerance against this mode) from "bf16 storage is accurate enough" (loose tolerance
         against the fp32 mode)."""
         self.emulate_bf16 = emulate_bf16
+        # with emulate_bf16: layer names after which a value is rounded to bf16. None = after every Conv2D /
+        # Conv2DTranspose / bilinear UpSampling2D (the UNet engine's storage points); a set = exactly those layers
+        # (an engine that fuses BatchNormalization / Add into the conv epilogue stores only the fused result)
+        self.round_layers = None if round_layers is None else set(round_layers)
         # heads the engine computes from the un-rounded fp32 accumulators of the producing conv (fused epilogue)
         self.fp32_input_heads = set(fp32_input_heads)
         cfg = model_config["config"]
@@ -108,7 +112,10 @@ class KerasGraph:
         y = self._layer_fp32(cn, name, c, ins)
         if self.emulate_bf16:
             is_head = cn == "Conv2D" and name in self.output_names
-            if cn in ("Conv2D", "Conv2DTranspose", "UpSampling2D") and not is_head:
+            if self.round_layers is not None:
+                if name in self.round_layers and not is_head:
+                    y = self._r(y)
+            elif cn in ("Conv2D", "Conv2DTranspose", "UpSampling2D") and not is_head:
                 y = self._r(y)
         return y
 

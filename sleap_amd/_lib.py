@@ -44,10 +44,13 @@ SIGNATURES = {
     "sa_stem16_u8_bf16": (_i, [_p, _i, _i, _i, _i, _p, _i, _i, _p, _p, _p]),
     "sa_stem16_pack": (_i, [_p, _p, _i, _i, _p, _p, _i, _p]),
     "sa_stem16_blob_bytes": (_sz, []),
+    "sa_conv3x3_ex_bf16": (_i, [_p, _i, _p, _i, _i, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _i, _i, _p]),
     "sa_conv3x3_heads_bf16": (_i, [_p, _i, _p, _i, _i, _p, _p, _i, _i, _i, _i, _i, _p, _i, _p, _p, _p, _p, _p, _p]),
     "sa_pack_conv3x3_weights": (_i, [_p, _i, _i, _i, _i, _i, _i, _p]),
     "sa_conv3x3_packed_elems": (_sz, [_i, _i, _i]),
     "sa_convt3x3s2_bf16": (_i, [_p, _i, _p, _p, _i, _i, _i, _i, _i, _p, _p]),
+    "sa_image_conv_bf16": (_i, [_p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p, _i, _i, _p, _p, _p, _p]),
+    "sa_add_bf16": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _p, _p]),
     "sa_maxpool2x2_bf16": (_i, [_p, _i, _i, _i, _i, _p, _p]),
     "sa_upsample2x_bf16": (_i, [_p, _i, _i, _i, _i, _i, _p, _p]),
     "sa_conv1x1_head": (_i, [_p, _i, _p, _p, _i, _i, _i, _i, _i, _p, _p]),

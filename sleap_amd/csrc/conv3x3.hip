@@ -240,6 +240,13 @@ struct ConvParams2 {
   const float* stem_w;     // [3][3][CIN][C0P] f32
   const float* stem_b;     // [C0P]
   int stem_is_u8, stem_relu;
+  // extended epilogue (EXT kernels): v = acc + bias; relu?; v = v*post_scale + post_shift (BatchNormalization placed
+  // AFTER the activation, hourglass.py:36-45); v += residual (Add layer; res_mode 1 = residual is half resolution and
+  // read with nearest-neighbour x2 upsampling, hourglass.py:183-191); relu_last? (ResNet: relu(bn(conv) + shortcut))
+  const float* post_scale;
+  const float* post_shift;
+  const uint16_t* residual;
+  int res_mode, relu_last;
 };
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -257,7 +264,7 @@ __device__ __forceinline__ int swz(int p) {
 // pixel that lies outside the image is set beyond num_records, for which the hardware writes zeros to LDS
 // (verified by tools/probes/buffer_lds_oob.hip) -- SAME padding costs nothing; the chunk's channel offset and
 // the weight-slab offset travel in the scalar offset, so issuing a copy is one SALU add + one VMEM instruction.
-template <int MT, int CK, int NW, int R, int NBUF, bool HEADS, int STEM_CIN>
+template <int MT, int CK, int NW, int R, int NBUF, bool HEADS, int STEM_CIN, bool EXT>
 __global__ void __launch_bounds__(NW * 64)
 conv3x3_dma_kernel(const ConvParams2 p) {
 #if defined(__HIP_DEVICE_COMPILE__)  // the body uses device-only types (buffer resources); the host pass only needs the stub
@@ -565,9 +572,36 @@ conv3x3_dma_kernel(const ConvParams2 p) {
       bb[g][2] = bq.z;
       bb[g][3] = bq.w;
     }
+    float ps[4][4], pt[4][4];
+    if constexpr (EXT) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int co = cobase + 8 * g + 4 * half;
+        float4 sq = make_float4(1.0f, 1.0f, 1.0f, 1.0f), tq = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (p.post_scale && co < p.CoutP) {
+          sq = *reinterpret_cast<const float4*>(p.post_scale + co);
+          tq = *reinterpret_cast<const float4*>(p.post_shift + co);
+        }
+        ps[g][0] = sq.x, ps[g][1] = sq.y, ps[g][2] = sq.z, ps[g][3] = sq.w;
+        pt[g][0] = tq.x, pt[g][1] = tq.y, pt[g][2] = tq.z, pt[g][3] = tq.w;
+      }
+    }
     auto act = [&](int r, int g, int j) {
-      const float t = acc[m][r][4 * g + j] + bb[g][j];
-      return p.relu ? fmaxf(t, 0.0f) : t;
+      float t = acc[m][r][4 * g + j] + bb[g][j];
+      if (p.relu) t = fmaxf(t, 0.0f);
+      if constexpr (EXT) {
+        t = fmaf(t, ps[g][j], pt[g][j]);
+        if (p.residual) {
+          const int gy = y0 + wave * R + r, co = cobase + 8 * g + 4 * half + j;
+          if (gy < H && gx < W && co < p.CoutP) {
+            const size_t ri = p.res_mode ? (((size_t)b * (H / 2) + (gy >> 1)) * (W / 2) + (gx >> 1))
+                                         : (((size_t)b * H + gy) * W + gx);
+            t += sa::bf2f(p.residual[ri * p.CoutP + co]);
+          }
+        }
+        if (p.relu_last) t = fmaxf(t, 0.0f);
+      }
+      return t;
     };
     auto store_pieces = [&](uint16_t* row_ptr, bool ok, const uint2 (&pk)[4]) {
 #pragma unroll
@@ -679,7 +713,7 @@ conv3x3_dma_kernel(const ConvParams2 p) {
 #endif
 }
 
-template <int MT, int CK, int NW, int R, int NBUF, bool HEADS, int STEM_CIN = 0>
+template <int MT, int CK, int NW, int R, int NBUF, bool HEADS, int STEM_CIN = 0, bool EXT = false>
 int launch2(const ConvParams2& p, hipStream_t st) {
   constexpr int TH = NW * R;
   constexpr int N_IN = ((TH + 2) * 34 * CK * 2 + 1023) / 1024;
@@ -696,7 +730,7 @@ int launch2(const ConvParams2& p, hipStream_t st) {
     return sa::fail(SA_ERR_UNSUPPORTED, "sa_conv3x3_bf16: one frame must be smaller than 4 GiB");
   static bool attr_set = false;
   if (!attr_set && lds > 64 * 1024) {
-    SA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_dma_kernel<MT, CK, NW, R, NBUF, HEADS, STEM_CIN>),
+    SA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_dma_kernel<MT, CK, NW, R, NBUF, HEADS, STEM_CIN, EXT>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
@@ -706,13 +740,17 @@ int launch2(const ConvParams2& p, hipStream_t st) {
       if ((size_t)p.head_c[hd] * p.CoutP * 4 > lds || p.head_c[hd] > 32 || p.head_c[hd] < 1)
         return sa::fail(SA_ERR_UNSUPPORTED, "fused head %d: %d channels not supported", hd, p.head_c[hd]);
   }
-  hipLaunchKernelGGL((conv3x3_dma_kernel<MT, CK, NW, R, NBUF, HEADS, STEM_CIN>), dim3((unsigned)nblk), dim3(NW * 64), lds, st, q);
+  hipLaunchKernelGGL((conv3x3_dma_kernel<MT, CK, NW, R, NBUF, HEADS, STEM_CIN, EXT>), dim3((unsigned)nblk), dim3(NW * 64), lds, st, q);
   SA_LAUNCH_CHECK();
   return SA_OK;
 }
 
 template <int MT, int CK>
 int launch2_pick(const ConvParams2& p, hipStream_t st) {
+  if (p.post_scale || p.residual || p.relu_last) {  // extended epilogue
+    if ((p.C0P + p.C1P) == CK) return launch2<MT, CK, 4, 2, 1, false, 0, true>(p, st);
+    return launch2<MT, CK, 8, 2, 2, false, 0, true>(p, st);
+  }
   if (p.n_heads > 0) return launch2<MT, CK, 8, 2, 2, true>(p, st);
   // single-chunk layers (Cin <= CK) are HBM-bound: small single-stage tiles, many workgroups per CU
   if ((p.C0P + p.C1P) == CK) return launch2<MT, CK, 4, 2, 1, false>(p, st);
@@ -757,7 +795,9 @@ int launch_mode(const ConvParams& p, int mode, hipStream_t st) {
 static int conv3x3_impl(const void* src0, int C0P, const void* src1, int C1P, int mode, const void* w,
                         const float* bias, int CoutP, int relu, int B, int H, int W, void* dst, void* dst_pool,
                         int n_heads, const float* const* head_w, const float* const* head_b, const int* head_c,
-                        const int* head_act, float* const* head_dst, sa_stream_t stream) {
+                        const int* head_act, float* const* head_dst, sa_stream_t stream,
+                        const float* post_scale = nullptr, const float* post_shift = nullptr,
+                        const void* residual = nullptr, int res_mode = 0, int relu_last = 0) {
   SA_REQUIRE(src0 && w && bias && (dst || dst_pool || n_heads > 0), "sa_conv3x3_bf16: NULL pointer");
   SA_REQUIRE(n_heads >= 0 && n_heads <= 2, "sa_conv3x3_bf16: at most 2 fused heads");
   SA_REQUIRE(C0P > 0 && C0P % 16 == 0 && C1P % 16 == 0 && CoutP > 0 && CoutP % 16 == 0,
@@ -808,6 +848,14 @@ static int conv3x3_impl(const void* src0, int C0P, const void* src1, int C1P, in
     q.H = H;
     q.W = W;
     q.relu = relu;
+    q.post_scale = post_scale;
+    q.post_shift = post_shift;
+    q.residual = (const uint16_t*)residual;
+    q.res_mode = res_mode;
+    q.relu_last = relu_last;
+    SA_REQUIRE(!(post_scale || residual || relu_last) || n_heads == 0, "sa_conv3x3: extended epilogue and fused heads are exclusive");
+    SA_REQUIRE(!post_scale == !post_shift, "sa_conv3x3: post_scale and post_shift come together");
+    SA_REQUIRE(!(residual && res_mode) || (H % 2 == 0 && W % 2 == 0), "sa_conv3x3: half-resolution residual needs even H, W");
     q.n_heads = n_heads;
     for (int hd = 0; hd < n_heads; ++hd) {
       q.head_w[hd] = head_w[hd];
@@ -825,8 +873,8 @@ static int conv3x3_impl(const void* src0, int C0P, const void* src1, int C1P, in
     if (co32_n >= 2) return ck32 ? launch2_pick<2, 32>(q, st) : launch2_pick<2, 16>(q, st);
     return ck32 ? launch2_pick<1, 32>(q, st) : launch2_pick<1, 16>(q, st);
   }
-  SA_REQUIRE(dst && !dst_pool && n_heads == 0,
-             "sa_conv3x3_bf16: pooled output / fused heads are not available with pool/upsample source modes");
+  SA_REQUIRE(dst && !dst_pool && n_heads == 0 && !post_scale && !residual && !relu_last,
+             "sa_conv3x3_bf16: pooled output / fused heads / extended epilogue are not available with pool/upsample source modes");
   if (co32_n >= 2) {
     return ck32 ? launch_mode<2, 4, 32>(p, src_mode, st) : launch_mode<2, 4, 16>(p, src_mode, st);
   }
@@ -871,6 +919,14 @@ int sa_conv3x3_bf16(const void* src0, int C0P, const void* src1, int C1P, int mo
                     sa_stream_t stream) {
   return conv3x3_impl(src0, C0P, src1, C1P, mode, w, bias, CoutP, relu, B, H, W, dst, dst_pool, 0, nullptr, nullptr,
                       nullptr, nullptr, nullptr, stream);
+}
+
+int sa_conv3x3_ex_bf16(const void* src0, int C0P, const void* src1, int C1P, int mode, const void* w,
+                       const float* bias, int CoutP, int relu, int B, int H, int W, void* dst, void* dst_pool,
+                       const float* post_scale, const float* post_shift, const void* residual, int res_mode,
+                       int relu_last, sa_stream_t stream) {
+  return conv3x3_impl(src0, C0P, src1, C1P, mode, w, bias, CoutP, relu, B, H, W, dst, dst_pool, 0, nullptr, nullptr,
+                      nullptr, nullptr, nullptr, stream, post_scale, post_shift, residual, res_mode, relu_last);
 }
 
 int sa_stem_conv3x3x2_bf16(const void* src, int src_is_u8, int B, int H, int W, int Cin, const float* w0,

@@ -66,6 +66,85 @@ stem_conv3x3_kernel(const void* __restrict__ src_, int B, int H, int W, const fl
 }
 
 // ------------------------------------------------------------------------------------------------
+// General first-layer convolution on the raw image (any kernel size / stride / explicit TF SAME pads), e.g. the
+// hourglass stem Conv2D(k7, s2, same)+ReLU+BatchNormalization (hourglass.py:75-85) or ResNet's
+// ZeroPadding2D(3)+Conv2D(k7, s2, valid). ensure_float fused for uint8 input. fp32 arithmetic, bf16 store.
+// thread = (output pixel, group of 8 output channels); weights [kh][kw][Cin][CoutP] f32 from LDS.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+image_conv_kernel(const void* __restrict__ src_, int is_u8, int B, int H, int W, int Cin, int kh, int kw, int stride,
+                  int pad_t, int pad_l, int Ho, int Wo, const float* __restrict__ w, const float* __restrict__ bias,
+                  int CoutP, int relu, const float* __restrict__ post_scale, const float* __restrict__ post_shift,
+                  uint16_t* __restrict__ dst) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  float* sw = reinterpret_cast<float*>(smem_raw);
+  const int nw = kh * kw * Cin * CoutP;
+  for (int i = threadIdx.x; i < nw; i += blockDim.x) sw[i] = w[i];
+  __syncthreads();
+  const int groups = CoutP / 8;
+  const size_t total = (size_t)B * Ho * Wo * groups;
+  for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
+    const int g = (int)(t % groups);
+    const size_t p = t / groups;
+    const int x = (int)(p % Wo);
+    const int y = (int)((p / Wo) % Ho);
+    const size_t b = p / ((size_t)Wo * Ho);
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = bias[g * 8 + j];
+    for (int dy = 0; dy < kh; ++dy) {
+      const int yy = y * stride + dy - pad_t;
+      if (yy < 0 || yy >= H) continue;
+      for (int dx = 0; dx < kw; ++dx) {
+        const int xx = x * stride + dx - pad_l;
+        if (xx < 0 || xx >= W) continue;
+        const size_t si = ((b * H + yy) * W + xx) * Cin;
+        for (int c = 0; c < Cin; ++c) {
+          const float v = is_u8 ? (float)reinterpret_cast<const uint8_t*>(src_)[si + c] * (1.0f / 255.0f)
+                                : reinterpret_cast<const float*>(src_)[si + c];
+          const float* wr = sw + ((dy * kw + dx) * Cin + c) * CoutP + g * 8;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) acc[j] = fmaf(v, wr[j], acc[j]);
+        }
+      }
+    }
+    bf16x8_t o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float v = relu ? fmaxf(acc[j], 0.0f) : acc[j];
+      if (post_scale) v = fmaf(v, post_scale[g * 8 + j], post_shift[g * 8 + j]);
+      o[j] = sa::f2bf(v);
+    }
+    *reinterpret_cast<bf16x8_t*>(dst + p * CoutP + g * 8) = o;
+  }
+}
+
+// Add layer: dst = a + b (bf16, same shape); b may be half resolution read with nearest-neighbour x2 upsampling
+__global__ void __launch_bounds__(256)
+add_kernel(const uint16_t* __restrict__ a, const uint16_t* __restrict__ bsrc, int B, int H, int W, int CP, int b_half,
+           int relu, uint16_t* __restrict__ dst) {
+  const int groups = CP / 8;
+  const size_t total = (size_t)B * H * W * groups;
+  for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
+    const int g = (int)(t % groups);
+    const size_t p = t / groups;
+    const int x = (int)(p % W);
+    const int y = (int)((p / W) % H);
+    const size_t b = p / ((size_t)W * H);
+    const bf16x8_t va = *reinterpret_cast<const bf16x8_t*>(a + p * CP + g * 8);
+    const size_t pb = b_half ? ((b * (H / 2) + (y >> 1)) * (W / 2) + (x >> 1)) : p;
+    const bf16x8_t vb = *reinterpret_cast<const bf16x8_t*>(bsrc + pb * CP + g * 8);
+    bf16x8_t o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float v = sa::bf2f(va[j]) + sa::bf2f(vb[j]);
+      o[j] = sa::f2bf(relu ? fmaxf(v, 0.0f) : v);
+    }
+    *reinterpret_cast<bf16x8_t*>(dst + p * CP + g * 8) = o;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // MaxPooling2D(2, s2) on even sizes
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
@@ -282,6 +361,34 @@ int sa_stem_conv3x3(const void* src, int src_is_u8, int B, int H, int W, int Cin
   else if (src_is_u8) SA_STEM(3, true);
   else SA_STEM(3, false);
 #undef SA_STEM
+  SA_LAUNCH_CHECK();
+  return SA_OK;
+}
+
+int sa_image_conv_bf16(const void* src, int src_is_u8, int B, int H, int W, int Cin, int kh, int kw, int stride,
+                       int pad_top, int pad_left, int Ho, int Wo, const float* w, const float* bias, int CoutP, int relu,
+                       const float* post_scale, const float* post_shift, void* dst, sa_stream_t stream) {
+  SA_REQUIRE(src && w && bias && dst, "sa_image_conv_bf16: NULL pointer");
+  SA_REQUIRE(B > 0 && H > 0 && W > 0 && Cin > 0 && kh > 0 && kw > 0 && stride > 0 && Ho > 0 && Wo > 0, "sa_image_conv_bf16: bad shape");
+  SA_REQUIRE(CoutP % 8 == 0, "sa_image_conv_bf16: CoutP must be a multiple of 8");
+  SA_REQUIRE(!post_scale == !post_shift, "sa_image_conv_bf16: post_scale and post_shift come together");
+  const size_t lds = sizeof(float) * (size_t)kh * kw * Cin * CoutP;
+  SA_REQUIRE(lds <= 64 * 1024, "sa_image_conv_bf16: weights (%zu B) exceed the LDS budget", lds);
+  const size_t total = (size_t)B * Ho * Wo * (CoutP / 8);
+  hipLaunchKernelGGL(image_conv_kernel, dim3(grid_for(total)), dim3(256), lds, (hipStream_t)stream, src, src_is_u8, B, H,
+                     W, Cin, kh, kw, stride, pad_top, pad_left, Ho, Wo, w, bias, CoutP, relu, post_scale, post_shift,
+                     (uint16_t*)dst);
+  SA_LAUNCH_CHECK();
+  return SA_OK;
+}
+
+int sa_add_bf16(const void* a, const void* b, int B, int H, int W, int CP, int b_half_res, int relu, void* dst,
+                sa_stream_t stream) {
+  SA_REQUIRE(a && b && dst && CP % 8 == 0, "sa_add_bf16: bad arguments");
+  SA_REQUIRE(!b_half_res || (H % 2 == 0 && W % 2 == 0), "sa_add_bf16: half-resolution operand needs even H, W");
+  const size_t total = (size_t)B * H * W * (CP / 8);
+  hipLaunchKernelGGL(add_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)a,
+                     (const uint16_t*)b, B, H, W, CP, b_half_res, relu, (uint16_t*)dst);
   SA_LAUNCH_CHECK();
   return SA_OK;
 }

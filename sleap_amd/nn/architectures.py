@@ -1,9 +1,10 @@
-"""Builds the Keras functional-graph description of SLEAP's UNet backbones + heads.
+"""Builds the Keras functional-graph description of SLEAP's UNet and (stacked) hourglass backbones + heads.
 
 Mirrors, as plain data (layer list with the reference's layer names and wiring), what the reference
 builds with Keras objects:
     sleap/nn/architectures/unet.py:46-278             UNet (stem / encoder / decoder stacks, from_config)
     sleap/nn/architectures/encoder_decoder.py:57-676  SimpleConvBlock, SimpleUpsamplingBlock, make_backbone
+    sleap/nn/architectures/hourglass.py:17-316        conv (Conv+ReLU+BN), StemBlock, Downsampling/UpsamplingBlock
     sleap/nn/heads.py:42-62                           Head.make_head (1x1 linear Conv2D named after the head class)
     sleap/nn/model.py:312-364                         Model.make_model (heads attach at matching stride)
 The result has the same schema as `json.loads(h5.attrs["model_config"])` so the engine, the
@@ -132,6 +133,98 @@ def build_unet_model_config(input_shape: Tuple[int, int, int], filters: int = 16
     return cfg, shapes
 
 
+def build_hourglass_model_config(input_shape: Tuple[int, int, int], stem_stride: int = 4, max_stride: int = 64,
+                                 output_stride: int = 4, stem_filters: int = 128, filters: int = 256,
+                                 filter_increase: int = 128, stacks: int = 3, interp_method: str = "nearest",
+                                 heads: Sequence[Tuple[str, int, int]] = ()) -> Tuple[dict, Dict[str, tuple]]:
+    """Hourglass.from_config (hourglass.py:299-316) + make_backbone (encoder_decoder.py:606-676) + Model.make_model.
+
+    Without `heads` the model outputs are the stack outputs (what tests/nn/architectures/test_hourglass.py builds).
+    With `heads`, every head attaches to every stack output under the same layer name (model.py:336-359), which
+    Keras rejects for stacks > 1; the same ValueError is raised here.
+    """
+    if stem_stride not in (2, 4):
+        raise NotImplementedError("hourglass stem_stride must be 2 or 4 (stride-1 'same' max pooling is not implemented)")
+    stem_blocks = int(math.log2(stem_stride))
+    down_blocks = int(math.log2(max_stride)) - stem_blocks
+    up_blocks = int(math.log2(max_stride / output_stride))
+    if stacks > 1 and down_blocks != up_blocks:
+        raise ValueError("If using a stacked configuration, the backbone must define symmetric encoder and decoder. "
+                         "Create a stem for initial downsampling if an output stride > 1 is desired.")
+    if stacks > 1 and heads:
+        raise ValueError(f'The name "{heads[0][0]}" is used {stacks} times in the model. All layer names should be unique.')
+    g = _G()
+    shapes: Dict[str, tuple] = {}
+    x = g.add("InputLayer", "input", {"batch_input_shape": [None, input_shape[0], input_shape[1], input_shape[2]]}, [])
+
+    def conv(x, cin, f, prefix, k=3, stride=1):  # hourglass.py:17-45
+        shapes[f"{prefix}_conv/kernel"] = (k, k, int(cin), int(f))
+        shapes[f"{prefix}_conv/bias"] = (int(f),)
+        for v in ("gamma", "beta", "moving_mean", "moving_variance"):
+            shapes[f"{prefix}_bn/{v}"] = (int(f),)
+        x = g.add("Conv2D", prefix + "_conv", {"filters": int(f), "kernel_size": [k, k], "strides": [stride, stride],
+                                                "padding": "same", "activation": "relu", "use_bias": True,
+                                                "dilation_rate": [1, 1]}, [x])
+        return g.add("BatchNormalization", prefix + "_bn", {"axis": [3], "momentum": 0.99, "epsilon": 0.001,
+                                                             "center": True, "scale": True}, [x])
+
+    def pool(x, name, stride=2):
+        return g.add("MaxPooling2D", name, {"pool_size": [2, 2], "strides": [stride, stride], "padding": "same"}, [x])
+
+    # ---- stem (StemBlock.make_block, hourglass.py:73-103)
+    x = conv(x, input_shape[2], stem_filters, "stem0_conv7x7", k=7, stride=2 if stem_stride == 4 else 1)
+    x = conv(x, stem_filters, 2 * stem_filters, "stem0_conv3x3")
+    x = pool(x, "stem0_pool")
+    x = conv(x, 2 * stem_filters, filters, "stem0_conv3x3_out")
+    cur_c = filters
+    stem_out = (x, cur_c)
+    outs, mids_per_stack = [], []
+    for s in range(stacks):
+        stride = stem_stride
+        feats = []  # encoder IntermediateFeatures (stride, tensor, channels)
+        for i in range(down_blocks):  # DownsamplingBlock (hourglass.py:123-139)
+            f = filters + i * filter_increase
+            x = pool(x, f"stack{s}_enc{i}_pool")
+            x = conv(x, cur_c, f, f"stack{s}_enc{i}_conv")
+            cur_c, stride = f, stride * 2
+            feats.append((stride, x, cur_c))
+        sources = [(stem_stride,) + stem_out] + feats[:-1]
+        mids = {}
+        for i in range(up_blocks):  # UpsamplingBlock (hourglass.py:162-191)
+            mids.setdefault(stride, (x, cur_c))
+            f = filters + (down_blocks - i - 1) * filter_increase
+            nxt = stride // 2
+            skip = next(((t, c) for (st, t, c) in sources if st == nxt), None)
+            if skip is None:
+                raise ValueError(f"hourglass decoder block {i} has no skip source at stride {nxt}")
+            pre = f"stack{s}_dec{i}"
+            x = conv(x, cur_c, f, pre + "_conv")
+            x = g.add("UpSampling2D", f"{pre}_{interp_method}", {"size": [2, 2], "interpolation": interp_method}, [x])
+            xs = conv(skip[0], skip[1], f, pre + "_skip")
+            x = g.add("Add", pre + "_skip_add", {}, [x, xs])
+            cur_c, stride = f, nxt
+        outs.append((x, cur_c, stride))
+        mids_per_stack.append(mids)
+    out_layers = [o[0] for o in outs]
+    if heads:
+        out_layers = []
+        x, c, stride = outs[0]
+        for head_name, channels, hs in heads:
+            if hs == stride:
+                src, sc = x, c
+            elif hs in mids_per_stack[0]:
+                src, sc = mids_per_stack[0][hs]
+            else:
+                raise ValueError(f"Could not find a feature activation for output at stride {hs}.")
+            shapes[f"{head_name}/kernel"] = (1, 1, int(sc), int(channels))
+            shapes[f"{head_name}/bias"] = (int(channels),)
+            out_layers.append(_conv(g, src, head_name, channels, k=1))
+    cfg = {"class_name": "Functional",
+           "config": {"name": "model", "layers": g.layers, "input_layers": [["input", 0, 0]],
+                      "output_layers": [[o, 0, 0] for o in out_layers]}}
+    return cfg, shapes
+
+
 def he_normal_weights(shapes: Dict[str, tuple], seed: int = 0) -> Dict[str, np.ndarray]:
     """Deterministic He-normal kernels / small biases (random-init weights for benchmarking)."""
     rng = np.random.default_rng(seed)
@@ -141,6 +234,12 @@ def he_normal_weights(shapes: Dict[str, tuple], seed: int = 0) -> Dict[str, np.n
         if k.endswith("/kernel"):
             fan_in = s[0] * s[1] * (s[3] if "trans_conv" in k else s[2])
             w[k] = (rng.standard_normal(s) * math.sqrt(2.0 / fan_in)).astype(np.float32)
+        elif k.endswith("/gamma"):
+            w[k] = (1.0 + 0.1 * rng.standard_normal(s)).astype(np.float32)
+        elif k.endswith("/moving_variance"):
+            w[k] = rng.uniform(0.5, 1.5, s).astype(np.float32)
+        elif k.endswith(("/beta", "/moving_mean")):
+            w[k] = (rng.standard_normal(s) * 0.1).astype(np.float32)
         else:
             w[k] = (rng.standard_normal(s) * 0.01).astype(np.float32)
     return w

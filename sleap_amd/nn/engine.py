@@ -10,6 +10,9 @@ launches (include/sleap_amd.h):
     InputLayer(+ensure_float) + first Conv2D               -> sa_stem_conv3x3 (u8 in, bf16 out)
     1x1 linear head convs                                  -> sa_conv1x1_head (f32 out)
     Conv2DTranspose(k3,s2)+Activation                      -> sa_convt3x3s2_bf16
+    Conv2D(relu)+BatchNormalization [+Add(skip, UpSampling2D(nearest)(x))]  (hourglass.py:17-45, 186-191)
+                                                           -> sa_conv3x3_ex_bf16 (post-affine + residual epilogue)
+    first Conv2D of any kernel size / stride (hourglass stem k7 s2) -> sa_image_conv_bf16
 
 Activations are bf16 NHWC with channels padded to a multiple of 16; accumulation is fp32.
 torch is used for device memory only.
@@ -86,7 +89,11 @@ class DeviceNetwork:
         n_buf = [0]
         self.buf_meta = {}  # id -> (cp, num, den, dtype)
         skip = set()  # layers fused into a predecessor
+        self.round_points = set()  # layer names whose output is the value stored (rounded) as bf16
         pooled_of: Dict[str, _T] = {}  # MaxPooling2D layer name -> pooled tensor written by the producing conv
+        t_alias: List[str] = []  # layer names fused into the conv being compiled (all map to its output tensor)
+        conv_of: Dict[int, list] = {}  # id(output _T) -> the plan op that writes it (for Add fusion)
+        round_of: Dict[int, str] = {}  # id(output _T) -> its entry in round_points
 
         def new_buf(c_alloc, num, den, dtype):
             i = n_buf[0]
@@ -135,6 +142,48 @@ class DeviceNetwork:
                 raise NotImplementedError(f"activation {act} on {name}")
             return out_name, 1 if act == "relu" else 0
 
+        def sole_consumer(name, class_name):
+            c = cons.get(name, [])
+            if len(c) == 1 and by_name[c[0]]["class_name"] == class_name and name not in self.output_names:
+                return by_name[c[0]]
+            return None
+
+        def bn_affine(l, coutp):
+            """Inference-mode BatchNormalization as y = x * scale + shift per channel (padded channels -> 0)."""
+            n, c = l["name"], l["config"]
+            ax = c.get("axis", -1)
+            ax = ax[0] if isinstance(ax, (list, tuple)) else ax
+            if ax not in (-1, 3):
+                raise NotImplementedError(f"BatchNormalization {n}: axis {ax}")
+            var = np.asarray(self.weights[f"{n}/moving_variance"], np.float64)
+            mean = np.asarray(self.weights[f"{n}/moving_mean"], np.float64)
+            gamma = np.asarray(self.weights[f"{n}/gamma"], np.float64) if c.get("scale", True) else np.ones_like(var)
+            beta = np.asarray(self.weights[f"{n}/beta"], np.float64) if c.get("center", True) else np.zeros_like(var)
+            sc = gamma / np.sqrt(var + c.get("epsilon", 1e-3))
+            scale, shift = np.zeros((coutp,), np.float32), np.zeros((coutp,), np.float32)
+            scale[: sc.shape[0]] = sc
+            shift[: sc.shape[0]] = beta - mean * sc
+            return upload_f32(scale), upload_f32(shift)
+
+        def conv_epilogue(l, coutp):
+            """Conv2D[+Activation][+BatchNormalization[+Activation(relu)]] -> (out_name, relu, ext dict or None)."""
+            out_name, relu = conv_activation(l)
+            ext = None
+            bn = sole_consumer(out_name, "BatchNormalization")
+            if bn is not None:
+                ps, pt = bn_affine(bn, coutp)
+                ext = {"ps": ps, "pt": pt, "res": None, "res_mode": 0, "relu_last": 0}
+                skip.add(bn["name"])
+                t_alias.append(bn["name"])
+                out_name = bn["name"]
+                a = sole_consumer(out_name, "Activation")
+                if a is not None and a["config"]["activation"] == "relu":
+                    ext["relu_last"] = 1
+                    skip.add(a["name"])
+                    t_alias.append(a["name"])
+                    out_name = a["name"]
+            return out_name, relu, ext
+
         for l in self.layers:
             cn, name, c = l["class_name"], l["name"], l["config"]
             if name in skip:
@@ -145,11 +194,17 @@ class DeviceNetwork:
             ins = [t[n[0]] for n in l["inbound_nodes"][0]]
             if cn == "Conv2D":
                 k = tuple(c["kernel_size"])
-                if tuple(c["strides"]) != (1, 1) or c["padding"] != "same" or tuple(c.get("dilation_rate", (1, 1))) != (1, 1):
-                    raise NotImplementedError(f"Conv2D {name}: only stride 1 / same / no dilation is implemented")
+                strides = tuple(c["strides"])
+                x = ins[0]
+                if c["padding"] != "same" or tuple(c.get("dilation_rate", (1, 1))) != (1, 1):
+                    raise NotImplementedError(f"Conv2D {name}: only padding='same' without dilation is implemented")
+                if (strides != (1, 1) or k not in ((1, 1), (3, 3))) and x.kind != "input":
+                    raise NotImplementedError(f"Conv2D {name}: kernel {k} stride {strides} is only implemented on the input image")
+                if strides[0] != strides[1]:
+                    raise NotImplementedError(f"Conv2D {name}: anisotropic stride {strides}")
                 kern = np.asarray(self.weights[f"{name}/kernel"], np.float32)
                 cin, cout = kern.shape[2], kern.shape[3]
-                x = ins[0]
+                t_alias.clear()
                 if k == (1, 1) and name in self.output_names:
                     act = {"linear": 0, "sigmoid": 1}.get(c.get("activation", "linear"))
                     if act is None:
@@ -164,10 +219,10 @@ class DeviceNetwork:
                     plan.append(("head", s, o, upload_f32(w), upload_f32(bias), act))
                     t[name] = o
                     continue
-                if k != (3, 3):
+                if k != (3, 3) and x.kind != "input":
                     raise NotImplementedError(f"Conv2D {name}: kernel {k} not implemented")
-                out_name, relu = conv_activation(l)
                 coutp = _pad16(cout)
+                out_name, relu, ext = conv_epilogue(l, coutp)
                 bias = padded_bias(name, cout, coutp, c.get("use_bias", True))
                 # consumers: MaxPooling2D(2) consumers are served by a pooled copy written by this conv's epilogue
                 consumers = [by_name[n] for n in cons.get(out_name, [])]
@@ -176,9 +231,18 @@ class DeviceNetwork:
                 need_full = (len(pools) != len(consumers)) or out_name in self.output_names or not consumers
                 o = _T("real", cout, x.num, x.den)  # its buffer is allocated below, only if someone reads it
                 o_pool = None
-                if x.kind == "input":
-                    if cin not in (1, 3):
-                        raise NotImplementedError("stem conv needs 1 or 3 input channels")
+                if x.kind == "input" and (k != (3, 3) or strides != (1, 1) or ext is not None or cin not in (1, 3)):
+                    # general first-layer conv on the raw image (hourglass stem: k7 s2 + ReLU + BN)
+                    o = _T("real", cout, x.num, x.den * strides[0], buf=new_buf(coutp, x.num, x.den * strides[0], "bf16"))
+                    w = np.zeros((k[0], k[1], cin, coutp), np.float32)
+                    w[..., :cout] = kern
+                    if 4 * w.size > 64 * 1024:
+                        raise NotImplementedError(f"Conv2D {name}: first-layer weights exceed the 64 KiB LDS budget")
+                    if ext is not None and ext["relu_last"]:
+                        raise NotImplementedError(f"Conv2D {name}: BN+ReLU after the first-layer conv")
+                    plan.append(["imgconv", o, upload_f32(w), bias, cin, relu, name, k, strides[0],
+                                 ext["ps"] if ext else None, ext["pt"] if ext else None])
+                elif x.kind == "input":
                     w = np.zeros((3, 3, cin, coutp), np.float32)
                     w[..., :cout] = kern
                     o.buf = new_buf(coutp, x.num, x.den, "bf16")
@@ -194,7 +258,7 @@ class DeviceNetwork:
                             s1, mode = materialize(p1.src), _lib.SRC1_UPSAMPLE2X
                         else:
                             s1, mode = materialize(p1), _lib.SRC1_DIRECT
-                    elif x.kind == "pool":
+                    elif x.kind == "pool" and ext is None:
                         s0, mode = materialize(x.src), _lib.SRC0_POOL2X
                     else:
                         s0 = materialize(x)
@@ -216,9 +280,14 @@ class DeviceNetwork:
                     check(h.sa_pack_conv3x3_weights(kc.ctypes.data_as(C.c_void_p), c0, c0p, c1, c1p, cout, coutp,
                                                     packed.ctypes.data_as(C.c_void_p)), "sa_pack_conv3x3_weights")
                     wdev = torch.from_numpy(packed.view(np.int16)).to(dev)
-                    plan.append(["conv", s0, s1, mode, wdev, bias, o, relu, o_pool, need_full, [], name])
+                    plan.append(["conv", s0, s1, mode, wdev, bias, o, relu, o_pool, need_full, [], name, ext])
+                    conv_of[id(o)] = plan[-1]
                 t[out_name] = o
                 t[name] = o
+                for a in t_alias:
+                    t[a] = o
+                self.round_points.add(out_name)
+                round_of[id(o)] = out_name
             elif cn == "Conv2DTranspose":
                 if tuple(c["kernel_size"]) != (3, 3) or tuple(c["strides"]) != (2, 2) or c["padding"] != "same":
                     raise NotImplementedError(f"Conv2DTranspose {name}: only k3 s2 same is implemented")
@@ -235,6 +304,7 @@ class DeviceNetwork:
                 plan.append(("convt", s, wb, bias, o, relu))
                 t[out_name] = o
                 t[name] = o
+                self.round_points.add(out_name)
             elif cn == "Activation":
                 raise NotImplementedError(f"standalone Activation {name} (not fused into a conv)")
             elif cn == "MaxPooling2D":
@@ -247,8 +317,76 @@ class DeviceNetwork:
                     raise NotImplementedError(f"UpSampling2D {name}: only x2 is implemented")
                 x = ins[0]
                 t[name] = _T("up", x.c, x.num * 2, x.den, src=x, interp=c.get("interpolation", "nearest"))
+                if c.get("interpolation", "nearest") == "bilinear":
+                    self.round_points.add(name)
             elif cn == "Concatenate":
                 t[name] = _T("concat", sum(i.c for i in ins), ins[0].num, ins[0].den, parts=ins)
+            elif cn == "Add":
+                if len(ins) != 2 or ins[0].c != ins[1].c:
+                    raise NotImplementedError(f"Add {name}: needs two inputs with equal channels")
+                in_names = [n[0] for n in l["inbound_nodes"][0]]
+                # fold the addition into the epilogue of the conv that produced the later operand when this Add is
+                # that tensor's only reader; the other operand (possibly UpSampling2D(nearest) of a half-resolution
+                # tensor, read with (y>>1, x>>1)) becomes the residual
+                fused = False
+                for i in (1, 0):
+                    a, b = ins[i], ins[1 - i]
+                    op = conv_of.get(id(a)) if a.kind == "real" else None
+                    if op is None or cons.get(in_names[i], []) != [name] or op[10] or op[8] is not None:
+                        continue
+                    if op[3] not in (_lib.SRC1_NONE, _lib.SRC1_DIRECT):
+                        continue
+                    if op[12] is not None and (op[12]["relu_last"] or op[12]["res"] is not None):
+                        continue
+                    # the residual must exist before the conv runs: kernels emitted to materialise it are moved in
+                    # front of the conv; an operand written by a later op can not be folded
+                    idx, n0 = next(i for i, q in enumerate(plan) if q is op), len(plan)
+                    if b.kind == "up" and b.interp == "nearest":
+                        res, res_mode = materialize(b.src), 1
+                    else:
+                        res, res_mode = materialize(b), 0
+                    moved = plan[n0:]
+                    del plan[n0:]
+                    plan[idx:idx] = moved
+                    idx += len(moved)
+                    if any(self._writes(q, res) for q in plan[idx:]):
+                        continue
+                    if op[12] is None:
+                        one = np.ones((a.cp,), np.float32)
+                        op[12] = {"ps": upload_f32(one), "pt": upload_f32(0 * one), "res": None, "res_mode": 0, "relu_last": 0}
+                    op[12]["res"], op[12]["res_mode"] = res, res_mode
+                    self.round_points.discard(round_of[id(a)])
+                    act = sole_consumer(name, "Activation")
+                    if act is not None and act["config"]["activation"] == "relu":
+                        op[12]["relu_last"] = 1
+                        skip.add(act["name"])
+                        t[act["name"]] = a
+                    round_of[id(a)] = act["name"] if op[12]["relu_last"] else name
+                    self.round_points.add(round_of[id(a)])
+                    t[name] = a
+                    fused = True
+                    break
+                if not fused:
+                    a, b, half = ins[0], ins[1], 0
+                    if a.kind == "up" and a.interp == "nearest" and b.kind != "up":
+                        a, b = b, a
+                    a = materialize(a)
+                    if b.kind == "up" and b.interp == "nearest":
+                        b, half = materialize(b.src), 1
+                    else:
+                        b = materialize(b)
+                    relu = 0
+                    act = sole_consumer(name, "Activation")
+                    o = _T("real", a.c, a.num, a.den, buf=new_buf(a.cp, a.num, a.den, "bf16"))
+                    if act is not None and act["config"]["activation"] == "relu":
+                        relu = 1
+                        skip.add(act["name"])
+                        t[act["name"]] = o
+                    plan.append(("add", a, b, half, relu, o))
+                    t[name] = o
+                    self.round_points.add(act["name"] if relu else name)
+            elif cn == "BatchNormalization":
+                raise NotImplementedError(f"BatchNormalization {name} does not directly follow a Conv2D")
             else:
                 raise NotImplementedError(f"Keras layer {cn} ({name}) is not implemented in the HIP engine")
         plan = self._fuse_heads(plan) if self.fuse_heads else plan
@@ -256,20 +394,36 @@ class DeviceNetwork:
         self.outputs = []
         for n in self.output_names:
             o = t[n]
-            if o.kind != "f32out":
-                raise NotImplementedError(f"model output {n} is not a 1x1 linear head")
+            if o.kind == "real" and o.buf is not None:
+                pass  # backbone feature output (bf16 in HBM); forward() hands back an fp32 copy
+            elif o.kind != "f32out":
+                raise NotImplementedError(f"model output {n} is neither a 1x1 head nor a stored feature tensor")
             self.outputs.append(o)
         self.n_buf = n_buf[0]
         # reduce fractions for stride bookkeeping
         self.max_stride = max(den // max(num, 1) for (_, num, den, _) in self.buf_meta.values())
 
     @staticmethod
+    def _writes(op, tensor):
+        k = op[0]
+        outs = {"conv": (6, 8), "stem": (1,), "imgconv": (1,), "pool": (2,), "up": (2,), "convt": (4,), "add": (5,),
+                "head": (2,)}.get(k)
+        if k == "stem2":
+            return DeviceNetwork._writes(op[2], tensor)
+        return any(op[i] is tensor for i in outs)
+
+    @staticmethod
     def _reads(op):
         k = op[0]
         if k == "conv":
-            return [t for t in (op[1], op[2]) if t is not None]
+            r = [t for t in (op[1], op[2]) if t is not None]
+            if op[12] is not None and op[12]["res"] is not None:
+                r.append(op[12]["res"])
+            return r
         if k in ("head", "pool", "up", "convt"):
             return [op[1]]
+        if k == "add":
+            return [op[1], op[2]]
         return []
 
     def _fuse_heads(self, plan):
@@ -282,7 +436,7 @@ class DeviceNetwork:
             if op[0] == "head":
                 prod = convs.get(id(op[1]))
                 if (prod is not None and prod[3] in (_lib.SRC1_NONE, _lib.SRC1_DIRECT) and prod[6].cp <= 128
-                        and len(prod[10]) < 2 and op[2].c <= 32):
+                        and len(prod[10]) < 2 and op[2].c <= 32 and prod[12] is None):
                     prod[10].append(op)
                     continue
             out.append(op)
@@ -308,7 +462,8 @@ class DeviceNetwork:
             if len(readers) != 1 or readers[0][0] != "conv":
                 continue
             cv = readers[0]
-            if cv[1] is not so or cv[2] is not None or cv[3] != _lib.SRC1_NONE or cv[10] or so.cp not in (16, 32) or cv[6].cp > 64:
+            if cv[1] is not so or cv[2] is not None or cv[3] != _lib.SRC1_NONE or cv[10] or so.cp not in (16, 32) or cv[6].cp > 64 \
+                    or cv[12] is not None:
                 continue
             w1_16 = None
             if so.cp == 16 and cv[6].cp == 16:  # register-resident 16x16x32 MFMA specialisation (uint8 input)
@@ -322,8 +477,8 @@ class DeviceNetwork:
                 check(h.sa_stem16_pack(vp(k0), vp(b0), k0.shape[2], k0.shape[3], vp(k1), vp(b1), k1.shape[3], vp(blob)),
                       "sa_stem16_pack")
                 w1_16 = torch.from_numpy(blob).to(self.device)
-            out[out.index(cv)] = ["stem2", op, cv, w1_16]
-            out.remove(op)
+            out[next(i for i, q in enumerate(out) if q is cv)] = ["stem2", op, cv, w1_16]
+            del out[next(i for i, q in enumerate(out) if q is op)]
             self.buf_meta.pop(so.buf, None)
             so.buf = None
         return out
@@ -396,6 +551,10 @@ class DeviceNetwork:
                 o, cin = op[1], op[4]
                 f = 2 * (H * o.num // o.den) * (W * o.num // o.den) * cin * o.c * 9
                 out.append((k, f"stem {cin}->{o.c} @{H * o.num // o.den}", f))
+            elif k == "imgconv":
+                o, cin, kk = op[1], op[4], op[7]
+                f = 2 * (H * o.num // o.den) * (W * o.num // o.den) * cin * o.c * kk[0] * kk[1]
+                out.append(("conv", f"imgconv{kk[0]}x{kk[1]}s{op[8]} {cin}->{o.c} @{H * o.num // o.den}", f))
             elif k == "conv":
                 s0, s1, o = op[1], op[2], op[6]
                 cin = s0.c + (s1.c if s1 is not None else 0)
@@ -403,6 +562,8 @@ class DeviceNetwork:
                 nm = f"conv3x3 {cin}->{o.c} @{H * o.num // o.den} mode{op[3]}"
                 for hd in op[10]:
                     nm += f" +head{hd[2].c}"
+                if op[12] is not None:
+                    nm += " +affine" + (" +res" if op[12]["res"] is not None else "")
                 out.append((k, nm, f))
             elif k == "head":
                 s, o = op[1], op[2]
@@ -437,7 +598,7 @@ class DeviceNetwork:
                 ev0.record()
                 profile.append((ev0, ev1))
             if kind == "stem2":
-                _, (_k, so, w0, b0, cin, relu0, _n0), (_c, _s0, _s1, _m, w1, b1, o, relu1, o_pool, need_full, _hd, _nm), w1_16 = op
+                _, (_k, so, w0, b0, cin, relu0, _n0), (_c, _s0, _s1, _m, w1, b1, o, relu1, o_pool, need_full, _hd, _nm, _ext), w1_16 = op
                 if cin != Cin:
                     raise ValueError(f"model expects {cin} input channels, got {Cin}")
                 is_u8 = 1 if imgs.dtype == torch.uint8 else 0
@@ -464,7 +625,7 @@ class DeviceNetwork:
                 check(h.sa_stem_conv3x3(_ptr(imgs), is_u8, B, H, W, cin, _ptr(w), _ptr(bias), o.cp, relu,
                                         _ptr(bufs[o.buf]), st), "sa_stem_conv3x3")
             elif kind == "conv" and op[10]:
-                _, s0, s1, mode, w, bias, o, relu, o_pool, need_full, heads, _nm = op
+                _, s0, s1, mode, w, bias, o, relu, o_pool, need_full, heads, _nm, _ext = op
                 oh, ow = hw(o)
                 n = len(heads)
                 arr = (C.c_void_p * n)
@@ -479,8 +640,38 @@ class DeviceNetwork:
                                               s1.cp if s1 is not None else 0, mode, _ptr(w), _ptr(bias), o.cp, relu, B, oh,
                                               ow, _ptr(bufs[o.buf]) if need_full else None, n, hw_, hb_, hc_, ha_, hd_, st),
                       "sa_conv3x3_heads_bf16")
+            elif kind == "conv" and op[12] is not None:
+                _, s0, s1, mode, w, bias, o, relu, o_pool, need_full, _heads, _nm, ext = op
+                oh, ow = hw(o)
+                res = ext["res"]
+                check(h.sa_conv3x3_ex_bf16(_ptr(bufs[s0.buf]), s0.cp, _ptr(bufs[s1.buf]) if s1 is not None else None,
+                                           s1.cp if s1 is not None else 0, mode, _ptr(w), _ptr(bias), o.cp, relu, B, oh, ow,
+                                           _ptr(bufs[o.buf]) if need_full else None,
+                                           _ptr(bufs[o_pool.buf]) if o_pool is not None else None,
+                                           _ptr(ext["ps"]), _ptr(ext["pt"]),
+                                           _ptr(bufs[res.buf]) if res is not None else None, ext["res_mode"],
+                                           ext["relu_last"], st), "sa_conv3x3_ex_bf16")
+            elif kind == "imgconv":
+                _, o, w, bias, cin, relu, _nm, k, stride, ps, pt = op
+                if cin != Cin:
+                    raise ValueError(f"model expects {cin} input channels, got {Cin}")
+                is_u8 = 1 if imgs.dtype == torch.uint8 else 0
+                if not is_u8 and imgs.dtype != torch.float32:
+                    raise ValueError("images must be uint8 or float32")
+                oh, ow = hw(o)
+                # TF "SAME": out = ceil(in / s), pad_total = max((out - 1) * s + k - in, 0), pad_before = pad_total // 2
+                pt_ = max((oh - 1) * stride + k[0] - H, 0) // 2
+                pl_ = max((ow - 1) * stride + k[1] - W, 0) // 2
+                check(h.sa_image_conv_bf16(_ptr(imgs), is_u8, B, H, W, cin, k[0], k[1], stride, pt_, pl_, oh, ow, _ptr(w),
+                                           _ptr(bias), o.cp, relu, _ptr(ps) if ps is not None else None,
+                                           _ptr(pt) if pt is not None else None, _ptr(bufs[o.buf]), st), "sa_image_conv_bf16")
+            elif kind == "add":
+                _, a, b, half, relu, o = op
+                oh, ow = hw(o)
+                check(h.sa_add_bf16(_ptr(bufs[a.buf]), _ptr(bufs[b.buf]), B, oh, ow, o.cp, half, relu, _ptr(bufs[o.buf]), st),
+                      "sa_add_bf16")
             elif kind == "conv":
-                _, s0, s1, mode, w, bias, o, relu, o_pool, need_full, _heads, _nm = op
+                _, s0, s1, mode, w, bias, o, relu, o_pool, need_full, _heads, _nm, _ext = op
                 oh, ow = hw(o)
                 check(h.sa_conv3x3_bf16(_ptr(bufs[s0.buf]), s0.cp, _ptr(bufs[s1.buf]) if s1 is not None else None,
                                         s1.cp if s1 is not None else 0, mode, _ptr(w), _ptr(bias), o.cp, relu, B, oh, ow,
@@ -508,7 +699,8 @@ class DeviceNetwork:
                 raise AssertionError(kind)
             if profile is not None:
                 ev1.record()
-        return [bufs[o.buf] for o in self.outputs]
+        from ..ops import from_bf16
+        return [bufs[o.buf] if o.kind == "f32out" else from_bf16(bufs[o.buf], o.c) for o in self.outputs]
 
     def conv_flops(self, H, W):
         """2*H*W*Cin*Cout*k*k over all convs for ONE frame (logical channels)."""
@@ -520,6 +712,9 @@ class DeviceNetwork:
             elif op[0] == "stem":
                 o, cin = op[1], op[4]
                 total += 2 * (H * o.num // o.den) * (W * o.num // o.den) * cin * o.c * 9
+            elif op[0] == "imgconv":
+                o, cin, kk = op[1], op[4], op[7]
+                total += 2 * (H * o.num // o.den) * (W * o.num // o.den) * cin * o.c * kk[0] * kk[1]
             elif op[0] == "conv":
                 s0, s1, o = op[1], op[2], op[6]
                 cin = s0.c + (s1.c if s1 is not None else 0)

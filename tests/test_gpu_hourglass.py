@@ -1,0 +1,217 @@
+"""Hourglass backbone on the device (SURVEY.md §8a row a2'): the extended conv epilogue (BatchNormalization after
+ReLU, residual Add with nearest-neighbour upsampling), the general first-layer conv, and whole-graph parity of
+`build_hourglass_model_config` graphs against the CPU oracle (oracle/keras_graph.py).
+
+Layer tests compare with a plain torch fp32 evaluation of the same op on the same bf16-rounded operands
+(|delta| <= 1e-2 max|ref|: accumulation order + one final bf16 rounding)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _bf(x):
+    return x.to(torch.bfloat16).to(torch.float32)
+
+
+def _padded(v, n, fill=0.0):
+    out = torch.full((n,), fill, dtype=torch.float32)
+    out[: v.numel()] = v
+    return out.cuda()
+
+
+EX_CASES = [
+    # (B, H, W, C0, C1, Cout, affine, residual: 0 none / 1 same res / 2 half res nearest, relu, relu_last, pooled)
+    (2, 16, 32, 32, 0, 32, True, 0, True, False, False),
+    (1, 24, 40, 64, 0, 96, True, 2, True, False, False),
+    (1, 20, 36, 48, 0, 80, True, 1, True, False, False),
+    (2, 16, 32, 16, 0, 16, True, 0, True, False, True),   # BN then fused max pool
+    (1, 18, 34, 32, 32, 64, False, 1, False, True, False),  # ResNet style: linear conv + shortcut, ReLU last
+    (1, 16, 16, 256, 0, 320, True, 2, True, False, False),
+]
+
+
+@pytest.mark.parametrize("B,H,W,C0,C1,Cout,affine,residual,relu,relu_last,pooled", EX_CASES)
+def test_conv3x3_extended_epilogue(B, H, W, C0, C1, Cout, affine, residual, relu, relu_last, pooled):
+    from sleap_amd import _lib, ops
+    from sleap_amd._lib import check
+    from sleap_amd.ops import _ptr, _stream
+
+    g = torch.Generator(device="cpu").manual_seed(H * 100 + C0 + Cout + residual)
+    k = torch.randn((3, 3, C0 + C1, Cout), generator=g) * (2.0 / (9 * (C0 + C1))) ** 0.5
+    bias = torch.randn((Cout,), generator=g) * 0.1
+    x0 = torch.randn((B, H, W, C0), generator=g)
+    x1 = torch.randn((B, H, W, C1), generator=g) if C1 else None
+    scale = 1.0 + 0.3 * torch.randn((Cout,), generator=g)  # negative values matter for BN-before-pool
+    scale[::7] *= -1.0
+    shift = 0.2 * torch.randn((Cout,), generator=g)
+    res = None
+    if residual == 1:
+        res = torch.randn((B, H, W, Cout), generator=g)
+    elif residual == 2:
+        res = torch.randn((B, H // 2, W // 2, Cout), generator=g)
+    # reference
+    rin = _bf(x0) if x1 is None else torch.cat([_bf(x0), _bf(x1)], dim=-1)
+    y = F.conv2d(rin.permute(0, 3, 1, 2), _bf(k).permute(3, 2, 0, 1), bias, padding=1).permute(0, 2, 3, 1)
+    if relu:
+        y = torch.relu(y)
+    if affine:
+        y = y * scale + shift
+    if res is not None:
+        r = _bf(res)
+        if residual == 2:
+            r = r.repeat_interleave(2, dim=1).repeat_interleave(2, dim=2)
+        y = y + r
+    if relu_last:
+        y = torch.relu(y)
+    # device
+    coutp = ops.pad16(Cout)
+    d0 = ops.to_bf16_padded(x0.cuda().contiguous())
+    d1 = ops.to_bf16_padded(x1.cuda().contiguous()) if x1 is not None else None
+    dres = ops.to_bf16_padded(res.cuda().contiguous()) if res is not None else None
+    pw = ops.pack_conv3x3_weights(k.numpy(), C0, C1)
+    bp = _padded(bias, coutp)
+    ps = _padded(scale, coutp, 1.0) if affine else None
+    pt = _padded(shift, coutp) if affine else None
+    out = torch.empty((B, H, W, coutp), dtype=torch.bfloat16, device="cuda")
+    outp = torch.empty((B, H // 2, W // 2, coutp), dtype=torch.bfloat16, device="cuda") if pooled else None
+    check(_lib.lib().sa_conv3x3_ex_bf16(_ptr(d0), d0.shape[3], _ptr(d1), d1.shape[3] if d1 is not None else 0,
+                                        _lib.SRC1_DIRECT if d1 is not None else _lib.SRC1_NONE, _ptr(pw), _ptr(bp), coutp,
+                                        int(relu), B, H, W, _ptr(out), _ptr(outp), _ptr(ps), _ptr(pt), _ptr(dres),
+                                        1 if residual == 2 else 0, int(relu_last), _stream()), "sa_conv3x3_ex_bf16")
+    got = ops.from_bf16(out, Cout).cpu()
+    lim = 1e-2 * float(y.abs().max())
+    assert float((got - y).abs().max()) <= lim, (float((got - y).abs().max()), lim)
+    if pooled:
+        want = F.max_pool2d(out.float().permute(0, 3, 1, 2), 2).permute(0, 2, 3, 1)
+        assert torch.equal(outp.float(), want)
+
+
+@pytest.mark.parametrize("dtype,B,H,W,Cin,Cout,k,stride,relu,affine", [
+    ("u8", 2, 64, 96, 1, 16, 7, 2, True, True),     # hourglass stem
+    ("u8", 1, 50, 38, 3, 24, 7, 2, True, True),     # even sizes, RGB, channel padding
+    ("f32", 1, 33, 47, 1, 16, 3, 1, True, False),
+    ("f32", 2, 32, 32, 1, 32, 5, 1, False, True),
+    ("u8", 1, 40, 40, 1, 8, 1, 1, True, False),
+])
+def test_image_conv_vs_torch(dtype, B, H, W, Cin, Cout, k, stride, relu, affine):
+    """General first-layer conv with TF 'SAME' padding (pad_before = pad_total // 2), fp32 arithmetic."""
+    from sleap_amd import _lib, ops
+    from sleap_amd._lib import check
+    from sleap_amd.ops import _ptr, _stream
+
+    g = torch.Generator(device="cpu").manual_seed(H + W + k)
+    if dtype == "u8":
+        img = torch.randint(0, 256, (B, H, W, Cin), generator=g, dtype=torch.uint8)
+        xf = img.float() * (1.0 / 255.0)
+    else:
+        img = torch.rand((B, H, W, Cin), generator=g)
+        xf = img
+    kern = torch.randn((k, k, Cin, Cout), generator=g) * (2.0 / (k * k * Cin)) ** 0.5
+    bias = 0.1 * torch.randn((Cout,), generator=g)
+    scale = 1.0 + 0.3 * torch.randn((Cout,), generator=g)
+    shift = 0.2 * torch.randn((Cout,), generator=g)
+    Ho, Wo = -(-H // stride), -(-W // stride)
+    ph, pw_ = max((Ho - 1) * stride + k - H, 0), max((Wo - 1) * stride + k - W, 0)
+    xp = F.pad(xf.permute(0, 3, 1, 2), (pw_ // 2, pw_ - pw_ // 2, ph // 2, ph - ph // 2))
+    y = F.conv2d(xp, kern.permute(3, 2, 0, 1), bias, stride=stride).permute(0, 2, 3, 1)
+    if relu:
+        y = torch.relu(y)
+    if affine:
+        y = y * scale + shift
+    assert y.shape[1:3] == (Ho, Wo)
+    coutp = ops.pad16(Cout)
+    w = torch.zeros((k, k, Cin, coutp))
+    w[..., :Cout] = kern
+    dimg, dw, db = img.cuda().contiguous(), w.cuda().contiguous(), _padded(bias, coutp)
+    ps = _padded(scale, coutp, 1.0) if affine else None
+    pt = _padded(shift, coutp) if affine else None
+    out = torch.empty((B, Ho, Wo, coutp), dtype=torch.bfloat16, device="cuda")
+    check(_lib.lib().sa_image_conv_bf16(_ptr(dimg), 1 if dtype == "u8" else 0, B, H, W, Cin, k, k, stride, ph // 2, pw_ // 2,
+                                        Ho, Wo, _ptr(dw), _ptr(db), coutp, int(relu), _ptr(ps), _ptr(pt), _ptr(out),
+                                        _stream()), "sa_image_conv_bf16")
+    got = ops.from_bf16(out, Cout).cpu()
+    # fp32 arithmetic on both sides: only the final bf16 rounding (2^-9 relative) separates them
+    assert float((got - y).abs().max()) <= 2.0 ** -8 * float(y.abs().max())
+    assert float(out.float()[..., Cout:].abs().max()) == 0.0 if coutp > Cout else True
+
+
+@pytest.mark.parametrize("half,relu", [(0, 0), (1, 0), (1, 1)])
+def test_add_vs_torch(half, relu):
+    from sleap_amd import _lib, ops
+    from sleap_amd._lib import check
+    from sleap_amd.ops import _ptr, _stream
+
+    g = torch.Generator(device="cpu").manual_seed(7 + half)
+    a = torch.randn((2, 12, 20, 48), generator=g)
+    b = torch.randn((2, 6, 10, 48) if half else (2, 12, 20, 48), generator=g)
+    da, db = ops.to_bf16_padded(a.cuda()), ops.to_bf16_padded(b.cuda())
+    out = torch.empty_like(da)
+    check(_lib.lib().sa_add_bf16(_ptr(da), _ptr(db), 2, 12, 20, 48, half, relu, _ptr(out), _stream()), "sa_add_bf16")
+    rb = _bf(b)
+    if half:
+        rb = rb.repeat_interleave(2, dim=1).repeat_interleave(2, dim=2)
+    ref = _bf(a) + rb
+    if relu:
+        ref = torch.relu(ref)
+    assert torch.equal(out.float().cpu(), _bf(ref))
+
+
+def _hourglass(h, w, stacks, heads, interp="nearest", seed=1, cin=1):
+    from sleap_amd.nn.architectures import build_hourglass_model_config, he_normal_weights
+
+    cfg, shapes = build_hourglass_model_config((h, w, cin), stem_stride=4, max_stride=32, output_stride=4, stem_filters=16,
+                                               filters=32, filter_increase=16, stacks=stacks, interp_method=interp,
+                                               heads=heads)
+    return cfg, he_normal_weights(shapes, seed=seed)
+
+
+def _parity(cfg, w, x_u8, tol_fp32, tol_bf16):
+    from oracle.keras_graph import KerasGraph, ensure_float
+    from sleap_amd.nn.engine import DeviceNetwork
+
+    net = DeviceNetwork(cfg, w)
+    outs = [o.cpu().numpy() for o in net.forward(torch.from_numpy(x_u8).cuda())]
+    xin = ensure_float(x_u8)
+    res = {}
+    for mode, tol in (("fp32", tol_fp32), ("bf16", tol_bf16)):
+        ref = KerasGraph(cfg, w, emulate_bf16=(mode == "bf16"), round_layers=net.round_points)(xin)
+        assert len(ref) == len(outs)
+        worst = 0.0
+        for o, r in zip(outs, ref):
+            assert o.shape == r.shape
+            worst = max(worst, float(np.abs(o - r).max() / np.abs(r).max()))
+        assert worst <= tol, f"{mode}: {worst:.4g} > {tol}"
+        res[mode] = worst
+    return net, res
+
+
+def test_hourglass_heads_vs_oracle():
+    """1-stack hourglass (stem k7 s2 + BN everywhere + nearest-upsample Add skips) with the bottom-up heads:
+    max|delta|/max|ref| <= 3e-2 vs the fp32 oracle and <= 2e-2 vs the oracle rounding to bf16 at the engine's
+    storage points. The whole decoder runs without a standalone upsample / add / pool launch."""
+    cfg, w = _hourglass(128, 160, 1, [("MultiInstanceConfmapsHead", 13, 4), ("PartAffinityFieldsHead", 24, 4)])
+    rng = np.random.default_rng(0)
+    net, _ = _parity(cfg, w, rng.integers(0, 256, (2, 128, 160, 1), dtype=np.uint8), 3e-2, 2e-2)
+    kinds = [op[0] for op in net.plan]
+    assert "add" not in kinds and "up" not in kinds and "pool" not in kinds, kinds
+
+
+def test_hourglass_stacked_features_vs_oracle():
+    """2-stack hourglass without heads (what the reference's own architecture test builds): both stack outputs."""
+    cfg, w = _hourglass(96, 96, 2, [])
+    rng = np.random.default_rng(1)
+    net, _ = _parity(cfg, w, rng.integers(0, 256, (1, 96, 96, 1), dtype=np.uint8), 4e-2, 2e-2)
+    assert len(net.outputs) == 2
+
+
+def test_hourglass_bilinear_rgb_vs_oracle():
+    """UpsamplingBlock's other interpolation (hourglass.py:160) + RGB input: bilinear upsample materialised,
+    the Add still folds into the skip conv (same-resolution residual)."""
+    cfg, w = _hourglass(64, 96, 1, [("SingleInstanceConfmapsHead", 5, 4)], interp="bilinear", cin=3)
+    rng = np.random.default_rng(2)
+    net, _ = _parity(cfg, w, rng.integers(0, 256, (2, 64, 96, 3), dtype=np.uint8), 3e-2, 2e-2)
+    kinds = [op[0] for op in net.plan]
+    assert "add" not in kinds and "up" in kinds
