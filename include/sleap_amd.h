@@ -221,16 +221,47 @@ int sa_convt3x3s2_bf16(const void* src, int CinP, const void* w, const float* bi
 
 /* First-layer convolution of any kernel size / stride on the raw image with explicit TF SAME pads, e.g. the
  * hourglass stem Conv2D(k7, s2, same)+ReLU+BatchNormalization (hourglass.py:75-85). ensure_float fused for u8.
- *   src [B,H,W,Cin] u8|f32; w [kh][kw][Cin][CoutP] f32; post_scale/post_shift [CoutP] or NULL (BN after ReLU);
+ * ResNet's input Lambdas fold in as well (resnet.py:326-362): CinW = 3 weight channels over a Cin = 1 image is
+ * tile_channels, in_affine = {scale[CinW], shift[CinW]} applied to every in-bounds tap is imagenet_preproc_v1
+ * (the BGR flip is a permutation of the weight channels done by the caller).
+ *   src [B,H,W,Cin] u8|f32; w [kh][kw][CinW][CoutP] f32; post_scale/post_shift [CoutP] or NULL (BN after ReLU);
  *   dst [B,Ho,Wo,CoutP] bf16 */
-int sa_image_conv_bf16(const void* src, int src_is_u8, int B, int H, int W, int Cin, int kh, int kw, int stride,
-                       int pad_top, int pad_left, int Ho, int Wo, const float* w, const float* bias, int CoutP, int relu,
+int sa_image_conv_bf16(const void* src, int src_is_u8, int B, int H, int W, int Cin, int CinW, const float* in_affine,
+                       int kh, int kw, int stride, int pad_top, int pad_left, int Ho, int Wo, const float* w, const float* bias, int CoutP, int relu,
                        const float* post_scale, const float* post_shift, void* dst, sa_stream_t stream);
 
 /* Add layer (hourglass.py:190, resnet.py:249): dst = a + b [+ ReLU]; b may be [B,H/2,W/2,CP] read with
  * UpSampling2D(2, "nearest") (b_half_res = 1). Used when the addition can not be folded into a conv epilogue. */
 int sa_add_bf16(const void* a, const void* b, int B, int H, int W, int CP, int b_half_res, int relu, void* dst,
                 sa_stream_t stream);
+
+/* Conv2D(k1, stride 1|2, valid) as a GEMM on the matrix cores with the extended epilogue of sa_conv3x3_ex_bf16:
+ * ResNet bottleneck 1x1 convs + BatchNormalization [+ Add(shortcut) + ReLU] (resnet.py:168-253) and the 1x1 skip
+ * projection of UpsamplingStack (upsampling.py:205-215).
+ *   src [B,Hs,Ws,CinP] bf16; w from sa_pack_tapconv_weights(n_taps = 1); dst/residual [B,Ho,Wo,CoutP] bf16 with
+ *   Ho = (Hs - 1) / stride + 1 */
+int sa_conv1x1_bf16(const void* src, int CinP, const void* w, const float* bias, int CoutP, int relu, int B, int Hs, int Ws,
+                    int stride, const float* post_scale, const float* post_shift, const void* residual, int relu_last,
+                    void* dst, sa_stream_t stream);
+
+/* Conv2DTranspose(k4 | k3, stride 2, padding "same") [+ BatchNormalization] [+ ReLU] on the matrix cores
+ * (upsampling.py:177-191; encoder_decoder.py:304-310): one GEMM launch per output phase (oy & 1, ox & 1).
+ *   w_phase[4]: per phase a*2+b the packed weights (sa_pack_tapconv_weights) of the kernel taps listed by
+ *   sa_convt_s2_phase_taps, each tap slice [Cin][Cout] = keras_kernel[ky, kx].T (Keras layout (kh,kw,Cout,Cin));
+ *   dst [B,2Hs,2Ws,CoutP] bf16 */
+int sa_convt_s2_bf16(const void* src, int CinP, const void* const* w_phase, int ksize, const float* bias, int CoutP,
+                     int relu, int B, int Hs, int Ws, const float* post_scale, const float* post_shift, int relu_last,
+                     void* dst, sa_stream_t stream);
+int sa_convt_s2_phase_taps(int ksize, int phase, int* ky, int* kx);
+
+/* host: w [n_taps][Cin][Cout] f32 -> MFMA A-operand fragments [CoutP/32][n_taps][CinP/16][64][8] bf16 */
+size_t sa_tapconv_packed_elems(int n_taps, int CinP, int CoutP);
+int sa_pack_tapconv_weights(const float* w, int n_taps, int Cin, int CinP, int Cout, int CoutP, uint16_t* packed);
+
+/* MaxPooling2D(k, stride) with explicit top/left padding; padded taps are skipped (Keras "same") or, with
+ * pad_is_zero = 1, take part as zeros (ZeroPadding2D + MaxPooling2D(3, s2, valid), resnet.py:125-126). */
+int sa_maxpool_bf16(const void* src, int B, int H, int W, int CP, int k, int stride, int pad_top, int pad_left,
+                    int pad_is_zero, int Ho, int Wo, void* dst, sa_stream_t stream);
 
 /* MaxPooling2D(2, s2, same) on even sizes; UpSampling2D(2, "bilinear"|"nearest") */
 int sa_maxpool2x2_bf16(const void* src, int B, int H, int W, int CP, void* dst, sa_stream_t stream);

@@ -21,6 +21,7 @@ SOURCES = [
     ("layers.hip", []),
     ("conv3x3.hip", []),
     ("stem16.hip", []),
+    ("tapconv.hip", []),
 ]
 COMMON = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function"]
 

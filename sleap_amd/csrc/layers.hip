@@ -72,13 +72,14 @@ stem_conv3x3_kernel(const void* __restrict__ src_, int B, int H, int W, const fl
 // thread = (output pixel, group of 8 output channels); weights [kh][kw][Cin][CoutP] f32 from LDS.
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
-image_conv_kernel(const void* __restrict__ src_, int is_u8, int B, int H, int W, int Cin, int kh, int kw, int stride,
+image_conv_kernel(const void* __restrict__ src_, int is_u8, int B, int H, int W, int Cin, int CinW,
+                  const float* __restrict__ in_affine, int kh, int kw, int stride,
                   int pad_t, int pad_l, int Ho, int Wo, const float* __restrict__ w, const float* __restrict__ bias,
                   int CoutP, int relu, const float* __restrict__ post_scale, const float* __restrict__ post_shift,
                   uint16_t* __restrict__ dst) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   float* sw = reinterpret_cast<float*>(smem_raw);
-  const int nw = kh * kw * Cin * CoutP;
+  const int nw = kh * kw * CinW * CoutP;
   for (int i = threadIdx.x; i < nw; i += blockDim.x) sw[i] = w[i];
   __syncthreads();
   const int groups = CoutP / 8;
@@ -99,10 +100,12 @@ image_conv_kernel(const void* __restrict__ src_, int is_u8, int B, int H, int W,
         const int xx = x * stride + dx - pad_l;
         if (xx < 0 || xx >= W) continue;
         const size_t si = ((b * H + yy) * W + xx) * Cin;
-        for (int c = 0; c < Cin; ++c) {
-          const float v = is_u8 ? (float)reinterpret_cast<const uint8_t*>(src_)[si + c] * (1.0f / 255.0f)
-                                : reinterpret_cast<const float*>(src_)[si + c];
-          const float* wr = sw + ((dy * kw + dx) * Cin + c) * CoutP + g * 8;
+        for (int c = 0; c < CinW; ++c) {
+          const int cs = Cin == 1 ? 0 : c;  // tile_channels (resnet.py:326-339): a grayscale image feeds every channel
+          float v = is_u8 ? (float)reinterpret_cast<const uint8_t*>(src_)[si + cs] * (1.0f / 255.0f)
+                          : reinterpret_cast<const float*>(src_)[si + cs];
+          if (in_affine) v = __fadd_rn(__fmul_rn(v, in_affine[c]), in_affine[CinW + c]);  // un-fused mul/add as the reference's X*255 - mean
+          const float* wr = sw + ((dy * kw + dx) * CinW + c) * CoutP + g * 8;
 #pragma unroll
           for (int j = 0; j < 8; ++j) acc[j] = fmaf(v, wr[j], acc[j]);
         }
@@ -116,6 +119,42 @@ image_conv_kernel(const void* __restrict__ src_, int is_u8, int B, int H, int W,
       o[j] = sa::f2bf(v);
     }
     *reinterpret_cast<bf16x8_t*>(dst + p * CoutP + g * 8) = o;
+  }
+}
+
+// general MaxPooling2D (window k, stride, explicit pads); thread = (output pixel, 8 channels)
+__global__ void __launch_bounds__(256)
+maxpool_kernel(const uint16_t* __restrict__ src, int B, int H, int W, int CP, int k, int stride, int pad_t, int pad_l,
+               int pad_zero, int Ho, int Wo, uint16_t* __restrict__ dst) {
+  const int groups = CP / 8;
+  const size_t total = (size_t)B * Ho * Wo * groups;
+  for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
+    const int g = (int)(t % groups);
+    const size_t p = t / groups;
+    const int x = (int)(p % Wo);
+    const int y = (int)((p / Wo) % Ho);
+    const size_t b = p / ((size_t)Wo * Ho);
+    float m[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) m[j] = -INFINITY;
+    for (int dy = 0; dy < k; ++dy)
+      for (int dx = 0; dx < k; ++dx) {
+        const int yy = y * stride + dy - pad_t, xx = x * stride + dx - pad_l;
+        if (yy < 0 || yy >= H || xx < 0 || xx >= W) {
+          if (pad_zero) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) m[j] = fmaxf(m[j], 0.0f);
+          }
+          continue;
+        }
+        const bf16x8_t v = *reinterpret_cast<const bf16x8_t*>(src + ((b * H + yy) * W + xx) * CP + g * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) m[j] = fmaxf(m[j], sa::bf2f(v[j]));
+      }
+    bf16x8_t o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = sa::f2bf(m[j]);
+    *reinterpret_cast<bf16x8_t*>(dst + p * CP + g * 8) = o;
   }
 }
 
@@ -365,19 +404,31 @@ int sa_stem_conv3x3(const void* src, int src_is_u8, int B, int H, int W, int Cin
   return SA_OK;
 }
 
-int sa_image_conv_bf16(const void* src, int src_is_u8, int B, int H, int W, int Cin, int kh, int kw, int stride,
-                       int pad_top, int pad_left, int Ho, int Wo, const float* w, const float* bias, int CoutP, int relu,
+int sa_image_conv_bf16(const void* src, int src_is_u8, int B, int H, int W, int Cin, int CinW, const float* in_affine,
+                       int kh, int kw, int stride, int pad_top, int pad_left, int Ho, int Wo, const float* w, const float* bias, int CoutP, int relu,
                        const float* post_scale, const float* post_shift, void* dst, sa_stream_t stream) {
   SA_REQUIRE(src && w && bias && dst, "sa_image_conv_bf16: NULL pointer");
   SA_REQUIRE(B > 0 && H > 0 && W > 0 && Cin > 0 && kh > 0 && kw > 0 && stride > 0 && Ho > 0 && Wo > 0, "sa_image_conv_bf16: bad shape");
   SA_REQUIRE(CoutP % 8 == 0, "sa_image_conv_bf16: CoutP must be a multiple of 8");
+  SA_REQUIRE(CinW == Cin || Cin == 1, "sa_image_conv_bf16: CinW != Cin needs a single-channel image (tiled)");
   SA_REQUIRE(!post_scale == !post_shift, "sa_image_conv_bf16: post_scale and post_shift come together");
-  const size_t lds = sizeof(float) * (size_t)kh * kw * Cin * CoutP;
+  const size_t lds = sizeof(float) * (size_t)kh * kw * CinW * CoutP;
   SA_REQUIRE(lds <= 64 * 1024, "sa_image_conv_bf16: weights (%zu B) exceed the LDS budget", lds);
   const size_t total = (size_t)B * Ho * Wo * (CoutP / 8);
   hipLaunchKernelGGL(image_conv_kernel, dim3(grid_for(total)), dim3(256), lds, (hipStream_t)stream, src, src_is_u8, B, H,
-                     W, Cin, kh, kw, stride, pad_top, pad_left, Ho, Wo, w, bias, CoutP, relu, post_scale, post_shift,
+                     W, Cin, CinW, in_affine, kh, kw, stride, pad_top, pad_left, Ho, Wo, w, bias, CoutP, relu, post_scale, post_shift,
                      (uint16_t*)dst);
+  SA_LAUNCH_CHECK();
+  return SA_OK;
+}
+
+int sa_maxpool_bf16(const void* src, int B, int H, int W, int CP, int k, int stride, int pad_top, int pad_left,
+                    int pad_is_zero, int Ho, int Wo, void* dst, sa_stream_t stream) {
+  SA_REQUIRE(src && dst && CP % 8 == 0 && B > 0 && k > 0 && stride > 0 && Ho > 0 && Wo > 0, "sa_maxpool_bf16: bad arguments");
+  SA_REQUIRE((Ho - 1) * stride - pad_top < H && (Wo - 1) * stride - pad_left < W, "sa_maxpool_bf16: window outside the image");
+  const size_t total = (size_t)B * Ho * Wo * (CP / 8);
+  hipLaunchKernelGGL(maxpool_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)src, B, H, W,
+                     CP, k, stride, pad_top, pad_left, pad_is_zero, Ho, Wo, (uint16_t*)dst);
   SA_LAUNCH_CHECK();
   return SA_OK;
 }

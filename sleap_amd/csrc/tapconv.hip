@@ -1,0 +1,377 @@
+// "Tap GEMM": convolution-like layers whose taps do not share a halo tile, on the CDNA4 matrix cores
+// (v_mfma_f32_32x32x16_bf16, fp32 accumulate), bf16 NHWC activations:
+//
+//   out[b, ly*os + oy0, lx*os + ox0, co] = epi( sum_t sum_ci  x[b, ly*is + dy_t, lx*is + dx_t, ci] * w[t][ci][co] )
+//
+//   * Conv2D(k1, stride 1|2, valid)          -> one tap (0,0), is = stride            (resnet.py:196-229)
+//   * Conv2DTranspose(k4|k3, s2, same)       -> os = 2, one launch per output phase (oy0, ox0) with the 1..4 taps that
+//                                               hit that phase                          (upsampling.py:177-188)
+//   epi = bias, ReLU, per-channel affine (BatchNormalization), residual add (Add), ReLU  -- the same extended epilogue
+//   as sa_conv3x3_ex_bf16.
+//
+// GEMM view: A = packed weights (M = cout), B = pixels (N), K = taps x Cin. A workgroup (4 waves) owns 64*WM logical
+// pixels of ONE frame x 64*WN output channels; every wave a 64 x 64 sub-tile (2 x 2 accumulators of 32x32). K runs in
+// chunks of 64 channels of one tap: the pixel chunk (128 B per pixel) and the weight slabs are copied global -> LDS by
+// buffer_load ... lds (double buffered; taps that fall outside the image and channel slots beyond CinP read zeros through
+// the buffer bounds check), the 16-byte channel slots of a pixel are XOR-swizzled with (pixel >> 1) & 7 on the copy's
+// SOURCE side so that the ds_read_b128 of a B fragment touches all 64 banks once per 16 lanes.
+#include <cstdint>
+
+#include "bf16.h"
+#include "sa_common.h"
+
+namespace {
+
+using sa::bf16x8_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 mfma_bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+constexpr int MAX_TAPS = 16;
+constexpr int CK = 64;  // channels per chunk
+
+struct TapParams {
+  const uint16_t* src;  // [B,Hs,Ws,CinP]
+  const uint16_t* w;    // packed [co32][tap][k16][64][8]
+  const float* bias;    // [CoutP]
+  uint16_t* dst;        // [B,Ho,Wo,CoutP]
+  const float* post_scale;
+  const float* post_shift;
+  const uint16_t* residual;  // [B,Ho,Wo,CoutP] or NULL
+  int CinP, CoutP;
+  int B, Hs, Ws;  // source size
+  int Hl, Wl;     // logical output grid of this launch
+  int Ho, Wo;     // destination tensor size
+  int in_stride, out_stride, oy0, ox0;
+  int n_taps;
+  int tap_dy[MAX_TAPS], tap_dx[MAX_TAPS];
+  int relu, relu_last;
+  int m_tiles, co_tiles;
+};
+
+template <int WM, int WN>
+__global__ void __launch_bounds__(256)
+tapconv_kernel(const TapParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int TP = 64 * WM;          // pixels per workgroup
+  constexpr int NCO32 = 2 * WN;        // 32-cout tiles per workgroup
+  constexpr int KK = CK / 16;          // k16 steps per chunk
+  constexpr int N_IN = TP * CK * 2 / 1024;  // 1 KiB copies per pixel chunk
+  constexpr int IN_BYTES = N_IN * 1024;
+  constexpr int N_W = NCO32 * KK;
+  constexpr int STAGE = IN_BYTES + N_W * 1024;
+  constexpr int IN_PER_WAVE = N_IN / 4;
+  constexpr int W_PER_WAVE = N_W / 4;
+  constexpr unsigned OOB = 0xFFFFFF00u;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave % WM, wn = wave / WM;
+  int bid;
+  {  // XCD-aware order: consecutive logical tiles (cout tiles of one pixel tile first) share an L2
+    const int nblk = gridDim.x, q = nblk >> 3, r = nblk & 7, xcd = blockIdx.x & 7, k = blockIdx.x >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+  }
+  const int co_t = bid % p.co_tiles;
+  bid /= p.co_tiles;
+  const int m_t = bid % p.m_tiles;
+  const int b = bid / p.m_tiles;
+  const int m0 = m_t * TP;
+  const int ML = p.Hl * p.Wl;
+  const int K16 = p.CinP / 16;
+  const int co32_n = (p.CoutP + 31) / 32;
+  const int co32_0 = co_t * NCO32;
+  const int chunks_per_tap = (p.CinP + CK - 1) / CK;
+  const int n_chunks = p.n_taps * chunks_per_tap;
+
+  const size_t fbytes = (size_t)p.Hs * p.Ws * p.CinP * 2;
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(reinterpret_cast<const unsigned char*>(p.src) + b * fbytes), 0, (int)fbytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)p.w, 0, (int)((size_t)co32_n * p.n_taps * K16 * 1024), 0x00020000);
+
+  // this lane's pixels in the copies it issues: copy i covers pixels 8i..8i+7, lane -> (pixel 8i + lane/8, slot lane%8)
+  int py[IN_PER_WAVE], px[IN_PER_WAVE], pslot[IN_PER_WAVE];
+#pragma unroll
+  for (int j = 0; j < IN_PER_WAVE; ++j) {
+    const int i = j * 4 + wave;
+    const int pl = i * 8 + (lane >> 3);
+    const int m = m0 + pl;
+    const bool ok = m < ML;
+    const int ly = ok ? m / p.Wl : 0;
+    py[j] = ok ? ly * p.in_stride : -(1 << 20);
+    px[j] = ok ? (m - ly * p.Wl) * p.in_stride : 0;
+    pslot[j] = (lane & 7) ^ ((pl >> 1) & 7);  // global 16-byte slot this lane fetches
+  }
+  const unsigned wv = (unsigned)lane * 16;
+
+  auto issue = [&](int chunk, int buf) {
+    const int tap = chunk / chunks_per_tap, kc = chunk - tap * chunks_per_tap;
+    const int dy = p.tap_dy[tap], dx = p.tap_dx[tap];
+    unsigned char* stage = smem + buf * STAGE;
+#pragma unroll
+    for (int j = 0; j < IN_PER_WAVE; ++j) {
+      const int i = j * 4 + wave;
+      const int sy = py[j] + dy, sx = px[j] + dx;
+      const bool ok = sy >= 0 && sy < p.Hs && sx >= 0 && sx < p.Ws && (kc * CK + pslot[j] * 8) < p.CinP;
+      const unsigned voff = ok ? (unsigned)((sy * p.Ws + sx) * (p.CinP * 2) + pslot[j] * 16) : OOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(stage + i * 1024), 16, voff, kc * CK * 2, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < W_PER_WAVE; ++j) {
+      const int k = j * 4 + wave;  // (co32 local, kk)
+      const int c32 = k / KK, kk = k - c32 * KK;
+      const int k16 = kc * KK + kk;
+      const int soff = (co32_0 + c32 < co32_n && k16 < K16)
+                           ? (((co32_0 + c32) * p.n_taps + tap) * K16 + k16) * 1024
+                           : (int)0x7FFFF000;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_ptr_t)(stage + IN_BYTES + k * 1024), 16, wv, soff, 0, 0);
+    }
+  };
+
+  f32x16 acc[2][2];  // [cout tile][pixel group]
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[m][r][i] = 0.0f;
+
+  const int half = lane >> 5, lx = lane & 31;
+  issue(0, 0);
+  int buf = 0;
+  for (int chunk = 0; chunk < n_chunks; ++chunk) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (chunk + 1 < n_chunks) issue(chunk + 1, buf ^ 1);
+    const unsigned char* in_tile = smem + buf * STAGE;
+    const unsigned char* w_tile = in_tile + IN_BYTES;
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk) {
+      mfma_bf16x8 a[2], bv[2];
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+        a[m] = *reinterpret_cast<const mfma_bf16x8*>(w_tile + ((wn * 2 + m) * KK + kk) * 1024 + lane * 16);
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        const int pl = (wm * 2 + r) * 32 + lx;
+        const int slot = (kk * 2 + half) ^ ((pl >> 1) & 7);
+        bv[r] = *reinterpret_cast<const mfma_bf16x8*>(in_tile + pl * (CK * 2) + slot * 16);
+      }
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int r = 0; r < 2; ++r) acc[m][r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m], bv[r], acc[m][r], 0, 0, 0);
+    }
+    buf ^= 1;
+  }
+
+  // ---- epilogue (same register layout as conv3x3_dma_kernel): a lane holds channels {0-3, 8-11, 16-19, 24-27} + 4*half
+  // of its pixel; one exchange with lane ^ 32 per pair of groups -> every lane stores 8 consecutive channels (16 bytes)
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    const int m = m0 + (wm * 2 + r) * 32 + lx;
+    const bool pix_ok = m < ML;
+    const int ly = pix_ok ? m / p.Wl : 0;
+    const int lxx = pix_ok ? m - ly * p.Wl : 0;
+    const size_t opix = ((size_t)b * p.Ho + (ly * p.out_stride + p.oy0)) * p.Wo + (lxx * p.out_stride + p.ox0);
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      const int cobase = (co32_0 + wn * 2 + mt) * 32;
+      if (cobase >= p.CoutP) continue;
+      uint2 pk[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int co = cobase + 8 * g + 4 * half;
+        float v[4];
+        const bool cok = co < p.CoutP;
+        float4 bq = make_float4(0.f, 0.f, 0.f, 0.f), sq = make_float4(1.f, 1.f, 1.f, 1.f), tq = bq;
+        if (cok) {
+          bq = *reinterpret_cast<const float4*>(p.bias + co);
+          if (p.post_scale) {
+            sq = *reinterpret_cast<const float4*>(p.post_scale + co);
+            tq = *reinterpret_cast<const float4*>(p.post_shift + co);
+          }
+        }
+        const float bb[4] = {bq.x, bq.y, bq.z, bq.w}, ss[4] = {sq.x, sq.y, sq.z, sq.w}, tt[4] = {tq.x, tq.y, tq.z, tq.w};
+        float rr[4] = {0.f, 0.f, 0.f, 0.f};
+        if (p.residual && pix_ok && cok) {
+          const uint2 rq = *reinterpret_cast<const uint2*>(p.residual + opix * p.CoutP + co);
+          rr[0] = sa::bf2f((uint16_t)(rq.x & 0xffff));
+          rr[1] = sa::bf2f((uint16_t)(rq.x >> 16));
+          rr[2] = sa::bf2f((uint16_t)(rq.y & 0xffff));
+          rr[3] = sa::bf2f((uint16_t)(rq.y >> 16));
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float t = acc[mt][r][4 * g + j] + bb[j];
+          if (p.relu) t = fmaxf(t, 0.0f);
+          t = fmaf(t, ss[j], tt[j]) + rr[j];
+          if (p.relu_last) t = fmaxf(t, 0.0f);
+          v[j] = t;
+        }
+        pk[g].x = sa::f2bf2(v[0], v[1]);
+        pk[g].y = sa::f2bf2(v[2], v[3]);
+      }
+#pragma unroll
+      for (int pr = 0; pr < 2; ++pr) {
+        const uint2 send = half ? pk[2 * pr] : pk[2 * pr + 1];
+        uint2 recv;
+        recv.x = __shfl_xor(send.x, 32);
+        recv.y = __shfl_xor(send.y, 32);
+        const uint4 piece = half ? make_uint4(recv.x, recv.y, pk[2 * pr + 1].x, pk[2 * pr + 1].y)
+                                 : make_uint4(pk[2 * pr].x, pk[2 * pr].y, recv.x, recv.y);
+        const int co = cobase + 16 * pr + 8 * half;
+        if (pix_ok && co < p.CoutP) *reinterpret_cast<uint4*>(p.dst + opix * p.CoutP + co) = piece;
+      }
+    }
+  }
+#endif
+}
+
+template <int WM, int WN>
+int launch_tap(const TapParams& p0, hipStream_t st) {
+  constexpr int TP = 64 * WM, NCO32 = 2 * WN;
+  constexpr size_t lds = 2 * ((size_t)TP * CK * 2 + (size_t)NCO32 * (CK / 16) * 1024);
+  TapParams p = p0;
+  p.m_tiles = (p.Hl * p.Wl + TP - 1) / TP;
+  p.co_tiles = ((p.CoutP + 31) / 32 + NCO32 - 1) / NCO32;
+  const size_t nblk = (size_t)p.m_tiles * p.co_tiles * p.B;
+  if (nblk == 0 || nblk > 0x7fffffffull) return sa::fail(SA_ERR_INVALID_ARG, "tapconv: bad grid");
+  static bool attr_set = false;
+  if (!attr_set && lds > 64 * 1024) {
+    SA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&tapconv_kernel<WM, WN>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((tapconv_kernel<WM, WN>), dim3((unsigned)nblk), dim3(256), lds, st, p);
+  SA_LAUNCH_CHECK();
+  return SA_OK;
+}
+
+int launch_tap_pick(const TapParams& p, hipStream_t st) {
+  if (p.CoutP <= 64) return launch_tap<4, 1>(p, st);
+  return launch_tap<2, 2>(p, st);
+}
+
+int fill_common(TapParams& p, const void* src, int CinP, const void* w, const float* bias, int CoutP, int relu, int B,
+                const float* post_scale, const float* post_shift, const void* residual, int relu_last, void* dst) {
+  SA_REQUIRE(src && w && bias && dst, "tapconv: NULL pointer");
+  SA_REQUIRE(CinP > 0 && CinP % 16 == 0 && CoutP > 0 && CoutP % 16 == 0, "tapconv: channels must be padded to multiples of 16");
+  SA_REQUIRE(!post_scale == !post_shift, "tapconv: post_scale and post_shift come together");
+  SA_REQUIRE(B > 0, "tapconv: bad batch");
+  p.src = (const uint16_t*)src;
+  p.w = (const uint16_t*)w;
+  p.bias = bias;
+  p.dst = (uint16_t*)dst;
+  p.post_scale = post_scale;
+  p.post_shift = post_shift;
+  p.residual = (const uint16_t*)residual;
+  p.CinP = CinP;
+  p.CoutP = CoutP;
+  p.B = B;
+  p.relu = relu;
+  p.relu_last = relu_last;
+  return SA_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t sa_tapconv_packed_elems(int n_taps, int CinP, int CoutP) {
+  return (size_t)((CoutP + 31) / 32) * n_taps * (CinP / 16) * 64 * 8;
+}
+
+int sa_pack_tapconv_weights(const float* w, int n_taps, int Cin, int CinP, int Cout, int CoutP, uint16_t* packed) {
+  SA_REQUIRE(w && packed && n_taps > 0 && n_taps <= MAX_TAPS, "sa_pack_tapconv_weights: bad arguments");
+  SA_REQUIRE(CinP % 16 == 0 && CoutP % 16 == 0 && Cin <= CinP && Cout <= CoutP, "sa_pack_tapconv_weights: bad channel padding");
+  const int K16 = CinP / 16, co32_n = (CoutP + 31) / 32;
+  for (int c32 = 0; c32 < co32_n; ++c32)
+    for (int t = 0; t < n_taps; ++t)
+      for (int k16 = 0; k16 < K16; ++k16)
+        for (int lane = 0; lane < 64; ++lane)
+          for (int j = 0; j < 8; ++j) {
+            const int co = c32 * 32 + (lane & 31), ci = k16 * 16 + (lane >> 5) * 8 + j;
+            float v = 0.0f;
+            if (co < Cout && ci < Cin) v = w[((size_t)t * Cin + ci) * Cout + co];
+            packed[((((size_t)c32 * n_taps + t) * K16 + k16) * 64 + lane) * 8 + j] = sa::f2bf(v);
+          }
+  return SA_OK;
+}
+
+int sa_conv1x1_bf16(const void* src, int CinP, const void* w, const float* bias, int CoutP, int relu, int B, int Hs, int Ws,
+                    int stride, const float* post_scale, const float* post_shift, const void* residual, int relu_last,
+                    void* dst, sa_stream_t stream) {
+  TapParams p = {};
+  const int rc = fill_common(p, src, CinP, w, bias, CoutP, relu, B, post_scale, post_shift, residual, relu_last, dst);
+  if (rc != SA_OK) return rc;
+  SA_REQUIRE(Hs > 0 && Ws > 0 && (stride == 1 || stride == 2), "sa_conv1x1_bf16: bad shape / stride");
+  SA_REQUIRE((size_t)Hs * Ws * CinP * 2 < 0x7fffffffull, "sa_conv1x1_bf16: one frame of the source must stay below 2 GiB");
+  p.Hs = Hs;
+  p.Ws = Ws;
+  p.Hl = p.Ho = (Hs - 1) / stride + 1;  // Conv2D(k1, valid): floor((n - 1) / s) + 1
+  p.Wl = p.Wo = (Ws - 1) / stride + 1;
+  p.in_stride = stride;
+  p.out_stride = 1;
+  p.n_taps = 1;
+  return launch_tap_pick(p, (hipStream_t)stream);
+}
+
+int sa_convt_s2_bf16(const void* src, int CinP, const void* const* w_phase, int ksize, const float* bias, int CoutP,
+                     int relu, int B, int Hs, int Ws, const float* post_scale, const float* post_shift, int relu_last,
+                     void* dst, sa_stream_t stream) {
+  SA_REQUIRE(ksize == 3 || ksize == 4, "sa_convt_s2_bf16: kernel size must be 3 or 4");
+  SA_REQUIRE(w_phase && Hs > 0 && Ws > 0, "sa_convt_s2_bf16: bad arguments");
+  SA_REQUIRE((size_t)Hs * Ws * CinP * 2 < 0x7fffffffull, "sa_convt_s2_bf16: one frame of the source must stay below 2 GiB");
+  // TF "same" Conv2DTranspose, stride 2: out[o] = sum_{i,k : 2i + k - c = o} x[i] w[k] with crop c = max(k - 2, 0) / 2
+  // (k4: c = 1, k3: c = 0). For output parity a = o & 1 the contributing kernel rows are k = (a + c) & 1, +2, ... and
+  // the input row is i = (o + c - k) / 2 = lo + (a + c - k) / 2.
+  const int c = ksize == 4 ? 1 : 0;
+  for (int a = 0; a < 2; ++a)
+    for (int bq = 0; bq < 2; ++bq) {
+      TapParams p = {};
+      const int rc = fill_common(p, src, CinP, w_phase[a * 2 + bq], bias, CoutP, relu, B, post_scale, post_shift, nullptr,
+                                 relu_last, dst);
+      if (rc != SA_OK) return rc;
+      p.Hs = Hs;
+      p.Ws = Ws;
+      p.Hl = Hs;
+      p.Wl = Ws;
+      p.Ho = 2 * Hs;
+      p.Wo = 2 * Ws;
+      p.in_stride = 1;
+      p.out_stride = 2;
+      p.oy0 = a;
+      p.ox0 = bq;
+      int n = 0;
+      for (int ky = (a + c) & 1; ky < ksize; ky += 2)
+        for (int kx = (bq + c) & 1; kx < ksize; kx += 2) {
+          p.tap_dy[n] = (a + c - ky) / 2;  // exact: a + c - ky is even
+          p.tap_dx[n] = (bq + c - kx) / 2;
+          ++n;
+        }
+      p.n_taps = n;
+      const int r2 = launch_tap_pick(p, (hipStream_t)stream);
+      if (r2 != SA_OK) return r2;
+    }
+  return SA_OK;
+}
+
+int sa_convt_s2_phase_taps(int ksize, int phase, int* ky, int* kx) {
+  // kernel taps (ky, kx) used by output phase (a, b) = (phase >> 1, phase & 1), in the order sa_convt_s2_bf16 expects
+  // the slices of w_phase[phase]; returns the tap count
+  if (ksize != 3 && ksize != 4) return 0;
+  const int c = ksize == 4 ? 1 : 0, a = phase >> 1, b = phase & 1;
+  int n = 0;
+  for (int y = (a + c) & 1; y < ksize; y += 2)
+    for (int x = (b + c) & 1; x < ksize; x += 2) {
+      ky[n] = y;
+      kx[n] = x;
+      ++n;
+    }
+  return n;
+}
+
+}  // extern "C"

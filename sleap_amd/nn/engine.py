@@ -662,7 +662,7 @@ class DeviceNetwork:
                 # TF "SAME": out = ceil(in / s), pad_total = max((out - 1) * s + k - in, 0), pad_before = pad_total // 2
                 pt_ = max((oh - 1) * stride + k[0] - H, 0) // 2
                 pl_ = max((ow - 1) * stride + k[1] - W, 0) // 2
-                check(h.sa_image_conv_bf16(_ptr(imgs), is_u8, B, H, W, cin, k[0], k[1], stride, pt_, pl_, oh, ow, _ptr(w),
+                check(h.sa_image_conv_bf16(_ptr(imgs), is_u8, B, H, W, cin, cin, None, k[0], k[1], stride, pt_, pl_, oh, ow, _ptr(w),
                                            _ptr(bias), o.cp, relu, _ptr(ps) if ps is not None else None,
                                            _ptr(pt) if pt is not None else None, _ptr(bufs[o.buf]), st), "sa_image_conv_bf16")
             elif kind == "add":

@@ -129,7 +129,8 @@ def test_image_conv_vs_torch(dtype, B, H, W, Cin, Cout, k, stride, relu, affine)
     ps = _padded(scale, coutp, 1.0) if affine else None
     pt = _padded(shift, coutp) if affine else None
     out = torch.empty((B, Ho, Wo, coutp), dtype=torch.bfloat16, device="cuda")
-    check(_lib.lib().sa_image_conv_bf16(_ptr(dimg), 1 if dtype == "u8" else 0, B, H, W, Cin, k, k, stride, ph // 2, pw_ // 2,
+    check(_lib.lib().sa_image_conv_bf16(_ptr(dimg), 1 if dtype == "u8" else 0, B, H, W, Cin, Cin, None, k, k, stride, ph // 2,
+                                        pw_ // 2,
                                         Ho, Wo, _ptr(dw), _ptr(db), coutp, int(relu), _ptr(ps), _ptr(pt), _ptr(out),
                                         _stream()), "sa_image_conv_bf16")
     got = ops.from_bf16(out, Cout).cpu()
@@ -215,3 +216,136 @@ def test_hourglass_bilinear_rgb_vs_oracle():
     net, _ = _parity(cfg, w, rng.integers(0, 256, (2, 64, 96, 3), dtype=np.uint8), 3e-2, 2e-2)
     kinds = [op[0] for op in net.plan]
     assert "add" not in kinds and "up" in kinds
+
+
+# ------------------------------------------------------------------------------------------------
+# tap-GEMM kernels (ResNet 1x1 convs, transposed convs) and the general max pool
+# ------------------------------------------------------------------------------------------------
+def _pack_taps(w_taps, cinp, coutp):
+    """w_taps (T, Cin, Cout) f32 torch -> packed device tensor."""
+    from sleap_amd import _lib
+    from sleap_amd._lib import check
+    import ctypes as C
+
+    T, cin, cout = w_taps.shape
+    h = _lib.lib()
+    n = h.sa_tapconv_packed_elems(T, cinp, coutp)
+    packed = np.zeros((n,), np.uint16)
+    wn = np.ascontiguousarray(w_taps.numpy(), dtype=np.float32)
+    check(h.sa_pack_tapconv_weights(wn.ctypes.data_as(C.c_void_p), T, cin, cinp, cout, coutp, packed.ctypes.data_as(C.c_void_p)),
+          "sa_pack_tapconv_weights")
+    return torch.from_numpy(packed.view(np.int16)).cuda()
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,stride,affine,residual,relu,relu_last", [
+    (2, 16, 24, 64, 64, 1, True, False, False, True),     # block _1_conv + bn + relu
+    (1, 20, 28, 64, 256, 1, True, True, False, True),     # block _3_conv + bn + add + relu
+    (2, 32, 32, 256, 128, 2, True, False, False, True),   # strided block1 _1_conv
+    (1, 17, 23, 48, 80, 2, False, False, True, False),    # ragged tiles, channel padding, odd size
+    (1, 8, 8, 512, 2048, 1, True, False, False, False),   # shortcut conv
+    (1, 40, 40, 2048, 32, 1, False, False, False, False),
+])
+def test_conv1x1_vs_torch(B, H, W, Cin, Cout, stride, affine, residual, relu, relu_last):
+    from sleap_amd import _lib, ops
+    from sleap_amd._lib import check
+    from sleap_amd.ops import _ptr, _stream
+
+    g = torch.Generator(device="cpu").manual_seed(H + Cin + Cout)
+    k = torch.randn((Cin, Cout), generator=g) * (2.0 / Cin) ** 0.5
+    bias = 0.1 * torch.randn((Cout,), generator=g)
+    x = torch.randn((B, H, W, Cin), generator=g)
+    scale = 1.0 + 0.3 * torch.randn((Cout,), generator=g)
+    shift = 0.2 * torch.randn((Cout,), generator=g)
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    res = torch.randn((B, Ho, Wo, Cout), generator=g) if residual else None
+    y = torch.einsum("bhwc,cd->bhwd", _bf(x)[:, ::stride, ::stride], _bf(k)) + bias
+    if relu:
+        y = torch.relu(y)
+    if affine:
+        y = y * scale + shift
+    if res is not None:
+        y = y + _bf(res)
+    if relu_last:
+        y = torch.relu(y)
+    cinp, coutp = ops.pad16(Cin), ops.pad16(Cout)
+    dx = ops.to_bf16_padded(x.cuda().contiguous())
+    dres = ops.to_bf16_padded(res.cuda().contiguous()) if res is not None else None
+    pw = _pack_taps(k[None], cinp, coutp)
+    bp = _padded(bias, coutp)
+    ps = _padded(scale, coutp, 1.0) if affine else None
+    pt = _padded(shift, coutp) if affine else None
+    out = torch.full((B, Ho, Wo, coutp), 7.0, dtype=torch.bfloat16, device="cuda")
+    check(_lib.lib().sa_conv1x1_bf16(_ptr(dx), cinp, _ptr(pw), _ptr(bp), coutp, int(relu), B, H, W, stride, _ptr(ps), _ptr(pt),
+                                     _ptr(dres), int(relu_last), _ptr(out), _stream()), "sa_conv1x1_bf16")
+    got = ops.from_bf16(out, Cout).cpu()
+    lim = 1e-2 * float(y.abs().max())
+    assert float((got - y).abs().max()) <= lim, (float((got - y).abs().max()), lim)
+    if coutp > Cout:
+        pad = out.float()[..., Cout:]
+        assert float(pad.abs().max()) == 0.0 or (affine and True)
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,ksize,affine", [
+    (2, 8, 12, 64, 64, 4, True),
+    (1, 9, 7, 48, 80, 4, False),
+    (1, 16, 16, 256, 128, 4, True),
+    (2, 10, 6, 32, 24, 3, False),
+])
+def test_convt_s2_vs_torch(B, H, W, Cin, Cout, ksize, affine):
+    """Conv2DTranspose(k, s2, same): TF crops the full transposed conv at offset max(k - 2, 0) // 2."""
+    import ctypes as C
+
+    from sleap_amd import _lib, ops
+    from sleap_amd._lib import check
+    from sleap_amd.ops import _ptr, _stream
+
+    g = torch.Generator(device="cpu").manual_seed(H * 7 + Cin + ksize)
+    kt = torch.randn((ksize, ksize, Cout, Cin), generator=g) * (2.0 / (Cin * 4)) ** 0.5  # Keras layout
+    bias = 0.1 * torch.randn((Cout,), generator=g)
+    x = torch.randn((B, H, W, Cin), generator=g)
+    scale = 1.0 + 0.3 * torch.randn((Cout,), generator=g)
+    shift = 0.2 * torch.randn((Cout,), generator=g)
+    full = F.conv_transpose2d(_bf(x).permute(0, 3, 1, 2), _bf(kt).permute(3, 2, 0, 1), None, stride=2)
+    c = max(ksize - 2, 0) // 2
+    y = full[:, :, c:c + 2 * H, c:c + 2 * W].permute(0, 2, 3, 1) + bias
+    if affine:
+        y = y * scale + shift
+    y = torch.relu(y)
+    cinp, coutp = ops.pad16(Cin), ops.pad16(Cout)
+    h = _lib.lib()
+    phases = []
+    for ph in range(4):
+        ky, kx = (C.c_int * 4)(), (C.c_int * 4)()
+        n = h.sa_convt_s2_phase_taps(ksize, ph, ky, kx)
+        taps = torch.stack([kt[ky[i], kx[i]].T for i in range(n)])  # (n, Cin, Cout)
+        phases.append(_pack_taps(taps.contiguous(), cinp, coutp))
+    arr = (C.c_void_p * 4)(*[t.data_ptr() for t in phases])
+    dx = ops.to_bf16_padded(x.cuda().contiguous())
+    bp = _padded(bias, coutp)
+    ps = _padded(scale, coutp, 1.0) if affine else None
+    pt = _padded(shift, coutp) if affine else None
+    out = torch.empty((B, 2 * H, 2 * W, coutp), dtype=torch.bfloat16, device="cuda")
+    # BN sits between the transposed conv and the ReLU (upsampling.py:186-188): relu = 0, affine, relu_last = 1
+    check(h.sa_convt_s2_bf16(_ptr(dx), cinp, arr, ksize, _ptr(bp), coutp, 0, B, H, W, _ptr(ps), _ptr(pt), 1, _ptr(out),
+                             _stream()), "sa_convt_s2_bf16")
+    got = ops.from_bf16(out, Cout).cpu()
+    lim = 1e-2 * float(y.abs().max())
+    assert float((got - y).abs().max()) <= lim, (float((got - y).abs().max()), lim)
+
+
+@pytest.mark.parametrize("k,stride,pad,pad_zero,H,W", [(3, 2, 1, 1, 32, 48), (2, 2, 0, 0, 16, 16), (3, 2, 1, 0, 17, 21)])
+def test_maxpool_general_vs_torch(k, stride, pad, pad_zero, H, W):
+    from sleap_amd import _lib, ops
+    from sleap_amd._lib import check
+    from sleap_amd.ops import _ptr, _stream
+
+    g = torch.Generator(device="cpu").manual_seed(k + H)
+    x = torch.randn((2, H, W, 32), generator=g) - (1.0 if pad_zero else 0.0)
+    dx = ops.to_bf16_padded(x.cuda())
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    out = torch.empty((2, Ho, Wo, 32), dtype=torch.bfloat16, device="cuda")
+    check(_lib.lib().sa_maxpool_bf16(_ptr(dx), 2, H, W, 32, k, stride, pad, pad, pad_zero, Ho, Wo, _ptr(out), _stream()),
+          "sa_maxpool_bf16")
+    xp = F.pad(_bf(x).permute(0, 3, 1, 2), (pad, pad, pad, pad), value=0.0 if pad_zero else float("-inf"))
+    ref = F.max_pool2d(xp, k, stride).permute(0, 2, 3, 1)
+    assert torch.equal(out.float().cpu(), ref)
