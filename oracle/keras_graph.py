@@ -191,6 +191,15 @@ class KerasGraph:
             var = w[f"{name}/moving_variance"]
             scale = g / torch.sqrt(var + eps)
             return x * scale.view(1, -1, 1, 1) + (be - mu * scale).view(1, -1, 1, 1)
+        if cn == "Lambda":
+            # the only Lambda layers the reference creates (resnet.py:326-362, 476-483), identified by layer name
+            x = ins[0]
+            if name == "tile_channels":
+                return x.repeat(1, 3, 1, 1)
+            if name == "imagenet_preproc_v1":
+                mean = torch.tensor([103.939, 116.779, 123.68], dtype=torch.float32).view(1, 3, 1, 1)
+                return (x * 255.0).flip(1) - mean
+            raise NotImplementedError(f"Lambda layer {name}")
         if cn == "ZeroPadding2D":
             (pt, pb), (pl, pr) = c["padding"]
             return F.pad(ins[0], (pl, pr, pt, pb))

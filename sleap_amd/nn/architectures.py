@@ -5,6 +5,8 @@ builds with Keras objects:
     sleap/nn/architectures/unet.py:46-278             UNet (stem / encoder / decoder stacks, from_config)
     sleap/nn/architectures/encoder_decoder.py:57-676  SimpleConvBlock, SimpleUpsamplingBlock, make_backbone
     sleap/nn/architectures/hourglass.py:17-316        conv (Conv+ReLU+BN), StemBlock, Downsampling/UpsamplingBlock
+    sleap/nn/architectures/resnet.py:46-541           make_resnet_model, block_v1, stack_v1, make_backbone_fn, ResNetv1
+    sleap/nn/architectures/upsampling.py:118-259      UpsamplingStack.make_stack
     sleap/nn/heads.py:42-62                           Head.make_head (1x1 linear Conv2D named after the head class)
     sleap/nn/model.py:312-364                         Model.make_model (heads attach at matching stride)
 The result has the same schema as `json.loads(h5.attrs["model_config"])` so the engine, the
@@ -214,6 +216,170 @@ def build_hourglass_model_config(input_shape: Tuple[int, int, int], stem_stride:
                 src, sc = x, c
             elif hs in mids_per_stack[0]:
                 src, sc = mids_per_stack[0][hs]
+            else:
+                raise ValueError(f"Could not find a feature activation for output at stride {hs}.")
+            shapes[f"{head_name}/kernel"] = (1, 1, int(sc), int(channels))
+            shapes[f"{head_name}/bias"] = (int(channels),)
+            out_layers.append(_conv(g, src, head_name, channels, k=1))
+    cfg = {"class_name": "Functional",
+           "config": {"name": "model", "layers": g.layers, "input_layers": [["input", 0, 0]],
+                      "output_layers": [[o, 0, 0] for o in out_layers]}}
+    return cfg, shapes
+
+
+RESNET_STACKS = {  # resnet.py:585-588, 639-642, 693-696
+    "ResNet50": [(64, 3, 1, "conv2"), (128, 4, 2, "conv3"), (256, 6, 2, "conv4"), (512, 3, 2, "conv5")],
+    "ResNet101": [(64, 3, 1, "conv2"), (128, 4, 2, "conv3"), (256, 23, 2, "conv4"), (512, 3, 2, "conv5")],
+    "ResNet152": [(64, 3, 1, "conv2"), (128, 8, 2, "conv3"), (256, 36, 2, "conv4"), (512, 3, 2, "conv5")],
+}
+
+
+def build_resnet_model_config(input_shape: Tuple[int, int, int], version: str = "ResNet50",
+                              features_output_stride: int = 32, pretrained: bool = False,
+                              upsampling: Optional[dict] = None,
+                              heads: Sequence[Tuple[str, int, int]] = ()) -> Tuple[dict, Dict[str, tuple]]:
+    """ResNetv1.make_backbone (resnet.py:467-541) [+ UpsamplingStack.make_stack] + Model.make_model.
+
+    `pretrained=True` adds the `tile_channels` (grayscale input) and `imagenet_preproc_v1` Lambda layers (weights are
+    still caller supplied; there is no download). `upsampling` = UpsamplingConfig fields as a dict: `output_stride`,
+    `method` ("transposed_conv" | "interpolation"), `skip_connections` (None | "add" | "concatenate"), `block_stride`,
+    `filters`, `filters_rate`, `refine_convs`, `batch_norm`, `transposed_conv_kernel_size` (config/model.py:515-559).
+    Without `heads` the output is the backbone / upsampling-stack output.
+    """
+    if version not in RESNET_STACKS:
+        raise ValueError(f"Invalid ResNet version in the configuration: {version}")
+    g = _G()
+    shapes: Dict[str, tuple] = {}
+    x = g.add("InputLayer", "input", {"batch_input_shape": [None, input_shape[0], input_shape[1], input_shape[2]]}, [])
+    cur_c = input_shape[2]
+    if pretrained:
+        if cur_c == 1:
+            x = g.add("Lambda", "tile_channels", {"function": "tile_channels"}, [x])
+            cur_c = 3
+        x = g.add("Lambda", "imagenet_preproc_v1", {"function": "imagenet_preproc_v1"}, [x])
+
+    def conv(x, name, cin, f, k, stride=1, padding="valid", dilation=1):
+        shapes[f"{name}/kernel"] = (k, k, int(cin), int(f))
+        shapes[f"{name}/bias"] = (int(f),)
+        return g.add("Conv2D", name, {"filters": int(f), "kernel_size": [k, k], "strides": [stride, stride],
+                                      "padding": padding, "activation": "linear", "use_bias": True,
+                                      "dilation_rate": [dilation, dilation]}, [x])
+
+    def bn(x, name, c, eps):
+        for v in ("gamma", "beta", "moving_mean", "moving_variance"):
+            shapes[f"{name}/{v}"] = (int(c),)
+        return g.add("BatchNormalization", name, {"axis": [3], "momentum": 0.99, "epsilon": eps, "center": True,
+                                                   "scale": True}, [x])
+
+    EPS = 1.001e-5
+    stem_stride1 = 1 if features_output_stride == 1 else 2
+    stem_stride2 = 1 if features_output_stride <= 2 else 2
+    # ---- stem (make_resnet_model, resnet.py:109-129)
+    x = g.add("ZeroPadding2D", "conv1_pad", {"padding": [[3, 3], [3, 3]]}, [x])
+    x = conv(x, "conv1_conv", cur_c, 64, 7, stem_stride1)
+    x = bn(x, "conv1_bn", 64, EPS)
+    x = _relu(g, x, "conv1_relu")
+    cur_c = 64
+    feats = [(stem_stride1, x, cur_c)]
+    x = g.add("ZeroPadding2D", "pool1_pad", {"padding": [[1, 1], [1, 1]]}, [x])
+    x = g.add("MaxPooling2D", "pool1_pool", {"pool_size": [3, 3], "strides": [stem_stride2, stem_stride2],
+                                             "padding": "valid"}, [x])
+    stride = stem_stride1 * stem_stride2
+    feats.append((stride, x, cur_c))
+
+    def block(x, cin, f, name, s=1, dilation=1, conv_shortcut=True):  # block_v1, resnet.py:168-229
+        if conv_shortcut:
+            sc = conv(x, name + "_0_conv", cin, 4 * f, 1, s, dilation=dilation)
+            sc = bn(sc, name + "_0_bn", 4 * f, EPS)
+        else:
+            sc = x
+        y = conv(x, name + "_1_conv", cin, f, 1, s, dilation=dilation)
+        y = bn(y, name + "_1_bn", f, EPS)
+        y = _relu(g, y, name + "_1_relu")
+        y = conv(y, name + "_2_conv", f, f, 3, padding="same")
+        y = bn(y, name + "_2_bn", f, EPS)
+        y = _relu(g, y, name + "_2_relu")
+        y = conv(y, name + "_3_conv", f, 4 * f, 1)
+        y = bn(y, name + "_3_bn", 4 * f, EPS)
+        y = g.add("Add", name + "_add", {}, [sc, y])
+        return _relu(g, y, name + "_out")
+
+    # ---- residual stacks with stride -> dilation conversion (make_backbone_fn, resnet.py:289-321)
+    dilation = 1
+    for f, blocks, stride1, name in RESNET_STACKS[version]:
+        if stride < features_output_stride:
+            stride *= stride1
+            s1 = stride1
+        elif stride == features_output_stride:
+            s1 = 1
+            if stride1 > 1:
+                dilation *= 2
+        else:
+            raise ValueError(f"Could not adjust output stride. Current: {stride}, desired: {features_output_stride}")
+        x = block(x, cur_c, f, name + "_block1", s=s1, dilation=dilation)
+        cur_c = 4 * f
+        for i in range(2, blocks + 1):
+            x = block(x, cur_c, f, f"{name}_block{i}", conv_shortcut=False)
+        feats.append((stride, x, cur_c))
+    mids = {}
+    out_stride = features_output_stride
+    if upsampling is not None:  # UpsamplingStack.make_stack, upsampling.py:118-259
+        u = dict(method="interpolation", skip_connections=None, block_stride=2, filters=64, filters_rate=1, refine_convs=2,
+                 batch_norm=True, transposed_conv_kernel_size=4)
+        u.update(upsampling)
+        us = u["block_stride"]
+        skip_sources = feats[2:] if u["skip_connections"] is not None else None
+        num_blocks = int((math.log(stride) - math.log(u["output_stride"])) / math.log(us))
+        mids[stride] = (x, cur_c)
+        for blk in range(num_blocks):
+            new_stride = stride // us
+            pre = f"upsample_s{stride}_to_s{new_stride}"
+            if u["method"] == "transposed_conv":
+                f = int(u["filters"] * u["filters_rate"] ** blk)
+                k = u["transposed_conv_kernel_size"]
+                shapes[f"{pre}_trans_conv/kernel"] = (k, k, f, int(cur_c))
+                shapes[f"{pre}_trans_conv/bias"] = (f,)
+                x = g.add("Conv2DTranspose", pre + "_trans_conv",
+                          {"filters": f, "kernel_size": [k, k], "strides": [us, us], "padding": "same",
+                           "activation": "linear", "use_bias": True, "dilation_rate": [1, 1], "output_padding": None}, [x])
+                cur_c = f
+                if u["batch_norm"]:
+                    x = bn(x, pre + "_bn", cur_c, 1e-3)
+                x = _relu(g, x, pre + "_relu")
+            else:
+                x = g.add("UpSampling2D", pre + "_interp", {"size": [us, us], "interpolation": "bilinear"}, [x])
+            stride = new_stride
+            if skip_sources is not None:
+                src = next(((t, c) for (st, t, c) in skip_sources if st == stride), None)
+                if src is not None:
+                    if u["skip_connections"] == "add":
+                        sx, sc = src
+                        if sc != cur_c:
+                            sx = conv(sx, pre + "_skip_conv1x1", sc, cur_c, 1, padding="same")
+                        x = g.add("Add", pre + "_skip_add", {}, [sx, x])
+                    else:
+                        x = g.add("Concatenate", pre + "_skip_concat", {"axis": -1}, [src[0], x])
+                        cur_c += src[1]
+            f = int(u["filters"] * u["filters_rate"] ** blk)
+            for i in range(u["refine_convs"]):
+                x = conv(x, f"{pre}_refine{i}_conv", cur_c, f, 3, padding="same")
+                cur_c = f
+                if u["batch_norm"]:
+                    x = bn(x, f"{pre}_refine{i}_bn", cur_c, 1e-3)
+                x = _relu(g, x, f"{pre}_refine{i}_relu")
+            mids[stride] = (x, cur_c)
+        out_stride = stride
+    else:
+        for st, t, c in feats:
+            mids.setdefault(st, (t, c))
+    out_layers = [x]
+    if heads:
+        out_layers = []
+        for head_name, channels, hs in heads:
+            if hs == out_stride:
+                src, sc = x, cur_c
+            elif hs in mids:
+                src, sc = mids[hs]
             else:
                 raise ValueError(f"Could not find a feature activation for output at stride {hs}.")
             shapes[f"{head_name}/kernel"] = (1, 1, int(sc), int(channels))

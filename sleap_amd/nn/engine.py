@@ -43,13 +43,16 @@ class _T:
         self.num, self.den = scale_num, scale_den  # spatial size = in_size * num / den
         self.buf = buf  # plan buffer id for real tensors
         self.parts = parts  # concat: list of _T
-        self.src = src  # pool/up: source _T
+        self.src = src  # pool/up/zpad: source _T
         self.interp = interp
+        self.tile = False  # input: tile_channels Lambda applied (resnet.py:326-339)
+        self.preproc = False  # input: imagenet_preproc_v1 Lambda applied (resnet.py:342-362)
+        self.pads = None  # zpad: ((top, bottom), (left, right))
 
 
 class DeviceNetwork:
     def __init__(self, model_config: dict, weights: Dict[str, np.ndarray], device=None, fuse_upsample: bool = False,
-                 fuse_heads: bool = True, fuse_stem: bool = True, use_stem16: bool = True):
+                 fuse_heads: bool = True, fuse_stem: bool = True, use_stem16: bool = True, mfma_convt: bool = True):
         """`fuse_upsample=True` folds UpSampling2D(bilinear) into the consuming conv's tile load (register-staged
         v1 kernel); the default materialises the upsampled tensor with the bandwidth-bound standalone kernel and
         feeds the asynchronous-DMA conv kernel (faster overall, measured in profiles/)."""
@@ -58,6 +61,7 @@ class DeviceNetwork:
         self.fuse_heads = fuse_heads
         self.fuse_stem = fuse_stem
         self.use_stem16 = use_stem16
+        self.mfma_convt = mfma_convt  # Conv2DTranspose on the matrix cores (tap GEMM per output phase) vs the VALU kernel
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         cfg = model_config["config"]
         self.layers = cfg["layers"]
@@ -196,16 +200,22 @@ class DeviceNetwork:
                 k = tuple(c["kernel_size"])
                 strides = tuple(c["strides"])
                 x = ins[0]
-                if c["padding"] != "same" or tuple(c.get("dilation_rate", (1, 1))) != (1, 1):
-                    raise NotImplementedError(f"Conv2D {name}: only padding='same' without dilation is implemented")
-                if (strides != (1, 1) or k not in ((1, 1), (3, 3))) and x.kind != "input":
+                img = x.src if x.kind == "zpad" else x  # ZeroPadding2D + valid conv on the image (resnet.py:109-114)
+                on_image = img.kind == "input"
+                if x.kind == "zpad" and not (on_image and c["padding"] == "valid"):
+                    raise NotImplementedError(f"Conv2D {name}: ZeroPadding2D is only folded into a valid conv on the input image")
+                if tuple(c.get("dilation_rate", (1, 1))) != (1, 1) and k != (1, 1):  # dilating a 1x1 kernel is a no-op
+                    raise NotImplementedError(f"Conv2D {name}: dilation is not implemented")
+                if c["padding"] != "same" and not (k == (1, 1) or x.kind == "zpad"):
+                    raise NotImplementedError(f"Conv2D {name}: padding='valid' is only implemented for 1x1 kernels")
+                if strides[0] != strides[1] or strides[0] not in (1, 2):
+                    raise NotImplementedError(f"Conv2D {name}: stride {strides}")
+                if not on_image and not (k == (3, 3) and strides == (1, 1)) and k != (1, 1):
                     raise NotImplementedError(f"Conv2D {name}: kernel {k} stride {strides} is only implemented on the input image")
-                if strides[0] != strides[1]:
-                    raise NotImplementedError(f"Conv2D {name}: anisotropic stride {strides}")
                 kern = np.asarray(self.weights[f"{name}/kernel"], np.float32)
                 cin, cout = kern.shape[2], kern.shape[3]
                 t_alias.clear()
-                if k == (1, 1) and name in self.output_names:
+                if k == (1, 1) and name in self.output_names and strides == (1, 1) and not on_image:
                     act = {"linear": 0, "sigmoid": 1}.get(c.get("activation", "linear"))
                     if act is None:
                         raise NotImplementedError(f"head {name}: activation {c.get('activation')}")
@@ -219,8 +229,6 @@ class DeviceNetwork:
                     plan.append(("head", s, o, upload_f32(w), upload_f32(bias), act))
                     t[name] = o
                     continue
-                if k != (3, 3) and x.kind != "input":
-                    raise NotImplementedError(f"Conv2D {name}: kernel {k} not implemented")
                 coutp = _pad16(cout)
                 out_name, relu, ext = conv_epilogue(l, coutp)
                 bias = padded_bias(name, cout, coutp, c.get("use_bias", True))
@@ -231,17 +239,55 @@ class DeviceNetwork:
                 need_full = (len(pools) != len(consumers)) or out_name in self.output_names or not consumers
                 o = _T("real", cout, x.num, x.den)  # its buffer is allocated below, only if someone reads it
                 o_pool = None
-                if x.kind == "input" and (k != (3, 3) or strides != (1, 1) or ext is not None or cin not in (1, 3)):
-                    # general first-layer conv on the raw image (hourglass stem: k7 s2 + ReLU + BN)
-                    o = _T("real", cout, x.num, x.den * strides[0], buf=new_buf(coutp, x.num, x.den * strides[0], "bf16"))
+                if on_image and (k != (3, 3) or strides != (1, 1) or ext is not None or cin not in (1, 3)
+                                 or x.kind == "zpad" or img.tile or img.preproc):
+                    # general first-layer conv on the raw image (hourglass stem: k7 s2 + ReLU + BN; ResNet stem:
+                    # [tile_channels, imagenet_preproc_v1,] ZeroPadding2D(3), k7 s2 valid, BN, ReLU)
+                    st = strides[0]
+                    o = _T("real", cout, x.num, x.den * st, buf=new_buf(coutp, x.num, x.den * st, "bf16"))
                     w = np.zeros((k[0], k[1], cin, coutp), np.float32)
                     w[..., :cout] = kern
+                    b_np = np.zeros((coutp,), np.float32)
+                    if c.get("use_bias", True):
+                        b_np[:cout] = self.weights[f"{name}/bias"]
                     if 4 * w.size > 64 * 1024:
                         raise NotImplementedError(f"Conv2D {name}: first-layer weights exceed the 64 KiB LDS budget")
-                    if ext is not None and ext["relu_last"]:
-                        raise NotImplementedError(f"Conv2D {name}: BN+ReLU after the first-layer conv")
-                    plan.append(["imgconv", o, upload_f32(w), bias, cin, relu, name, k, strides[0],
-                                 ext["ps"] if ext else None, ext["pt"] if ext else None])
+                    ps = pt = None
+                    if ext is not None and not relu:
+                        # BatchNormalization directly after the linear conv: fold into the fp32 weights and bias
+                        sc, sh = ext["ps"].cpu().numpy(), ext["pt"].cpu().numpy()
+                        w = w * sc
+                        b_np = b_np * sc + sh
+                        relu = ext["relu_last"]
+                    elif ext is not None:
+                        if ext["relu_last"]:
+                            raise NotImplementedError(f"Conv2D {name}: ReLU-BN-ReLU after the first-layer conv")
+                        ps, pt = ext["ps"], ext["pt"]
+                    in_affine = None
+                    if img.preproc:
+                        # X*255, RGB->BGR, minus the caffe channel means: the flip becomes a permutation of the weight
+                        # channels, scale and shift are applied per in-bounds tap inside the kernel
+                        if cin != 3:
+                            raise NotImplementedError("imagenet_preproc_v1 expects 3 channels")
+                        w = np.ascontiguousarray(w[:, :, ::-1, :])
+                        in_affine = upload_f32(np.array([255.0] * 3 + [-123.68, -116.779, -103.939], np.float32))
+                    src_c = 1 if img.tile else cin
+                    pads = (x.pads[0][0], x.pads[1][0]) if x.kind == "zpad" else None
+                    plan.append(["imgconv", o, upload_f32(np.ascontiguousarray(w)), upload_f32(b_np), src_c, relu, name, k, st,
+                                 ps, pt, cin, in_affine, pads])
+                elif k == (1, 1):
+                    # Conv2D(k1, stride 1|2) on the matrix cores (ResNet bottleneck convs, skip projections)
+                    s0 = materialize(x)
+                    st = strides[0]
+                    o = _T("real", cout, x.num, x.den * st, buf=new_buf(coutp, x.num, x.den * st, "bf16"))
+                    h = _lib.lib()
+                    packed = np.zeros((h.sa_tapconv_packed_elems(1, s0.cp, coutp),), np.uint16)
+                    kc = np.ascontiguousarray(kern[0, 0])
+                    check(h.sa_pack_tapconv_weights(kc.ctypes.data_as(C.c_void_p), 1, cin, s0.cp, cout, coutp,
+                                                    packed.ctypes.data_as(C.c_void_p)), "sa_pack_tapconv_weights")
+                    wdev = torch.from_numpy(packed.view(np.int16)).to(dev)
+                    plan.append(["conv1x1", s0, None, st, wdev, bias, o, relu, None, True, [], name, ext])
+                    conv_of[id(o)] = plan[-1]
                 elif x.kind == "input":
                     w = np.zeros((3, 3, cin, coutp), np.float32)
                     w[..., :cout] = kern
@@ -289,28 +335,80 @@ class DeviceNetwork:
                 self.round_points.add(out_name)
                 round_of[id(o)] = out_name
             elif cn == "Conv2DTranspose":
-                if tuple(c["kernel_size"]) != (3, 3) or tuple(c["strides"]) != (2, 2) or c["padding"] != "same":
-                    raise NotImplementedError(f"Conv2DTranspose {name}: only k3 s2 same is implemented")
+                ksz = tuple(c["kernel_size"])
+                if ksz not in ((3, 3), (4, 4)) or tuple(c["strides"]) != (2, 2) or c["padding"] != "same":
+                    raise NotImplementedError(f"Conv2DTranspose {name}: only k3/k4 s2 same is implemented")
                 kern = np.asarray(self.weights[f"{name}/kernel"], np.float32)  # (kh, kw, Cout, Cin)
                 cout, cin = kern.shape[2], kern.shape[3]
                 s = materialize(ins[0])
-                out_name, relu = conv_activation(l)
                 coutp = _pad16(cout)
-                w = np.zeros((3, 3, coutp, s.cp), np.float32)
-                w[:, :, :cout, :cin] = kern
-                wb = torch.from_numpy(w).to(dev).to(torch.bfloat16).contiguous()
+                t_alias.clear()
+                out_name, relu, ext = conv_epilogue(l, coutp)
                 bias = padded_bias(name, cout, coutp, c.get("use_bias", True))
                 o = _T("real", cout, s.num * 2, s.den, buf=new_buf(coutp, s.num * 2, s.den, "bf16"))
-                plan.append(("convt", s, wb, bias, o, relu))
+                if ksz == (3, 3) and ext is None and not self.mfma_convt:
+                    w = np.zeros((3, 3, coutp, s.cp), np.float32)
+                    w[:, :, :cout, :cin] = kern
+                    wb = torch.from_numpy(w).to(dev).to(torch.bfloat16).contiguous()
+                    plan.append(("convt", s, wb, bias, o, relu))
+                else:
+                    # one tap-GEMM launch per output phase; phase weights = the kernel taps of that phase, transposed
+                    h = _lib.lib()
+                    phases = []
+                    for ph in range(4):
+                        ky, kx = (C.c_int * 4)(), (C.c_int * 4)()
+                        n = h.sa_convt_s2_phase_taps(ksz[0], ph, ky, kx)
+                        taps = np.ascontiguousarray(np.stack([kern[ky[i], kx[i]].T for i in range(n)]))  # (n, Cin, Cout)
+                        packed = np.zeros((h.sa_tapconv_packed_elems(n, s.cp, coutp),), np.uint16)
+                        check(h.sa_pack_tapconv_weights(taps.ctypes.data_as(C.c_void_p), n, cin, s.cp, cout, coutp,
+                                                        packed.ctypes.data_as(C.c_void_p)), "sa_pack_tapconv_weights")
+                        phases.append(torch.from_numpy(packed.view(np.int16)).to(dev))
+                    plan.append(("convt2", s, phases, bias, o, relu, ksz[0], ext, cin))
                 t[out_name] = o
                 t[name] = o
+                for a in t_alias:
+                    t[a] = o
                 self.round_points.add(out_name)
             elif cn == "Activation":
                 raise NotImplementedError(f"standalone Activation {name} (not fused into a conv)")
-            elif cn == "MaxPooling2D":
-                if tuple(c["pool_size"]) != (2, 2) or tuple(c["strides"]) != (2, 2):
-                    raise NotImplementedError(f"MaxPooling2D {name}: only 2x2 s2 is implemented")
+            elif cn == "Lambda":
                 x = ins[0]
+                if x.kind != "input" or name not in ("tile_channels", "imagenet_preproc_v1"):
+                    raise NotImplementedError(f"Lambda layer {name}")
+                y = _T("input", 3 if name == "tile_channels" else x.c)
+                y.tile, y.preproc = x.tile or name == "tile_channels", x.preproc or name == "imagenet_preproc_v1"
+                t[name] = y
+            elif cn == "ZeroPadding2D":
+                x = ins[0]
+                pd = c["padding"]
+                y = _T("zpad", x.c, x.num, x.den, src=x)
+                y.pads = ((pd[0][0], pd[0][1]), (pd[1][0], pd[1][1]))
+                t[name] = y
+            elif cn == "MaxPooling2D":
+                x = ins[0]
+                ksz, pst = tuple(c["pool_size"]), tuple(c["strides"] or c["pool_size"])
+                if x.kind == "zpad" or ksz != (2, 2) or pst != (2, 2):
+                    # general window (ResNet: ZeroPadding2D(1) + MaxPooling2D(3, s2, valid)); the output must be exactly
+                    # in/stride so that the engine's stride bookkeeping (sizes = input * num / den) holds
+                    if ksz[0] != ksz[1] or pst[0] != pst[1]:
+                        raise NotImplementedError(f"MaxPooling2D {name}: anisotropic window")
+                    kk, st = ksz[0], pst[0]
+                    if x.kind == "zpad":
+                        if c["padding"] != "valid":
+                            raise NotImplementedError(f"MaxPooling2D {name}: ZeroPadding2D + 'same' pooling")
+                        (ptop, pbot), (pleft, pright) = x.pads
+                        if ptop != pleft or pbot != pright or not (kk - st <= ptop + pbot <= kk - 1) or st not in (1, 2):
+                            raise NotImplementedError(f"MaxPooling2D {name}: padding {x.pads} for window {kk} stride {st}")
+                        srcT, pad, pad_zero = x.src, ptop, 1
+                    else:
+                        if c["padding"] != "same" or st not in (1, 2):
+                            raise NotImplementedError(f"MaxPooling2D {name}: window {kk} stride {st} padding {c['padding']}")
+                        srcT, pad, pad_zero = x, None, 0  # TF SAME: pad_before = pad_total // 2, resolved at run time
+                    s0 = materialize(srcT)
+                    o = _T("real", s0.c, s0.num, s0.den * st, buf=new_buf(s0.cp, s0.num, s0.den * st, "bf16"))
+                    plan.append(("poolg", s0, o, kk, st, pad, pad_zero))
+                    t[name] = o
+                    continue
                 t[name] = pooled_of[name] if name in pooled_of else _T("pool", x.c, x.num, x.den * 2, src=x)
             elif cn == "UpSampling2D":
                 if tuple(c["size"]) != (2, 2):
@@ -334,8 +432,10 @@ class DeviceNetwork:
                     op = conv_of.get(id(a)) if a.kind == "real" else None
                     if op is None or cons.get(in_names[i], []) != [name] or op[10] or op[8] is not None:
                         continue
-                    if op[3] not in (_lib.SRC1_NONE, _lib.SRC1_DIRECT):
+                    if op[0] == "conv" and op[3] not in (_lib.SRC1_NONE, _lib.SRC1_DIRECT):
                         continue
+                    if op[0] == "conv1x1" and b.kind == "up" and b.interp == "nearest":
+                        continue  # the GEMM epilogue only reads a same-resolution residual
                     if op[12] is not None and (op[12]["relu_last"] or op[12]["res"] is not None):
                         continue
                     # the residual must exist before the conv runs: kernels emitted to materialise it are moved in
@@ -406,8 +506,8 @@ class DeviceNetwork:
     @staticmethod
     def _writes(op, tensor):
         k = op[0]
-        outs = {"conv": (6, 8), "stem": (1,), "imgconv": (1,), "pool": (2,), "up": (2,), "convt": (4,), "add": (5,),
-                "head": (2,)}.get(k)
+        outs = {"conv": (6, 8), "conv1x1": (6,), "stem": (1,), "imgconv": (1,), "pool": (2,), "poolg": (2,), "up": (2,),
+                "convt": (4,), "convt2": (4,), "add": (5,), "head": (2,)}.get(k)
         if k == "stem2":
             return DeviceNetwork._writes(op[2], tensor)
         return any(op[i] is tensor for i in outs)
@@ -415,12 +515,12 @@ class DeviceNetwork:
     @staticmethod
     def _reads(op):
         k = op[0]
-        if k == "conv":
+        if k in ("conv", "conv1x1"):
             r = [t for t in (op[1], op[2]) if t is not None]
             if op[12] is not None and op[12]["res"] is not None:
                 r.append(op[12]["res"])
             return r
-        if k in ("head", "pool", "up", "convt"):
+        if k in ("head", "pool", "poolg", "up", "convt", "convt2"):
             return [op[1]]
         if k == "add":
             return [op[1], op[2]]
@@ -551,8 +651,19 @@ class DeviceNetwork:
                 o, cin = op[1], op[4]
                 f = 2 * (H * o.num // o.den) * (W * o.num // o.den) * cin * o.c * 9
                 out.append((k, f"stem {cin}->{o.c} @{H * o.num // o.den}", f))
+            elif k == "conv1x1":
+                s0, o = op[1], op[6]
+                f = 2 * (H * o.num // o.den) * (W * o.num // o.den) * s0.c * o.c
+                nm = f"conv1x1s{op[3]} {s0.c}->{o.c} @{H * o.num // o.den}"
+                if op[12] is not None:
+                    nm += " +affine" + (" +res" if op[12]["res"] is not None else "")
+                out.append(("conv", nm, f))
+            elif k == "convt2":
+                s, o, ksz = op[1], op[4], op[6]
+                f = 2 * (H * s.num // s.den) * (W * s.num // s.den) * s.c * o.c * ksz * ksz
+                out.append(("convt", f"convT{ksz} {s.c}->{o.c} @{H * s.num // s.den}", f))
             elif k == "imgconv":
-                o, cin, kk = op[1], op[4], op[7]
+                o, cin, kk = op[1], op[11], op[7]
                 f = 2 * (H * o.num // o.den) * (W * o.num // o.den) * cin * o.c * kk[0] * kk[1]
                 out.append(("conv", f"imgconv{kk[0]}x{kk[1]}s{op[8]} {cin}->{o.c} @{H * o.num // o.den}", f))
             elif k == "conv":
@@ -651,8 +762,34 @@ class DeviceNetwork:
                                            _ptr(ext["ps"]), _ptr(ext["pt"]),
                                            _ptr(bufs[res.buf]) if res is not None else None, ext["res_mode"],
                                            ext["relu_last"], st), "sa_conv3x3_ex_bf16")
+            elif kind == "conv1x1":
+                _, s0, _s1, stride, w, bias, o, relu, _op, _nf, _heads, _nm, ext = op
+                sh, sw = hw(s0)
+                res = ext["res"] if ext else None
+                check(h.sa_conv1x1_bf16(_ptr(bufs[s0.buf]), s0.cp, _ptr(w), _ptr(bias), o.cp, relu, B, sh, sw, stride,
+                                        _ptr(ext["ps"]) if ext else None, _ptr(ext["pt"]) if ext else None,
+                                        _ptr(bufs[res.buf]) if res is not None else None, ext["relu_last"] if ext else 0,
+                                        _ptr(bufs[o.buf]), st), "sa_conv1x1_bf16")
+            elif kind == "convt2":
+                _, s, phases, bias, o, relu, ksz, ext, _cin = op
+                sh, sw = hw(s)
+                arr = (C.c_void_p * 4)(*[q.data_ptr() for q in phases])
+                check(h.sa_convt_s2_bf16(_ptr(bufs[s.buf]), s.cp, arr, ksz, _ptr(bias), o.cp, relu, B, sh, sw,
+                                         _ptr(ext["ps"]) if ext else None, _ptr(ext["pt"]) if ext else None,
+                                         ext["relu_last"] if ext else 0, _ptr(bufs[o.buf]), st), "sa_convt_s2_bf16")
+            elif kind == "poolg":
+                _, s, o, kk, stride, pad, pad_zero = op
+                sh, sw = hw(s)
+                oh, ow = hw(o)
+                if pad is None:
+                    pad_t = max((oh - 1) * stride + kk - sh, 0) // 2
+                    pad_l = max((ow - 1) * stride + kk - sw, 0) // 2
+                else:
+                    pad_t = pad_l = pad
+                check(h.sa_maxpool_bf16(_ptr(bufs[s.buf]), B, sh, sw, s.cp, kk, stride, pad_t, pad_l, pad_zero, oh, ow,
+                                        _ptr(bufs[o.buf]), st), "sa_maxpool_bf16")
             elif kind == "imgconv":
-                _, o, w, bias, cin, relu, _nm, k, stride, ps, pt = op
+                _, o, w, bias, cin, relu, _nm, k, stride, ps, pt, cin_w, in_affine, pads = op
                 if cin != Cin:
                     raise ValueError(f"model expects {cin} input channels, got {Cin}")
                 is_u8 = 1 if imgs.dtype == torch.uint8 else 0
@@ -662,7 +799,11 @@ class DeviceNetwork:
                 # TF "SAME": out = ceil(in / s), pad_total = max((out - 1) * s + k - in, 0), pad_before = pad_total // 2
                 pt_ = max((oh - 1) * stride + k[0] - H, 0) // 2
                 pl_ = max((ow - 1) * stride + k[1] - W, 0) // 2
-                check(h.sa_image_conv_bf16(_ptr(imgs), is_u8, B, H, W, cin, cin, None, k[0], k[1], stride, pt_, pl_, oh, ow, _ptr(w),
+                if pads is not None:  # explicit ZeroPadding2D + valid conv
+                    pt_, pl_ = pads
+                check(h.sa_image_conv_bf16(_ptr(imgs), is_u8, B, H, W, cin, cin_w,
+                                           _ptr(in_affine) if in_affine is not None else None, k[0], k[1], stride, pt_, pl_,
+                                           oh, ow, _ptr(w),
                                            _ptr(bias), o.cp, relu, _ptr(ps) if ps is not None else None,
                                            _ptr(pt) if pt is not None else None, _ptr(bufs[o.buf]), st), "sa_image_conv_bf16")
             elif kind == "add":
@@ -713,8 +854,14 @@ class DeviceNetwork:
                 o, cin = op[1], op[4]
                 total += 2 * (H * o.num // o.den) * (W * o.num // o.den) * cin * o.c * 9
             elif op[0] == "imgconv":
-                o, cin, kk = op[1], op[4], op[7]
+                o, cin, kk = op[1], op[11], op[7]
                 total += 2 * (H * o.num // o.den) * (W * o.num // o.den) * cin * o.c * kk[0] * kk[1]
+            elif op[0] == "conv1x1":
+                s0, o = op[1], op[6]
+                total += 2 * (H * o.num // o.den) * (W * o.num // o.den) * s0.c * o.c
+            elif op[0] == "convt2":
+                s, o, ksz = op[1], op[4], op[6]
+                total += 2 * (H * s.num // s.den) * (W * s.num // s.den) * s.c * o.c * ksz * ksz
             elif op[0] == "conv":
                 s0, s1, o = op[1], op[2], op[6]
                 cin = s0.c + (s1.c if s1 is not None else 0)

@@ -282,7 +282,7 @@ def test_conv1x1_vs_torch(B, H, W, Cin, Cout, stride, affine, residual, relu, re
     assert float((got - y).abs().max()) <= lim, (float((got - y).abs().max()), lim)
     if coutp > Cout:
         pad = out.float()[..., Cout:]
-        assert float(pad.abs().max()) == 0.0 or (affine and True)
+        assert float(pad.abs().max()) == 0.0 
 
 
 @pytest.mark.parametrize("B,H,W,Cin,Cout,ksize,affine", [
@@ -349,3 +349,44 @@ def test_maxpool_general_vs_torch(k, stride, pad, pad_zero, H, W):
     xp = F.pad(_bf(x).permute(0, 3, 1, 2), (pad, pad, pad, pad), value=0.0 if pad_zero else float("-inf"))
     ref = F.max_pool2d(xp, k, stride).permute(0, 2, 3, 1)
     assert torch.equal(out.float().cpu(), ref)
+
+
+# ------------------------------------------------------------------------------------------------
+# ResNet backbones + UpsamplingStack (SURVEY.md §8a row a2'')
+# ------------------------------------------------------------------------------------------------
+def _resnet(h, w, cin=1, seed=3, **kw):
+    from sleap_amd.nn.architectures import build_resnet_model_config, he_normal_weights
+
+    cfg, shapes = build_resnet_model_config((h, w, cin), **kw)
+    return cfg, he_normal_weights(shapes, seed=seed)
+
+
+def test_resnet50_pretrained_style_transposed_concat_vs_oracle():
+    """ResNet-50 with the input Lambdas (tile_channels + imagenet_preproc_v1), stride-32 features, transposed-conv
+    (k4, BN) upsampling stack with concatenated skips to stride 4, heads at strides 4 and 8."""
+    cfg, w = _resnet(128, 96, features_output_stride=32, pretrained=True,
+                     upsampling=dict(output_stride=4, method="transposed_conv", skip_connections="concatenate"),
+                     heads=[("MultiInstanceConfmapsHead", 5, 4), ("PartAffinityFieldsHead", 8, 8)])
+    rng = np.random.default_rng(0)
+    net, res = _parity(cfg, w, rng.integers(0, 256, (2, 128, 96, 1), dtype=np.uint8), 5e-2, 3e-2)
+    kinds = [op[0] for op in net.plan]
+    assert "add" not in kinds and kinds.count("conv1x1") == 36 and kinds.count("convt2") == 3
+
+
+def test_resnet50_stride16_bilinear_add_vs_oracle():
+    """features_output_stride 16 (conv5 unstrided, dilated 1x1 convs = no-op), bilinear upsampling with additive
+    skips through 1x1 projections; RGB input without the ImageNet Lambdas."""
+    cfg, w = _resnet(64, 96, cin=3, features_output_stride=16, pretrained=False,
+                     upsampling=dict(output_stride=4, method="interpolation", skip_connections="add", filters=32),
+                     heads=[("MultiInstanceConfmapsHead", 5, 4)])
+    rng = np.random.default_rng(1)
+    net, _ = _parity(cfg, w, rng.integers(0, 256, (1, 64, 96, 3), dtype=np.uint8), 5e-2, 3e-2)
+    assert "add" not in [op[0] for op in net.plan]
+
+
+def test_resnet50_backbone_features_vs_oracle():
+    """Backbone only (what tests/nn/architectures/test_resnet.py builds): (B, H/32, W/32, 2048) features."""
+    cfg, w = _resnet(96, 96, features_output_stride=32)
+    rng = np.random.default_rng(2)
+    net, _ = _parity(cfg, w, rng.integers(0, 256, (2, 96, 96, 1), dtype=np.uint8), 5e-2, 3e-2)
+    assert net.outputs[0].c == 2048
