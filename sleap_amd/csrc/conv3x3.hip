@@ -652,59 +652,72 @@ conv3x3_dma_kernel(const ConvParams2 p) {
     }
   }
 
-  // ---- fused 1x1 heads: out[n] = act(b[n] + sum_co relu(conv)[co] * Wh[n][co]) from the UN-ROUNDED fp32 values.
-  // This workgroup holds all CoutP (<= MT*32) channels of its pixels: every lane owns 16*MT channels of pixel
-  // (row r, column lx); the partner lane (lane ^ 32) owns the other half.
+  // ---- fused 1x1 heads on the matrix cores: out[n, pixel] = act(b[n] + sum_co Wh[n][co] * f[co, pixel]) with
+  // f = bf16(relu(conv + bias)), exactly the value the un-fused path stores and sa_conv1x1_head reads back.
+  // This workgroup holds all CoutP (<= MT*32) channels of its pixels. GEMM view: A = head weights (rows n < 32),
+  // B = features; the B fragment of k-step s of cout tile m is built straight from the accumulator registers
+  // 8s..8s+7 of the lane (no cross-lane movement): lane half h, element j <-> channel 16s + 8*(j>>2) + 4h + (j&3) of
+  // the tile, and the A fragment is gathered from the fp32 head weights with the same channel map. The weights enter
+  // as hi + lo bf16 terms (two MFMAs), which keeps ~16 mantissa bits of the fp32 head kernel.
   if constexpr (HEADS) {
-    float* wh = reinterpret_cast<float*>(smem);
     for (int hd = 0; hd < p.n_heads; ++hd) {
       const int NH = p.head_c[hd];
-      __syncthreads();  // main-loop LDS reads (or the previous head) are done
-      for (int i = tid; i < NH * p.CoutP; i += NW * 64) wh[i] = p.head_w[hd][i];
-      __syncthreads();
-      float hacc[R][32];
+      const int nrow = lane & 31;
+      f32x16 hacc[R];
 #pragma unroll
       for (int r = 0; r < R; ++r)
 #pragma unroll
-        for (int n = 0; n < 32; ++n) hacc[r][n] = 0.0f;
+        for (int i = 0; i < 16; ++i) hacc[r][i] = 0.0f;
 #pragma unroll
       for (int m = 0; m < MT; ++m) {
+        const int cobase = (co32_0 + m) * 32;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int co = (co32_0 + m) * 32 + 4 * half + 8 * g;
-          if (co >= p.CoutP) continue;
-          const float4 bq = *reinterpret_cast<const float4*>(p.bias + co);
-          const float bb[4] = {bq.x, bq.y, bq.z, bq.w};
-          float v[R][4];
+        for (int s2 = 0; s2 < 2; ++s2) {
+          const int c_lo = cobase + 16 * s2 + 4 * half;  // channels c_lo..c_lo+3 and c_lo+8..c_lo+11
+          if (cobase + 16 * s2 >= p.CoutP) continue;     // wave-uniform
+          float4 w0 = make_float4(0.f, 0.f, 0.f, 0.f), w1 = w0;
+          if (nrow < NH) {
+            const float* wr = p.head_w[hd] + (size_t)nrow * p.CoutP + c_lo;
+            w0 = *reinterpret_cast<const float4*>(wr);
+            w1 = *reinterpret_cast<const float4*>(wr + 8);
+          }
+          const float wv[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+          bf16x8_t ahi, alo;
 #pragma unroll
-          for (int r = 0; r < R; ++r)
+          for (int j = 0; j < 8; ++j) {
+            ahi[j] = sa::f2bf(wv[j]);
+            alo[j] = sa::f2bf(wv[j] - sa::bf2f(ahi[j]));
+          }
+          const float4 b0 = *reinterpret_cast<const float4*>(p.bias + c_lo);
+          const float4 b1 = *reinterpret_cast<const float4*>(p.bias + c_lo + 8);
+          const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              float t = acc[m][r][4 * g + j] + bb[j];
-              v[r][j] = p.relu ? fmaxf(t, 0.0f) : t;
+          for (int r = 0; r < R; ++r) {
+            bf16x8_t fq;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              const float t = acc[m][r][8 * s2 + j] + bb[j];
+              fq[j] = sa::f2bf(p.relu ? fmaxf(t, 0.0f) : t);
             }
-#pragma unroll
-          for (int n = 0; n < 32; ++n) {
-            if (n < NH) {
-              const float4 wq = *reinterpret_cast<const float4*>(wh + n * p.CoutP + co);
-#pragma unroll
-              for (int r = 0; r < R; ++r)
-                hacc[r][n] = fmaf(v[r][3], wq.w, fmaf(v[r][2], wq.z, fmaf(v[r][1], wq.y, fmaf(v[r][0], wq.x, hacc[r][n]))));
-            }
+            const mfma_bf16x8 bf = __builtin_bit_cast(mfma_bf16x8, fq);
+            hacc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(mfma_bf16x8, ahi), bf, hacc[r], 0, 0, 0);
+            hacc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(mfma_bf16x8, alo), bf, hacc[r], 0, 0, 0);
           }
         }
       }
+      // D layout: lane holds head channels (reg&3) + 8*(reg>>2) + 4*half of pixel lane&31
 #pragma unroll
       for (int r = 0; r < R; ++r) {
         const int gy = y0 + wave * R + r;
-        float* out = p.head_dst[hd] + (((size_t)b * H + gy) * W + gx) * NH;
+        const bool ok = gy < H && gx < W;
+        float* out = p.head_dst[hd] + (((size_t)b * H + (ok ? gy : 0)) * W + (ok ? gx : 0)) * NH;
 #pragma unroll
-        for (int n = 0; n < 32; ++n) {
+        for (int i = 0; i < 16; ++i) {
+          const int n = (i & 3) + 8 * (i >> 2) + 4 * half;
           if (n < NH) {
-            float t = hacc[r][n] + __shfl_xor(hacc[r][n], 32);
-            t += p.head_b[hd][n];
+            float t = hacc[r][i] + p.head_b[hd][n];
             if (p.head_act[hd] == 1) t = 1.0f / (1.0f + __expf(-t));
-            if (half == 0 && gy < H && gx < W) out[n] = t;
+            if (ok) out[n] = t;
           }
         }
       }

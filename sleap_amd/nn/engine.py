@@ -612,7 +612,8 @@ class DeviceNetwork:
         raise KeyError(output_index)
 
     def fused_head_names(self):
-        """Output layer names whose 1x1 head is computed inside the producing conv's epilogue (from fp32 values)."""
+        """Output layer names whose 1x1 head is computed inside the producing conv's epilogue (on the matrix cores, from
+        the same bf16-rounded features the un-fused path would store)."""
         names = []
         for op in self.plan:
             if op[0] == "conv":

@@ -186,7 +186,7 @@ def _run_graph_parity(cfg, weights, x_u8, tol, skip=()):
     xin = ensure_float(x_u8)
     worst = {}
     for mode in ("bf16", "fp32"):
-        ref = KerasGraph(cfg, weights, emulate_bf16=(mode == "bf16"), fp32_input_heads=net.fused_head_names())(xin)
+        ref = KerasGraph(cfg, weights, emulate_bf16=(mode == "bf16"))(xin)
         assert len(outs) == len(ref)
         w = 0.0
         for name, o, r in zip(net.output_names, outs, ref):

@@ -22,7 +22,7 @@ net = DeviceNetwork(cfg, w)
 outs = net.forward(torch.from_numpy(x).cuda())
 torch.cuda.synchronize()
 bufs = net._buffers[(2, 128, 160)]
-_, allt = KerasGraph(cfg, w, emulate_bf16=True, fp32_input_heads=net.fused_head_names())(ensure_float(x), return_all=True)
+_, allt = KerasGraph(cfg, w, emulate_bf16=True)(ensure_float(x), return_all=True)
 _, allf = KerasGraph(cfg, w, emulate_bf16=False)(ensure_float(x), return_all=True)
 # map plan ops to layer names: conv ops are in layer order
 conv_layers = [l["name"] for l in cfg["config"]["layers"] if l["class_name"] in ("Conv2D", "Conv2DTranspose")]
