@@ -244,6 +244,52 @@ upsample2x_kernel(const uint16_t* __restrict__ src, int B, int H, int W, int CP,
   }
 }
 
+// Bilinear x2, one thread per SOURCE pixel and 8-channel group: the 3x3 clamped neighbourhood is loaded once (9 loads
+// for 4 outputs instead of 16) and the 2x2 output block is produced with the same operation order as up2_lerp
+// (horizontal lerp of the two rows, then vertical), so results are bit-identical to upsample2x_kernel.
+__global__ void __launch_bounds__(256)
+upsample2x_bilinear_block_kernel(const uint16_t* __restrict__ src, int B, int H, int W, int CP, uint16_t* __restrict__ dst) {
+  const int groups = CP / 8;
+  const size_t total = (size_t)B * H * W * groups;
+  for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
+    const int g = (int)(t % groups);
+    const size_t p = t / groups;
+    const int j = (int)(p % W);
+    const int i = (int)((p / W) % H);
+    const size_t b = p / ((size_t)W * H);
+    const int ys[3] = {max(i - 1, 0), i, min(i + 1, H - 1)};
+    const int xs[3] = {max(j - 1, 0), j, min(j + 1, W - 1)};
+    const uint16_t* base = src + b * H * W * (size_t)CP + g * 8;
+    float hl[3][8], hr[3][8];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const uint16_t* row = base + (size_t)ys[r] * W * CP;
+      const bf16x8_t vm = *reinterpret_cast<const bf16x8_t*>(row + (size_t)xs[0] * CP);
+      const bf16x8_t v0 = *reinterpret_cast<const bf16x8_t*>(row + (size_t)xs[1] * CP);
+      const bf16x8_t vp = *reinterpret_cast<const bf16x8_t*>(row + (size_t)xs[2] * CP);
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        const float m = sa::bf2f(vm[c]), z = sa::bf2f(v0[c]), q = sa::bf2f(vp[c]);
+        hl[r][c] = m + (z - m) * 0.75f;  // output column 2j:   taps (j-1, j), weight 0.75 on j
+        hr[r][c] = z + (q - z) * 0.25f;  // output column 2j+1: taps (j, j+1), weight 0.25 on j+1
+      }
+    }
+    bf16x8_t o00, o01, o10, o11;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      o00[c] = sa::f2bf(hl[0][c] + (hl[1][c] - hl[0][c]) * 0.75f);  // row 2i
+      o01[c] = sa::f2bf(hr[0][c] + (hr[1][c] - hr[0][c]) * 0.75f);
+      o10[c] = sa::f2bf(hl[1][c] + (hl[2][c] - hl[1][c]) * 0.25f);  // row 2i+1
+      o11[c] = sa::f2bf(hr[1][c] + (hr[2][c] - hr[1][c]) * 0.25f);
+    }
+    uint16_t* o = dst + (((b * 2 * H + 2 * i) * 2 * W) + 2 * j) * (size_t)CP + g * 8;
+    *reinterpret_cast<bf16x8_t*>(o) = o00;
+    *reinterpret_cast<bf16x8_t*>(o + CP) = o01;
+    *reinterpret_cast<bf16x8_t*>(o + (size_t)2 * W * CP) = o10;
+    *reinterpret_cast<bf16x8_t*>(o + (size_t)2 * W * CP + CP) = o11;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // 1x1 linear head (heads.py:42-62): bf16 features x f32 weights -> f32 maps with exact channel count.
 // thread = pixel; weights [Cout][CinP] staged in LDS (broadcast reads).
@@ -456,9 +502,15 @@ int sa_maxpool2x2_bf16(const void* src, int B, int H, int W, int CP, void* dst, 
 int sa_upsample2x_bf16(const void* src, int B, int H, int W, int CP, int bilinear, void* dst,
                        sa_stream_t stream) {
   SA_REQUIRE(CP % 8 == 0, "sa_upsample2x_bf16: CP%%8 != 0");
-  const size_t total = (size_t)B * 4 * H * W * (CP / 8);
-  hipLaunchKernelGGL(upsample2x_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
-                     (const uint16_t*)src, B, H, W, CP, bilinear, (uint16_t*)dst);
+  if (bilinear) {
+    const size_t total = (size_t)B * H * W * (CP / 8);
+    hipLaunchKernelGGL(upsample2x_bilinear_block_kernel, dim3(grid_for(total, 256, 256 * 32)), dim3(256), 0,
+                       (hipStream_t)stream, (const uint16_t*)src, B, H, W, CP, (uint16_t*)dst);
+  } else {
+    const size_t total = (size_t)B * 4 * H * W * (CP / 8);
+    hipLaunchKernelGGL(upsample2x_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
+                       (const uint16_t*)src, B, H, W, CP, bilinear, (uint16_t*)dst);
+  }
   SA_LAUNCH_CHECK();
   return SA_OK;
 }

@@ -596,7 +596,20 @@ class DeviceNetwork:
                 dtype = torch.bfloat16 if dt == "bf16" else torch.float32
                 bufs[i] = torch.empty((B, h, w, c_alloc), dtype=dtype, device=self.device)
             self._buffers = {key: bufs}  # keep one shape resident
+            self._slot1 = {}
         return self._buffers[key]
+
+    def _slot_buffers(self, bufs, slot):
+        """Output buffers of slot 1 (slot 0 = the base set): a second copy of every model-output tensor so that the
+        consumer of call i can still read its outputs while call i+1 runs on another stream."""
+        if slot == 0:
+            return bufs
+        view = dict(bufs)
+        for o in self.outputs:
+            if o.buf not in self._slot1:
+                self._slot1[o.buf] = torch.empty_like(bufs[o.buf])
+            view[o.buf] = self._slot1[o.buf]
+        return view
 
     def rescale_head(self, output_index: int, scale, shift):
         """out' = scale[c] * out + shift[c] folded into the 1x1 head's weights (used to calibrate random heads)."""
@@ -687,15 +700,15 @@ class DeviceNetwork:
                 out.append((k, k, 0))
         return out
 
-    def forward(self, imgs: torch.Tensor, profile: Optional[list] = None) -> List[torch.Tensor]:
+    def forward(self, imgs: torch.Tensor, profile: Optional[list] = None, slot: int = 0) -> List[torch.Tensor]:
         """imgs: (B, H, W, C) uint8 or float32 CUDA tensor, H and W multiples of the max stride.
         Returns the model outputs (float32, NHWC) in `output_names` order. The returned tensors are
-        views of cached buffers that the next call overwrites."""
+        views of cached buffers that the next call with the same `slot` (0 or 1) overwrites."""
         assert imgs.is_cuda and imgs.is_contiguous()
         B, H, W, Cin = imgs.shape
         if H % self.max_stride or W % self.max_stride:
             raise ValueError(f"input size {(H, W)} must be a multiple of the model stride {self.max_stride}")
-        bufs = self._get_buffers(B, H, W)
+        bufs = self._slot_buffers(self._get_buffers(B, H, W), slot)
         h = _lib.lib()
         st = _stream()
 

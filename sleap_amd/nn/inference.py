@@ -78,6 +78,55 @@ class InferenceLayer:
             ensure_grayscale = keras_model.in_channels == 1
         self.ensure_grayscale = ensure_grayscale
         self.ensure_float = ensure_float
+        # Network / post-processing overlap across consecutive calls (new; the reference runs everything in one TF
+        # graph): the network of call i+1 runs on a side HIP stream while the caller's stream still executes the
+        # post-processing of call i. Model outputs are double buffered. `assume_inputs_ready`: a DEVICE input tensor
+        # is normally ordered after everything already queued on the caller's stream (safe, but that includes the
+        # previous call's post-processing); set it when the frames were produced long before (resident video).
+        self.overlap_postproc = False
+        self.assume_inputs_ready = False
+        self._net_stream = None
+        self._slot = 0
+        self._slot_free = [None, None]
+        self._pending_slot = None
+
+    def run_network(self, data):
+        """preprocess + network forward -> list of model outputs, valid on the CURRENT stream."""
+        if not self.overlap_postproc:
+            return self.keras_model.forward(self.preprocess(data))
+        cur = torch.cuda.current_stream()
+        if self._net_stream is None:
+            self._net_stream = torch.cuda.Stream()
+        ns = self._net_stream
+        self.release_outputs()  # outputs of a previous call that nobody released: everything queued so far may read them
+        slot = self._slot
+        self._slot ^= 1
+        src = data["image"] if isinstance(data, dict) else data
+        on_device = isinstance(src, torch.Tensor) and src.is_cuda
+        if on_device and not self.assume_inputs_ready:
+            ready = torch.cuda.Event()
+            ready.record(cur)
+            ns.wait_event(ready)
+        if self._slot_free[slot] is not None:
+            ns.wait_event(self._slot_free[slot])  # the consumer of this slot's previous outputs has finished
+        with torch.cuda.stream(ns):
+            imgs = self.preprocess(data)
+            preds = self.keras_model.forward(imgs, slot=slot)
+            done = torch.cuda.Event()
+            done.record(ns)
+        if on_device:
+            src.record_stream(ns)
+        cur.wait_event(done)
+        self._pending_slot = slot
+        return preds
+
+    def release_outputs(self):
+        """Call once the post-processing that reads the last `run_network` outputs has been queued."""
+        if self._pending_slot is not None:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+            self._slot_free[self._pending_slot] = ev
+            self._pending_slot = None
 
     def preprocess(self, imgs, resize_img: bool = True) -> torch.Tensor:
         """inference.py:940-967: grayscale|rgb -> float -> resize -> pad (bottom/right zeros).
@@ -286,11 +335,11 @@ class BottomUpInferenceLayer(InferenceLayer):
         self.return_pafs = return_pafs
         self.return_paf_graph = return_paf_graph
         self.max_peaks = max_peaks
+        self.overlap_postproc = True
 
     def forward_pass(self, data):
         """inference.py:2864-2890 -> (cms, pafs, offsets|None), float32 NHWC device tensors."""
-        imgs = self.preprocess(data)
-        preds = self.keras_model.forward(imgs)
+        preds = self.run_network(data)
         offsets = preds[self.offsets_ind] if self.offsets_ind is not None else None
         return preds[self.confmaps_ind], preds[self.pafs_ind], offsets
 
@@ -315,14 +364,16 @@ class BottomUpInferenceLayer(InferenceLayer):
             inst = (inst / np.float32(self.input_scale)) + np.float32(0.5)  # :2980-2984
         out = {"instance_peaks": inst, "instance_peak_vals": vals, "instance_scores": scores, "n_valid": n_inst,
                "status": status}
+        keep = (lambda t: t.clone()) if self.overlap_postproc else (lambda t: t)  # slot buffers get recycled
         if self.return_confmaps:
-            out["confmaps"] = cms
+            out["confmaps"] = keep(cms)
         if self.return_pafs:
-            out["part_affinity_fields"] = pafs
+            out["part_affinity_fields"] = keep(pafs)
         if self.return_paf_graph:
             out["peaks"], out["peak_vals"], out["peak_channel_inds"], out["peak_count"] = peak_xy, peak_val, peak_chan, peak_count
             node_count, node_peaks, line_scores, match_dst, match_score = res[5]
             out["paf_node_count"], out["paf_node_peaks"], out["line_scores"] = node_count, node_peaks, line_scores
+        self.release_outputs()
         return out
 
     __call__ = call
