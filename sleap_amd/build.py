@@ -19,9 +19,10 @@ ARCH = "gfx950"
 SOURCES = [
     ("postproc.hip", ["-ffp-contract=off"]),
     ("layers.hip", []),
-    ("conv3x3.hip", []),
-    ("stem16.hip", []),
-    ("tapconv.hip", []),
+    # the MFMA kernels never see NaNs they must preserve: without this every fmaxf carries two canonicalising v_max
+    ("conv3x3.hip", ["-fno-honor-nans"]),
+    ("stem16.hip", ["-fno-honor-nans"]),
+    ("tapconv.hip", ["-fno-honor-nans"]),
 ]
 COMMON = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function"]
 

@@ -59,4 +59,20 @@ __device__ __forceinline__ float up2_lerp(float tl, float tr, float bl, float br
   return t + (b - t) * wy;
 }
 
+#if defined(__HIP_DEVICE_COMPILE__)
+// value of the neighbouring lane (lane ^ 1) through DPP quad_perm [1,0,3,2]: no LDS crossbar (ds_bpermute) involved
+__device__ __forceinline__ float dpp_xor1(float v) {
+  const int i = __float_as_int(v);
+  return __int_as_float(__builtin_amdgcn_update_dpp(i, i, 0xB1, 0xF, 0xF, false));
+}
+// v_permlane32_swap: exchanges a's upper 32 lanes with b's lower 32 lanes. Afterwards lane l < 32 holds
+// {a[l], a[l+32]} in (a, b) and lane l >= 32 holds {b[l-32], b[l]}: one instruction per dword turns the MFMA
+// accumulator split (channels 0-3 in the lower half-wave, 4-7 in the upper) into 8 consecutive channels per lane.
+__device__ __forceinline__ void swap32(unsigned& a, unsigned& b) {
+  const auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+  a = r[0];
+  b = r[1];
+}
+#endif
+
 }  // namespace sa

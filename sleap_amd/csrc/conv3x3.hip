@@ -606,14 +606,12 @@ conv3x3_dma_kernel(const ConvParams2 p) {
     auto store_pieces = [&](uint16_t* row_ptr, bool ok, const uint2 (&pk)[4]) {
 #pragma unroll
       for (int pr = 0; pr < 2; ++pr) {
-        const uint2 send = half ? pk[2 * pr] : pk[2 * pr + 1];
-        uint2 recv;
-        recv.x = __shfl_xor(send.x, 32);
-        recv.y = __shfl_xor(send.y, 32);
-        const uint4 piece = half ? make_uint4(recv.x, recv.y, pk[2 * pr + 1].x, pk[2 * pr + 1].y)
-                                 : make_uint4(pk[2 * pr].x, pk[2 * pr].y, recv.x, recv.y);
+        // lower half-wave: own group 2pr (channels 0-3) + partner's (4-7); upper: partner's group 2pr+1 + own
+        uint2 a = pk[2 * pr], c = pk[2 * pr + 1];
+        sa::swap32(a.x, c.x);
+        sa::swap32(a.y, c.y);
         const int co = cobase + 16 * pr + 8 * half;
-        if (ok && co < p.CoutP) *reinterpret_cast<uint4*>(row_ptr + co) = piece;
+        if (ok && co < p.CoutP) *reinterpret_cast<uint4*>(row_ptr + co) = make_uint4(a.x, a.y, c.x, c.y);
       }
     };
     if (p.dst) {
@@ -641,7 +639,7 @@ conv3x3_dma_kernel(const ConvParams2 p) {
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             const float t = fmaxf(act(r, g, j), act(r + 1, g, j));
-            t4[j] = fmaxf(t, __shfl_xor(t, 1));
+            t4[j] = fmaxf(t, sa::dpp_xor1(t));
           }
           pk[g].x = sa::f2bf2(t4[0], t4[1]);
           pk[g].y = sa::f2bf2(t4[2], t4[3]);

@@ -209,6 +209,163 @@ stem16_kernel(const Stem16Params p) {
 #endif
 }
 
+
+// ---- v2 (grayscale, W % 4 == 0): same arithmetic, re-laid-out for the LDS and VALU budgets the counters showed
+// to be binding (profiles/r01_pmc_sq_counters.md: LDS array 83 % busy, VALU issue 84 %):
+//   * the raw tile is stored as a table of horizontal tap triplets {p[x], p[x+1], p[x+2], 0} (8 bytes per entry, bf16),
+//     so conv0's B operand is ONE aligned ds_read_b64 per lane instead of three 16-bit reads;
+//   * the conv0 activation tile is dense (32 B per pixel): with the hardware's ds_read_b128 lane groups
+//     ({0-3,12-15,20-27}, ...) the dense layout is conflict-free for conv1's reads, the 48-byte stride was not;
+//   * pixel coordinates advance incrementally (no per-group division), bias1 is the accumulator's initial value, and
+//     the ReLU of a pooled-only output is applied after the 2x2 max (max commutes with ReLU).
+__global__ void __launch_bounds__(256)
+stem16_gray_kernel(const Stem16Params p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int TH = SA_STEM16_TH, TW = SA_STEM16_TW, PH = TH + 2, PW = TW + 2, RH = TH + 4;
+  constexpr int RS = 48;  // triplet-table row stride in entries: 96 dwords = 32 (mod 64) banks between kernel rows
+  __shared__ __attribute__((aligned(16))) uint2 rawt[(RH + 1) * RS];
+  __shared__ __attribute__((aligned(16))) unsigned char act[(PH * PW + 16) * 32];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n16 = lane & 15, kb = lane >> 4;
+  int bid = blockIdx.x;
+  const int tx_i = bid % p.tiles_x;
+  bid /= p.tiles_x;
+  const int ty_i = bid % p.tiles_y;
+  const int b = bid / p.tiles_y;
+  const int x0 = tx_i * TW, y0 = ty_i * TH;
+  const int H = p.H, W = p.W;
+
+  // ---- triplet table: thread (row, dq) loads the two aligned dwords covering image columns x0-4+4dq .. +7 and emits
+  // the entries of raw columns tx = 4dq-2 .. 4dq+1 (raw column tx <-> image column x0 - 2 + tx; zero outside the image)
+  if (tid < RH * 9) {
+    const int ty = tid / 9, dq = tid - ty * 9;
+    const int gy = y0 + ty - 2, gx = x0 - 4 + dq * 4;
+    unsigned v0 = 0, v1 = 0;
+    if (gy >= 0 && gy < H) {
+      const uint8_t* row = p.src + ((size_t)b * H + gy) * W;
+      if (gx >= 0 && gx < W) v0 = *reinterpret_cast<const unsigned*>(row + gx);
+      if (gx + 4 >= 0 && gx + 4 < W) v1 = *reinterpret_cast<const unsigned*>(row + gx + 4);
+    }
+    unsigned h[6];  // bf16 bits of pixels 0..5 of the 8 (integers 0..255 are exact: the high half of the float)
+#pragma unroll
+    for (int e = 0; e < 6; ++e) {
+      const unsigned byte = e < 4 ? (v0 >> (8 * e)) & 0xFF : (v1 >> (8 * (e - 4))) & 0xFF;
+      h[e] = __float_as_uint((float)byte) >> 16;
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int tx = dq * 4 - 2 + e;
+      if (tx >= 0 && tx < PW) rawt[ty * RS + tx] = make_uint2(h[e] | (h[e + 1] << 16), h[e + 2]);
+    }
+  }
+  const uint4* blob4 = reinterpret_cast<const uint4*>(p.blob);
+  mfma_bf16x8 wa[3], wb[5];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) wa[i] = __builtin_bit_cast(mfma_bf16x8, blob4[i * 64 + lane]);
+#pragma unroll
+  for (int i = 0; i < 5; ++i) wb[i] = __builtin_bit_cast(mfma_bf16x8, blob4[(3 + i) * 64 + lane]);
+  const float* biases = reinterpret_cast<const float*>(p.blob + 8 * 64 * 8);
+  const float4 q0 = *reinterpret_cast<const float4*>(biases + kb * 4);
+  const float4 q1 = *reinterpret_cast<const float4*>(biases + 16 + kb * 4);
+  const float bias0[4] = {q0.x, q0.y, q0.z, q0.w}, bias1[4] = {q1.x, q1.y, q1.z, q1.w};
+  __syncthreads();
+
+  // ---- conv0 on the (PH x PW) halo tile: group g = wave + 4*it covers halo pixels 16g .. 16g+15
+  constexpr int NG0 = (PH * PW + 15) / 16;
+  {
+    int pl = wave * 16 + n16;
+    int ty = pl / PW, tx = pl - ty * PW;
+    const int kbc = kb < 3 ? kb : 0;
+    for (int g = wave; g < NG0; g += 4) {
+      const bool valid = pl < PH * PW;
+      uint2 tq = rawt[(ty + kbc) * RS + tx];  // rows up to RH are allocated: the tail of the last group reads garbage
+      if (kb == 3) tq = make_uint2(0u, 0u);
+      const uint4 bq4 = make_uint4(tq.x, tq.y, 0u, 0u);
+      const mfma_bf16x8 bf = __builtin_bit_cast(mfma_bf16x8, bq4);
+      f32x4 d = {bias0[0], bias0[1], bias0[2], bias0[3]};
+      d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[0], bf, d, 0, 0, 0);
+      d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[1], bf, d, 0, 0, 0);
+      d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[2], bf, d, 0, 0, 0);
+      // outside the image: conv1's SAME padding = 0
+      const bool in_img = valid && (unsigned)(y0 + ty - 1) < (unsigned)H && (unsigned)(x0 + tx - 1) < (unsigned)W;
+      float v[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float t = p.relu0 ? fmaxf(d[j], 0.0f) : d[j];
+        v[j] = in_img ? t : 0.0f;
+      }
+      if (valid) *reinterpret_cast<uint2*>(act + pl * 32 + kb * 8) = make_uint2(sa::f2bf2(v[0], v[1]), sa::f2bf2(v[2], v[3]));
+      pl += 64;  // 64 = PW + 30
+      tx += 30;
+      ty += 1;
+      if (tx >= PW) {
+        tx -= PW;
+        ty += 1;
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- conv1: wave w owns rows 4w..4w+3, two 16-pixel groups per row; step s covers taps 2s (lanes kb 0,1) and 2s+1
+  // (lanes kb 2,3); tap 9 is zero-weight padding and reads tap 0's address
+  f32x4 acc[4][2];
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) acc[r][h] = (f32x4){bias1[0], bias1[1], bias1[2], bias1[3]};
+  const unsigned char* abase = act + ((wave * 4) * PW + n16) * 32 + (kb & 1) * 16;
+#pragma unroll
+  for (int s = 0; s < 5; ++s) {
+    constexpr int dummy = 0;
+    (void)dummy;
+    const int ta = 2 * s, tb = 2 * s + 1 < 9 ? 2 * s + 1 : 0;
+    const int off = (kb >> 1) ? ((tb / 3) * PW + tb % 3) : ((ta / 3) * PW + ta % 3);
+    const unsigned char* sb = abase + off * 32;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const mfma_bf16x8 bv = *reinterpret_cast<const mfma_bf16x8*>(sb + (r * PW + h * 16) * 32);
+        acc[r][h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[s], bv, acc[r][h], 0, 0, 0);
+      }
+  }
+
+  // ---- epilogue: lane holds couts kb*4..+3 of pixel (row, h*16 + n16)
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int gx = x0 + h * 16 + n16;
+    if (p.dst) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int gy = y0 + wave * 4 + r;
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = p.relu1 ? fmaxf(acc[r][h][j], 0.0f) : acc[r][h][j];
+        if (gy < H && gx < W)
+          *reinterpret_cast<uint2*>(p.dst + (((size_t)b * H + gy) * W + gx) * 16 + kb * 4) =
+              make_uint2(sa::f2bf2(v[0], v[1]), sa::f2bf2(v[2], v[3]));
+      }
+    }
+    if (p.dst_pool) {
+#pragma unroll
+      for (int r = 0; r < 4; r += 2) {
+        float t4[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float t = fmaxf(acc[r][h][j], acc[r + 1][h][j]);
+          t = fmaxf(t, sa::dpp_xor1(t));
+          t4[j] = p.relu1 ? fmaxf(t, 0.0f) : t;  // relu(max(.)) == max(relu(.))
+        }
+        const int gy = y0 + wave * 4 + r;
+        if (!(lane & 1) && gy < H && gx < W)
+          *reinterpret_cast<uint2*>(p.dst_pool + (((size_t)b * (H / 2) + gy / 2) * (W / 2) + gx / 2) * 16 + kb * 4) =
+              make_uint2(sa::f2bf2(t4[0], t4[1]), sa::f2bf2(t4[2], t4[3]));
+      }
+    }
+  }
+#endif
+}
+
 }  // namespace
 
 extern "C" {
@@ -281,7 +438,9 @@ int sa_stem16_u8_bf16(const void* src, int B, int H, int W, int Cin, const void*
   p.tiles_y = (H + SA_STEM16_TH - 1) / SA_STEM16_TH;
   const size_t nblk = (size_t)p.tiles_x * p.tiles_y * B;
   if (nblk > 0x7fffffffull) return sa::fail(SA_ERR_INVALID_ARG, "sa_stem16_u8_bf16: grid too large");
-  if (Cin == 1)
+  if (Cin == 1 && (W & 3) == 0 && ((uintptr_t)src & 3) == 0)
+    hipLaunchKernelGGL(stem16_gray_kernel, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, p);
+  else if (Cin == 1)
     hipLaunchKernelGGL((stem16_kernel<1>), dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, p);
   else
     hipLaunchKernelGGL((stem16_kernel<3>), dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, p);

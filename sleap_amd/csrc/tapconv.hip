@@ -216,14 +216,11 @@ tapconv_kernel(const TapParams p) {
       }
 #pragma unroll
       for (int pr = 0; pr < 2; ++pr) {
-        const uint2 send = half ? pk[2 * pr] : pk[2 * pr + 1];
-        uint2 recv;
-        recv.x = __shfl_xor(send.x, 32);
-        recv.y = __shfl_xor(send.y, 32);
-        const uint4 piece = half ? make_uint4(recv.x, recv.y, pk[2 * pr + 1].x, pk[2 * pr + 1].y)
-                                 : make_uint4(pk[2 * pr].x, pk[2 * pr].y, recv.x, recv.y);
+        uint2 a = pk[2 * pr], c = pk[2 * pr + 1];
+        sa::swap32(a.x, c.x);
+        sa::swap32(a.y, c.y);
         const int co = cobase + 16 * pr + 8 * half;
-        if (pix_ok && co < p.CoutP) *reinterpret_cast<uint4*>(p.dst + opix * p.CoutP + co) = piece;
+        if (pix_ok && co < p.CoutP) *reinterpret_cast<uint4*>(p.dst + opix * p.CoutP + co) = make_uint4(a.x, a.y, c.x, c.y);
       }
     }
   }
