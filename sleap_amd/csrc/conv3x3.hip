@@ -358,13 +358,28 @@ conv3x3_dma_kernel(const ConvParams2 p) {
     }
   };
 
+  // Multi-chunk kernels (NBUF == 2) start the accumulators at the bias (the loads hide behind the first copy, the
+  // epilogue saves one add per value); single-chunk kernels are latency-bound on their prologue and add it at the end.
+  constexpr bool BIAS_INIT = (NBUF == 2);
   f32x16 acc[MT][R];
 #pragma unroll
-  for (int m = 0; m < MT; ++m)
+  for (int m = 0; m < MT; ++m) {
 #pragma unroll
-    for (int r = 0; r < R; ++r)
+    for (int g = 0; g < 4; ++g) {
+      float4 bq = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      if constexpr (BIAS_INIT) {
+        const int co = (co32_0 + m) * 32 + 8 * g + 4 * (lane >> 5);
+        if (co < p.CoutP) bq = *reinterpret_cast<const float4*>(p.bias + co);
+      }
 #pragma unroll
-      for (int i = 0; i < 16; ++i) acc[m][r][i] = 0.0f;
+      for (int r = 0; r < R; ++r) {
+        acc[m][r][4 * g + 0] = bq.x;
+        acc[m][r][4 * g + 1] = bq.y;
+        acc[m][r][4 * g + 2] = bq.z;
+        acc[m][r][4 * g + 3] = bq.w;
+      }
+    }
+  }
 
   const int n_chunks = CinP / CK;
   issue(0, 0);
@@ -566,7 +581,7 @@ conv3x3_dma_kernel(const ConvParams2 p) {
     for (int g = 0; g < 4; ++g) {
       const int co = cobase + 8 * g + 4 * half;
       float4 bq = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-      if (co < p.CoutP) bq = *reinterpret_cast<const float4*>(p.bias + co);
+      if (!BIAS_INIT && co < p.CoutP) bq = *reinterpret_cast<const float4*>(p.bias + co);
       bb[g][0] = bq.x;
       bb[g][1] = bq.y;
       bb[g][2] = bq.z;
@@ -586,9 +601,9 @@ conv3x3_dma_kernel(const ConvParams2 p) {
         pt[g][0] = tq.x, pt[g][1] = tq.y, pt[g][2] = tq.z, pt[g][3] = tq.w;
       }
     }
+    const float lowv = p.relu ? 0.0f : -INFINITY;  // ReLU as one v_max against a wave-uniform bound
     auto act = [&](int r, int g, int j) {
-      float t = acc[m][r][4 * g + j] + bb[g][j];
-      if (p.relu) t = fmaxf(t, 0.0f);
+      float t = fmaxf(acc[m][r][4 * g + j] + bb[g][j], lowv);
       if constexpr (EXT) {
         t = fmaf(t, ps[g][j], pt[g][j]);
         if (p.residual) {
@@ -680,15 +695,18 @@ conv3x3_dma_kernel(const ConvParams2 p) {
             w1 = *reinterpret_cast<const float4*>(wr + 8);
           }
           const float wv[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+          float4 b0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), b1 = b0;
+          if (!BIAS_INIT) {
+            b0 = *reinterpret_cast<const float4*>(p.bias + c_lo);
+            b1 = *reinterpret_cast<const float4*>(p.bias + c_lo + 8);
+          }
+          const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
           bf16x8_t ahi, alo;
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
             ahi[j] = sa::f2bf(wv[j]);
             alo[j] = sa::f2bf(wv[j] - sa::bf2f(ahi[j]));
           }
-          const float4 b0 = *reinterpret_cast<const float4*>(p.bias + c_lo);
-          const float4 b1 = *reinterpret_cast<const float4*>(p.bias + c_lo + 8);
-          const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
 #pragma unroll
           for (int r = 0; r < R; ++r) {
             bf16x8_t fq;
