@@ -282,6 +282,59 @@ int sa_resize_bilinear_f32(const float* src, int B, int H, int W, int C, int Ho,
 int sa_f32_to_bf16_padded(const float* src, int n_pix, int C, int CP, void* dst, sa_stream_t stream);
 int sa_bf16_to_f32(const void* src, int n_pix, int CP, int C, float* dst, sa_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Cross-frame identity tracking (host code). Replaces sleap.nn.tracking.Tracker with the
+ * `simple` / `simplemaxtracks` candidate makers (tracking.py:442-507, 542-841) and sleap/nn/tracker/components.py
+ * (similarities :33-196, greedy / Hungarian matching :199-226, pre-cull :229-417, FrameMatches :469-640,
+ * connect_single_track_breaks :419-466). Optical-flow candidates (cv2) and the Kalman tracker (pykalman) are not covered.
+ * Tracks are integers: the index into the tracker's list of spawned tracks (reference name "track_<index>").
+ * ------------------------------------------------------------------------------------------------ */
+enum { SA_SIM_INSTANCE = 0, SA_SIM_CENTROID = 1, SA_SIM_IOU = 2, SA_SIM_NORMALIZED_INSTANCE = 3, SA_SIM_OBJECT_KEYPOINT = 4 };
+enum { SA_MATCH_GREEDY = 0, SA_MATCH_HUNGARIAN = 1 };
+
+typedef struct sa_tracker_config {   /* Tracker.make_tracker_by_name arguments, tracking.py:844-876 */
+  int max_tracks_mode;               /* 0 = SimpleCandidateMaker, 1 = SimpleMaxTracksCandidateMaker */
+  int similarity;                    /* SA_SIM_* */
+  int match;                         /* SA_MATCH_* */
+  int track_window;
+  double robust;                     /* robust_best_instance: in (0,1) -> np.quantile of the track's similarities, else max */
+  int min_new_track_points;
+  int min_match_points;
+  int target_instance_count;
+  int pre_cull_to_target;
+  double pre_cull_iou_threshold;     /* <= 0: score-only culling */
+  int max_tracks;
+  int max_tracking;
+  int oks_n_errors;                  /* 0 = keypoint_errors None (= 1) */
+  const double* oks_errors;
+  int oks_score_weighting;
+  int oks_normalization;             /* 0 "all", 1 "ref", 2 "union" */
+} sa_tracker_config;
+
+void* sa_tracker_create(const sa_tracker_config* cfg);   /* NULL on invalid configuration (sa_last_error) */
+void sa_tracker_destroy(void* tracker);
+int sa_tracker_reset(void* tracker);                     /* Tracker.reset_candidates */
+int sa_tracker_n_tracks(void* tracker);                  /* tracks spawned so far */
+
+/* Tracker.track for ONE frame (tracking.py:642-773). points [n, n_nodes, 2] f32 (x, y; NaN = missing node),
+ * point_scores [n, n_nodes] or NULL, inst_scores [n] or NULL, t < 0 = infer the time step.
+ * Returns the tracked instances in the reference's order (matches first, then newly spawned tracks):
+ * out_index[k] = index of the k-th returned instance in the input, out_track[k], out_score[k] = tracking_score
+ * (match similarity; 0 for spawned tracks); *n_out <= n (instances can be culled or refused a new track). */
+int sa_tracker_track(void* tracker, int n, int n_nodes, const float* points, const float* point_scores,
+                     const float* inst_scores, int img_h, int img_w, int t, int* out_index, int* out_track,
+                     double* out_score, int* n_out);
+
+/* The same over n_frames consecutive frames laid out like the predictor's output: points [F, I, N, 2] NaN padded,
+ * point_scores [F, I, N], inst_scores [F, I], n_valid [F]. out_track [F, I] (-1 = not tracked), out_score [F, I],
+ * out_order [F, I] = position in the frame's returned list (or -1); t0 < 0 = infer every step. */
+int sa_tracker_track_frames(void* tracker, int n_frames, int max_inst, int n_nodes, const float* points,
+                            const float* point_scores, const float* inst_scores, const int* n_valid, int img_h, int img_w,
+                            int t0, int* out_track, double* out_score, int* out_order);
+
+/* connect_single_track_breaks (components.py:419-466) in place on a [F, I] track table (-1 = empty slot). */
+int sa_connect_single_track_breaks(int n_frames, int max_inst, const int* order, int* track, int instance_count);
+
 #ifdef __cplusplus
 }
 #endif

@@ -57,6 +57,13 @@ SIGNATURES = {
     "sa_tapconv_packed_elems": (C.c_size_t, [_i, _i, _i]),
     "sa_pack_tapconv_weights": (_i, [_p, _i, _i, _i, _i, _i, _p]),
     "sa_maxpool_bf16": (_i, [_p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p]),
+    "sa_tracker_create": (_p, [_p]),
+    "sa_tracker_destroy": (None, [_p]),
+    "sa_tracker_reset": (_i, [_p]),
+    "sa_tracker_n_tracks": (_i, [_p]),
+    "sa_tracker_track": (_i, [_p, _i, _i, _p, _p, _p, _i, _i, _i, _p, _p, _p, _p]),
+    "sa_tracker_track_frames": (_i, [_p, _i, _i, _i, _p, _p, _p, _p, _i, _i, _i, _p, _p, _p]),
+    "sa_connect_single_track_breaks": (_i, [_i, _i, _p, _p, _i]),
     "sa_maxpool2x2_bf16": (_i, [_p, _i, _i, _i, _i, _p, _p]),
     "sa_upsample2x_bf16": (_i, [_p, _i, _i, _i, _i, _i, _p, _p]),
     "sa_conv1x1_head": (_i, [_p, _i, _p, _p, _i, _i, _i, _i, _i, _p, _p]),

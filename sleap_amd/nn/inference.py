@@ -751,7 +751,34 @@ class Predictor:
         if make_labels:
             raise ImportError("predict(make_labels=True) builds sleap.Labels with the reference's own classes, which is "
                               "only wired up for the bottom-up predictor here; call predict(data, make_labels=False)")
-        return list(self._predict_generator(data))
+        return self._apply_tracker(list(self._predict_generator(data)))
+
+    def _apply_tracker(self, outs: List[Dict[str, np.ndarray]]) -> List[Dict[str, np.ndarray]]:
+        """Identity tracking over the gathered per-batch arrays, strictly in frame order, where the reference runs it
+        (inference.py:3306-3313, 3345-3346). Adds `track_inds (b, I)` (-1 = no track), `tracking_scores (b, I)` and
+        `track_order (b, I)` (position in the tracker's returned list) to every batch; `predictor.tracker.spawned_tracks`
+        names the tracks. Requires the array tracker of `sleap_amd.nn.tracking`."""
+        trk = self.tracker
+        if not trk or not outs or not hasattr(trk, "track_frames"):
+            return outs
+        for ex in outs:
+            hw = ex["image"].shape[1:3] if "image" in ex else (1, 1)
+            r = trk.track_frames(ex["instance_peaks"], ex.get("instance_peak_vals"), ex.get("instance_scores"),
+                                 ex.get("n_valid"), img_hw=hw, t0=int(ex["frame_ind"][0]))
+            ex["track_inds"], ex["tracking_scores"], ex["track_order"] = r["track"], r["tracking_score"], r["order"]
+        imax = max(ex["track_inds"].shape[1] for ex in outs)
+
+        def cat(key, fill):
+            return np.ascontiguousarray(np.concatenate(
+                [np.pad(ex[key], ((0, 0), (0, imax - ex[key].shape[1])), constant_values=fill) for ex in outs]))
+
+        table = trk.final_pass(cat("track_inds", -1).astype(np.int32), cat("track_order", -1).astype(np.int32))
+        o = 0
+        for ex in outs:
+            b, i = ex["track_inds"].shape
+            ex["track_inds"] = table[o:o + b, :i].copy()
+            o += b
+        return outs
 
 
 class SingleInstancePredictor(Predictor):
@@ -1018,7 +1045,7 @@ class BottomUpPredictor(Predictor):
         gen = self._predict_generator(data)
         if make_labels:
             return self._make_labeled_frames_from_generator(gen, data)
-        return list(gen)
+        return self._apply_tracker(list(gen))
 
     def _make_labeled_frames_from_generator(self, generator, data):
         """inference.py:3230-3348 -- hands arrays to sleap's own result containers."""
@@ -1069,11 +1096,19 @@ def load_model(model_path: Union[str, List[str]], batch_size: int = 4, peak_thre
             resolved.extend(found)
         else:
             resolved.append(mp)
-    if tracker is not None:
-        raise NotImplementedError("tracking (sleap.nn.tracking) is outside this package's hot path; pass the "
-                                  "reference's own Tracker through predictor.tracker")
+    tracker_obj = None
+    if tracker is not None:  # inference.py:4985-4998
+        from .tracking import Tracker
+
+        use_max_tracker = tracker_max_instances is not None
+        if use_max_tracker and not tracker.endswith("maxtracks"):
+            tracker += "maxtracks"
+        tracker_obj = Tracker.make_tracker_by_name(tracker=tracker, track_window=tracker_window,
+                                                   post_connect_single_breaks=True, max_tracking=use_max_tracker,
+                                                   max_tracks=tracker_max_instances)
     predictor = Predictor.from_model_paths(resolved, peak_threshold=peak_threshold,
                                            integral_refinement=refinement == "integral", batch_size=batch_size,
                                            resize_input_layer=resize_input_layer, max_instances=max_instances)
     predictor.verbosity = progress_reporting if progress_reporting in ("json", "none") else "none"
+    predictor.tracker = tracker_obj
     return predictor

@@ -1,0 +1,202 @@
+"""Cross-frame identity tracking on the predictor's array outputs.
+
+Mirrors `sleap.nn.tracking.Tracker` (sleap/nn/tracking.py:542-992) for the `simple` and `simplemaxtracks` candidate
+makers: same `make_tracker_by_name` keyword arguments, defaults and error messages, same per-frame `track` semantics
+(candidate pool from the last `track_window` frames, similarity matrix against the best / robust-quantile candidate of
+every track, greedy or Hungarian assignment, new tracks for what is left, optional pre-cull and single-break
+connection). The work happens in `libsleap_amd.so` (`csrc/tracker.hip`, host C++ -- no Python objects per instance, no
+GIL while a batch of frames is tracked); this module only marshals arrays.
+
+Instances are arrays, not `PredictedInstance`s: points (n, N, 2) with NaN for missing nodes, point scores (n, N),
+instance scores (n,). Tracks are integers, `spawned_tracks[i]` is the reference's name for track i.
+Not covered (they need cv2 / pykalman, absent offline): optical-flow candidate makers, the Kalman tracker.
+"""
+import ctypes as C
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+from .. import _lib
+from .._lib import check
+
+SIMILARITY = {"instance": 0, "centroid": 1, "iou": 2, "normalized_instance": 3, "object_keypoint": 4}
+MATCH = {"greedy": 0, "hungarian": 1}
+OKS_NORM = {"all": 0, "ref": 1, "union": 2}
+
+
+class _Config(C.Structure):
+    _fields_ = [("max_tracks_mode", C.c_int), ("similarity", C.c_int), ("match", C.c_int), ("track_window", C.c_int),
+                ("robust", C.c_double), ("min_new_track_points", C.c_int), ("min_match_points", C.c_int),
+                ("target_instance_count", C.c_int), ("pre_cull_to_target", C.c_int), ("pre_cull_iou_threshold", C.c_double),
+                ("max_tracks", C.c_int), ("max_tracking", C.c_int), ("oks_n_errors", C.c_int),
+                ("oks_errors", C.POINTER(C.c_double)), ("oks_score_weighting", C.c_int), ("oks_normalization", C.c_int)]
+
+
+def _f32(a):
+    return None if a is None else np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class Tracker:
+    """`Tracker.make_tracker_by_name(tracker="simple", similarity="instance", match="greedy", track_window=5, ...)`."""
+
+    def __init__(self, **kwargs):
+        self._h = None
+        self._configure(**kwargs)
+
+    @classmethod
+    def make_tracker_by_name(cls, tracker: str = "flow", similarity: str = "instance", match: str = "greedy",
+                             track_window: int = 5, robust: float = 1.0, min_new_track_points: int = 0,
+                             min_match_points: int = 0, img_scale: float = 1.0, of_window_size: int = 21,
+                             of_max_levels: int = 3, save_shifted_instances: bool = False, target_instance_count: int = 0,
+                             pre_cull_to_target: bool = False, pre_cull_iou_threshold: Optional[float] = None,
+                             post_connect_single_breaks: bool = False, clean_instance_count: int = 0,
+                             clean_iou_threshold: Optional[float] = None, kf_init_frame_count: int = 0,
+                             kf_node_indices: Optional[list] = None, max_tracks: Optional[int] = None,
+                             max_tracking: bool = False, oks_errors: Optional[list] = None,
+                             oks_score_weighting: bool = False, oks_normalization: str = "all", **kwargs):
+        return cls(tracker=tracker, similarity=similarity, match=match, track_window=track_window, robust=robust,
+                   min_new_track_points=min_new_track_points, min_match_points=min_match_points,
+                   target_instance_count=target_instance_count, pre_cull_to_target=pre_cull_to_target,
+                   pre_cull_iou_threshold=pre_cull_iou_threshold, post_connect_single_breaks=post_connect_single_breaks,
+                   clean_instance_count=clean_instance_count, kf_init_frame_count=kf_init_frame_count,
+                   kf_node_indices=kf_node_indices, max_tracks=max_tracks, max_tracking=max_tracking,
+                   oks_errors=oks_errors, oks_score_weighting=oks_score_weighting, oks_normalization=oks_normalization)
+
+    def _configure(self, tracker="simple", similarity="instance", match="greedy", track_window=5, robust=1.0,
+                   min_new_track_points=0, min_match_points=0, target_instance_count=0, pre_cull_to_target=False,
+                   pre_cull_iou_threshold=None, post_connect_single_breaks=False, clean_instance_count=0,
+                   kf_init_frame_count=0, kf_node_indices=None, max_tracks=None, max_tracking=False, oks_errors=None,
+                   oks_score_weighting=False, oks_normalization="all"):
+        max_tracking = max_tracking if max_tracks else False  # tracking.py:879
+        if max_tracking and tracker in ("simple", "flow"):
+            tracker += "maxtracks"
+        if tracker not in ("simple", "flow", "simplemaxtracks", "flowmaxtracks"):
+            raise ValueError(f"{tracker} is not a valid tracker.")
+        if similarity not in SIMILARITY:
+            raise ValueError(f"{similarity} is not a valid tracker similarity function.")
+        if match not in MATCH:
+            raise ValueError(f"{match} is not a valid tracker matching function.")
+        if tracker.startswith("flow"):
+            raise NotImplementedError("optical-flow candidate makers need cv2.calcOpticalFlowPyrLK; use tracker='simple' "
+                                      "or 'simplemaxtracks'")
+        if kf_init_frame_count:
+            if not (max_tracks or target_instance_count):
+                raise ValueError("Kalman filter requires max tracks or target instance count.")
+            raise NotImplementedError("the Kalman tracker (pykalman) is not implemented")
+        if clean_instance_count:
+            raise NotImplementedError("clean_instance_count (deprecated TrackCleaner) is not implemented; use "
+                                      "target_instance_count with pre_cull_to_target")
+        if oks_normalization not in OKS_NORM:
+            raise ValueError(f"{oks_normalization} is not a valid object keypoint normalization.")
+        self.tracker_name, self.similarity, self.match = tracker, similarity, match
+        self.track_window = int(track_window)
+        self.robust_best_instance = float(robust)
+        self.min_new_track_points, self.min_match_points = int(min_new_track_points), int(min_match_points)
+        self.target_instance_count = int(target_instance_count)
+        self.post_connect_single_breaks = bool(post_connect_single_breaks)
+        self.max_tracks, self.max_tracking = max_tracks, bool(max_tracking)
+        errs = None
+        if oks_errors is not None and np.size(oks_errors) > 0:
+            errs = np.ascontiguousarray(np.atleast_1d(oks_errors), dtype=np.float64)
+        self._oks_errors = errs  # keep alive
+        cfg = _Config(1 if tracker == "simplemaxtracks" else 0, SIMILARITY[similarity], MATCH[match], self.track_window,
+                      self.robust_best_instance, self.min_new_track_points, self.min_match_points,
+                      self.target_instance_count, int(bool(pre_cull_to_target)),
+                      float(pre_cull_iou_threshold) if pre_cull_iou_threshold else 0.0, int(max_tracks or 0),
+                      int(self.max_tracking), 0 if errs is None else errs.size,
+                      None if errs is None else errs.ctypes.data_as(C.POINTER(C.c_double)), int(bool(oks_score_weighting)),
+                      OKS_NORM[oks_normalization])
+        h = _lib.lib()
+        self._h = h.sa_tracker_create(C.byref(cfg))
+        if not self._h:
+            raise ValueError(h.sa_last_error().decode())
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            try:
+                _lib.lib().sa_tracker_destroy(C.c_void_p(self._h))
+            except Exception:
+                pass
+            self._h = None
+
+    # ------------------------------------------------------------------ reference-shaped surface
+    @property
+    def is_valid(self) -> bool:
+        return True
+
+    @property
+    def uses_image(self) -> bool:
+        return False
+
+    @property
+    def has_max_tracking(self) -> bool:
+        return self.tracker_name == "simplemaxtracks"
+
+    @property
+    def spawned_tracks(self) -> List[str]:
+        return [f"track_{i}" for i in range(_lib.lib().sa_tracker_n_tracks(C.c_void_p(self._h)))]
+
+    def reset_candidates(self):
+        check(_lib.lib().sa_tracker_reset(C.c_void_p(self._h)), "sa_tracker_reset")
+
+    def get_name(self) -> str:
+        maker = "SimpleMaxTracksCandidateMaker" if self.has_max_tracking else "SimpleCandidateMaker"
+        sim = {"instance": "instance_similarity", "centroid": "centroid_distance", "iou": "instance_iou",
+               "normalized_instance": "normalized_instance_similarity",
+               "object_keypoint": "object_keypoint_similarity"}[self.similarity]
+        return f"{maker}.{sim}.{self.match}_matching"
+
+    def track(self, points, point_scores=None, instance_scores=None, img_hw=(1, 1), img=None, t: Optional[int] = None):
+        """One frame (tracking.py:642-773). -> dict(index (m,), track (m,), tracking_score (m,)): the tracked instances
+        in the reference's order (matches first, then newly spawned tracks); `index` points back into the input."""
+        pts = _f32(points)
+        n = 0 if pts is None else pts.shape[0]
+        n_nodes = pts.shape[1] if n else 1
+        ps, sc = _f32(point_scores), _f32(instance_scores)
+        idx, trk = np.full((max(n, 1),), -1, np.int32), np.full((max(n, 1),), -1, np.int32)
+        tsc = np.zeros((max(n, 1),), np.float64)
+        n_out = C.c_int(0)
+        check(_lib.lib().sa_tracker_track(C.c_void_p(self._h), n, n_nodes, _ptr(pts) if n else None, _ptr(ps) if n else None,
+                                          _ptr(sc) if n else None, int(img_hw[0]), int(img_hw[1]), -1 if t is None else int(t),
+                                          _ptr(idx), _ptr(trk), _ptr(tsc), C.byref(n_out)), "sa_tracker_track")
+        m = n_out.value
+        return {"index": idx[:m].copy(), "track": trk[:m].copy(), "tracking_score": tsc[:m].copy()}
+
+    def track_frames(self, instance_peaks, instance_peak_vals=None, instance_scores=None, n_valid=None, img_hw=(1, 1),
+                     t0: Optional[int] = None):
+        """A run of consecutive frames in the predictor's output layout (F, I, N, 2) NaN padded. ->
+        dict(track (F, I) int32 with -1 for empty / dropped slots, tracking_score (F, I), order (F, I))."""
+        pts = _f32(instance_peaks)
+        F, I, N = pts.shape[0], pts.shape[1], pts.shape[2]
+        if n_valid is None:
+            n_valid = (~np.isnan(pts).all(axis=(2, 3))).sum(axis=1)
+        nv = np.ascontiguousarray(n_valid, dtype=np.int32)
+        ps, sc = _f32(instance_peak_vals), _f32(instance_scores)
+        trk = np.full((F, I), -1, np.int32)
+        tsc = np.full((F, I), np.nan, np.float64)
+        order = np.full((F, I), -1, np.int32)
+        check(_lib.lib().sa_tracker_track_frames(C.c_void_p(self._h), F, I, N, _ptr(pts), _ptr(ps), _ptr(sc), _ptr(nv),
+                                                 int(img_hw[0]), int(img_hw[1]), -1 if t0 is None else int(t0), _ptr(trk),
+                                                 _ptr(tsc), _ptr(order)), "sa_tracker_track_frames")
+        return {"track": trk, "tracking_score": tsc, "order": order}
+
+    def final_pass(self, track: np.ndarray, order: Optional[np.ndarray] = None) -> np.ndarray:
+        """tracking.py:816-835 on the (F, I) track table of a whole video (modified in place and returned)."""
+        if (self.target_instance_count or self.max_tracks) and self.post_connect_single_breaks:
+            if not self.target_instance_count:
+                self.target_instance_count = int(self.max_tracks)
+            connect_single_track_breaks(track, self.target_instance_count, order)
+        return track
+
+
+def connect_single_track_breaks(track: np.ndarray, instance_count: int, order: Optional[np.ndarray] = None) -> np.ndarray:
+    """components.py:419-466 on a (F, I) int32 track table (-1 = no instance), in place."""
+    assert track.dtype == np.int32 and track.flags.c_contiguous and track.ndim == 2
+    od = None if order is None else np.ascontiguousarray(order, dtype=np.int32)
+    check(_lib.lib().sa_connect_single_track_breaks(track.shape[0], track.shape[1], _ptr(od), _ptr(track), int(instance_count)),
+          "sa_connect_single_track_breaks")
+    return track

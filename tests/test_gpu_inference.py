@@ -137,3 +137,31 @@ def test_preprocess_matches_oracle(shape, dtype, scale, stride):  # ref :399-497
         g = ensure_float(g)
     assert g.shape == want.shape
     assert_allclose(g, want, atol=1.0 / 255 + 1e-6 if scale != 1.0 or shape[-1] == 3 else 0)
+
+
+def test_predict_with_tracker_matches_oracle_tracker(predictor, frames):
+    """load_model(tracker="simple") + predict: track ids / scores equal the NumPy restatement of the reference tracker
+    fed with the same predicted instances, frame by frame across batch boundaries (inference.py:3306-3313, 4985-4998)."""
+    from oracle import tracking as OT
+    from sleap_amd.nn.inference import load_model
+
+    p = load_model(MODEL_DIR, batch_size=2, progress_reporting="none", tracker="simple", tracker_window=3)
+    p.inference_model.bottomup_layer.peak_threshold = predictor.inference_model.bottomup_layer.peak_threshold
+    assert p.tracker.get_name() == "SimpleCandidateMaker.instance_similarity.greedy_matching"
+    outs = p.predict(frames, make_labels=False)
+    ot = OT.Tracker(tracker="simple", similarity="instance", match="greedy", track_window=3)
+    n_tracked = 0
+    for ex in outs:
+        assert ex["track_inds"].shape == ex["instance_scores"].shape
+        for f in range(len(ex["frame_ind"])):
+            nv = int(ex["n_valid"][f])
+            insts = [OT.Inst(ex["instance_peaks"][f, i], ex["instance_peak_vals"][f, i], ex["instance_scores"][f, i], uid=i)
+                     for i in range(nv)]
+            res = ot.track(insts, img_hw=frames.shape[1:3], t=int(ex["frame_ind"][f]))
+            assert sorted((r.uid, r.track) for r in res) == sorted(
+                (i, int(ex["track_inds"][f, i])) for i in range(ex["track_inds"].shape[1]) if ex["track_inds"][f, i] >= 0)
+            for k, r in enumerate(res):
+                assert ex["track_order"][f, r.uid] == k
+                assert ex["tracking_scores"][f, r.uid] == pytest.approx(r.tracking_score, rel=1e-12, abs=1e-300)
+            n_tracked += len(res)
+    assert n_tracked > 0 and len(p.tracker.spawned_tracks) == len(ot.spawned_tracks)

@@ -1,0 +1,170 @@
+"""The native tracker (csrc/tracker.hip through the C ABI) against the NumPy restatement of the reference's tracker
+(oracle/tracking.py, itself pinned to the reference's tests in test_oracle_tracking.py): identical track assignment, order
+of returned instances and spawned-track numbering on random walks with drop-outs, missing nodes and extra detections;
+tracking scores to 1e-12 (exp() implementations differ in the last bit). Host code only: runs without a GPU."""
+import itertools
+
+import numpy as np
+import pytest
+
+from oracle import tracking as T
+
+
+def _sequence(seed, n_frames=40, n_animals=4, n_nodes=6, p_drop=0.15, p_miss=0.15, p_extra=0.1, step=3.0):
+    rng = np.random.default_rng(seed)
+    base = rng.uniform(20, 200, (n_animals, 1, 2)) + rng.normal(0, 6, (n_animals, n_nodes, 2))
+    frames = []
+    for _ in range(n_frames):
+        base = base + rng.normal(0, step, (n_animals, 1, 2))
+        insts = []
+        for a in rng.permutation(n_animals):
+            if rng.random() < p_drop:
+                continue
+            pts = (base[a] + rng.normal(0, 0.5, (n_nodes, 2))).astype(np.float32)
+            pts[rng.random(n_nodes) < p_miss] = np.nan
+            insts.append((pts, rng.uniform(0.2, 1, n_nodes).astype(np.float32), np.float32(rng.uniform(0.3, 1))))
+        if rng.random() < p_extra:
+            pts = rng.uniform(20, 200, (n_nodes, 2)).astype(np.float32)
+            insts.append((pts, rng.uniform(0.2, 1, n_nodes).astype(np.float32), np.float32(rng.uniform(0.1, 0.5))))
+        frames.append(insts)
+    frames[3] = []  # an empty frame
+    return frames
+
+
+def _run_oracle(frames, img_hw, **kw):
+    tr = T.Tracker(**kw)
+    out = []
+    for insts in frames:
+        lst = [T.Inst(p, s, sc, uid=i) for i, (p, s, sc) in enumerate(insts)]
+        res = tr.track(lst, img_hw=img_hw)
+        out.append([(r.uid, r.track, r.tracking_score) for r in res])
+    return out, len(tr.spawned_tracks)
+
+
+def _run_native(frames, img_hw, **kw):
+    from sleap_amd.nn.tracking import Tracker
+
+    tr = Tracker.make_tracker_by_name(**kw)
+    out = []
+    for insts in frames:
+        if insts:
+            pts = np.stack([p for p, _, _ in insts])
+            ps = np.stack([s for _, s, _ in insts])
+            sc = np.array([c for _, _, c in insts], np.float32)
+            r = tr.track(pts, ps, sc, img_hw=img_hw)
+        else:
+            r = tr.track(np.zeros((0, 6, 2), np.float32), img_hw=img_hw)
+        out.append(list(zip(r["index"].tolist(), r["track"].tolist(), r["tracking_score"].tolist())))
+    return out, len(tr.spawned_tracks)
+
+
+def _compare(a, b):
+    assert len(a) == len(b)
+    for f, (fa, fb) in enumerate(zip(a, b)):
+        assert [(u, t) for u, t, _ in fa] == [(u, t) for u, t, _ in fb], f"frame {f}: {fa} vs {fb}"
+        for (_, _, sa_), (_, _, sb) in zip(fa, fb):
+            assert sa_ == pytest.approx(sb, rel=1e-12, abs=1e-300), f"frame {f}"
+
+
+CASES = [dict(tracker=t, similarity=s, match=m) for t, s, m in itertools.product(
+    ["simple", "simplemaxtracks"], ["instance", "normalized_instance", "centroid", "iou", "object_keypoint"],
+    ["greedy", "hungarian"])]
+
+
+@pytest.mark.parametrize("case", CASES, ids=lambda c: f"{c['tracker']}-{c['similarity']}-{c['match']}")
+def test_native_tracker_matches_oracle(case):
+    kw = dict(case, track_window=3)
+    if case["tracker"] == "simplemaxtracks":
+        kw.update(max_tracks=4, max_tracking=True)
+    frames = _sequence(hash(str(sorted(case.items()))) % 1000, step=0.7 if case["similarity"] == "instance" else 3.0)
+    a, na = _run_oracle(frames, (256, 320), **kw)
+    b, nb = _run_native(frames, (256, 320), **kw)
+    _compare(a, b)
+    assert na == nb and na >= 4
+
+
+@pytest.mark.parametrize("kw", [
+    dict(tracker="simple", similarity="instance", match="greedy", robust=0.8, track_window=5),
+    dict(tracker="simple", similarity="iou", match="hungarian", robust=0.95, track_window=4),
+    dict(tracker="simple", similarity="centroid", match="greedy", min_new_track_points=5, min_match_points=4),
+    dict(tracker="simple", similarity="centroid", match="hungarian", target_instance_count=3, pre_cull_to_target=True),
+    dict(tracker="simple", similarity="iou", match="greedy", target_instance_count=3, pre_cull_to_target=True,
+         pre_cull_iou_threshold=0.3),
+    dict(tracker="simple", similarity="object_keypoint", match="greedy", oks_errors=[1.5, 2.5, 4], oks_score_weighting=True,
+         oks_normalization="union"),
+    dict(tracker="simple", similarity="object_keypoint", match="hungarian", oks_errors=[3.0], oks_normalization="ref"),
+    dict(tracker="simple", similarity="centroid", match="greedy", max_tracks=3, max_tracking=True, track_window=2),
+    dict(tracker="simplemaxtracks", similarity="iou", match="greedy", max_tracks=2, max_tracking=False),
+], ids=lambda k: "-".join(f"{a}={b}" for a, b in k.items() if a not in ("tracker", "similarity", "match"))[:60])
+def test_native_tracker_options(kw):
+    frames = _sequence(11, n_frames=50, p_drop=0.25, p_extra=0.3)
+    a, na = _run_oracle(frames, (1, 1), **kw)
+    b, nb = _run_native(frames, (1, 1), **kw)
+    _compare(a, b)
+    assert na == nb
+
+
+def test_reference_known_answers_native():
+    """The reference's max-tracking scenarios (tests/nn/test_tracker_components.py) through the native tracker."""
+    from test_oracle_tracking import EXTRA, GAP_BOTH, GAP_SINGLE, make_insts
+
+    def n_tracks(trx, **kw):
+        frames = [[(i.points.astype(np.float32), np.ones(3, np.float32), np.float32(1)) for i in f] for f in make_insts(trx)]
+        out, _ = _run_native([[(p, s, c) for p, s, c in f] for f in frames], (1, 1), **kw)
+        return len({t for f in out for _, t, _ in f})
+
+    simple = dict(tracker="simple", match="hungarian", track_window=2)
+    maxtr = dict(tracker="simplemaxtracks", match="hungarian", track_window=2, max_tracks=2, max_tracking=True)
+    assert n_tracks(GAP_SINGLE, **simple) == 3 and n_tracks(GAP_SINGLE, **maxtr) == 2
+    assert n_tracks(GAP_BOTH, **simple) == 4 and n_tracks(GAP_BOTH, **maxtr) == 2
+    assert n_tracks(EXTRA, **simple) == 4 and n_tracks(EXTRA, **maxtr) == 2
+
+
+def test_track_frames_equals_per_frame_calls_and_connect_breaks():
+    from sleap_amd.nn.tracking import Tracker, connect_single_track_breaks
+
+    frames = _sequence(5, n_frames=30, n_nodes=6)
+    I = max(len(f) for f in frames)
+    pts = np.full((len(frames), I, 6, 2), np.nan, np.float32)
+    ps = np.zeros((len(frames), I, 6), np.float32)
+    sc = np.zeros((len(frames), I), np.float32)
+    nv = np.zeros((len(frames),), np.int32)
+    for f, insts in enumerate(frames):
+        nv[f] = len(insts)
+        for i, (p, s, c) in enumerate(insts):
+            pts[f, i], ps[f, i], sc[f, i] = p, s, c
+    kw = dict(tracker="simple", similarity="iou", match="hungarian", track_window=3, target_instance_count=4,
+              post_connect_single_breaks=True)
+    res = Tracker.make_tracker_by_name(**kw).track_frames(pts, ps, sc, nv, img_hw=(1, 1))
+    per, _ = _run_native(frames, (1, 1), **kw)
+    for f, lst in enumerate(per):
+        assert sorted((u, t) for u, t, _ in lst) == sorted((i, int(res["track"][f, i])) for i in range(I) if res["track"][f, i] >= 0)
+        for k, (u, _, s) in enumerate(lst):
+            assert res["order"][f, u] == k and res["tracking_score"][f, u] == s
+    # connect_single_track_breaks vs the oracle on the tracked table
+    ofr = [[T.Inst([[0, 0]], track=int(res["track"][f, i]), uid=i) for i in np.argsort(res["order"][f], kind="stable")
+            if res["track"][f, i] >= 0] for f in range(len(frames))]
+    T.connect_single_track_breaks(ofr, 4)
+    tbl = res["track"].copy()
+    connect_single_track_breaks(tbl, 4, res["order"])
+    for f, lst in enumerate(ofr):
+        for inst in lst:
+            assert tbl[f, inst.uid] == inst.track
+    assert (tbl != res["track"]).any()  # the scenario actually reconnects something
+
+
+def test_errors_like_reference():
+    from sleap_amd.nn.tracking import Tracker
+
+    with pytest.raises(ValueError, match="is not a valid tracker"):
+        Tracker.make_tracker_by_name(tracker="nope")
+    with pytest.raises(ValueError, match="not a valid tracker similarity"):
+        Tracker.make_tracker_by_name(tracker="simple", similarity="cosine")
+    with pytest.raises(ValueError, match="not a valid tracker matching"):
+        Tracker.make_tracker_by_name(tracker="simple", match="optimal")
+    with pytest.raises(ValueError, match="Kalman filter requires max tracks or target instance count"):
+        Tracker.make_tracker_by_name(tracker="simple", kf_init_frame_count=10)
+    with pytest.raises(NotImplementedError):
+        Tracker.make_tracker_by_name()  # reference default is the optical-flow tracker
+    t = Tracker.make_tracker_by_name(tracker="simple", similarity="iou", match="hungarian")
+    assert t.get_name() == "SimpleCandidateMaker.instance_iou.hungarian_matching"
