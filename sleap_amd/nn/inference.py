@@ -753,6 +753,21 @@ class Predictor:
                               "only wired up for the bottom-up predictor here; call predict(data, make_labels=False)")
         return self._apply_tracker(list(self._predict_generator(data)))
 
+    def save_predictions(self, filename: str, outs: List[Dict[str, np.ndarray]], video: Optional[dict] = None,
+                         part_names: Optional[List[str]] = None, edges=None):
+        """Write `predict(make_labels=False)` results as a `.slp` file the reference can open (`sleap.load_file`):
+        the columnar writer of `sleap_amd.io.slp` instead of per-instance `PredictedInstance` objects + `Labels.save`."""
+        from ..io import slp
+
+        if part_names is None:
+            scorer = getattr(getattr(self.inference_model, "bottomup_layer", None), "paf_scorer", None)
+            if scorer is None:
+                raise ValueError("part_names / edges are required for predictors without a PAFScorer")
+            part_names, edges = scorer.part_names, scorer.edge_inds
+        names = self.tracker.spawned_tracks if self.tracker and hasattr(self.tracker, "spawned_tracks") else None
+        return slp.write_slp(filename, outs, part_names, edges or [], video=video, track_names=names,
+                             max_instances=self.max_instances if hasattr(self, "max_instances") else None)
+
     def _apply_tracker(self, outs: List[Dict[str, np.ndarray]]) -> List[Dict[str, np.ndarray]]:
         """Identity tracking over the gathered per-batch arrays, strictly in frame order, where the reference runs it
         (inference.py:3306-3313, 3345-3346). Adds `track_inds (b, I)` (-1 = no track), `tracking_scores (b, I)` and

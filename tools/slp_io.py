@@ -1,0 +1,55 @@
+"""HDF5 side of the .slp reader / writer, runnable under any interpreter that has h5py (this image: /opt/conda/bin/python3.9).
+
+    python tools/slp_io.py read  <file.slp> <out.npz>     tables + metadata -> npz
+    python tools/slp_io.py write <in.npz>   <file.slp>     npz (as produced by sleap_amd.io.slp) -> .slp
+
+Dataset layout as written by the reference (sleap/io/format/hdf5.py:265-575): group `metadata` with attrs `format_id`
+(float) and `json` (bytes); string datasets `videos_json`, `tracks_json`, `suggestions_json` (one JSON document per
+element, float64 when empty); structured datasets `frames`, `instances`, `points`, `pred_points`, all 1-D with
+maxshape (None,).
+"""
+import sys
+
+import numpy as np
+
+
+def read(path, out):
+    import h5py
+
+    d = {}
+    with h5py.File(path, "r") as f:
+        for k in ("frames", "instances", "points", "pred_points"):
+            d[k] = f[k][:]
+        for k in ("videos_json", "tracks_json", "suggestions_json"):
+            arr = f[k][:] if k in f else np.zeros((0,))
+            d[k] = np.array([x.decode() if isinstance(x, bytes) else str(x) for x in arr], dtype=object) if len(arr) else \
+                np.zeros((0,), dtype=object)
+        m = f["metadata"].attrs
+        d["format_id"] = np.float64(m["format_id"])
+        j = m["json"]
+        d["json"] = np.array(j.decode() if isinstance(j, bytes) else (j.tobytes().decode() if hasattr(j, "tobytes") else str(j)),
+                             dtype=object)
+    np.savez(out, **{k: (v if v.dtype != object else np.array(v.tolist(), dtype=str)) for k, v in d.items()})
+
+
+def write(npz, path):
+    import os
+
+    import h5py
+
+    z = np.load(npz, allow_pickle=False)
+    if os.path.exists(path):
+        os.unlink(path)  # hdf5.py:282-283
+    with h5py.File(path, "a") as f:
+        g = f.require_group("metadata")
+        g.attrs["format_id"] = float(z["format_id"])
+        for key in ("videos_json", "tracks_json", "suggestions_json"):
+            data = [np.string_(s) for s in z[key].tolist()]
+            f.create_dataset(key, data=data, maxshape=(None,))
+        g.attrs["json"] = np.string_(str(z["json"]))
+        for key in ("points", "pred_points", "instances", "frames"):
+            f.create_dataset(key, data=z[key], maxshape=(None,), dtype=z[key].dtype)
+
+
+if __name__ == "__main__":
+    {"read": read, "write": write}[sys.argv[1]](sys.argv[2], sys.argv[3])
