@@ -1,0 +1,273 @@
+"""Frame sources and the per-rank frame feed.
+
+The reference reads frames one at a time on a single Python thread (`tf.py_function(video.get_frame)`,
+sleap/nn/data/providers.py:371-439, "we don't parallelize here for thread safety"), which caps any fast predictor. Here:
+
+* `Video` -- the thin facade of sleap/io/video.py:1023-1508 over array-like backends: `NumpyVideo` (in-memory array or a
+  memory-mapped `.npy`, sleap/io/video.py:511-590) and `HDF5Video` (dataset of frames in an HDF5 file with the reference's
+  `input_format` / `convert_range` options, sleap/io/video.py:47-338). Media files (`MediaVideo`, cv2 / H.264) are out of
+  reach offline: no decoder exists in this image.
+* `VideoReader` -- the provider surface (`videos`, `example_indices`, `len`, `make_dataset()` yielding the same example
+  dictionaries).
+* `FramePrefetcher` -- the throughput piece: a producer thread reads whole batches ahead of the consumer into a small ring
+  of page-locked host buffers; the predictor uploads them with asynchronous copies on its network stream, so reading,
+  H2D transfer, network and post-processing of consecutive batches overlap. Under torch.distributed every rank runs its
+  own prefetcher over its own contiguous slice of each global batch (no rank reads another rank's frames).
+"""
+import os
+import queue
+import threading
+from typing import Iterator, List, Optional, Sequence, Tuple, Union
+
+import numpy as np
+
+
+class NumpyVideo:
+    """sleap/io/video.py:511-590: frames as an array (frames, height, width, channels)."""
+
+    def __init__(self, filename: Union[str, np.ndarray]):
+        if isinstance(filename, str):
+            self.filename = filename
+            self._data = np.load(filename, mmap_mode="r")
+        else:
+            self.filename = "numpy array"
+            self._data = filename
+        if self._data.ndim == 3:
+            self._data = self._data[..., None]
+        if self._data.ndim != 4:
+            raise ValueError(f"video array must have shape (frames, height, width, channels), got {self._data.shape}")
+
+    frames = property(lambda self: self._data.shape[0])
+    height = property(lambda self: self._data.shape[1])
+    width = property(lambda self: self._data.shape[2])
+    channels = property(lambda self: self._data.shape[3])
+    dtype = property(lambda self: self._data.dtype)
+
+    def get_frame(self, idx: int) -> np.ndarray:
+        return np.asarray(self._data[idx])
+
+    def get_frames(self, lo: int, hi: int) -> np.ndarray:
+        return np.asarray(self._data[lo:hi])
+
+
+class HDF5Video:
+    """sleap/io/video.py:47-338: a frames dataset inside an HDF5 file.
+
+    input_format "channels_last" = (frames, height, width, channels), "channels_first" = (frames, channels, width, height)
+    (video.py:114-126 transposes 2 <-> 1 and moves channels last); convert_range: float data in [0, 1] is scaled to
+    uint8 [0, 255] (video.py:306-312). Needs h5py in the running interpreter."""
+
+    def __init__(self, filename: str, dataset: str, input_format: str = "channels_last", convert_range: bool = True):
+        try:
+            import h5py
+        except ImportError as e:  # pragma: no cover
+            raise ImportError("HDF5Video needs h5py in this interpreter; convert the dataset to .npy once "
+                              "(np.save) and use NumpyVideo, which memory-maps it") from e
+        if input_format not in ("channels_last", "channels_first"):
+            raise ValueError(f"unknown input_format {input_format}")
+        self.filename, self.dataset, self.input_format, self.convert_range = filename, dataset, input_format, convert_range
+        self._f = h5py.File(filename, "r")
+        self._d = self._f[dataset]
+        s = self._d.shape
+        if len(s) != 4:
+            raise ValueError(f"dataset {dataset} must be 4-D, got {s}")
+        self._shape = (s[0], s[1], s[2], s[3]) if input_format == "channels_last" else (s[0], s[3], s[2], s[1])
+
+    frames = property(lambda self: self._shape[0])
+    height = property(lambda self: self._shape[1])
+    width = property(lambda self: self._shape[2])
+    channels = property(lambda self: self._shape[3])
+
+    @property
+    def dtype(self):
+        return np.dtype(np.uint8) if (self.convert_range and self._d.dtype.kind == "f") else self._d.dtype
+
+    def _fix(self, x):
+        if self.input_format == "channels_first":
+            x = np.transpose(x, (0, 3, 2, 1))
+        if self.convert_range and x.dtype.kind == "f" and np.max(x, initial=0.0) <= 1.0:
+            x = (x * 255).astype(np.uint8)
+        return x
+
+    def get_frame(self, idx: int) -> np.ndarray:
+        return self._fix(self._d[idx:idx + 1])[0]
+
+    def get_frames(self, lo: int, hi: int) -> np.ndarray:
+        return self._fix(self._d[lo:hi])
+
+
+class Video:
+    """sleap/io/video.py:1023-1508 (`sleap.Video`): the facade the predictor, the providers and the writer talk to."""
+
+    def __init__(self, backend):
+        self.backend = backend
+
+    @classmethod
+    def from_numpy(cls, filename: Union[str, np.ndarray], *args, **kwargs) -> "Video":
+        return cls(NumpyVideo(filename))
+
+    @classmethod
+    def from_hdf5(cls, dataset: str, filename: str, input_format: str = "channels_last", convert_range: bool = True) -> "Video":
+        return cls(HDF5Video(filename, dataset, input_format, convert_range))
+
+    @classmethod
+    def from_filename(cls, filename: str, dataset: Optional[str] = None, input_format: str = "channels_last", **kwargs) -> "Video":
+        ext = os.path.splitext(filename)[1].lower()
+        if ext == ".npy":
+            return cls.from_numpy(filename)
+        if ext in (".h5", ".hdf5", ".slp"):
+            if dataset is None:
+                raise ValueError("an HDF5 video needs the name of its frames dataset")
+            return cls.from_hdf5(dataset, filename, input_format)
+        if ext in (".mp4", ".avi", ".mov", ".mj2", ".mkv"):
+            raise NotImplementedError("media files need a video decoder (cv2 / ffmpeg); none is available offline")
+        raise ValueError(f"Could not detect backend for specified filename: {filename}")
+
+    num_frames = frames = property(lambda self: self.backend.frames)
+    height = property(lambda self: self.backend.height)
+    width = property(lambda self: self.backend.width)
+    channels = property(lambda self: self.backend.channels)
+    dtype = property(lambda self: self.backend.dtype)
+    shape = property(lambda self: (self.backend.frames, self.backend.height, self.backend.width, self.backend.channels))
+    filename = property(lambda self: self.backend.filename)
+
+    def __len__(self) -> int:
+        return self.backend.frames
+
+    def get_frame(self, idx: int) -> np.ndarray:
+        if idx < 0 or idx >= len(self):
+            raise KeyError(f"Unable to load frame {idx} from {type(self.backend).__name__}.")  # video.py:403-405 wording
+        return self.backend.get_frame(int(idx))
+
+    def get_frames(self, idxs) -> np.ndarray:
+        idxs = list(idxs)
+        if idxs and idxs == list(range(idxs[0], idxs[0] + len(idxs))) and 0 <= idxs[0] and idxs[-1] < len(self):
+            return self.backend.get_frames(idxs[0], idxs[-1] + 1)
+        return np.stack([self.get_frame(i) for i in idxs]) if idxs else np.zeros((0,) + self.shape[1:], self.dtype)
+
+    def __getitem__(self, key):
+        if isinstance(key, slice):
+            lo, hi, step = key.indices(len(self))
+            if step == 1:
+                return self.backend.get_frames(lo, hi)
+            return self.get_frames(range(lo, hi, step))
+        if isinstance(key, (int, np.integer)):
+            return self.get_frame(int(key) % len(self) if key < 0 else int(key))
+        return self.get_frames(key)
+
+    def backend_dict(self) -> dict:
+        """The `backend` record the `.slp` writer stores in `videos_json`."""
+        return {"filename": str(self.backend.filename), "grayscale": self.channels == 1, "bgr": True,
+                "dataset": getattr(self.backend, "dataset", ""), "input_format": getattr(self.backend, "input_format", "")}
+
+
+class VideoReader:
+    """sleap/nn/data/providers.py:301-439: `VideoReader(video, example_indices=None)`."""
+
+    def __init__(self, video: Video, example_indices: Optional[Sequence[int]] = None):
+        self.video = video
+        self.example_indices = None if example_indices is None else [int(i) for i in example_indices]
+
+    @classmethod
+    def from_filepath(cls, filename: str, example_indices=None, **kwargs) -> "VideoReader":
+        return cls(Video.from_filename(filename, **kwargs), example_indices)
+
+    @property
+    def videos(self) -> List[Video]:
+        return [self.video]
+
+    @property
+    def output_keys(self) -> List[str]:
+        return ["image", "raw_image_size", "video_ind", "frame_ind", "scale"]
+
+    def indices(self) -> List[int]:
+        return list(range(len(self.video))) if self.example_indices is None else self.example_indices
+
+    def __len__(self) -> int:
+        return len(self.indices())
+
+    def make_dataset(self) -> Iterator[dict]:
+        for i in self.indices():
+            img = self.video.get_frame(i)
+            yield {"image": img, "raw_image_size": np.array(img.shape, dtype=np.int32), "video_ind": 0,
+                   "frame_ind": np.int64(i), "scale": np.ones((2,), np.float32)}
+
+
+class FramePrefetcher:
+    """Reads batches `[(lo, hi), ...]` (positions in `reader.indices()`) ahead of the consumer.
+
+    Yields `(lo, hi, frame_inds, batch)`; `batch` is a page-locked uint8/float32 torch tensor (a plain one without CUDA)
+    that stays valid until the next-but-`depth - 1` item has been requested -- call `release(event)` with a recorded
+    torch.cuda.Event after queueing the upload if the copy is asynchronous. A `KeyError("Unable to load frame ...")`
+    from the source ends the stream quietly, as the reference does (inference.py:3333-3339); other errors re-raise."""
+
+    def __init__(self, reader: Union[VideoReader, Video, np.ndarray], ranges: Sequence[Tuple[int, int]], depth: int = 3,
+                 pin_memory: Optional[bool] = None):
+        import torch
+
+        if isinstance(reader, np.ndarray):
+            reader = Video.from_numpy(reader)
+        if isinstance(reader, Video):
+            reader = VideoReader(reader)
+        self.reader, self.ranges, self.depth = reader, list(ranges), max(2, int(depth))
+        self._idx = reader.indices()
+        self._pin = torch.cuda.is_available() if pin_memory is None else bool(pin_memory)
+        self._q: "queue.Queue" = queue.Queue(maxsize=self.depth - 1)
+        self._free: "queue.Queue" = queue.Queue()
+        self._bufs = []
+        self._events = {}
+        bmax = max((hi - lo for lo, hi in self.ranges), default=0)
+        v = reader.video
+        for k in range(self.depth):
+            t = torch.empty((bmax, v.height, v.width, v.channels), dtype=torch.uint8 if v.dtype == np.uint8 else torch.float32)
+            if self._pin and bmax:
+                t = t.pin_memory()
+            self._bufs.append(t)
+            self._free.put(k)
+        self._thread = threading.Thread(target=self._produce, daemon=True)
+        self._pending_release = None
+        self._thread.start()
+
+    def _produce(self):
+        try:
+            for lo, hi in self.ranges:
+                inds = self._idx[lo:hi]
+                k = self._free.get()
+                ev = self._events.pop(k, None)
+                if ev is not None:
+                    ev.synchronize()  # the upload that read this buffer last has finished
+                buf = self._bufs[k][: hi - lo]
+                try:
+                    frames = self.reader.video.get_frames(inds)
+                except KeyError as e:
+                    if "Unable to load frame" in str(e):
+                        break
+                    raise
+                np.copyto(buf.numpy(), frames, casting="unsafe")  # straight into the page-locked buffer (no temporary)
+                self._q.put((lo, hi, np.asarray(inds, dtype=np.int64), buf, k))
+            self._q.put(None)
+        except BaseException as e:  # noqa: BLE001 - handed to the consumer thread
+            self._q.put(e)
+
+    def __iter__(self):
+        while True:
+            if self._pending_release is not None:  # the previous item was not released explicitly: assume a synchronous use
+                self._free.put(self._pending_release)
+                self._pending_release = None
+            item = self._q.get()
+            if item is None:
+                return
+            if isinstance(item, BaseException):
+                raise item
+            lo, hi, inds, buf, k = item
+            self._pending_release = k
+            yield lo, hi, inds, buf
+
+    def release(self, event=None):
+        """Hand the most recently yielded buffer back; `event` (torch.cuda.Event) marks the end of its asynchronous upload."""
+        k = self._pending_release
+        if k is not None:
+            if event is not None:
+                self._events[k] = event
+            self._free.put(k)
+            self._pending_release = None

@@ -1003,22 +1003,45 @@ class BottomUpPredictor(Predictor):
 
         Under torch.distributed each rank runs the network on its contiguous slice of the batch and one
         all-gather assembles the batch on every rank (parallel.gather_batch_results)."""
-        frames = self._frames_of(data)
-        n = len(frames)
+        from ..io.video import FramePrefetcher, Video, VideoReader
+
+        if isinstance(data, torch.Tensor):
+            data = data.cpu().numpy()
+        if isinstance(data, np.ndarray):
+            data = Video.from_numpy(data)
+        if isinstance(data, Video):
+            data = VideoReader(data)
+        reader = data if isinstance(data, VideoReader) else VideoReader(Video.from_numpy(np.stack(list(self._frames_of(data)))))
+        n = len(reader)
+        index_of = np.asarray(reader.indices(), dtype=np.int64)
         layer = self.inference_model.bottomup_layer
         rank, world = parallel.rank_world()
         i_gather = layer.paf_scorer.max_instances  # instance capacity of the gathered buffer, equal on all ranks
         t0 = time.time()
         n_done = 0
         last_report = t0
-        for i0 in range(0, n, self.batch_size):
-            i1 = min(i0 + self.batch_size, n)
-            lo, hi = parallel.shard_range(i0, i1, rank, world)
-            batch = frames[lo:hi]
-            if isinstance(batch, list):
-                batch = np.stack(batch)
+        batches = [(i0, min(i0 + self.batch_size, n)) for i0 in range(0, n, self.batch_size)]
+        mine = [parallel.shard_range(i0, i1, rank, world) for i0, i1 in batches]
+        # this rank's frames are read ahead by a producer thread into page-locked buffers (sleap_amd/io/video.py)
+        feeder = FramePrefetcher(reader, [r for r in mine if r[1] > r[0]], depth=3)
+        feed = iter(feeder)
+        src = getattr(reader.video.backend, "_data", None)  # in-memory / memory-mapped source: "image" is a view of it
+        for (i0, i1), (lo, hi) in zip(batches, mine):
+            batch = None
             if hi > lo:
+                try:
+                    _lo, _hi, _inds, batch = next(feed)
+                except StopIteration:  # the source stopped early ("Unable to load frame"): end like the reference does
+                    return
                 outs = self.inference_model.call_checked(batch)
+                done = torch.cuda.Event()
+                done.record(layer._net_stream if layer._net_stream is not None else torch.cuda.current_stream())
+                if world == 1:
+                    if src is None:
+                        image = batch.numpy().copy()  # the page-locked buffer is recycled
+                    else:
+                        image = src[lo:hi] if reader.example_indices is None else src[index_of[lo:hi]]
+                feeder.release(done)
                 if world > 1 and outs["instance_scores"].shape[1] != i_gather:
                     # this rank's caps grew; the collective needs one width on every rank
                     if int(outs["n_valid"].max().item()) > i_gather:
@@ -1039,10 +1062,10 @@ class BottomUpPredictor(Predictor):
             ex = InferenceModel._unrag(res, numpy=True)
             ex.pop("status", None)
             ex["video_ind"] = np.zeros((i1 - i0,), np.int64)
-            ex["frame_ind"] = np.arange(i0, i1, dtype=np.int64)
+            ex["frame_ind"] = index_of[i0:i1].copy()
             ex["scale"] = np.ones((i1 - i0, 2), np.float32)
             if world == 1:
-                ex["image"] = batch if isinstance(batch, np.ndarray) else np.asarray(batch)
+                ex["image"] = image
             n_done += i1 - i0
             now = time.time()
             if self.verbosity == "json" and (now - last_report) >= 1.0 / max(self.report_rate, 1e-6) and rank == 0:

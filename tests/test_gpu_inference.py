@@ -165,3 +165,49 @@ def test_predict_with_tracker_matches_oracle_tracker(predictor, frames):
                 assert ex["tracking_scores"][f, r.uid] == pytest.approx(r.tracking_score, rel=1e-12, abs=1e-300)
             n_tracked += len(res)
     assert n_tracked > 0 and len(p.tracker.spawned_tracks) == len(ot.spawned_tracks)
+
+
+def test_predict_from_video_sources_equals_array_input(predictor, frames, tmp_path):
+    """Predictor.predict over a `Video` (memory-mapped .npy through the prefetching feed) and over a `VideoReader` with
+    example_indices returns what predict(ndarray) returns for the same frames (providers.py:301-439)."""
+    from sleap_amd.io.video import Video, VideoReader
+
+    ref = predictor.predict(frames, make_labels=False)
+    np.save(tmp_path / "clip.npy", frames)
+    got = predictor.predict(Video.from_filename(str(tmp_path / "clip.npy")), make_labels=False)
+    assert len(got) == len(ref)
+    for a, b in zip(ref, got):
+        for k in ("instance_peaks", "instance_peak_vals", "instance_scores", "n_valid", "frame_ind"):
+            assert_array_equal(a[k], b[k])
+        assert_array_equal(a["image"], b["image"])
+    sub = predictor.predict(VideoReader(Video.from_numpy(frames), example_indices=[3, 1, 4]), make_labels=False)
+    flat_ref = {int(f): (ex["instance_peaks"][i], ex["n_valid"][i]) for ex in ref for i, f in enumerate(ex["frame_ind"])}
+    seen = []
+    for ex in sub:
+        for i, f in enumerate(ex["frame_ind"]):
+            seen.append(int(f))
+            nv = int(ex["n_valid"][i])
+            assert nv == flat_ref[int(f)][1]
+            assert_array_equal(ex["instance_peaks"][i, :nv], flat_ref[int(f)][0][:nv])
+            assert_array_equal(ex["image"][i], frames[int(f)])
+    assert seen == [3, 1, 4]
+
+
+def test_save_predictions_round_trip(predictor, frames, tmp_path):
+    from sleap_amd.io import slp
+
+    outs = predictor.predict(frames, make_labels=False)
+    path = str(tmp_path / "pred.slp")
+    t = predictor.save_predictions(path, outs, video={"filename": "synthetic.npy", "grayscale": True, "bgr": True,
+                                                      "dataset": "", "input_format": ""})
+    r = slp.read_slp(path)
+    assert len(r["frames"]) == len(frames) and len(r["instances"]) == len(t["instances"]) == int(sum(
+        int((~np.isnan(ex["instance_peaks"][i, :int(ex["n_valid"][i])]).all(axis=(1, 2))).sum()) for ex in outs
+        for i in range(len(ex["n_valid"]))))
+    back = slp.tables_to_arrays(r, 2)[0]
+    k = 0
+    for ex in outs:
+        for i in range(len(ex["n_valid"])):
+            nv = int(back["n_valid"][k])
+            assert_array_equal(back["instance_peaks"][k, :nv], ex["instance_peaks"][i, :nv])
+            k += 1

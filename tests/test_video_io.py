@@ -1,0 +1,80 @@
+"""Frame sources and the prefetching feed (sleap_amd/io/video.py; reference sleap/io/video.py, nn/data/providers.py)."""
+import numpy as np
+import pytest
+
+from sleap_amd.io.video import FramePrefetcher, Video, VideoReader
+
+
+@pytest.fixture
+def clip():
+    rng = np.random.default_rng(0)
+    return rng.integers(0, 256, (23, 12, 16, 1), dtype=np.uint8)
+
+
+def test_video_facade(clip, tmp_path):
+    v = Video.from_numpy(clip)
+    assert len(v) == 23 and v.shape == (23, 12, 16, 1) and (v.height, v.width, v.channels) == (12, 16, 1)
+    assert np.array_equal(v.get_frame(5), clip[5]) and np.array_equal(v[3:9], clip[3:9]) and np.array_equal(v[-1], clip[-1])
+    assert np.array_equal(v.get_frames([2, 7, 3]), clip[[2, 7, 3]]) and np.array_equal(v[::5], clip[::5])
+    with pytest.raises(KeyError, match="Unable to load frame"):
+        v.get_frame(23)
+    np.save(tmp_path / "clip.npy", clip)
+    m = Video.from_filename(str(tmp_path / "clip.npy"))  # memory mapped
+    assert len(m) == 23 and np.array_equal(m[10:14], clip[10:14]) and m.backend_dict()["grayscale"]
+    assert Video.from_numpy(clip[..., 0]).shape == (23, 12, 16, 1)  # (frames, h, w) gets a channel axis
+    with pytest.raises(NotImplementedError):
+        Video.from_filename("movie.mp4")
+    with pytest.raises(ValueError, match="Could not detect backend"):
+        Video.from_filename("movie.xyz")
+
+
+def test_video_reader_examples(clip):
+    r = VideoReader(Video.from_numpy(clip), example_indices=[4, 9, 2])
+    exs = list(r.make_dataset())
+    assert len(r) == 3 and [int(e["frame_ind"]) for e in exs] == [4, 9, 2]
+    e = exs[1]
+    assert set(e) == set(r.output_keys) and np.array_equal(e["image"], clip[9])
+    assert e["raw_image_size"].tolist() == [12, 16, 1] and e["raw_image_size"].dtype == np.int32
+    assert e["video_ind"] == 0 and e["scale"].tolist() == [1.0, 1.0] and r.videos[0] is r.video
+    assert len(VideoReader(Video.from_numpy(clip))) == 23
+
+
+@pytest.mark.parametrize("depth", [2, 3, 5])
+def test_prefetcher_order_and_content(clip, depth):
+    ranges = [(i, min(i + 4, 23)) for i in range(0, 23, 4)]  # ragged last batch
+    got = []
+    pf = FramePrefetcher(clip, ranges, depth=depth, pin_memory=False)
+    for lo, hi, inds, batch in pf:
+        got.append((lo, hi, inds.tolist(), batch.numpy().copy()))
+        pf.release()
+    assert [(a, b) for a, b, _, _ in got] == ranges
+    for lo, hi, inds, b in got:
+        assert inds == list(range(lo, hi)) and np.array_equal(b, clip[lo:hi])
+
+
+def test_prefetcher_sharded_indices_and_implicit_release(clip):
+    r = VideoReader(Video.from_numpy(clip), example_indices=list(range(20, 2, -3)))  # 20, 17, 14, 11, 8, 5
+    out = [(inds.tolist(), b.numpy().copy()) for _, _, inds, b in FramePrefetcher(r, [(1, 3), (3, 6)], pin_memory=False)]
+    assert out[0][0] == [17, 14] and out[1][0] == [11, 8, 5]
+    assert np.array_equal(out[1][1], clip[[11, 8, 5]])
+
+
+def test_prefetcher_error_handling(clip):
+    class Broken(Video):
+        def get_frames(self, idxs):
+            idxs = list(idxs)
+            if 8 in idxs:
+                raise KeyError("Unable to load frame 8 from MediaVideo.")
+            return super().get_frames(idxs)
+
+    # a seeking error ends the stream quietly (inference.py:3333-3339) ...
+    got = [lo for lo, _, _, _ in FramePrefetcher(VideoReader(Broken.from_numpy(clip)), [(0, 4), (4, 8), (8, 12), (12, 16)],
+                                                 pin_memory=False)]
+    assert got == [0, 4]
+
+    class Worse(Video):
+        def get_frames(self, idxs):
+            raise RuntimeError("disk on fire")
+
+    with pytest.raises(RuntimeError, match="disk on fire"):  # ... anything else reaches the caller
+        list(FramePrefetcher(VideoReader(Worse.from_numpy(clip)), [(0, 4)], pin_memory=False))
