@@ -15,6 +15,7 @@
 // distinct 16-byte slots (stride/16 is odd), so B-fragment reads are bank-conflict free; packed
 // weights are stored lane-linear so A-fragment reads are consecutive 16 B per lane.
 #include <cstdint>
+#include <cstdlib>
 #include <vector>
 
 #include "bf16.h"
@@ -849,7 +850,17 @@ static int conv3x3_impl(const void* src0, int C0P, const void* src1, int C1P, in
   p.W = W;
   p.relu = relu;
   hipStream_t st = (hipStream_t)stream;
-  const bool ck32 = (C0P % 32 == 0) && (C1P % 32 == 0);
+  // Chunk size. 16-channel chunks halve the LDS footprint of a stage (19.6 KB halo tile + MT*9 KB weights), so TWO
+  // 8-wave workgroups fit on a CU and one's copies / epilogue overlap the other's MFMAs: measured 2-14 % faster than
+  // 32-channel chunks (one workgroup per CU) on every multi-chunk layer of the benchmark model, 1.36-1.49 PFLOP/s on the
+  // Cin >= 256 layers. The exception is the Cin = 32, Cout <= 32 layer, where one 32-channel chunk (no K loop at all) wins.
+  // SA_CONV_VARIANT=ck32 / ck16 force either choice (tools/conv_bench.py experiments).
+  static const int force_ck = [] {
+    const char* v = getenv("SA_CONV_VARIANT");
+    return !v ? 0 : !strcmp(v, "ck16") ? 16 : !strcmp(v, "ck32") ? 32 : 0;
+  }();
+  const bool can32 = (C0P % 32 == 0) && (C1P % 32 == 0);
+  const bool ck32 = can32 && (force_ck == 32 || (force_ck == 0 && C0P + C1P == 32 && CoutP <= 32));
   const int co32_n = (CoutP + 31) / 32;
   const int src_mode = mode & 7;
   if (src_mode == SA_SRC1_NONE || src_mode == SA_SRC1_DIRECT) {
