@@ -784,6 +784,7 @@ int launch2_pick(const ConvParams2& p, hipStream_t st) {
   if (p.n_heads > 0) return launch2<MT, CK, 8, 2, 2, true>(p, st);
   // single-chunk layers (Cin <= CK) are HBM-bound: small single-stage tiles, many workgroups per CU
   if ((p.C0P + p.C1P) == CK) return launch2<MT, CK, 4, 2, 1, false>(p, st);
+  // (4-wave / 8x32 and 4-wave / 16x32 tiles were measured 4-6 % slower than 8 waves x 2 rows on every multi-chunk layer)
   return launch2<MT, CK, 8, 2, 2, false>(p, st);
 }
 
