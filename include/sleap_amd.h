@@ -230,6 +230,17 @@ int sa_image_conv_bf16(const void* src, int src_is_u8, int B, int H, int W, int 
                        int kh, int kw, int stride, int pad_top, int pad_left, int Ho, int Wo, const float* w, const float* bias, int CoutP, int relu,
                        const float* post_scale, const float* post_shift, void* dst, sa_stream_t stream);
 
+/* The k7 stems on the matrix cores for uint8 images (hourglass.py:75-85, resnet.py:109-121): raw pixels are exact bf16 B
+ * operands, the fp32 kernel x input scale enters as hi + lo bf16 fragments, the ImageNet means ride in the bias plus an
+ * exact out-of-image indicator term (csrc/imgconv.hip). sa_imgconv_pack (host): w [k][k][CinW][Cout] f32, in_scale[CinW]
+ * applied to the raw 0..255 value, mean[CinW] or NULL, bias_io [CoutP] in/out. relu / post affine as sa_image_conv_bf16. */
+size_t sa_imgconv_packed_elems(int ksize, int CinW, int CoutP);
+int sa_imgconv_pack(const float* w, int ksize, int CinW, int Cout, int CoutP, const float* in_scale, const float* mean,
+                    uint16_t* packed, float* bias_io);
+int sa_imgconv_u8_bf16(const void* src, int B, int H, int W, int Cin, int CinW, int ksize, int stride, int pad_top,
+                       int pad_left, int Ho, int Wo, const void* wfrag, const float* bias, int CoutP, int relu,
+                       int has_mean, const float* post_scale, const float* post_shift, void* dst, sa_stream_t stream);
+
 /* Add layer (hourglass.py:190, resnet.py:249): dst = a + b [+ ReLU]; b may be [B,H/2,W/2,CP] read with
  * UpSampling2D(2, "nearest") (b_half_res = 1). Used when the addition can not be folded into a conv epilogue. */
 int sa_add_bf16(const void* a, const void* b, int B, int H, int W, int CP, int b_half_res, int relu, void* dst,

@@ -3,6 +3,7 @@
 // transposed convolution and dtype plumbing. The MFMA 3x3 convolution lives in conv3x3.hip.
 //
 // All kernels move 16 B per lane (8 bf16 channels) so that a wave touches whole 1 KiB lines.
+#include <algorithm>
 #include <cstdint>
 
 #include "bf16.h"
@@ -332,6 +333,67 @@ conv1x1_head_kernel(const uint16_t* __restrict__ src, int CinP, const float* __r
   }
 }
 
+// The same head as a GEMM on the matrix cores (Cout <= 32, CinP % 16 == 0): A = head weights as hi + lo bf16 fragments
+// (16 mantissa bits of the fp32 kernel), built once per workgroup into LDS; B = 32 pixels x 16 channels read straight
+// from the NHWC feature tensor (one 16-byte load per lane and k-step, no staging: a pixel's 64-byte line serves two
+// consecutive k-steps out of L1); fp32 accumulate; the lane that holds head channel n of pixel p stores it.
+// Bandwidth-bound (reads the bf16 features once) instead of Cout x Cin VALU FMAs per pixel.
+typedef __attribute__((ext_vector_type(8))) __bf16 head_bf16x8;
+typedef __attribute__((ext_vector_type(16))) float head_f32x16;
+
+__global__ void __launch_bounds__(256)
+conv1x1_head_mfma_kernel(const uint16_t* __restrict__ src, int CinP, const float* __restrict__ w,
+                         const float* __restrict__ bias, int Cout, int act, size_t n_pix, float* __restrict__ dst) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  bf16x8_t* frag = reinterpret_cast<bf16x8_t*>(smem_raw);  // [K16][2 terms][64 lanes]
+  const int K16 = CinP / 16;
+  for (int i = threadIdx.x; i < K16 * 64; i += blockDim.x) {
+    const int k16 = i >> 6, l = i & 63, n = l & 31, k0 = k16 * 16 + (l >> 5) * 8;
+    bf16x8_t hi, lo;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float v = n < Cout ? w[(size_t)n * CinP + k0 + j] : 0.0f;
+      hi[j] = sa::f2bf(v);
+      lo[j] = sa::f2bf(v - sa::bf2f(hi[j]));
+    }
+    frag[(k16 * 2 + 0) * 64 + l] = hi;
+    frag[(k16 * 2 + 1) * 64 + l] = lo;
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, half = lane >> 5, lx = lane & 31;
+  const size_t n_groups = (n_pix + 31) / 32;
+  const size_t wave0 = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = (size_t)gridDim.x * 4;
+  for (size_t g = wave0; g < n_groups; g += n_waves) {
+    const size_t p = g * 32 + lx;
+    const bool ok = p < n_pix;
+    const uint16_t* s = src + (ok ? p : 0) * CinP + half * 8;
+    head_f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+    for (int k16 = 0; k16 < K16; ++k16) {
+      const head_bf16x8 b = *reinterpret_cast<const head_bf16x8*>(s + k16 * 16);
+      const head_bf16x8 a0 = __builtin_bit_cast(head_bf16x8, frag[(k16 * 2 + 0) * 64 + lane]);
+      const head_bf16x8 a1 = __builtin_bit_cast(head_bf16x8, frag[(k16 * 2 + 1) * 64 + lane]);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b, acc, 0, 0, 0);
+    }
+    if (ok) {
+      float* o = dst + p * Cout;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int n = (i & 3) + 8 * (i >> 2) + 4 * half;
+        if (n < Cout) {
+          float v = acc[i] + bias[n];
+          if (act == 1) v = 1.0f / (1.0f + __expf(-v));
+          o[n] = v;
+        }
+      }
+    }
+  }
+#endif
+}
+
 // ------------------------------------------------------------------------------------------------
 // Conv2DTranspose(k3, s2, same): out[y][x] = sum_{2i+ky=y, 2j+kx=x} in[i][j] . w[ky][kx], output 2H x 2W
 // (full transposed conv cropped at the end). Direct kernel: only the reference's small fixture
@@ -519,6 +581,16 @@ int sa_conv1x1_head(const void* src, int CinP, const float* w, const float* bias
                     int B, int H, int W, float* dst, sa_stream_t stream) {
   SA_REQUIRE(CinP % 8 == 0 && Cout > 0, "sa_conv1x1_head: CinP%%8 != 0 or Cout <= 0");
   SA_REQUIRE(act == 0 || act == 1, "sa_conv1x1_head: act must be 0 (linear) or 1 (sigmoid)");
+  const size_t n_pix_all = (size_t)B * H * W;
+  if (Cout <= 32 && CinP % 16 == 0 && (size_t)CinP / 16 * 2048 <= 64 * 1024) {
+    const size_t lds_m = (size_t)CinP / 16 * 2048;
+    const size_t groups = (n_pix_all + 31) / 32;
+    const int grid = (int)std::min<size_t>((groups + 3) / 4, 256 * 8);
+    hipLaunchKernelGGL(conv1x1_head_mfma_kernel, dim3(grid), dim3(256), lds_m, (hipStream_t)stream, (const uint16_t*)src,
+                       CinP, w, bias, Cout, act, n_pix_all, dst);
+    SA_LAUNCH_CHECK();
+    return SA_OK;
+  }
   constexpr int CO = 8;
   const int CoutR = (Cout + CO - 1) / CO * CO;
   const size_t lds = sizeof(float) * (size_t)CoutR * CinP;

@@ -52,7 +52,8 @@ class _T:
 
 class DeviceNetwork:
     def __init__(self, model_config: dict, weights: Dict[str, np.ndarray], device=None, fuse_upsample: bool = False,
-                 fuse_heads: bool = True, fuse_stem: bool = True, use_stem16: bool = True, mfma_convt: bool = True):
+                 fuse_heads: bool = True, fuse_stem: bool = True, use_stem16: bool = True, mfma_convt: bool = True,
+                 mfma_stem: bool = True):
         """`fuse_upsample=True` folds UpSampling2D(bilinear) into the consuming conv's tile load (register-staged
         v1 kernel); the default materialises the upsampled tensor with the bandwidth-bound standalone kernel and
         feeds the asynchronous-DMA conv kernel (faster overall, measured in profiles/)."""
@@ -61,6 +62,7 @@ class DeviceNetwork:
         self.fuse_heads = fuse_heads
         self.fuse_stem = fuse_stem
         self.use_stem16 = use_stem16
+        self.mfma_stem = mfma_stem  # k7 first-layer convs of uint8 frames on the matrix cores (csrc/imgconv.hip)
         self.mfma_convt = mfma_convt  # Conv2DTranspose on the matrix cores (tap GEMM per output phase) vs the VALU kernel
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         cfg = model_config["config"]
@@ -273,8 +275,23 @@ class DeviceNetwork:
                         in_affine = upload_f32(np.array([255.0] * 3 + [-123.68, -116.779, -103.939], np.float32))
                     src_c = 1 if img.tile else cin
                     pads = (x.pads[0][0], x.pads[1][0]) if x.kind == "zpad" else None
+                    mf = None
+                    if k == (7, 7) and cin in (1, 3) and self.mfma_stem:
+                        # uint8 frames: the same conv on the matrix cores (csrc/imgconv.hip); weights x input scale as
+                        # hi + lo bf16 fragments, ImageNet means folded into the bias + an exact border indicator term
+                        h = _lib.lib()
+                        wk = np.ascontiguousarray(w[..., :cout], dtype=np.float32)
+                        packed = np.zeros((h.sa_imgconv_packed_elems(7, cin, coutp),), np.uint16)
+                        bias_io = np.ascontiguousarray(b_np, dtype=np.float32).copy()
+                        scale = np.full((cin,), 1.0 if img.preproc else 1.0 / 255.0, np.float32)
+                        mean = np.array([123.68, 116.779, 103.939], np.float32) if img.preproc else None
+                        vp = lambda a: a.ctypes.data_as(C.c_void_p) if a is not None else None  # noqa: E731
+                        check(h.sa_imgconv_pack(vp(wk), 7, cin, cout, coutp, vp(scale), vp(mean), vp(packed), vp(bias_io)),
+                              "sa_imgconv_pack")
+                        mf = {"w": torch.from_numpy(packed.view(np.int16)).to(dev), "bias": upload_f32(bias_io),
+                              "has_mean": int(img.preproc)}
                     plan.append(["imgconv", o, upload_f32(np.ascontiguousarray(w)), upload_f32(b_np), src_c, relu, name, k, st,
-                                 ps, pt, cin, in_affine, pads])
+                                 ps, pt, cin, in_affine, pads, mf])
                 elif k == (1, 1):
                     # Conv2D(k1, stride 1|2) on the matrix cores (ResNet bottleneck convs, skip projections)
                     s0 = materialize(x)
@@ -803,7 +820,7 @@ class DeviceNetwork:
                 check(h.sa_maxpool_bf16(_ptr(bufs[s.buf]), B, sh, sw, s.cp, kk, stride, pad_t, pad_l, pad_zero, oh, ow,
                                         _ptr(bufs[o.buf]), st), "sa_maxpool_bf16")
             elif kind == "imgconv":
-                _, o, w, bias, cin, relu, _nm, k, stride, ps, pt, cin_w, in_affine, pads = op
+                _, o, w, bias, cin, relu, _nm, k, stride, ps, pt, cin_w, in_affine, pads, mf = op
                 if cin != Cin:
                     raise ValueError(f"model expects {cin} input channels, got {Cin}")
                 is_u8 = 1 if imgs.dtype == torch.uint8 else 0
@@ -815,6 +832,14 @@ class DeviceNetwork:
                 pl_ = max((ow - 1) * stride + k[1] - W, 0) // 2
                 if pads is not None:  # explicit ZeroPadding2D + valid conv
                     pt_, pl_ = pads
+                if is_u8 and mf is not None:
+                    check(h.sa_imgconv_u8_bf16(_ptr(imgs), B, H, W, cin, cin_w, k[0], stride, pt_, pl_, oh, ow, _ptr(mf["w"]),
+                                               _ptr(mf["bias"]), o.cp, relu, mf["has_mean"],
+                                               _ptr(ps) if ps is not None else None, _ptr(pt) if pt is not None else None,
+                                               _ptr(bufs[o.buf]), st), "sa_imgconv_u8_bf16")
+                    if profile is not None:
+                        ev1.record()
+                    continue
                 check(h.sa_image_conv_bf16(_ptr(imgs), is_u8, B, H, W, cin, cin_w,
                                            _ptr(in_affine) if in_affine is not None else None, k[0], k[1], stride, pt_, pl_,
                                            oh, ow, _ptr(w),

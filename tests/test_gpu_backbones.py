@@ -390,3 +390,73 @@ def test_resnet50_backbone_features_vs_oracle():
     rng = np.random.default_rng(2)
     net, _ = _parity(cfg, w, rng.integers(0, 256, (2, 96, 96, 1), dtype=np.uint8), 5e-2, 3e-2)
     assert net.outputs[0].c == 2048
+
+
+@pytest.mark.parametrize("B,H,W,Cin,CinW,Cout,stride,mean,relu,affine", [
+    (2, 64, 96, 1, 1, 128, 2, False, True, True),    # hourglass stem (pad 2/3 from TF SAME)
+    (1, 70, 50, 3, 3, 64, 2, True, True, False),     # ResNet stem on RGB with the ImageNet means, borders everywhere
+    (2, 128, 128, 1, 3, 64, 2, True, True, False),   # tile_channels: grayscale image, 3 weight channels; interior tiles
+    (1, 40, 72, 1, 1, 24, 1, False, False, True),    # stride 1, channel padding (24 -> 32)
+    (1, 33, 47, 3, 3, 16, 2, False, True, False),    # odd sizes
+])
+def test_imgconv_mfma_vs_torch(B, H, W, Cin, CinW, Cout, stride, mean, relu, affine):
+    """k7 stem conv on the matrix cores vs fp32 torch on the same uint8 image: hi+lo bf16 weights (16 mantissa bits), exact
+    pixel operands, fp32 accumulation -> only the final bf16 rounding (2^-9) plus ~2^-16 weight error remain."""
+    import ctypes as C
+
+    from sleap_amd import _lib, ops
+    from sleap_amd._lib import check
+    from sleap_amd.ops import _ptr, _stream
+
+    g = torch.Generator(device="cpu").manual_seed(H + W + Cout)
+    img = torch.randint(0, 256, (B, H, W, Cin), generator=g, dtype=torch.uint8)
+    kern = torch.randn((7, 7, CinW, Cout), generator=g) * (2.0 / (49 * CinW)) ** 0.5 * (0.02 if mean else 1.0)
+    bias = 0.1 * torch.randn((Cout,), generator=g)
+    scale = 1.0 + 0.3 * torch.randn((Cout,), generator=g)
+    shift = 0.2 * torch.randn((Cout,), generator=g)
+    means = torch.tensor([123.68, 116.779, 103.939])[:CinW]
+    x = img.float()
+    if Cin == 1 and CinW == 3:
+        x = x.repeat(1, 1, 1, 3)
+    if mean:
+        x = x - means  # (u8 / 255) * 255 - mean, already in weight-channel order
+    else:
+        x = x * (1.0 / 255.0)
+    if mean:  # ZeroPadding2D(3) + valid conv (resnet.py:109-114)
+        pt = pl = 3
+        Ho, Wo = (H + 6 - 7) // stride + 1, (W + 6 - 7) // stride + 1
+        xp = F.pad(x.permute(0, 3, 1, 2), (3, 3, 3, 3))
+    else:  # TF SAME
+        Ho, Wo = -(-H // stride), -(-W // stride)
+        ph, pw = max((Ho - 1) * stride + 7 - H, 0), max((Wo - 1) * stride + 7 - W, 0)
+        pt, pl = ph // 2, pw // 2
+        xp = F.pad(x.permute(0, 3, 1, 2), (pl, pw - pl, pt, ph - pt))
+    y = F.conv2d(xp.double(), kern.permute(3, 2, 0, 1).double(), bias.double(), stride=stride).float().permute(0, 2, 3, 1)
+    assert y.shape[1:3] == (Ho, Wo)
+    if relu:
+        y = torch.relu(y)
+    if affine:
+        y = y * scale + shift
+    h = _lib.lib()
+    coutp = ops.pad16(Cout)
+    packed = np.zeros((h.sa_imgconv_packed_elems(7, CinW, coutp),), np.uint16)
+    bias_io = np.zeros((coutp,), np.float32)
+    bias_io[:Cout] = bias.numpy()
+    wk = np.ascontiguousarray(kern.numpy(), dtype=np.float32)
+    sc = np.full((CinW,), 1.0 if mean else 1.0 / 255.0, np.float32)
+    mn = np.ascontiguousarray(means.numpy(), dtype=np.float32) if mean else None
+    vp = lambda a: a.ctypes.data_as(C.c_void_p) if a is not None else None  # noqa: E731
+    check(h.sa_imgconv_pack(vp(wk), 7, CinW, Cout, coutp, vp(sc), vp(mn), vp(packed), vp(bias_io)), "sa_imgconv_pack")
+    dw = torch.from_numpy(packed.view(np.int16)).cuda()
+    db = torch.from_numpy(bias_io).cuda()
+    ps = _padded(scale, coutp, 1.0) if affine else None
+    psh = _padded(shift, coutp) if affine else None
+    out = torch.full((B, Ho, Wo, coutp), 7.0, dtype=torch.bfloat16, device="cuda")
+    dimg = img.cuda().contiguous()
+    check(h.sa_imgconv_u8_bf16(_ptr(dimg), B, H, W, Cin, CinW, 7, stride, pt, pl, Ho, Wo, _ptr(dw), _ptr(db), coutp, int(relu),
+                               int(mean), _ptr(ps), _ptr(psh), _ptr(out), _stream()), "sa_imgconv_u8_bf16")
+    got = ops.from_bf16(out, Cout).cpu()
+    lim = 2.0 ** -8 * float(y.abs().max())
+    assert float((got - y).abs().max()) <= lim, (float((got - y).abs().max()), lim)
+    if coutp > Cout:
+        assert float(out.float()[..., Cout:].abs().max()) == 0.0
