@@ -23,6 +23,7 @@ SOURCES = [
     ("conv3x3.hip", ["-fno-honor-nans"]),
     ("stem16.hip", ["-fno-honor-nans"]),
     ("tapconv.hip", ["-fno-honor-nans"]),
+    ("convpair.hip", ["-fno-honor-nans"]),
     ("imgconv.hip", ["-fno-honor-nans", "-std=c++20"]),
     ("tracker.hip", []),
 ]

@@ -1,0 +1,277 @@
+// One encoder block of SLEAP's UNet in ONE kernel: Conv2D(k3, 16 -> 32)+bias+ReLU -> Conv2D(k3, 32 -> 32)+bias+ReLU
+// [-> full store] [-> MaxPool2D(2) store] (encoder_decoder.py:109-131, block 1 of baseline_medium_rf: filters 16, rate 2).
+//
+// Why: on their own these are the two worst-utilised layers of the network (matrix cores 19 % and 36 % busy,
+// profiles/r01_v5_pmc_mfma_util.md): with Cin = 16 / 32 a tile issues 18 / 36 MFMAs per wave between an address set-up
+// and an epilogue, and the 32-channel intermediate (1.07 GB per 64 frames) goes to HBM and back. Here the intermediate
+// lives only in LDS as bf16 -- the same rounding the stored tensor would get, and the same MFMA accumulation order, so the
+// result is bitwise what sa_conv3x3_bf16 twice produces -- and one tile carries 58 MFMAs per wave for one prologue and one
+// epilogue.
+//
+// Workgroup = 8 waves, 16 x 32 output pixels. LDS (71936 B -> two workgroups per CU):
+//   [0, 39168)        intermediate halo tile 18 x 34 px x 32 ch, 64 B per pixel, 16-byte slots XOR (pixel >> 2) & 3
+//   [39168, 62720)    input halo tile 20 x 36 px x 16 ch, 32 B per pixel, slots XOR (pixel >> 3) & 1      (phase A only)
+//   [62720, 71936)    conv-a weights, 9 slabs of 1 KiB (MFMA A fragments, sa_pack_conv3x3_weights)        (phase A only)
+//   [39168, 57600)    conv-b weights, 18 slabs -- copied into the region phase A has finished with
+// Phase A: conv-a on all 612 halo pixels (20 groups of 32 over the 8 waves; +20 % conv-a FLOPs for the halo), written to
+// the intermediate tile with zeros outside the image (= conv-b's SAME padding). Phase B: the usual 9-tap loop.
+#include <cstdint>
+
+#include "bf16.h"
+#include "sa_common.h"
+
+namespace {
+
+using sa::bf16x8_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 mfma_bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+struct PairParams {
+  const uint16_t* src;  // [B,H,W,16]
+  const uint16_t* wa;   // packed (C0P 16 -> CoutP 32): [1][1][9][64][8]
+  const uint16_t* wb;   // packed (C0P 32 -> CoutP 32): [1][2][9][64][8]
+  const float* bias_a;  // [32]
+  const float* bias_b;  // [32]
+  uint16_t* dst;        // [B,H,W,32] or NULL
+  uint16_t* dst_pool;   // [B,H/2,W/2,32] or NULL
+  int B, H, W, relu_a, relu_b, tiles_x, tiles_y;
+};
+
+__global__ void __launch_bounds__(512)
+convpair_16_32_32_kernel(const PairParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int NW = 8, R = 2, TH = NW * R, TW = 32;
+  constexpr int PH = TH + 2, PW = TW + 2;    // intermediate halo tile
+  constexpr int QH = TH + 4, QW = TW + 4;    // input halo tile
+  constexpr int INTER_BYTES = PH * PW * 64;  // 39168
+  constexpr int IN_BYTES = QH * QW * 32;     // 23040
+  constexpr int N_IN = (IN_BYTES + 1023) / 1024;  // 23 copies (the last one half used)
+  constexpr int WA_OFF = INTER_BYTES + N_IN * 1024;
+  constexpr unsigned OOB = 0xFFFFFF00u;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* inter = smem;
+  unsigned char* in_tile = smem + INTER_BYTES;
+  unsigned char* wa_tile = smem + WA_OFF;
+  unsigned char* wb_tile = smem + INTER_BYTES;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5, lx = lane & 31;
+  int bid;
+  {
+    const int nblk = gridDim.x, q = nblk >> 3, r = nblk & 7, xcd = blockIdx.x & 7, k = blockIdx.x >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+  }
+  const int tx_i = bid % p.tiles_x;
+  bid /= p.tiles_x;
+  const int ty_i = bid % p.tiles_y;
+  const int b = bid / p.tiles_y;
+  const int x0 = tx_i * TW, y0 = ty_i * TH;
+  const int H = p.H, W = p.W;
+
+  const size_t fbytes = (size_t)H * W * 32;
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(reinterpret_cast<const unsigned char*>(p.src) + b * fbytes), 0, (int)fbytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rwa = __builtin_amdgcn_make_buffer_rsrc((void*)p.wa, 0, 9 * 1024, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rwb = __builtin_amdgcn_make_buffer_rsrc((void*)p.wb, 0, 18 * 1024, 0x00020000);
+
+  // ---- copies: input halo tile (pixels outside the image -> zeros through the buffer bounds check) + conv-a weights
+#pragma unroll
+  for (int j = 0; j < (N_IN + NW - 1) / NW; ++j) {
+    const int i = j * NW + wave;
+    if (i < N_IN) {
+      const int o = i * 1024 + lane * 16;
+      const int pl = o >> 5, s = (o >> 4) & 1;
+      const int ty = pl / QW, tx = pl - ty * QW;
+      const int gy = y0 + ty - 2, gx = x0 + tx - 2;
+      const bool ok = pl < QH * QW && gy >= 0 && gy < H && gx >= 0 && gx < W;
+      const unsigned voff = ok ? (unsigned)(gy * W + gx) * 32u + (unsigned)((s ^ ((pl >> 3) & 1)) * 16) : OOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(in_tile + i * 1024), 16, voff, 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int k = j * NW + wave;
+    if (k < 9) __builtin_amdgcn_raw_ptr_buffer_load_lds(rwa, (lds_ptr_t)(wa_tile + k * 1024), 16, (unsigned)lane * 16, k * 1024, 0, 0);
+  }
+  const float4 ba0 = *reinterpret_cast<const float4*>(p.bias_a + 4 * half);
+  const float4 ba1 = *reinterpret_cast<const float4*>(p.bias_a + 8 + 4 * half);
+  const float4 ba2 = *reinterpret_cast<const float4*>(p.bias_a + 16 + 4 * half);
+  const float4 ba3 = *reinterpret_cast<const float4*>(p.bias_a + 24 + 4 * half);
+  const float bias_a[16] = {ba0.x, ba0.y, ba0.z, ba0.w, ba1.x, ba1.y, ba1.z, ba1.w,
+                            ba2.x, ba2.y, ba2.z, ba2.w, ba3.x, ba3.y, ba3.z, ba3.w};
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  // ---- phase A: conv-a (16 -> 32) on the 612 halo pixels, 32 per group
+  constexpr int NGA = (PH * PW + 31) / 32;  // 20
+  const float low_a = p.relu_a ? 0.0f : -INFINITY;
+  for (int g = wave; g < NGA; g += NW) {
+    const int pl = g * 32 + lx;
+    const bool valid = pl < PH * PW;
+    const int plc = valid ? pl : 0;
+    const int ty = plc / PW, tx = plc - ty * PW;
+    f32x16 d;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) d[i] = 0.0f;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int pin = (ty + tap / 3) * QW + tx + tap % 3;
+      const mfma_bf16x8 a = *reinterpret_cast<const mfma_bf16x8*>(wa_tile + tap * 1024 + lane * 16);
+      const mfma_bf16x8 bv = *reinterpret_cast<const mfma_bf16x8*>(in_tile + pin * 32 + ((half ^ ((pin >> 3) & 1)) * 16));
+      d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bv, d, 0, 0, 0);
+    }
+    const int gy = y0 + ty - 1, gx = x0 + tx - 1;
+    const bool in_img = valid && gy >= 0 && gy < H && gx >= 0 && gx < W;
+    // lane holds channels (i&3) + 8*(i>>2) + 4*half; one v_permlane32_swap per dword -> 8 consecutive channels per lane
+    uint2 pk[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float v[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float t = fmaxf(d[4 * q + j] + bias_a[4 * q + j], low_a);
+        v[j] = in_img ? t : 0.0f;
+      }
+      pk[q].x = sa::f2bf2(v[0], v[1]);
+      pk[q].y = sa::f2bf2(v[2], v[3]);
+    }
+#pragma unroll
+    for (int pr = 0; pr < 2; ++pr) {
+      uint2 x = pk[2 * pr], y = pk[2 * pr + 1];
+      sa::swap32(x.x, y.x);
+      sa::swap32(x.y, y.y);
+      const int slot = 2 * pr + half;  // channels 8*slot .. 8*slot+7
+      if (valid) *reinterpret_cast<uint4*>(inter + pl * 64 + ((slot ^ ((pl >> 2) & 3)) * 16)) = make_uint4(x.x, x.y, y.x, y.y);
+    }
+  }
+  __syncthreads();  // the intermediate tile is complete; the input tile and conv-a weights are dead
+
+  // ---- conv-b weights into the freed region
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const int k = j * NW + wave;
+    if (k < 18) __builtin_amdgcn_raw_ptr_buffer_load_lds(rwb, (lds_ptr_t)(wb_tile + k * 1024), 16, (unsigned)lane * 16, k * 1024, 0, 0);
+  }
+  float bb[4][4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const float4 q = *reinterpret_cast<const float4*>(p.bias_b + 8 * g + 4 * half);
+    bb[g][0] = q.x;
+    bb[g][1] = q.y;
+    bb[g][2] = q.z;
+    bb[g][3] = q.w;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  // ---- phase B: conv-b (32 -> 32), wave owns rows wave*2, wave*2+1
+  f32x16 acc[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[r][i] = 0.0f;
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap) {
+    const int dy = tap / 3, dx = tap % 3;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const mfma_bf16x8 a = *reinterpret_cast<const mfma_bf16x8*>(wb_tile + (kk * 9 + tap) * 1024 + lane * 16);
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const int pl = (wave * R + r + dy) * PW + lx + dx;
+        const int slot = (kk * 2 + half) ^ ((pl >> 2) & 3);
+        const mfma_bf16x8 bv = *reinterpret_cast<const mfma_bf16x8*>(inter + pl * 64 + slot * 16);
+        acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bv, acc[r], 0, 0, 0);
+      }
+    }
+  }
+
+  // ---- epilogue (as conv3x3_dma_kernel)
+  const float low_b = p.relu_b ? 0.0f : -INFINITY;
+  const int gx = x0 + lx;
+  auto act = [&](int r, int g, int j) { return fmaxf(acc[r][4 * g + j] + bb[g][j], low_b); };
+  auto store_pieces = [&](uint16_t* row_ptr, bool ok, const uint2 (&pk)[4]) {
+#pragma unroll
+    for (int pr = 0; pr < 2; ++pr) {
+      uint2 x = pk[2 * pr], y = pk[2 * pr + 1];
+      sa::swap32(x.x, y.x);
+      sa::swap32(x.y, y.y);
+      if (ok) *reinterpret_cast<uint4*>(row_ptr + 16 * pr + 8 * half) = make_uint4(x.x, x.y, y.x, y.y);
+    }
+  };
+  if (p.dst) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int gy = y0 + wave * R + r;
+      uint2 pk[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        pk[g].x = sa::f2bf2(act(r, g, 0), act(r, g, 1));
+        pk[g].y = sa::f2bf2(act(r, g, 2), act(r, g, 3));
+      }
+      const bool ok = gy < H && gx < W;
+      store_pieces(p.dst + (((size_t)b * H + (ok ? gy : 0)) * W + (ok ? gx : 0)) * 32, ok, pk);
+    }
+  }
+  if (p.dst_pool) {
+    const int gy = y0 + wave * R;
+    uint2 pk[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      float t4[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float t = fmaxf(act(0, g, j), act(1, g, j));
+        t4[j] = fmaxf(t, sa::dpp_xor1(t));
+      }
+      pk[g].x = sa::f2bf2(t4[0], t4[1]);
+      pk[g].y = sa::f2bf2(t4[2], t4[3]);
+    }
+    const bool ok = !(lane & 1) && gy < H && gx < W;
+    store_pieces(p.dst_pool + (((size_t)b * (H / 2) + (ok ? gy / 2 : 0)) * (W / 2) + (ok ? gx / 2 : 0)) * 32, ok, pk);
+  }
+#endif
+}
+
+}  // namespace
+
+extern "C" int sa_conv3x3_pair_bf16(const void* src, int C0P, const void* wa, const float* bias_a, int relu_a, int C1P,
+                                    const void* wb, const float* bias_b, int relu_b, int C2P, int B, int H, int W, void* dst,
+                                    void* dst_pool, sa_stream_t stream) {
+  SA_REQUIRE(src && wa && wb && bias_a && bias_b && (dst || dst_pool), "sa_conv3x3_pair_bf16: NULL pointer");
+  if (C0P != 16 || C1P != 32 || C2P != 32)
+    return sa::fail(SA_ERR_UNSUPPORTED, "sa_conv3x3_pair_bf16: only the 16 -> 32 -> 32 block is implemented (got %d -> %d -> %d)",
+                    C0P, C1P, C2P);
+  SA_REQUIRE(B > 0 && H > 0 && W > 0, "sa_conv3x3_pair_bf16: bad shape");
+  SA_REQUIRE(!dst_pool || (H % 2 == 0 && W % 2 == 0), "sa_conv3x3_pair_bf16: pooled output needs even H, W");
+  SA_REQUIRE((size_t)H * W * 32 < 0xFFFFFF00ull, "sa_conv3x3_pair_bf16: one frame must be smaller than 4 GiB");
+  PairParams p;
+  p.src = (const uint16_t*)src;
+  p.wa = (const uint16_t*)wa;
+  p.wb = (const uint16_t*)wb;
+  p.bias_a = bias_a;
+  p.bias_b = bias_b;
+  p.dst = (uint16_t*)dst;
+  p.dst_pool = (uint16_t*)dst_pool;
+  p.B = B;
+  p.H = H;
+  p.W = W;
+  p.relu_a = relu_a;
+  p.relu_b = relu_b;
+  p.tiles_x = (W + 31) / 32;
+  p.tiles_y = (H + 15) / 16;
+  const size_t nblk = (size_t)p.tiles_x * p.tiles_y * B;
+  if (nblk > 0x7fffffffull) return sa::fail(SA_ERR_INVALID_ARG, "sa_conv3x3_pair_bf16: grid too large");
+  constexpr int lds = 18 * 34 * 64 + 23 * 1024 + 9 * 1024;  // 71936
+  static bool attr_set = false;
+  if (!attr_set) {
+    SA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&convpair_16_32_32_kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(convpair_16_32_32_kernel, dim3((unsigned)nblk), dim3(512), lds, (hipStream_t)stream, p);
+  SA_LAUNCH_CHECK();
+  return SA_OK;
+}

@@ -19,6 +19,7 @@ torch is used for device memory only.
 """
 import ctypes as C
 import json
+import os
 from typing import Dict, List, Optional
 
 import numpy as np
@@ -53,7 +54,7 @@ class _T:
 class DeviceNetwork:
     def __init__(self, model_config: dict, weights: Dict[str, np.ndarray], device=None, fuse_upsample: bool = False,
                  fuse_heads: bool = True, fuse_stem: bool = True, use_stem16: bool = True, mfma_convt: bool = True,
-                 mfma_stem: bool = True):
+                 mfma_stem: bool = True, fuse_pairs: bool = True):
         """`fuse_upsample=True` folds UpSampling2D(bilinear) into the consuming conv's tile load (register-staged
         v1 kernel); the default materialises the upsampled tensor with the bandwidth-bound standalone kernel and
         feeds the asynchronous-DMA conv kernel (faster overall, measured in profiles/)."""
@@ -62,6 +63,8 @@ class DeviceNetwork:
         self.fuse_heads = fuse_heads
         self.fuse_stem = fuse_stem
         self.use_stem16 = use_stem16
+        # 16->32->32 encoder block in one launch (csrc/convpair.hip); SA_FUSE_PAIRS=0 turns it off for A/B measurements
+        self.fuse_pairs = fuse_pairs and os.environ.get("SA_FUSE_PAIRS", "1") != "0"
         self.mfma_stem = mfma_stem  # k7 first-layer convs of uint8 frames on the matrix cores (csrc/imgconv.hip)
         self.mfma_convt = mfma_convt  # Conv2DTranspose on the matrix cores (tap GEMM per output phase) vs the VALU kernel
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
@@ -516,6 +519,8 @@ class DeviceNetwork:
             elif o.kind != "f32out":
                 raise NotImplementedError(f"model output {n} is neither a 1x1 head nor a stored feature tensor")
             self.outputs.append(o)
+        if self.fuse_pairs:
+            self.plan = self._fuse_pairs(self.plan)
         self.n_buf = n_buf[0]
         # reduce fractions for stride bookkeeping
         self.max_stride = max(den // max(num, 1) for (_, num, den, _) in self.buf_meta.values())
@@ -525,13 +530,15 @@ class DeviceNetwork:
         k = op[0]
         outs = {"conv": (6, 8), "conv1x1": (6,), "stem": (1,), "imgconv": (1,), "pool": (2,), "poolg": (2,), "up": (2,),
                 "convt": (4,), "convt2": (4,), "add": (5,), "head": (2,)}.get(k)
-        if k == "stem2":
+        if k in ("stem2", "pair"):
             return DeviceNetwork._writes(op[2], tensor)
         return any(op[i] is tensor for i in outs)
 
     @staticmethod
     def _reads(op):
         k = op[0]
+        if k == "pair":
+            return [op[1][1]]
         if k in ("conv", "conv1x1"):
             r = [t for t in (op[1], op[2]) if t is not None]
             if op[12] is not None and op[12]["res"] is not None:
@@ -565,6 +572,30 @@ class DeviceNetwork:
                     op[9] = False  # need_full
                     self.buf_meta.pop(o.buf, None)
                     o.buf = None
+        return out
+
+    def _fuse_pairs(self, plan):
+        """conv(16 -> 32) whose only reader is a conv(32 -> 32) -> one launch (sa_conv3x3_pair_bf16); the intermediate tensor
+        is never allocated. Plain convs only (no concat / pooled-source / heads / extended epilogue on either)."""
+        out = list(plan)
+
+        def plain(op):
+            return (op[0] == "conv" and op[2] is None and op[3] == _lib.SRC1_NONE and not op[10] and op[12] is None)
+
+        for x in list(out):
+            if not plain(x) or x[1].cp != 16 or x[6].cp != 32 or x[8] is not None or x[6].buf is None:
+                continue
+            readers = [q for q in out if any(t is x[6] for t in self._reads(q))]
+            if len(readers) != 1 or not plain(readers[0]):
+                continue
+            y = readers[0]
+            if y[1] is not x[6] or y[6].cp != 32 or any(x[6] is o for o in self.outputs):
+                continue
+            i = next(k for k, q in enumerate(out) if q is y)
+            out[i] = ["pair", x, y]
+            del out[next(k for k, q in enumerate(out) if q is x)]
+            self.buf_meta.pop(x[6].buf, None)
+            x[6].buf = None
         return out
 
     def _fuse_stem(self, plan):
@@ -682,6 +713,11 @@ class DeviceNetwork:
                 o, cin = op[1], op[4]
                 f = 2 * (H * o.num // o.den) * (W * o.num // o.den) * cin * o.c * 9
                 out.append((k, f"stem {cin}->{o.c} @{H * o.num // o.den}", f))
+            elif k == "pair":
+                s0, mid, o = op[1][1], op[1][6], op[2][6]
+                hh = H * o.num // o.den
+                f = 2 * hh * (W * o.num // o.den) * (s0.c * mid.c + mid.c * o.c) * 9
+                out.append(("conv", f"conv3x3 pair {s0.c}->{mid.c}->{o.c} @{hh}", f))
             elif k == "conv1x1":
                 s0, o = op[1], op[6]
                 f = 2 * (H * o.num // o.den) * (W * o.num // o.den) * s0.c * o.c
@@ -793,6 +829,13 @@ class DeviceNetwork:
                                            _ptr(ext["ps"]), _ptr(ext["pt"]),
                                            _ptr(bufs[res.buf]) if res is not None else None, ext["res_mode"],
                                            ext["relu_last"], st), "sa_conv3x3_ex_bf16")
+            elif kind == "pair":
+                _, xa, yb = op
+                s0, o, o_pool, need_full = xa[1], yb[6], yb[8], yb[9]
+                oh, ow = hw(o)
+                check(h.sa_conv3x3_pair_bf16(_ptr(bufs[s0.buf]), s0.cp, _ptr(xa[4]), _ptr(xa[5]), xa[7], xa[6].cp, _ptr(yb[4]),
+                                             _ptr(yb[5]), yb[7], o.cp, B, oh, ow, _ptr(bufs[o.buf]) if need_full else None,
+                                             _ptr(bufs[o_pool.buf]) if o_pool is not None else None, st), "sa_conv3x3_pair_bf16")
             elif kind == "conv1x1":
                 _, s0, _s1, stride, w, bias, o, relu, _op, _nf, _heads, _nm, ext = op
                 sh, sw = hw(s0)
@@ -895,6 +938,9 @@ class DeviceNetwork:
             elif op[0] == "imgconv":
                 o, cin, kk = op[1], op[11], op[7]
                 total += 2 * (H * o.num // o.den) * (W * o.num // o.den) * cin * o.c * kk[0] * kk[1]
+            elif op[0] == "pair":
+                s0, mid, o = op[1][1], op[1][6], op[2][6]
+                total += 2 * (H * o.num // o.den) * (W * o.num // o.den) * (s0.c * mid.c + mid.c * o.c) * 9
             elif op[0] == "conv1x1":
                 s0, o = op[1], op[6]
                 total += 2 * (H * o.num // o.den) * (W * o.num // o.den) * s0.c * o.c

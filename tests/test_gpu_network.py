@@ -258,7 +258,7 @@ def test_layerwise_vs_bf16_emulating_oracle():
     i = 0
     checked = 0
     for op in net.plan:
-        if op[0] == "stem2":  # fused first two convs: the first one's activation only ever lives in LDS
+        if op[0] in ("stem2", "pair"):  # two convs in one launch: the first one's activation only ever lives in LDS
             i += 1
             op = op[2]
         if op[0] not in ("stem", "conv"):
@@ -277,7 +277,7 @@ def test_layerwise_vs_bf16_emulating_oracle():
         scale = np.abs(r).max()
         err = np.abs(d - r).max() / scale
         assert err <= 2.0 ** -6, (name, err)
-        if checked <= 2:
+        if i <= 2:  # the first two conv LAYERS (not launches: fused launches skip layers whose output never leaves LDS)
             frac = (np.abs(d - r) > 1e-6 * scale).mean()
             assert frac < 2e-3 and err <= 2.0 ** -7 * 1.01, (name, frac, err)
 
@@ -299,3 +299,44 @@ def test_fusion_variants_agree(fuse):
             pass
         else:
             assert float((a - b).abs().max()) <= 2e-2 * float(a.abs().max())
+
+
+@pytest.mark.parametrize("B,H,W,full,pooled", [(2, 32, 64, True, False), (1, 48, 96, False, True), (2, 16, 32, True, True),
+                                                (1, 37, 45, True, False), (1, 18, 34, False, True)])
+def test_conv_pair_is_bitwise_two_convs(B, H, W, full, pooled):
+    """sa_conv3x3_pair_bf16 (16 -> 32 -> 32 encoder block, intermediate in LDS) == sa_conv3x3_bf16 twice, bit for bit:
+    same bf16 rounding of the intermediate, same MFMA accumulation order; ragged tiles and image borders included."""
+    from sleap_amd import _lib, ops
+    from sleap_amd._lib import check
+    from sleap_amd.ops import _ptr, _stream
+
+    g = torch.Generator(device="cpu").manual_seed(H * 10 + W)
+    ka = torch.randn((3, 3, 16, 32), generator=g) * (2.0 / (9 * 16)) ** 0.5
+    kb = torch.randn((3, 3, 32, 32), generator=g) * (2.0 / (9 * 32)) ** 0.5
+    ba, bb = (0.1 * torch.randn((32,), generator=g)).cuda(), (0.1 * torch.randn((32,), generator=g)).cuda()
+    x = ops.to_bf16_padded(torch.randn((B, H, W, 16), generator=g).cuda())
+    wa, wb = ops.pack_conv3x3_weights(ka.numpy(), 16), ops.pack_conv3x3_weights(kb.numpy(), 32)
+    mid = ops.conv3x3(x, None, 0, wa, ba, 32, True, (H, W))
+    ref = ops.conv3x3(mid, None, 0, wb, bb, 32, True, (H, W), full=full, pooled=pooled)
+    ref = ref if isinstance(ref, tuple) else ((ref, None) if full else (None, ref))
+    out = torch.full((B, H, W, 32), 7.0, dtype=torch.bfloat16, device="cuda") if full else None
+    outp = torch.full((B, H // 2, W // 2, 32), 7.0, dtype=torch.bfloat16, device="cuda") if pooled else None
+    check(_lib.lib().sa_conv3x3_pair_bf16(_ptr(x), 16, _ptr(wa), _ptr(ba), 1, 32, _ptr(wb), _ptr(bb), 1, 32, B, H, W, _ptr(out),
+                                          _ptr(outp), _stream()), "sa_conv3x3_pair_bf16")
+    if full:
+        assert torch.equal(out, ref[0])
+    if pooled:
+        assert torch.equal(outp, ref[1])
+
+
+def test_pair_fusion_switch_is_bitwise_neutral():
+    from sleap_amd.nn.engine import DeviceNetwork
+
+    cfg, w = _benchmark_unet(96, 128)
+    x = torch.from_numpy(_fly_frames(2, 96, 128, 6)).cuda()
+    a = DeviceNetwork(cfg, w)
+    assert "pair" in [op[0] for op in a.plan]
+    base = [o.clone() for o in a.forward(x)]
+    other = [o.clone() for o in DeviceNetwork(cfg, w, fuse_pairs=False).forward(x)]
+    for p, q in zip(base, other):
+        assert torch.equal(p, q)
