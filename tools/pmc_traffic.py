@@ -8,7 +8,7 @@ import re
 import sys
 from collections import defaultdict
 
-PAT = re.compile(r"(conv3x3_dma_kernel<[^>]*>|stem16_kernel<\d>|stem16_gray_kernel|upsample2x_kernel|upsample2x_bilinear_block_kernel)")
+PAT = re.compile(r"(conv3x3_dma_kernel<[^>]*>|stem16_kernel<\d>|stem16_gray_kernel|convpair_16_32_32_kernel|upsample2x_kernel|upsample2x_bilinear_block_kernel)")
 
 
 def load(path, counter):
@@ -34,10 +34,10 @@ def main(fetch_csv, write_csv, n_fwd):
         if "upsample" not in key[0]:
             tf += sum(f[key]) / 1024 * 2
             tw += sum(w.get(key, [0])) / 1024
-    print(f"\nconv family (conv3x3_dma_kernel + stem16_kernel), all launches of the run: FETCH x2 {tf / 1024:.2f} GB, "
+    print(f"\nconv family (conv3x3_dma_kernel + convpair + stem16), all launches of the run: FETCH x2 {tf / 1024:.2f} GB, "
           f"WRITE {tw / 1024:.2f} GB over {n_fwd} forward passes of 64 frames (timed steps + warm-up + the 4 instrumented passes of bench.py; +1 calibration pass of 2 frames)")
-    print(f"-> per step (17 launches, 64 frames): {(tf + tw) / 1024 / n_fwd:.2f} GB = "
-          f"{(tf + tw) / n_fwd / 64:.0f} MB/frame; algorithmic minimum of the fused plan: 190 MB/frame (DESIGN.md §3)")
+    print(f"-> per step (all conv-family launches of one forward pass, 64 frames): {(tf + tw) / 1024 / n_fwd:.2f} GB = "
+          f"{(tf + tw) / n_fwd / 64:.0f} MB/frame; algorithmic activations in + out of the current plan: DESIGN.md section 3")
 
 
 if __name__ == "__main__":
