@@ -200,3 +200,59 @@ def connect_single_track_breaks(track: np.ndarray, instance_count: int, order: O
     check(_lib.lib().sa_connect_single_track_breaks(track.shape[0], track.shape[1], _ptr(od), _ptr(track), int(instance_count)),
           "sa_connect_single_track_breaks")
     return track
+
+
+def run_tracker(outs, tracker: Tracker, img_hw=(1, 1)):
+    """tracking.py:1542-1581 on per-batch prediction dicts: every frame goes through `tracker.track` in order with the time
+    step inferred (the reference does not pass `t` here), existing tracks are discarded; then `final_pass`.
+    Adds / replaces `track_inds`, `tracking_scores`, `track_order` in every dict and returns the list."""
+    outs = list(outs)
+    if not outs:
+        return outs
+    for ex in outs:
+        hw = ex["image"].shape[1:3] if "image" in ex else img_hw
+        r = tracker.track_frames(ex["instance_peaks"], ex.get("instance_peak_vals"), ex.get("instance_scores"),
+                                 ex.get("n_valid"), img_hw=hw, t0=None)
+        ex["track_inds"], ex["tracking_scores"], ex["track_order"] = r["track"], r["tracking_score"], r["order"]
+    imax = max(ex["track_inds"].shape[1] for ex in outs)
+
+    def cat(key):
+        return np.ascontiguousarray(np.concatenate(
+            [np.pad(ex[key], ((0, 0), (0, imax - ex[key].shape[1])), constant_values=-1) for ex in outs]).astype(np.int32))
+
+    table = tracker.final_pass(cat("track_inds"), cat("track_order"))
+    o = 0
+    for ex in outs:
+        b, i = ex["track_inds"].shape
+        ex["track_inds"] = table[o:o + b, :i].copy()
+        o += b
+    return outs
+
+
+def retrack(slp_in: str, slp_out: str, **tracker_kwargs):
+    """`sleap-track --tracking.tracker ... predictions.slp` (inference.py:5712-5733): read a prediction file, run the tracker
+    over its predicted instances, write the result. Returns the tables written."""
+    import json
+
+    from ..io import slp
+
+    src = slp.read_slp(slp_in)
+    meta = json.loads(str(src["json"]))
+    names = [n["name"] for n in meta["nodes"]]
+    sk = meta["skeletons"][0]
+    order = [n["id"] for n in sk["nodes"]]  # skeleton node order -> index into the global node list
+    part_names = [names[i] for i in order]
+    pos = {g: k for k, g in enumerate(order)}
+    edges = [(pos[l["source"]], pos[l["target"]]) for l in sorted(sk["links"], key=lambda l: l["edge_insert_idx"])]
+    pred = dict(src)
+    keep = src["instances"]["instance_type"] == 1  # predicted instances only (user labels are not re-tracked here)
+    if not keep.all():
+        raise NotImplementedError("retrack(): files that mix user-labelled and predicted instances")
+    outs = slp.tables_to_arrays(pred, len(part_names))
+    for ex in outs:
+        del ex["track_inds"], ex["tracking_scores"]
+    tracker = Tracker.make_tracker_by_name(**tracker_kwargs)
+    outs = run_tracker(outs, tracker)
+    video = json.loads(str(src["videos_json"][0]))["backend"] if len(src["videos_json"]) else None
+    return slp.write_slp(slp_out, outs, part_names, edges, video=video, track_names=tracker.spawned_tracks,
+                         provenance=meta.get("provenance") or None)

@@ -168,3 +168,50 @@ def test_errors_like_reference():
         Tracker.make_tracker_by_name()  # reference default is the optical-flow tracker
     t = Tracker.make_tracker_by_name(tracker="simple", similarity="iou", match="hungarian")
     assert t.get_name() == "SimpleCandidateMaker.instance_iou.hungarian_matching"
+
+
+def test_retrack_prediction_file(tmp_path):
+    """read .slp -> run_tracker (time step inferred, as tracking.py:1542-1581) -> write .slp, against the oracle tracker."""
+    import json
+
+    from sleap_amd.io import slp
+    from sleap_amd.nn.tracking import retrack
+
+    frames = _sequence(21, n_frames=25, n_nodes=6, p_miss=0.1)
+    I = max(len(f) for f in frames)
+    ex = {"instance_peaks": np.full((len(frames), I, 6, 2), np.nan, np.float32),
+          "instance_peak_vals": np.zeros((len(frames), I, 6), np.float32), "instance_scores": np.zeros((len(frames), I), np.float32),
+          "n_valid": np.array([len(f) for f in frames], np.int32), "frame_ind": np.arange(100, 100 + len(frames)),
+          "video_ind": np.zeros(len(frames), np.int64)}
+    for f, insts in enumerate(frames):
+        for i, (p, s, c) in enumerate(insts):
+            ex["instance_peaks"][f, i], ex["instance_peak_vals"][f, i], ex["instance_scores"][f, i] = p, s, c
+    names = list("abcdef")
+    src, dst = str(tmp_path / "pred.slp"), str(tmp_path / "pred.tracked.slp")
+    slp.write_slp(src, [ex], names, [(0, 1), (1, 2), (2, 3), (3, 4), (4, 5)], video={"filename": "v.mp4", "grayscale": True,
+                                                                                      "bgr": True, "dataset": "", "input_format": ""})
+    kw = dict(tracker="simple", similarity="centroid", match="hungarian", track_window=3)
+    t = retrack(src, dst, **kw)
+    r = slp.read_slp(dst)
+    # oracle on the instances as stored in the file (frames with all-NaN instances already dropped by the writer)
+    ot = T.Tracker(**kw)
+    back = slp.tables_to_arrays(slp.read_slp(src), 6)[0]
+    want = []
+    for f in range(len(frames)):
+        nv = int(back["n_valid"][f])
+        lst = [T.Inst(back["instance_peaks"][f, i], back["instance_peak_vals"][f, i], back["instance_scores"][f, i], uid=i)
+               for i in range(nv)]
+        want.append([(x.uid, x.track) for x in ot.track(lst, img_hw=(1, 1))])
+    seen = []
+    for f, lst in enumerate(want):
+        a, b = int(r["frames"]["instance_id_start"][f]), int(r["frames"]["instance_id_end"][f])
+        assert b - a == len(lst)
+        for k, (uid, tr) in enumerate(lst):
+            if tr not in seen:
+                seen.append(tr)
+            assert int(r["instances"]["track"][a + k]) == seen.index(tr)
+            p0 = int(r["instances"]["point_id_start"][a + k])
+            np.testing.assert_array_equal(r["pred_points"]["x"][p0:p0 + 6].astype(np.float32), back["instance_peaks"][f, uid, :, 0])
+    assert [json.loads(s)[1] for s in r["tracks_json"].tolist()] == [f"track_{i}" for i in seen]
+    assert json.loads(str(r["json"]))["nodes"][2]["name"] == "c" and np.array_equal(r["frames"]["frame_idx"], ex["frame_ind"])
+    assert len(t["tracks"]) == len(seen) >= 4

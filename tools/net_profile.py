@@ -47,7 +47,7 @@ for (k, nm, f), ms in zip(descs, acc):
     a[0] += ms
     a[1] += f * B
     a[2] += 1
-    if ms > 0.03 * acc.sum():
+    if ms > float(sys.argv[4] if len(sys.argv) > 4 else 0.03) * acc.sum():
         print(f"{nm:52s} {ms:8.3f} ms {f * B / ms / 1e9 if ms else 0:8.1f} TFLOP/s")
 print("---- by kind")
 for key, (ms, fl, n) in sorted(agg.items(), key=lambda kv: -kv[1][0]):
