@@ -49,6 +49,14 @@ struct TapParams {
   int m_tiles, co_tiles;
 };
 
+// m / w for 0 <= m < 2^23 without the ~40-instruction integer division: float reciprocal estimate + one correction step
+__device__ __forceinline__ int fast_div(int m, int w, float inv_w) {
+  int q = (int)(((float)m + 0.5f) * inv_w);
+  if (q * w > m) --q;
+  if ((q + 1) * w <= m) ++q;
+  return q;
+}
+
 template <int WM, int WN>
 __global__ void __launch_bounds__(256)
 tapconv_kernel(const TapParams p) {
@@ -80,6 +88,7 @@ tapconv_kernel(const TapParams p) {
   const int m0 = m_t * TP;
   const int ML = p.Hl * p.Wl;
   const int K16 = p.CinP / 16;
+  const float inv_wl = 1.0f / (float)p.Wl;
   const int co32_n = (p.CoutP + 31) / 32;
   const int co32_0 = co_t * NCO32;
   const int chunks_per_tap = (p.CinP + CK - 1) / CK;
@@ -99,7 +108,7 @@ tapconv_kernel(const TapParams p) {
     const int pl = i * 8 + (lane >> 3);
     const int m = m0 + pl;
     const bool ok = m < ML;
-    const int ly = ok ? m / p.Wl : 0;
+    const int ly = ok ? fast_div(m, p.Wl, inv_wl) : 0;
     py[j] = ok ? ly * p.in_stride : -(1 << 20);
     px[j] = ok ? (m - ly * p.Wl) * p.in_stride : 0;
     pslot[j] = (lane & 7) ^ ((pl >> 1) & 7);  // global 16-byte slot this lane fetches
@@ -169,60 +178,67 @@ tapconv_kernel(const TapParams p) {
 
   // ---- epilogue (same register layout as conv3x3_dma_kernel): a lane holds channels {0-3, 8-11, 16-19, 24-27} + 4*half
   // of its pixel; one exchange with lane ^ 32 per pair of groups -> every lane stores 8 consecutive channels (16 bytes)
+  uint16_t* drow[2];
+  const uint16_t* rrow[2];
+  bool pix_ok[2];
 #pragma unroll
   for (int r = 0; r < 2; ++r) {
     const int m = m0 + (wm * 2 + r) * 32 + lx;
-    const bool pix_ok = m < ML;
-    const int ly = pix_ok ? m / p.Wl : 0;
-    const int lxx = pix_ok ? m - ly * p.Wl : 0;
-    const size_t opix = ((size_t)b * p.Ho + (ly * p.out_stride + p.oy0)) * p.Wo + (lxx * p.out_stride + p.ox0);
+    pix_ok[r] = m < ML;
+    const int ly = pix_ok[r] ? fast_div(m, p.Wl, inv_wl) : 0;
+    const int lxx = pix_ok[r] ? m - ly * p.Wl : 0;
+    const size_t off = (((size_t)b * p.Ho + (ly * p.out_stride + p.oy0)) * p.Wo + (lxx * p.out_stride + p.ox0)) * p.CoutP;
+    drow[r] = p.dst + off;
+    rrow[r] = p.residual ? p.residual + off : nullptr;
+  }
+  const float lowv = p.relu ? 0.0f : -INFINITY, lowl = p.relu_last ? 0.0f : -INFINITY;
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-      const int cobase = (co32_0 + wn * 2 + mt) * 32;
-      if (cobase >= p.CoutP) continue;
-      uint2 pk[4];
+  for (int mt = 0; mt < 2; ++mt) {
+    const int cobase = (co32_0 + wn * 2 + mt) * 32;
+    if (cobase >= p.CoutP) continue;
+    uint2 pk[2][4];
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int co = cobase + 8 * g + 4 * half;
+    for (int g = 0; g < 4; ++g) {
+      const int co = cobase + 8 * g + 4 * half;
+      const bool cok = co < p.CoutP;
+      // per-channel parameters: once per channel group, shared by both pixel groups
+      float4 bq = make_float4(0.f, 0.f, 0.f, 0.f), sq = make_float4(1.f, 1.f, 1.f, 1.f), tq = bq;
+      if (cok) {
+        bq = *reinterpret_cast<const float4*>(p.bias + co);
+        if (p.post_scale) {
+          sq = *reinterpret_cast<const float4*>(p.post_scale + co);
+          tq = *reinterpret_cast<const float4*>(p.post_shift + co);
+        }
+      }
+      const float bb[4] = {bq.x, bq.y, bq.z, bq.w}, ss[4] = {sq.x, sq.y, sq.z, sq.w}, tt[4] = {tq.x, tq.y, tq.z, tq.w};
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        uint2 q = make_uint2(0u, 0u);
+        if (rrow[r] && pix_ok[r] && cok) q = *reinterpret_cast<const uint2*>(rrow[r] + co);
+        // bf16 -> f32 is a 16-bit shift: two of the four values need only a mask
+        const float rr[4] = {__uint_as_float(q.x << 16), __uint_as_float(q.x & 0xffff0000u), __uint_as_float(q.y << 16),
+                             __uint_as_float(q.y & 0xffff0000u)};
         float v[4];
-        const bool cok = co < p.CoutP;
-        float4 bq = make_float4(0.f, 0.f, 0.f, 0.f), sq = make_float4(1.f, 1.f, 1.f, 1.f), tq = bq;
-        if (cok) {
-          bq = *reinterpret_cast<const float4*>(p.bias + co);
-          if (p.post_scale) {
-            sq = *reinterpret_cast<const float4*>(p.post_scale + co);
-            tq = *reinterpret_cast<const float4*>(p.post_shift + co);
-          }
-        }
-        const float bb[4] = {bq.x, bq.y, bq.z, bq.w}, ss[4] = {sq.x, sq.y, sq.z, sq.w}, tt[4] = {tq.x, tq.y, tq.z, tq.w};
-        float rr[4] = {0.f, 0.f, 0.f, 0.f};
-        if (p.residual && pix_ok && cok) {
-          const uint2 rq = *reinterpret_cast<const uint2*>(p.residual + opix * p.CoutP + co);
-          rr[0] = sa::bf2f((uint16_t)(rq.x & 0xffff));
-          rr[1] = sa::bf2f((uint16_t)(rq.x >> 16));
-          rr[2] = sa::bf2f((uint16_t)(rq.y & 0xffff));
-          rr[3] = sa::bf2f((uint16_t)(rq.y >> 16));
-        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          float t = acc[mt][r][4 * g + j] + bb[j];
-          if (p.relu) t = fmaxf(t, 0.0f);
+          float t = fmaxf(acc[mt][r][4 * g + j] + bb[j], lowv);
           t = fmaf(t, ss[j], tt[j]) + rr[j];
-          if (p.relu_last) t = fmaxf(t, 0.0f);
-          v[j] = t;
+          v[j] = fmaxf(t, lowl);
         }
-        pk[g].x = sa::f2bf2(v[0], v[1]);
-        pk[g].y = sa::f2bf2(v[2], v[3]);
+        pk[r][g].x = sa::f2bf2(v[0], v[1]);
+        pk[r][g].y = sa::f2bf2(v[2], v[3]);
       }
+    }
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
 #pragma unroll
       for (int pr = 0; pr < 2; ++pr) {
-        uint2 a = pk[2 * pr], c = pk[2 * pr + 1];
+        uint2 a = pk[r][2 * pr], c = pk[r][2 * pr + 1];
         sa::swap32(a.x, c.x);
         sa::swap32(a.y, c.y);
         const int co = cobase + 16 * pr + 8 * half;
-        if (pix_ok && co < p.CoutP) *reinterpret_cast<uint4*>(p.dst + opix * p.CoutP + co) = make_uint4(a.x, a.y, c.x, c.y);
+        if (pix_ok[r] && co < p.CoutP) *reinterpret_cast<uint4*>(drow[r] + co) = make_uint4(a.x, a.y, c.x, c.y);
       }
-    }
   }
 #endif
 }
@@ -236,6 +252,8 @@ int launch_tap(const TapParams& p0, hipStream_t st) {
   p.co_tiles = ((p.CoutP + 31) / 32 + NCO32 - 1) / NCO32;
   const size_t nblk = (size_t)p.m_tiles * p.co_tiles * p.B;
   if (nblk == 0 || nblk > 0x7fffffffull) return sa::fail(SA_ERR_INVALID_ARG, "tapconv: bad grid");
+  if ((size_t)p.Hl * p.Wl >= (1u << 23))  // fast_div's float estimate is exact below 2^23
+    return sa::fail(SA_ERR_UNSUPPORTED, "tapconv: more than 2^23 output pixels per frame");
   static bool attr_set = false;
   if (!attr_set && lds > 64 * 1024) {
     SA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&tapconv_kernel<WM, WN>),
