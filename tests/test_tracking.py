@@ -215,3 +215,16 @@ def test_retrack_prediction_file(tmp_path):
     assert [json.loads(s)[1] for s in r["tracks_json"].tolist()] == [f"track_{i}" for i in seen]
     assert json.loads(str(r["json"]))["nodes"][2]["name"] == "c" and np.array_equal(r["frames"]["frame_idx"], ex["frame_ind"])
     assert len(t["tracks"]) == len(seen) >= 4
+
+
+@pytest.mark.parametrize("max_tracks", [2, 3, 5])
+def test_max_tracks_is_never_exceeded(max_tracks):
+    """The invariant of tests/nn/test_inference.py::test_max_tracks_matching_queue (at most `max_tracks` tracks exist when
+    max tracking is on), on random walks with drop-outs and spurious detections, for the native tracker and the oracle."""
+    frames = _sequence(100 + max_tracks, n_frames=60, n_animals=5, p_drop=0.2, p_extra=0.4)
+    kw = dict(tracker="simple", similarity="instance", match="greedy", track_window=5, max_tracks=max_tracks, max_tracking=True)
+    a, na = _run_oracle(frames, (1, 1), **kw)
+    b, nb = _run_native(frames, (1, 1), **kw)
+    _compare(a, b)
+    assert na == nb <= max_tracks
+    assert len({t for f in b for _, t, _ in f}) <= max_tracks
