@@ -58,7 +58,7 @@ def cpu_baseline(mc, weights, scorer_args, frames_u8, budget_s, device_result=No
     from oracle.keras_graph import KerasGraph, preprocess
 
     # torch-CPU convolutions stop scaling (and collapse at 256 threads) on the 2x64-core EPYC host of the GPU box:
-    # measured 0.22 s/frame at 16-32 threads, 0.40 s at 64, 0.73 s at 128, 17.5 s at 256 (tools/cpu_probe.py).
+    # measured 0.22 s/frame at 16-32 threads, 0.40 s at 64, 0.73 s at 128, 17.5 s at 256 (tests/diagnostics/cpu_probe.py).
     cores = min(os.cpu_count() or 1, 32)
     torch.set_num_threads(cores)
     g = KerasGraph(mc, weights)
@@ -105,7 +105,7 @@ def cpu_baseline(mc, weights, scorer_args, frames_u8, budget_s, device_result=No
                     n_close += int((d[np.isfinite(d)] <= 0.5).sum())
         # NB random-init heads: the confidence maps are noise-like with many local maxima near the 0.2 threshold, and the
         # bf16-vs-fp32 network difference (~2 % of range) moves a few across it, so the two peak sets differ before grouping
-        # (measured: tools/parity_probe.py). Trained-model agreement: tests/test_gpu_inference.py
+        # (measured: tests/diagnostics/parity_probe.py). Trained-model agreement: tests/test_gpu_inference.py
         out["parity_vs_oracle"] = {"frames": n, "instances": n_inst, "peaks": n_pk, "peaks_within_0.5px": n_close,
                                    "max_peak_delta_px": round(max_d, 4),
                                    "frames_with_different_instance_count": bad_count,

@@ -2,7 +2,7 @@
 Runs the ORACLE post-processing on (a) the oracle's fp32 maps and (b) the device's maps for bench.py's 8 sample frames and
 reports, per frame, instance counts and how close the decisive PAF line scores sit to the min_line_scores cut (0.25).
 
-    python tools/parity_probe.py
+    python tests/diagnostics/parity_probe.py
 """
 import sys
 

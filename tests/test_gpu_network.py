@@ -216,7 +216,7 @@ def test_fixture_bottomup_network_vs_oracle():
 def test_fixture_bilinear_network_vs_oracle():
     """Trained fixture with the bilinear-upsampling decoder. Its features reach |x| ~ 100 on these (out of
     distribution) frames, so one bf16 ulp of a feature is 0.5 and the linear head, a sum with heavy cancellation,
-    shows ~4 % of its range; every bf16 layer itself is within 2 ulp (tools/layer_diff.py). The sigmoid
+    shows ~4 % of its range; every bf16 layer itself is within 2 ulp (tests/diagnostics/layer_diff.py). The sigmoid
     ClassMapsHead (identity head, out of scope) is executed but not compared."""
     from sleap_amd.nn.engine import load_keras_npz
 
