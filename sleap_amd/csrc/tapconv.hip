@@ -47,6 +47,12 @@ struct TapParams {
   int tap_dy[MAX_TAPS], tap_dx[MAX_TAPS];
   int relu, relu_last;
   int m_tiles, co_tiles;
+  // n_phases > 1: the output phases of a stride-2 transposed conv as ONE grid (phase = fastest block index): per phase its
+  // packed weights, output offset and (<= 4) taps; the single-phase fields above are ignored then
+  int n_phases;
+  const uint16_t* ph_w[4];
+  int ph_oy[4], ph_ox[4], ph_ntaps[4];
+  int ph_dy[4][4], ph_dx[4][4];
 };
 
 // m / w for 0 <= m < 2^23 without the ~40-instruction integer division: float reciprocal estimate + one correction step
@@ -81,6 +87,15 @@ tapconv_kernel(const TapParams p) {
     const int nblk = gridDim.x, q = nblk >> 3, r = nblk & 7, xcd = blockIdx.x & 7, k = blockIdx.x >> 3;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
   }
+  int ph = 0;
+  if (p.n_phases > 1) {
+    ph = bid % p.n_phases;
+    bid /= p.n_phases;
+  }
+  const bool multi = p.n_phases > 1;
+  const uint16_t* wsel = multi ? p.ph_w[ph] : p.w;
+  const int n_taps = multi ? p.ph_ntaps[ph] : p.n_taps;
+  const int oy0 = multi ? p.ph_oy[ph] : p.oy0, ox0 = multi ? p.ph_ox[ph] : p.ox0;
   const int co_t = bid % p.co_tiles;
   bid /= p.co_tiles;
   const int m_t = bid % p.m_tiles;
@@ -92,13 +107,13 @@ tapconv_kernel(const TapParams p) {
   const int co32_n = (p.CoutP + 31) / 32;
   const int co32_0 = co_t * NCO32;
   const int chunks_per_tap = (p.CinP + CK - 1) / CK;
-  const int n_chunks = p.n_taps * chunks_per_tap;
+  const int n_chunks = n_taps * chunks_per_tap;
 
   const size_t fbytes = (size_t)p.Hs * p.Ws * p.CinP * 2;
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
       (void*)(reinterpret_cast<const unsigned char*>(p.src) + b * fbytes), 0, (int)fbytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)p.w, 0, (int)((size_t)co32_n * p.n_taps * K16 * 1024), 0x00020000);
+      (void*)wsel, 0, (int)((size_t)co32_n * n_taps * K16 * 1024), 0x00020000);
 
   // this lane's pixels in the copies it issues: copy i covers pixels 8i..8i+7, lane -> (pixel 8i + lane/8, slot lane%8)
   int py[IN_PER_WAVE], px[IN_PER_WAVE], pslot[IN_PER_WAVE];
@@ -117,7 +132,7 @@ tapconv_kernel(const TapParams p) {
 
   auto issue = [&](int chunk, int buf) {
     const int tap = chunk / chunks_per_tap, kc = chunk - tap * chunks_per_tap;
-    const int dy = p.tap_dy[tap], dx = p.tap_dx[tap];
+    const int dy = multi ? p.ph_dy[ph][tap] : p.tap_dy[tap], dx = multi ? p.ph_dx[ph][tap] : p.tap_dx[tap];
     unsigned char* stage = smem + buf * STAGE;
 #pragma unroll
     for (int j = 0; j < IN_PER_WAVE; ++j) {
@@ -133,7 +148,7 @@ tapconv_kernel(const TapParams p) {
       const int c32 = k / KK, kk = k - c32 * KK;
       const int k16 = kc * KK + kk;
       const int soff = (co32_0 + c32 < co32_n && k16 < K16)
-                           ? (((co32_0 + c32) * p.n_taps + tap) * K16 + k16) * 1024
+                           ? (((co32_0 + c32) * n_taps + tap) * K16 + k16) * 1024
                            : (int)0x7FFFF000;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_ptr_t)(stage + IN_BYTES + k * 1024), 16, wv, soff, 0, 0);
     }
@@ -187,7 +202,7 @@ tapconv_kernel(const TapParams p) {
     pix_ok[r] = m < ML;
     const int ly = pix_ok[r] ? fast_div(m, p.Wl, inv_wl) : 0;
     const int lxx = pix_ok[r] ? m - ly * p.Wl : 0;
-    const size_t off = (((size_t)b * p.Ho + (ly * p.out_stride + p.oy0)) * p.Wo + (lxx * p.out_stride + p.ox0)) * p.CoutP;
+    const size_t off = (((size_t)b * p.Ho + (ly * p.out_stride + oy0)) * p.Wo + (lxx * p.out_stride + ox0)) * p.CoutP;
     drow[r] = p.dst + off;
     rrow[r] = p.residual ? p.residual + off : nullptr;
   }
@@ -250,7 +265,7 @@ int launch_tap(const TapParams& p0, hipStream_t st) {
   TapParams p = p0;
   p.m_tiles = (p.Hl * p.Wl + TP - 1) / TP;
   p.co_tiles = ((p.CoutP + 31) / 32 + NCO32 - 1) / NCO32;
-  const size_t nblk = (size_t)p.m_tiles * p.co_tiles * p.B;
+  const size_t nblk = (size_t)p.m_tiles * p.co_tiles * p.B * (p.n_phases > 1 ? p.n_phases : 1);
   if (nblk == 0 || nblk > 0x7fffffffull) return sa::fail(SA_ERR_INVALID_ARG, "tapconv: bad grid");
   if ((size_t)p.Hl * p.Wl >= (1u << 23))  // fast_div's float estimate is exact below 2^23
     return sa::fail(SA_ERR_UNSUPPORTED, "tapconv: more than 2^23 output pixels per frame");
@@ -344,34 +359,36 @@ int sa_convt_s2_bf16(const void* src, int CinP, const void* const* w_phase, int 
   // (k4: c = 1, k3: c = 0). For output parity a = o & 1 the contributing kernel rows are k = (a + c) & 1, +2, ... and
   // the input row is i = (o + c - k) / 2 = lo + (a + c - k) / 2.
   const int c = ksize == 4 ? 1 : 0;
+  TapParams p = {};
+  const int rc = fill_common(p, src, CinP, w_phase[0], bias, CoutP, relu, B, post_scale, post_shift, nullptr, relu_last, dst);
+  if (rc != SA_OK) return rc;
+  p.Hs = Hs;
+  p.Ws = Ws;
+  p.Hl = Hs;
+  p.Wl = Ws;
+  p.Ho = 2 * Hs;
+  p.Wo = 2 * Ws;
+  p.in_stride = 1;
+  p.out_stride = 2;
+  p.n_phases = 4;  // all four output phases in one grid: 4x the workgroups of a per-phase launch, no serialisation
   for (int a = 0; a < 2; ++a)
     for (int bq = 0; bq < 2; ++bq) {
-      TapParams p = {};
-      const int rc = fill_common(p, src, CinP, w_phase[a * 2 + bq], bias, CoutP, relu, B, post_scale, post_shift, nullptr,
-                                 relu_last, dst);
-      if (rc != SA_OK) return rc;
-      p.Hs = Hs;
-      p.Ws = Ws;
-      p.Hl = Hs;
-      p.Wl = Ws;
-      p.Ho = 2 * Hs;
-      p.Wo = 2 * Ws;
-      p.in_stride = 1;
-      p.out_stride = 2;
-      p.oy0 = a;
-      p.ox0 = bq;
+      const int ph = a * 2 + bq;
+      SA_REQUIRE(w_phase[ph], "sa_convt_s2_bf16: NULL phase weights");
+      p.ph_w[ph] = (const uint16_t*)w_phase[ph];
+      p.ph_oy[ph] = a;
+      p.ph_ox[ph] = bq;
       int n = 0;
       for (int ky = (a + c) & 1; ky < ksize; ky += 2)
         for (int kx = (bq + c) & 1; kx < ksize; kx += 2) {
-          p.tap_dy[n] = (a + c - ky) / 2;  // exact: a + c - ky is even
-          p.tap_dx[n] = (bq + c - kx) / 2;
+          p.ph_dy[ph][n] = (a + c - ky) / 2;  // exact: a + c - ky is even
+          p.ph_dx[ph][n] = (bq + c - kx) / 2;
           ++n;
         }
-      p.n_taps = n;
-      const int r2 = launch_tap_pick(p, (hipStream_t)stream);
-      if (r2 != SA_OK) return r2;
+      p.ph_ntaps[ph] = n;
     }
-  return SA_OK;
+  p.n_taps = 4;
+  return launch_tap_pick(p, (hipStream_t)stream);
 }
 
 int sa_convt_s2_phase_taps(int ksize, int phase, int* ky, int* kx) {

@@ -211,3 +211,8 @@ def test_save_predictions_round_trip(predictor, frames, tmp_path):
             nv = int(back["n_valid"][k])
             assert_array_equal(back["instance_peaks"][k, :nv], ex["instance_peaks"][i, :nv])
             k += 1
+
+
+def test_predict_on_empty_input(predictor, frames):
+    """Zero frames in -> zero batches out (and the tracker / writer paths accept that)."""
+    assert predictor.predict(frames[:0], make_labels=False) == []
