@@ -158,6 +158,38 @@ def _tool() -> str:
     return os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tools", "slp_io.py")
 
 
+def write_tables(filename: str, t: Dict[str, np.ndarray], part_names: Sequence[str], edges: Sequence[Sequence[int]],
+                 video: Optional[dict] = None, track_names: Optional[Sequence[str]] = None,
+                 provenance: Optional[dict] = None) -> None:
+    """Write already built tables (build_tables) in the reference's `.slp` layout."""
+    meta = skeleton_json(part_names, edges)
+    if provenance:
+        meta["provenance"] = provenance
+    videos = [_dumps({"backend": video or {"filename": "", "grayscale": True, "bgr": True, "dataset": "", "input_format": ""}})]
+    tracks = []
+    for tid, spawned in zip(np.asarray(t["tracks"]).tolist(), np.asarray(t["track_spawned_on"]).tolist()):
+        nm = track_names[tid] if track_names is not None and tid < len(track_names) else f"track_{tid}"
+        tracks.append(_dumps([int(spawned), nm]))
+    payload = {"frames": t["frames"], "instances": t["instances"], "pred_points": t["pred_points"], "points": t["points"],
+               "videos_json": np.array(videos, dtype=str), "tracks_json": np.array(tracks, dtype=str),
+               "suggestions_json": np.array([], dtype=str), "format_id": np.float64(FORMAT_ID),
+               "json": np.array(_dumps(meta), dtype=str)}
+    with tempfile.TemporaryDirectory() as td:
+        npz = os.path.join(td, "t.npz")
+        np.savez(npz, **payload)
+        try:
+            import h5py  # noqa: F401
+
+            sys.path.insert(0, os.path.dirname(_tool()))
+            try:
+                import slp_io
+            finally:
+                sys.path.pop(0)
+            slp_io.write(npz, filename)
+        except ImportError:
+            subprocess.run([_h5_python(), _tool(), "write", npz, filename], check=True)
+
+
 def write_slp(filename: str, outs: Sequence[Dict[str, np.ndarray]], part_names: Sequence[str], edges: Sequence[Sequence[int]],
               video: Optional[dict] = None, track_names: Optional[Sequence[str]] = None,
               max_instances: Optional[int] = None, provenance: Optional[dict] = None) -> Dict[str, np.ndarray]:
@@ -166,35 +198,7 @@ def write_slp(filename: str, outs: Sequence[Dict[str, np.ndarray]], part_names: 
     video: the `backend` dictionary of the source video, e.g. {"filename": "clip.mp4", "grayscale": True, "bgr": True,
     "dataset": "", "input_format": ""}; track_names[i] names tracker track i (default "track_<i>")."""
     t = build_tables(outs, max_instances=max_instances)
-    meta = skeleton_json(part_names, edges)
-    if provenance:
-        meta["provenance"] = provenance
-    videos = [_dumps({"backend": video or {"filename": "", "grayscale": True, "bgr": True, "dataset": "", "input_format": ""}})]
-    tracks = []
-    for tid, spawned in zip(t["tracks"].tolist(), t["track_spawned_on"].tolist()):
-        nm = track_names[tid] if track_names is not None and tid < len(track_names) else f"track_{tid}"
-        tracks.append(_dumps([int(spawned), nm]))
-    payload = {"frames": t["frames"], "instances": t["instances"], "pred_points": t["pred_points"], "points": t["points"],
-               "videos_json": np.array(videos, dtype=str), "tracks_json": np.array(tracks, dtype=str),
-               "suggestions_json": np.array([], dtype=str), "format_id": np.float64(FORMAT_ID),
-               "json": np.array(_dumps(meta), dtype=str)}
-    try:
-        import h5py  # noqa: F401
-
-        with tempfile.TemporaryDirectory() as td:
-            npz = os.path.join(td, "t.npz")
-            np.savez(npz, **payload)
-            sys.path.insert(0, os.path.dirname(_tool()))
-            try:
-                import slp_io
-            finally:
-                sys.path.pop(0)
-            slp_io.write(npz, filename)
-    except ImportError:
-        with tempfile.TemporaryDirectory() as td:
-            npz = os.path.join(td, "t.npz")
-            np.savez(npz, **payload)
-            subprocess.run([_h5_python(), _tool(), "write", npz, filename], check=True)
+    write_tables(filename, t, part_names, edges, video=video, track_names=track_names, provenance=provenance)
     return t
 
 

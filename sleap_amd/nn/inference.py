@@ -748,10 +748,39 @@ class Predictor:
 
     def predict(self, data, make_labels: bool = True):
         """inference.py:496-531 (see BottomUpPredictor.predict for the output contract)."""
-        if make_labels:
-            raise ImportError("predict(make_labels=True) builds sleap.Labels with the reference's own classes, which is "
-                              "only wired up for the bottom-up predictor here; call predict(data, make_labels=False)")
-        return self._apply_tracker(list(self._predict_generator(data)))
+        outs = self._apply_tracker(list(self._predict_generator(data)))
+        return self._make_labels(outs, data) if make_labels else outs
+
+    def _skeleton_info(self):
+        """(part_names, edge_inds) for the result containers; edges are only known to the bottom-up predictor (PAFScorer)."""
+        scorer = getattr(getattr(self.inference_model, "bottomup_layer", None), "paf_scorer", None)
+        if scorer is not None:
+            return scorer.part_names, scorer.edge_inds
+        for attr in ("confmap_config", "centroid_config"):
+            cfg = getattr(self, attr, None)
+            if cfg:
+                for head in (cfg.get("model", {}).get("heads", {}) or {}).values():
+                    if isinstance(head, dict):
+                        names = head.get("part_names") or (head.get("confmaps") or {}).get("part_names")
+                        if names:
+                            return list(names), []
+        return None, []
+
+    def _make_labels(self, outs, data):
+        """`predict(data)` -> array-backed `sleap_amd.io.labels.Labels` (same filtering / ordering as the reference's object
+        builder, inference.py:3230-3348; `.save()` writes a `.slp`, `.to_sleap()` gives the reference's own classes)."""
+        from ..io.labels import Labels
+        from ..io.video import Video, VideoReader
+
+        names, edges = self._skeleton_info()
+        if names is None:
+            n = outs[0]["instance_peaks"].shape[2] if outs else 0
+            names = [f"node_{i}" for i in range(n)]
+        video = data.video if isinstance(data, VideoReader) else data if isinstance(data, Video) else (
+            Video.from_numpy(data) if isinstance(data, np.ndarray) else None)
+        tn = self.tracker.spawned_tracks if self.tracker and hasattr(self.tracker, "spawned_tracks") else None
+        return Labels.from_predictions(outs, names, edges, video=video, track_names=tn,
+                                       max_instances=getattr(self, "max_instances", None))
 
     def save_predictions(self, filename: str, outs: List[Dict[str, np.ndarray]], video: Optional[dict] = None,
                          part_names: Optional[List[str]] = None, edges=None):
@@ -1078,40 +1107,10 @@ class BottomUpPredictor(Predictor):
     def predict(self, data, make_labels: bool = True):
         """inference.py:496-531. `make_labels=False` -> list of per-batch dicts of NumPy arrays
         (`instance_peaks (b, Imax, N, 2)` NaN-padded, `instance_peak_vals`, `instance_scores`, `n_valid`,
-        `video_ind`, `frame_ind`, ...). `make_labels=True` builds `sleap.Labels` with the UNMODIFIED
-        reference classes and therefore needs the `sleap` package importable."""
-        gen = self._predict_generator(data)
-        if make_labels:
-            return self._make_labeled_frames_from_generator(gen, data)
-        return self._apply_tracker(list(gen))
-
-    def _make_labeled_frames_from_generator(self, generator, data):
-        """inference.py:3230-3348 -- hands arrays to sleap's own result containers."""
-        try:
-            import sleap  # noqa: F401  (out of scope for this package: the reference's containers are used as-is)
-        except Exception as e:  # noqa: BLE001
-            raise ImportError("predict(make_labels=True) builds sleap.Labels with the reference's own classes; "
-                              "install `sleap` or call predict(data, make_labels=False)") from e
-        skeleton = sleap.Skeleton.from_names_and_edge_inds(  # pragma: no cover (needs sleap)
-            self.inference_model.bottomup_layer.paf_scorer.part_names,
-            self.inference_model.bottomup_layer.paf_scorer.edge_inds)
-        video = data if isinstance(data, sleap.Video) else sleap.Video.from_numpy(np.asarray(data))
-        lfs = []
-        for ex in generator:  # pragma: no cover
-            for fi, pts, conf, sc, nv in zip(ex["frame_ind"], ex["instance_peaks"], ex["instance_peak_vals"],
-                                             ex["instance_scores"], ex["n_valid"]):
-                insts = []
-                for p, c, s in zip(pts[:nv], conf[:nv], sc[:nv]):
-                    if np.isnan(p).all():
-                        continue
-                    insts.append(sleap.PredictedInstance.from_numpy(points=p, point_confidences=c,
-                                                                    instance_score=s, skeleton=skeleton))
-                if self.max_instances is not None and len(insts) > self.max_instances:
-                    insts = sorted(insts, key=lambda x: x.score, reverse=True)[: self.max_instances]
-                if self.tracker:
-                    insts = self.tracker.track(untracked_instances=insts, img=None, t=int(fi))
-                lfs.append(sleap.LabeledFrame(video=video, frame_idx=int(fi), instances=insts))
-        return sleap.Labels(lfs)  # pragma: no cover
+        `video_ind`, `frame_ind`, ...). `make_labels=True` (the reference's default) returns the array-backed
+        `sleap_amd.io.labels.Labels` (`len`, indexing, `.numpy()`, `.save("x.slp")`, `.to_sleap()`)."""
+        outs = self._apply_tracker(list(self._predict_generator(data)))
+        return self._make_labels(outs, data) if make_labels else outs
 
 
 def load_model(model_path: Union[str, List[str]], batch_size: int = 4, peak_threshold: float = 0.2,

@@ -216,3 +216,30 @@ def test_save_predictions_round_trip(predictor, frames, tmp_path):
 def test_predict_on_empty_input(predictor, frames):
     """Zero frames in -> zero batches out (and the tracker / writer paths accept that)."""
     assert predictor.predict(frames[:0], make_labels=False) == []
+
+
+def test_predict_default_returns_labels(predictor, frames, tmp_path):
+    """`predictor.predict(video)` with the reference's default make_labels=True: array-backed Labels whose frames /
+    instances equal the raw arrays, usable without the sleap package, and savable as .slp."""
+    from sleap_amd.io.labels import Labels
+    from sleap_amd.io.video import Video
+
+    raw = predictor.predict(frames, make_labels=False)
+    labels = predictor.predict(Video.from_numpy(frames))
+    assert isinstance(labels, Labels) and len(labels) == len(frames)
+    assert labels.skeleton.node_names == ["A", "B"] and labels.skeleton.edge_inds == [(0, 1)]
+    k = 0
+    for ex in raw:
+        for b in range(len(ex["n_valid"])):
+            lf = labels[k]
+            k += 1
+            nv = int(ex["n_valid"][b])
+            keep = [i for i in range(nv) if not np.isnan(ex["instance_peaks"][b, i]).all()]
+            assert lf.frame_idx == int(ex["frame_ind"][b]) and len(lf) == len(keep)
+            for inst, i in zip(lf.instances, keep):
+                pts = ex["instance_peaks"][b, i].copy()
+                pts[np.isnan(pts).any(axis=1)] = np.nan
+                assert_array_equal(inst.numpy(), pts)
+    assert labels.numpy(untracked=True).shape[0] == len(frames)
+    labels.save(str(tmp_path / "out.slp"))
+    assert len(Labels.load_file(str(tmp_path / "out.slp"))) == len(frames)
