@@ -40,3 +40,14 @@ def test_paf_scorer_attrs():
     cfg = {"confmaps": {"part_names": ["a", "b"]}, "pafs": {"edges": [["a", "b"]], "output_stride": 4}}
     s2 = PAFScorer.from_config(cfg, min_line_scores=0.1)
     assert s2.pafs_stride == 4 and s2.edge_inds == [(0, 1)] and s2.min_line_scores == 0.1
+
+
+def test_top_level_exports_are_lazy():
+    """`import sleap_amd` must stay cheap (no torch, no HIP library); sleap.load_model / load_file / Video / Labels names."""
+    import subprocess
+    import sys
+
+    code = ("import sys, sleap_amd; assert 'torch' not in sys.modules; "
+            "assert sleap_amd.Video.__name__ == 'Video' and sleap_amd.Labels.__name__ == 'Labels'; "
+            "assert callable(sleap_amd.load_file); assert 'torch' not in sys.modules; print('ok')")
+    assert subprocess.run([sys.executable, "-c", code], capture_output=True, text=True).stdout.strip() == "ok"
