@@ -55,19 +55,28 @@ class HDF5Video:
 
     input_format "channels_last" = (frames, height, width, channels), "channels_first" = (frames, channels, width, height)
     (video.py:114-126 transposes 2 <-> 1 and moves channels last); convert_range: float data in [0, 1] is scaled to
-    uint8 [0, 255] (video.py:306-312). Needs h5py in the running interpreter."""
+    uint8 [0, 255] (video.py:306-312). Read with h5py when importable, else through a one-time .npy copy."""
 
     def __init__(self, filename: str, dataset: str, input_format: str = "channels_last", convert_range: bool = True):
-        try:
-            import h5py
-        except ImportError as e:  # pragma: no cover
-            raise ImportError("HDF5Video needs h5py in this interpreter; convert the dataset to .npy once "
-                              "(np.save) and use NumpyVideo, which memory-maps it") from e
         if input_format not in ("channels_last", "channels_first"):
             raise ValueError(f"unknown input_format {input_format}")
         self.filename, self.dataset, self.input_format, self.convert_range = filename, dataset, input_format, convert_range
-        self._f = h5py.File(filename, "r")
-        self._d = self._f[dataset]
+        try:
+            import h5py
+
+            self._f = h5py.File(filename, "r")
+            self._d = self._f[dataset]
+        except ImportError:
+            # no h5py in this interpreter: the frames dataset is copied ONCE to a memory-mapped .npy next to the file by
+            # tools/slp_io.py under the interpreter that has h5py (SLEAP_AMD_H5_PYTHON), as model_io does for best_model.h5
+            import subprocess
+
+            from .slp import _h5_python, _tool
+
+            cache = f"{filename}.{dataset.strip('/').replace('/', '_')}.npy"
+            if not os.path.exists(cache) or os.path.getmtime(cache) < os.path.getmtime(filename):
+                subprocess.run([_h5_python(), _tool(), "frames", filename, dataset, cache], check=True)
+            self._d = np.load(cache, mmap_mode="r")
         s = self._d.shape
         if len(s) != 4:
             raise ValueError(f"dataset {dataset} must be 4-D, got {s}")

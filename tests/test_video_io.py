@@ -78,3 +78,30 @@ def test_prefetcher_error_handling(clip):
 
     with pytest.raises(RuntimeError, match="disk on fire"):  # ... anything else reaches the caller
         list(FramePrefetcher(VideoReader(Worse.from_numpy(clip)), [(0, 4)], pin_memory=False))
+
+
+def test_hdf5_video(clip, tmp_path):
+    """HDF5Video (sleap/io/video.py:47-338): channels_last / channels_first layouts and float [0,1] -> uint8 range conversion.
+    The file is written by the interpreter that has h5py; reading works with or without h5py in this one."""
+    import os
+    import subprocess
+
+    from sleap_amd.io.slp import _h5_python
+
+    if not os.path.exists(_h5_python()):
+        pytest.skip("no interpreter with h5py")
+    path = str(tmp_path / "vid.h5")
+    np.save(tmp_path / "a.npy", clip)
+    code = ("import h5py, numpy as np, sys; a = np.load(sys.argv[1]); f = h5py.File(sys.argv[2], 'w'); "
+            "f['box'] = a; f['cf'] = np.transpose(a, (0, 3, 2, 1)); f['flt'] = a.astype('float32') / 255.0; f.close()")
+    subprocess.run([_h5_python(), "-c", code, str(tmp_path / "a.npy"), path], check=True)
+    v = Video.from_hdf5("box", path)
+    assert v.shape == (23, 12, 16, 1) and np.array_equal(v[4:9], clip[4:9]) and np.array_equal(v.get_frame(22), clip[22])
+    cf = Video.from_hdf5("cf", path, input_format="channels_first")
+    assert cf.shape == (23, 12, 16, 1) and np.array_equal(cf[0:3], clip[0:3])
+    fl = Video.from_filename(path, dataset="flt")
+    got = fl[2:6]
+    assert got.dtype == np.uint8 and np.abs(got.astype(int) - clip[2:6].astype(int)).max() <= 1
+    assert fl.backend_dict()["dataset"] == "flt"
+    out = [b.numpy().copy() for _, _, _, b in FramePrefetcher(VideoReader(v), [(0, 5), (5, 10)], pin_memory=False)]
+    assert np.array_equal(out[1], clip[5:10])

@@ -2,6 +2,7 @@
 
     python tools/slp_io.py read  <file.slp> <out.npz>     tables + metadata -> npz
     python tools/slp_io.py write <in.npz>   <file.slp>     npz (as produced by sleap_amd.io.slp) -> .slp
+    python tools/slp_io.py frames <file.h5> <dataset> <out.npy>   frames dataset of an HDF5 video -> memory-mappable .npy
 
 Dataset layout as written by the reference (sleap/io/format/hdf5.py:265-575): group `metadata` with attrs `format_id`
 (float) and `json` (bytes); string datasets `videos_json`, `tracks_json`, `suggestions_json` (one JSON document per
@@ -51,5 +52,21 @@ def write(npz, path):
             f.create_dataset(key, data=z[key], maxshape=(None,), dtype=z[key].dtype)
 
 
+def frames(path, dataset, out):
+    """Copy a frames dataset of an HDF5 video to a .npy file (memory-mappable) without loading it whole."""
+    import h5py
+
+    with h5py.File(path, "r") as f:
+        d = f[dataset]
+        mm = np.lib.format.open_memmap(out, mode="w+", dtype=d.dtype, shape=d.shape)
+        step = max(1, (64 << 20) // max(1, int(np.prod(d.shape[1:])) * d.dtype.itemsize))
+        for i in range(0, d.shape[0], step):
+            mm[i:i + step] = d[i:i + step]
+        mm.flush()
+
+
 if __name__ == "__main__":
-    {"read": read, "write": write}[sys.argv[1]](sys.argv[2], sys.argv[3])
+    if sys.argv[1] == "frames":
+        frames(sys.argv[2], sys.argv[3], sys.argv[4])
+    else:
+        {"read": read, "write": write}[sys.argv[1]](sys.argv[2], sys.argv[3])
