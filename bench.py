@@ -47,6 +47,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=20.0)
     ap.add_argument("--layers", action="store_true", help="also print the per-layer table to stderr")
+    ap.add_argument("--dtype", choices=("bf16", "fp16"), default="bf16",
+                    help="16-bit storage type of activations / conv weights (one library build each; accumulation is fp32)")
     return ap.parse_args()
 
 
@@ -134,7 +136,7 @@ def main():
 
     H = W = args.size
     B = args.batch
-    pred, mc, weights = build_benchmark_predictor(H, W, batch_size=B, seed=0)
+    pred, mc, weights = build_benchmark_predictor(H, W, batch_size=B, seed=0, dtype=args.dtype)
     layer = pred.inference_model.bottomup_layer
     net = layer.keras_model
     scorer = layer.paf_scorer
@@ -226,7 +228,7 @@ def main():
             "metric": "frames/sec at 1024x1024 bottom-up (13 nodes)", "value": round(fps, 2), "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": "BASELINE configs[3]: bottom-up UNet(baseline_medium_rf: f16 r2 s32->4 bilinear)"
                                    f"+PAFs, {H}x{W}x1 u8, 13 nodes/12 edges, 4 animals, random-init weights with "
                                    "calibrated heads", "frames_per_gpu_per_step": B, "global_batch": B * world,

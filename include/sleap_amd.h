@@ -40,6 +40,7 @@ extern "C" {
 #define SA_STATUS_INSTANCE_OVERFLOW 4  /* more instances than `max_instances` */
 #define SA_STATUS_LSA_INFEASIBLE 8     /* scipy would raise "cost matrix is infeasible" */
 #define SA_STATUS_PAF_OOB 16           /* a PAF line sample fell outside the PAF tensor (TF-CPU raises) */
+#define SA_STATUS_NONFINITE 32         /* the confidence maps hold inf / NaN (an fp16-storage network overflowed) */
 
 typedef void* sa_stream_t;
 

@@ -16,6 +16,8 @@ semantics follow the documented TF/Keras rules collected in SURVEY.md §8(a):
 import json
 import math
 
+import os
+
 import numpy as np
 import torch
 import torch.nn.functional as F
@@ -51,13 +53,18 @@ def _act(x, name):
 class KerasGraph:
     """Executes the layer list of a Keras `Functional` model config in NCHW torch tensors."""
 
-    def __init__(self, model_config, weights, emulate_bf16=False, fp32_input_heads=(), round_layers=None):
-        """`emulate_bf16=True` rounds weights/activations to bfloat16 at exactly the points where the HIP engine
-        stores bf16 (conv / transposed-conv / upsample outputs, 3x3 conv weights except the fp32 stem; heads
+    def __init__(self, model_config, weights, emulate_bf16=False, fp32_input_heads=(), round_layers=None, emulate_dtype=None):
+        """`emulate_bf16=True` rounds weights/activations to the engine's 16-bit storage type (`emulate_dtype`) at exactly the
+        points where the HIP engine stores it (conv / transposed-conv / upsample outputs, 3x3 conv weights except the fp32 stem; heads
         keep fp32 weights and outputs), with fp32 accumulation in between. It separates "the kernels compute what
         they claim" (tight tolerance against this mode) from "bf16 storage is accurate enough" (loose tolerance
         against the fp32 mode)."""
         self.emulate_bf16 = emulate_bf16
+        # storage type emulated at the rounding points: torch.float16 / torch.bfloat16; None follows the same switch as the
+        # engine under test (SLEAP_AMD_DTYPE, default fp16) so that one test suite checks either build of the library
+        if emulate_dtype is None:
+            emulate_dtype = {"fp16": torch.float16, "bf16": torch.bfloat16}[os.environ.get("SLEAP_AMD_DTYPE", "fp16")]
+        self.emulate_dtype = emulate_dtype
         # with emulate_bf16: layer names after which a value is rounded to bf16. None = after every Conv2D /
         # Conv2DTranspose / bilinear UpSampling2D (the UNet engine's storage points); a set = exactly those layers
         # (an engine that fuses BatchNormalization / Add into the conv epilogue stores only the fused result)
@@ -106,7 +113,7 @@ class KerasGraph:
         return outs
 
     def _r(self, t):
-        return t.to(torch.bfloat16).to(torch.float32) if self.emulate_bf16 else t
+        return t.to(self.emulate_dtype).to(torch.float32) if self.emulate_bf16 else t
 
     def _layer(self, cn, name, c, ins):
         y = self._layer_fp32(cn, name, c, ins)

@@ -14,6 +14,7 @@ STATUS_NODE_PEAK_OVERFLOW = 2
 STATUS_INSTANCE_OVERFLOW = 4
 STATUS_LSA_INFEASIBLE = 8
 STATUS_PAF_OOB = 16
+STATUS_NONFINITE = 32
 
 REFINE = {None: 0, "none": 0, "integral": 1, "local": 2, "offsets": 3}
 
@@ -84,28 +85,49 @@ class SleapAmdError(RuntimeError):
     pass
 
 
-def lib():
-    """Load (once) and return the ctypes handle. Raises if the HIP library is unavailable."""
+DTYPES = ("bf16", "fp16")  # 16-bit storage type of the network kernels: one library build each (csrc/bf16.h)
+# fp16 is the default because it is the one that agrees END TO END with the reference's fp32 network (11 mantissa bits: heads
+# within 0.1-0.5 % of range; bf16's 8 bits: 1-4 %, which flips marginal peak / matching decisions -- DESIGN.md section 4).
+# bf16 has fp32's range and is the fallback for networks whose activations exceed 65504 (SA_STATUS_NONFINITE reports that).
+DEFAULT_DTYPE = os.environ.get("SLEAP_AMD_DTYPE", "fp16")
+if DEFAULT_DTYPE not in DTYPES:
+    raise ValueError(f"SLEAP_AMD_DTYPE={DEFAULT_DTYPE!r}: expected one of {DTYPES}")
+_libs = {}
+
+
+def lib_path(dtype: str = None) -> str:
+    dtype = dtype or DEFAULT_DTYPE
+    return LIB_PATH if dtype == "bf16" else os.path.join(HERE, "lib", f"libsleap_amd_{dtype}.so")
+
+
+def lib(dtype: str = None):
+    """Load (once) and return the ctypes handle of the library variant whose network kernels store activations and weights
+    as `dtype` (None: DEFAULT_DTYPE). Post-processing, tracker and host entry points are identical in every variant.
+    Raises if the HIP library is unavailable: there is no CPU fallback."""
     global _lib
-    if _lib is not None:
-        return _lib
+    dtype = dtype or DEFAULT_DTYPE
+    if dtype not in DTYPES:
+        raise ValueError(f"unknown storage dtype {dtype!r}; one of {DTYPES}")
+    if dtype in _libs:
+        return _libs[dtype]
     # torch ships its own libamdhip64; it must be the first (and only) HIP runtime in the process, otherwise
     # device pointers handed over by torch belong to a different runtime than the one launching our kernels.
     import torch  # noqa: F401
-    if not os.path.exists(LIB_PATH):
+    path = lib_path(dtype)
+    if not os.path.exists(path):
         try:
             from . import build as _build
 
-            _build.build(verbose=False)
+            _build.build(verbose=False, dtypes=(dtype,))
         except Exception as e:  # noqa: BLE001
             raise ImportError(
-                f"libsleap_amd.so not found at {LIB_PATH} and could not be built ({e}); "
+                f"{os.path.basename(path)} not found at {path} and could not be built ({e}); "
                 "run `python -m sleap_amd.build` (needs hipcc). There is no CPU fallback."
             ) from e
     try:
-        h = C.CDLL(LIB_PATH)
+        h = C.CDLL(path)
     except OSError as e:
-        raise ImportError(f"could not load {LIB_PATH}: {e}. There is no CPU fallback.") from e
+        raise ImportError(f"could not load {path}: {e}. There is no CPU fallback.") from e
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(h, name, None)
         if fn is None:  # tests/test_abi.py asserts that this never happens for a released build
@@ -113,7 +135,9 @@ def lib():
             continue
         fn.restype = res
         fn.argtypes = args
-    _lib = h
+    _libs[dtype] = h
+    if dtype == DEFAULT_DTYPE:
+        _lib = h
     return h
 
 

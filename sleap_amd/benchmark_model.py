@@ -80,10 +80,10 @@ def calibrate_heads(net: DeviceNetwork, frames_u8: torch.Tensor, n_animals=4, cm
             weights[f"{name}/kernel"], weights[f"{name}/bias"] = k, b
 
 
-def build_benchmark_predictor(height=1024, width=1024, batch_size=64, n_animals=4, seed=0, calib_frames=2):
+def build_benchmark_predictor(height=1024, width=1024, batch_size=64, n_animals=4, seed=0, calib_frames=2, dtype=None):
     """-> (BottomUpPredictor on the current CUDA device, keras-style model_config, weights dict)."""
     cfg, mc, weights = build_benchmark_graph(height, width, seed=seed)
-    net = DeviceNetwork(mc, weights)
+    net = DeviceNetwork(mc, weights, dtype=dtype)
     frames, _ = render_frames(calib_frames, height, width, n_animals, seed=1234)
     calibrate_heads(net, torch.from_numpy(frames).cuda(), n_animals, weights=weights)
     pred = BottomUpPredictor(bottomup_config=cfg, bottomup_model=net, batch_size=batch_size)

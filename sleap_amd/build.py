@@ -43,8 +43,18 @@ def _deps():
     return hdrs
 
 
-def build(force=False, verbose=True):
-    os.makedirs(LIBDIR, exist_ok=True)
+# storage-type variants of the network kernels (csrc/bf16.h): name -> (library file, extra defines)
+VARIANTS = {"bf16": (LIB, []), "fp16": (os.path.join(LIBDIR, "libsleap_amd_fp16.so"), ["-DSA_HALF_FP16=1"])}
+
+
+def lib_path(dtype="bf16"):
+    return VARIANTS[dtype][0]
+
+
+def _build_variant(dtype, force, verbose):
+    lib, defines = VARIANTS[dtype]
+    objdir = LIBDIR if dtype == "bf16" else os.path.join(LIBDIR, dtype)
+    os.makedirs(objdir, exist_ok=True)
     hipcc = _hipcc()
     objs = []
     rebuilt = False
@@ -53,19 +63,27 @@ def build(force=False, verbose=True):
         s = os.path.join(CSRC, src)
         if not os.path.exists(s):
             continue
-        o = os.path.join(LIBDIR, src.replace(".hip", ".o"))
+        o = os.path.join(objdir, src.replace(".hip", ".o"))
         objs.append(o)
         if force or not os.path.exists(o) or os.path.getmtime(o) < max(os.path.getmtime(s), dep_mtime):
-            cmd = [hipcc, "-c", s, "-o", o] + COMMON + extra
+            cmd = [hipcc, "-c", s, "-o", o] + COMMON + extra + defines
             if verbose:
                 print(" ".join(cmd), flush=True)
             subprocess.check_call(cmd)
             rebuilt = True
-    if rebuilt or not os.path.exists(LIB):
-        cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB] + objs
+    if rebuilt or not os.path.exists(lib):
+        cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", lib] + objs
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
+    return lib
+
+
+def build(force=False, verbose=True, dtypes=("bf16", "fp16")):
+    """Compile every storage-type variant; returns the path of the default (bf16) library."""
+    os.makedirs(LIBDIR, exist_ok=True)
+    for d in dtypes:
+        _build_variant(d, force, verbose)
     return LIB
 
 

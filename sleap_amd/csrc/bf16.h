@@ -1,4 +1,10 @@
-// bf16 helpers shared by the network kernels (device side).
+// 16-bit storage type of the network kernels. One library build = one type:
+//   default            bfloat16 (8-bit mantissa, fp32 range)                      -> libsleap_amd.so
+//   -DSA_HALF_FP16=1   IEEE half (11-bit mantissa, max 65504)                     -> libsleap_amd_fp16.so
+// Same kernels, same MFMA shapes and rates (v_mfma_f32_32x32x16_{bf16,f16}, v_mfma_f32_16x16x32_{bf16,f16}); only the
+// conversions and the operand element type differ. Why both: tests/diagnostics/precision_probe.py -- with bf16 storage the
+// heads are 1-4 % of their range away from an fp32 network, which flips marginal peak / matching decisions; with fp16 storage
+// the difference is 0.1-0.5 % and the end-to-end results agree. bf16 never overflows; fp16 can (activations > 65504).
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -6,12 +12,39 @@
 
 namespace sa {
 
-typedef __attribute__((ext_vector_type(8))) unsigned short bf16x8_t;  // 16 B = 8 bf16 channels
-typedef __attribute__((ext_vector_type(4))) unsigned short bf16x4_t;
+typedef __attribute__((ext_vector_type(8))) unsigned short h16x8_t;  // 16 B = 8 channels (raw bits)
+typedef __attribute__((ext_vector_type(4))) unsigned short h16x4_t;
 
-// round-to-nearest-even float -> bf16 (NaN kept quiet). Device code uses the hardware conversion
-// (v_cvt_pk_bf16_f32 on gfx950, same rounding); the host twin is used by the weight packer.
-__host__ __device__ inline uint16_t f2bf(float f) {
+#if defined(SA_HALF_FP16)
+typedef _Float16 half_elem;
+#define SA_MFMA_32x32x16 __builtin_amdgcn_mfma_f32_32x32x16_f16
+#define SA_MFMA_16x16x32 __builtin_amdgcn_mfma_f32_16x16x32_f16
+#define SA_HALF_NAME "fp16"
+#else
+typedef __bf16 half_elem;
+#define SA_MFMA_32x32x16 __builtin_amdgcn_mfma_f32_32x32x16_bf16
+#define SA_MFMA_16x16x32 __builtin_amdgcn_mfma_f32_16x16x32_bf16
+#define SA_HALF_NAME "bf16"
+#endif
+typedef __attribute__((ext_vector_type(8))) half_elem mfma_h8;  // MFMA A / B operand: 8 consecutive k values
+
+// uint8 pixels enter the matrix-core stems as the storage-type value `byte * U8_ACT_SCALE` (exact in both types), with
+// the packed first-layer weights carrying `input_scale / U8_ACT_SCALE`, split into hi + lo (+ mid) terms. bf16 has fp32's
+// exponent range, so the split terms of w / 255 are normal numbers. In fp16 the lo terms of w / 255 (~1e-3 * 2^-12) would
+// be subnormal (spacing 6e-8, two or three significant bits left); moving 2^-8 of the scale to the pixel side keeps the
+// absolute weight error at 3e-8 of weights that are now O(0.1 - 1).
+#if defined(SA_HALF_FP16)
+constexpr float U8_ACT_SCALE = 1.0f / 256.0f;
+#else
+constexpr float U8_ACT_SCALE = 1.0f;
+#endif
+
+// round-to-nearest-even float -> storage bits. Device code uses the hardware conversion (v_cvt_pk_bf16_f32 /
+// v_cvt_pk_f16_f32 on gfx950); the host twin is used by the weight packers.
+__host__ __device__ inline uint16_t f2h(float f) {
+#if defined(SA_HALF_FP16)
+  return __builtin_bit_cast(uint16_t, static_cast<_Float16>(f));
+#else
 #if defined(__HIP_DEVICE_COMPILE__)
   return __builtin_bit_cast(uint16_t, static_cast<__bf16>(f));
 #endif
@@ -20,22 +53,27 @@ __host__ __device__ inline uint16_t f2bf(float f) {
   if ((v.u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((v.u >> 16) | 0x40);
   const uint32_t lsb = (v.u >> 16) & 1u;
   return (uint16_t)((v.u + 0x7fffu + lsb) >> 16);
+#endif
 }
 
 #if defined(__HIP_DEVICE_COMPILE__)
 typedef __attribute__((ext_vector_type(2))) float f32x2_t;
-typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
-// two floats -> packed bf16 pair (lo in bits 0..15) with ONE v_cvt_pk_bf16_f32
-__device__ __forceinline__ uint32_t f2bf2(float lo, float hi) {
+typedef __attribute__((ext_vector_type(2))) half_elem half2_elem;
+// two floats -> packed pair (lo in bits 0..15) with ONE v_cvt_pk_{bf16,f16}_f32
+__device__ __forceinline__ uint32_t f2h2(float lo, float hi) {
   f32x2_t v = {lo, hi};
-  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, half2_elem));
 }
 #endif
 
-__host__ __device__ inline float bf2f(uint16_t h) {
+__host__ __device__ inline float h2f(uint16_t h) {
+#if defined(SA_HALF_FP16)
+  return (float)__builtin_bit_cast(_Float16, h);
+#else
   union { float f; uint32_t u; } v;
   v.u = ((uint32_t)h) << 16;
   return v.f;
+#endif
 }
 
 // UpSampling2D(2, bilinear) == tf.image.resize half-pixel centres: output index o reads source

@@ -23,8 +23,8 @@
 
 namespace {
 
-using sa::bf16x8_t;
-typedef __attribute__((ext_vector_type(8))) __bf16 mfma_bf16x8;
+using sa::h16x8_t;
+using sa::mfma_h8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 struct ConvParams {
@@ -39,15 +39,15 @@ struct ConvParams {
   int tiles_x, tiles_y, co_tiles;
 };
 
-__device__ __forceinline__ bf16x8_t zero8() {
-  bf16x8_t z = {0, 0, 0, 0, 0, 0, 0, 0};
+__device__ __forceinline__ h16x8_t zero8() {
+  h16x8_t z = {0, 0, 0, 0, 0, 0, 0, 0};
   return z;
 }
 
-__device__ __forceinline__ bf16x8_t max8(bf16x8_t a, bf16x8_t b) {
-  bf16x8_t o;
+__device__ __forceinline__ h16x8_t max8(h16x8_t a, h16x8_t b) {
+  h16x8_t o;
 #pragma unroll
-  for (int j = 0; j < 8; ++j) o[j] = (sa::bf2f(a[j]) >= sa::bf2f(b[j])) ? a[j] : b[j];
+  for (int j = 0; j < 8; ++j) o[j] = (sa::h2f(a[j]) >= sa::h2f(b[j])) ? a[j] : b[j];
   return o;
 }
 
@@ -99,20 +99,20 @@ conv3x3_mfma_kernel(const ConvParams p) {
       const int pix = piece / PARTS;
       const int tx = pix % PW, ty = pix / PW;
       const int gy = y0 + ty - 1, gx = x0 + tx - 1;
-      bf16x8_t v = zero8();
+      h16x8_t v = zero8();
       if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
         if (!from1) {
           const int c = c_lo + part * 8;
           if (MODE & 4) {
             const int Ws = 2 * W;
             const uint16_t* s = p.src0 + (((size_t)b * 2 * H + 2 * gy) * Ws + 2 * gx) * p.C0P + c;
-            const bf16x8_t a = *reinterpret_cast<const bf16x8_t*>(s);
-            const bf16x8_t a1 = *reinterpret_cast<const bf16x8_t*>(s + p.C0P);
-            const bf16x8_t a2 = *reinterpret_cast<const bf16x8_t*>(s + (size_t)Ws * p.C0P);
-            const bf16x8_t a3 = *reinterpret_cast<const bf16x8_t*>(s + (size_t)Ws * p.C0P + p.C0P);
+            const h16x8_t a = *reinterpret_cast<const h16x8_t*>(s);
+            const h16x8_t a1 = *reinterpret_cast<const h16x8_t*>(s + p.C0P);
+            const h16x8_t a2 = *reinterpret_cast<const h16x8_t*>(s + (size_t)Ws * p.C0P);
+            const h16x8_t a3 = *reinterpret_cast<const h16x8_t*>(s + (size_t)Ws * p.C0P + p.C0P);
             v = max8(max8(a, a1), max8(a2, a3));
           } else {
-            v = *reinterpret_cast<const bf16x8_t*>(p.src0 + (((size_t)b * H + gy) * W + gx) * p.C0P + c);
+            v = *reinterpret_cast<const h16x8_t*>(p.src0 + (((size_t)b * H + gy) * W + gx) * p.C0P + c);
           }
         } else {
           const int c = c_lo - p.C0P + part * 8;
@@ -123,29 +123,29 @@ conv3x3_mfma_kernel(const ConvParams p) {
             sa::up2_taps(gy, Hs, yA, yB, wy);
             sa::up2_taps(gx, Ws, xA, xB, wx);
             const uint16_t* base = p.src1 + (size_t)b * Hs * Ws * p.C1P + c;
-            const bf16x8_t tl = *reinterpret_cast<const bf16x8_t*>(base + ((size_t)yA * Ws + xA) * p.C1P);
-            const bf16x8_t tr = *reinterpret_cast<const bf16x8_t*>(base + ((size_t)yA * Ws + xB) * p.C1P);
-            const bf16x8_t bl = *reinterpret_cast<const bf16x8_t*>(base + ((size_t)yB * Ws + xA) * p.C1P);
-            const bf16x8_t br = *reinterpret_cast<const bf16x8_t*>(base + ((size_t)yB * Ws + xB) * p.C1P);
+            const h16x8_t tl = *reinterpret_cast<const h16x8_t*>(base + ((size_t)yA * Ws + xA) * p.C1P);
+            const h16x8_t tr = *reinterpret_cast<const h16x8_t*>(base + ((size_t)yA * Ws + xB) * p.C1P);
+            const h16x8_t bl = *reinterpret_cast<const h16x8_t*>(base + ((size_t)yB * Ws + xA) * p.C1P);
+            const h16x8_t br = *reinterpret_cast<const h16x8_t*>(base + ((size_t)yB * Ws + xB) * p.C1P);
 #pragma unroll
             for (int j = 0; j < 8; ++j)
-              v[j] = sa::f2bf(sa::up2_lerp(sa::bf2f(tl[j]), sa::bf2f(tr[j]), sa::bf2f(bl[j]), sa::bf2f(br[j]), wy, wx));
+              v[j] = sa::f2h(sa::up2_lerp(sa::h2f(tl[j]), sa::h2f(tr[j]), sa::h2f(bl[j]), sa::h2f(br[j]), wy, wx));
           } else {
-            v = *reinterpret_cast<const bf16x8_t*>(p.src1 + (((size_t)b * H + gy) * W + gx) * p.C1P + c);
+            v = *reinterpret_cast<const h16x8_t*>(p.src1 + (((size_t)b * H + gy) * W + gx) * p.C1P + c);
           }
         }
       }
-      *reinterpret_cast<bf16x8_t*>(in_tile + pix * PIX + part * 16) = v;
+      *reinterpret_cast<h16x8_t*>(in_tile + pix * PIX + part * 16) = v;
     }
     // ---------------- stage the packed weights of this chunk (lane-linear 16 B pieces)
     for (int i = tid; i < W_BYTES / 16; i += 256) {
       const int m = i / (KK * 9 * 64);
       const int rest = i % (KK * 9 * 64);
       const int co32 = co32_0 + m;
-      bf16x8_t v = zero8();
+      h16x8_t v = zero8();
       if (co32 < co32_n)
-        v = *reinterpret_cast<const bf16x8_t*>(p.w + (((size_t)co32 * K16 + chunk * KK) * 9 * 64 + rest) * 8);
-      *reinterpret_cast<bf16x8_t*>(w_tile + (size_t)i * 16) = v;
+        v = *reinterpret_cast<const h16x8_t*>(p.w + (((size_t)co32 * K16 + chunk * KK) * 9 * 64 + rest) * 8);
+      *reinterpret_cast<h16x8_t*>(w_tile + (size_t)i * 16) = v;
     }
     __syncthreads();
     // ---------------- 9 taps x KK k-steps of MFMA
@@ -154,19 +154,19 @@ conv3x3_mfma_kernel(const ConvParams p) {
       const int dy = tap / 3, dx = tap % 3;
 #pragma unroll
       for (int kk = 0; kk < KK; ++kk) {
-        mfma_bf16x8 a[MT];
+        mfma_h8 a[MT];
 #pragma unroll
         for (int m = 0; m < MT; ++m)
-          a[m] = *reinterpret_cast<const mfma_bf16x8*>(w_tile + ((m * KK + kk) * 9 + tap) * 1024 + lane * 16);
+          a[m] = *reinterpret_cast<const mfma_h8*>(w_tile + ((m * KK + kk) * 9 + tap) * 1024 + lane * 16);
 #pragma unroll
         for (int r = 0; r < R; ++r) {
           const int row = wave * R + r;
           const int pix = (row + dy) * PW + (lane & 31) + dx;
-          const mfma_bf16x8 bv =
-              *reinterpret_cast<const mfma_bf16x8*>(in_tile + pix * PIX + kk * 32 + (lane >> 5) * 16);
+          const mfma_h8 bv =
+              *reinterpret_cast<const mfma_h8*>(in_tile + pix * PIX + kk * 32 + (lane >> 5) * 16);
 #pragma unroll
           for (int m = 0; m < MT; ++m)
-            acc[m][r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m], bv, acc[m][r], 0, 0, 0);
+            acc[m][r] = SA_MFMA_32x32x16(a[m], bv, acc[m][r], 0, 0, 0);
         }
       }
     }
@@ -188,14 +188,14 @@ conv3x3_mfma_kernel(const ConvParams p) {
         if (co >= p.CoutP) continue;
         const float4 bq = *reinterpret_cast<const float4*>(p.bias + co);
         const float bb[4] = {bq.x, bq.y, bq.z, bq.w};
-        sa::bf16x4_t o;
+        sa::h16x4_t o;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           float v = acc[m][r][4 * g + j] + bb[j];
           if (p.relu) v = fmaxf(v, 0.0f);
-          o[j] = sa::f2bf(v);
+          o[j] = sa::f2h(v);
         }
-        *reinterpret_cast<sa::bf16x4_t*>(out + co) = o;
+        *reinterpret_cast<sa::h16x4_t*>(out + co) = o;
       }
     }
   }
@@ -403,29 +403,29 @@ conv3x3_dma_kernel(const ConvParams2 p) {
         float v = 0.0f;
         if (gy >= 0 && gy < H && gx >= 0 && gx < W)
           v = (float)reinterpret_cast<const uint8_t*>(p.stem_src)[(((size_t)b * H + gy) * W + gx) * STEM_CIN + c];
-        rawh[i] = sa::f2bf(v);
+        rawh[i] = sa::f2h(v);
       }
       const int hf = lane >> 5, l32 = lane & 31;
-      mfma_bf16x8 wa[NK16][3];
+      mfma_h8 wa[NK16][3];
 #pragma unroll
       for (int ks = 0; ks < NK16; ++ks) {
-        bf16x8_t t0, t1, t2;
+        h16x8_t t0, t1, t2;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           const int k = ks * 16 + hf * 8 + j;
           float wv = 0.0f;
           if (k < KT && l32 < CK) wv = p.stem_w[k * CK + l32] * (1.0f / 255.0f);
-          const uint16_t h0 = sa::f2bf(wv);
-          const float r1 = wv - sa::bf2f(h0);
-          const uint16_t h1 = sa::f2bf(r1);
-          const uint16_t h2 = sa::f2bf(r1 - sa::bf2f(h1));
+          const uint16_t h0 = sa::f2h(wv);
+          const float r1 = wv - sa::h2f(h0);
+          const uint16_t h1 = sa::f2h(r1);
+          const uint16_t h2 = sa::f2h(r1 - sa::h2f(h1));
           t0[j] = h0;
           t1[j] = h1;
           t2[j] = h2;
         }
-        wa[ks][0] = __builtin_bit_cast(mfma_bf16x8, t0);
-        wa[ks][1] = __builtin_bit_cast(mfma_bf16x8, t1);
-        wa[ks][2] = __builtin_bit_cast(mfma_bf16x8, t2);
+        wa[ks][0] = __builtin_bit_cast(mfma_h8, t0);
+        wa[ks][1] = __builtin_bit_cast(mfma_h8, t1);
+        wa[ks][2] = __builtin_bit_cast(mfma_h8, t2);
       }
       __syncthreads();
       constexpr int NG = (PH * PW + 31) / 32;
@@ -439,7 +439,7 @@ conv3x3_dma_kernel(const ConvParams2 p) {
         for (int i = 0; i < 16; ++i) d[i] = 0.0f;
 #pragma unroll
         for (int ks = 0; ks < NK16; ++ks) {
-          bf16x8_t bq;
+          h16x8_t bq;
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
             const int k = ks * 16 + hf * 8 + j;
@@ -451,9 +451,9 @@ conv3x3_dma_kernel(const ConvParams2 p) {
             bq[j] = hf ? v1 : v0;
             (void)k;
           }
-          const mfma_bf16x8 bf = __builtin_bit_cast(mfma_bf16x8, bq);
+          const mfma_h8 bf = __builtin_bit_cast(mfma_h8, bq);
 #pragma unroll
-          for (int part = 0; part < 3; ++part) d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[ks][part], bf, d, 0, 0, 0);
+          for (int part = 0; part < 3; ++part) d = SA_MFMA_32x32x16(wa[ks][part], bf, d, 0, 0, 0);
         }
         const int gy = y0 + ty - 1, gx = x0 + tx - 1;
         const bool in_img = valid && gy >= 0 && gy < H && gx >= 0 && gx < W;
@@ -471,7 +471,7 @@ conv3x3_dma_kernel(const ConvParams2 p) {
             for (int j = 0; j < 4; ++j) {
               float t = d[4 * q + j] + p.stem_b[8 * q + 4 * hf + j];
               if (p.stem_relu) t = fmaxf(t, 0.0f);
-              h4[j] = in_img ? sa::f2bf(t) : (uint16_t)0;
+              h4[j] = in_img ? sa::f2h(t) : (uint16_t)0;
             }
             pk[e][0] = (unsigned)h4[0] | ((unsigned)h4[1] << 16);
             pk[e][1] = (unsigned)h4[2] | ((unsigned)h4[3] << 16);
@@ -509,7 +509,7 @@ conv3x3_dma_kernel(const ConvParams2 p) {
         const int pl = it / PIECES, q = it - pl * PIECES;
         const int ty = pl / PW, tx = pl - ty * PW;
         const int gy = y0 + ty - 1, gx = x0 + tx - 1;
-        bf16x8_t o = zero8();
+        h16x8_t o = zero8();
         if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
           float a8[8];
 #pragma unroll
@@ -526,9 +526,9 @@ conv3x3_dma_kernel(const ConvParams2 p) {
                 for (int j = 0; j < 8; ++j) a8[j] = fmaf(v, wr[j], a8[j]);
               }
 #pragma unroll
-          for (int j = 0; j < 8; ++j) o[j] = sa::f2bf(p.stem_relu ? fmaxf(a8[j], 0.0f) : a8[j]);
+          for (int j = 0; j < 8; ++j) o[j] = sa::f2h(p.stem_relu ? fmaxf(a8[j], 0.0f) : a8[j]);
         }
-        *reinterpret_cast<bf16x8_t*>(smem + pl * PIXB + (q ^ swz<CK>(pl)) * 16) = o;
+        *reinterpret_cast<h16x8_t*>(smem + pl * PIXB + (q ^ swz<CK>(pl)) * 16) = o;
       }
     }
   }
@@ -545,18 +545,18 @@ conv3x3_dma_kernel(const ConvParams2 p) {
       const int dy = tap / 3, dx = tap % 3;
 #pragma unroll
       for (int kk = 0; kk < KK; ++kk) {
-        mfma_bf16x8 a[MT];
+        mfma_h8 a[MT];
 #pragma unroll
         for (int m = 0; m < MT; ++m)
-          a[m] = *reinterpret_cast<const mfma_bf16x8*>(w_tile + ((m * KK + kk) * 9 + tap) * 1024 + lane * 16);
+          a[m] = *reinterpret_cast<const mfma_h8*>(w_tile + ((m * KK + kk) * 9 + tap) * 1024 + lane * 16);
 #pragma unroll
         for (int r = 0; r < R; ++r) {
           const int pl = (wave * R + r + dy) * PW + lx + dx;
           const int slot = (kk * 2 + half) ^ swz<CK>(pl);
-          const mfma_bf16x8 bv = *reinterpret_cast<const mfma_bf16x8*>(in_tile + pl * PIXB + slot * 16);
+          const mfma_h8 bv = *reinterpret_cast<const mfma_h8*>(in_tile + pl * PIXB + slot * 16);
 #pragma unroll
           for (int m = 0; m < MT; ++m)
-            acc[m][r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m], bv, acc[m][r], 0, 0, 0);
+            acc[m][r] = SA_MFMA_32x32x16(a[m], bv, acc[m][r], 0, 0, 0);
         }
       }
     }
@@ -612,7 +612,7 @@ conv3x3_dma_kernel(const ConvParams2 p) {
           if (gy < H && gx < W && co < p.CoutP) {
             const size_t ri = p.res_mode ? (((size_t)b * (H / 2) + (gy >> 1)) * (W / 2) + (gx >> 1))
                                          : (((size_t)b * H + gy) * W + gx);
-            t += sa::bf2f(p.residual[ri * p.CoutP + co]);
+            t += sa::h2f(p.residual[ri * p.CoutP + co]);
           }
         }
         if (p.relu_last) t = fmaxf(t, 0.0f);
@@ -637,8 +637,8 @@ conv3x3_dma_kernel(const ConvParams2 p) {
         uint2 pk[4];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-          pk[g].x = sa::f2bf2(act(r, g, 0), act(r, g, 1));
-          pk[g].y = sa::f2bf2(act(r, g, 2), act(r, g, 3));
+          pk[g].x = sa::f2h2(act(r, g, 0), act(r, g, 1));
+          pk[g].y = sa::f2h2(act(r, g, 2), act(r, g, 3));
         }
         const bool ok = gy < H && gx < W;
         store_pieces(p.dst + (((size_t)b * H + (ok ? gy : 0)) * W + (ok ? gx : 0)) * p.CoutP, ok, pk);
@@ -657,8 +657,8 @@ conv3x3_dma_kernel(const ConvParams2 p) {
             const float t = fmaxf(act(r, g, j), act(r + 1, g, j));
             t4[j] = fmaxf(t, sa::dpp_xor1(t));
           }
-          pk[g].x = sa::f2bf2(t4[0], t4[1]);
-          pk[g].y = sa::f2bf2(t4[2], t4[3]);
+          pk[g].x = sa::f2h2(t4[0], t4[1]);
+          pk[g].y = sa::f2h2(t4[2], t4[3]);
         }
         const bool ok = !(lane & 1) && gy < H && gx < W;
         store_pieces(p.dst_pool + (((size_t)b * (H / 2) + (ok ? gy / 2 : 0)) * (W / 2) + (ok ? gx / 2 : 0)) * p.CoutP, ok, pk);
@@ -702,23 +702,23 @@ conv3x3_dma_kernel(const ConvParams2 p) {
             b1 = *reinterpret_cast<const float4*>(p.bias + c_lo + 8);
           }
           const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
-          bf16x8_t ahi, alo;
+          h16x8_t ahi, alo;
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
-            ahi[j] = sa::f2bf(wv[j]);
-            alo[j] = sa::f2bf(wv[j] - sa::bf2f(ahi[j]));
+            ahi[j] = sa::f2h(wv[j]);
+            alo[j] = sa::f2h(wv[j] - sa::h2f(ahi[j]));
           }
 #pragma unroll
           for (int r = 0; r < R; ++r) {
-            bf16x8_t fq;
+            h16x8_t fq;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
               const float t = acc[m][r][8 * s2 + j] + bb[j];
-              fq[j] = sa::f2bf(p.relu ? fmaxf(t, 0.0f) : t);
+              fq[j] = sa::f2h(p.relu ? fmaxf(t, 0.0f) : t);
             }
-            const mfma_bf16x8 bf = __builtin_bit_cast(mfma_bf16x8, fq);
-            hacc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(mfma_bf16x8, ahi), bf, hacc[r], 0, 0, 0);
-            hacc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(mfma_bf16x8, alo), bf, hacc[r], 0, 0, 0);
+            const mfma_h8 bf = __builtin_bit_cast(mfma_h8, fq);
+            hacc[r] = SA_MFMA_32x32x16(__builtin_bit_cast(mfma_h8, ahi), bf, hacc[r], 0, 0, 0);
+            hacc[r] = SA_MFMA_32x32x16(__builtin_bit_cast(mfma_h8, alo), bf, hacc[r], 0, 0, 0);
           }
         }
       }
@@ -950,7 +950,7 @@ int sa_pack_conv3x3_weights(const float* kk, int C0, int C0P, int C1, int C1P, i
             }
             float v = 0.0f;
             if (co < Cout && ci >= 0) v = kk[((size_t)tap * Cin + ci) * Cout + co];  // (kh,kw,Cin,Cout)
-            packed[((((size_t)co32 * K16 + k16) * 9 + tap) * 64 + lane) * 8 + j] = sa::f2bf(v);
+            packed[((((size_t)co32 * K16 + k16) * 9 + tap) * 64 + lane) * 8 + j] = sa::f2h(v);
           }
   return SA_OK;
 }

@@ -22,8 +22,8 @@
 
 namespace {
 
-using sa::bf16x8_t;
-typedef __attribute__((ext_vector_type(8))) __bf16 mfma_bf16x8;
+using sa::h16x8_t;
+using sa::mfma_h8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
@@ -118,9 +118,9 @@ convpair_16_32_32_kernel(const PairParams p) {
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
       const int pin = (ty + tap / 3) * QW + tx + tap % 3;
-      const mfma_bf16x8 a = *reinterpret_cast<const mfma_bf16x8*>(wa_tile + tap * 1024 + lane * 16);
-      const mfma_bf16x8 bv = *reinterpret_cast<const mfma_bf16x8*>(in_tile + pin * 32 + ((half ^ ((pin >> 3) & 1)) * 16));
-      d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bv, d, 0, 0, 0);
+      const mfma_h8 a = *reinterpret_cast<const mfma_h8*>(wa_tile + tap * 1024 + lane * 16);
+      const mfma_h8 bv = *reinterpret_cast<const mfma_h8*>(in_tile + pin * 32 + ((half ^ ((pin >> 3) & 1)) * 16));
+      d = SA_MFMA_32x32x16(a, bv, d, 0, 0, 0);
     }
     const int gy = y0 + ty - 1, gx = x0 + tx - 1;
     const bool in_img = valid && gy >= 0 && gy < H && gx >= 0 && gx < W;
@@ -134,8 +134,8 @@ convpair_16_32_32_kernel(const PairParams p) {
         const float t = fmaxf(d[4 * q + j] + bias_a[4 * q + j], low_a);
         v[j] = in_img ? t : 0.0f;
       }
-      pk[q].x = sa::f2bf2(v[0], v[1]);
-      pk[q].y = sa::f2bf2(v[2], v[3]);
+      pk[q].x = sa::f2h2(v[0], v[1]);
+      pk[q].y = sa::f2h2(v[2], v[3]);
     }
 #pragma unroll
     for (int pr = 0; pr < 2; ++pr) {
@@ -177,13 +177,13 @@ convpair_16_32_32_kernel(const PairParams p) {
     const int dy = tap / 3, dx = tap % 3;
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
-      const mfma_bf16x8 a = *reinterpret_cast<const mfma_bf16x8*>(wb_tile + (kk * 9 + tap) * 1024 + lane * 16);
+      const mfma_h8 a = *reinterpret_cast<const mfma_h8*>(wb_tile + (kk * 9 + tap) * 1024 + lane * 16);
 #pragma unroll
       for (int r = 0; r < R; ++r) {
         const int pl = (wave * R + r + dy) * PW + lx + dx;
         const int slot = (kk * 2 + half) ^ ((pl >> 2) & 3);
-        const mfma_bf16x8 bv = *reinterpret_cast<const mfma_bf16x8*>(inter + pl * 64 + slot * 16);
-        acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bv, acc[r], 0, 0, 0);
+        const mfma_h8 bv = *reinterpret_cast<const mfma_h8*>(inter + pl * 64 + slot * 16);
+        acc[r] = SA_MFMA_32x32x16(a, bv, acc[r], 0, 0, 0);
       }
     }
   }
@@ -208,8 +208,8 @@ convpair_16_32_32_kernel(const PairParams p) {
       uint2 pk[4];
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        pk[g].x = sa::f2bf2(act(r, g, 0), act(r, g, 1));
-        pk[g].y = sa::f2bf2(act(r, g, 2), act(r, g, 3));
+        pk[g].x = sa::f2h2(act(r, g, 0), act(r, g, 1));
+        pk[g].y = sa::f2h2(act(r, g, 2), act(r, g, 3));
       }
       const bool ok = gy < H && gx < W;
       store_pieces(p.dst + (((size_t)b * H + (ok ? gy : 0)) * W + (ok ? gx : 0)) * 32, ok, pk);
@@ -226,8 +226,8 @@ convpair_16_32_32_kernel(const PairParams p) {
         const float t = fmaxf(act(0, g, j), act(1, g, j));
         t4[j] = fmaxf(t, sa::dpp_xor1(t));
       }
-      pk[g].x = sa::f2bf2(t4[0], t4[1]);
-      pk[g].y = sa::f2bf2(t4[2], t4[3]);
+      pk[g].x = sa::f2h2(t4[0], t4[1]);
+      pk[g].y = sa::f2h2(t4[2], t4[3]);
     }
     const bool ok = !(lane & 1) && gy < H && gx < W;
     store_pieces(p.dst_pool + (((size_t)b * (H / 2) + (ok ? gy / 2 : 0)) * (W / 2) + (ok ? gx / 2 : 0)) * 32, ok, pk);

@@ -22,8 +22,8 @@
 
 namespace {
 
-using sa::bf16x8_t;
-typedef __attribute__((ext_vector_type(8))) __bf16 mfma_bf16x8;
+using sa::h16x8_t;
+using sa::mfma_h8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 struct ImgConvParams {
@@ -66,9 +66,9 @@ imgconv_mfma_kernel(const ImgConvParams p) {
 #pragma unroll
     for (int c = 0; c < CINW; ++c) {
       const float v = in ? (float)s[p.src_c == 1 ? 0 : c] : 0.0f;
-      raw[i * CINW + c] = (uint16_t)(__float_as_uint(v) >> 16);  // exact for 0..255
+      raw[i * CINW + c] = sa::f2h(v * sa::U8_ACT_SCALE);  // exact in bf16 and in fp16
     }
-    oob[i] = in ? (uint16_t)0 : (uint16_t)0x3F80;  // bf16 1.0 where the tap is outside the image
+    oob[i] = in ? (uint16_t)0 : sa::f2h(1.0f);  // 1.0 where the tap is outside the image
   }
   __syncthreads();
 
@@ -91,17 +91,17 @@ imgconv_mfma_kernel(const ImgConvParams p) {
       constexpr int ks = decltype(ks_c)::value;
       constexpr bool ind = decltype(ind_c)::value;
       constexpr int kstep = ind ? NK16 + ks : ks;
-      mfma_bf16x8 a[2][2];
+      mfma_h8 a[2][2];
 #pragma unroll
       for (int m = 0; m < 2; ++m)
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
           const int c32 = (m == 1 && !two) ? cp : cp + m;
-          a[m][t] = __builtin_bit_cast(mfma_bf16x8, wf[(((size_t)c32 * NKALL + kstep) * 2 + t) * 64 + lane]);
+          a[m][t] = __builtin_bit_cast(mfma_h8, wf[(((size_t)c32 * NKALL + kstep) * 2 + t) * 64 + lane]);
         }
 #pragma unroll
       for (int r = 0; r < R; ++r) {
-        bf16x8_t bq;
+        h16x8_t bq;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           constexpr int CW = ind ? 1 : CINW, KLIM = ind ? KH * KW : KT;
@@ -117,11 +117,11 @@ imgconv_mfma_kernel(const ImgConvParams p) {
             bq[j] = (half ? v1 : v0) ? x : (uint16_t)0;
           }
         }
-        const mfma_bf16x8 bf = __builtin_bit_cast(mfma_bf16x8, bq);
+        const mfma_h8 bf = __builtin_bit_cast(mfma_h8, bq);
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
-          for (int t = 0; t < 2; ++t) acc[m][r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][t], bf, acc[m][r], 0, 0, 0);
+          for (int t = 0; t < 2; ++t) acc[m][r] = SA_MFMA_32x32x16(a[m][t], bf, acc[m][r], 0, 0, 0);
       }
     };
     auto run = [&](auto ind_c, auto... ks) { (step(ks, ind_c), ...); };
@@ -158,8 +158,8 @@ imgconv_mfma_kernel(const ImgConvParams p) {
           float v[4];
 #pragma unroll
           for (int j = 0; j < 4; ++j) v[j] = fmaf(fmaxf(acc[m][r][4 * g + j] + bb[j], lowv), ss[j], tt[j]);
-          pk[g].x = sa::f2bf2(v[0], v[1]);
-          pk[g].y = sa::f2bf2(v[2], v[3]);
+          pk[g].x = sa::f2h2(v[0], v[1]);
+          pk[g].y = sa::f2h2(v[2], v[3]);
         }
 #pragma unroll
         for (int pr = 0; pr < 2; ++pr) {
@@ -205,8 +205,8 @@ int sa_imgconv_pack(const float* w, int ksize, int CinW, int Cout, int CoutP, co
   const int KT = ksize * ksize * CinW, NK16 = (KT + 15) / 16, NKI16 = (ksize * ksize + 15) / 16, NKALL = NK16 + NKI16;
   const int co32_n = (CoutP + 31) / 32;
   auto split = [&](float v, uint16_t* hi, uint16_t* lo) {
-    *hi = sa::f2bf(v);
-    *lo = sa::f2bf(v - sa::bf2f(*hi));
+    *hi = sa::f2h(v);
+    *lo = sa::f2h(v - sa::h2f(*hi));
   };
   std::vector<double> vsum((size_t)CoutP, 0.0);
   for (int c32 = 0; c32 < co32_n; ++c32)
@@ -220,7 +220,7 @@ int sa_imgconv_pack(const float* w, int ksize, int CinW, int Cout, int CoutP, co
               const int k = ks * 16 + (lane >> 5) * 8 + j;
               if (k < KT) {
                 const int tap = k / CinW, c = k % CinW;
-                v = w[((size_t)tap * CinW + c) * Cout + co] * (in_scale ? in_scale[c] : 1.0f);
+                v = w[((size_t)tap * CinW + c) * Cout + co] * (in_scale ? in_scale[c] : 1.0f) * (1.0f / sa::U8_ACT_SCALE);
               }
             } else if (mean) {
               const int tap = (ks - NK16) * 16 + (lane >> 5) * 8 + j;

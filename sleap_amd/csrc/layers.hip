@@ -12,7 +12,7 @@
 
 namespace {
 
-using sa::bf16x8_t;
+using sa::h16x8_t;
 
 // ------------------------------------------------------------------------------------------------
 // stem: ensure_float (x * 1/255, normalization.py:34-49) + Conv2D(k3,same) + bias + ReLU, Cin in {1,3}
@@ -60,10 +60,10 @@ stem_conv3x3_kernel(const void* __restrict__ src_, int B, int H, int W, const fl
         }
       }
     }
-    bf16x8_t o;
+    h16x8_t o;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) o[j] = sa::f2bf(relu ? fmaxf(acc[j], 0.0f) : acc[j]);
-    *reinterpret_cast<bf16x8_t*>(dst + p * CoutP + g * 8) = o;
+    for (int j = 0; j < 8; ++j) o[j] = sa::f2h(relu ? fmaxf(acc[j], 0.0f) : acc[j]);
+    *reinterpret_cast<h16x8_t*>(dst + p * CoutP + g * 8) = o;
   }
 }
 
@@ -113,14 +113,14 @@ image_conv_kernel(const void* __restrict__ src_, int is_u8, int B, int H, int W,
         }
       }
     }
-    bf16x8_t o;
+    h16x8_t o;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       float v = relu ? fmaxf(acc[j], 0.0f) : acc[j];
       if (post_scale) v = fmaf(v, post_scale[g * 8 + j], post_shift[g * 8 + j]);
-      o[j] = sa::f2bf(v);
+      o[j] = sa::f2h(v);
     }
-    *reinterpret_cast<bf16x8_t*>(dst + p * CoutP + g * 8) = o;
+    *reinterpret_cast<h16x8_t*>(dst + p * CoutP + g * 8) = o;
   }
 }
 
@@ -149,14 +149,14 @@ maxpool_kernel(const uint16_t* __restrict__ src, int B, int H, int W, int CP, in
           }
           continue;
         }
-        const bf16x8_t v = *reinterpret_cast<const bf16x8_t*>(src + ((b * H + yy) * W + xx) * CP + g * 8);
+        const h16x8_t v = *reinterpret_cast<const h16x8_t*>(src + ((b * H + yy) * W + xx) * CP + g * 8);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) m[j] = fmaxf(m[j], sa::bf2f(v[j]));
+        for (int j = 0; j < 8; ++j) m[j] = fmaxf(m[j], sa::h2f(v[j]));
       }
-    bf16x8_t o;
+    h16x8_t o;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) o[j] = sa::f2bf(m[j]);
-    *reinterpret_cast<bf16x8_t*>(dst + p * CP + g * 8) = o;
+    for (int j = 0; j < 8; ++j) o[j] = sa::f2h(m[j]);
+    *reinterpret_cast<h16x8_t*>(dst + p * CP + g * 8) = o;
   }
 }
 
@@ -172,16 +172,16 @@ add_kernel(const uint16_t* __restrict__ a, const uint16_t* __restrict__ bsrc, in
     const int x = (int)(p % W);
     const int y = (int)((p / W) % H);
     const size_t b = p / ((size_t)W * H);
-    const bf16x8_t va = *reinterpret_cast<const bf16x8_t*>(a + p * CP + g * 8);
+    const h16x8_t va = *reinterpret_cast<const h16x8_t*>(a + p * CP + g * 8);
     const size_t pb = b_half ? ((b * (H / 2) + (y >> 1)) * (W / 2) + (x >> 1)) : p;
-    const bf16x8_t vb = *reinterpret_cast<const bf16x8_t*>(bsrc + pb * CP + g * 8);
-    bf16x8_t o;
+    const h16x8_t vb = *reinterpret_cast<const h16x8_t*>(bsrc + pb * CP + g * 8);
+    h16x8_t o;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      float v = sa::bf2f(va[j]) + sa::bf2f(vb[j]);
-      o[j] = sa::f2bf(relu ? fmaxf(v, 0.0f) : v);
+      float v = sa::h2f(va[j]) + sa::h2f(vb[j]);
+      o[j] = sa::f2h(relu ? fmaxf(v, 0.0f) : v);
     }
-    *reinterpret_cast<bf16x8_t*>(dst + p * CP + g * 8) = o;
+    *reinterpret_cast<h16x8_t*>(dst + p * CP + g * 8) = o;
   }
 }
 
@@ -199,15 +199,15 @@ maxpool2x2_kernel(const uint16_t* __restrict__ src, int B, int H, int W, int CP,
     const int y = (int)((p / Wo) % Ho);
     const size_t b = p / ((size_t)Wo * Ho);
     const uint16_t* s = src + ((b * H + 2 * y) * W + 2 * x) * CP + g * 8;
-    const bf16x8_t a = *reinterpret_cast<const bf16x8_t*>(s);
-    const bf16x8_t c = *reinterpret_cast<const bf16x8_t*>(s + CP);
-    const bf16x8_t d = *reinterpret_cast<const bf16x8_t*>(s + (size_t)W * CP);
-    const bf16x8_t e = *reinterpret_cast<const bf16x8_t*>(s + (size_t)W * CP + CP);
-    bf16x8_t o;
+    const h16x8_t a = *reinterpret_cast<const h16x8_t*>(s);
+    const h16x8_t c = *reinterpret_cast<const h16x8_t*>(s + CP);
+    const h16x8_t d = *reinterpret_cast<const h16x8_t*>(s + (size_t)W * CP);
+    const h16x8_t e = *reinterpret_cast<const h16x8_t*>(s + (size_t)W * CP + CP);
+    h16x8_t o;
 #pragma unroll
     for (int j = 0; j < 8; ++j)
-      o[j] = sa::f2bf(fmaxf(fmaxf(sa::bf2f(a[j]), sa::bf2f(c[j])), fmaxf(sa::bf2f(d[j]), sa::bf2f(e[j]))));
-    *reinterpret_cast<bf16x8_t*>(dst + p * CP + g * 8) = o;
+      o[j] = sa::f2h(fmaxf(fmaxf(sa::h2f(a[j]), sa::h2f(c[j])), fmaxf(sa::h2f(d[j]), sa::h2f(e[j]))));
+    *reinterpret_cast<h16x8_t*>(dst + p * CP + g * 8) = o;
   }
 }
 
@@ -226,23 +226,23 @@ upsample2x_kernel(const uint16_t* __restrict__ src, int B, int H, int W, int CP,
     const int x = (int)(p % Wo);
     const int y = (int)((p / Wo) % Ho);
     const size_t b = p / ((size_t)Wo * Ho);
-    bf16x8_t o;
+    h16x8_t o;
     if (!bilinear) {
-      o = *reinterpret_cast<const bf16x8_t*>(src + ((b * H + y / 2) * W + x / 2) * CP + g * 8);
+      o = *reinterpret_cast<const h16x8_t*>(src + ((b * H + y / 2) * W + x / 2) * CP + g * 8);
     } else {
       int y0, y1, x0, x1;
       float wy, wx;
       sa::up2_taps(y, H, y0, y1, wy);
       sa::up2_taps(x, W, x0, x1, wx);
       const uint16_t* base = src + b * H * W * (size_t)CP + g * 8;
-      const bf16x8_t a = *reinterpret_cast<const bf16x8_t*>(base + ((size_t)y0 * W + x0) * CP);
-      const bf16x8_t c = *reinterpret_cast<const bf16x8_t*>(base + ((size_t)y0 * W + x1) * CP);
-      const bf16x8_t d = *reinterpret_cast<const bf16x8_t*>(base + ((size_t)y1 * W + x0) * CP);
-      const bf16x8_t e = *reinterpret_cast<const bf16x8_t*>(base + ((size_t)y1 * W + x1) * CP);
+      const h16x8_t a = *reinterpret_cast<const h16x8_t*>(base + ((size_t)y0 * W + x0) * CP);
+      const h16x8_t c = *reinterpret_cast<const h16x8_t*>(base + ((size_t)y0 * W + x1) * CP);
+      const h16x8_t d = *reinterpret_cast<const h16x8_t*>(base + ((size_t)y1 * W + x0) * CP);
+      const h16x8_t e = *reinterpret_cast<const h16x8_t*>(base + ((size_t)y1 * W + x1) * CP);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) o[j] = sa::f2bf(sa::up2_lerp(sa::bf2f(a[j]), sa::bf2f(c[j]), sa::bf2f(d[j]), sa::bf2f(e[j]), wy, wx));
+      for (int j = 0; j < 8; ++j) o[j] = sa::f2h(sa::up2_lerp(sa::h2f(a[j]), sa::h2f(c[j]), sa::h2f(d[j]), sa::h2f(e[j]), wy, wx));
     }
-    *reinterpret_cast<bf16x8_t*>(dst + p * CP + g * 8) = o;
+    *reinterpret_cast<h16x8_t*>(dst + p * CP + g * 8) = o;
   }
 }
 
@@ -266,29 +266,29 @@ upsample2x_bilinear_block_kernel(const uint16_t* __restrict__ src, int B, int H,
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
       const uint16_t* row = base + (size_t)ys[r] * W * CP;
-      const bf16x8_t vm = *reinterpret_cast<const bf16x8_t*>(row + (size_t)xs[0] * CP);
-      const bf16x8_t v0 = *reinterpret_cast<const bf16x8_t*>(row + (size_t)xs[1] * CP);
-      const bf16x8_t vp = *reinterpret_cast<const bf16x8_t*>(row + (size_t)xs[2] * CP);
+      const h16x8_t vm = *reinterpret_cast<const h16x8_t*>(row + (size_t)xs[0] * CP);
+      const h16x8_t v0 = *reinterpret_cast<const h16x8_t*>(row + (size_t)xs[1] * CP);
+      const h16x8_t vp = *reinterpret_cast<const h16x8_t*>(row + (size_t)xs[2] * CP);
 #pragma unroll
       for (int c = 0; c < 8; ++c) {
-        const float m = sa::bf2f(vm[c]), z = sa::bf2f(v0[c]), q = sa::bf2f(vp[c]);
+        const float m = sa::h2f(vm[c]), z = sa::h2f(v0[c]), q = sa::h2f(vp[c]);
         hl[r][c] = m + (z - m) * 0.75f;  // output column 2j:   taps (j-1, j), weight 0.75 on j
         hr[r][c] = z + (q - z) * 0.25f;  // output column 2j+1: taps (j, j+1), weight 0.25 on j+1
       }
     }
-    bf16x8_t o00, o01, o10, o11;
+    h16x8_t o00, o01, o10, o11;
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
-      o00[c] = sa::f2bf(hl[0][c] + (hl[1][c] - hl[0][c]) * 0.75f);  // row 2i
-      o01[c] = sa::f2bf(hr[0][c] + (hr[1][c] - hr[0][c]) * 0.75f);
-      o10[c] = sa::f2bf(hl[1][c] + (hl[2][c] - hl[1][c]) * 0.25f);  // row 2i+1
-      o11[c] = sa::f2bf(hr[1][c] + (hr[2][c] - hr[1][c]) * 0.25f);
+      o00[c] = sa::f2h(hl[0][c] + (hl[1][c] - hl[0][c]) * 0.75f);  // row 2i
+      o01[c] = sa::f2h(hr[0][c] + (hr[1][c] - hr[0][c]) * 0.75f);
+      o10[c] = sa::f2h(hl[1][c] + (hl[2][c] - hl[1][c]) * 0.25f);  // row 2i+1
+      o11[c] = sa::f2h(hr[1][c] + (hr[2][c] - hr[1][c]) * 0.25f);
     }
     uint16_t* o = dst + (((b * 2 * H + 2 * i) * 2 * W) + 2 * j) * (size_t)CP + g * 8;
-    *reinterpret_cast<bf16x8_t*>(o) = o00;
-    *reinterpret_cast<bf16x8_t*>(o + CP) = o01;
-    *reinterpret_cast<bf16x8_t*>(o + (size_t)2 * W * CP) = o10;
-    *reinterpret_cast<bf16x8_t*>(o + (size_t)2 * W * CP + CP) = o11;
+    *reinterpret_cast<h16x8_t*>(o) = o00;
+    *reinterpret_cast<h16x8_t*>(o + CP) = o01;
+    *reinterpret_cast<h16x8_t*>(o + (size_t)2 * W * CP) = o10;
+    *reinterpret_cast<h16x8_t*>(o + (size_t)2 * W * CP + CP) = o11;
   }
 }
 
@@ -312,10 +312,10 @@ conv1x1_head_kernel(const uint16_t* __restrict__ src, int CinP, const float* __r
 #pragma unroll
       for (int j = 0; j < CO; ++j) acc[j] = 0.0f;
       for (int k = 0; k < CinP; k += 8) {
-        const bf16x8_t v = *reinterpret_cast<const bf16x8_t*>(s + k);
+        const h16x8_t v = *reinterpret_cast<const h16x8_t*>(s + k);
         float f[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) f[i] = sa::bf2f(v[i]);
+        for (int i = 0; i < 8; ++i) f[i] = sa::h2f(v[i]);
 #pragma unroll
         for (int j = 0; j < CO; ++j) {
           const float* wr = sw + (c0 + j) * CinP + k;
@@ -339,7 +339,7 @@ conv1x1_head_kernel(const uint16_t* __restrict__ src, int CinP, const float* __r
 // from the NHWC feature tensor (one 16-byte load per lane and k-step, no staging: a pixel's 64-byte line serves two
 // consecutive k-steps out of L1); fp32 accumulate; the lane that holds head channel n of pixel p stores it.
 // Bandwidth-bound (reads the bf16 features once) instead of Cout x Cin VALU FMAs per pixel.
-typedef __attribute__((ext_vector_type(8))) __bf16 head_bf16x8;
+typedef sa::mfma_h8 head_bf16x8;
 typedef __attribute__((ext_vector_type(16))) float head_f32x16;
 
 __global__ void __launch_bounds__(256)
@@ -347,16 +347,16 @@ conv1x1_head_mfma_kernel(const uint16_t* __restrict__ src, int CinP, const float
                          const float* __restrict__ bias, int Cout, int act, size_t n_pix, float* __restrict__ dst) {
 #if defined(__HIP_DEVICE_COMPILE__)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  bf16x8_t* frag = reinterpret_cast<bf16x8_t*>(smem_raw);  // [K16][2 terms][64 lanes]
+  h16x8_t* frag = reinterpret_cast<h16x8_t*>(smem_raw);  // [K16][2 terms][64 lanes]
   const int K16 = CinP / 16;
   for (int i = threadIdx.x; i < K16 * 64; i += blockDim.x) {
     const int k16 = i >> 6, l = i & 63, n = l & 31, k0 = k16 * 16 + (l >> 5) * 8;
-    bf16x8_t hi, lo;
+    h16x8_t hi, lo;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const float v = n < Cout ? w[(size_t)n * CinP + k0 + j] : 0.0f;
-      hi[j] = sa::f2bf(v);
-      lo[j] = sa::f2bf(v - sa::bf2f(hi[j]));
+      hi[j] = sa::f2h(v);
+      lo[j] = sa::f2h(v - sa::h2f(hi[j]));
     }
     frag[(k16 * 2 + 0) * 64 + l] = hi;
     frag[(k16 * 2 + 1) * 64 + l] = lo;
@@ -376,8 +376,8 @@ conv1x1_head_mfma_kernel(const uint16_t* __restrict__ src, int CinP, const float
       const head_bf16x8 b = *reinterpret_cast<const head_bf16x8*>(s + k16 * 16);
       const head_bf16x8 a0 = __builtin_bit_cast(head_bf16x8, frag[(k16 * 2 + 0) * 64 + lane]);
       const head_bf16x8 a1 = __builtin_bit_cast(head_bf16x8, frag[(k16 * 2 + 1) * 64 + lane]);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b, acc, 0, 0, 0);
+      acc = SA_MFMA_32x32x16(a0, b, acc, 0, 0, 0);
+      acc = SA_MFMA_32x32x16(a1, b, acc, 0, 0, 0);
     }
     if (ok) {
       float* o = dst + p * Cout;
@@ -423,14 +423,14 @@ convt3x3s2_kernel(const uint16_t* __restrict__ src, int CinP, const uint16_t* __
         const uint16_t* s = src + ((b * H + i) * W + j) * CinP;
         const uint16_t* wr = w + ((size_t)(ky * 3 + kx) * CoutP + co) * CinP;
         for (int k = 0; k < CinP; k += 8) {
-          const bf16x8_t a = *reinterpret_cast<const bf16x8_t*>(s + k);
-          const bf16x8_t q = *reinterpret_cast<const bf16x8_t*>(wr + k);
+          const h16x8_t a = *reinterpret_cast<const h16x8_t*>(s + k);
+          const h16x8_t q = *reinterpret_cast<const h16x8_t*>(wr + k);
 #pragma unroll
-          for (int e = 0; e < 8; ++e) acc = fmaf(sa::bf2f(a[e]), sa::bf2f(q[e]), acc);
+          for (int e = 0; e < 8; ++e) acc = fmaf(sa::h2f(a[e]), sa::h2f(q[e]), acc);
         }
       }
     }
-    dst[t] = sa::f2bf(relu ? fmaxf(acc, 0.0f) : acc);
+    dst[t] = sa::f2h(relu ? fmaxf(acc, 0.0f) : acc);
   }
 }
 
@@ -467,7 +467,7 @@ __global__ void f32_to_bf16_padded_kernel(const float* __restrict__ src, size_t 
   for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
     const int c = (int)(t % CP);
     const size_t p = t / CP;
-    dst[t] = (c < C) ? sa::f2bf(src[p * C + c]) : (uint16_t)0;
+    dst[t] = (c < C) ? sa::f2h(src[p * C + c]) : (uint16_t)0;
   }
 }
 
@@ -477,7 +477,7 @@ __global__ void bf16_to_f32_kernel(const uint16_t* __restrict__ src, size_t n_pi
   for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
     const int c = (int)(t % C);
     const size_t p = t / C;
-    dst[t] = sa::bf2f(src[p * CP + c]);
+    dst[t] = sa::h2f(src[p * CP + c]);
   }
 }
 

@@ -69,6 +69,9 @@ nms_scan_kernel(const float* __restrict__ cms, int H, int W, int C, float thr, i
     const float4* img4 = reinterpret_cast<const float4*>(img);
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
       const float4 q = img4[i];
+      // inf - inf and NaN - NaN are NaN: one test for "any of the four is not finite"
+      const float qs = __fadd_rn(__fadd_rn(q.x, q.y), __fadd_rn(q.z, q.w));
+      if (__fsub_rn(qs, qs) != 0.0f) atomicOr(&status[b], SA_STATUS_NONFINITE);
       if (!(q.x > thr || q.y > thr || q.z > thr || q.w > thr)) continue;
       const float vals[4] = {q.x, q.y, q.z, q.w};
 #pragma unroll
@@ -85,6 +88,7 @@ nms_scan_kernel(const float* __restrict__ cms, int H, int W, int C, float thr, i
   } else {
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < plane; e += stride) {
       const float v = img[e];
+      if (__fsub_rn(v, v) != 0.0f) atomicOr(&status[b], SA_STATUS_NONFINITE);
       if (!(v > thr)) continue;
       const int c = (int)(e % C);
       const size_t p = e / C;

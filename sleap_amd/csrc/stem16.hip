@@ -20,9 +20,9 @@
 
 namespace {
 
-typedef __attribute__((ext_vector_type(8))) __bf16 mfma_bf16x8;
+using sa::mfma_h8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
-using sa::bf16x8_t;
+using sa::h16x8_t;
 
 struct Stem16Params {
   const uint8_t* src;   // [B,H,W,CIN] u8
@@ -57,7 +57,7 @@ stem16_kernel(const Stem16Params p) {
   const int x0 = tx_i * TW, y0 = ty_i * TH;
   const int H = p.H, W = p.W;
 
-  // ---- raw tile (zero outside the image = conv0's SAME padding), pixel values as bf16 (exact for 0..255)
+  // ---- raw tile (zero outside the image = conv0's SAME padding), pixel values x U8_ACT_SCALE in the storage type (exact for 0..255)
   if (CIN == 1 && (W & 3) == 0) {
     // aligned dword loads: columns x0-4 .. x0+35 (10 dwords per row); raw column tx corresponds to gx = x0 + tx - 2
     for (int i = tid; i < RH * 10; i += 256) {
@@ -69,7 +69,7 @@ stem16_kernel(const Stem16Params p) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int tx = dq * 4 + e - 2;
-        if (tx >= 0 && tx < RW) raw[ty * RW + tx] = sa::f2bf((float)((v >> (8 * e)) & 0xFF));
+        if (tx >= 0 && tx < RW) raw[ty * RW + tx] = sa::f2h((float)((v >> (8 * e)) & 0xFF) * sa::U8_ACT_SCALE);
       }
     }
   } else {
@@ -79,16 +79,16 @@ stem16_kernel(const Stem16Params p) {
       const int gy = y0 + ty - 2, gx = x0 + tx - 2;
       float v = 0.0f;
       if (gy >= 0 && gy < H && gx >= 0 && gx < W) v = (float)p.src[(((size_t)b * H + gy) * W + gx) * CIN + c];
-      raw[i] = sa::f2bf(v);
+      raw[i] = sa::f2h(v * sa::U8_ACT_SCALE);
     }
   }
   // ---- weights: MFMA A fragments packed per lane on the host (sa_stem16_pack), register resident
   const uint4* blob4 = reinterpret_cast<const uint4*>(p.blob);
-  mfma_bf16x8 wa[3], wb[5];
+  mfma_h8 wa[3], wb[5];
 #pragma unroll
-  for (int i = 0; i < 3; ++i) wa[i] = __builtin_bit_cast(mfma_bf16x8, blob4[i * 64 + lane]);
+  for (int i = 0; i < 3; ++i) wa[i] = __builtin_bit_cast(mfma_h8, blob4[i * 64 + lane]);
 #pragma unroll
-  for (int i = 0; i < 5; ++i) wb[i] = __builtin_bit_cast(mfma_bf16x8, blob4[(3 + i) * 64 + lane]);
+  for (int i = 0; i < 5; ++i) wb[i] = __builtin_bit_cast(mfma_h8, blob4[(3 + i) * 64 + lane]);
   const float* biases = reinterpret_cast<const float*>(p.blob + 8 * 64 * 8);
   const float4 q0 = *reinterpret_cast<const float4*>(biases + kb * 4);  // D rows of this lane: couts kb*4 .. kb*4+3
   const float4 q1 = *reinterpret_cast<const float4*>(biases + 16 + kb * 4);
@@ -102,7 +102,7 @@ stem16_kernel(const Stem16Params p) {
     const bool valid = pl < PH * PW;
     const int plc = valid ? pl : 0;
     const int ty = plc / PW, tx = plc - ty * PW;
-    bf16x8_t bq = {0, 0, 0, 0, 0, 0, 0, 0};
+    h16x8_t bq = {0, 0, 0, 0, 0, 0, 0, 0};
     if (CIN == 1) {
       if (kb < 3) {
         const uint16_t* r = raw + (ty + kb) * RW + tx;
@@ -120,11 +120,11 @@ stem16_kernel(const Stem16Params p) {
         }
       }
     }
-    const mfma_bf16x8 bf = __builtin_bit_cast(mfma_bf16x8, bq);
+    const mfma_h8 bf = __builtin_bit_cast(mfma_h8, bq);
     f32x4 d = {0.0f, 0.0f, 0.0f, 0.0f};
-    d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[0], bf, d, 0, 0, 0);
-    d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[1], bf, d, 0, 0, 0);
-    d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[2], bf, d, 0, 0, 0);
+    d = SA_MFMA_16x16x32(wa[0], bf, d, 0, 0, 0);
+    d = SA_MFMA_16x16x32(wa[1], bf, d, 0, 0, 0);
+    d = SA_MFMA_16x16x32(wa[2], bf, d, 0, 0, 0);
     const int gy = y0 + ty - 1, gx = x0 + tx - 1;
     const bool in_img = valid && gy >= 0 && gy < H && gx >= 0 && gx < W;  // outside: conv1's SAME padding = 0
     float v[4];
@@ -136,8 +136,8 @@ stem16_kernel(const Stem16Params p) {
     }
     if (valid) {
       uint2 o;
-      o.x = sa::f2bf2(v[0], v[1]);
-      o.y = sa::f2bf2(v[2], v[3]);
+      o.x = sa::f2h2(v[0], v[1]);
+      o.y = sa::f2h2(v[2], v[3]);
       *reinterpret_cast<uint2*>(act + pl * APIX + kb * 8) = o;
     }
   }
@@ -158,8 +158,8 @@ stem16_kernel(const Stem16Params p) {
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         const int pl = (wave * 4 + r + dy) * PW + h * 16 + n16 + dx;
-        const mfma_bf16x8 bv = *reinterpret_cast<const mfma_bf16x8*>(act + pl * APIX + (kb & 1) * 16);
-        acc[r][h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[s], bv, acc[r][h], 0, 0, 0);
+        const mfma_h8 bv = *reinterpret_cast<const mfma_h8*>(act + pl * APIX + (kb & 1) * 16);
+        acc[r][h] = SA_MFMA_16x16x32(wb[s], bv, acc[r][h], 0, 0, 0);
       }
   }
 
@@ -181,8 +181,8 @@ stem16_kernel(const Stem16Params p) {
         const int gy = y0 + wave * 4 + r;
         if (gy < H && gx < W) {
           uint2 o;
-          o.x = sa::f2bf2(v[r][0], v[r][1]);
-          o.y = sa::f2bf2(v[r][2], v[r][3]);
+          o.x = sa::f2h2(v[r][0], v[r][1]);
+          o.y = sa::f2h2(v[r][2], v[r][3]);
           *reinterpret_cast<uint2*>(p.dst + (((size_t)b * H + gy) * W + gx) * 16 + kb * 4) = o;
         }
       }
@@ -199,8 +199,8 @@ stem16_kernel(const Stem16Params p) {
         const int gy = y0 + wave * 4 + r;
         if (!(lane & 1) && gy < H && gx < W) {
           uint2 o;
-          o.x = sa::f2bf2(t4[0], t4[1]);
-          o.y = sa::f2bf2(t4[2], t4[3]);
+          o.x = sa::f2h2(t4[0], t4[1]);
+          o.y = sa::f2h2(t4[2], t4[3]);
           *reinterpret_cast<uint2*>(p.dst_pool + (((size_t)b * (H / 2) + gy / 2) * (W / 2) + gx / 2) * 16 + kb * 4) = o;
         }
       }
@@ -246,11 +246,11 @@ stem16_gray_kernel(const Stem16Params p) {
       if (gx >= 0 && gx < W) v0 = *reinterpret_cast<const unsigned*>(row + gx);
       if (gx + 4 >= 0 && gx + 4 < W) v1 = *reinterpret_cast<const unsigned*>(row + gx + 4);
     }
-    unsigned h[6];  // bf16 bits of pixels 0..5 of the 8 (integers 0..255 are exact: the high half of the float)
+    unsigned h[6];  // storage bits of pixels 0..5 of the 8 (0..255 x U8_ACT_SCALE: exact in bf16 and fp16)
 #pragma unroll
     for (int e = 0; e < 6; ++e) {
       const unsigned byte = e < 4 ? (v0 >> (8 * e)) & 0xFF : (v1 >> (8 * (e - 4))) & 0xFF;
-      h[e] = __float_as_uint((float)byte) >> 16;
+      h[e] = sa::f2h((float)byte * sa::U8_ACT_SCALE);
     }
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -259,11 +259,11 @@ stem16_gray_kernel(const Stem16Params p) {
     }
   }
   const uint4* blob4 = reinterpret_cast<const uint4*>(p.blob);
-  mfma_bf16x8 wa[3], wb[5];
+  mfma_h8 wa[3], wb[5];
 #pragma unroll
-  for (int i = 0; i < 3; ++i) wa[i] = __builtin_bit_cast(mfma_bf16x8, blob4[i * 64 + lane]);
+  for (int i = 0; i < 3; ++i) wa[i] = __builtin_bit_cast(mfma_h8, blob4[i * 64 + lane]);
 #pragma unroll
-  for (int i = 0; i < 5; ++i) wb[i] = __builtin_bit_cast(mfma_bf16x8, blob4[(3 + i) * 64 + lane]);
+  for (int i = 0; i < 5; ++i) wb[i] = __builtin_bit_cast(mfma_h8, blob4[(3 + i) * 64 + lane]);
   const float* biases = reinterpret_cast<const float*>(p.blob + 8 * 64 * 8);
   const float4 q0 = *reinterpret_cast<const float4*>(biases + kb * 4);
   const float4 q1 = *reinterpret_cast<const float4*>(biases + 16 + kb * 4);
@@ -281,11 +281,11 @@ stem16_gray_kernel(const Stem16Params p) {
       uint2 tq = rawt[(ty + kbc) * RS + tx];  // rows up to RH are allocated: the tail of the last group reads garbage
       if (kb == 3) tq = make_uint2(0u, 0u);
       const uint4 bq4 = make_uint4(tq.x, tq.y, 0u, 0u);
-      const mfma_bf16x8 bf = __builtin_bit_cast(mfma_bf16x8, bq4);
+      const mfma_h8 bf = __builtin_bit_cast(mfma_h8, bq4);
       f32x4 d = {bias0[0], bias0[1], bias0[2], bias0[3]};
-      d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[0], bf, d, 0, 0, 0);
-      d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[1], bf, d, 0, 0, 0);
-      d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[2], bf, d, 0, 0, 0);
+      d = SA_MFMA_16x16x32(wa[0], bf, d, 0, 0, 0);
+      d = SA_MFMA_16x16x32(wa[1], bf, d, 0, 0, 0);
+      d = SA_MFMA_16x16x32(wa[2], bf, d, 0, 0, 0);
       // outside the image: conv1's SAME padding = 0
       const bool in_img = valid && (unsigned)(y0 + ty - 1) < (unsigned)H && (unsigned)(x0 + tx - 1) < (unsigned)W;
       float v[4];
@@ -294,7 +294,7 @@ stem16_gray_kernel(const Stem16Params p) {
         const float t = p.relu0 ? fmaxf(d[j], 0.0f) : d[j];
         v[j] = in_img ? t : 0.0f;
       }
-      if (valid) *reinterpret_cast<uint2*>(act + pl * 32 + kb * 8) = make_uint2(sa::f2bf2(v[0], v[1]), sa::f2bf2(v[2], v[3]));
+      if (valid) *reinterpret_cast<uint2*>(act + pl * 32 + kb * 8) = make_uint2(sa::f2h2(v[0], v[1]), sa::f2h2(v[2], v[3]));
       pl += 64;  // 64 = PW + 30
       tx += 30;
       ty += 1;
@@ -325,8 +325,8 @@ stem16_gray_kernel(const Stem16Params p) {
     for (int r = 0; r < 4; ++r)
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
-        const mfma_bf16x8 bv = *reinterpret_cast<const mfma_bf16x8*>(sb + (r * PW + h * 16) * 32);
-        acc[r][h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[s], bv, acc[r][h], 0, 0, 0);
+        const mfma_h8 bv = *reinterpret_cast<const mfma_h8*>(sb + (r * PW + h * 16) * 32);
+        acc[r][h] = SA_MFMA_16x16x32(wb[s], bv, acc[r][h], 0, 0, 0);
       }
   }
 
@@ -343,7 +343,7 @@ stem16_gray_kernel(const Stem16Params p) {
         for (int j = 0; j < 4; ++j) v[j] = p.relu1 ? fmaxf(acc[r][h][j], 0.0f) : acc[r][h][j];
         if (gy < H && gx < W)
           *reinterpret_cast<uint2*>(p.dst + (((size_t)b * H + gy) * W + gx) * 16 + kb * 4) =
-              make_uint2(sa::f2bf2(v[0], v[1]), sa::f2bf2(v[2], v[3]));
+              make_uint2(sa::f2h2(v[0], v[1]), sa::f2h2(v[2], v[3]));
       }
     }
     if (p.dst_pool) {
@@ -359,7 +359,7 @@ stem16_gray_kernel(const Stem16Params p) {
         const int gy = y0 + wave * 4 + r;
         if (!(lane & 1) && gy < H && gx < W)
           *reinterpret_cast<uint2*>(p.dst_pool + (((size_t)b * (H / 2) + gy / 2) * (W / 2) + gx / 2) * 16 + kb * 4) =
-              make_uint2(sa::f2bf2(t4[0], t4[1]), sa::f2bf2(t4[2], t4[3]));
+              make_uint2(sa::f2h2(t4[0], t4[1]), sa::f2h2(t4[2], t4[3]));
       }
     }
   }
@@ -373,7 +373,7 @@ extern "C" {
 size_t sa_stem16_blob_bytes(void) { return 8 * 64 * 8 * 2 + 32 * 4; }
 
 // HOST: Keras kernels conv0 (3,3,Cin,C0) f32 / conv1 (3,3,C0,C1) f32 + biases -> the per-lane MFMA A-fragment blob:
-//   wa[3][64][8] bf16: conv0 weights * 1/255 split hi/mid/lo; lane l -> cout l&15, k = (l>>4)*8 + j
+//   wa[3][64][8] bf16: conv0 weights * 1/255 / U8_ACT_SCALE split hi/mid/lo; lane l -> cout l&15, k = (l>>4)*8 + j
 //                      (Cin=1: k-block = kernel row, j = kernel column; Cin=3: k = tap*3 + c)
 //   wb[5][64][8] bf16: conv1, step s covers taps 2s (k-blocks 0,1 = channels 0-7, 8-15) and 2s+1 (k-blocks 2,3)
 //   bias0[16], bias1[16] f32
@@ -392,13 +392,13 @@ int sa_stem16_pack(const float* k0, const float* b0, int Cin, int C0, const floa
         f = k;
       }
       float wv = 0.0f;
-      if (f >= 0 && m < C0) wv = k0[(size_t)f * C0 + m] * (1.0f / 255.0f);
-      const uint16_t h0 = sa::f2bf(wv);
-      const float r1 = wv - sa::bf2f(h0);
-      const uint16_t h1 = sa::f2bf(r1);
+      if (f >= 0 && m < C0) wv = k0[(size_t)f * C0 + m] * (1.0f / 255.0f) * (1.0f / sa::U8_ACT_SCALE);
+      const uint16_t h0 = sa::f2h(wv);
+      const float r1 = wv - sa::h2f(h0);
+      const uint16_t h1 = sa::f2h(r1);
       w[(0 * 64 + l) * 8 + j] = h0;
       w[(1 * 64 + l) * 8 + j] = h1;
-      w[(2 * 64 + l) * 8 + j] = sa::f2bf(r1 - sa::bf2f(h1));
+      w[(2 * 64 + l) * 8 + j] = sa::f2h(r1 - sa::h2f(h1));
     }
     for (int s = 0; s < 5; ++s) {
       const int tap = 2 * s + (kb >> 1);
@@ -406,7 +406,7 @@ int sa_stem16_pack(const float* k0, const float* b0, int Cin, int C0, const floa
         const int ci = (kb & 1) * 8 + j;
         float v = 0.0f;
         if (tap < 9 && ci < C0 && m < C1) v = k1[((size_t)tap * C0 + ci) * C1 + m];
-        w[((3 + s) * 64 + l) * 8 + j] = sa::f2bf(v);
+        w[((3 + s) * 64 + l) * 8 + j] = sa::f2h(v);
       }
     }
   }

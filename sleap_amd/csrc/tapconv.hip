@@ -22,8 +22,8 @@
 
 namespace {
 
-using sa::bf16x8_t;
-typedef __attribute__((ext_vector_type(8))) __bf16 mfma_bf16x8;
+using sa::h16x8_t;
+using sa::mfma_h8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
@@ -173,20 +173,20 @@ tapconv_kernel(const TapParams p) {
     const unsigned char* w_tile = in_tile + IN_BYTES;
 #pragma unroll
     for (int kk = 0; kk < KK; ++kk) {
-      mfma_bf16x8 a[2], bv[2];
+      mfma_h8 a[2], bv[2];
 #pragma unroll
       for (int m = 0; m < 2; ++m)
-        a[m] = *reinterpret_cast<const mfma_bf16x8*>(w_tile + ((wn * 2 + m) * KK + kk) * 1024 + lane * 16);
+        a[m] = *reinterpret_cast<const mfma_h8*>(w_tile + ((wn * 2 + m) * KK + kk) * 1024 + lane * 16);
 #pragma unroll
       for (int r = 0; r < 2; ++r) {
         const int pl = (wm * 2 + r) * 32 + lx;
         const int slot = (kk * 2 + half) ^ ((pl >> 1) & 7);
-        bv[r] = *reinterpret_cast<const mfma_bf16x8*>(in_tile + pl * (CK * 2) + slot * 16);
+        bv[r] = *reinterpret_cast<const mfma_h8*>(in_tile + pl * (CK * 2) + slot * 16);
       }
 #pragma unroll
       for (int m = 0; m < 2; ++m)
 #pragma unroll
-        for (int r = 0; r < 2; ++r) acc[m][r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m], bv[r], acc[m][r], 0, 0, 0);
+        for (int r = 0; r < 2; ++r) acc[m][r] = SA_MFMA_32x32x16(a[m], bv[r], acc[m][r], 0, 0, 0);
     }
     buf ^= 1;
   }
@@ -230,9 +230,8 @@ tapconv_kernel(const TapParams p) {
       for (int r = 0; r < 2; ++r) {
         uint2 q = make_uint2(0u, 0u);
         if (rrow[r] && pix_ok[r] && cok) q = *reinterpret_cast<const uint2*>(rrow[r] + co);
-        // bf16 -> f32 is a 16-bit shift: two of the four values need only a mask
-        const float rr[4] = {__uint_as_float(q.x << 16), __uint_as_float(q.x & 0xffff0000u), __uint_as_float(q.y << 16),
-                             __uint_as_float(q.y & 0xffff0000u)};
+        const float rr[4] = {sa::h2f((uint16_t)(q.x & 0xffff)), sa::h2f((uint16_t)(q.x >> 16)), sa::h2f((uint16_t)(q.y & 0xffff)),
+                             sa::h2f((uint16_t)(q.y >> 16))};
         float v[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -240,8 +239,8 @@ tapconv_kernel(const TapParams p) {
           t = fmaf(t, ss[j], tt[j]) + rr[j];
           v[j] = fmaxf(t, lowl);
         }
-        pk[r][g].x = sa::f2bf2(v[0], v[1]);
-        pk[r][g].y = sa::f2bf2(v[2], v[3]);
+        pk[r][g].x = sa::f2h2(v[0], v[1]);
+        pk[r][g].y = sa::f2h2(v[2], v[3]);
       }
     }
 #pragma unroll
@@ -326,7 +325,7 @@ int sa_pack_tapconv_weights(const float* w, int n_taps, int Cin, int CinP, int C
             const int co = c32 * 32 + (lane & 31), ci = k16 * 16 + (lane >> 5) * 8 + j;
             float v = 0.0f;
             if (co < Cout && ci < Cin) v = w[((size_t)t * Cin + ci) * Cout + co];
-            packed[((((size_t)c32 * n_taps + t) * K16 + k16) * 64 + lane) * 8 + j] = sa::f2bf(v);
+            packed[((((size_t)c32 * n_taps + t) * K16 + k16) * 64 + lane) * 8 + j] = sa::f2h(v);
           }
   return SA_OK;
 }

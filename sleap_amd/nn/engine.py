@@ -51,14 +51,23 @@ class _T:
         self.pads = None  # zpad: ((top, bottom), (left, right))
 
 
+DEFAULT_DTYPE = None  # set (temporarily) by load_model(dtype=...); otherwise _lib.DEFAULT_DTYPE (SLEAP_AMD_DTYPE or "fp16")
+
+
 class DeviceNetwork:
     def __init__(self, model_config: dict, weights: Dict[str, np.ndarray], device=None, fuse_upsample: bool = False,
                  fuse_heads: bool = True, fuse_stem: bool = True, use_stem16: bool = True, mfma_convt: bool = True,
-                 mfma_stem: bool = True, fuse_pairs: bool = True):
+                 mfma_stem: bool = True, fuse_pairs: bool = True, dtype: Optional[str] = None):
         """`fuse_upsample=True` folds UpSampling2D(bilinear) into the consuming conv's tile load (register-staged
         v1 kernel); the default materialises the upsampled tensor with the bandwidth-bound standalone kernel and
         feeds the asynchronous-DMA conv kernel (faster overall, measured in profiles/)."""
         require_cuda()
+        # 16-bit storage type of activations and conv weights: "fp16" (default; 11-bit mantissa: heads within 0.1-0.5 % of an
+        # fp32 network, finite range 65504) or "bf16" (fp32 range, 8-bit mantissa: 1-4 %). SLEAP_AMD_DTYPE sets the default.
+        # Each type is its own build of the kernel library (csrc/bf16.h, _lib.lib(dtype)); accumulation is fp32 in both.
+        self.dtype = dtype or DEFAULT_DTYPE or _lib.DEFAULT_DTYPE
+        self._h = _lib.lib(self.dtype)
+        self._tdtype = torch.float16 if self.dtype == "fp16" else torch.bfloat16
         self.fuse_upsample = fuse_upsample
         self.fuse_heads = fuse_heads
         self.fuse_stem = fuse_stem
@@ -282,7 +291,7 @@ class DeviceNetwork:
                     if k == (7, 7) and cin in (1, 3) and self.mfma_stem:
                         # uint8 frames: the same conv on the matrix cores (csrc/imgconv.hip); weights x input scale as
                         # hi + lo bf16 fragments, ImageNet means folded into the bias + an exact border indicator term
-                        h = _lib.lib()
+                        h = self._h
                         wk = np.ascontiguousarray(w[..., :cout], dtype=np.float32)
                         packed = np.zeros((h.sa_imgconv_packed_elems(7, cin, coutp),), np.uint16)
                         bias_io = np.ascontiguousarray(b_np, dtype=np.float32).copy()
@@ -300,7 +309,7 @@ class DeviceNetwork:
                     s0 = materialize(x)
                     st = strides[0]
                     o = _T("real", cout, x.num, x.den * st, buf=new_buf(coutp, x.num, x.den * st, "bf16"))
-                    h = _lib.lib()
+                    h = self._h
                     packed = np.zeros((h.sa_tapconv_packed_elems(1, s0.cp, coutp),), np.uint16)
                     kc = np.ascontiguousarray(kern[0, 0])
                     check(h.sa_pack_tapconv_weights(kc.ctypes.data_as(C.c_void_p), 1, cin, s0.cp, cout, coutp,
@@ -339,7 +348,7 @@ class DeviceNetwork:
                     c0, c1 = s0.c, (s1.c if s1 is not None else 0)
                     assert c0 + c1 == cin, (name, c0, c1, cin)
                     c0p, c1p = s0.cp, (s1.cp if s1 is not None else 0)
-                    h = _lib.lib()
+                    h = self._h
                     n = h.sa_conv3x3_packed_elems(c0p, c1p, coutp)
                     packed = np.zeros((n,), np.uint16)
                     kc = np.ascontiguousarray(kern)
@@ -369,11 +378,11 @@ class DeviceNetwork:
                 if ksz == (3, 3) and ext is None and not self.mfma_convt:
                     w = np.zeros((3, 3, coutp, s.cp), np.float32)
                     w[:, :, :cout, :cin] = kern
-                    wb = torch.from_numpy(w).to(dev).to(torch.bfloat16).contiguous()
+                    wb = torch.from_numpy(w).to(dev).to(self._tdtype).contiguous()
                     plan.append(("convt", s, wb, bias, o, relu))
                 else:
                     # one tap-GEMM launch per output phase; phase weights = the kernel taps of that phase, transposed
-                    h = _lib.lib()
+                    h = self._h
                     phases = []
                     for ph in range(4):
                         ky, kx = (C.c_int * 4)(), (C.c_int * 4)()
@@ -615,7 +624,7 @@ class DeviceNetwork:
                 continue
             w1_16 = None
             if so.cp == 16 and cv[6].cp == 16:  # register-resident 16x16x32 MFMA specialisation (uint8 input)
-                h = _lib.lib()
+                h = self._h
                 k0 = np.ascontiguousarray(self.weights[op[6] + "/kernel"], dtype=np.float32)
                 k1 = np.ascontiguousarray(self.weights[cv[11] + "/kernel"], dtype=np.float32)
                 b0 = np.ascontiguousarray(self.weights.get(op[6] + "/bias", np.zeros(k0.shape[3])), dtype=np.float32)
@@ -641,7 +650,7 @@ class DeviceNetwork:
             bufs = {}
             for i, (c_alloc, num, den, dt) in self.buf_meta.items():
                 h, w = H * num // den, W * num // den
-                dtype = torch.bfloat16 if dt == "bf16" else torch.float32
+                dtype = self._tdtype if dt == "bf16" else torch.float32
                 bufs[i] = torch.empty((B, h, w, c_alloc), dtype=dtype, device=self.device)
             self._buffers = {key: bufs}  # keep one shape resident
             self._slot1 = {}
@@ -762,7 +771,7 @@ class DeviceNetwork:
         if H % self.max_stride or W % self.max_stride:
             raise ValueError(f"input size {(H, W)} must be a multiple of the model stride {self.max_stride}")
         bufs = self._slot_buffers(self._get_buffers(B, H, W), slot)
-        h = _lib.lib()
+        h = self._h
         st = _stream()
 
         def hw(tt):

@@ -238,6 +238,10 @@ class InferenceModel:
             bits = 0
             for v in outs["status"].tolist():
                 bits |= int(v)
+            if bits & _lib.STATUS_NONFINITE:
+                raise FloatingPointError(
+                    "the network's confidence maps contain inf / NaN: activations left the range of the 16-bit storage type "
+                    "(fp16: 65504). Load the model with dtype='bf16' (or SLEAP_AMD_DTYPE=bf16), which has fp32's range.")
             if bits & _lib.STATUS_LSA_INFEASIBLE:
                 raise ValueError("cost matrix is infeasible")  # what scipy raises inside the reference
             over = bits & (_lib.STATUS_PEAK_OVERFLOW | _lib.STATUS_NODE_PEAK_OVERFLOW | _lib.STATUS_INSTANCE_OVERFLOW)
@@ -1117,8 +1121,11 @@ def load_model(model_path: Union[str, List[str]], batch_size: int = 4, peak_thre
                refinement: str = "integral", tracker: Optional[str] = None, tracker_window: int = 5,
                tracker_max_instances: Optional[int] = None, disable_gpu_preallocation: bool = True,
                progress_reporting: str = "rich", resize_input_layer: bool = True,
-               max_instances: Optional[int] = None) -> Predictor:
-    """inference.py:4865-5004: accepts model folders, `training_config.json` paths or `.zip` archives."""
+               max_instances: Optional[int] = None, dtype: Optional[str] = None) -> Predictor:
+    """inference.py:4865-5004: accepts model folders, `training_config.json` paths or `.zip` archives.
+
+    New: `dtype` = 16-bit storage type of the network's activations / conv weights, "bf16" (default) or "fp16" (closer to the
+    reference's fp32 numerics, finite range)."""
     if isinstance(model_path, str):
         model_paths = [model_path]
     else:
@@ -1143,9 +1150,15 @@ def load_model(model_path: Union[str, List[str]], batch_size: int = 4, peak_thre
         tracker_obj = Tracker.make_tracker_by_name(tracker=tracker, track_window=tracker_window,
                                                    post_connect_single_breaks=True, max_tracking=use_max_tracker,
                                                    max_tracks=tracker_max_instances)
-    predictor = Predictor.from_model_paths(resolved, peak_threshold=peak_threshold,
-                                           integral_refinement=refinement == "integral", batch_size=batch_size,
-                                           resize_input_layer=resize_input_layer, max_instances=max_instances)
+    from . import engine as _engine
+
+    prev, _engine.DEFAULT_DTYPE = _engine.DEFAULT_DTYPE, dtype or _engine.DEFAULT_DTYPE
+    try:
+        predictor = Predictor.from_model_paths(resolved, peak_threshold=peak_threshold,
+                                               integral_refinement=refinement == "integral", batch_size=batch_size,
+                                               resize_input_layer=resize_input_layer, max_instances=max_instances)
+    finally:
+        _engine.DEFAULT_DTYPE = prev
     predictor.verbosity = progress_reporting if progress_reporting in ("json", "none") else "none"
     predictor.tracker = tracker_obj
     return predictor

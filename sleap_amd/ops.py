@@ -195,27 +195,37 @@ def pad16(c):
     return (c + 15) // 16 * 16
 
 
-def to_bf16_padded(x_f32):
-    """(B,H,W,C) f32 CUDA -> (B,H,W,pad16(C)) bf16 CUDA (zero padded)."""
+# 16-bit storage type of the network kernels <-> the torch dtype of the buffers that hold it (sleap_amd/_lib.py: lib(dtype))
+TORCH_DTYPE = {"bf16": torch.bfloat16, "fp16": torch.float16}
+
+
+def _dtype_of(t) -> str:
+    return "fp16" if t.dtype == torch.float16 else "bf16"
+
+
+def to_bf16_padded(x_f32, dtype: str = None):
+    """(B,H,W,C) f32 CUDA -> (B,H,W,pad16(C)) 16-bit CUDA tensor of the storage type `dtype` ("bf16" / "fp16"; None: the
+    default, _lib.DEFAULT_DTYPE), zero padded. (The entry points keep their `_bf16` names in both library builds.)"""
+    dtype = dtype or _lib.DEFAULT_DTYPE
     B, H, W, Cc = x_f32.shape
-    out = torch.empty((B, H, W, pad16(Cc)), dtype=torch.bfloat16, device=x_f32.device)
-    check(_lib.lib().sa_f32_to_bf16_padded(_ptr(x_f32), B * H * W, Cc, pad16(Cc), _ptr(out), _stream()), "sa_f32_to_bf16_padded")
+    out = torch.empty((B, H, W, pad16(Cc)), dtype=TORCH_DTYPE[dtype], device=x_f32.device)
+    check(_lib.lib(dtype).sa_f32_to_bf16_padded(_ptr(x_f32), B * H * W, Cc, pad16(Cc), _ptr(out), _stream()), "sa_f32_to_bf16_padded")
     return out
 
 
 def from_bf16(x_bf16, c):
     B, H, W, CP = x_bf16.shape
     out = torch.empty((B, H, W, c), dtype=torch.float32, device=x_bf16.device)
-    check(_lib.lib().sa_bf16_to_f32(_ptr(x_bf16), B * H * W, CP, c, _ptr(out), _stream()), "sa_bf16_to_f32")
+    check(_lib.lib(_dtype_of(x_bf16)).sa_bf16_to_f32(_ptr(x_bf16), B * H * W, CP, c, _ptr(out), _stream()), "sa_bf16_to_f32")
     return out
 
 
-def pack_conv3x3_weights(kernel, c0, c1=0):
-    """Keras (3,3,c0+c1,cout) f32 numpy -> packed bf16 (as int16 CUDA tensor)."""
+def pack_conv3x3_weights(kernel, c0, c1=0, dtype: str = None):
+    """Keras (3,3,c0+c1,cout) f32 numpy -> packed 16-bit MFMA fragments (as int16 CUDA tensor) for the `dtype` library."""
     kernel = np.ascontiguousarray(kernel, dtype=np.float32)
     cout = kernel.shape[3]
     c0p, c1p, coutp = pad16(c0), (pad16(c1) if c1 else 0), pad16(cout)
-    h = _lib.lib()
+    h = _lib.lib(dtype)
     n = h.sa_conv3x3_packed_elems(c0p, c1p, coutp)
     packed = np.zeros((n,), np.uint16)
     check(h.sa_pack_conv3x3_weights(kernel.ctypes.data_as(C.c_void_p), c0, c0p, c1, c1p, cout, coutp,
@@ -226,9 +236,9 @@ def pack_conv3x3_weights(kernel, c0, c1=0):
 def conv3x3(src0, src1, mode, packed_w, bias_padded, coutp, relu, out_hw, full=True, pooled=False):
     B = src0.shape[0]
     H, W = out_hw
-    out = torch.empty((B, H, W, coutp), dtype=torch.bfloat16, device=src0.device) if full else None
-    outp = torch.empty((B, H // 2, W // 2, coutp), dtype=torch.bfloat16, device=src0.device) if pooled else None
-    check(_lib.lib().sa_conv3x3_bf16(_ptr(src0), src0.shape[3], _ptr(src1), src1.shape[3] if src1 is not None else 0,
+    out = torch.empty((B, H, W, coutp), dtype=src0.dtype, device=src0.device) if full else None
+    outp = torch.empty((B, H // 2, W // 2, coutp), dtype=src0.dtype, device=src0.device) if pooled else None
+    check(_lib.lib(_dtype_of(src0)).sa_conv3x3_bf16(_ptr(src0), src0.shape[3], _ptr(src1), src1.shape[3] if src1 is not None else 0,
                                      mode, _ptr(packed_w), _ptr(bias_padded), coutp, int(relu), B, H, W, _ptr(out),
                                      _ptr(outp), _stream()), "sa_conv3x3_bf16")
     if full and pooled:

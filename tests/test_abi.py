@@ -13,10 +13,15 @@ def _declared():
     return sorted(set(re.findall(r"\b(sa_[a-z0-9_]+)\s*\(", src)))
 
 
-def test_all_declared_symbols_exported_and_bound():
+import pytest
+
+
+@pytest.mark.parametrize("dtype", _lib.DTYPES)
+def test_all_declared_symbols_exported_and_bound(dtype):
+    """Both builds of the library (bf16 and fp16 storage, csrc/bf16.h) export the same ABI."""
     names = _declared()
     assert len(names) >= 15
-    h = _lib.lib()
+    h = _lib.lib(dtype)
     for n in names:
         assert hasattr(h, n), f"{n} declared in sleap_amd.h but not exported"
         assert n in _lib.SIGNATURES, f"{n} has no ctypes signature"

@@ -11,9 +11,15 @@ import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
 
+# the suite follows the storage type of the library build under test (SLEAP_AMD_DTYPE, default fp16); the tolerances below were
+# written for bf16 (8 mantissa bits) and hold a fortiori for fp16 (11)
+from sleap_amd import _lib as _L  # noqa: E402
+
+TD = {"bf16": torch.bfloat16, "fp16": torch.float16}[_L.DEFAULT_DTYPE]
+
 
 def _bf(x):
-    return x.to(torch.bfloat16).to(torch.float32)
+    return x.to(TD).to(torch.float32)
 
 
 def _padded(v, n, fill=0.0):
@@ -75,8 +81,8 @@ def test_conv3x3_extended_epilogue(B, H, W, C0, C1, Cout, affine, residual, relu
     bp = _padded(bias, coutp)
     ps = _padded(scale, coutp, 1.0) if affine else None
     pt = _padded(shift, coutp) if affine else None
-    out = torch.empty((B, H, W, coutp), dtype=torch.bfloat16, device="cuda")
-    outp = torch.empty((B, H // 2, W // 2, coutp), dtype=torch.bfloat16, device="cuda") if pooled else None
+    out = torch.empty((B, H, W, coutp), dtype=TD, device="cuda")
+    outp = torch.empty((B, H // 2, W // 2, coutp), dtype=TD, device="cuda") if pooled else None
     check(_lib.lib().sa_conv3x3_ex_bf16(_ptr(d0), d0.shape[3], _ptr(d1), d1.shape[3] if d1 is not None else 0,
                                         _lib.SRC1_DIRECT if d1 is not None else _lib.SRC1_NONE, _ptr(pw), _ptr(bp), coutp,
                                         int(relu), B, H, W, _ptr(out), _ptr(outp), _ptr(ps), _ptr(pt), _ptr(dres),
@@ -128,7 +134,7 @@ def test_image_conv_vs_torch(dtype, B, H, W, Cin, Cout, k, stride, relu, affine)
     dimg, dw, db = img.cuda().contiguous(), w.cuda().contiguous(), _padded(bias, coutp)
     ps = _padded(scale, coutp, 1.0) if affine else None
     pt = _padded(shift, coutp) if affine else None
-    out = torch.empty((B, Ho, Wo, coutp), dtype=torch.bfloat16, device="cuda")
+    out = torch.empty((B, Ho, Wo, coutp), dtype=TD, device="cuda")
     check(_lib.lib().sa_image_conv_bf16(_ptr(dimg), 1 if dtype == "u8" else 0, B, H, W, Cin, Cin, None, k, k, stride, ph // 2,
                                         pw_ // 2,
                                         Ho, Wo, _ptr(dw), _ptr(db), coutp, int(relu), _ptr(ps), _ptr(pt), _ptr(out),
@@ -274,7 +280,7 @@ def test_conv1x1_vs_torch(B, H, W, Cin, Cout, stride, affine, residual, relu, re
     bp = _padded(bias, coutp)
     ps = _padded(scale, coutp, 1.0) if affine else None
     pt = _padded(shift, coutp) if affine else None
-    out = torch.full((B, Ho, Wo, coutp), 7.0, dtype=torch.bfloat16, device="cuda")
+    out = torch.full((B, Ho, Wo, coutp), 7.0, dtype=TD, device="cuda")
     check(_lib.lib().sa_conv1x1_bf16(_ptr(dx), cinp, _ptr(pw), _ptr(bp), coutp, int(relu), B, H, W, stride, _ptr(ps), _ptr(pt),
                                      _ptr(dres), int(relu_last), _ptr(out), _stream()), "sa_conv1x1_bf16")
     got = ops.from_bf16(out, Cout).cpu()
@@ -324,7 +330,7 @@ def test_convt_s2_vs_torch(B, H, W, Cin, Cout, ksize, affine):
     bp = _padded(bias, coutp)
     ps = _padded(scale, coutp, 1.0) if affine else None
     pt = _padded(shift, coutp) if affine else None
-    out = torch.empty((B, 2 * H, 2 * W, coutp), dtype=torch.bfloat16, device="cuda")
+    out = torch.empty((B, 2 * H, 2 * W, coutp), dtype=TD, device="cuda")
     # BN sits between the transposed conv and the ReLU (upsampling.py:186-188): relu = 0, affine, relu_last = 1
     check(h.sa_convt_s2_bf16(_ptr(dx), cinp, arr, ksize, _ptr(bp), coutp, 0, B, H, W, _ptr(ps), _ptr(pt), 1, _ptr(out),
                              _stream()), "sa_convt_s2_bf16")
@@ -343,7 +349,7 @@ def test_maxpool_general_vs_torch(k, stride, pad, pad_zero, H, W):
     x = torch.randn((2, H, W, 32), generator=g) - (1.0 if pad_zero else 0.0)
     dx = ops.to_bf16_padded(x.cuda())
     Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
-    out = torch.empty((2, Ho, Wo, 32), dtype=torch.bfloat16, device="cuda")
+    out = torch.empty((2, Ho, Wo, 32), dtype=TD, device="cuda")
     check(_lib.lib().sa_maxpool_bf16(_ptr(dx), 2, H, W, 32, k, stride, pad, pad, pad_zero, Ho, Wo, _ptr(out), _stream()),
           "sa_maxpool_bf16")
     xp = F.pad(_bf(x).permute(0, 3, 1, 2), (pad, pad, pad, pad), value=0.0 if pad_zero else float("-inf"))
@@ -451,7 +457,7 @@ def test_imgconv_mfma_vs_torch(B, H, W, Cin, CinW, Cout, stride, mean, relu, aff
     db = torch.from_numpy(bias_io).cuda()
     ps = _padded(scale, coutp, 1.0) if affine else None
     psh = _padded(shift, coutp) if affine else None
-    out = torch.full((B, Ho, Wo, coutp), 7.0, dtype=torch.bfloat16, device="cuda")
+    out = torch.full((B, Ho, Wo, coutp), 7.0, dtype=TD, device="cuda")
     dimg = img.cuda().contiguous()
     check(h.sa_imgconv_u8_bf16(_ptr(dimg), B, H, W, Cin, CinW, 7, stride, pt, pl, Ho, Wo, _ptr(dw), _ptr(db), coutp, int(relu),
                                int(mean), _ptr(ps), _ptr(psh), _ptr(out), _stream()), "sa_imgconv_u8_bf16")

@@ -1,0 +1,168 @@
+"""The fp16-storage build of the network kernels (libsleap_amd_fp16.so, csrc/bf16.h with SA_HALF_FP16): same kernels, IEEE half
+instead of bfloat16 for activations and conv weights. Layer tests against plain torch fp32 on fp16-rounded operands; whole
+networks against the fp32 CPU oracle (tolerances 8x tighter than the bf16 ones: 11 vs 8 mantissa bits); and the reason the
+variant exists: END-TO-END agreement with the fp32 oracle (network + post-processing) on the trained fixture model."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+MODELS = os.path.join(os.path.dirname(__file__), "golden", "models")
+
+
+def _h(x):
+    return x.to(torch.float16).to(torch.float32)
+
+
+@pytest.mark.parametrize("B,H,W,C0,C1,Cout,mode", [(2, 16, 32, 16, 0, 16, 0), (1, 37, 45, 32, 0, 64, 0), (1, 24, 40, 36, 54, 36, 1),
+                                                    (2, 32, 32, 64, 0, 128, 0), (1, 16, 16, 256, 0, 96, 0)])
+def test_conv3x3_fp16_vs_torch(B, H, W, C0, C1, Cout, mode):
+    from sleap_amd import ops
+
+    g = torch.Generator(device="cpu").manual_seed(B * 1000 + H * 10 + C0 + C1 + Cout + mode)
+    k = torch.randn((3, 3, C0 + C1, Cout), generator=g) * (2.0 / (9 * (C0 + C1))) ** 0.5
+    bias = torch.randn((Cout,), generator=g) * 0.1
+    x0 = torch.randn((B, H, W, C0), generator=g)
+    x1 = torch.randn((B, H, W, C1), generator=g) if mode == 1 else None
+    rin = _h(x0) if x1 is None else torch.cat([_h(x0), _h(x1)], dim=-1)
+    ref = torch.relu(F.conv2d(rin.permute(0, 3, 1, 2), _h(k).permute(3, 2, 0, 1), bias, padding=1)).permute(0, 2, 3, 1)
+    d0 = ops.to_bf16_padded(x0.cuda().contiguous(), dtype="fp16")
+    d1 = ops.to_bf16_padded(x1.cuda().contiguous(), dtype="fp16") if x1 is not None else None
+    assert d0.dtype == torch.float16
+    pw = ops.pack_conv3x3_weights(k.numpy(), C0, C1, dtype="fp16")
+    coutp = ops.pad16(Cout)
+    bp = torch.zeros((coutp,), dtype=torch.float32)
+    bp[:Cout] = bias
+    pooled = H % 2 == 0 and W % 2 == 0
+    out = ops.conv3x3(d0, d1, mode, pw, bp.cuda(), coutp, True, (H, W), full=True, pooled=pooled)
+    if pooled:
+        out, outp = out
+        assert torch.equal(outp.float(), F.max_pool2d(out.float().permute(0, 3, 1, 2), 2).permute(0, 2, 3, 1))
+    got = ops.from_bf16(out, Cout).cpu()
+    # identical fp16 operands, fp32 accumulation on both sides: only summation order and the final fp16 rounding (2^-11) differ
+    assert float((got - ref).abs().max()) <= 2e-3 * float(ref.abs().max())
+
+
+def _benchmark_unet(h, w):
+    from sleap_amd.nn.architectures import build_unet_model_config, he_normal_weights
+
+    cfg, shapes = build_unet_model_config((h, w, 1), 16, 2, 32, 4, True, True,
+                                          heads=[("MultiInstanceConfmapsHead", 13, 4), ("PartAffinityFieldsHead", 24, 8)])
+    return cfg, he_normal_weights(shapes, seed=1)
+
+
+def _rel(outs, ref):
+    return max(float(np.abs(o - r).max() / np.abs(r).max()) for o, r in zip(outs, ref))
+
+
+def test_unet_fp16_vs_oracles_and_vs_bf16():
+    """Benchmark UNet (all fusions on: stem16, 16->32->32 block, MFMA heads): heads within 4e-3 of the fp32 oracle (the bf16
+    build: 3e-2) and within 2e-3 of the oracle that rounds to fp16 at the engine's storage points."""
+    from oracle.keras_graph import KerasGraph, ensure_float
+    from sleap_amd.nn.engine import DeviceNetwork
+    from sleap_amd.synth import render_frames
+
+    cfg, w = _benchmark_unet(128, 160)
+    x = render_frames(2, 128, 160, n_animals=2, seed=3)[0]
+    net = DeviceNetwork(cfg, w, dtype="fp16")
+    assert net.dtype == "fp16" and {"stem2", "pair"} <= {op[0] for op in net.plan}
+    outs = [o.cpu().numpy() for o in net.forward(torch.from_numpy(x).cuda())]
+    xin = ensure_float(x)
+    e32 = _rel(outs, KerasGraph(cfg, w)(xin))
+    e16 = _rel(outs, KerasGraph(cfg, w, emulate_bf16=True, emulate_dtype=torch.float16)(xin))
+    ebf = _rel([o.cpu().numpy() for o in DeviceNetwork(cfg, w, dtype="bf16").forward(torch.from_numpy(x).cuda())], KerasGraph(cfg, w)(xin))
+    assert e32 <= 4e-3 and e16 <= 2e-3, (e32, e16)
+    assert e32 < ebf / 4, (e32, ebf)  # the point of the variant
+    other = [o.cpu().numpy() for o in DeviceNetwork(cfg, w, dtype="fp16", fuse_pairs=False, fuse_stem=False, fuse_heads=False)
+             .forward(torch.from_numpy(x).cuda())]
+    assert _rel(outs, other) <= 2e-3  # fused and un-fused plans agree to fp16 rounding
+
+
+def test_hourglass_and_resnet_fp16_vs_oracle():
+    """The other backbones through the fp16 build: k7 stem on the matrix cores, BN / residual epilogues, tap GEMMs,
+    transposed convs."""
+    from oracle.keras_graph import KerasGraph, ensure_float
+    from sleap_amd.nn.architectures import build_hourglass_model_config, build_resnet_model_config, he_normal_weights
+    from sleap_amd.nn.engine import DeviceNetwork
+
+    rng = np.random.default_rng(0)
+    cfg, sh = build_hourglass_model_config((128, 160, 1), 4, 32, 4, 16, 32, 16, stacks=1,
+                                           heads=[("MultiInstanceConfmapsHead", 13, 4), ("PartAffinityFieldsHead", 24, 4)])
+    w = he_normal_weights(sh, 1)
+    x = rng.integers(0, 256, (2, 128, 160, 1), dtype=np.uint8)
+    outs = [o.cpu().numpy() for o in DeviceNetwork(cfg, w, dtype="fp16").forward(torch.from_numpy(x).cuda())]
+    assert _rel(outs, KerasGraph(cfg, w)(ensure_float(x))) <= 5e-3
+    # ResNet-50 without the ImageNet Lambdas (inputs in [0, 1]); BN statistics are random but bounded, activations stay
+    # far below fp16's 65504 at this depth for this seed -- the assertion below would catch an overflow (inf / nan)
+    cfg, sh = build_resnet_model_config((96, 96, 1), "ResNet50", 32, pretrained=False,
+                                        upsampling=dict(output_stride=4, method="transposed_conv", skip_connections="concatenate"),
+                                        heads=[("MultiInstanceConfmapsHead", 5, 4)])
+    w = he_normal_weights(sh, 3)
+    x = rng.integers(0, 256, (1, 96, 96, 1), dtype=np.uint8)
+    outs = [o.cpu().numpy() for o in DeviceNetwork(cfg, w, dtype="fp16").forward(torch.from_numpy(x).cuda())]
+    ref = KerasGraph(cfg, w)(ensure_float(x))
+    assert np.isfinite(outs[0]).all() and _rel(outs, ref) <= 1e-2
+
+
+def _fixture_agreement(dtype, thresholds=(0.5, 0.8)):
+    """-> {thr: (frames agreeing in instance count AND node assignment, peaks compared, peaks within 0.5 px)}"""
+    from oracle import paf_grouping as opg
+    from oracle import peak_finding as opf
+    from oracle.keras_graph import KerasGraph, load_npz_model, preprocess
+    from sleap_amd.nn.inference import load_model
+    from sleap_amd.synth import render_frames
+
+    model = os.path.join(MODELS, "minimal_instance.UNet.bottomup")
+    frames = render_frames(6, 384, 384, n_animals=2, seed=11)[0]
+    cfg, w = load_npz_model(os.path.join(model, "best_model.npz"))
+    cms, pafs, offs = KerasGraph(cfg, w)(preprocess(frames))
+    p = load_model(model, batch_size=6, progress_reporting="none", dtype=dtype)
+    layer = p.inference_model.bottomup_layer
+    assert layer.keras_model.dtype == dtype
+    sc = opg.PAFScorer(["A", "B"], [("A", "B")], 4, oob="zero")
+    res = {}
+    for thr in thresholds:
+        layer.peak_threshold = thr
+        outs = p.predict(frames, make_labels=False)[0]
+        pts, vals, si, ci = opf.find_local_peaks_with_offsets(cms, offs, thr)
+        pts = pts * np.float32(2)
+        o = sc.predict(pafs, [pts[si == b] for b in range(6)], [vals[si == b] for b in range(6)], [ci[si == b] for b in range(6)])
+        ok = n_peaks = n_close = 0
+        for b in range(6):
+            n = int(outs["n_valid"][b])
+            want = np.asarray(o[0][b]).reshape(-1, 2, 2)
+            got = outs["instance_peaks"][b, :n]
+            if n != len(want) or not np.array_equal(np.isnan(got), np.isnan(want)):
+                continue
+            ok += 1
+            d = np.linalg.norm(got - want, axis=-1)
+            d = d[np.isfinite(d)]
+            n_peaks += d.size
+            n_close += int((d <= 0.5).sum())
+        res[thr] = (ok, n_peaks, n_close)
+    return res
+
+
+def test_fixture_end_to_end_agreement_with_fp32_oracle():
+    """north_star: "peak coordinates within +-0.5 px and identical instance assignments" against the fp32 path.
+    Trained fixture model, fp32 CPU oracle network + restated post-processing vs the device path on 6 synthetic frames, at
+    thresholds where the maps carry ~80 (0.5) and ~17 (0.8) peaks per frame.
+
+    What can be asserted: this fixture's decisions are conditioned such that white noise of 3e-4 of the maps' range already
+    moves 1 of 54 grouped peaks in the ORACLE ITSELF (tests/diagnostics/precision_probe.py `conditioning`,
+    profiles/r01_precision_probe.md), so no 16-bit storage can promise 100 %. fp16 storage (~1e-3 of range): every frame has
+    the oracle's instance count and node assignment and >= 95 % of the grouped peaks are within 0.5 px (measured: 53/54 and
+    22/22). bf16 storage (~1-4e-2) does clearly worse on the same comparison, which is why fp16 is the default."""
+    f16, b16 = _fixture_agreement("fp16"), _fixture_agreement("bf16")
+    for thr, (ok, n, close) in f16.items():
+        assert ok == 6, (thr, f16)
+        assert n >= 15 and close >= 0.95 * n, (thr, f16)
+    def score(r):
+        return sum(ok for ok, _, _ in r.values()), sum(c for _, _, c in r.values())
+
+    assert score(f16) > score(b16), (f16, b16)
+    print("fixture agreement fp16", f16, "bf16", b16)

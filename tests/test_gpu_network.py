@@ -14,11 +14,17 @@ import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
 
+# the suite follows the storage type of the library build under test (SLEAP_AMD_DTYPE, default fp16); the tolerances below were
+# written for bf16 (8 mantissa bits) and hold a fortiori for fp16 (11)
+from sleap_amd import _lib as _L  # noqa: E402
+
+TD = {"bf16": torch.bfloat16, "fp16": torch.float16}[_L.DEFAULT_DTYPE]
+
 MODELS = os.path.join(os.path.dirname(__file__), "golden", "models")
 
 
 def _bf(x):
-    return x.to(torch.bfloat16).to(torch.float32)
+    return x.to(TD).to(torch.float32)
 
 
 def _ref_conv(x_nhwc, k_keras, bias, relu):
@@ -131,7 +137,7 @@ def test_small_layers_vs_torch():
     k = torch.randn((3, 3, 1, 16), generator=g)
     b = torch.randn((16,), generator=g)
     d_img, d_k, d_b = img.cuda(), k.cuda().contiguous(), b.cuda()
-    out = torch.empty((2, 20, 36, 16), dtype=torch.bfloat16, device="cuda")
+    out = torch.empty((2, 20, 36, 16), dtype=TD, device="cuda")
     check(h.sa_stem_conv3x3(_ptr(d_img), 1, 2, 20, 36, 1, _ptr(d_k), _ptr(d_b), 16, 1, _ptr(out), _stream()), "stem")
     _close(out.float().cpu(), _ref_conv(img.float() * np.float32(1 / 255), k, b, True), 1e-2)
     # stem f32 rgb
@@ -139,18 +145,18 @@ def test_small_layers_vs_torch():
     k3 = torch.randn((3, 3, 3, 8), generator=g)
     b3 = torch.randn((8,), generator=g)
     d_img, d_k, d_b = imgf.cuda(), k3.cuda().contiguous(), b3.cuda()
-    out = torch.empty((1, 12, 12, 8), dtype=torch.bfloat16, device="cuda")
+    out = torch.empty((1, 12, 12, 8), dtype=TD, device="cuda")
     check(h.sa_stem_conv3x3(_ptr(d_img), 0, 1, 12, 12, 3, _ptr(d_k), _ptr(d_b), 8, 0, _ptr(out), _stream()), "stem")
     _close(out.float().cpu(), _ref_conv(imgf, k3, b3, False), 1e-2)
     # pool / upsample
     x = torch.randn((2, 12, 20, 32), generator=g)
     xd = ops.to_bf16_padded(x.cuda())
-    o = torch.empty((2, 6, 10, 32), dtype=torch.bfloat16, device="cuda")
+    o = torch.empty((2, 6, 10, 32), dtype=TD, device="cuda")
     check(h.sa_maxpool2x2_bf16(_ptr(xd), 2, 12, 20, 32, _ptr(o), _stream()), "pool")
     ref = F.max_pool2d(_bf(x).permute(0, 3, 1, 2), 2).permute(0, 2, 3, 1)
     assert torch.equal(o.float().cpu(), ref)
     for bil, modeN in ((1, "bilinear"), (0, "nearest")):
-        o = torch.empty((2, 24, 40, 32), dtype=torch.bfloat16, device="cuda")
+        o = torch.empty((2, 24, 40, 32), dtype=TD, device="cuda")
         check(h.sa_upsample2x_bf16(_ptr(xd), 2, 12, 20, 32, bil, _ptr(o), _stream()), "up")
         kw = dict(align_corners=False) if bil else {}
         ref = F.interpolate(_bf(x).permute(0, 3, 1, 2), scale_factor=2.0, mode=modeN, **kw).permute(0, 2, 3, 1)
@@ -165,8 +171,8 @@ def test_small_layers_vs_torch():
     # transposed conv k3 s2 same == full transposed conv cropped at the end
     kt = torch.randn((3, 3, 16, 32), generator=g) * 0.1  # (kh, kw, Cout, Cin)
     bt = torch.randn((16,), generator=g)
-    d_w, d_b = kt.cuda().to(torch.bfloat16).contiguous(), bt.cuda()
-    o = torch.empty((2, 24, 40, 16), dtype=torch.bfloat16, device="cuda")
+    d_w, d_b = kt.cuda().to(TD).contiguous(), bt.cuda()
+    o = torch.empty((2, 24, 40, 16), dtype=TD, device="cuda")
     check(h.sa_convt3x3s2_bf16(_ptr(xd), 32, _ptr(d_w), _ptr(d_b), 16, 1, 2, 12, 20, _ptr(o), _stream()), "convt")
     ref = F.conv_transpose2d(_bf(x).permute(0, 3, 1, 2), _bf(kt).permute(3, 2, 0, 1), None, stride=2)[:, :, :24, :40]
     ref = torch.relu(ref + bt.view(1, -1, 1, 1)).permute(0, 2, 3, 1)
@@ -319,8 +325,8 @@ def test_conv_pair_is_bitwise_two_convs(B, H, W, full, pooled):
     mid = ops.conv3x3(x, None, 0, wa, ba, 32, True, (H, W))
     ref = ops.conv3x3(mid, None, 0, wb, bb, 32, True, (H, W), full=full, pooled=pooled)
     ref = ref if isinstance(ref, tuple) else ((ref, None) if full else (None, ref))
-    out = torch.full((B, H, W, 32), 7.0, dtype=torch.bfloat16, device="cuda") if full else None
-    outp = torch.full((B, H // 2, W // 2, 32), 7.0, dtype=torch.bfloat16, device="cuda") if pooled else None
+    out = torch.full((B, H, W, 32), 7.0, dtype=TD, device="cuda") if full else None
+    outp = torch.full((B, H // 2, W // 2, 32), 7.0, dtype=TD, device="cuda") if pooled else None
     check(_lib.lib().sa_conv3x3_pair_bf16(_ptr(x), 16, _ptr(wa), _ptr(ba), 1, 32, _ptr(wb), _ptr(bb), 1, 32, B, H, W, _ptr(out),
                                           _ptr(outp), _stream()), "sa_conv3x3_pair_bf16")
     if full:

@@ -136,6 +136,23 @@ def test_peak_overflow_is_flagged(pf):
         pf.find_local_peaks(cms, 0.2, None, max_peaks=16)
 
 
+@pytest.mark.parametrize("C", [4, 3])  # float4 scan and scalar scan
+@pytest.mark.parametrize("bad", [float("inf"), float("-inf"), float("nan")])
+def test_nonfinite_confidence_maps_are_flagged(C, bad):
+    """SA_STATUS_NONFINITE: an fp16-storage network that overflowed hands inf / NaN maps to peak finding; the frame is
+    flagged (BottomUpInferenceModel.call_checked raises) instead of silently producing fewer peaks."""
+    import torch
+
+    from sleap_amd import _lib, ops
+
+    cms = torch.rand((3, 17, 19, C), generator=torch.Generator().manual_seed(1)).mul(0.1).cuda()
+    st = ops.find_local_peaks(cms, None, 0.2, None, 5, 1.0, 64)[4].cpu().numpy()
+    assert (st & _lib.STATUS_NONFINITE == 0).all()
+    cms[1, 16, 18, C - 1] = bad
+    st = ops.find_local_peaks(cms, None, 0.2, None, 5, 1.0, 64)[4].cpu().numpy()
+    assert [int(v) & _lib.STATUS_NONFINITE for v in st] == [0, _lib.STATUS_NONFINITE, 0]
+
+
 @pytest.mark.parametrize("refinement", [None, "integral", "local"])
 def test_global_peaks_vs_oracle(pf, refinement):
     rng = np.random.default_rng(4)
