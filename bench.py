@@ -15,7 +15,7 @@ results (all-gathered over ranks when N > 1), on frames already resident in HBM.
 
 Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
   roofline      conv3x3 MFMA kernel family: algorithmic TFLOP/s (2*H*W*Cin*Cout*9 over its launches) over
-                its HIP-event-measured time inside this process, vs the 2.5 PFLOP/s dense bf16 MFMA peak
+                its HIP-event-measured time inside this process, vs the 2.5 PFLOP/s dense fp16 / bf16 MFMA peak
   cpu_baseline  the CPU oracle (torch-CPU fp32 convs + NumPy/SciPy post-processing; "port") timed on the
                 host cores over a bounded sample of the same workload (N=1 only)
 """
@@ -31,10 +31,10 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-PEAK_BF16_TFLOPS = 2500.0  # dense, /opt/skills/guides/MI355X_MICROARCH.md
+PEAK_BF16_TFLOPS = 2500.0  # dense, fp16 and bf16 alike (/opt/skills/guides/MI355X_MICROARCH.md)
 # HBM bytes of the conv kernel family per step of the DEFAULT workload (64 frames of 1024x1024), from two separate
-# rocprofv3 --pmc passes (FETCH_SIZE doubled per the gfx950 correction, WRITE_SIZE): profiles/r01_v6_pmc_hbm_traffic.md
-MEASURED_CONV_TRAFFIC_BYTES_PER_STEP = 12.72e9
+# rocprofv3 --pmc passes (FETCH_SIZE doubled per the gfx950 correction, WRITE_SIZE): profiles/r01_v7_pmc_hbm_traffic.md
+MEASURED_CONV_TRAFFIC_BYTES_PER_STEP = 12.67e9
 
 
 def parse():
@@ -47,8 +47,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=20.0)
     ap.add_argument("--layers", action="store_true", help="also print the per-layer table to stderr")
-    ap.add_argument("--dtype", choices=("bf16", "fp16"), default="bf16",
-                    help="16-bit storage type of activations / conv weights (one library build each; accumulation is fp32)")
+    ap.add_argument("--dtype", choices=("bf16", "fp16"), default=None,
+                    help="16-bit storage type of activations / conv weights (one library build each; accumulation is fp32). "
+                         "Default: the package default (fp16, SLEAP_AMD_DTYPE)")
     return ap.parse_args()
 
 
@@ -86,7 +87,7 @@ def cpu_baseline(mc, weights, scorer_args, frames_u8, budget_s, device_result=No
            "sample": f"{n} frame(s) of the same 1024x1024 workload, one batch, after a 1-frame warm-up; "
                      f"torch-CPU fp32 convs ({cores} threads) + NumPy/SciPy post-processing"}
     if device_result is not None:
-        # fp32 CPU network + reference post-processing vs bf16 device path on the same frames, positionally
+        # fp32 CPU network + reference post-processing vs the 16-bit-storage device path on the same frames, positionally
         max_d, bad_count, bad_mask, n_inst, n_pk, n_close = 0.0, 0, 0, 0, 0, 0
         for f in range(n):
             want = np.asarray(ref[0][f], dtype=np.float32).reshape(-1, len(scorer_args["nodes"]), 2)
@@ -106,7 +107,8 @@ def cpu_baseline(mc, weights, scorer_args, frames_u8, budget_s, device_result=No
                     n_pk += int(np.isfinite(d).sum())
                     n_close += int((d[np.isfinite(d)] <= 0.5).sum())
         # NB random-init heads: the confidence maps are noise-like with many local maxima near the 0.2 threshold, and the
-        # bf16-vs-fp32 network difference (~2 % of range) moves a few across it, so the two peak sets differ before grouping
+        # 16-bit-storage-vs-fp32 network difference (bf16 ~2 % of range, fp16 ~0.2 %) can move one across it, so the two peak sets
+        # may differ before grouping
         # (measured: tests/diagnostics/parity_probe.py). Trained-model agreement: tests/test_gpu_inference.py
         out["parity_vs_oracle"] = {"frames": n, "instances": n_inst, "peaks": n_pk, "peaks_within_0.5px": n_close,
                                    "max_peak_delta_px": round(max_d, 4),
@@ -134,6 +136,8 @@ def main():
     from sleap_amd.benchmark_model import build_benchmark_predictor
     from sleap_amd.synth import FLIES13_EDGES, FLIES13_NODES, render_frames
 
+    from sleap_amd import _lib
+    args.dtype = args.dtype or _lib.DEFAULT_DTYPE
     H = W = args.size
     B = args.batch
     pred, mc, weights = build_benchmark_predictor(H, W, batch_size=B, seed=0, dtype=args.dtype)
@@ -214,7 +218,7 @@ def main():
             "kernel": f"conv3x3_dma_kernel + convpair + stem16_gray_kernel (the {n_conv} MFMA conv launches of one step)", "bound": "mfma", "achieved": round(achieved, 2),
             "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
             "traffic": (MEASURED_CONV_TRAFFIC_BYTES_PER_STEP if (B == 64 and H == 1024 and W == 1024) else None),
-            "traffic_unit": "HBM bytes per step over the kernel family's launches (rocprofv3 PMC, profiles/r01_v6_pmc_hbm_traffic.md)",
+            "traffic_unit": "HBM bytes per step over the kernel family's launches (rocprofv3 PMC, profiles/r01_v7_pmc_hbm_traffic.md)",
             "launches_per_step": n_conv, "avg_launch_ms": round(conv_ms / n_conv, 4),
             "algorithmic_gflop_per_frame": round(conv_fl / B / 1e9, 2),
             "network_ms_per_step": round(all_ms, 3), "postproc_ms_per_step": round(post_ms, 3),

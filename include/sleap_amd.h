@@ -13,8 +13,13 @@
  *   - all pointers except those marked HOST are DEVICE pointers owned by the caller; nothing is
  *     allocated behind the caller's back
  *   - `stream` is a `hipStream_t` passed as `void*`; all work is enqueued asynchronously
- *   - image-like tensors are NHWC; activations inside the network are bf16 with the channel count
+ *   - image-like tensors are NHWC; activations inside the network are 16-bit with the channel count
  *     padded to a multiple of 16 ("CP" below), network heads / maps are float32 with exact channels
+ *   - the 16-bit storage type of activations and packed conv weights is a BUILD property of the
+ *     library: libsleap_amd_fp16.so stores IEEE half (the default build the Python layer loads),
+ *     libsleap_amd.so stores bfloat16; `sa_storage_dtype()` names it. Both export this same ABI;
+ *     the entry points keep their historical `_bf16` suffix and "bf16" in the comments below
+ *     means "the build's storage type". Accumulation is float32 in both.
  */
 #ifndef SLEAP_AMD_H
 #define SLEAP_AMD_H
@@ -45,6 +50,8 @@ extern "C" {
 typedef void* sa_stream_t;
 
 int sa_abi_version(void);
+/* "fp16" or "bf16": the 16-bit storage type this build of the library was compiled for. */
+const char* sa_storage_dtype(void);
 const char* sa_last_error(void);
 /* HOST out-params. `arch` receives e.g. "gfx950". */
 int sa_device_info(int device, int* n_cu, int* lds_bytes, int* wave_size, char* arch, int arch_len);

@@ -28,6 +28,7 @@ _sz = C.c_size_t
 # name -> (restype, argtypes); must list every symbol of include/sleap_amd.h
 SIGNATURES = {
     "sa_abi_version": (_i, []),
+    "sa_storage_dtype": (C.c_char_p, []),
     "sa_last_error": (C.c_char_p, []),
     "sa_device_info": (_i, [_i, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), C.c_char_p, _i]),
     "sa_find_local_peaks_workspace": (_sz, [_i, _i]),

@@ -403,7 +403,7 @@ conv3x3_dma_kernel(const ConvParams2 p) {
         float v = 0.0f;
         if (gy >= 0 && gy < H && gx >= 0 && gx < W)
           v = (float)reinterpret_cast<const uint8_t*>(p.stem_src)[(((size_t)b * H + gy) * W + gx) * STEM_CIN + c];
-        rawh[i] = sa::f2h(v);
+        rawh[i] = sa::f2h(v * sa::U8_ACT_SCALE);
       }
       const int hf = lane >> 5, l32 = lane & 31;
       mfma_h8 wa[NK16][3];
@@ -414,7 +414,7 @@ conv3x3_dma_kernel(const ConvParams2 p) {
         for (int j = 0; j < 8; ++j) {
           const int k = ks * 16 + hf * 8 + j;
           float wv = 0.0f;
-          if (k < KT && l32 < CK) wv = p.stem_w[k * CK + l32] * (1.0f / 255.0f);
+          if (k < KT && l32 < CK) wv = p.stem_w[k * CK + l32] * (1.0f / 255.0f) * (1.0f / sa::U8_ACT_SCALE);
           const uint16_t h0 = sa::f2h(wv);
           const float r1 = wv - sa::h2f(h0);
           const uint16_t h1 = sa::f2h(r1);

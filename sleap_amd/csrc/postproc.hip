@@ -13,6 +13,7 @@
 #include <cstdint>
 #include <vector>
 
+#include "bf16.h"
 #include "lsa.h"
 #include "sa_common.h"
 
@@ -654,6 +655,8 @@ paf_group_kernel(const float* __restrict__ peak_xy, const float* __restrict__ pe
 extern "C" {
 
 int sa_abi_version(void) { return SA_ABI_VERSION; }
+
+const char* sa_storage_dtype(void) { return SA_HALF_NAME; }
 
 const char* sa_last_error(void) { return sa::err_buf(); }
 

@@ -56,7 +56,7 @@ def compare(ref, got, n_nodes):
 def run(name, cfg, w, frames, thr, scorer, stride, n_nodes, has_offsets):
     x = preprocess(frames)
     outs = {}
-    for mode, kw in (("fp32", {}), ("bf16", dict(emulate_bf16=True)), ("fp16", dict(emulate_bf16=True, emulate_dtype=torch.float16))):
+    for mode, kw in (("fp32", {}), ("bf16", dict(emulate_bf16=True, emulate_dtype=torch.bfloat16)), ("fp16", dict(emulate_bf16=True, emulate_dtype=torch.float16))):
         o = KerasGraph(cfg, w, **kw)(x)
         outs[mode] = (o[0], o[1], o[2] if has_offsets else None)
     print(f"== {name} (threshold {thr})")

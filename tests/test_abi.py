@@ -27,6 +27,7 @@ def test_all_declared_symbols_exported_and_bound(dtype):
         assert n in _lib.SIGNATURES, f"{n} has no ctypes signature"
     assert set(_lib.SIGNATURES) == set(names)
     assert h.sa_abi_version() == 1
+    assert h.sa_storage_dtype().decode() == dtype
 
 
 def test_argument_validation_without_gpu():
