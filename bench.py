@@ -47,6 +47,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=20.0)
     ap.add_argument("--layers", action="store_true", help="also print the per-layer table to stderr")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise the RCCL process group and run the gather / barrier / max-reduce path even with one rank "
+                         "(exercises the N > 1 code on a 1-GPU box)")
     ap.add_argument("--dtype", choices=("bf16", "fp16"), default=None,
                     help="16-bit storage type of activations / conv weights (one library build each; accumulation is fp32). "
                          "Default: the package default (fp16, SLEAP_AMD_DTYPE)")
@@ -127,8 +130,10 @@ def main():
     torch.cuda.set_device(local_rank)
     import torch.distributed as dist
 
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group(backend="nccl", rank=rank, world_size=world,
                                 device_id=torch.device("cuda", local_rank))
 
@@ -156,7 +161,7 @@ def main():
     def step():
         outs = pred.inference_model.call(frames)
         packed = parallel.pack_results(outs)
-        if world > 1:
+        if use_dist:
             dist.all_gather_into_tensor(gathered, packed)
             host_out.copy_(gathered, non_blocking=True)
         else:
@@ -165,7 +170,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -177,7 +182,7 @@ def main():
         step()
     fence()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
@@ -247,7 +252,7 @@ def main():
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 
