@@ -98,6 +98,9 @@ _libs = {}
 
 def lib_path(dtype: str = None) -> str:
     dtype = dtype or DEFAULT_DTYPE
+    override = os.environ.get(f"SLEAP_AMD_LIB_{dtype.upper()}")  # A/B experiments: a differently built library file
+    if override:
+        return override
     return LIB_PATH if dtype == "bf16" else os.path.join(HERE, "lib", f"libsleap_amd_{dtype}.so")
 
 

@@ -21,10 +21,13 @@ SOURCES = [
     ("layers.hip", []),
     # the MFMA kernels never see NaNs they must preserve: without this every fmaxf carries two canonicalising v_max
     ("conv3x3.hip", ["-fno-honor-nans"]),
-    ("stem16.hip", ["-fno-honor-nans"]),
+    # + VGPR-form MFMA: left to itself the compiler puts these kernels' accumulators in AGPRs and pays one v_accvgpr_read
+    # per accumulator register in the (VALU-bound) epilogues: stem16 0.840 -> 0.804 ms, imgconv 0.210 -> 0.137 ms (A/B on one
+    # box, tools/ab_lib.sh). The 8-wave conv3x3 kernels are VGPR-form already; forcing it on the others changed nothing.
+    ("stem16.hip", ["-fno-honor-nans", "-mllvm", "-amdgpu-mfma-vgpr-form"]),
     ("tapconv.hip", ["-fno-honor-nans"]),
     ("convpair.hip", ["-fno-honor-nans"]),
-    ("imgconv.hip", ["-fno-honor-nans", "-std=c++20"]),
+    ("imgconv.hip", ["-fno-honor-nans", "-std=c++20", "-mllvm", "-amdgpu-mfma-vgpr-form"]),
     ("tracker.hip", []),
 ]
 COMMON = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function"]
@@ -56,8 +59,7 @@ def _build_variant(dtype, force, verbose):
     objdir = LIBDIR if dtype == "bf16" else os.path.join(LIBDIR, dtype)
     os.makedirs(objdir, exist_ok=True)
     hipcc = _hipcc()
-    objs = []
-    rebuilt = False
+    objs, cmds = [], []
     dep_mtime = max(os.path.getmtime(h) for h in _deps())
     for src, extra in SOURCES:
         s = os.path.join(CSRC, src)
@@ -66,11 +68,18 @@ def _build_variant(dtype, force, verbose):
         o = os.path.join(objdir, src.replace(".hip", ".o"))
         objs.append(o)
         if force or not os.path.exists(o) or os.path.getmtime(o) < max(os.path.getmtime(s), dep_mtime):
-            cmd = [hipcc, "-c", s, "-o", o] + COMMON + extra + defines
+            cmds.append([hipcc, "-c", s, "-o", o] + COMMON + extra + defines)
+    rebuilt = bool(cmds)
+    if cmds:  # the translation units are independent: compile them concurrently (80 s -> ~25 s per variant)
+        from concurrent.futures import ThreadPoolExecutor
+
+        def run(cmd):
             if verbose:
                 print(" ".join(cmd), flush=True)
             subprocess.check_call(cmd)
-            rebuilt = True
+
+        with ThreadPoolExecutor(max_workers=min(len(cmds), os.cpu_count() or 1, 8)) as ex:
+            list(ex.map(run, cmds))
     if rebuilt or not os.path.exists(lib):
         cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", lib] + objs
         if verbose:

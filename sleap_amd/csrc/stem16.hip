@@ -223,9 +223,9 @@ stem16_gray_kernel(const Stem16Params p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int TH = SA_STEM16_TH, TW = SA_STEM16_TW, PH = TH + 2, PW = TW + 2, RH = TH + 4;
   constexpr int RS = 48;  // triplet-table row stride in entries: 96 dwords = 32 (mod 64) banks between kernel rows
-  __shared__ __attribute__((aligned(16))) uint2 rawt[(RH + 1) * RS];
+  __shared__ __attribute__((aligned(16))) uint2 rawt[(RH + 1) * RS];  // row RH: entry 0 is the zero operand
   __shared__ __attribute__((aligned(16))) unsigned char act[(PH * PW + 16) * 32];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int n16 = lane & 15, kb = lane >> 4;
   int bid = blockIdx.x;
   const int tx_i = bid % p.tiles_x;
@@ -237,6 +237,7 @@ stem16_gray_kernel(const Stem16Params p) {
 
   // ---- triplet table: thread (row, dq) loads the two aligned dwords covering image columns x0-4+4dq .. +7 and emits
   // the entries of raw columns tx = 4dq-2 .. 4dq+1 (raw column tx <-> image column x0 - 2 + tx; zero outside the image)
+  if (tid == 255) rawt[RH * RS] = make_uint2(0u, 0u);
   if (tid < RH * 9) {
     const int ty = tid / 9, dq = tid - ty * 9;
     const int gy = y0 + ty - 2, gx = x0 - 4 + dq * 4;
@@ -270,37 +271,54 @@ stem16_gray_kernel(const Stem16Params p) {
   const float bias0[4] = {q0.x, q0.y, q0.z, q0.w}, bias1[4] = {q1.x, q1.y, q1.z, q1.w};
   __syncthreads();
 
-  // ---- conv0 on the (PH x PW) halo tile: group g = wave + 4*it covers halo pixels 16g .. 16g+15
-  constexpr int NG0 = (PH * PW + 15) / 16;
+  // ---- conv0 on the (PH x PW) halo tile. Columns 0..31 of every halo row are two 16-pixel groups: wave w takes column
+  // segment w & 1 of rows (w >> 1), (w >> 1) + 2, ... -- every per-lane quantity (table address, output address, column
+  // validity) is loop invariant up to a compile-time stride and the row validity is wave uniform, so a group costs its three
+  // MFMAs plus ~10 VALU instructions (the former "16 consecutive halo pixels per group" mapping needed 34 for its
+  // lane-dependent row / column walk, and this loop was the VALU-bound half of the kernel: 0.80 -> 0.63-0.68 ms).
+  // Columns 32, 33 (36 pixels) are three more groups, done by waves 0-2 afterwards.
+  const float low0 = p.relu0 ? 0.0f : -__builtin_huge_valf();
+  auto conv0_store = [&](const f32x4 d, bool in_img, unsigned char* dstp) {
+    const unsigned m = in_img ? 0xFFFFFFFFu : 0u;  // outside the image: conv1's SAME padding = 0
+    *reinterpret_cast<uint2*>(dstp) = make_uint2(sa::f2h2(fmaxf(d[0], low0), fmaxf(d[1], low0)) & m,
+                                                 sa::f2h2(fmaxf(d[2], low0), fmaxf(d[3], low0)) & m);
+  };
+  auto operand = [&](const uint2 tq) { return __builtin_bit_cast(mfma_h8, make_uint4(tq.x, tq.y, 0u, 0u)); };
   {
-    int pl = wave * 16 + n16;
-    int ty = pl / PW, tx = pl - ty * PW;
-    const int kbc = kb < 3 ? kb : 0;
-    for (int g = wave; g < NG0; g += 4) {
-      const bool valid = pl < PH * PW;
-      uint2 tq = rawt[(ty + kbc) * RS + tx];  // rows up to RH are allocated: the tail of the last group reads garbage
-      if (kb == 3) tq = make_uint2(0u, 0u);
-      const uint4 bq4 = make_uint4(tq.x, tq.y, 0u, 0u);
-      const mfma_h8 bf = __builtin_bit_cast(mfma_h8, bq4);
-      f32x4 d = {bias0[0], bias0[1], bias0[2], bias0[3]};
-      d = SA_MFMA_16x16x32(wa[0], bf, d, 0, 0, 0);
-      d = SA_MFMA_16x16x32(wa[1], bf, d, 0, 0, 0);
-      d = SA_MFMA_16x16x32(wa[2], bf, d, 0, 0, 0);
-      // outside the image: conv1's SAME padding = 0
-      const bool in_img = valid && (unsigned)(y0 + ty - 1) < (unsigned)H && (unsigned)(x0 + tx - 1) < (unsigned)W;
-      float v[4];
+    const int seg = wave & 1, tx = seg * 16 + n16;
+    const bool colok = (unsigned)(x0 + tx - 1) < (unsigned)W;
+    // lanes kb == 3 carry K slots 24..31 (no taps): they read the zero entry with stride 0
+    const uint2* src = kb < 3 ? rawt + ((wave >> 1) + kb) * RS + tx : rawt + RH * RS;
+    const int sstep = kb < 3 ? 2 * RS : 0;
+    unsigned char* dstp = act + ((wave >> 1) * PW + tx) * 32 + kb * 8;
+    auto rowok = [&](int it) { return (unsigned)(y0 + (wave >> 1) + 2 * it - 1) < (unsigned)H; };  // wave uniform
+    // three groups at a time: the hi / mid / lo MFMAs of one group depend on each other, those of different groups do not
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float t = p.relu0 ? fmaxf(d[j], 0.0f) : d[j];
-        v[j] = in_img ? t : 0.0f;
+    for (int it = 0; it < PH / 2; it += 3) {
+      mfma_h8 bf[3];
+      f32x4 d[3];
+#pragma unroll
+      for (int u = 0; u < 3; ++u) {
+        bf[u] = operand(src[(it + u) * sstep]);
+        d[u] = (f32x4){bias0[0], bias0[1], bias0[2], bias0[3]};
       }
-      if (valid) *reinterpret_cast<uint2*>(act + pl * 32 + kb * 8) = make_uint2(sa::f2h2(v[0], v[1]), sa::f2h2(v[2], v[3]));
-      pl += 64;  // 64 = PW + 30
-      tx += 30;
-      ty += 1;
-      if (tx >= PW) {
-        tx -= PW;
-        ty += 1;
+#pragma unroll
+      for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int u = 0; u < 3; ++u) d[u] = SA_MFMA_16x16x32(wa[t], bf[u], d[u], 0, 0, 0);
+#pragma unroll
+      for (int u = 0; u < 3; ++u) conv0_store(d[u], colok && rowok(it + u), dstp + (it + u) * (2 * PW * 32));
+    }
+    if (wave < 3) {  // columns 32, 33: pixel q = 16 * wave + n16 of the 36 -> row q >> 1, column 32 + (q & 1)
+      const int q = wave * 16 + n16;
+      if (q < 2 * PH) {
+        const int ty2 = q >> 1, tx2 = 32 + (q & 1);
+        const mfma_h8 bf = operand(kb < 3 ? rawt[(ty2 + kb) * RS + tx2] : make_uint2(0u, 0u));
+        f32x4 d = {bias0[0], bias0[1], bias0[2], bias0[3]};
+#pragma unroll
+        for (int t = 0; t < 3; ++t) d = SA_MFMA_16x16x32(wa[t], bf, d, 0, 0, 0);
+        conv0_store(d, (unsigned)(y0 + ty2 - 1) < (unsigned)H && (unsigned)(x0 + tx2 - 1) < (unsigned)W,
+                    act + (ty2 * PW + tx2) * 32 + kb * 8);
       }
     }
   }
@@ -330,38 +348,37 @@ stem16_gray_kernel(const Stem16Params p) {
       }
   }
 
-  // ---- epilogue: lane holds couts kb*4..+3 of pixel (row, h*16 + n16)
+  // ---- epilogue: lane holds couts kb*4..+3 of pixel (row, h*16 + n16). ReLU is one v_max against a uniform bound
+  // (0 or -inf); every address is one 64-bit base per lane plus compile-time offsets.
+  const float low1 = p.relu1 ? 0.0f : -__builtin_huge_valf();
+  const int gy0 = y0 + wave * 4, gx0 = x0 + n16;
+  if (p.dst) {
+    uint16_t* dp = p.dst + (((size_t)b * H + gy0) * W + gx0) * 16 + kb * 4;
 #pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    const int gx = x0 + h * 16 + n16;
-    if (p.dst) {
+    for (int h = 0; h < 2; ++h)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int gy = y0 + wave * 4 + r;
-        float v[4];
+      for (int r = 0; r < 4; ++r)
+        if (gy0 + r < H && gx0 + h * 16 < W)
+          *reinterpret_cast<uint2*>(dp + ((size_t)r * W + h * 16) * 16) =
+              make_uint2(sa::f2h2(fmaxf(acc[r][h][0], low1), fmaxf(acc[r][h][1], low1)),
+                         sa::f2h2(fmaxf(acc[r][h][2], low1), fmaxf(acc[r][h][3], low1)));
+  }
+  if (p.dst_pool) {
+    uint16_t* pp = p.dst_pool + (((size_t)b * (H / 2) + gy0 / 2) * (W / 2) + gx0 / 2) * 16 + kb * 4;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = p.relu1 ? fmaxf(acc[r][h][j], 0.0f) : acc[r][h][j];
-        if (gy < H && gx < W)
-          *reinterpret_cast<uint2*>(p.dst + (((size_t)b * H + gy) * W + gx) * 16 + kb * 4) =
-              make_uint2(sa::f2h2(v[0], v[1]), sa::f2h2(v[2], v[3]));
-      }
-    }
-    if (p.dst_pool) {
+    for (int h = 0; h < 2; ++h)
 #pragma unroll
       for (int r = 0; r < 4; r += 2) {
         float t4[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          float t = fmaxf(acc[r][h][j], acc[r + 1][h][j]);
-          t = fmaxf(t, sa::dpp_xor1(t));
-          t4[j] = p.relu1 ? fmaxf(t, 0.0f) : t;  // relu(max(.)) == max(relu(.))
+          const float t = fmaxf(fmaxf(acc[r][h][j], acc[r + 1][h][j]), low1);  // relu(max(.)) == max(relu(.))
+          t4[j] = fmaxf(t, sa::dpp_xor1(t));
         }
-        const int gy = y0 + wave * 4 + r;
-        if (!(lane & 1) && gy < H && gx < W)
-          *reinterpret_cast<uint2*>(p.dst_pool + (((size_t)b * (H / 2) + gy / 2) * (W / 2) + gx / 2) * 16 + kb * 4) =
+        if (!(lane & 1) && gy0 + r < H && gx0 + h * 16 < W)
+          *reinterpret_cast<uint2*>(pp + ((size_t)(r / 2) * (W / 2) + h * 8) * 16) =
               make_uint2(sa::f2h2(t4[0], t4[1]), sa::f2h2(t4[2], t4[3]));
       }
-    }
   }
 #endif
 }
