@@ -391,8 +391,15 @@ def build_resnet_model_config(input_shape: Tuple[int, int, int], version: str = 
     return cfg, shapes
 
 
-def he_normal_weights(shapes: Dict[str, tuple], seed: int = 0) -> Dict[str, np.ndarray]:
-    """Deterministic He-normal kernels / small biases (random-init weights for benchmarking)."""
+def he_normal_weights(shapes: Dict[str, tuple], seed: int = 0, residual_scale: float = 1.0) -> Dict[str, np.ndarray]:
+    """Deterministic He-normal kernels / small biases (random-init weights for benchmarking).
+
+    `residual_scale` multiplies the last conv of every ResNet bottleneck block (`*_block<i>_3_conv`). With 1.0 and these
+    near-identity BatchNormalization statistics the residual stream doubles its variance per block (ResNet-50 on x255
+    ImageNet-range inputs: activations 5e2 after the stem, > 6.5e4 = fp16's range from conv4_block3 on); ~0.25 keeps a
+    random-init ResNet in the range a trained one lives in (the usual "zero-init the last BN of each block" practice)."""
+    import re
+
     rng = np.random.default_rng(seed)
     w = {}
     for k in sorted(shapes):
@@ -400,6 +407,8 @@ def he_normal_weights(shapes: Dict[str, tuple], seed: int = 0) -> Dict[str, np.n
         if k.endswith("/kernel"):
             fan_in = s[0] * s[1] * (s[3] if "trans_conv" in k else s[2])
             w[k] = (rng.standard_normal(s) * math.sqrt(2.0 / fan_in)).astype(np.float32)
+            if residual_scale != 1.0 and re.search(r"_block\d+_3_conv/kernel$", k):
+                w[k] *= np.float32(residual_scale)
         elif k.endswith("/gamma"):
             w[k] = (1.0 + 0.1 * rng.standard_normal(s)).astype(np.float32)
         elif k.endswith("/moving_variance"):

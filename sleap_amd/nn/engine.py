@@ -68,6 +68,7 @@ class DeviceNetwork:
         self.dtype = dtype or DEFAULT_DTYPE or _lib.DEFAULT_DTYPE
         self._h = _lib.lib(self.dtype)
         self._tdtype = torch.float16 if self.dtype == "fp16" else torch.bfloat16
+        self._range_checked = False
         self.fuse_upsample = fuse_upsample
         self.fuse_heads = fuse_heads
         self.fuse_stem = fuse_stem
@@ -651,9 +652,10 @@ class DeviceNetwork:
             for i, (c_alloc, num, den, dt) in self.buf_meta.items():
                 h, w = H * num // den, W * num // den
                 dtype = self._tdtype if dt == "bf16" else torch.float32
-                bufs[i] = torch.empty((B, h, w, c_alloc), dtype=dtype, device=self.device)
+                bufs[i] = torch.zeros((B, h, w, c_alloc), dtype=dtype, device=self.device)
             self._buffers = {key: bufs}  # keep one shape resident
             self._slot1 = {}
+            self._range_checked = False
         return self._buffers[key]
 
     def _slot_buffers(self, bufs, slot):
@@ -664,7 +666,7 @@ class DeviceNetwork:
         view = dict(bufs)
         for o in self.outputs:
             if o.buf not in self._slot1:
-                self._slot1[o.buf] = torch.empty_like(bufs[o.buf])
+                self._slot1[o.buf] = torch.zeros_like(bufs[o.buf])
             view[o.buf] = self._slot1[o.buf]
         return view
 
@@ -931,8 +933,38 @@ class DeviceNetwork:
                 raise AssertionError(kind)
             if profile is not None:
                 ev1.record()
+        if self.dtype == "fp16" and not self._range_checked and profile is None:
+            self._check_fp16_range(bufs)
         from ..ops import from_bf16
         return [bufs[o.buf] if o.kind == "f32out" else from_bf16(bufs[o.buf], o.c) for o in self.outputs]
+
+    def _check_fp16_range(self, bufs):
+        """fp16 storage has a finite range. Once per input shape (after the first forward; one synchronisation) every stored
+        activation tensor is scanned: inf / NaN -> FloatingPointError, more than a quarter of the range used -> a warning.
+        Why here and not only at the outputs: ReLU is a v_max, which returns the non-NaN operand, so the NaNs that an
+        overflowed (+inf) activation produces downstream (inf - inf) are scrubbed to 0 again and the heads of a badly
+        overflowed network can come out FINITE; the first tensor that overflowed, however, holds +inf in HBM.
+        (Intermediates that live only in LDS -- fused stem / encoder block -- are not seen by this scan; peak finding's
+        SA_STATUS_NONFINITE catches what reaches the maps.)"""
+        self._range_checked = True
+        worst = 0.0
+        for i, t in bufs.items():
+            if t.dtype != torch.float16:
+                continue
+            lo, hi = torch.aminmax(t)  # no temporary; NaN propagates
+            m = max(abs(float(lo)), abs(float(hi)))
+            m = m if m == m else float("nan")
+            if not np.isfinite(m) or float(lo) != float(lo) or float(hi) != float(hi):
+                self._range_checked = False
+                raise FloatingPointError(
+                    f"activations left the range of fp16 storage (65504) in plan tensor {i}: load the model with dtype='bf16' "
+                    "(or SLEAP_AMD_DTYPE=bf16), which has fp32's range")
+            worst = max(worst, m)
+        if worst > 65504.0 / 4:
+            import warnings
+
+            warnings.warn(f"fp16 storage: the largest activation of the first batch is {worst:.0f}, within 4x of the format's "
+                          "range (65504); consider dtype='bf16' for this model")
 
     def conv_flops(self, H, W):
         """2*H*W*Cin*Cout*k*k over all convs for ONE frame (logical channels)."""

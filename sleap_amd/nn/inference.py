@@ -244,9 +244,7 @@ class InferenceModel:
             for v in outs["status"].tolist():
                 bits |= int(v)
             if bits & _lib.STATUS_NONFINITE:
-                raise FloatingPointError(
-                    "the network's confidence maps contain inf / NaN: activations left the range of the 16-bit storage type "
-                    "(fp16: 65504). Load the model with dtype='bf16' (or SLEAP_AMD_DTYPE=bf16), which has fp32's range.")
+                raise FloatingPointError(NONFINITE_MESSAGE)
             if bits & _lib.STATUS_LSA_INFEASIBLE:
                 raise ValueError("cost matrix is infeasible")  # what scipy raises inside the reference
             over = bits & (_lib.STATUS_PEAK_OVERFLOW | _lib.STATUS_NODE_PEAK_OVERFLOW | _lib.STATUS_INSTANCE_OVERFLOW)
@@ -300,6 +298,10 @@ class InferenceModel:
         keys = ("instance_peaks", "instance_peak_vals", "instance_scores", "n_valid", "status")
         outs = {k: torch.cat([p[k] for p in parts], dim=0) for k in keys}
         return self._unrag(outs, numpy)
+
+
+NONFINITE_MESSAGE = ("the network's confidence maps contain inf / NaN: activations left the range of the 16-bit storage type "
+                     "(fp16: 65504). Load the model with dtype='bf16' (or SLEAP_AMD_DTYPE=bf16), which has fp32's range.")
 
 
 class BottomUpInferenceLayer(InferenceLayer):
@@ -518,7 +520,10 @@ class CentroidCrop(InferenceLayer):
             pxy, pval, pch, pcnt, status = ops.find_local_peaks(cms, offsets, self.peak_threshold, refinement,
                                                                 self.integral_patch_size, float(self.output_stride),
                                                                 self.max_peaks)
-            if not (int(status.max().item()) & _lib.STATUS_PEAK_OVERFLOW) or self.max_peaks >= 16384:
+            bits = int(np.bitwise_or.reduce(status.cpu().numpy()))
+            if bits & _lib.STATUS_NONFINITE:
+                raise FloatingPointError(NONFINITE_MESSAGE)
+            if not (bits & _lib.STATUS_PEAK_OVERFLOW) or self.max_peaks >= 16384:
                 break
             self.max_peaks *= 2
         P = pval.shape[1]

@@ -189,6 +189,7 @@ def _parity(cfg, w, x_u8, tol_fp32, tol_bf16):
         worst = 0.0
         for o, r in zip(outs, ref):
             assert o.shape == r.shape
+            assert np.isfinite(o).all() and np.isfinite(r).all()  # max() below would silently drop a NaN
             worst = max(worst, float(np.abs(o - r).max() / np.abs(r).max()))
         assert worst <= tol, f"{mode}: {worst:.4g} > {tol}"
         res[mode] = worst
@@ -360,11 +361,13 @@ def test_maxpool_general_vs_torch(k, stride, pad, pad_zero, H, W):
 # ------------------------------------------------------------------------------------------------
 # ResNet backbones + UpsamplingStack (SURVEY.md §8a row a2'')
 # ------------------------------------------------------------------------------------------------
-def _resnet(h, w, cin=1, seed=3, **kw):
+def _resnet(h, w, cin=1, seed=3, residual_scale=0.25, **kw):
+    """residual_scale 0.25: a random-init ResNet whose activations stay in the range of a trained one (and of fp16 storage);
+    1.0 = plain He init, which leaves fp16's range at depth (test_resnet50_plain_he_init_...)."""
     from sleap_amd.nn.architectures import build_resnet_model_config, he_normal_weights
 
     cfg, shapes = build_resnet_model_config((h, w, cin), **kw)
-    return cfg, he_normal_weights(shapes, seed=seed)
+    return cfg, he_normal_weights(shapes, seed=seed, residual_scale=residual_scale)
 
 
 def test_resnet50_pretrained_style_transposed_concat_vs_oracle():
@@ -377,6 +380,30 @@ def test_resnet50_pretrained_style_transposed_concat_vs_oracle():
     net, res = _parity(cfg, w, rng.integers(0, 256, (2, 128, 96, 1), dtype=np.uint8), 5e-2, 3e-2)
     kinds = [op[0] for op in net.plan]
     assert "add" not in kinds and kinds.count("conv1x1") == 36 and kinds.count("convt2") == 3
+
+
+def test_resnet50_plain_he_init_overflows_fp16_and_runs_in_bf16():
+    """Plain He init (residual_scale 1): activations pass 65504 around conv4_block3. The fp16 build must say so on the
+    first forward (engine range check -- the heads themselves can come out finite because ReLU scrubs the NaNs), the bf16
+    build must match the oracle."""
+    from sleap_amd import _lib
+    from sleap_amd.nn.engine import DeviceNetwork
+
+    cfg, w = _resnet(128, 96, residual_scale=1.0, features_output_stride=32, pretrained=True,
+                     upsampling=dict(output_stride=4, method="transposed_conv", skip_connections="concatenate"),
+                     heads=[("MultiInstanceConfmapsHead", 5, 4), ("PartAffinityFieldsHead", 8, 8)])
+    x = torch.from_numpy(np.random.default_rng(0).integers(0, 256, (2, 128, 96, 1), dtype=np.uint8)).cuda()
+    with pytest.raises(FloatingPointError, match="bf16"):
+        DeviceNetwork(cfg, w, dtype="fp16").forward(x)
+    from oracle.keras_graph import KerasGraph, ensure_float
+
+    net = DeviceNetwork(cfg, w, dtype="bf16")
+    outs = [o.cpu().numpy() for o in net.forward(x)]
+    ref = KerasGraph(cfg, w)(ensure_float(x.cpu().numpy()))
+    for o, r in zip(outs, ref):
+        assert np.isfinite(o).all()
+        assert float(np.abs(o - r).max() / np.abs(r).max()) <= 5e-2
+    assert _lib.DEFAULT_DTYPE in _lib.DTYPES
 
 
 def test_resnet50_stride16_bilinear_add_vs_oracle():

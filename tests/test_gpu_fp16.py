@@ -56,6 +56,7 @@ def _benchmark_unet(h, w):
 
 
 def _rel(outs, ref):
+    assert all(np.isfinite(o).all() for o in outs)  # max() would silently drop a NaN
     return max(float(np.abs(o - r).max() / np.abs(r).max()) for o, r in zip(outs, ref))
 
 
@@ -101,7 +102,7 @@ def test_hourglass_and_resnet_fp16_vs_oracle():
     cfg, sh = build_resnet_model_config((96, 96, 1), "ResNet50", 32, pretrained=False,
                                         upsampling=dict(output_stride=4, method="transposed_conv", skip_connections="concatenate"),
                                         heads=[("MultiInstanceConfmapsHead", 5, 4)])
-    w = he_normal_weights(sh, 3)
+    w = he_normal_weights(sh, 3, residual_scale=0.25)
     x = rng.integers(0, 256, (1, 96, 96, 1), dtype=np.uint8)
     outs = [o.cpu().numpy() for o in DeviceNetwork(cfg, w, dtype="fp16").forward(torch.from_numpy(x).cuda())]
     ref = KerasGraph(cfg, w)(ensure_float(x))
@@ -166,3 +167,22 @@ def test_fixture_end_to_end_agreement_with_fp32_oracle():
 
     assert score(f16) > score(b16), (f16, b16)
     print("fixture agreement fp16", f16, "bf16", b16)
+
+
+def test_fp16_overflow_is_reported_and_bf16_is_the_way_out():
+    """Weights blown up until activations exceed 65504: the fp16 build's maps hold inf / NaN, peak finding flags the frames
+    (SA_STATUS_NONFINITE) and the checked call raises; the bf16 build (fp32 range) runs the same model."""
+    from sleap_amd.benchmark_model import build_benchmark_graph
+    from sleap_amd.nn.engine import DeviceNetwork
+    from sleap_amd.nn.inference import BottomUpPredictor
+    from sleap_amd.synth import render_frames
+
+    cfg, mc, w = build_benchmark_graph(128, 128, seed=2)
+    w = {k: (v * np.float32(2.5) if k.endswith("/kernel") else v) for k, v in w.items()}
+    frames = render_frames(2, 128, 128, n_animals=2, seed=1)[0]
+    with pytest.raises(FloatingPointError, match="bf16"):
+        BottomUpPredictor(bottomup_config=cfg, bottomup_model=DeviceNetwork(mc, w, dtype="fp16"), batch_size=2).predict(
+            frames, make_labels=False)
+    outs = BottomUpPredictor(bottomup_config=cfg, bottomup_model=DeviceNetwork(mc, w, dtype="bf16"), batch_size=2).predict(
+        frames, make_labels=False)
+    assert np.isfinite(outs[0]["instance_scores"][np.isfinite(outs[0]["instance_scores"])]).all()

@@ -199,6 +199,7 @@ def _run_graph_parity(cfg, weights, x_u8, tol, skip=()):
             assert o.shape == r.shape
             if any(sk in name for sk in skip):
                 continue
+            assert np.isfinite(o).all()  # max() below would silently drop a NaN
             w = max(w, float(np.abs(o - r).max() / max(np.abs(r).max(), 1e-6)))
         worst[mode] = w
         assert w <= tol, f"{mode}: max rel err {w:.4g} > {tol}"

@@ -110,10 +110,9 @@ cfg, sh = A.build_resnet_model_config((1024, 1024, 1), "ResNet50", 32, pretraine
                                       upsampling=dict(output_stride=4, method="transposed_conv", skip_connections="concatenate",
                                                       filters=64, refine_convs=2),
                                       heads=[("MultiInstanceConfmapsHead", 24, 4), ("PartAffinityFieldsHead", 46, 8)])
-# bf16 storage for this one: with random-init weights and identity BatchNormalization statistics the residual stream of
-# ResNet-50 doubles its variance per block (x255 ImageNet-range inputs on top) and leaves fp16's range -- the fp16 build
-# reports that (SA_STATUS_NONFINITE -> FloatingPointError); a trained network's BN keeps activations O(1-10)
-rnet = DeviceNetwork(cfg, A.he_normal_weights(sh, 0), dtype="bf16")
+# residual_scale 0.25: plain He init lets the residual stream of ResNet-50 double its variance per block and leave fp16's
+# range (the fp16 build reports it: FloatingPointError from the engine's range check); a trained network's BN keeps it O(1-10)
+rnet = DeviceNetwork(cfg, A.he_normal_weights(sh, 0, residual_scale=0.25))
 calibrate_local(rnet, fr[:2], 0, 8)
 pafs = rnet.forward(fr[:2])[1]
 rnet.rescale_head(1, [0.5 / max(float(pafs.std()), 1e-6)] * 46, [0.0] * 46)
@@ -122,6 +121,6 @@ bl = BottomUpInferenceLayer(rnet, scorer, pad_to_stride=32, cm_output_stride=4, 
                             refinement="integral", max_peaks=1024)
 bl.assume_inputs_ready = True
 bm = BottomUpInferenceModel(bl)
-o = timed(bm.call_checked, fr, "configs[4] bottom-up ResNet-50 + transposed-conv upsampling stack + PAFs, 1024x1024, 24 nodes / 23 edges (bf16 storage)", 16)
+o = timed(bm.call_checked, fr, "configs[4] bottom-up ResNet-50 + transposed-conv upsampling stack + PAFs, 1024x1024, 24 nodes / 23 edges", 16)
 print(f"|   (configs[4] status bits {int(np.bitwise_or.reduce(o['status'].cpu().numpy().astype(np.int64)))}, "
       f"instances per frame {float(o['n_valid'].float().mean()):.2f}; configs[0] {o0}) | | | | |")

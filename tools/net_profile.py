@@ -26,7 +26,7 @@ elif kind == "hourglass":
 else:
     cfg, sh = A.build_unet_model_config((H, H, 1), 16, 2, 32, 4, True, True,
                                         heads=[("MultiInstanceConfmapsHead", 13, 4), ("PartAffinityFieldsHead", 24, 8)])
-net = DeviceNetwork(cfg, A.he_normal_weights(sh, 0))
+net = DeviceNetwork(cfg, A.he_normal_weights(sh, 0, residual_scale=0.25))
 x = torch.randint(0, 256, (B, H, H, 1), dtype=torch.uint8, device="cuda")
 for _ in range(2):
     net.forward(x)
