@@ -63,9 +63,16 @@ def cpu_baseline(mc, weights, scorer_args, frames_u8, budget_s, device_result=No
     from oracle import peak_finding as opf
     from oracle.keras_graph import KerasGraph, preprocess
 
-    # torch-CPU convolutions stop scaling (and collapse at 256 threads) on the 2x64-core EPYC host of the GPU box:
-    # measured 0.22 s/frame at 16-32 threads, 0.40 s at 64, 0.73 s at 128, 17.5 s at 256 (tests/diagnostics/cpu_probe.py).
+    # The GPU box's container has a CPU quota (cgroup cpu.max: 16 CPUs of the 256 the OS reports): more threads than that
+    # only spin and get the whole process throttled -- measured 0.22 s/frame at 16-32 threads, 0.40 s at 64, 0.73 s at 128,
+    # 17.5 s at 256 (tests/diagnostics/cpu_probe.py). Use the quota when it can be read, at most 32 threads otherwise.
     cores = min(os.cpu_count() or 1, 32)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            cores = max(1, min(cores, int(int(q) / int(per))))
+    except (OSError, ValueError):
+        pass
     torch.set_num_threads(cores)
     g = KerasGraph(mc, weights)
     scorer = opg.PAFScorer(scorer_args["nodes"], scorer_args["edges"], scorer_args["stride"], oob="zero")

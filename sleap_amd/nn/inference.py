@@ -86,6 +86,8 @@ class InferenceLayer:
         self.overlap_postproc = False
         self.assume_inputs_ready = False
         self._net_stream = None
+        self._copy_stream = None
+        self.last_upload_done = None  # event: the most recent host batch has been copied to the device
         self._slot = 0
         self._slot_free = [None, None]
         self._pending_slot = None
@@ -112,6 +114,19 @@ class InferenceLayer:
             ready = torch.cuda.Event()
             ready.record(cur)
             ns.wait_event(ready)
+        if isinstance(src, torch.Tensor) and not src.is_cuda and src.is_pinned() and src.ndim == 4:
+            # page-locked host batch (the FramePrefetcher's): upload on a copy stream of its own so that the DMA of batch
+            # k+1 runs under the network of batch k instead of queueing behind it on the network stream
+            if self._copy_stream is None:
+                self._copy_stream = torch.cuda.Stream()
+            with torch.cuda.stream(self._copy_stream):
+                dev = src.cuda(non_blocking=True)
+                up = torch.cuda.Event()
+                up.record(self._copy_stream)
+            dev.record_stream(ns)
+            ns.wait_event(up)
+            data = dict(data, image=dev) if isinstance(data, dict) else dev
+            self.last_upload_done = up
         if self._slot_free[slot] is not None:
             ns.wait_event(self._slot_free[slot])  # the consumer of this slot's previous outputs has finished
         with torch.cuda.stream(ns):
@@ -1065,57 +1080,119 @@ class BottomUpPredictor(Predictor):
         last_report = t0
         batches = [(i0, min(i0 + self.batch_size, n)) for i0 in range(0, n, self.batch_size)]
         mine = [parallel.shard_range(i0, i1, rank, world) for i0, i1 in batches]
-        # this rank's frames are read ahead by a producer thread into page-locked buffers (sleap_amd/io/video.py)
-        feeder = FramePrefetcher(reader, [r for r in mine if r[1] > r[0]], depth=3)
+        # This rank's frames are read ahead by a producer thread into page-locked buffers (sleap_amd/io/video.py). The loop is a
+        # two-deep software pipeline: batch k+1 is SUBMITTED (upload on the copy stream, network, post-processing, result
+        # gather and the copy of the packed results to a page-locked host buffer -- all asynchronous) before batch k is
+        # FINALISED (wait for its results, inspect the status words, build the example). A per-batch synchronisation would
+        # leave the GPU idle between batches and undo the network / post-processing overlap.
+        feeder = FramePrefetcher(reader, [r for r in mine if r[1] > r[0]], depth=4)
         feed = iter(feeder)
         src = getattr(reader.video.backend, "_data", None)  # in-memory / memory-mapped source: "image" is a view of it
-        for (i0, i1), (lo, hi) in zip(batches, mine):
-            batch = None
+        n_nodes = layer.paf_scorer.n_nodes
+        dev = layer.keras_model.device
+        over_mask = _lib.STATUS_PEAK_OVERFLOW | _lib.STATUS_NODE_PEAK_OVERFLOW | _lib.STATUS_INSTANCE_OVERFLOW
+        host_pool = {}
+
+        def run_shard(batch, checked_width=None):
+            """-> (packed results of the whole batch on this rank's device or None, instance capacity)"""
+            packed, ig = None, layer.paf_scorer.max_instances
+            if batch is not None:
+                outs = self.inference_model.call(batch)
+                ig = outs["instance_scores"].shape[1]
+                packed = parallel.pack_results(outs)
+            return packed, ig
+
+        def to_host(packed, n_batch, ig):
+            g = parallel.gather_batch_results(packed, n_batch, ig, n_nodes, world, device=dev)
+            if g.is_cuda:
+                key = tuple(g.shape)
+                ring = host_pool.setdefault(key, [])
+                if len(ring) < 3:  # at most two batches are in flight; page-locked allocations are expensive
+                    ring.append(torch.empty(g.shape, dtype=g.dtype).pin_memory())
+                host_pool["n"] = host_pool.get("n", 0) + 1
+                host = ring[host_pool["n"] % len(ring)] if len(ring) == 3 else ring[-1]
+                host.copy_(g, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record()
+                return host, ev
+            return g, None
+
+        def submit(i0, i1, lo, hi):
+            t = {"i0": i0, "i1": i1, "lo": lo, "hi": hi, "batch": None, "key": None, "image": None, "up": None}
             if hi > lo:
-                try:
-                    _lo, _hi, _inds, batch = next(feed)
-                except StopIteration:  # the source stopped early ("Unable to load frame"): end like the reference does
-                    return
-                outs = self.inference_model.call_checked(batch)
-                done = torch.cuda.Event()
-                done.record(layer._net_stream if layer._net_stream is not None else torch.cuda.current_stream())
+                _lo, _hi, _inds, batch = next(feed)
+                t["batch"], t["key"] = batch, feeder.hold()
+            packed, t["ig"] = run_shard(t["batch"])
+            if t["batch"] is not None:
+                t["up"] = layer.last_upload_done
                 if world == 1:
                     if src is None:
-                        image = batch.numpy().copy()  # the page-locked buffer is recycled
+                        t["image"] = t["batch"].numpy().copy()  # the page-locked buffer is recycled
                     else:
-                        image = src[lo:hi] if reader.example_indices is None else src[index_of[lo:hi]]
-                feeder.release(done)
-                if world > 1 and outs["instance_scores"].shape[1] != i_gather:
-                    # this rank's caps grew; the collective needs one width on every rank
-                    if int(outs["n_valid"].max().item()) > i_gather:
-                        raise GroupingOverflowError(
-                            f"a frame has more than max_instances={i_gather} instances; under torch.distributed "
-                            "construct the PAFScorer with a larger max_instances on every rank")
-                    outs = dict(outs)
-                    for k in ("instance_peaks", "instance_peak_vals", "instance_scores"):
-                        outs[k] = outs[k][:, :i_gather].contiguous()
-                elif world == 1:
-                    i_gather = outs["instance_scores"].shape[1]
-                packed = parallel.pack_results(outs)
-            else:
-                packed = None
-            packed = parallel.gather_batch_results(packed, i1 - i0, i_gather, layer.paf_scorer.n_nodes, world,
-                                                   device=layer.keras_model.device)
-            res = parallel.unpack_results(packed, i_gather, layer.paf_scorer.n_nodes)
-            ex = InferenceModel._unrag(res, numpy=True)
-            ex.pop("status", None)
+                        t["image"] = src[lo:hi] if reader.example_indices is None else src[index_of[lo:hi]]
+            t["host"], t["ev"] = to_host(packed, i1 - i0, t["ig"])
+            return t
+
+        def finalise(t):
+            while True:
+                if t["ev"] is not None:
+                    t["ev"].synchronize()
+                # host side in NumPy only (see parallel.unpack_results_np); the page-locked buffer is recycled, hence the copy
+                res = parallel.unpack_results_np(t["host"].numpy().copy(), t["ig"], n_nodes)
+                bits = int(np.bitwise_or.reduce(res["status"].astype(np.int64))) if len(res["status"]) else 0
+                if bits & _lib.STATUS_NONFINITE:
+                    raise FloatingPointError(NONFINITE_MESSAGE)
+                if bits & _lib.STATUS_LSA_INFEASIBLE:
+                    raise ValueError("cost matrix is infeasible")  # what scipy raises inside the reference
+                over = bits & over_mask
+                if not over:
+                    break
+                # a fixed-capacity device buffer overflowed somewhere in the batch. Every rank sees the same status words
+                # (they travel in the gathered rows), so every rank doubles the same caps and re-runs its shard.
+                if not self.inference_model._grow_caps(over):
+                    raise GroupingOverflowError(
+                        f"a frame exceeds the hard capacity of the device buffers (status bits {bits})")
+                packed, t["ig"] = run_shard(t["batch"])
+                t["host"], t["ev"] = to_host(packed, t["i1"] - t["i0"], t["ig"])
+            if t["key"] is not None:
+                # the results of this batch are on the host, so its upload finished long ago: no event for the producer
+                # thread to wait on (and no HIP call from that thread at all)
+                feeder.release_key(t["key"], None)
+            bound = int(res["n_valid"].max()) if len(res["n_valid"]) else 0  # unrag_example: the batch's bounding shape
+            ex = {k: np.ascontiguousarray(res[k][:, :bound]) for k in ("instance_peaks", "instance_peak_vals", "instance_scores")}
+            ex["n_valid"] = res["n_valid"].astype(np.int64)
+            i0, i1 = t["i0"], t["i1"]
             ex["video_ind"] = np.zeros((i1 - i0,), np.int64)
             ex["frame_ind"] = index_of[i0:i1].copy()
             ex["scale"] = np.ones((i1 - i0, 2), np.float32)
             if world == 1:
-                ex["image"] = image
-            n_done += i1 - i0
+                ex["image"] = t["image"]
+            return ex
+
+        def report(n_done, last_report):
             now = time.time()
             if self.verbosity == "json" and (now - last_report) >= 1.0 / max(self.report_rate, 1e-6) and rank == 0:
                 el = now - t0
                 print(json.dumps({"n_processed": n_done, "n_total": n, "elapsed": el, "rate": n_done / max(el, 1e-9),
                                   "eta": (n - n_done) / max(n_done / max(el, 1e-9), 1e-9)}), flush=True)
-                last_report = now
+                return now
+            return last_report
+
+        pending = []
+        for (i0, i1), (lo, hi) in zip(batches, mine):
+            try:
+                pending.append(submit(i0, i1, lo, hi))
+            except StopIteration:  # the source stopped early ("Unable to load frame"): end like the reference does
+                break
+            if len(pending) > 1:
+                ex = finalise(pending.pop(0))
+                n_done += len(ex["frame_ind"])
+                last_report = report(n_done, last_report)
+                yield ex
+        while pending:
+            ex = finalise(pending.pop(0))
+            n_done += len(ex["frame_ind"])
+            last_report = report(n_done, last_report)
             yield ex
 
     def predict(self, data, make_labels: bool = True):

@@ -8,6 +8,7 @@ B/world * (I*N*3 + I + 2) floats -- tens of KB, latency-bound, never chunked.
 """
 from typing import Dict, Optional, Tuple
 
+import numpy as np
 import torch
 import torch.distributed as dist
 
@@ -55,6 +56,19 @@ def unpack_results(packed: torch.Tensor, max_instances: int, n_nodes: int) -> Di
     o += I
     return {"instance_peaks": peaks, "instance_peak_vals": vals, "instance_scores": scores,
             "n_valid": packed[:, o].to(torch.int32), "status": packed[:, o + 1].to(torch.int32)}
+
+
+def unpack_results_np(packed, max_instances: int, n_nodes: int):
+    """`unpack_results` for a host NumPy array. Deliberately NumPy: torch CPU ops enter OpenMP parallel regions whose idle
+    threads spin, and under a container CPU quota (cpu.max 16 CPUs of 256 on the GPU boxes) a few of them per batch exhaust
+    the quota -- the whole process then stalls for the rest of the 100 ms CFS period (measured: 88 ms stalls every third
+    batch in the predict loop, tools/predict_e2e.py)."""
+    b = packed.shape[0]
+    I, N = max_instances, n_nodes
+    o = I * N * 2
+    return {"instance_peaks": packed[:, :o].reshape(b, I, N, 2), "instance_peak_vals": packed[:, o:o + I * N].reshape(b, I, N),
+            "instance_scores": packed[:, o + I * N:o + I * N + I], "n_valid": packed[:, o + I * N + I].astype(np.int32),
+            "status": packed[:, o + I * N + I + 1].astype(np.int32)}
 
 
 def gather_batch_results(packed: Optional[torch.Tensor], n_batch: int, max_instances: int, n_nodes: int, world: int,
