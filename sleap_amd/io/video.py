@@ -49,6 +49,47 @@ class NumpyVideo:
     def get_frames(self, lo: int, hi: int) -> np.ndarray:
         return np.asarray(self._data[lo:hi])
 
+    READ_THREADS = int(os.environ.get("SLEAP_AMD_READ_THREADS", "8"))
+
+    def read_into(self, lo: int, hi: int, out: np.ndarray) -> bool:
+        """Frames [lo, hi) of a `.npy` FILE straight into `out` (C-contiguous, same dtype) with positional reads, a few threads
+        wide (1 thread 6.5 k, 4: 8.5 k, 8: 9.9 k, 12: 9.3 k frames/s of 1024 x 1024 from the page cache). Copying out of the memory map instead faults the file in page by page: 6.9 GB/s = 6.5 k frames/s
+        on the GPU box, less than the network consumes; pread from the page cache is not bound by that. -> False when the
+        source is not a plain C-ordered file-backed array (the caller falls back to `get_frames`)."""
+        d = self._data
+        if not isinstance(d, np.memmap) or not d.flags.c_contiguous or out.dtype != d.dtype or not out.flags.c_contiguous:
+            return False
+        frame_bytes = int(np.prod(d.shape[1:])) * d.dtype.itemsize
+        if out.nbytes != (hi - lo) * frame_bytes:
+            return False
+        if getattr(self, "_fd", None) is None:
+            self._fd = os.open(d.filename, os.O_RDONLY)
+            self._pool = None
+        base = d.offset + lo * frame_bytes
+        mv = memoryview(out).cast("B")
+        n = out.nbytes
+
+        def rd(a, b):
+            pos = a
+            while pos < b:
+                got = os.preadv(self._fd, [mv[pos:b]], base + pos)
+                if got <= 0:
+                    raise IOError(f"short read from {d.filename}")
+                pos += got
+
+        k = max(1, min(self.READ_THREADS, n >> 22))
+        if k == 1:
+            rd(0, n)
+            return True
+        if self._pool is None:
+            from concurrent.futures import ThreadPoolExecutor
+
+            self._pool = ThreadPoolExecutor(max_workers=self.READ_THREADS)
+        step = -(-n // k)
+        step += (-step) % 4096
+        list(self._pool.map(lambda a: rd(a, min(a + step, n)), range(0, n, step)))
+        return True
+
 
 class HDF5Video:
     """sleap/io/video.py:47-338: a frames dataset inside an HDF5 file.
@@ -248,12 +289,17 @@ class FramePrefetcher:
                     ev.synchronize()  # the upload that read this buffer last has finished
                 buf = self._bufs[k][: hi - lo]
                 try:
-                    frames = self.reader.video.get_frames(inds)
+                    rd = getattr(self.reader.video.backend, "read_into", None)
+                    contiguous = len(inds) > 0 and int(inds[-1]) - int(inds[0]) + 1 == len(inds) and \
+                        (len(inds) == 1 or bool((np.diff(np.asarray(inds)) == 1).all()))
+                    if not (rd is not None and contiguous and 0 <= int(inds[0]) and int(inds[-1]) < len(self.reader.video)
+                            and rd(int(inds[0]), int(inds[-1]) + 1, buf.numpy())):
+                        frames = self.reader.video.get_frames(inds)
+                        self._stage(buf.numpy(), frames)  # straight into the page-locked buffer (no temporary)
                 except KeyError as e:
                     if "Unable to load frame" in str(e):
                         break
                     raise
-                self._stage(buf.numpy(), frames)  # straight into the page-locked buffer (no temporary)
                 self._q.put((lo, hi, np.asarray(inds, dtype=np.int64), buf, k))
             self._q.put(None)
         except BaseException as e:  # noqa: BLE001 - handed to the consumer thread

@@ -105,3 +105,24 @@ def test_hdf5_video(clip, tmp_path):
     assert fl.backend_dict()["dataset"] == "flt"
     out = [b.numpy().copy() for _, _, _, b in FramePrefetcher(VideoReader(v), [(0, 5), (5, 10)], pin_memory=False)]
     assert np.array_equal(out[1], clip[5:10])
+
+
+def test_npy_file_positional_reads_equal_memory_map(tmp_path):
+    """NumpyVideo.read_into (pread, several threads) == slicing the memory map; declines what it can not serve."""
+    from sleap_amd.io.video import FramePrefetcher, NumpyVideo, Video
+
+    a = np.random.default_rng(5).integers(0, 256, (37, 96, 128, 1), dtype=np.uint8)
+    path = str(tmp_path / "v.npy")
+    np.save(path, a)
+    nv = NumpyVideo(path)
+    out = np.empty((9, 96, 128, 1), np.uint8)
+    assert nv.read_into(5, 14, out) and np.array_equal(out, a[5:14])
+    big = np.empty((37, 96, 128, 1), np.uint8)
+    nv.READ_THREADS = 3
+    assert nv.read_into(0, 37, big) and np.array_equal(big, a)
+    assert not nv.read_into(0, 9, np.empty((9, 96, 128, 1), np.float32))  # dtype mismatch -> caller falls back
+    assert not nv.read_into(0, 8, out)  # size mismatch
+    assert not NumpyVideo(a).read_into(0, 9, out)  # in-memory array: nothing to pread
+    got = [b.numpy()[: hi - lo].copy() for lo, hi, _, b in
+           FramePrefetcher(Video.from_filename(path), [(0, 16), (16, 32), (32, 37)], depth=3, pin_memory=False)]
+    assert np.array_equal(np.concatenate(got), a)
