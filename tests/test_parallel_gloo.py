@@ -35,6 +35,12 @@ def test_pack_unpack_roundtrip():
     u = parallel.unpack_results(p, I, N)
     for k in outs:
         np.testing.assert_array_equal(u[k].numpy(), outs[k].numpy())
+    # the NumPy twin used on the host side of the predict loop (no torch CPU ops there: container CPU quotas)
+    un = parallel.unpack_results_np(p.numpy(), I, N)
+    assert set(un) == set(u)
+    for k in outs:
+        np.testing.assert_array_equal(un[k], outs[k].numpy())
+        assert un[k].dtype == outs[k].numpy().dtype
 
 
 def _free_port():
