@@ -51,6 +51,28 @@ class _T:
         self.pads = None  # zpad: ((top, bottom), (left, right))
 
 
+class ConvOp(list):
+    """One 3x3 (`kind` "conv") or 1x1 (`kind` "conv1x1") convolution launch of the plan. It is still a list -- the executor
+    unpacks it positionally -- but the passes that inspect or rewrite plan entries use the slot names below.
+      src0, src1   input tensors (src1: second Concatenate operand, None otherwise)
+      mode         SRC1_* / SRC0_POOL2X flag of the 3x3 kernel; the STRIDE for a 1x1 conv
+      w, bias      packed weights (device), bias (device, padded)
+      out          output tensor; out_pool: its fused MaxPool2D(2) copy or None; need_full: `out` itself is stored
+      heads        1x1 head ops computed in this conv's epilogue
+      ext          None or {"ps", "pt", "res", "res_mode", "relu_last"}: post-affine (BatchNormalization), residual, last ReLU
+    """
+    FIELDS = ("kind", "src0", "src1", "mode", "w", "bias", "out", "relu", "out_pool", "need_full", "heads", "name", "ext")
+
+
+def _slot(i):
+    return property(lambda self: self[i], lambda self, v: self.__setitem__(i, v))
+
+
+for _i, _f in enumerate(ConvOp.FIELDS):
+    setattr(ConvOp, _f, _slot(_i))
+ConvOp.stride = ConvOp.mode  # the same slot, read as what it means for a 1x1 conv
+
+
 DEFAULT_DTYPE = None  # set (temporarily) by load_model(dtype=...); otherwise _lib.DEFAULT_DTYPE (SLEAP_AMD_DTYPE or "fp16")
 
 
@@ -316,7 +338,7 @@ class DeviceNetwork:
                     check(h.sa_pack_tapconv_weights(kc.ctypes.data_as(C.c_void_p), 1, cin, s0.cp, cout, coutp,
                                                     packed.ctypes.data_as(C.c_void_p)), "sa_pack_tapconv_weights")
                     wdev = torch.from_numpy(packed.view(np.int16)).to(dev)
-                    plan.append(["conv1x1", s0, None, st, wdev, bias, o, relu, None, True, [], name, ext])
+                    plan.append(ConvOp(["conv1x1", s0, None, st, wdev, bias, o, relu, None, True, [], name, ext]))
                     conv_of[id(o)] = plan[-1]
                 elif x.kind == "input":
                     w = np.zeros((3, 3, cin, coutp), np.float32)
@@ -356,7 +378,7 @@ class DeviceNetwork:
                     check(h.sa_pack_conv3x3_weights(kc.ctypes.data_as(C.c_void_p), c0, c0p, c1, c1p, cout, coutp,
                                                     packed.ctypes.data_as(C.c_void_p)), "sa_pack_conv3x3_weights")
                     wdev = torch.from_numpy(packed.view(np.int16)).to(dev)
-                    plan.append(["conv", s0, s1, mode, wdev, bias, o, relu, o_pool, need_full, [], name, ext])
+                    plan.append(ConvOp(["conv", s0, s1, mode, wdev, bias, o, relu, o_pool, need_full, [], name, ext]))
                     conv_of[id(o)] = plan[-1]
                 t[out_name] = o
                 t[name] = o
@@ -460,13 +482,13 @@ class DeviceNetwork:
                 for i in (1, 0):
                     a, b = ins[i], ins[1 - i]
                     op = conv_of.get(id(a)) if a.kind == "real" else None
-                    if op is None or cons.get(in_names[i], []) != [name] or op[10] or op[8] is not None:
+                    if op is None or cons.get(in_names[i], []) != [name] or op.heads or op.out_pool is not None:
                         continue
-                    if op[0] == "conv" and op[3] not in (_lib.SRC1_NONE, _lib.SRC1_DIRECT):
+                    if op.kind == "conv" and op.mode not in (_lib.SRC1_NONE, _lib.SRC1_DIRECT):
                         continue
-                    if op[0] == "conv1x1" and b.kind == "up" and b.interp == "nearest":
+                    if op.kind == "conv1x1" and b.kind == "up" and b.interp == "nearest":
                         continue  # the GEMM epilogue only reads a same-resolution residual
-                    if op[12] is not None and (op[12]["relu_last"] or op[12]["res"] is not None):
+                    if op.ext is not None and (op.ext["relu_last"] or op.ext["res"] is not None):
                         continue
                     # the residual must exist before the conv runs: kernels emitted to materialise it are moved in
                     # front of the conv; an operand written by a later op can not be folded
@@ -481,17 +503,17 @@ class DeviceNetwork:
                     idx += len(moved)
                     if any(self._writes(q, res) for q in plan[idx:]):
                         continue
-                    if op[12] is None:
+                    if op.ext is None:
                         one = np.ones((a.cp,), np.float32)
-                        op[12] = {"ps": upload_f32(one), "pt": upload_f32(0 * one), "res": None, "res_mode": 0, "relu_last": 0}
-                    op[12]["res"], op[12]["res_mode"] = res, res_mode
+                        op.ext = {"ps": upload_f32(one), "pt": upload_f32(0 * one), "res": None, "res_mode": 0, "relu_last": 0}
+                    op.ext["res"], op.ext["res_mode"] = res, res_mode
                     self.round_points.discard(round_of[id(a)])
                     act = sole_consumer(name, "Activation")
                     if act is not None and act["config"]["activation"] == "relu":
-                        op[12]["relu_last"] = 1
+                        op.ext["relu_last"] = 1
                         skip.add(act["name"])
                         t[act["name"]] = a
-                    round_of[id(a)] = act["name"] if op[12]["relu_last"] else name
+                    round_of[id(a)] = act["name"] if op.ext["relu_last"] else name
                     self.round_points.add(round_of[id(a)])
                     t[name] = a
                     fused = True
@@ -550,9 +572,9 @@ class DeviceNetwork:
         if k == "pair":
             return [op[1][1]]
         if k in ("conv", "conv1x1"):
-            r = [t for t in (op[1], op[2]) if t is not None]
-            if op[12] is not None and op[12]["res"] is not None:
-                r.append(op[12]["res"])
+            r = [t for t in (op.src0, op.src1) if t is not None]
+            if op.ext is not None and op.ext["res"] is not None:
+                r.append(op.ext["res"])
             return r
         if k in ("head", "pool", "poolg", "up", "convt", "convt2"):
             return [op[1]]
@@ -564,22 +586,22 @@ class DeviceNetwork:
         """Move 1x1 heads into the epilogue of the conv that produces their input (<= 2 heads, <= 32 channels each,
         producer with <= 128 padded output channels on the DMA path). If the heads were the only readers the bf16
         feature tensor is never written."""
-        convs = {id(op[6]): op for op in plan if op[0] == "conv"}
+        convs = {id(op.out): op for op in plan if op[0] == "conv"}
         out = []
         for op in plan:
-            if op[0] == "head":
+            if op[0] == "head":  # ("head", src, out, w, bias, activation)
                 prod = convs.get(id(op[1]))
-                if (prod is not None and prod[3] in (_lib.SRC1_NONE, _lib.SRC1_DIRECT) and prod[6].cp <= 128
-                        and len(prod[10]) < 2 and op[2].c <= 32 and prod[12] is None):
-                    prod[10].append(op)
+                if (prod is not None and prod.mode in (_lib.SRC1_NONE, _lib.SRC1_DIRECT) and prod.out.cp <= 128
+                        and len(prod.heads) < 2 and op[2].c <= 32 and prod.ext is None):
+                    prod.heads.append(op)
                     continue
             out.append(op)
         for op in out:
-            if op[0] == "conv" and op[10]:
-                o = op[6]
+            if op[0] == "conv" and op.heads:
+                o = op.out
                 readers = sum(1 for q in out for t in self._reads(q) if t is o)
                 if readers == 0:
-                    op[9] = False  # need_full
+                    op.need_full = False
                     self.buf_meta.pop(o.buf, None)
                     o.buf = None
         return out
@@ -590,22 +612,22 @@ class DeviceNetwork:
         out = list(plan)
 
         def plain(op):
-            return (op[0] == "conv" and op[2] is None and op[3] == _lib.SRC1_NONE and not op[10] and op[12] is None)
+            return (op[0] == "conv" and op.src1 is None and op.mode == _lib.SRC1_NONE and not op.heads and op.ext is None)
 
         for x in list(out):
-            if not plain(x) or x[1].cp != 16 or x[6].cp != 32 or x[8] is not None or x[6].buf is None:
+            if not plain(x) or x.src0.cp != 16 or x.out.cp != 32 or x.out_pool is not None or x.out.buf is None:
                 continue
-            readers = [q for q in out if any(t is x[6] for t in self._reads(q))]
+            readers = [q for q in out if any(t is x.out for t in self._reads(q))]
             if len(readers) != 1 or not plain(readers[0]):
                 continue
             y = readers[0]
-            if y[1] is not x[6] or y[6].cp != 32 or any(x[6] is o for o in self.outputs):
+            if y.src0 is not x.out or y.out.cp != 32 or any(x.out is o for o in self.outputs):
                 continue
             i = next(k for k, q in enumerate(out) if q is y)
             out[i] = ["pair", x, y]
             del out[next(k for k, q in enumerate(out) if q is x)]
-            self.buf_meta.pop(x[6].buf, None)
-            x[6].buf = None
+            self.buf_meta.pop(x.out.buf, None)
+            x.out.buf = None
         return out
 
     def _fuse_stem(self, plan):
@@ -620,16 +642,17 @@ class DeviceNetwork:
             if len(readers) != 1 or readers[0][0] != "conv":
                 continue
             cv = readers[0]
-            if cv[1] is not so or cv[2] is not None or cv[3] != _lib.SRC1_NONE or cv[10] or so.cp not in (16, 32) or cv[6].cp > 64 \
-                    or cv[12] is not None:
+            if cv.src0 is not so or cv.src1 is not None or cv.mode != _lib.SRC1_NONE or cv.heads or so.cp not in (16, 32) \
+                    or cv.out.cp > 64 or cv.ext is not None:
                 continue
             w1_16 = None
-            if so.cp == 16 and cv[6].cp == 16:  # register-resident 16x16x32 MFMA specialisation (uint8 input)
+            stem_name = op[6]  # ("stem", out, w, bias, cin, relu, layer name)
+            if so.cp == 16 and cv.out.cp == 16:  # register-resident 16x16x32 MFMA specialisation (uint8 input)
                 h = self._h
-                k0 = np.ascontiguousarray(self.weights[op[6] + "/kernel"], dtype=np.float32)
-                k1 = np.ascontiguousarray(self.weights[cv[11] + "/kernel"], dtype=np.float32)
-                b0 = np.ascontiguousarray(self.weights.get(op[6] + "/bias", np.zeros(k0.shape[3])), dtype=np.float32)
-                b1 = np.ascontiguousarray(self.weights.get(cv[11] + "/bias", np.zeros(k1.shape[3])), dtype=np.float32)
+                k0 = np.ascontiguousarray(self.weights[stem_name + "/kernel"], dtype=np.float32)
+                k1 = np.ascontiguousarray(self.weights[cv.name + "/kernel"], dtype=np.float32)
+                b0 = np.ascontiguousarray(self.weights.get(stem_name + "/bias", np.zeros(k0.shape[3])), dtype=np.float32)
+                b1 = np.ascontiguousarray(self.weights.get(cv.name + "/bias", np.zeros(k1.shape[3])), dtype=np.float32)
                 blob = np.zeros((h.sa_stem16_blob_bytes(),), np.uint8)
                 vp = lambda a: a.ctypes.data_as(C.c_void_p)
                 check(h.sa_stem16_pack(vp(k0), vp(b0), k0.shape[2], k0.shape[3], vp(k1), vp(b1), k1.shape[3], vp(blob)),
@@ -689,7 +712,7 @@ class DeviceNetwork:
         names = []
         for op in self.plan:
             if op[0] == "conv":
-                for hd in op[10]:
+                for hd in op.heads:
                     names.append(self.output_names[[id(o) for o in self.outputs].index(id(hd[2]))])
         return names
 
@@ -698,7 +721,7 @@ class DeviceNetwork:
             if op[0] == "head":
                 yield op
             elif op[0] == "conv":
-                for hd in op[10]:
+                for hd in op.heads:
                     yield hd
 
     def export_head(self, output_index: int):
@@ -716,7 +739,7 @@ class DeviceNetwork:
         for op in self.plan:
             k = op[0]
             if k == "stem2":
-                so, cin, o = op[1][1], op[1][4], op[2][6]
+                so, cin, o = op[1][1], op[1][4], op[2].out  # ["stem2", stem op, ConvOp, stem16 blob]
                 hh = H * o.num // o.den
                 f = 2 * hh * (W * o.num // o.den) * (cin * so.c + so.c * o.c) * 9
                 out.append(("conv", f"stem+conv3x3 {cin}->{so.c}->{o.c} @{hh}", f))
@@ -725,16 +748,16 @@ class DeviceNetwork:
                 f = 2 * (H * o.num // o.den) * (W * o.num // o.den) * cin * o.c * 9
                 out.append((k, f"stem {cin}->{o.c} @{H * o.num // o.den}", f))
             elif k == "pair":
-                s0, mid, o = op[1][1], op[1][6], op[2][6]
+                s0, mid, o = op[1].src0, op[1].out, op[2].out  # ["pair", ConvOp a, ConvOp b]
                 hh = H * o.num // o.den
                 f = 2 * hh * (W * o.num // o.den) * (s0.c * mid.c + mid.c * o.c) * 9
                 out.append(("conv", f"conv3x3 pair {s0.c}->{mid.c}->{o.c} @{hh}", f))
             elif k == "conv1x1":
-                s0, o = op[1], op[6]
+                s0, o = op.src0, op.out
                 f = 2 * (H * o.num // o.den) * (W * o.num // o.den) * s0.c * o.c
-                nm = f"conv1x1s{op[3]} {s0.c}->{o.c} @{H * o.num // o.den}"
-                if op[12] is not None:
-                    nm += " +affine" + (" +res" if op[12]["res"] is not None else "")
+                nm = f"conv1x1s{op.stride} {s0.c}->{o.c} @{H * o.num // o.den}"
+                if op.ext is not None:
+                    nm += " +affine" + (" +res" if op.ext["res"] is not None else "")
                 out.append(("conv", nm, f))
             elif k == "convt2":
                 s, o, ksz = op[1], op[4], op[6]
@@ -745,14 +768,14 @@ class DeviceNetwork:
                 f = 2 * (H * o.num // o.den) * (W * o.num // o.den) * cin * o.c * kk[0] * kk[1]
                 out.append(("conv", f"imgconv{kk[0]}x{kk[1]}s{op[8]} {cin}->{o.c} @{H * o.num // o.den}", f))
             elif k == "conv":
-                s0, s1, o = op[1], op[2], op[6]
+                s0, s1, o = op.src0, op.src1, op.out
                 cin = s0.c + (s1.c if s1 is not None else 0)
                 f = 2 * (H * o.num // o.den) * (W * o.num // o.den) * cin * o.c * 9
-                nm = f"conv3x3 {cin}->{o.c} @{H * o.num // o.den} mode{op[3]}"
-                for hd in op[10]:
+                nm = f"conv3x3 {cin}->{o.c} @{H * o.num // o.den} mode{op.mode}"
+                for hd in op.heads:
                     nm += f" +head{hd[2].c}"
-                if op[12] is not None:
-                    nm += " +affine" + (" +res" if op[12]["res"] is not None else "")
+                if op.ext is not None:
+                    nm += " +affine" + (" +res" if op.ext["res"] is not None else "")
                 out.append((k, nm, f))
             elif k == "head":
                 s, o = op[1], op[2]
@@ -813,7 +836,7 @@ class DeviceNetwork:
                     raise ValueError("images must be uint8 or float32")
                 check(h.sa_stem_conv3x3(_ptr(imgs), is_u8, B, H, W, cin, _ptr(w), _ptr(bias), o.cp, relu,
                                         _ptr(bufs[o.buf]), st), "sa_stem_conv3x3")
-            elif kind == "conv" and op[10]:
+            elif kind == "conv" and op.heads:
                 _, s0, s1, mode, w, bias, o, relu, o_pool, need_full, heads, _nm, _ext = op
                 oh, ow = hw(o)
                 n = len(heads)
@@ -829,7 +852,7 @@ class DeviceNetwork:
                                               s1.cp if s1 is not None else 0, mode, _ptr(w), _ptr(bias), o.cp, relu, B, oh,
                                               ow, _ptr(bufs[o.buf]) if need_full else None, n, hw_, hb_, hc_, ha_, hd_, st),
                       "sa_conv3x3_heads_bf16")
-            elif kind == "conv" and op[12] is not None:
+            elif kind == "conv" and op.ext is not None:
                 _, s0, s1, mode, w, bias, o, relu, o_pool, need_full, _heads, _nm, ext = op
                 oh, ow = hw(o)
                 res = ext["res"]
@@ -971,7 +994,7 @@ class DeviceNetwork:
         total = 0
         for op in self.plan:
             if op[0] == "stem2":
-                so, cin, o = op[1][1], op[1][4], op[2][6]
+                so, cin, o = op[1][1], op[1][4], op[2].out
                 total += 2 * (H * o.num // o.den) * (W * o.num // o.den) * (cin * so.c + so.c * o.c) * 9
             elif op[0] == "stem":
                 o, cin = op[1], op[4]
@@ -980,16 +1003,16 @@ class DeviceNetwork:
                 o, cin, kk = op[1], op[11], op[7]
                 total += 2 * (H * o.num // o.den) * (W * o.num // o.den) * cin * o.c * kk[0] * kk[1]
             elif op[0] == "pair":
-                s0, mid, o = op[1][1], op[1][6], op[2][6]
+                s0, mid, o = op[1].src0, op[1].out, op[2].out
                 total += 2 * (H * o.num // o.den) * (W * o.num // o.den) * (s0.c * mid.c + mid.c * o.c) * 9
             elif op[0] == "conv1x1":
-                s0, o = op[1], op[6]
+                s0, o = op.src0, op.out
                 total += 2 * (H * o.num // o.den) * (W * o.num // o.den) * s0.c * o.c
             elif op[0] == "convt2":
                 s, o, ksz = op[1], op[4], op[6]
                 total += 2 * (H * s.num // s.den) * (W * s.num // s.den) * s.c * o.c * ksz * ksz
             elif op[0] == "conv":
-                s0, s1, o = op[1], op[2], op[6]
+                s0, s1, o = op.src0, op.src1, op.out
                 cin = s0.c + (s1.c if s1 is not None else 0)
                 total += 2 * (H * o.num // o.den) * (W * o.num // o.den) * cin * o.c * 9
             elif op[0] == "head":
