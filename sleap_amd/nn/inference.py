@@ -495,9 +495,13 @@ class SingleInstanceInferenceModel(InferenceModel):
         outs = {k: torch.cat([p[k].clone() for p in parts], dim=0) for k in parts[0]}
         return {k: v.cpu().numpy() for k, v in outs.items()} if numpy else outs
 
+    @staticmethod
+    def outputs_to_numpy(outs):
+        return {k: v.cpu().numpy() for k, v in outs.items()}
+
     def predict_on_batch(self, data, numpy: bool = False, **kwargs):
         outs = self.call(data)
-        return {k: v.cpu().numpy() for k, v in outs.items()} if numpy else outs
+        return self.outputs_to_numpy(outs) if numpy else outs
 
 
 class CentroidCrop(InferenceLayer):
@@ -649,13 +653,14 @@ class TopDownInferenceModel(InferenceModel):
     def _to_numpy(outs):
         return {k: (v.cpu().numpy() if isinstance(v, torch.Tensor) else v) for k, v in outs.items()}
 
-    def predict_on_batch(self, data, numpy: bool = False, **kwargs):
-        outs = self.call(data)
-        if not numpy:
-            return outs
+    def outputs_to_numpy(self, outs):
         res = self._to_numpy(outs)
         res["n_valid"] = res["n_valid"].astype(np.int64)
         return res
+
+    def predict_on_batch(self, data, numpy: bool = False, **kwargs):
+        outs = self.call(data)
+        return self.outputs_to_numpy(outs) if numpy else outs
 
     def predict(self, data, numpy: bool = True, batch_size: int = 4, **kwargs):
         imgs = data["image"] if isinstance(data, dict) else data
@@ -751,10 +756,31 @@ class Predictor:
         frames = self._frames_of(data)
         n = len(frames)
         rank, world = parallel.rank_world()
-        for i0 in range(0, n, self.batch_size):
+        small = {"instance_peaks", "instance_peak_vals", "instance_scores", "n_valid", "centroids", "centroid_vals"}
+
+        def submit(i0):
+            """Queue one batch (everything asynchronous that the model leaves asynchronous) -> a ticket."""
             i1 = min(i0 + self.batch_size, n)
             lo, hi = parallel.shard_range(i0, i1, rank, world)
-            ex = self.inference_model.predict_on_batch(frames[lo:hi], numpy=True) if hi > lo else None
+            dev = self.inference_model.predict_on_batch(frames[lo:hi], numpy=False) if hi > lo else None
+            if dev is not None and not set(dev) <= small:
+                # maps / crops may alias network buffers that the next batch overwrites: convert before anything else runs
+                dev = self.inference_model.outputs_to_numpy(dev)
+            return i0, i1, dev
+
+        # two-deep pipeline: batch k+1 is queued before batch k is brought to the host (the conversion synchronises), so the
+        # GPU works on k+1 while the host waits for, converts and hands out k
+        if n == 0:
+            return
+        tickets = [submit(0)]
+        for i_next in list(range(self.batch_size, n, self.batch_size)) + [None]:
+            nxt = submit(i_next) if i_next is not None else None
+            i0, i1, dev = tickets.pop(0)
+            if nxt is not None:
+                tickets.append(nxt)
+            ex = None
+            if dev is not None:
+                ex = dev if isinstance(next(iter(dev.values())), np.ndarray) else self.inference_model.outputs_to_numpy(dev)
             if world > 1:
                 parts = [None] * world
                 dist.all_gather_object(parts, ex)
