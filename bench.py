@@ -56,6 +56,18 @@ def parse():
     return ap.parse_args()
 
 
+def cpu_budget(limit=32):
+    """CPUs this process may actually use: the cgroup quota when there is one (cpu.max), else the visible count, <= limit."""
+    cores = min(os.cpu_count() or 1, limit)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            cores = max(1, min(cores, int(int(q) / int(per))))
+    except (OSError, ValueError):
+        pass
+    return cores
+
+
 def cpu_baseline(mc, weights, scorer_args, frames_u8, budget_s, device_result=None):
     """Times the CPU oracle on a bounded sample of the same frames (all host cores for the convs) and, as the checker,
     compares its instances with the device's for those frames (north_star: peaks within 0.5 px, identical assignments)."""
@@ -66,13 +78,7 @@ def cpu_baseline(mc, weights, scorer_args, frames_u8, budget_s, device_result=No
     # The GPU box's container has a CPU quota (cgroup cpu.max: 16 CPUs of the 256 the OS reports): more threads than that
     # only spin and get the whole process throttled -- measured 0.22 s/frame at 16-32 threads, 0.40 s at 64, 0.73 s at 128,
     # 17.5 s at 256 (tests/diagnostics/cpu_probe.py). Use the quota when it can be read, at most 32 threads otherwise.
-    cores = min(os.cpu_count() or 1, 32)
-    try:
-        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
-        if q != "max":
-            cores = max(1, min(cores, int(int(q) / int(per))))
-    except (OSError, ValueError):
-        pass
+    cores = cpu_budget()
     torch.set_num_threads(cores)
     g = KerasGraph(mc, weights)
     scorer = opg.PAFScorer(scorer_args["nodes"], scorer_args["edges"], scorer_args["stride"], oob="zero")
@@ -135,6 +141,9 @@ def main():
     if world != args.gpus and world > 1:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
     torch.cuda.set_device(local_rank)
+    # torch's CPU kernels spin in OpenMP regions sized by the VISIBLE core count; under a container CPU quota that throttles
+    # the whole process. The timed loop has no torch CPU ops, this keeps stray ones harmless.
+    torch.set_num_threads(max(1, cpu_budget() // max(world, 1)))
     import torch.distributed as dist
 
     use_dist = world > 1 or args.force_dist
