@@ -111,6 +111,12 @@ __device__ __forceinline__ void swap32(unsigned& a, unsigned& b) {
   a = r[0];
   b = r[1];
 }
+// v_permlane16_swap: exchanges a's odd rows of 16 lanes (lanes 16-31, 48-63) with b's even rows (0-15, 32-47).
+__device__ __forceinline__ void swap16(unsigned& a, unsigned& b) {
+  const auto r = __builtin_amdgcn_permlane16_swap(a, b, false, false);
+  a = r[0];
+  b = r[1];
+}
 #endif
 
 }  // namespace sa

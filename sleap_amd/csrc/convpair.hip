@@ -8,11 +8,13 @@
 // result is bitwise what sa_conv3x3_bf16 twice produces -- and one tile carries 58 MFMAs per wave for one prologue and one
 // epilogue.
 //
-// Workgroup = 8 waves, 16 x 32 output pixels. LDS (71936 B -> two workgroups per CU):
+// Workgroup = 8 waves, 16 x 32 output pixels. LDS (81152 B -> two workgroups per CU):
 //   [0, 39168)        intermediate halo tile 18 x 34 px x 32 ch, 64 B per pixel, 16-byte slots XOR (pixel >> 2) & 3
 //   [39168, 62720)    input halo tile 20 x 36 px x 16 ch, 32 B per pixel, slots XOR (pixel >> 3) & 1      (phase A only)
-//   [62720, 71936)    conv-a weights, 9 slabs of 1 KiB (MFMA A fragments, sa_pack_conv3x3_weights)        (phase A only)
-//   [39168, 57600)    conv-b weights, 18 slabs -- copied into the region phase A has finished with
+//   [62720, 81152)    conv-b weights, 18 slabs of 1 KiB (MFMA A fragments, sa_pack_conv3x3_weights)
+// conv-a's nine A fragments are register resident (global loads at kernel start), which is what makes room for conv-b's
+// weights beside the input tile: everything is requested up front, phase B starts without a third barrier or a mid-kernel
+// wait for L2 (0.635 -> 0.58 ms per 64 frames of 512 x 512 against the version that re-used the input tile's space).
 // Phase A: conv-a on all 612 halo pixels (20 groups of 32 over the 8 waves; +20 % conv-a FLOPs for the halo), written to
 // the intermediate tile with zeros outside the image (= conv-b's SAME padding). Phase B: the usual 9-tap loop.
 #include <cstdint>
@@ -52,8 +54,10 @@ convpair_16_32_32_kernel(const PairParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* inter = smem;
   unsigned char* in_tile = smem + INTER_BYTES;
-  unsigned char* wa_tile = smem + WA_OFF;
-  unsigned char* wb_tile = smem + INTER_BYTES;
+  // conv-a's nine A fragments live in registers, which frees room for conv-b's weights next to the input tile: they are
+  // copied at kernel start with everything else (81152 B, still two workgroups per CU) and phase B starts without a third
+  // barrier or a mid-kernel wait for L2
+  unsigned char* wb_tile = smem + WA_OFF;
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -73,7 +77,6 @@ convpair_16_32_32_kernel(const PairParams p) {
   const size_t fbytes = (size_t)H * W * 32;
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
       (void*)(reinterpret_cast<const unsigned char*>(p.src) + b * fbytes), 0, (int)fbytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rwa = __builtin_amdgcn_make_buffer_rsrc((void*)p.wa, 0, 9 * 1024, 0x00020000);
   const __amdgpu_buffer_rsrc_t rwb = __builtin_amdgcn_make_buffer_rsrc((void*)p.wb, 0, 18 * 1024, 0x00020000);
 
   // ---- copies: input halo tile (pixels outside the image -> zeros through the buffer bounds check) + conv-a weights
@@ -91,10 +94,14 @@ convpair_16_32_32_kernel(const PairParams p) {
     }
   }
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
+  for (int j = 0; j < 3; ++j) {
     const int k = j * NW + wave;
-    if (k < 9) __builtin_amdgcn_raw_ptr_buffer_load_lds(rwa, (lds_ptr_t)(wa_tile + k * 1024), 16, (unsigned)lane * 16, k * 1024, 0, 0);
+    if (k < 18) __builtin_amdgcn_raw_ptr_buffer_load_lds(rwb, (lds_ptr_t)(wb_tile + k * 1024), 16, (unsigned)lane * 16, k * 1024, 0, 0);
   }
+  mfma_h8 wa_reg[9];
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap)
+    wa_reg[tap] = *reinterpret_cast<const mfma_h8*>(p.wa + ((size_t)tap * 64 + lane) * 8);
   const float4 ba0 = *reinterpret_cast<const float4*>(p.bias_a + 4 * half);
   const float4 ba1 = *reinterpret_cast<const float4*>(p.bias_a + 8 + 4 * half);
   const float4 ba2 = *reinterpret_cast<const float4*>(p.bias_a + 16 + 4 * half);
@@ -118,7 +125,7 @@ convpair_16_32_32_kernel(const PairParams p) {
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
       const int pin = (ty + tap / 3) * QW + tx + tap % 3;
-      const mfma_h8 a = *reinterpret_cast<const mfma_h8*>(wa_tile + tap * 1024 + lane * 16);
+      const mfma_h8 a = wa_reg[tap];
       const mfma_h8 bv = *reinterpret_cast<const mfma_h8*>(in_tile + pin * 32 + ((half ^ ((pin >> 3) & 1)) * 16));
       d = SA_MFMA_32x32x16(a, bv, d, 0, 0, 0);
     }
@@ -148,12 +155,6 @@ convpair_16_32_32_kernel(const PairParams p) {
   }
   __syncthreads();  // the intermediate tile is complete; the input tile and conv-a weights are dead
 
-  // ---- conv-b weights into the freed region
-#pragma unroll
-  for (int j = 0; j < 3; ++j) {
-    const int k = j * NW + wave;
-    if (k < 18) __builtin_amdgcn_raw_ptr_buffer_load_lds(rwb, (lds_ptr_t)(wb_tile + k * 1024), 16, (unsigned)lane * 16, k * 1024, 0, 0);
-  }
   float bb[4][4];
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
@@ -163,8 +164,6 @@ convpair_16_32_32_kernel(const PairParams p) {
     bb[g][2] = q.z;
     bb[g][3] = q.w;
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
 
   // ---- phase B: conv-b (32 -> 32), wave owns rows wave*2, wave*2+1
   f32x16 acc[R];
@@ -264,7 +263,7 @@ extern "C" int sa_conv3x3_pair_bf16(const void* src, int C0P, const void* wa, co
   p.tiles_y = (H + 15) / 16;
   const size_t nblk = (size_t)p.tiles_x * p.tiles_y * B;
   if (nblk > 0x7fffffffull) return sa::fail(SA_ERR_INVALID_ARG, "sa_conv3x3_pair_bf16: grid too large");
-  constexpr int lds = 18 * 34 * 64 + 23 * 1024 + 9 * 1024;  // 71936
+  constexpr int lds = 18 * 34 * 64 + 23 * 1024 + 18 * 1024;  // 81152: intermediate tile + input tile + conv-b weights
   static bool attr_set = false;
   if (!attr_set) {
     SA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&convpair_16_32_32_kernel),

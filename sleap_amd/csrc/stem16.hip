@@ -276,7 +276,8 @@ stem16_gray_kernel(const Stem16Params p) {
   // validity) is loop invariant up to a compile-time stride and the row validity is wave uniform, so a group costs its three
   // MFMAs plus ~10 VALU instructions (the former "16 consecutive halo pixels per group" mapping needed 34 for its
   // lane-dependent row / column walk, and this loop was the VALU-bound half of the kernel: 0.80 -> 0.63-0.68 ms).
-  // Columns 32, 33 (36 pixels) are three more groups, done by waves 0-2 afterwards.
+  // Columns 32, 33 (36 pixels) are three more groups, done by waves 0-2 afterwards. (Measured and dropped: pairing two
+  // groups with v_permlane16_swap into one 16-byte store per lane -- 2-way instead of 2 x 4-way bank conflicts -- 0.60 -> 0.63 ms.)
   const float low0 = p.relu0 ? 0.0f : -__builtin_huge_valf();
   auto conv0_store = [&](const f32x4 d, bool in_img, unsigned char* dstp) {
     const unsigned m = in_img ? 0xFFFFFFFFu : 0u;  // outside the image: conv1's SAME padding = 0
