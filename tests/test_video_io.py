@@ -126,3 +126,26 @@ def test_npy_file_positional_reads_equal_memory_map(tmp_path):
     got = [b.numpy()[: hi - lo].copy() for lo, hi, _, b in
            FramePrefetcher(Video.from_filename(path), [(0, 16), (16, 32), (32, 37)], depth=3, pin_memory=False)]
     assert np.array_equal(np.concatenate(got), a)
+
+
+def test_prefetcher_hold_and_release_key_keep_buffers_until_released():
+    """A consumer with several batches in flight (`Predictor._predict_generator`) takes buffers with hold() and hands them
+    back later with release_key(): a held buffer must not be refilled, and the stream must still complete."""
+    from sleap_amd.io.video import FramePrefetcher, Video
+
+    a = np.arange(12 * 4 * 4, dtype=np.uint8).reshape(12, 4, 4, 1)
+    fp = FramePrefetcher(Video.from_numpy(a), [(i, i + 2) for i in range(0, 12, 2)], depth=4, pin_memory=False)
+    held, seen = [], []
+    for lo, hi, inds, buf in fp:
+        key = fp.hold()
+        held.append((key, lo, hi, buf))
+        if len(held) > 2:  # two batches stay in flight
+            k, l, h, b = held.pop(0)
+            assert np.array_equal(b.numpy()[: h - l], a[l:h])  # not overwritten while held
+            seen.append((l, h))
+            fp.release_key(k)
+    for k, l, h, b in held:
+        assert np.array_equal(b.numpy()[: h - l], a[l:h])
+        seen.append((l, h))
+        fp.release_key(k)
+    assert seen == [(i, i + 2) for i in range(0, 12, 2)]
