@@ -89,7 +89,8 @@ def _build_variant(dtype, force, verbose):
 
 
 def build(force=False, verbose=True, dtypes=("bf16", "fp16")):
-    """Compile every storage-type variant; returns the path of the default (bf16) library."""
+    """Compile every storage-type variant (fp16 = the default the Python layer loads, bf16); returns the path of the bf16
+    library file (`libsleap_amd.so`, the historical name)."""
     os.makedirs(LIBDIR, exist_ok=True)
     for d in dtypes:
         _build_variant(d, force, verbose)

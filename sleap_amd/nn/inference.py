@@ -1237,8 +1237,8 @@ def load_model(model_path: Union[str, List[str]], batch_size: int = 4, peak_thre
                max_instances: Optional[int] = None, dtype: Optional[str] = None) -> Predictor:
     """inference.py:4865-5004: accepts model folders, `training_config.json` paths or `.zip` archives.
 
-    New: `dtype` = 16-bit storage type of the network's activations / conv weights, "bf16" (default) or "fp16" (closer to the
-    reference's fp32 numerics, finite range)."""
+    New: `dtype` = 16-bit storage type of the network's activations / conv weights: "fp16" (default, SLEAP_AMD_DTYPE; the one
+    that tracks the reference's fp32 numerics, finite range 65504) or "bf16" (fp32's range; see DESIGN.md sections 2 and 4)."""
     if isinstance(model_path, str):
         model_paths = [model_path]
     else:
