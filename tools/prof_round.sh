@@ -1,7 +1,7 @@
 set -x
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/v8
+O=$R/gpurun_out/v10
 mkdir -p $O
 cd $R
 timeout 300 python bench.py > $O/bench_line.json 2> $O/bench_err.log
