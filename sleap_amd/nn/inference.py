@@ -1119,6 +1119,9 @@ class BottomUpPredictor(Predictor):
         over_mask = _lib.STATUS_PEAK_OVERFLOW | _lib.STATUS_NODE_PEAK_OVERFLOW | _lib.STATUS_INSTANCE_OVERFLOW
         host_pool = {}
 
+        def caps():
+            return (layer.max_peaks, layer.paf_scorer.max_node_peaks, layer.paf_scorer.max_instances)
+
         def run_shard(batch, checked_width=None):
             """-> (packed results of the whole batch on this rank's device or None, instance capacity)"""
             packed, ig = None, layer.paf_scorer.max_instances
@@ -1148,6 +1151,7 @@ class BottomUpPredictor(Predictor):
             if hi > lo:
                 _lo, _hi, _inds, batch = next(feed)
                 t["batch"], t["key"] = batch, feeder.hold()
+            t["caps"] = caps()
             packed, t["ig"] = run_shard(t["batch"])
             if t["batch"] is not None:
                 t["up"] = layer.last_upload_done
@@ -1174,10 +1178,13 @@ class BottomUpPredictor(Predictor):
                 if not over:
                     break
                 # a fixed-capacity device buffer overflowed somewhere in the batch. Every rank sees the same status words
-                # (they travel in the gathered rows), so every rank doubles the same caps and re-runs its shard.
-                if not self.inference_model._grow_caps(over):
+                # (they travel in the gathered rows), so every rank takes the same decision: if the caps have not changed
+                # since this result was computed, double the ones that overflowed; then re-run the shard. (A batch that was
+                # in flight while an earlier one grew the caps is first re-run with the caps as they are now.)
+                if t["caps"] == caps() and not self.inference_model._grow_caps(over):
                     raise GroupingOverflowError(
                         f"a frame exceeds the hard capacity of the device buffers (status bits {bits})")
+                t["caps"] = caps()
                 packed, t["ig"] = run_shard(t["batch"])
                 t["host"], t["ev"] = to_host(packed, t["i1"] - t["i0"], t["ig"])
             if t["key"] is not None:

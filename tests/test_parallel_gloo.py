@@ -81,3 +81,89 @@ def test_two_rank_gather(n_batch):
         assert p.exitcode == 0
     res = dict(q.get(timeout=10) for _ in range(world))
     assert res == {0: True, 1: True}
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# The predict loop under torch.distributed, without a GPU: the real `BottomUpPredictor._predict_generator` (two-deep pipeline,
+# frame sharding, gather, overflow handling) around a stand-in model whose "network" reads the answer out of the frame.
+# Frame t encodes (k_t instances, id t); the stand-in reports SA_STATUS_INSTANCE_OVERFLOW when k_t exceeds the current
+# capacity, as the grouping kernel does. Both ranks must double the same caps, re-run, and end with identical, complete results.
+def _fake_predictor(max_instances):
+    from types import SimpleNamespace
+
+    from sleap_amd import _lib
+    from sleap_amd.nn.inference import BottomUpInferenceModel, BottomUpPredictor
+
+    N = 3
+    layer = SimpleNamespace(paf_scorer=SimpleNamespace(max_instances=max_instances, n_nodes=N, max_node_peaks=8), max_peaks=64,
+                            keras_model=SimpleNamespace(device=torch.device("cpu")), last_upload_done=None)
+
+    class Model(BottomUpInferenceModel):
+        def __init__(self):
+            self.bottomup_layer = layer
+            self.calls = 0
+
+        def call(self, batch):
+            self.calls += 1
+            x = batch if isinstance(batch, torch.Tensor) else torch.from_numpy(np.asarray(batch))
+            b, I = x.shape[0], layer.paf_scorer.max_instances
+            k, t = x[:, 0, 0, 0].to(torch.int64), x[:, 0, 1, 0].to(torch.float32)
+            peaks = torch.full((b, I, N, 2), float("nan"))
+            vals = torch.full((b, I, N), float("nan"))
+            scores = torch.full((b, I), float("nan"))
+            status = torch.zeros((b,), dtype=torch.int32)
+            for f in range(b):
+                n = min(int(k[f]), I)
+                if int(k[f]) > I:
+                    status[f] = _lib.STATUS_INSTANCE_OVERFLOW
+                for i in range(n):
+                    peaks[f, i] = t[f] + i
+                    vals[f, i] = 0.5
+                    scores[f, i] = 1.0 + i
+            return {"instance_peaks": peaks, "instance_peak_vals": vals, "instance_scores": scores,
+                    "n_valid": torch.minimum(k, torch.tensor(I)).to(torch.int32), "status": status}
+
+    pred = BottomUpPredictor.__new__(BottomUpPredictor)
+    pred.inference_model, pred.batch_size, pred.verbosity, pred.report_rate, pred.tracker = Model(), 4, "none", 2.0, None
+    return pred, layer
+
+
+def _predict_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        T = 13  # 4 batches, the last one short (1 frame: rank 1 gets an empty shard)
+        ks = [1, 2, 0, 2, 3, 1, 5, 2, 0, 1, 4, 2, 5]
+        frames = np.zeros((T, 4, 4, 1), np.uint8)
+        frames[:, 0, 0, 0], frames[:, 0, 1, 0] = ks, np.arange(T)
+        pred, layer = _fake_predictor(max_instances=2)
+        exs = list(pred._predict_generator(frames))
+        n_valid = np.concatenate([e["n_valid"] for e in exs])
+        frame_ind = np.concatenate([e["frame_ind"] for e in exs])
+        ok = n_valid.tolist() == ks and frame_ind.tolist() == list(range(T))
+        for e in exs:
+            for f, t in enumerate(e["frame_ind"]):
+                for i in range(int(e["n_valid"][f])):
+                    ok = ok and bool((e["instance_peaks"][f, i] == t + i).all()) and e["instance_scores"][f, i] == 1.0 + i
+        q.put((rank, ok, layer.paf_scorer.max_instances, pred.inference_model.calls))
+    finally:
+        if world > 1:
+            dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [1, 2])
+def test_predict_loop_overflow_consensus(world):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_predict_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0
+    res = sorted(q.get(timeout=10) for _ in range(world))
+    assert all(ok for _, ok, _, _ in res), res
+    assert [caps for _, _, caps, _ in res] == [8] * world, res  # 2 -> 4 (k = 3) -> 8 (k = 5): the same on every rank
