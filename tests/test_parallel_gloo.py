@@ -167,3 +167,66 @@ def test_predict_loop_overflow_consensus(world):
     res = sorted(q.get(timeout=10) for _ in range(world))
     assert all(ok for _, ok, _, _ in res), res
     assert [caps for _, _, caps, _ in res] == [8] * world, res  # 2 -> 4 (k = 3) -> 8 (k = 5): the same on every rank
+
+
+# The base generator (top-down / single-instance predictors): frame sharding + all_gather_object of ragged NumPy results, with
+# batch k+1 queued before batch k is converted. Stand-in model: instance count and coordinates are read out of the frame.
+def _base_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from sleap_amd.nn.inference import Predictor
+
+        class Model:
+            order = []
+
+            def predict_on_batch(self, x, numpy=False):
+                x = np.asarray(x)
+                b, k = x.shape[0], x[:, 0, 0, 0].astype(np.int64)
+                imax = int(k.max())  # ragged across batches AND ranks: the gather pads to the widest
+                peaks = torch.full((b, imax, 2, 2), float("nan"))
+                for f in range(b):
+                    peaks[f, : k[f]] = float(x[f, 0, 1, 0])
+                self.order.append(("submit", int(x[0, 0, 1, 0])))
+                return {"instance_peaks": peaks, "instance_peak_vals": peaks[..., 0].clone(), "n_valid": torch.from_numpy(k)}
+
+            def outputs_to_numpy(self, outs):
+                self.order.append(("convert", int(np.nanmin(outs["instance_peaks"].numpy()[0])) if outs["n_valid"][0] > 0 else -1))
+                return {k: v.numpy() for k, v in outs.items()}
+
+        T = 11
+        ks = [1, 2, 3, 1, 2, 1, 4, 1, 2, 2, 3]
+        frames = np.zeros((T, 4, 4, 1), np.uint8)
+        frames[:, 0, 0, 0], frames[:, 0, 1, 0] = ks, np.arange(T) + 1
+        pred = Predictor.__new__(Predictor)
+        pred.inference_model, pred.batch_size = Model(), 4
+        exs = list(pred._predict_generator(frames))
+        ok = np.concatenate([e["n_valid"] for e in exs]).tolist() == ks
+        ok = ok and np.concatenate([e["frame_ind"] for e in exs]).tolist() == list(range(T))
+        for e in exs:
+            for f, t in enumerate(e["frame_ind"]):
+                n = int(e["n_valid"][f])
+                ok = ok and bool((e["instance_peaks"][f, :n] == t + 1).all()) and bool(np.isnan(e["instance_peaks"][f, n:]).all())
+        # pipelining: the second batch is submitted before the first is converted
+        kinds = [a for a, _ in pred.inference_model.order]
+        ok = ok and kinds[:3] == ["submit", "submit", "convert"]
+        q.put((rank, bool(ok)))
+    finally:
+        if world > 1:
+            dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [1, 2])
+def test_base_predict_loop_shards_gathers_and_pipelines(world):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_base_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0
+    assert sorted(q.get(timeout=10) for _ in range(world)) == [(r, True) for r in range(world)]
