@@ -92,3 +92,57 @@ def test_save_load_round_trip(tmp_path):
     np.testing.assert_array_equal(labels.numpy(untracked=True), back.numpy(untracked=True))
     back.save(str(tmp_path / "p2.slp"))  # a loaded file can be written again
     assert len(Labels.load_file(str(tmp_path / "p2.slp")).predicted_instances) == len(labels.predicted_instances)
+
+
+def test_predict_to_labels_with_tracker_without_gpu(tmp_path):
+    """`Predictor.predict(frames)` end to end on the host side -- pipelined generator, native tracker, Labels views,
+    `.numpy()` -- around a stand-in model (two animals walking; the "network" reads them out of the frame)."""
+    from types import SimpleNamespace
+
+    import torch
+
+    from sleap_amd.nn.inference import BottomUpInferenceModel, BottomUpPredictor
+    from sleap_amd.nn.tracking import Tracker
+
+    T, N = 10, 3
+    rng = np.random.default_rng(0)
+    walk = np.cumsum(rng.normal(0, 1.0, (T, 2, 1, 2)), axis=0) + np.array([[[20.0, 20.0]], [[80.0, 60.0]]])[None]
+    pts = (walk + np.arange(N)[None, None, :, None] * 3.0).astype(np.float32)  # (T, 2 animals, N nodes, 2)
+    frames = np.zeros((T, 8, 8, 1), np.uint8)
+    frames[:, 0, 0, 0] = np.arange(T)
+    layer = SimpleNamespace(paf_scorer=SimpleNamespace(max_instances=4, n_nodes=N, max_node_peaks=8, part_names=["a", "b", "c"],
+                                                       edge_inds=[(0, 1), (1, 2)]),
+                            max_peaks=64, keras_model=SimpleNamespace(device=torch.device("cpu")), last_upload_done=None)
+
+    class Model(BottomUpInferenceModel):
+        def __init__(self):
+            self.bottomup_layer = layer
+
+        def call(self, batch):
+            t = batch[:, 0, 0, 0].to(torch.int64).numpy()
+            b = len(t)
+            peaks = np.full((b, 4, N, 2), np.nan, np.float32)
+            vals = np.full((b, 4, N), np.nan, np.float32)
+            scores = np.full((b, 4), np.nan, np.float32)
+            for f in range(b):
+                order = [1, 0] if t[f] % 2 else [0, 1]  # the detector does not keep the animals in order
+                for i, a in enumerate(order):
+                    peaks[f, i], vals[f, i], scores[f, i] = pts[t[f], a], 0.9, 2.0
+            return {"instance_peaks": torch.from_numpy(peaks), "instance_peak_vals": torch.from_numpy(vals),
+                    "instance_scores": torch.from_numpy(scores), "n_valid": torch.full((b,), 2, dtype=torch.int32),
+                    "status": torch.zeros((b,), dtype=torch.int32)}
+
+    pred = BottomUpPredictor.__new__(BottomUpPredictor)
+    pred.inference_model, pred.batch_size, pred.verbosity, pred.report_rate = Model(), 4, "none", 2.0
+    pred.max_instances = None
+    pred.tracker = Tracker.make_tracker_by_name(tracker="simple", similarity="centroid", match="hungarian", track_window=3)
+    labels = pred.predict(frames)  # make_labels=True, the reference's default
+    assert len(labels) == T and len(labels.tracks) == 2
+    arr = labels.numpy()  # (frames, tracks, nodes, 2): each track follows ONE animal although the detection order alternates
+    assert arr.shape == (T, 2, N, 2)
+    first = [int(np.argmin([np.abs(arr[0, k] - pts[0, a]).max() for a in range(2)])) for k in range(2)]
+    assert sorted(first) == [0, 1]
+    for k in range(2):
+        np.testing.assert_allclose(arr[:, k], pts[:, first[k]], atol=1e-5)
+    lf = labels[3]
+    assert lf.frame_idx == 3 and len(lf.instances) == 2 and all(i.track is not None for i in lf.instances)
