@@ -146,6 +146,102 @@ class HDF5Video:
         return self._fix(self._d[lo:hi])
 
 
+class SingleImageVideo:
+    """sleap/io/video.py:803-998: a list of image files (jpg / jpeg / png / tif / tiff) presented as a video.
+
+    The reference decodes with `cv2.imread` (always 3 channels, 8 bit, BGR) and flips to RGB; here Pillow decodes and
+    converts to 8-bit RGB, which is the same array for 8-bit grayscale / RGB / RGBA PNG and TIFF files (lossless formats).
+    JPEG: both sit on libjpeg(-turbo), but their IDCT / upsampling choices are not guaranteed bit-identical -- parity unpinned
+    for lossy files. `grayscale=None` detects it from the first frame as the reference does (channel 0 == channel 2
+    everywhere -> one channel is presented); missing files are looked up next to `filename` (video.py:845-856)."""
+
+    EXTS = ("jpg", "jpeg", "png", "tif", "tiff")
+    DECODE_THREADS = int(os.environ.get("SLEAP_AMD_READ_THREADS", "8"))
+
+    def __init__(self, filename: Optional[str] = None, filenames: Optional[Sequence[str]] = None, height_: Optional[int] = None,
+                 width_: Optional[int] = None, channels_: Optional[int] = None, grayscale: Optional[bool] = None):
+        filenames = list(filenames or [])
+        if not filename and filenames:
+            filename = filenames[0]
+        elif filename and not filenames:
+            filenames = [filename]
+        if not filenames:
+            raise ValueError("SingleImageVideo needs at least one image file")
+        self.filename, self.filenames = filename, filenames
+        self.height_, self.width_, self.channels_ = height_, width_, channels_
+        self._detect_grayscale = grayscale is None
+        self.grayscale = bool(grayscale) if grayscale is not None else False
+        self._probed = False
+        self._pool = None
+
+    def _get_filename(self, idx: int) -> str:
+        f = self.filenames[idx]
+        if os.path.exists(f):
+            return f
+        g = os.path.join(os.path.dirname(self.filename), os.path.basename(f))
+        if os.path.exists(g):
+            return g
+        raise FileNotFoundError(f"Unable to locate file {idx}: {self.filenames[idx]}")
+
+    def _load_idx(self, idx: int) -> np.ndarray:
+        from PIL import Image
+
+        with Image.open(self._get_filename(idx)) as im:
+            return np.asarray(im.convert("RGB"))
+
+    def _probe(self):
+        if not self._probed:
+            f = self._load_idx(0)
+            if self._detect_grayscale:
+                self.grayscale = bool((f[..., 0] == f[..., -1]).all())
+            self.height_ = f.shape[0] if self.height_ is None else self.height_
+            self.width_ = f.shape[1] if self.width_ is None else self.width_
+            self.channels_ = f.shape[2] if self.channels_ is None else self.channels_
+            self._probed = True
+
+    frames = property(lambda self: len(self.filenames))
+    dtype = property(lambda self: np.dtype(np.uint8))
+
+    @property
+    def height(self):
+        self._probe()
+        return self.height_
+
+    @property
+    def width(self):
+        self._probe()
+        return self.width_
+
+    @property
+    def channels(self):
+        self._probe()
+        return 1 if self.grayscale else self.channels_
+
+    def get_frame(self, idx: int, grayscale: Optional[bool] = None) -> np.ndarray:
+        self._probe()
+        frame = self._load_idx(int(idx))
+        if self.grayscale if grayscale is None else grayscale:
+            frame = frame[..., 0][..., None]
+        return frame
+
+    def get_frames(self, lo: int, hi: int) -> np.ndarray:
+        """Decoded by a few threads (Pillow releases the GIL while it decodes)."""
+        self._probe()
+        n = hi - lo
+        if n <= 2 or self.DECODE_THREADS <= 1:
+            return np.stack([self.get_frame(i) for i in range(lo, hi)])
+        if self._pool is None:
+            from concurrent.futures import ThreadPoolExecutor
+
+            self._pool = ThreadPoolExecutor(max_workers=self.DECODE_THREADS)
+        return np.stack(list(self._pool.map(self.get_frame, range(lo, hi))))
+
+    def backend_dict(self) -> dict:
+        """The attrs fields of the reference's backend, as its `.slp` files store them."""
+        return {"filename": self.filename, "filenames": list(self.filenames), "height_": self.height, "width_": self.width,
+                "channels_": self.channels_, "grayscale": self.grayscale}
+
+
 class Video:
     """sleap/io/video.py:1023-1508 (`sleap.Video`): the facade the predictor, the providers and the writer talk to."""
 
@@ -161,8 +257,16 @@ class Video:
         return cls(HDF5Video(filename, dataset, input_format, convert_range))
 
     @classmethod
+    def from_image_filenames(cls, filenames: Sequence[str], height: Optional[int] = None, width: Optional[int] = None,
+                             *args, **kwargs) -> "Video":
+        """video.py:1227-1241: individual image files as one video."""
+        return cls(SingleImageVideo(filenames=list(filenames), height_=height, width_=width))
+
+    @classmethod
     def from_filename(cls, filename: str, dataset: Optional[str] = None, input_format: str = "channels_last", **kwargs) -> "Video":
         ext = os.path.splitext(filename)[1].lower()
+        if ext.lstrip(".") in SingleImageVideo.EXTS:
+            return cls(SingleImageVideo(filename=filename, grayscale=kwargs.get("grayscale")))
         if ext == ".npy":
             return cls.from_numpy(filename)
         if ext in (".h5", ".hdf5", ".slp"):
@@ -207,6 +311,8 @@ class Video:
 
     def backend_dict(self) -> dict:
         """The `backend` record the `.slp` writer stores in `videos_json`."""
+        if hasattr(self.backend, "backend_dict"):
+            return self.backend.backend_dict()
         return {"filename": str(self.backend.filename), "grayscale": self.channels == 1, "bgr": True,
                 "dataset": getattr(self.backend, "dataset", ""), "input_format": getattr(self.backend, "input_format", "")}
 

@@ -1,4 +1,6 @@
 """Frame sources and the prefetching feed (sleap_amd/io/video.py; reference sleap/io/video.py, nn/data/providers.py)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -149,3 +151,53 @@ def test_prefetcher_hold_and_release_key_keep_buffers_until_released():
         seen.append((l, h))
         fp.release_key(k)
     assert seen == [(i, i + 2) for i in range(0, 12, 2)]
+
+
+# ------------------------------------------------------------------------------------------ image-sequence videos
+GOLDEN_VIDEOS = os.path.join(os.path.dirname(__file__), "golden", "videos")
+
+
+def test_images_video_reference_expectations():  # ref tests/io/test_video.py:359-369, :30-41 (the reference's robot*.jpg)
+    from sleap_amd.io.video import SingleImageVideo, Video
+
+    filenames = [os.path.join(GOLDEN_VIDEOS, f"robot{i}.jpg") for i in range(3)]
+    vid = Video.from_image_filenames(filenames)
+    assert vid.frames == len(filenames) and vid.height == 320 and vid.width == 560 and vid.channels == 3
+    assert vid[0:1].shape == (1, 320, 560, 3) and vid.get_frame(1).dtype == np.uint8
+    assert type(Video.from_filename(filenames[0]).backend) is SingleImageVideo
+    with pytest.raises(ValueError):
+        Video.from_filename("this_has_no_video_extension")
+    d = vid.backend_dict()  # the attrs fields the reference serialises for this backend
+    assert d["filenames"] == filenames and d["grayscale"] is False and (d["height_"], d["width_"], d["channels_"]) == (320, 560, 3)
+
+
+def test_image_sequence_lossless_round_trip_grayscale_detection_and_feed(tmp_path):
+    """PNG / TIFF are lossless: frames come back exactly; a gray sequence is detected (channel 0 == channel 2) and presented
+    with one channel as the reference does; a moved folder is found through `filename`; the prefetcher feeds from it."""
+    from PIL import Image
+
+    from sleap_amd.io.video import FramePrefetcher, SingleImageVideo, Video
+
+    rng = np.random.default_rng(0)
+    gray = rng.integers(0, 256, (7, 40, 56), dtype=np.uint8)
+    rgb = rng.integers(0, 256, (3, 40, 56, 3), dtype=np.uint8)
+    gfiles, cfiles = [], []
+    for i, g in enumerate(gray):
+        f = str(tmp_path / f"g{i:02d}.{'png' if i % 2 else 'tif'}")
+        Image.fromarray(g).save(f)
+        gfiles.append(f)
+    for i, c in enumerate(rgb):
+        f = str(tmp_path / f"c{i}.png")
+        Image.fromarray(c).save(f)
+        cfiles.append(f)
+    v = Video.from_image_filenames(gfiles)
+    assert v.shape == (7, 40, 56, 1) and v.backend.grayscale is True
+    assert np.array_equal(v[0:7], gray[..., None]) and np.array_equal(v.get_frame(3), gray[3][..., None])
+    assert np.array_equal(Video.from_image_filenames(cfiles)[0:3], rgb)
+    assert SingleImageVideo(filenames=gfiles, grayscale=False).get_frame(0).shape == (40, 56, 3)  # explicit override
+    got = [b.numpy()[: hi - lo].copy() for lo, hi, _, b in FramePrefetcher(v, [(0, 4), (4, 7)], depth=3, pin_memory=False)]
+    assert np.array_equal(np.concatenate(got), gray[..., None])
+    moved = SingleImageVideo(filename=gfiles[0], filenames=["/nonexistent/" + os.path.basename(f) for f in gfiles])
+    assert np.array_equal(moved.get_frame(5)[..., 0], gray[5])  # video.py:845-856: looked up next to `filename`
+    with pytest.raises(FileNotFoundError):
+        SingleImageVideo(filename=gfiles[0], filenames=["/nonexistent/zzz.png"]).get_frame(0)
