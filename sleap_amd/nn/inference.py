@@ -1100,7 +1100,6 @@ class BottomUpPredictor(Predictor):
         index_of = np.asarray(reader.indices(), dtype=np.int64)
         layer = self.inference_model.bottomup_layer
         rank, world = parallel.rank_world()
-        i_gather = layer.paf_scorer.max_instances  # instance capacity of the gathered buffer, equal on all ranks
         t0 = time.time()
         n_done = 0
         last_report = t0
@@ -1122,7 +1121,7 @@ class BottomUpPredictor(Predictor):
         def caps():
             return (layer.max_peaks, layer.paf_scorer.max_node_peaks, layer.paf_scorer.max_instances)
 
-        def run_shard(batch, checked_width=None):
+        def run_shard(batch):
             """-> (packed results of the whole batch on this rank's device or None, instance capacity)"""
             packed, ig = None, layer.paf_scorer.max_instances
             if batch is not None:
