@@ -154,13 +154,20 @@ def test_prefetcher_hold_and_release_key_keep_buffers_until_released():
 
 
 # ------------------------------------------------------------------------------------------ image-sequence videos
-GOLDEN_VIDEOS = os.path.join(os.path.dirname(__file__), "golden", "videos")
+def test_images_video_reference_expectations(tmp_path):
+    """The expectations of the reference's tests/io/test_video.py:359-369 and :30-41 (three 560 x 320 colour JPEGs: frames,
+    height, width, channels, the shape of `vid[0]`, backend detection by extension), on JPEGs written here."""
+    from PIL import Image
 
-
-def test_images_video_reference_expectations():  # ref tests/io/test_video.py:359-369, :30-41 (the reference's robot*.jpg)
     from sleap_amd.io.video import SingleImageVideo, Video
 
-    filenames = [os.path.join(GOLDEN_VIDEOS, f"robot{i}.jpg") for i in range(3)]
+    rng = np.random.default_rng(1)
+    filenames = []
+    for i in range(3):
+        base = np.kron(rng.integers(0, 256, (20, 35, 3), dtype=np.uint8), np.ones((16, 16, 1), np.uint8))  # 320 x 560 blocks
+        f = str(tmp_path / f"robot{i}.jpg")
+        Image.fromarray(base).save(f, quality=90)
+        filenames.append(f)
     vid = Video.from_image_filenames(filenames)
     assert vid.frames == len(filenames) and vid.height == 320 and vid.width == 560 and vid.channels == 3
     assert vid[0:1].shape == (1, 320, 560, 3) and vid.get_frame(1).dtype == np.uint8
