@@ -51,3 +51,17 @@ def test_top_level_exports_are_lazy():
             "assert sleap_amd.Video.__name__ == 'Video' and sleap_amd.Labels.__name__ == 'Labels'; "
             "assert callable(sleap_amd.load_file); assert 'torch' not in sys.modules; print('ok')")
     assert subprocess.run([sys.executable, "-c", code], capture_output=True, text=True).stdout.strip() == "ok"
+
+
+def test_find_head_and_output_stride():  # ref tests/nn/test_inference.py:500-539 (on stand-ins for the Keras models)
+    from types import SimpleNamespace
+
+    from sleap_amd.nn.inference import find_head, get_model_output_stride
+
+    m = SimpleNamespace(output_names=["A_0"], output_strides=lambda: [1])
+    assert find_head(m, "A") == 0 and find_head(m, "B") is None
+    assert get_model_output_stride(m) == 1
+    m = SimpleNamespace(output_names=["MultiInstanceConfmapsHead_0", "PartAffinityFieldsHead_0"], output_strides=lambda: [2, 4])
+    assert get_model_output_stride(m) == 4  # output_ind=-1: the last output
+    assert get_model_output_stride(m, output_ind=0) == 2 and get_model_output_stride(m, output_ind=1) == 4
+    assert find_head(m, "PartAffinityFieldsHead") == 1
