@@ -799,6 +799,7 @@ class Predictor:
             ex["video_ind"] = np.zeros((i1 - i0,), np.int64)
             ex["frame_ind"] = np.arange(i0, i1, dtype=np.int64)
             ex["scale"] = np.ones((i1 - i0, 2), np.float32)
+            ex["image_hw"] = np.asarray(frames[0].shape[:2] if hasattr(frames[0], "shape") else (1, 1), np.int64)
             yield ex
 
     def predict(self, data, make_labels: bool = True):
@@ -852,32 +853,36 @@ class Predictor:
         return slp.write_slp(filename, outs, part_names, edges or [], video=video, track_names=names,
                              max_instances=self.max_instances if hasattr(self, "max_instances") else None)
 
+    def _instance_scores(self, outs):
+        """The score the reference gives each PredictedInstance, as `instance_scores` where the model does not emit one:
+        top-down -> the centroid confidence (inference.py:2639-2660 `instance_score=score` over `centroid_vals`);
+        single-instance -> `np.nansum(confidences)` (inference.py:1578). Bottom-up models emit it themselves."""
+        for ex in outs:
+            if "instance_scores" in ex:
+                continue
+            if "centroid_vals" in ex:
+                ex["instance_scores"] = np.asarray(ex["centroid_vals"], np.float32)
+            elif "instance_peak_vals" in ex:
+                ex["instance_scores"] = np.nansum(np.asarray(ex["instance_peak_vals"], np.float32), axis=-1)
+        return outs
+
     def _apply_tracker(self, outs: List[Dict[str, np.ndarray]]) -> List[Dict[str, np.ndarray]]:
         """Identity tracking over the gathered per-batch arrays, strictly in frame order, where the reference runs it
         (inference.py:3306-3313, 3345-3346). Adds `track_inds (b, I)` (-1 = no track), `tracking_scores (b, I)` and
         `track_order (b, I)` (position in the tracker's returned list) to every batch; `predictor.tracker.spawned_tracks`
-        names the tracks. Requires the array tracker of `sleap_amd.nn.tracking`."""
+        names the tracks. What reaches the tracker is what the reference hands it (`tracking.select_instances`): all-NaN
+        instances dropped, and -- bottom-up only (inference.py:3297-3304) -- the `max_instances` best by score, in that
+        order. Requires the array tracker of `sleap_amd.nn.tracking`."""
+        outs = self._instance_scores(outs)
         trk = self.tracker
         if not trk or not outs or not hasattr(trk, "track_frames"):
             return outs
-        for ex in outs:
-            hw = ex["image"].shape[1:3] if "image" in ex else (1, 1)
-            r = trk.track_frames(ex["instance_peaks"], ex.get("instance_peak_vals"), ex.get("instance_scores"),
-                                 ex.get("n_valid"), img_hw=hw, t0=int(ex["frame_ind"][0]))
-            ex["track_inds"], ex["tracking_scores"], ex["track_order"] = r["track"], r["tracking_score"], r["order"]
-        imax = max(ex["track_inds"].shape[1] for ex in outs)
+        from .tracking import finish_tracks, image_hw_of, track_example
 
-        def cat(key, fill):
-            return np.ascontiguousarray(np.concatenate(
-                [np.pad(ex[key], ((0, 0), (0, imax - ex[key].shape[1])), constant_values=fill) for ex in outs]))
-
-        table = trk.final_pass(cat("track_inds", -1).astype(np.int32), cat("track_order", -1).astype(np.int32))
-        o = 0
+        cap = getattr(self, "max_instances", None) if isinstance(self, BottomUpPredictor) else None
         for ex in outs:
-            b, i = ex["track_inds"].shape
-            ex["track_inds"] = table[o:o + b, :i].copy()
-            o += b
-        return outs
+            track_example(trk, ex, img_hw=image_hw_of(ex), max_instances=cap)
+        return finish_tracks(outs, trk)
 
 
 class SingleInstancePredictor(Predictor):
@@ -1098,6 +1103,7 @@ class BottomUpPredictor(Predictor):
         reader = data if isinstance(data, VideoReader) else VideoReader(Video.from_numpy(np.stack(list(self._frames_of(data)))))
         n = len(reader)
         index_of = np.asarray(reader.indices(), dtype=np.int64)
+        image_hw = np.asarray(reader.video.shape[1:3], np.int64)  # raw frame size (tracker similarities; present on every rank)
         layer = self.inference_model.bottomup_layer
         rank, world = parallel.rank_world()
         t0 = time.time()
@@ -1197,6 +1203,7 @@ class BottomUpPredictor(Predictor):
             ex["video_ind"] = np.zeros((i1 - i0,), np.int64)
             ex["frame_ind"] = index_of[i0:i1].copy()
             ex["scale"] = np.ones((i1 - i0, 2), np.float32)
+            ex["image_hw"] = image_hw
             if world == 1:
                 ex["image"] = t["image"]
             return ex

@@ -79,7 +79,10 @@ def load_keras_model(folder: str) -> Tuple[dict, Dict[str, np.ndarray]]:
     """-> (model_config dict as stored in the HDF5 attr `model_config`, {"<layer>/<weight>": float32 array})."""
     npz = os.path.join(folder, "best_model.npz")
     h5 = os.path.join(folder, "best_model.h5")
-    if not os.path.exists(npz):
+    # an extracted copy is only trusted while it is at least as new as the .h5 beside it (a model retrained or overwritten
+    # in the same folder must not be served from stale weights)
+    stale = os.path.exists(npz) and os.path.exists(h5) and os.path.getmtime(h5) > os.path.getmtime(npz)
+    if stale or not os.path.exists(npz):
         if not os.path.exists(h5):
             raise FileNotFoundError(f"neither best_model.h5 nor best_model.npz in {folder}")
         tools = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "tools")

@@ -202,18 +202,85 @@ def connect_single_track_breaks(track: np.ndarray, instance_count: int, order: O
     return track
 
 
-def run_tracker(outs, tracker: Tracker, img_hw=(1, 1)):
-    """tracking.py:1542-1581 on per-batch prediction dicts: every frame goes through `tracker.track` in order with the time
-    step inferred (the reference does not pass `t` here), existing tracks are discarded; then `final_pass`.
-    Adds / replaces `track_inds`, `tracking_scores`, `track_order` in every dict and returns the list."""
-    outs = list(outs)
-    if not outs:
-        return outs
-    for ex in outs:
-        hw = ex["image"].shape[1:3] if "image" in ex else img_hw
-        r = tracker.track_frames(ex["instance_peaks"], ex.get("instance_peak_vals"), ex.get("instance_scores"),
-                                 ex.get("n_valid"), img_hw=hw, t0=None)
-        ex["track_inds"], ex["tracking_scores"], ex["track_order"] = r["track"], r["tracking_score"], r["order"]
+def select_instances(ex, max_instances: Optional[int] = None):
+    """Which slots of a prediction dict the reference hands to `tracker.track`, and in which order -> list (one per frame) of
+    int arrays of slot indices. Reference: inference.py:2641-2660 (top-down) / 3283-3304 (bottom-up): the first `n_valid`
+    slots, minus instances whose points are ALL NaN (`if np.isnan(pts).all(): continue` -- they must never reach the
+    tracker: they would spawn or steal a track and poison the similarity quantiles with NaN), and -- bottom-up with
+    `max_instances` -- `sorted(key=score, reverse=True)[:max_instances]` (stable), which also becomes the tracker's input
+    order."""
+    pts = np.asarray(ex["instance_peaks"])
+    F, I = pts.shape[0], pts.shape[1]
+    n_valid = np.asarray(ex["n_valid"]) if ex.get("n_valid") is not None else np.full((F,), I)
+    ok = (np.arange(I)[None, :] < n_valid[:, None]) & ~np.isnan(pts).all(axis=(2, 3))
+    scores = ex.get("instance_scores")
+    sel = []
+    for f in range(F):
+        idx = np.nonzero(ok[f])[0]
+        if max_instances is not None and scores is not None:
+            idx = idx[np.argsort(-np.asarray(scores[f], np.float64)[idx], kind="stable")][:max_instances]
+        sel.append(idx)
+    return sel
+
+
+def track_example(tracker: Tracker, ex, img_hw=(1, 1), max_instances: Optional[int] = None, use_frame_ind: bool = True):
+    """Run `tracker` over the frames of one prediction dict and add `track_inds`, `tracking_scores`, `track_order` (all
+    (F, I), -1 / NaN / -1 for slots that were not tracked). Only the instances `select_instances` picks are tracked (compacted,
+    with a source-index map back to the slots); `t` follows `frame_ind` frame by frame (non-contiguous readers), as
+    inference.py:2662-2668 passes `t=frame_ind`."""
+    pts = _f32(ex["instance_peaks"])
+    F, I, N = pts.shape[0], pts.shape[1], pts.shape[2]
+    sel = select_instances(ex, max_instances)
+    m = max([len(s) for s in sel] + [1])
+    cp = np.full((F, m, N, 2), np.nan, np.float32)
+    vals, scores = ex.get("instance_peak_vals"), ex.get("instance_scores")
+    cv = None if vals is None else np.full((F, m, N), np.nan, np.float32)
+    cs = None if scores is None else np.full((F, m), np.nan, np.float32)
+    nv = np.zeros((F,), np.int32)
+    for f, idx in enumerate(sel):
+        k = len(idx)
+        nv[f] = k
+        cp[f, :k] = pts[f, idx]
+        if cv is not None:
+            cv[f, :k] = np.asarray(vals)[f, idx]
+        if cs is not None:
+            cs[f, :k] = np.asarray(scores)[f, idx]
+    trk = np.full((F, I), -1, np.int32)
+    tsc = np.full((F, I), np.nan, np.float64)
+    order = np.full((F, I), -1, np.int32)
+    fi = np.asarray(ex["frame_ind"], np.int64) if (use_frame_ind and "frame_ind" in ex) else None
+    # runs of consecutive frame indices share one native call (t = t0 + f inside it)
+    a = 0
+    while a < F:
+        b = a + 1
+        while fi is not None and b < F and fi[b] == fi[b - 1] + 1:
+            b += 1
+        if fi is None:
+            b = F
+        r = tracker.track_frames(cp[a:b], None if cv is None else cv[a:b], None if cs is None else cs[a:b], nv[a:b],
+                                 img_hw=img_hw, t0=None if fi is None else int(fi[a]))
+        for f in range(a, b):
+            k = nv[f]
+            trk[f, sel[f]] = r["track"][f - a, :k]
+            tsc[f, sel[f]] = r["tracking_score"][f - a, :k]
+            order[f, sel[f]] = r["order"][f - a, :k]
+        a = b
+    ex["track_inds"], ex["tracking_scores"], ex["track_order"] = trk, tsc, order
+    return ex
+
+
+def image_hw_of(ex, default=(1, 1)):
+    """Frame height / width for the size-normalised similarities: the carried raw size (`image_hw`, present in every
+    predictor output) or the image itself."""
+    if "image_hw" in ex:
+        return int(ex["image_hw"][0]), int(ex["image_hw"][1])
+    if "image" in ex:
+        return tuple(ex["image"].shape[1:3])
+    return default
+
+
+def finish_tracks(outs, tracker: Tracker):
+    """`Tracker.final_pass` (tracking.py:816-835) over the concatenated (F, I) track table of all batches."""
     imax = max(ex["track_inds"].shape[1] for ex in outs)
 
     def cat(key):
@@ -227,6 +294,18 @@ def run_tracker(outs, tracker: Tracker, img_hw=(1, 1)):
         ex["track_inds"] = table[o:o + b, :i].copy()
         o += b
     return outs
+
+
+def run_tracker(outs, tracker: Tracker, img_hw=(1, 1)):
+    """tracking.py:1542-1581 on per-batch prediction dicts: every frame goes through `tracker.track` in order with the time
+    step inferred (the reference does not pass `t` here), existing tracks are discarded; then `final_pass`.
+    Adds / replaces `track_inds`, `tracking_scores`, `track_order` in every dict and returns the list."""
+    outs = list(outs)
+    if not outs:
+        return outs
+    for ex in outs:
+        track_example(tracker, ex, img_hw=image_hw_of(ex, img_hw), use_frame_ind=False)
+    return finish_tracks(outs, tracker)
 
 
 def retrack(slp_in: str, slp_out: str, **tracker_kwargs):

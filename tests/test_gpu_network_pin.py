@@ -1,0 +1,81 @@
+"""Device path vs the reference-pinned network oracle, end to end, on the reference's own in-distribution frames.
+
+tests/test_oracle_network_pin.py ties the fp32 oracle (preprocess -> Keras graph -> global peaks) to the reference's e2e
+golden (tests/nn/test_inference.py:592-610: trained `minimal_robot.UNet.single_instance` vs the user labels of
+`small_robot_minimal.slp`). Here `load_model(...).predict(frames)` -- uint8 RGB frames in, the resize kernel (input_scaling
+0.5), the MFMA network, the device peak finder, the +0.5 un-scaling -- must reproduce that oracle within north_star's
+tolerance: EVERY peak within 0.5 px, same NaN mask, under both 16-bit storage types. Peak values are ~1.0 against a 0.2
+threshold, so nothing here is decided by the threshold; one of the six peaks is a 0.7 % near tie between two maxima 24 px
+apart (documented in the oracle test) -- a storage type that perturbs the maps by more than that fails this test by 21 px,
+not by a rounding error.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from test_oracle_network_pin import MODEL, oracle_robot_predictions, robot_golden
+
+pytestmark = pytest.mark.gpu
+
+TOL_PX = 0.5  # BASELINE.json north_star: "peak coordinates within +-0.5 px"
+
+
+@pytest.mark.parametrize("dtype", ["fp16", "bf16"])
+@pytest.mark.parametrize("batch_size", [4, 2])
+def test_robot_frames_end_to_end_within_half_pixel(dtype, batch_size):
+    from sleap_amd.nn.inference import SingleInstancePredictor, load_model
+
+    frames, _, gt = robot_golden()
+    want, want_vals, want_cms = oracle_robot_predictions(frames)
+    p = load_model(MODEL, batch_size=batch_size, dtype=dtype)
+    assert isinstance(p, SingleInstancePredictor) and not p.is_grayscale
+    assert p.inference_model.single_instance_layer.keras_model.dtype == dtype
+    outs = p.predict(frames, make_labels=False)
+    got = np.concatenate([o["instance_peaks"] for o in outs])
+    vals = np.concatenate([o["instance_peak_vals"] for o in outs])
+    assert got.shape == want.shape == (3, 1, 2, 2)
+    assert not np.isnan(got).any()
+    d = np.linalg.norm(got - want, axis=-1)
+    assert d.max() <= TOL_PX, (dtype, d)
+    # measured: fp16 <= 0.01 px, bf16 <= 0.1 px; confidence values within the storage type's error of the fp32 ones
+    assert d.max() <= (0.02 if dtype == "fp16" else 0.2), (dtype, d)
+    np.testing.assert_allclose(vals, want_vals, atol=4e-3 if dtype == "fp16" else 4e-2)
+    # and therefore the reference's own assertion holds for the device path wherever it holds for the oracle
+    for f in range(3):
+        for n in range(2):
+            if (f, n) != (0, 0):
+                np.testing.assert_allclose(got[f, 0, n], gt[0, n], atol=10.0)
+
+
+@pytest.mark.parametrize("dtype", ["fp16", "bf16"])
+def test_robot_confidence_maps_vs_oracle(dtype):
+    """The maps themselves (return_confmaps=True) against the fp32 oracle: the network half in isolation."""
+    from sleap_amd.nn.inference import load_model
+
+    frames, _, _ = robot_golden()
+    _, _, want_cms = oracle_robot_predictions(frames)
+    p = load_model(MODEL, batch_size=4, dtype=dtype)
+    layer = p.inference_model.single_instance_layer
+    layer.return_confmaps = True
+    outs = p.predict(frames, make_labels=False)
+    cms = np.concatenate([o["confmaps"] for o in outs])
+    assert cms.shape == want_cms.shape
+    err = float(np.abs(cms - want_cms).max() / np.abs(want_cms).max())
+    assert err <= (3e-3 if dtype == "fp16" else 3e-2), err
+
+
+def test_labels_from_robot_frames_match_reference_structure():
+    """predict(..., make_labels=True): 3 labelled frames with one 2-node instance each (the reference's
+    `len(labels_pr[0].instances) == 1`, test_inference.py:602-603), scores = nansum of the point confidences
+    (inference.py:1578)."""
+    from sleap_amd.nn.inference import load_model
+
+    frames, _, _ = robot_golden()
+    want, want_vals, _ = oracle_robot_predictions(frames)
+    labels = load_model(MODEL, batch_size=4).predict(frames)
+    assert len(labels) == 3
+    for f in range(3):
+        assert len(labels[f].instances) == 1
+        np.testing.assert_allclose(labels[f][0].numpy(), want[f, 0], atol=TOL_PX)
+        np.testing.assert_allclose(labels[f][0].score, np.nansum(want_vals[f, 0]), atol=1e-2)

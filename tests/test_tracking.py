@@ -236,3 +236,143 @@ def test_max_tracks_matching_queue(max_tracks):
     b, nb = _run_native(frames, (1, 1), **kw)
     _compare(a, b)
     assert nb == len(tr.spawned_tracks)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# What reaches the tracker from a prediction dict (inference.py:2641-2668, 3283-3313): all-NaN instances never do, bottom-up
+# `max_instances` is applied (by score, stable) BEFORE tracking, `t` follows frame_ind.
+# ---------------------------------------------------------------------------------------------------------------------------
+def _example_from(frames, n_nodes=6, nan_slots=()):
+    """frames (list of instance lists) -> prediction dict with NaN-padded arrays; `nan_slots` = {(frame, slot)} of all-NaN
+    instances inserted in the MIDDLE of the valid range (what the top-down model emits for a crop with no node above the
+    threshold)."""
+    rows = []
+    for f, insts in enumerate(frames):
+        lst = list(insts)
+        for (ff, slot) in sorted(nan_slots):
+            if ff == f:
+                lst.insert(min(slot, len(lst)), (np.full((n_nodes, 2), np.nan, np.float32),
+                                                 np.full((n_nodes,), np.nan, np.float32), np.float32(0.9)))
+        rows.append(lst)
+    I = max(len(r) for r in rows)
+    F = len(rows)
+    ex = {"instance_peaks": np.full((F, I, n_nodes, 2), np.nan, np.float32),
+          "instance_peak_vals": np.full((F, I, n_nodes), np.nan, np.float32),
+          "instance_scores": np.full((F, I), np.nan, np.float32), "n_valid": np.zeros((F,), np.int64),
+          "frame_ind": np.arange(F, dtype=np.int64), "video_ind": np.zeros((F,), np.int64)}
+    for f, lst in enumerate(rows):
+        ex["n_valid"][f] = len(lst)
+        for i, (p, s, c) in enumerate(lst):
+            ex["instance_peaks"][f, i], ex["instance_peak_vals"][f, i], ex["instance_scores"][f, i] = p, s, c
+    return ex, rows
+
+
+def _oracle_over_rows(rows, img_hw, max_instances=None, t_of=None, **kw):
+    """The reference's loop: drop all-NaN, optional sorted-by-score truncation, tracker.track(t=frame_ind)."""
+    tr = T.Tracker(**kw)
+    out = []
+    for f, lst in enumerate(rows):
+        insts = [T.Inst(p, s, c, uid=i) for i, (p, s, c) in enumerate(lst) if not np.isnan(p).all()]
+        if max_instances is not None:
+            insts = sorted(insts, key=lambda a: a.score, reverse=True)[: min(max_instances, len(insts))]
+        res = tr.track(insts, img_hw=img_hw, t=None if t_of is None else int(t_of[f]))
+        out.append([(r.uid, r.track) for r in res])
+    return out, tr
+
+
+@pytest.mark.parametrize("kw", [dict(tracker="simple", similarity="instance", match="greedy"),
+                                dict(tracker="simple", similarity="normalized_instance", match="hungarian", robust=0.9),
+                                dict(tracker="simplemaxtracks", similarity="iou", match="hungarian", max_tracks=4,
+                                     max_tracking=True)])
+def test_all_nan_instances_never_reach_the_tracker(kw):
+    from sleap_amd.nn.tracking import Tracker, track_example
+
+    frames = _sequence(11, n_frames=25)
+    nan_slots = {(2, 1), (5, 0), (6, 2), (7, 1), (12, 1), (20, 3)}
+    ex, rows = _example_from(frames, nan_slots=nan_slots)
+    want, otr = _oracle_over_rows(rows, (200, 220), t_of=ex["frame_ind"], **kw)
+    tr = Tracker.make_tracker_by_name(**kw)
+    track_example(tr, ex, img_hw=(200, 220))
+    for f, lst in enumerate(want):
+        got = sorted((int(ex["track_order"][f, i]), i, int(ex["track_inds"][f, i])) for i in range(ex["track_inds"].shape[1])
+                     if ex["track_order"][f, i] >= 0)
+        assert [(i, t) for _, i, t in got] == lst, f"frame {f}"
+    for (f, slot) in nan_slots:
+        assert ex["track_inds"][f, slot] == -1 and ex["track_order"][f, slot] == -1
+    assert len(tr.spawned_tracks) == len(otr.spawned_tracks)
+    # and a control: feeding the NaN instances unfiltered changes the numbering (or makes the Hungarian cost matrix infeasible)
+    from sleap_amd._lib import SleapAmdError
+
+    ex2, _ = _example_from(frames, nan_slots=nan_slots)
+    tr2 = Tracker.make_tracker_by_name(**kw)
+    try:
+        r = tr2.track_frames(ex2["instance_peaks"], ex2["instance_peak_vals"], ex2["instance_scores"], ex2["n_valid"],
+                             img_hw=(200, 220), t0=0)
+        assert len(tr2.spawned_tracks) != len(tr.spawned_tracks) or (r["track"] != ex["track_inds"]).any()
+    except SleapAmdError as e:
+        assert "infeasible" in str(e)
+
+
+def test_max_instances_is_applied_before_tracking_and_survives_to_the_tables():
+    from sleap_amd.io import slp
+    from sleap_amd.nn.tracking import Tracker, finish_tracks, track_example
+
+    kw = dict(tracker="simple", similarity="instance", match="greedy")
+    frames = _sequence(12, n_frames=20, p_extra=0.5)
+    ex, rows = _example_from(frames)
+    want, _ = _oracle_over_rows(rows, (1, 1), max_instances=2, t_of=ex["frame_ind"], **kw)
+    tr = Tracker.make_tracker_by_name(**kw)
+    track_example(tr, ex, img_hw=(1, 1), max_instances=2)
+    finish_tracks([ex], tr)
+    t = slp.build_tables([ex], max_instances=2)
+    for f, lst in enumerate(want):
+        a, b = int(t["frames"]["instance_id_start"][f]), int(t["frames"]["instance_id_end"][f])
+        assert b - a == len(lst) <= 2
+        got_tracks = [int(t["tracks"][k]) for k in t["instances"]["track"][a:b]]
+        assert got_tracks == [trk for _, trk in lst], f"frame {f}"
+        # the rows written are the instances the oracle tracked, in its order
+        for k, (uid, _) in enumerate(lst):
+            np.testing.assert_array_equal(t["instances"]["score"][a + k], rows[f][uid][2])
+
+
+def test_tracker_time_follows_frame_ind():
+    """A reader over a subset of frames (VideoReader(example_indices=...)): `t` is the frame index, not position."""
+    from sleap_amd.nn.tracking import Tracker, track_example
+
+    frames = _sequence(13, n_frames=12)
+    ex, rows = _example_from(frames)
+    ex["frame_ind"] = np.array([0, 1, 2, 10, 11, 12, 30, 31, 40, 50, 51, 52], np.int64)
+    kw = dict(tracker="simple", similarity="centroid", match="hungarian")
+    want, otr = _oracle_over_rows(rows, (1, 1), t_of=ex["frame_ind"], **kw)
+    tr = Tracker.make_tracker_by_name(**kw)
+    track_example(tr, ex)
+    for f, lst in enumerate(want):
+        got = sorted((int(ex["track_order"][f, i]), i, int(ex["track_inds"][f, i])) for i in range(ex["track_inds"].shape[1])
+                     if ex["track_order"][f, i] >= 0)
+        assert [(i, t) for _, i, t in got] == lst
+
+
+def test_instance_scores_for_topdown_and_single_instance_outputs():
+    """inference.py:2639-2660 (top-down: instance score = centroid confidence) and :1578 (single instance: nansum of the
+    point confidences) -- what Labels / .slp files store as `score` and what the tracker's culling ranks by."""
+    from sleap_amd.io import slp
+    from sleap_amd.nn.inference import Predictor
+
+    rng = np.random.default_rng(0)
+    p = Predictor.__new__(Predictor)
+    p.tracker = None
+    pk = rng.random((3, 2, 4, 2)).astype(np.float32)
+    pv = rng.random((3, 2, 4)).astype(np.float32)
+    pv[1, 0, 2] = np.nan
+    cv = rng.random((3, 2)).astype(np.float32)
+    base = {"instance_peaks": pk, "instance_peak_vals": pv, "n_valid": np.array([2, 2, 1]), "frame_ind": np.arange(3),
+            "video_ind": np.zeros(3, np.int64)}
+    td = p._apply_tracker([dict(base, centroids=pk[:, :, 0], centroid_vals=cv)])
+    np.testing.assert_array_equal(td[0]["instance_scores"], cv)
+    t = slp.build_tables(td)
+    np.testing.assert_array_equal(t["instances"]["score"], [cv[0, 0], cv[0, 1], cv[1, 0], cv[1, 1], cv[2, 0]])
+    si = p._apply_tracker([dict(base)])
+    np.testing.assert_allclose(si[0]["instance_scores"], np.nansum(pv, axis=-1))
+    assert np.isfinite(si[0]["instance_scores"]).all()
+    bu = p._apply_tracker([dict(base, instance_scores=cv * 2)])
+    np.testing.assert_array_equal(bu[0]["instance_scores"], cv * 2)  # a model that emits scores keeps them
