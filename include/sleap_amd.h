@@ -224,6 +224,15 @@ int sa_conv3x3_heads_bf16(const void* src0, int C0P, const void* src1, int C1P, 
                           const float* const* head_w, const float* const* head_b, const int* head_c,
                           const int* head_act, float* const* head_dst, sa_stream_t stream);
 
+/* Launch policy of the 3x3 MFMA kernels (process-wide, HOST). By default a layer with more tiles than the chip holds
+ * workgroups is launched PERSISTENT: occupancy x CUs workgroups, each walking its share of the (frame, tile, cout-tile)
+ * list with the first chunk of its next tile prefetched into the idle LDS stage while the current tile's epilogue runs.
+ *   n  > 0  launch at most n workgroups in total (tests: a handful of workgroups over many tiles, uneven tails)
+ *   n == 0  automatic (default; SA_CONV_PERSIST=0 in the environment = one workgroup per tile, =k = k workgroups per CU)
+ *   n  < 0  one workgroup per tile
+ * Returns the previous value. Results do not depend on it (each tile's arithmetic is the same). */
+int sa_conv3x3_set_grid_limit(int n);
+
 /* HOST helper: Keras Conv2D kernel (3,3,Cin,Cout) f32 -> the packed bf16 layout above. The input
  * channel axis is the concatenation [C0 | C1]; each part is zero-padded to C0P / C1P. */
 int sa_pack_conv3x3_weights(const float* keras_kernel, int C0, int C0P, int C1, int C1P, int Cout,
@@ -361,6 +370,64 @@ int sa_tracker_track_frames(void* tracker, int n_frames, int max_inst, int n_nod
 
 /* connect_single_track_breaks (components.py:419-466) in place on a [F, I] track table (-1 = empty slot). */
 int sa_connect_single_track_breaks(int n_frames, int max_inst, const int* order, int* track, int instance_count);
+
+/* ------------------------------------------------------------------------------------------------
+ * Whole network / whole layer in one call -- replaces `keras_model(imgs)` (sleap/nn/inference.py:2864-2890) and
+ * `BottomUpInferenceLayer.call` (:2938-3003) for one batch. A non-Python host runs the hot path through these alone.
+ *
+ * `plan` (HOST, int64 words) is the launch plan `sleap_amd.nn.engine.DeviceNetwork` compiles from the Keras graph of
+ * `best_model.h5` (`DeviceNetwork.plan_words()`): buffer table, output table and one record per fused launch. It is
+ * process-local: weight operands appear as DEVICE ADDRESSES of tensors the caller uploaded (packed with the sa_pack_* helpers)
+ * and keeps alive while the handle exists. The handle itself owns no device memory.
+ *   workspace   caller-owned device scratch of sa_network_workspace_bytes(net, B, H, W) bytes holding every stored activation
+ *               tensor of the plan (256-byte aligned slots); zero it once after allocation
+ *   outputs     HOST array of sa_network_n_outputs(net) device pointers, model-output order (`keras_model.output_names`):
+ *               [B, h, w, c] float32 each (sa_network_output_shape). 1x1 heads are written there directly; a 16-bit feature
+ *               tensor that is a model output is converted. An entry may be NULL (head kept in the workspace, see
+ *               sa_network_buffer).
+ *   images      [B,H,W,C] uint8 (`images_are_u8`) or float32 in [0,1]; H, W multiples of sa_network_max_stride(net)
+ * Nothing is allocated or synchronised; all launches go to `stream`. Errors: SA_ERR_INVALID_ARG (shape / channel mismatch),
+ * SA_ERR_WORKSPACE (workspace too small), plus whatever a layer entry point reports. */
+typedef struct sa_network sa_network_t;
+int sa_network_create(const int64_t* plan, size_t n_words, sa_network_t** out);
+void sa_network_destroy(sa_network_t* net);
+int sa_network_n_outputs(const sa_network_t* net);
+int sa_network_in_channels(const sa_network_t* net);
+int sa_network_max_stride(const sa_network_t* net);
+int sa_network_output_shape(const sa_network_t* net, int index, int H, int W, int* h, int* w, int* c);
+size_t sa_network_workspace_bytes(const sa_network_t* net, int B, int H, int W);
+void* sa_network_buffer(const sa_network_t* net, int buf, int B, int H, int W, void* workspace, int* h, int* w, int* cp,
+                        int* is_f32);
+int sa_network_forward(const sa_network_t* net, const void* images, int images_are_u8, int B, int H, int W, int C,
+                       float* const* outputs, void* workspace, size_t ws_bytes, sa_stream_t stream);
+
+/* Parameters of BottomUpInferenceLayer + PAFScorer (inference.py:2793-2860, paf_grouping.py:1318-1404) for
+ * sa_bottomup_predict. `edges` [n_edges][2] and `sorted_edge_inds` [n_sorted] are DEVICE int32 tables (skeleton edge node
+ * indices; PAFScorer.sorted_edge_inds). */
+typedef struct sa_bottomup_params {
+  int confmaps_ind, pafs_ind, offsets_ind; /* model-output indices (find_head); offsets_ind = -1 without the head */
+  float peak_threshold;                    /* 0.2 */
+  int refinement;                          /* SA_REFINE_INTEGRAL / SA_REFINE_LOCAL / SA_REFINE_NONE */
+  int integral_patch_size;                 /* 5 */
+  float cm_output_stride, pafs_stride;
+  int n_nodes, n_edges;
+  const int32_t* edges;
+  const int32_t* sorted_edge_inds;
+  int n_sorted;
+  float max_edge_length_ratio, dist_penalty_weight; /* 0.25, 1.0 */
+  int n_points;                                     /* 10 */
+  float min_line_scores;                            /* 0.25 */
+  int min_instance_peaks;                           /* 0 */
+  int max_peaks, max_node_peaks, max_instances;     /* capacities of the fixed-shape buffers (status bits report overflow) */
+} sa_bottomup_params;
+
+size_t sa_bottomup_workspace_bytes(const sa_network_t* net, const sa_bottomup_params* params, int B, int H, int W);
+/* -> instance_peaks [B,max_instances,n_nodes,2] f32 (NaN padded, image pixels of the network input), instance_peak_vals
+ * [B,max_instances,n_nodes], instance_scores [B,max_instances], n_instances [B] i32, status [B] i32 (SA_STATUS_* bits; zeroed
+ * here). The +0.5 / input_scale un-scaling of inference.py:2985-2990 is the caller's (it applies only when input_scale != 1). */
+int sa_bottomup_predict(const sa_network_t* net, const sa_bottomup_params* params, const void* images, int images_are_u8, int B,
+                        int H, int W, int C, float* instance_peaks, float* instance_peak_vals, float* instance_scores,
+                        int32_t* n_instances, int32_t* status, void* workspace, size_t ws_bytes, sa_stream_t stream);
 
 #ifdef __cplusplus
 }

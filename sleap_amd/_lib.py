@@ -50,6 +50,7 @@ SIGNATURES = {
     "sa_conv3x3_heads_bf16": (_i, [_p, _i, _p, _i, _i, _p, _p, _i, _i, _i, _i, _i, _p, _i, _p, _p, _p, _p, _p, _p]),
     "sa_pack_conv3x3_weights": (_i, [_p, _i, _i, _i, _i, _i, _i, _p]),
     "sa_conv3x3_packed_elems": (_sz, [_i, _i, _i]),
+    "sa_conv3x3_set_grid_limit": (_i, [_i]),
     "sa_convt3x3s2_bf16": (_i, [_p, _i, _p, _p, _i, _i, _i, _i, _i, _p, _p]),
     "sa_image_conv_bf16": (_i, [_p, _i, _i, _i, _i, _i, _i, _p, _i, _i, _i, _i, _i, _i, _i, _p, _p, _i, _i, _p, _p, _p, _p]),
     "sa_imgconv_packed_elems": (C.c_size_t, [_i, _i, _i]),
@@ -76,6 +77,17 @@ SIGNATURES = {
     "sa_resize_bilinear_f32": (_i, [_p, _i, _i, _i, _i, _i, _i, _p, _p]),
     "sa_f32_to_bf16_padded": (_i, [_p, _i, _i, _i, _p, _p]),
     "sa_bf16_to_f32": (_i, [_p, _i, _i, _i, _p, _p]),
+    "sa_network_create": (_i, [_p, _sz, _p]),
+    "sa_network_destroy": (None, [_p]),
+    "sa_network_n_outputs": (_i, [_p]),
+    "sa_network_in_channels": (_i, [_p]),
+    "sa_network_max_stride": (_i, [_p]),
+    "sa_network_output_shape": (_i, [_p, _i, _i, _i, _p, _p, _p]),
+    "sa_network_workspace_bytes": (_sz, [_p, _i, _i, _i]),
+    "sa_network_buffer": (_p, [_p, _i, _i, _i, _i, _p, _p, _p, _p, _p]),
+    "sa_network_forward": (_i, [_p, _p, _i, _i, _i, _i, _i, _p, _p, _sz, _p]),
+    "sa_bottomup_workspace_bytes": (_sz, [_p, _p, _i, _i, _i]),
+    "sa_bottomup_predict": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _sz, _p]),
 }
 
 _lib = None

@@ -29,6 +29,7 @@ SOURCES = [
     ("convpair.hip", ["-fno-honor-nans"]),
     ("imgconv.hip", ["-fno-honor-nans", "-std=c++20", "-mllvm", "-amdgpu-mfma-vgpr-form"]),
     ("tracker.hip", []),
+    ("network.hip", []),
 ]
 COMMON = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function"]
 

@@ -97,6 +97,11 @@ __device__ __forceinline__ float up2_lerp(float tl, float tr, float bl, float br
   return t + (b - t) * wy;
 }
 
+// four floats at dword alignment: stored with one global_store_dwordx4 (gfx950 global accesses need dword alignment only)
+struct __attribute__((packed, aligned(4))) f32x4_unaligned {
+  float x, y, z, w;
+};
+
 #if defined(__HIP_DEVICE_COMPILE__)
 // value of the neighbouring lane (lane ^ 1) through DPP quad_perm [1,0,3,2]: no LDS crossbar (ds_bpermute) involved
 __device__ __forceinline__ float dpp_xor1(float v) {

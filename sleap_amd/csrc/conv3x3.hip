@@ -23,6 +23,8 @@
 
 namespace {
 
+int g_grid_limit = 0;  // sa_conv3x3_set_grid_limit
+
 using sa::h16x8_t;
 using sa::mfma_h8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
@@ -266,7 +268,7 @@ __device__ __forceinline__ int swz(int p) {
 // (verified by tools/probes/buffer_lds_oob.hip) -- SAME padding costs nothing; the chunk's channel offset and
 // the weight-slab offset travel in the scalar offset, so issuing a copy is one SALU add + one VMEM instruction.
 template <int MT, int CK, int NW, int R, int NBUF, bool HEADS, int STEM_CIN, bool EXT>
-__global__ void __launch_bounds__(NW * 64)
+__global__ void __launch_bounds__(NW * 64, (NW == 8 && MT <= 2 && NBUF == 2 && !EXT && CK == 16 && STEM_CIN == 0) ? 4 : 1)
 conv3x3_dma_kernel(const ConvParams2 p) {
 #if defined(__HIP_DEVICE_COMPILE__)  // the body uses device-only types (buffer resources); the host pass only needs the stub
   constexpr int TH = NW * R, TW = 32, PH = TH + 2, PW = TW + 2;
@@ -284,67 +286,89 @@ conv3x3_dma_kernel(const ConvParams2 p) {
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  // XCD-aware block order: hardware places block i on XCD i % 8; give every XCD a contiguous range of logical
-  // tiles so that the cout tiles / neighbouring spatial tiles that re-read the same input share one L2.
-  int bid;
-  {
-    const int nblk = gridDim.x, q = nblk >> 3, r = nblk & 7, xcd = blockIdx.x & 7, k = blockIdx.x >> 3;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
-  }
-  const int co_t = bid % p.co_tiles;
-  bid /= p.co_tiles;
-  const int tx_i = bid % p.tiles_x;
-  bid /= p.tiles_x;
-  const int ty_i = bid % p.tiles_y;
-  const int b = bid / p.tiles_y;
-  const int x0 = tx_i * TW, y0 = ty_i * TH;
   const int H = p.H, W = p.W;
   const int CinP = p.C0P + p.C1P;
   const int K16 = CinP / 16;
-  const int co32_0 = co_t * MT;
   const int co32_n = (p.CoutP + 31) / 32;
+  // Tile schedule. Logical tiles 0..n_tiles-1 are ordered (frame, tile row, tile column, cout tile) and split into 8
+  // contiguous ranges, one per XCD (hardware places block i on XCD i % 8): the cout tiles / neighbouring spatial tiles that
+  // re-read the same input share one L2. A workgroup is PERSISTENT when the host launches fewer workgroups than tiles: the
+  // j-th workgroup of an XCD (of g8 there) walks tiles start + j, start + j + g8, ... of its XCD's range, and while it runs
+  // the last chunk of one tile the first chunk of its next tile is already being copied into the idle LDS stage -- the
+  // epilogue (convert / permute / stores) of tile t overlaps the HBM latency of tile t+1 instead of being followed by a
+  // workgroup teardown, a launch, address set-up and an exposed first copy (measured as ~2.9 chunk-times per tile: 72 % on
+  // top of a 4-chunk layer). With gridDim == n_tiles every workgroup has exactly one tile (g8 == the range length).
+  const int n_tiles = p.co_tiles * p.tiles_x * p.tiles_y * p.B;
+  int L, L_end, L_step;
+  {
+    const int q = n_tiles >> 3, r = n_tiles & 7, xcd = blockIdx.x & 7, k = blockIdx.x >> 3;
+    const int start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    L_step = ((int)gridDim.x - xcd + 7) >> 3;
+    L = start + k;
+    L_end = start + q + (xcd < r ? 1 : 0);
+  }
+  if (L >= L_end) return;  // wave-uniform
+  struct Tile {
+    int co32_0, x0, y0, b;
+  };
+  auto decode = [&](int l) {
+    Tile t;
+    t.co32_0 = (l % p.co_tiles) * MT;
+    l /= p.co_tiles;
+    t.x0 = (l % p.tiles_x) * TW;
+    l /= p.tiles_x;
+    t.y0 = (l % p.tiles_y) * TH;
+    t.b = l / p.tiles_y;
+    return t;
+  };
+  Tile cur = decode(L);
 
   // ---- buffer descriptors (wave-uniform): one frame of each source, the packed weights
   const size_t f0 = (size_t)H * W * p.C0P * 2, f1 = (size_t)H * W * p.C1P * 2;
-  const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)(STEM_CIN ? reinterpret_cast<const unsigned char*>(p.w) : reinterpret_cast<const unsigned char*>(p.src0) + b * f0), 0,
-      (int)f0, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)(p.C1P ? reinterpret_cast<const unsigned char*>(p.src1) + b * f1 : reinterpret_cast<const unsigned char*>(p.w)), 0,
-      (int)f1, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(
       (void*)p.w, 0, (int)((size_t)co32_n * K16 * 9 * 1024), 0x00020000);
 
-  // ---- per-lane byte offsets of this wave's input copies inside a frame (same for every chunk)
-  unsigned voff0[IN_PER_WAVE], voff1[IN_PER_WAVE];
+  // ---- per-lane byte offsets of this wave's input copies inside a frame (same for every chunk of a tile)
+  // `ln` = the lane id; inside the tile loop it is passed through an opaque asm so that the compiler re-derives these few
+  // per-lane values per tile instead of hoisting a dozen of them into registers that stay live across the MFMA loop
+  auto make_voff = [&](const Tile& t, int ln, unsigned (&v0)[IN_PER_WAVE], unsigned (&v1)[IN_PER_WAVE]) {
 #pragma unroll
-  for (int j = 0; j < IN_PER_WAVE; ++j) {
-    const int i = j * NW + wave;
-    const int o = i * 1024 + lane * 16;
-    const int pl = o / PIXB, s = (o % PIXB) / 16;
-    const int ty = pl / PW, tx = pl - ty * PW;
-    const int gy = y0 + ty - 1, gx = x0 + tx - 1;
-    const bool ok = (i < N_IN) && (pl < PH * PW) && gy >= 0 && gy < H && gx >= 0 && gx < W;
-    const unsigned pix = (unsigned)(gy * W + gx);
-    const unsigned q16 = (unsigned)((s ^ swz<CK>(pl)) * 16);
-    voff0[j] = ok ? pix * (unsigned)(p.C0P * 2) + q16 : OOB;
-    voff1[j] = ok ? pix * (unsigned)(p.C1P * 2) + q16 : OOB;
-  }
+    for (int j = 0; j < IN_PER_WAVE; ++j) {
+      const int i = j * NW + wave;
+      const int o = i * 1024 + ln * 16;
+      const int pl = o / PIXB, s = (o % PIXB) / 16;
+      const int ty = pl / PW, tx = pl - ty * PW;
+      const int gy = t.y0 + ty - 1, gx = t.x0 + tx - 1;
+      const bool ok = (i < N_IN) && (pl < PH * PW) && gy >= 0 && gy < H && gx >= 0 && gx < W;
+      const unsigned pix = (unsigned)(gy * W + gx);
+      const unsigned q16 = (unsigned)((s ^ swz<CK>(pl)) * 16);
+      v0[j] = ok ? pix * (unsigned)(p.C0P * 2) + q16 : OOB;
+      v1[j] = ok ? pix * (unsigned)(p.C1P * 2) + q16 : OOB;
+    }
+  };
+  unsigned voff0[IN_PER_WAVE], voff1[IN_PER_WAVE];
+  make_voff(cur, lane, voff0, voff1);
   const unsigned wv = (unsigned)lane * 16;
 
-  auto issue = [&](int chunk, int buf) {
+  auto issue = [&](const Tile& t, const unsigned (&v0)[IN_PER_WAVE], const unsigned (&v1)[IN_PER_WAVE], int chunk, int buf) {
     const int c_lo = chunk * CK;
     const bool from1 = c_lo >= p.C0P;
     const int cc2 = (from1 ? c_lo - p.C0P : c_lo) * 2;
     unsigned char* stage = smem + buf * STAGE;
+    const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(STEM_CIN ? reinterpret_cast<const unsigned char*>(p.w) : reinterpret_cast<const unsigned char*>(p.src0) + t.b * f0), 0,
+        (int)f0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(p.C1P ? reinterpret_cast<const unsigned char*>(p.src1) + t.b * f1 : reinterpret_cast<const unsigned char*>(p.w)), 0,
+        (int)f1, 0x00020000);
 #pragma unroll
     for (int j = 0; j < IN_PER_WAVE; ++j) {
       const int i = j * NW + wave;
       if (STEM_CIN == 0 && i < N_IN) {
         if (from1)
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, (lds_ptr_t)(stage + i * 1024), 16, voff1[j], cc2, 0, 0);
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, (lds_ptr_t)(stage + i * 1024), 16, v1[j], cc2, 0, 0);
         else
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, (lds_ptr_t)(stage + i * 1024), 16, voff0[j], cc2, 0, 0);
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, (lds_ptr_t)(stage + i * 1024), 16, v0[j], cc2, 0, 0);
       }
     }
 #pragma unroll
@@ -353,7 +377,7 @@ conv3x3_dma_kernel(const ConvParams2 p) {
       if (k < N_W) {
         const int m = k / (KK * 9), rest = k - m * (KK * 9);
         // cout tiles beyond CoutP read out of range -> zeros
-        const int soff = (co32_0 + m < co32_n) ? (((co32_0 + m) * K16 + chunk * KK) * 9 + rest) * 1024 : (int)0x7FFFF000;
+        const int soff = (t.co32_0 + m < co32_n) ? (((t.co32_0 + m) * K16 + chunk * KK) * 9 + rest) * 1024 : (int)0x7FFFF000;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_ptr_t)(stage + IN_BYTES + k * 1024), 16, wv, soff, 0, 0);
       }
     }
@@ -363,27 +387,33 @@ conv3x3_dma_kernel(const ConvParams2 p) {
   // epilogue saves one add per value); single-chunk kernels are latency-bound on their prologue and add it at the end.
   constexpr bool BIAS_INIT = (NBUF == 2);
   f32x16 acc[MT][R];
+  auto init_acc = [&](const Tile& t) {
+    int ln_i = lane;
+    asm volatile("" : "+v"(ln_i));
 #pragma unroll
-  for (int m = 0; m < MT; ++m) {
+    for (int m = 0; m < MT; ++m) {
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      float4 bq = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-      if constexpr (BIAS_INIT) {
-        const int co = (co32_0 + m) * 32 + 8 * g + 4 * (lane >> 5);
-        if (co < p.CoutP) bq = *reinterpret_cast<const float4*>(p.bias + co);
-      }
+      for (int g = 0; g < 4; ++g) {
+        float4 bq = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if constexpr (BIAS_INIT) {
+          const int co = (t.co32_0 + m) * 32 + 8 * g + 4 * (ln_i >> 5);
+          if (co < p.CoutP) bq = *reinterpret_cast<const float4*>(p.bias + co);
+        }
 #pragma unroll
-      for (int r = 0; r < R; ++r) {
-        acc[m][r][4 * g + 0] = bq.x;
-        acc[m][r][4 * g + 1] = bq.y;
-        acc[m][r][4 * g + 2] = bq.z;
-        acc[m][r][4 * g + 3] = bq.w;
+        for (int r = 0; r < R; ++r) {
+          acc[m][r][4 * g + 0] = bq.x;
+          acc[m][r][4 * g + 1] = bq.y;
+          acc[m][r][4 * g + 2] = bq.z;
+          acc[m][r][4 * g + 3] = bq.w;
+        }
       }
     }
-  }
+  };
 
   const int n_chunks = CinP / CK;
-  issue(0, 0);
+  issue(cur, voff0, voff1, 0, 0);
+  const int x0 = cur.x0, y0 = cur.y0, b = cur.b;  // the fused first layer (STEM_CIN > 0) is never persistent
+  (void)x0, (void)y0, (void)b;
   if constexpr (STEM_CIN > 0) {
     // First conv on the raw image, written as bf16 straight into the swizzled LDS tile of the second conv.
     // Halo pixels outside the image are ZERO (the second conv's SAME padding pads the first conv's OUTPUT); the
@@ -533,11 +563,49 @@ conv3x3_dma_kernel(const ConvParams2 p) {
     }
   }
   int buf = 0;
-  const int half = lane >> 5, lx = lane & 31;
+  // LDS byte offsets (inside a stage) of this lane's B fragments for k-step 0: halo row wave*R + (r + dy) in 0..R+1,
+  // column lane&31 + dx; one register each (left to the compiler, pixel offset and swizzled slot are kept apart: 2 x 12
+  // registers, which with the tile loop around everything spills into the MFMA loop). k-step kk flips bit 1 of the slot:
+  // (2 kk + half) ^ swz == (half ^ swz) ^ 2 kk, i.e. the byte offset ^ 32 kk (pixel offsets are multiples of 2 CK >= 64 there).
+  unsigned boff[R + 2][3];
+  {
+    const int half_m = lane >> 5, lx_m = lane & 31;
+#pragma unroll
+    for (int rr = 0; rr < R + 2; ++rr)
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) {
+        const int pl = (wave * R + rr) * PW + lx_m + dx;
+        boff[rr][dx] = (unsigned)(pl * PIXB + ((half_m ^ swz<CK>(pl)) * 16));
+        asm volatile("" : "+v"(boff[rr][dx]));  // keep it ONE register (the optimiser re-splits the sum otherwise)
+      }
+  }
+#pragma clang loop unroll(disable)
+  for (;;) {  // ---- tiles of this workgroup
+  init_acc(cur);
+  const int L_next = L + L_step;
+  // Persistent variants: only where ONE workgroup fits per CU (MT = 4: the 128-channel fused-head layer). Measured on MI355X
+  // (profiles/r02_persistent_ab.md): there the cross-tile prefetch removes an exposed launch + first-copy latency per tile
+  // (0.416 -> 0.393 ms); with two workgroups per CU the other workgroup already covers that gap, and the persistent loop
+  // only adds a wait for the epilogue's STORES (vmcnt counts them together with the copies) in front of every tile: 2-9 %
+  // slower on every MT <= 2 layer, most on the HBM-bound 256x256 ones. Those keep one tile per workgroup.
+  constexpr bool PERSIST = (NBUF == 2) && (STEM_CIN == 0) && !EXT && (CK == 16) && (MT == 4);
+  const bool more = PERSIST && L_next < L_end;  // wave-uniform
+  Tile nxt = cur;
+#pragma clang loop unroll(disable)
   for (int chunk = 0; chunk < n_chunks; ++chunk) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (NBUF == 2 && chunk + 1 < n_chunks) issue(chunk + 1, buf ^ 1);
+    if constexpr (NBUF == 2) {
+      if (chunk + 1 < n_chunks) {
+        issue(cur, voff0, voff1, chunk + 1, buf ^ 1);
+      } else if (more) {  // cross-tile prefetch: chunk 0 of the next tile lands while this tile's epilogue runs
+        nxt = decode(L_next);
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        make_voff(nxt, ln, voff0, voff1);  // this tile issues no more copies: its offsets are dead
+        issue(nxt, voff0, voff1, 0, buf ^ 1);
+      }
+    }
     const unsigned char* in_tile = smem + buf * STAGE;
     const unsigned char* w_tile = in_tile + IN_BYTES;
 #pragma unroll
@@ -551,9 +619,7 @@ conv3x3_dma_kernel(const ConvParams2 p) {
           a[m] = *reinterpret_cast<const mfma_h8*>(w_tile + ((m * KK + kk) * 9 + tap) * 1024 + lane * 16);
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-          const int pl = (wave * R + r + dy) * PW + lx + dx;
-          const int slot = (kk * 2 + half) ^ swz<CK>(pl);
-          const mfma_h8 bv = *reinterpret_cast<const mfma_h8*>(in_tile + pl * PIXB + slot * 16);
+          const mfma_h8 bv = *reinterpret_cast<const mfma_h8*>(in_tile + (boff[r + dy][dx] ^ (unsigned)(kk * 32)));
 #pragma unroll
           for (int m = 0; m < MT; ++m)
             acc[m][r] = SA_MFMA_32x32x16(a[m], bv, acc[m][r], 0, 0, 0);
@@ -564,9 +630,14 @@ conv3x3_dma_kernel(const ConvParams2 p) {
       buf ^= 1;
     } else if (chunk + 1 < n_chunks) {  // single stage: refill after everyone finished reading it
       __syncthreads();
-      issue(chunk + 1, 0);
+      issue(cur, voff0, voff1, chunk + 1, 0);
     }
   }
+  const int co32_0 = cur.co32_0, x0 = cur.x0, y0 = cur.y0, b = cur.b;
+  // the epilogue's per-lane constants are re-derived per tile (opaque copy of the lane id) for the same reason as above
+  int lane_e = lane;
+  asm volatile("" : "+v"(lane_e));
+  const int half = lane_e >> 5, lx = lane_e & 31;
 
   // ---- epilogue: bias + ReLU, bf16 pack. A lane holds channels {0-3, 8-11, 16-19, 24-27} + 4*half of its pixel;
   // exchanging one 8-byte group with the partner lane (lane ^ 32) per pair of groups gives every lane 8 CONSECUTIVE
@@ -660,7 +731,7 @@ conv3x3_dma_kernel(const ConvParams2 p) {
           pk[g].x = sa::f2h2(t4[0], t4[1]);
           pk[g].y = sa::f2h2(t4[2], t4[3]);
         }
-        const bool ok = !(lane & 1) && gy < H && gx < W;
+        const bool ok = !(lane_e & 1) && gy < H && gx < W;
         store_pieces(p.dst_pool + (((size_t)b * (H / 2) + (ok ? gy / 2 : 0)) * (W / 2) + (ok ? gx / 2 : 0)) * p.CoutP, ok, pk);
       }
     }
@@ -676,7 +747,7 @@ conv3x3_dma_kernel(const ConvParams2 p) {
   if constexpr (HEADS) {
     for (int hd = 0; hd < p.n_heads; ++hd) {
       const int NH = p.head_c[hd];
-      const int nrow = lane & 31;
+      const int nrow = lane_e & 31;
       f32x16 hacc[R];
 #pragma unroll
       for (int r = 0; r < R; ++r)
@@ -722,24 +793,50 @@ conv3x3_dma_kernel(const ConvParams2 p) {
           }
         }
       }
-      // D layout: lane holds head channels (reg&3) + 8*(reg>>2) + 4*half of pixel lane&31
+      // D layout: lane holds head channels (reg&3) + 8*(reg>>2) + 4*half of pixel lane&31, i.e. four runs of 4 CONSECUTIVE
+      // channels: one 16-byte store per complete run (the rows of a [.., NH] f32 tensor are only 4-byte aligned for odd NH;
+      // gfx950 global stores need dword alignment only), scalar stores for the ragged tail run. 13 channels: 2 stores per
+      // lane instead of 8 / 5 -- the epilogue of the head layers was store-issue bound.
+      float hb[4][4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int n = j + 8 * g + 4 * half;
+          hb[g][j] = n < NH ? p.head_b[hd][n] : 0.0f;
+        }
+      const bool sig = p.head_act[hd] == 1;
 #pragma unroll
       for (int r = 0; r < R; ++r) {
         const int gy = y0 + wave * R + r;
         const bool ok = gy < H && gx < W;
         float* out = p.head_dst[hd] + (((size_t)b * H + (ok ? gy : 0)) * W + (ok ? gx : 0)) * NH;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const int n = (i & 3) + 8 * (i >> 2) + 4 * half;
-          if (n < NH) {
-            float t = hacc[r][i] + p.head_b[hd][n];
-            if (p.head_act[hd] == 1) t = 1.0f / (1.0f + __expf(-t));
-            if (ok) out[n] = t;
+        for (int g = 0; g < 4; ++g) {
+          const int n0 = 8 * g + 4 * half;
+          float t[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            t[j] = hacc[r][4 * g + j] + hb[g][j];
+            if (sig) t[j] = 1.0f / (1.0f + __expf(-t[j]));
+          }
+          if (!ok) continue;
+          if (n0 + 4 <= NH) {
+            *reinterpret_cast<sa::f32x4_unaligned*>(out + n0) = sa::f32x4_unaligned{t[0], t[1], t[2], t[3]};
+          } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              if (n0 + j < NH) out[n0 + j] = t[j];
           }
         }
       }
     }
   }
+  // ---- next tile of this workgroup (its first chunk is in flight already when NBUF == 2)
+  if (!more) break;
+  cur = nxt;
+  L = L_next;
+  }  // tiles
 #endif
 }
 
@@ -770,7 +867,33 @@ int launch2(const ConvParams2& p, hipStream_t st) {
       if ((size_t)p.head_c[hd] * p.CoutP * 4 > lds || p.head_c[hd] > 32 || p.head_c[hd] < 1)
         return sa::fail(SA_ERR_UNSUPPORTED, "fused head %d: %d channels not supported", hd, p.head_c[hd]);
   }
-  hipLaunchKernelGGL((conv3x3_dma_kernel<MT, CK, NW, R, NBUF, HEADS, STEM_CIN, EXT>), dim3((unsigned)nblk), dim3(NW * 64), lds, st, q);
+  // Persistent launch for the double-buffered kernels: as many workgroups as the chip holds at once (occupancy x CUs), each
+  // walking its share of the tiles with the next tile's first chunk prefetched across the tile boundary (see the kernel).
+  // SA_CONV_PERSIST=0 launches one workgroup per tile (the pre-persistent behaviour, for A/B runs); SA_CONV_PERSIST=n (n > 0)
+  // forces n workgroups per CU.
+  size_t grid = nblk;
+  if (NBUF == 2 && STEM_CIN == 0 && !EXT && CK == 16 && MT == 4) {  // = PERSIST in the kernel
+    static const int persist = [] {
+      const char* v = getenv("SA_CONV_PERSIST");
+      return v ? atoi(v) : -1;
+    }();
+    static int per_cu = 0, n_cu = 0;
+    if (!n_cu) {
+      int dev = 0, nb = 0;
+      SA_HIP_CHECK(hipGetDevice(&dev));
+      SA_HIP_CHECK(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+      SA_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(
+          &nb, reinterpret_cast<const void*>(&conv3x3_dma_kernel<MT, CK, NW, R, NBUF, HEADS, STEM_CIN, EXT>), NW * 64, lds));
+      per_cu = nb > 0 ? nb : 1;
+    }
+    if (g_grid_limit > 0) {
+      if ((size_t)g_grid_limit < grid) grid = (size_t)g_grid_limit;
+    } else if (g_grid_limit == 0 && persist != 0) {
+      const size_t cap = (size_t)(persist > 0 ? persist : per_cu) * (size_t)n_cu;
+      if (cap < grid) grid = cap;
+    }
+  }
+  hipLaunchKernelGGL((conv3x3_dma_kernel<MT, CK, NW, R, NBUF, HEADS, STEM_CIN, EXT>), dim3((unsigned)grid), dim3(NW * 64), lds, st, q);
   SA_LAUNCH_CHECK();
   return SA_OK;
 }
@@ -924,6 +1047,12 @@ static int conv3x3_impl(const void* src0, int C0P, const void* src1, int C1P, in
 
 
 extern "C" {
+
+int sa_conv3x3_set_grid_limit(int n) {
+  const int prev = g_grid_limit;
+  g_grid_limit = n;
+  return prev;
+}
 
 size_t sa_conv3x3_packed_elems(int C0P, int C1P, int CoutP) {
   const size_t co32 = (CoutP + 31) / 32, k16 = (size_t)(C0P + C1P) / 16;

@@ -79,6 +79,18 @@ class LabeledFrame:
     def __len__(self):
         return len(self.instances)
 
+    def __getitem__(self, index):  # sleap/instance.py:1390-1392: `labeled_frame[i]` is its i-th instance
+        return self.instances[index]
+
+    def __iter__(self):
+        return iter(self.instances)
+
+    def numpy(self) -> np.ndarray:
+        """(n_instances, n_nodes, 2) with NaN for missing nodes (instance.py `LabeledFrame.numpy`)."""
+        if not self.instances:
+            return np.zeros((0, 0, 2), np.float32)
+        return np.stack([inst.numpy() for inst in self.instances])
+
 
 class Labels:
     def __init__(self, tables: Dict[str, np.ndarray], skeleton: Skeleton, video=None, track_names: Optional[Sequence[str]] = None,

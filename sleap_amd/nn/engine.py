@@ -667,16 +667,134 @@ class DeviceNetwork:
     def output_strides(self):
         return [o.den // o.num for o in self.outputs]
 
+    # ------------------------------------------------------------------ C executor (include/sleap_amd.h: sa_network_*)
+    PLAN_MAGIC = 0x53414E4554303031  # "SANET001"
+    _K = {"stem2": 1, "stem": 2, "conv": 3, "pair": 4, "conv1x1": 5, "convt2": 6, "convt": 7, "poolg": 8, "imgconv": 9,
+          "add": 10, "head": 11, "pool": 12, "up": 13}
+
+    def plan_words(self) -> np.ndarray:
+        """The compiled plan as the int64 word stream `sa_network_create` reads (csrc/network.hip): header, buffer table
+        (cp, num, den, kind: 0 = 16-bit, 1 = f32, 2 = virtual / shape only), output table, one record per launch. Weight operands
+        are the device addresses of tensors this object keeps alive -- the words are valid inside this process only."""
+        bufs = {i: [c, num, den, 1 if dt == "f32" else 0] for i, (c, num, den, dt) in self.buf_meta.items()}
+        n_ids = [max(list(bufs) + [-1]) + 1]
+        virtual = {}
+
+        def bid(t):
+            """buffer id of a plan tensor; tensors the fusion passes keep on chip get a virtual (shape-only) entry"""
+            if t is None:
+                return -1
+            if t.buf is not None:
+                return t.buf
+            if id(t) not in virtual:
+                virtual[id(t)] = n_ids[0]
+                bufs[n_ids[0]] = [t.cp, t.num, t.den, 2]
+                n_ids[0] += 1
+            return virtual[id(t)]
+
+        def dp(x):
+            return 0 if x is None else int(x.data_ptr())
+
+        ops = []
+        for op in self.plan:
+            k = op[0]
+            if k == "stem2":
+                _, (_k, so, w0, b0, cin, relu0, _n0), cv, w1_16 = op
+                a = [cin, dp(w0), dp(b0), so.cp, relu0, dp(cv.w), dp(cv.bias), cv.out.cp, cv.relu,
+                     bid(cv.out) if cv.need_full else -1, bid(cv.out_pool), dp(w1_16) if (w1_16 is not None and self.use_stem16) else 0]
+            elif k == "stem":
+                _, o, w, bias, cin, relu, _n0 = op
+                a = [bid(o), dp(w), dp(bias), cin, relu]
+            elif k == "conv":
+                a = [bid(op.src0), bid(op.src1), op.mode, dp(op.w), dp(op.bias), bid(op.out), op.relu, bid(op.out_pool),
+                     1 if op.need_full else 0, len(op.heads)]
+                for hd in op.heads:  # ("head", src, out, w, bias, activation)
+                    assert hd[3].shape[1] == op.out.cp
+                    a += [dp(hd[3]), dp(hd[4]), hd[2].c, hd[5], bid(hd[2])]
+                e = op.ext
+                a += [1, dp(e["ps"]), dp(e["pt"]), bid(e["res"]), e["res_mode"], e["relu_last"]] if e is not None else [0] * 6
+            elif k == "pair":
+                _, xa, yb = op
+                a = [bid(xa.src0), dp(xa.w), dp(xa.bias), xa.relu, xa.out.cp, dp(yb.w), dp(yb.bias), yb.relu, bid(yb.out),
+                     1 if yb.need_full else 0, bid(yb.out_pool)]
+            elif k == "conv1x1":
+                e = op.ext
+                a = [bid(op.src0), dp(op.w), dp(op.bias), op.relu, op.stride, 1 if e else 0, dp(e["ps"]) if e else 0,
+                     dp(e["pt"]) if e else 0, bid(e["res"]) if e else -1, e["relu_last"] if e else 0, bid(op.out)]
+            elif k == "convt2":
+                _, s_, phases, bias, o, relu, ksz, ext, _cin = op
+                a = [bid(s_)] + [dp(q) for q in phases] + [ksz, dp(bias), relu, 1 if ext else 0, dp(ext["ps"]) if ext else 0,
+                                                            dp(ext["pt"]) if ext else 0, ext["relu_last"] if ext else 0, bid(o)]
+            elif k == "convt":
+                _, s_, w, bias, o, relu = op
+                a = [bid(s_), dp(w), dp(bias), relu, bid(o)]
+            elif k == "poolg":
+                _, s_, o, kk, stride, pad, pad_zero = op
+                a = [bid(s_), bid(o), kk, stride, -1 if pad is None else pad, pad_zero]
+            elif k == "imgconv":
+                _, o, w, bias, cin, relu, _nm, kk, stride, ps, pt, cin_w, in_affine, pads, mf = op
+                a = [bid(o), dp(w), dp(bias), cin, relu, kk[0], kk[1], stride, dp(ps), dp(pt), cin_w, dp(in_affine),
+                     1 if pads is not None else 0, pads[0] if pads is not None else 0, pads[1] if pads is not None else 0,
+                     dp(mf["w"]) if mf else 0, dp(mf["bias"]) if mf else 0, mf["has_mean"] if mf else 0]
+            elif k == "add":
+                _, ta, tb, half, relu, o = op
+                a = [bid(ta), bid(tb), half, relu, bid(o)]
+            elif k == "head":
+                _, s_, o, w, bias, act = op
+                a = [bid(s_), dp(w), dp(bias), o.c, act, bid(o)]
+            elif k == "pool":
+                a = [bid(op[1]), bid(op[2])]
+            elif k == "up":
+                a = [bid(op[1]), bid(op[2]), op[3]]
+            else:
+                raise AssertionError(k)
+            ops.append([self._K[k], len(a)] + [int(v) for v in a])
+        words = [self.PLAN_MAGIC, n_ids[0], len(self.outputs), len(ops), int(self.in_channels), int(self.max_stride)]
+        for i in range(n_ids[0]):
+            words += bufs.get(i, [16, 1, 1, 2])  # ids the fusion passes retired: virtual placeholders
+        for o in self.outputs:
+            words += [o.buf, o.c, 1 if o.kind == "f32out" else 0]
+        for r in ops:
+            words += r
+        return np.asarray(words, dtype=np.int64)
+
+    def _handle(self):
+        """The `sa_network_t*` of this plan (created on first use; the plan is immutable after `_compile`)."""
+        if getattr(self, "_net", None) is None:
+            words = self.plan_words()
+            out = C.c_void_p()
+            check(self._h.sa_network_create(words.ctypes.data_as(C.c_void_p), words.size, C.byref(out)), "sa_network_create")
+            self._net = out
+        return self._net
+
+    def __del__(self):
+        net, self._net = getattr(self, "_net", None), None
+        if net:
+            try:
+                self._h.sa_network_destroy(net)
+            except Exception:  # noqa: BLE001 -- interpreter shutdown
+                pass
+
     # ------------------------------------------------------------------ run
     def _get_buffers(self, B, H, W):
+        """One device workspace per input shape (sa_network_workspace_bytes), zeroed once, kept resident; `bufs[i]` are typed
+        views of the plan's tensors inside it at the offsets the C executor uses (sa_network_buffer)."""
         key = (B, H, W)
         if key not in self._buffers:
+            net, h = self._handle(), self._h
+            n = int(h.sa_network_workspace_bytes(net, B, H, W))
+            ws = torch.zeros((max(n, 256),), dtype=torch.uint8, device=self.device)
             bufs = {}
             for i, (c_alloc, num, den, dt) in self.buf_meta.items():
-                h, w = H * num // den, W * num // den
+                hh, ww, cp, f32 = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+                addr = h.sa_network_buffer(net, i, B, H, W, _ptr(ws), C.byref(hh), C.byref(ww), C.byref(cp), C.byref(f32))
+                assert addr and (hh.value, ww.value, cp.value) == (H * num // den, W * num // den, c_alloc)
+                off = addr - ws.data_ptr()
                 dtype = self._tdtype if dt == "bf16" else torch.float32
-                bufs[i] = torch.zeros((B, h, w, c_alloc), dtype=dtype, device=self.device)
+                nbytes = B * hh.value * ww.value * c_alloc * (2 if dt == "bf16" else 4)
+                bufs[i] = ws[off:off + nbytes].view(dtype).view(B, hh.value, ww.value, c_alloc)
             self._buffers = {key: bufs}  # keep one shape resident
+            self._workspace = ws
             self._slot1 = {}
             self._range_checked = False
         return self._buffers[key]
@@ -798,6 +916,23 @@ class DeviceNetwork:
         bufs = self._slot_buffers(self._get_buffers(B, H, W), slot)
         h = self._h
         st = _stream()
+        if profile is None and os.environ.get("SA_ENGINE_PYTHON_LOOP", "0") != "1":
+            # product path: the whole launch sequence runs inside the library (csrc/network.hip); the Python loop below is
+            # the same sequence with a HIP event pair around every launch (bench.py --layers, tools/net_profile.py)
+            if imgs.dtype not in (torch.uint8, torch.float32):
+                raise ValueError("images must be uint8 or float32")
+            if Cin != self.in_channels:
+                raise ValueError(f"model expects {self.in_channels} input channels, got {Cin}")
+            outs = [bufs[o.buf] if o.kind == "f32out" else
+                    torch.empty((B, H * o.num // o.den, W * o.num // o.den, o.c), dtype=torch.float32, device=self.device)
+                    for o in self.outputs]
+            arr = (C.c_void_p * len(outs))(*[t.data_ptr() for t in outs])
+            ws = self._workspace
+            check(h.sa_network_forward(self._handle(), _ptr(imgs), 1 if imgs.dtype == torch.uint8 else 0, B, H, W, Cin, arr,
+                                       _ptr(ws), ws.numel(), st), "sa_network_forward")
+            if self.dtype == "fp16" and not self._range_checked:
+                self._check_fp16_range(bufs)
+            return outs
 
         def hw(tt):
             return H * tt.num // tt.den, W * tt.num // tt.den

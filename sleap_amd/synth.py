@@ -52,3 +52,55 @@ def render_frames(n_frames, height, width, n_animals=4, seed=0):
                 img[y0:y1, x0:x1] -= (70 + 5 * k) * blob[y0 - cy + r : y1 - cy + r, x0 - cx + r : x1 - cx + r]
         frames[t, :, :, 0] = np.clip(img, 0, 255).astype(np.uint8)
     return frames, insts
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# v2 renderer: frames a network can actually be TRAINED on (tools/train_benchmark_model.py) so that the benchmark and the
+# end-to-end parity tests run on confident, well separated detections (4 instances x 13 nodes per frame) instead of the
+# noise-like maps of a random-init network.
+#   * every node type has its own blob (amplitude / radius code), so node identity is decodable locally;
+#   * every skeleton edge is drawn as a line that fades from its source to its destination node, so the direction of the
+#     part-affinity field is decodable locally;
+#   * animals keep `min_sep` px between centres (default 170 > the largest body extent), i.e. they never overlap.
+# Same skeleton, template pose, similarity transforms, jitter and background statistics as `render_frames`.
+# ---------------------------------------------------------------------------------------------------------------------------
+_EDGE_IDX = [(FLIES13_NODES.index(a), FLIES13_NODES.index(b)) for a, b in FLIES13_EDGES]
+# per node: (amplitude subtracted from the ~170 background, gaussian radius in px)
+_NODE_CODE = [(150.0, 4.5), (160.0, 6.0), (140.0, 5.0), (70.0, 4.0), (110.0, 4.0), (60.0, 2.5), (100.0, 2.5), (60.0, 3.5),
+              (100.0, 3.5), (80.0, 3.0), (125.0, 3.0), (-70.0, 2.0), (-45.0, 3.0)]
+
+
+def render_flies(n_frames, height, width, n_animals=4, seed=0, min_sep=170.0, margin=128.0, return_instances=True):
+    """-> (frames uint8 (T, H, W, 1), list of (A, 13, 2) float32 instance arrays in (x, y) image pixels)."""
+    rng = np.random.default_rng(seed)
+    frames = np.empty((n_frames, height, width, 1), np.uint8)
+    insts = []
+    for t in range(n_frames):
+        inst = random_instances(rng, n_animals, height, width, margin=min(margin, min(height, width) / 4), min_sep=min_sep)
+        insts.append(inst)
+        small = rng.normal(0, 1, (height // 16 + 1, width // 16 + 1)).astype(np.float32)
+        img = 170 + 12 * np.kron(small, np.ones((16, 16), np.float32))[:height, :width]
+        img += rng.normal(0, 4, (height, width)).astype(np.float32)
+        for a in inst:
+            for (s, d) in _EDGE_IDX:  # limbs first, node blobs on top
+                p0, p1 = a[s].astype(np.float64), a[d].astype(np.float64)
+                x0, x1 = int(max(min(p0[0], p1[0]) - 6, 0)), int(min(max(p0[0], p1[0]) + 7, width))
+                y0, y1 = int(max(min(p0[1], p1[1]) - 6, 0)), int(min(max(p0[1], p1[1]) + 7, height))
+                if x1 <= x0 or y1 <= y0:
+                    continue
+                yy, xx = np.mgrid[y0:y1, x0:x1].astype(np.float32)
+                v = p1 - p0
+                tt = np.clip(((xx - p0[0]) * v[0] + (yy - p0[1]) * v[1]) / max(float(v @ v), 1.0), 0.0, 1.0)
+                d2 = (xx - (p0[0] + tt * v[0])) ** 2 + (yy - (p0[1] + tt * v[1])) ** 2
+                img[y0:y1, x0:x1] -= (55.0 - 35.0 * tt) * np.exp(-d2 / (2 * 1.5 ** 2))
+            for k, p in enumerate(a):
+                amp, rad = _NODE_CODE[k]
+                r = int(3 * rad) + 1
+                cx, cy = int(round(float(p[0]))), int(round(float(p[1])))
+                x0, x1, y0, y1 = max(cx - r, 0), min(cx + r + 1, width), max(cy - r, 0), min(cy + r + 1, height)
+                if x1 <= x0 or y1 <= y0:
+                    continue
+                yy, xx = np.mgrid[y0:y1, x0:x1].astype(np.float32)
+                img[y0:y1, x0:x1] -= amp * np.exp(-((xx - p[0]) ** 2 + (yy - p[1]) ** 2) / (2 * rad ** 2))
+        frames[t, :, :, 0] = np.clip(img, 0, 255).astype(np.uint8)
+    return frames, insts

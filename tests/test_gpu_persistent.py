@@ -1,0 +1,86 @@
+"""The persistent tile schedule of the 3x3 MFMA kernels (csrc/conv3x3.hip: a workgroup walks several tiles, the first chunk of
+its next tile is prefetched across the tile boundary) must not change a single bit: every tile's arithmetic is the same as
+with one workgroup per tile. `sa_conv3x3_set_grid_limit` forces a handful of workgroups over many tiles -- uneven tails,
+workgroup counts that are not multiples of 8 (the XCD split), odd and even chunk counts (the LDS stage parity carries across
+tiles), two-source K loops, pooled stores, fused heads -- at sizes far below the point where the automatic policy turns
+persistent (occupancy x 256 CUs tiles)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture
+def grid_limit():
+    from sleap_amd import _lib
+
+    libs = [_lib.lib("fp16"), _lib.lib("bf16")]
+
+    def set_(n):
+        for h in libs:
+            h.sa_conv3x3_set_grid_limit(int(n))
+
+    yield set_
+    set_(0)
+
+
+@pytest.mark.parametrize("dtype", ["fp16", "bf16"])
+@pytest.mark.parametrize("B,H,W,C0,C1,Cout,mode,pooled", [
+    (3, 48, 96, 32, 0, 64, 0, True),     # 2 chunks, 27 tiles, pooled + full
+    (2, 40, 70, 64, 0, 64, 0, False),    # 4 chunks, ragged right/bottom tiles
+    (2, 32, 64, 48, 0, 128, 0, False),   # 3 chunks (odd: stage parity flips per tile), 2 cout tiles
+    (1, 64, 64, 64, 128, 64, 1, False),  # concat: 12 chunks from two sources
+    (5, 16, 32, 256, 0, 32, 0, True),    # 16 chunks, one cout tile of 32
+])
+def test_persistent_schedule_is_bitwise_neutral(grid_limit, dtype, B, H, W, C0, C1, Cout, mode, pooled):
+    from sleap_amd import ops
+
+    g = torch.Generator(device="cpu").manual_seed(B * 131 + H + C0 + C1 + Cout)
+    k = torch.randn((3, 3, C0 + C1, Cout), generator=g) * (2.0 / (9 * (C0 + C1))) ** 0.5
+    x0 = ops.to_bf16_padded(torch.randn((B, H, W, C0), generator=g).cuda(), dtype=dtype)
+    x1 = ops.to_bf16_padded(torch.randn((B, H, W, C1), generator=g).cuda(), dtype=dtype) if C1 else None
+    pw = ops.pack_conv3x3_weights(k.numpy(), C0, C1, dtype=dtype)
+    coutp = ops.pad16(Cout)
+    bias = torch.zeros((coutp,), dtype=torch.float32)
+    bias[:Cout] = torch.randn((Cout,), generator=g) * 0.1
+    bias = bias.cuda()
+
+    def run():
+        out = ops.conv3x3(x0, x1, mode, pw, bias, coutp, True, (H, W), full=True, pooled=pooled)
+        torch.cuda.synchronize()
+        return [o.clone() for o in (out if pooled else (out,))]
+
+    grid_limit(-1)  # one workgroup per tile
+    ref = run()
+    n_tiles = B * ((H + 15) // 16) * ((W + 31) // 32) * ((coutp + 63) // 64)
+    for n in (1, 3, 7, 8, 13, n_tiles - 1):
+        if n < 1:
+            continue
+        grid_limit(n)
+        for a, b in zip(run(), ref):
+            assert torch.equal(a.view(torch.int16), b.view(torch.int16)), f"grid limit {n} of {n_tiles} tiles"
+
+
+@pytest.mark.parametrize("dtype", ["fp16", "bf16"])
+def test_persistent_network_forward_is_bitwise_neutral(grid_limit, dtype):
+    """The benchmark UNet (fused stem / pair / heads included) at a small size: heads identical for every schedule."""
+    from sleap_amd.nn.architectures import build_unet_model_config, he_normal_weights
+    from sleap_amd.nn.engine import DeviceNetwork
+    from sleap_amd.synth import render_frames
+
+    cfg, shapes = build_unet_model_config((160, 224, 1), 16, 2, 32, 4, True, True,
+                                          heads=[("MultiInstanceConfmapsHead", 13, 4), ("PartAffinityFieldsHead", 24, 8)])
+    net = DeviceNetwork(cfg, he_normal_weights(shapes, seed=3), dtype=dtype)
+    x = torch.from_numpy(render_frames(3, 160, 224, n_animals=2, seed=5)[0]).cuda()
+    grid_limit(-1)
+    ref = [o.clone() for o in net.forward(x)]
+    for n in (2, 5, 16):
+        grid_limit(n)
+        for a, b in zip(net.forward(x), ref):
+            assert torch.equal(a, b), f"grid limit {n}"
+    grid_limit(0)
+    for a, b in zip(net.forward(x), ref):
+        assert torch.equal(a, b)
