@@ -228,12 +228,13 @@ def main():
         cms, pafs, offs = layer.forward_pass(frames)
         torch.cuda.synchronize()
         e0.record()
-        pk = layer.find_peaks(cms, offs)
-        scorer.predict_padded(pafs, *pk)
+        refinement = layer.refinement if layer.refinement in ("integral", "local") else None
+        pp = scorer.predict_from_maps(cms, offs, pafs, layer.peak_threshold, refinement, layer.integral_patch_size,
+                                      layer.cm_output_stride, layer.max_peaks)
         e1.record()
         torch.cuda.synchronize()
         post_ms = e0.elapsed_time(e1)
-        mean_peaks = float(pk[3].float().mean())
+        mean_peaks = float(pp["peak_count"].float().mean())
         achieved = conv_fl / (conv_ms * 1e-3) / 1e12
         roofline = {
             "kernel": f"conv3x3_dma_kernel + convpair + stem16_gray_kernel (the {n_conv} MFMA conv launches of one step)", "bound": "mfma", "achieved": round(achieved, 2),

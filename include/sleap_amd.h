@@ -127,6 +127,60 @@ int sa_paf_match(const float* line_scores, const int32_t* node_count, const int3
                  int32_t* status, void* workspace, size_t ws_bytes, sa_stream_t stream);
 
 /* Bytes of device workspace sa_paf_match / sa_paf_group need (one buffer may serve both, sequentially). */
+/* The pieces of the scoring stage the reference exposes (and tests) as module-level functions; the hot path runs the fused
+ * sa_paf_score, which shares their arithmetic. All per SAMPLE, flat candidate lists (K candidates).
+ *   sa_paf_line_subs      make_line_subs (paf_grouping.py:145-222): peaks_xy [n_peaks,2] f32, edge_peak_inds [K,2] i32,
+ *                         edge_inds [K] i32 -> subs [K,n_points,2,3] i32 = [row, col, 2*edge + {0,1}] (linspace, round half to
+ *                         even, no clipping -- as the reference)
+ *   sa_gather_nd3         tf.gather_nd(pafs_sample [H,W,C] f32, subs [n,3]) of get_paf_lines (:225-275) -> out [n];
+ *                         out-of-range subscripts read 0 and OR SA_STATUS_PAF_OOB into *status (may be NULL)
+ *   sa_paf_line_scores    score_paf_lines (:325-403): paf_lines [K,n_points,2] -> line_scores [K]
+ *   sa_distance_penalty   compute_distance_penalty (:278-322), elementwise over n lengths */
+int sa_paf_line_subs(const float* peaks_xy, const int32_t* edge_peak_inds, const int32_t* edge_inds, int K, int n_points,
+                     float pafs_stride, int32_t* subs, sa_stream_t stream);
+int sa_gather_nd3(const float* src, int H, int W, int C, const int32_t* subs, int n, float* out, int32_t* status,
+                  sa_stream_t stream);
+int sa_paf_line_scores(const float* paf_lines, const float* peaks_xy, const int32_t* edge_peak_inds, int K, int n_points,
+                       float max_edge_length, float dist_penalty_weight, float* line_scores, sa_stream_t stream);
+int sa_distance_penalty(const float* lengths, int n, float max_edge_length, float dist_penalty_weight, float* out,
+                        sa_stream_t stream);
+
+/* group_instances with the connections given as an explicit, ordered list instead of match tables -- the dictionary form
+ * of assign_connections_to_instances / make_predicted_instances (paf_grouping.py:799-981; the reference walks
+ * `connections.items()` in insertion order, any number of connections per edge type):
+ *   conn_edge/src/dst [B,conn_stride] i32, conn_score [B,conn_stride] f32, conn_count [B] i32: connection q of frame b joins
+ *   peak `src` of node edges[edge][0] with peak `dst` of node edges[edge][1] (indices within the node's peak list)
+ *   assign_out [B,N,max_node_peaks] i32 or NULL: the raw instance id of every (node, peak) slot (-1 = unassigned, < -1 =
+ *   dropped by min_instance_peaks) = the reference's `instance_assignments` dictionary
+ *   assign_in / order_in [B,N,max_node_peaks] i32 + order_count [B] i32, or all NULL: make_predicted_instances on GIVEN
+ *   assignments -- the greedy walk is skipped, `assign_in` is the slot -> instance id table and `order_in` lists the assigned
+ *   slots (node * max_node_peaks + peak) in the dictionary's key order (later keys overwrite earlier ones in a cell)
+ * Other arguments as sa_paf_group. */
+int sa_paf_group_connections(const float* peak_xy, const float* peak_val, const int32_t* node_count, const int32_t* node_peaks,
+                             int max_peaks, const int32_t* conn_edge, const int32_t* conn_src, const int32_t* conn_dst,
+                             const float* conn_score, const int32_t* conn_count, int conn_stride, const int32_t* edges, int B,
+                             int E, int N, int max_node_peaks, float min_line_scores, int min_instance_peaks, int max_instances,
+                             float* instance_peaks, float* instance_peak_vals, float* instance_scores, int32_t* n_instances,
+                             int32_t* assign_out, const int32_t* assign_in, const int32_t* order_in, const int32_t* order_count,
+                             int32_t* status, void* workspace, size_t ws_bytes, sa_stream_t stream);
+
+/* find_peaks + PAFScorer.predict of BottomUpInferenceLayer.call (inference.py:2892-2936, paf_grouping.py:1629-1705) in TWO
+ * launches: the NMS scan over all confidence maps, then one workgroup per frame that sorts + refines its peaks, scores the
+ * candidate connections, matches every edge (one wavefront per edge) and assembles the instances (sa_find_local_peaks +
+ * sa_paf_score + sa_paf_match + sa_paf_group fused; same arithmetic, same outputs, same status bits). All the intermediate
+ * tables are outputs (caller-owned, shapes as in the separate entry points). Capacities beyond one workgroup's LDS fall back
+ * to the separate kernels inside the call. workspace: sa_bottomup_postproc_workspace bytes. */
+size_t sa_bottomup_postproc_workspace(int B, int max_peaks, int E, int N, int max_node_peaks);
+int sa_bottomup_postproc(const float* cms, const float* offsets, int B, int H, int W, int C, float threshold, int refinement,
+                         int patch_size, float xy_scale, int max_peaks, const float* pafs, int Hp, int Wp, int E,
+                         const int32_t* edges, const int32_t* sorted_edge_inds, int n_sorted, int N, int n_points,
+                         float pafs_stride, float max_edge_length, float dist_penalty_weight, int max_node_peaks,
+                         float min_line_scores, int min_instance_peaks, int max_instances, float* peak_xy, float* peak_val,
+                         int32_t* peak_chan, int32_t* peak_count, int32_t* node_count, int32_t* node_peaks, float* line_scores,
+                         int32_t* match_dst, float* match_score, float* instance_peaks, float* instance_peak_vals,
+                         float* instance_scores, int32_t* n_instances, int32_t* status, void* workspace, size_t ws_bytes,
+                         sa_stream_t stream);
+
 size_t sa_paf_workspace(int B, int E, int N, int max_node_peaks);
 
 /* group_instances_sample = assign_connections_to_instances + make_predicted_instances
@@ -145,6 +199,10 @@ int sa_paf_group(const float* peak_xy, const float* peak_val, const int32_t* nod
 /* HOST-side Hungarian solve (same code as the device path; for tests / tooling).
  * cost [nr,nc] f64 row-major; row_ind/col_ind sized min(nr,nc). Returns #pairs or -1 if infeasible. */
 int sa_lsa_host(const double* cost, int nr, int nc, int64_t* row_ind, int64_t* col_ind);
+/* Same contract; runs the wave-cooperative form of the solver that the matching kernel uses (one wavefront per (frame, edge):
+ * column scan, dual update and initialisation spread over 64 lanes, SciPy's tie rule kept by an order-aware reduction) with
+ * its lanes emulated on the host -- the CPU-side check of that code path against SciPy. */
+int sa_lsa_host_wave(const double* cost, int nr, int nc, int64_t* row_ind, int64_t* col_ind);
 
 /* ------------------------------------------------------------------------------------------------
  * Network layers -- replace the TensorFlow/cuDNN ops behind the Keras graph built by

@@ -38,8 +38,18 @@ SIGNATURES = {
     "sa_paf_score": (_i, [_p, _i, _i, _i, _i, _p, _p, _p, _i, _p, _i, _i, _f, _f, _f, _i, _p, _p, _p, _p, _p]),
     "sa_paf_match": (_i, [_p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _sz, _p]),
     "sa_paf_workspace": (_sz, [_i, _i, _i, _i]),
+    "sa_paf_group_connections": (_i, [_p, _p, _p, _p, _i, _p, _p, _p, _p, _p, _i, _p, _i, _i, _i, _i, _f, _i, _i, _p, _p, _p,
+                                      _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
+    "sa_bottomup_postproc_workspace": (_sz, [_i, _i, _i, _i, _i]),
+    "sa_bottomup_postproc": (_i, [_p, _p, _i, _i, _i, _i, _f, _i, _i, _f, _i, _p, _i, _i, _i, _p, _p, _i, _i, _i, _f, _f, _f, _i,
+                                  _f, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
+    "sa_paf_line_subs": (_i, [_p, _p, _p, _i, _i, _f, _p, _p]),
+    "sa_gather_nd3": (_i, [_p, _i, _i, _i, _p, _i, _p, _p, _p]),
+    "sa_paf_line_scores": (_i, [_p, _p, _p, _i, _i, _f, _f, _p, _p]),
+    "sa_distance_penalty": (_i, [_p, _i, _f, _f, _p, _p]),
     "sa_paf_group": (_i, [_p, _p, _p, _p, _i, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _i, _i, _p, _p, _p, _p, _p, _p, _sz, _p]),
     "sa_lsa_host": (_i, [_p, _i, _i, _p, _p]),
+    "sa_lsa_host_wave": (_i, [_p, _i, _i, _p, _p]),
     "sa_stem_conv3x3": (_i, [_p, _i, _i, _i, _i, _i, _p, _p, _i, _i, _p, _p]),
     "sa_conv3x3_bf16": (_i, [_p, _i, _p, _i, _i, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p]),
     "sa_stem_conv3x3x2_bf16": (_i, [_p, _i, _i, _i, _i, _i, _p, _p, _i, _i, _p, _p, _i, _i, _p, _p, _p]),

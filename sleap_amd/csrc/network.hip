@@ -310,11 +310,10 @@ size_t sa_bottomup_workspace_bytes(const sa_network_t* net, const sa_bottomup_pa
     t += align256((size_t)B * oh * ow * oc * 4);
   }
   const int N = q->n_nodes, E = q->n_edges, NP = q->max_node_peaks, MP = q->max_peaks;
-  t += align256(sa_find_local_peaks_workspace(B, MP));
+  t += align256(sa_bottomup_postproc_workspace(B, MP, E, N, NP));
   t += align256((size_t)B * MP * 2 * 4) + 2 * align256((size_t)B * MP * 4) + align256((size_t)B * 4);  // peak_xy, val, chan, count
   t += align256((size_t)B * N * 4) + align256((size_t)B * N * NP * 4) + align256((size_t)B * E * NP * NP * 4);  // node tables, line scores
   t += 2 * align256((size_t)B * E * NP * 4);                                                                    // match_dst / score
-  t += align256(sa_paf_workspace(B, E, N, NP));
   return t;
 }
 
@@ -343,8 +342,8 @@ int sa_bottomup_predict(const sa_network_t* net, const sa_bottomup_params* q, co
     heads[(size_t)i] = static_cast<float*>(take((size_t)B * oh[i] * ow[i] * oc[i] * 4));
   }
   const int N = q->n_nodes, E = q->n_edges, NP = q->max_node_peaks, MP = q->max_peaks;
-  const size_t pk_ws_bytes = sa_find_local_peaks_workspace(B, MP);
-  void* pk_ws = take(pk_ws_bytes);
+  const size_t pp_ws_bytes = sa_bottomup_postproc_workspace(B, MP, E, N, NP);
+  void* pp_ws = take(pp_ws_bytes);
   float* peak_xy = static_cast<float*>(take((size_t)B * MP * 2 * 4));
   float* peak_val = static_cast<float*>(take((size_t)B * MP * 4));
   int32_t* peak_chan = static_cast<int32_t*>(take((size_t)B * MP * 4));
@@ -354,8 +353,6 @@ int sa_bottomup_predict(const sa_network_t* net, const sa_bottomup_params* q, co
   float* line_scores = static_cast<float*>(take((size_t)B * E * NP * NP * 4));
   int32_t* match_dst = static_cast<int32_t*>(take((size_t)B * E * NP * 4));
   float* match_score = static_cast<float*>(take((size_t)B * E * NP * 4));
-  const size_t paf_ws_bytes = sa_paf_workspace(B, E, N, NP);
-  void* paf_ws = take(paf_ws_bytes);
   hipStream_t st = (hipStream_t)stream;
   SA_HIP_CHECK(hipMemsetAsync(status, 0, (size_t)B * 4, st));
 
@@ -366,22 +363,16 @@ int sa_bottomup_predict(const sa_network_t* net, const sa_bottomup_params* q, co
   SA_REQUIRE(oc[ci] == N, "sa_bottomup_predict: confidence maps have %d channels, skeleton has %d nodes", oc[ci], N);
   SA_REQUIRE(oc[pi] == 2 * E, "sa_bottomup_predict: PAFs have %d channels, skeleton has %d edges", oc[pi], E);
   const int refinement = oi >= 0 ? SA_REFINE_OFFSETS : q->refinement;
-  rc = sa_find_local_peaks(heads[ci], oi >= 0 ? heads[oi] : nullptr, B, oh[ci], ow[ci], N, q->peak_threshold, refinement,
-                           q->integral_patch_size, q->cm_output_stride, MP, peak_xy, peak_val, peak_chan, peak_count, status, pk_ws,
-                           pk_ws_bytes, stream);
-  if (rc != SA_OK) return rc;
   // PAFScorer.max_edge_length (paf_grouping.py:469-473): ratio * max over (H, W, 2E) of the PAF tensor * stride, f32 products
   int mx = oh[pi] > ow[pi] ? oh[pi] : ow[pi];
   if (2 * E > mx) mx = 2 * E;
   const float max_edge_length = q->max_edge_length_ratio * (float)mx * q->pafs_stride;
-  rc = sa_paf_score(heads[pi], B, oh[pi], ow[pi], E, peak_xy, peak_chan, peak_count, MP, q->edges, N, q->n_points, q->pafs_stride,
-                    max_edge_length, q->dist_penalty_weight, NP, node_count, node_peaks, line_scores, status, stream);
-  if (rc != SA_OK) return rc;
-  rc = sa_paf_match(line_scores, node_count, q->edges, B, E, N, NP, match_dst, match_score, status, paf_ws, paf_ws_bytes, stream);
-  if (rc != SA_OK) return rc;
-  return sa_paf_group(peak_xy, peak_val, node_count, node_peaks, MP, match_dst, match_score, q->edges, q->sorted_edge_inds,
-                      q->n_sorted, B, E, N, NP, q->min_line_scores, q->min_instance_peaks, q->max_instances, instance_peaks,
-                      instance_peak_vals, instance_scores, n_instances, status, paf_ws, paf_ws_bytes, stream);
+  return sa_bottomup_postproc(heads[ci], oi >= 0 ? heads[oi] : nullptr, B, oh[ci], ow[ci], N, q->peak_threshold, refinement,
+                              q->integral_patch_size, q->cm_output_stride, MP, heads[pi], oh[pi], ow[pi], E, q->edges,
+                              q->sorted_edge_inds, q->n_sorted, N, q->n_points, q->pafs_stride, max_edge_length,
+                              q->dist_penalty_weight, NP, q->min_line_scores, q->min_instance_peaks, q->max_instances, peak_xy,
+                              peak_val, peak_chan, peak_count, node_count, node_peaks, line_scores, match_dst, match_score,
+                              instance_peaks, instance_peak_vals, instance_scores, n_instances, status, pp_ws, pp_ws_bytes, stream);
 }
 
 }  // extern "C"

@@ -188,16 +188,13 @@ __device__ void refine_offset(const float* __restrict__ img, const float* __rest
 }
 
 // One workgroup per frame: bitonic-sort the frame's keys (restores tf.where's row-major (y,x,c)
-// order, which every downstream index depends on) and refine each peak.
-__global__ void __launch_bounds__(256)
-peaks_sort_refine_kernel(const float* __restrict__ cms, const float* __restrict__ offsets, int H,
-                         int W, int C, int mode, int k, float xy_scale, int max_peaks,
-                         const uint32_t* __restrict__ keys, int32_t* __restrict__ counts,
-                         float* __restrict__ peak_xy, float* __restrict__ peak_val,
-                         int32_t* __restrict__ peak_chan) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  uint32_t* sk = reinterpret_cast<uint32_t*>(smem_raw);
-  const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+// order, which every downstream index depends on) and refine each peak. `sk`: LDS, next_pow2(max_peaks) words.
+__device__ void frame_sort_refine(int b, uint32_t* sk, const float* __restrict__ cms, const float* __restrict__ offsets, int H,
+                                  int W, int C, int mode, int k, float xy_scale, int max_peaks,
+                                  const uint32_t* __restrict__ keys, int32_t* __restrict__ counts,
+                                  float* __restrict__ peak_xy, float* __restrict__ peak_val,
+                                  int32_t* __restrict__ peak_chan) {
+  const int tid = threadIdx.x, nt = blockDim.x;
   const int n = min(counts[b], max_peaks);
   int n2 = 1;
   while (n2 < n) n2 <<= 1;
@@ -235,7 +232,19 @@ peaks_sort_refine_kernel(const float* __restrict__ cms, const float* __restrict_
     peak_val[o] = img[e];
     peak_chan[o] = c;
   }
+  __syncthreads();  // every thread has read counts[b]
   if (tid == 0) counts[b] = n;
+}
+
+__global__ void __launch_bounds__(256)
+peaks_sort_refine_kernel(const float* __restrict__ cms, const float* __restrict__ offsets, int H,
+                         int W, int C, int mode, int k, float xy_scale, int max_peaks,
+                         const uint32_t* __restrict__ keys, int32_t* __restrict__ counts,
+                         float* __restrict__ peak_xy, float* __restrict__ peak_val,
+                         int32_t* __restrict__ peak_chan) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  frame_sort_refine(blockIdx.x, reinterpret_cast<uint32_t*>(smem_raw), cms, offsets, H, W, C, mode, k, xy_scale, max_peaks, keys,
+                    counts, peak_xy, peak_val, peak_chan);
 }
 
 // find_global_peaks_rough (+ refinement): one workgroup per (frame, channel).
@@ -363,22 +372,72 @@ crop_and_resize_kernel(const T* __restrict__ images, int H, int W, int C, const 
 // PAF scoring
 // ------------------------------------------------------------------------------------------------
 
+// ---- arithmetic of one candidate line, shared by the fused scoring kernel and the stand-alone entry points behind the
+// reference's module-level functions (make_line_subs / get_paf_lines / score_paf_lines / compute_distance_penalty)
+struct LineDir {
+  float vx, vy, len, ux, uy, ddx, ddy;
+};
+
+__device__ __forceinline__ LineDir line_dir(float sx, float sy, float ex, float ey, int n_points) {
+  LineDir d;
+  // spatial vector, tf.norm = sqrt(sum(v*v)) (paf_grouping.py:378-383)
+  d.vx = __fsub_rn(ex, sx);
+  d.vy = __fsub_rn(ey, sy);
+  d.len = __fsqrt_rn(__fadd_rn(__fmul_rn(d.vx, d.vx), __fmul_rn(d.vy, d.vy)));
+  d.ux = __fdiv_rn(d.vx, d.len);
+  d.uy = __fdiv_rn(d.vy, d.len);
+  // tf.linspace: delta = (stop - start) / (n - 1); start + delta * i; exact end points
+  const int steps = max(n_points - 1, 1);
+  d.ddx = __fdiv_rn(d.vx, (float)steps);
+  d.ddy = __fdiv_rn(d.vy, (float)steps);
+  return d;
+}
+
+__device__ __forceinline__ void line_point(const LineDir& d, float sx, float sy, float ex, float ey, int i, int n_points,
+                                           float& px, float& py) {
+  if (i == 0) {
+    px = sx;
+    py = sy;
+  } else if (i == n_points - 1) {
+    px = ex;
+    py = ey;
+  } else {
+    px = __fadd_rn(sx, __fmul_rn(d.ddx, (float)i));
+    py = __fadd_rn(sy, __fmul_rn(d.ddy, (float)i));
+  }
+}
+
+// one line point's projection of the PAF vector on the unit vector (paf_lines @ spatial_vecs, :386-388)
+__device__ __forceinline__ float line_dot(const LineDir& d, float fx, float fy) {
+  return __fadd_rn(__fmul_rn(fx, d.ux), __fmul_rn(fy, d.uy));
+}
+
+// compute_distance_penalty (paf_grouping.py:278-322)
+__device__ __forceinline__ float distance_penalty(float len, float max_edge_length, float dist_penalty_weight) {
+  return __fmul_rn(fminf(__fsub_rn(__fdiv_rn(max_edge_length, len), 1.0f), 0.0f), dist_penalty_weight);
+}
+
+// mean over the line points + distance penalty (:399-401)
+__device__ __forceinline__ float line_total(const LineDir& d, float acc, int n_points, float max_edge_length,
+                                            float dist_penalty_weight) {
+  return __fadd_rn(__fdiv_rn(acc, (float)n_points), distance_penalty(d.len, max_edge_length, dist_penalty_weight));
+}
+
 // One workgroup per frame. Phase 1 buckets the frame's peaks by node type (stable, so the s-th
 // entry of a node is its s-th peak in (y,x) order == tf.argsort/top_k order, paf_grouping.py:105).
 // Phase 2 walks the dense (edge, src, dst) candidate space; every candidate samples n_points
 // nearest-pixel PAF vectors along src->dst and averages their projection on the unit vector.
-__global__ void __launch_bounds__(256)
-paf_score_kernel(const float* __restrict__ pafs, int Hp, int Wp, int E,
-                 const float* __restrict__ peak_xy, const int32_t* __restrict__ peak_chan,
-                 const int32_t* __restrict__ peak_count, int max_peaks,
-                 const int32_t* __restrict__ edges, int N, int n_points, float pafs_stride,
-                 float max_edge_length, float dist_penalty_weight, int NP,
-                 int32_t* __restrict__ node_count, int32_t* __restrict__ node_peaks,
-                 float* __restrict__ line_scores, int32_t* __restrict__ status) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+__device__ void frame_score(int b, unsigned char* smem_raw, const float* __restrict__ pafs, int Hp, int Wp, int E,
+                            const float* __restrict__ peak_xy, const int32_t* __restrict__ peak_chan,
+                            const int32_t* __restrict__ peak_count, int max_peaks,
+                            const int32_t* __restrict__ edges, int N, int n_points, float pafs_stride,
+                            float max_edge_length, float dist_penalty_weight, int NP,
+                            int32_t* __restrict__ node_count, int32_t* __restrict__ node_peaks,
+                            float* __restrict__ line_scores, int32_t* __restrict__ status) {
+
   int32_t* s_cnt = reinterpret_cast<int32_t*>(smem_raw);  // [N]
   int32_t* s_list = s_cnt + N;                            // [N][NP]
-  const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+  const int tid = threadIdx.x, nt = blockDim.x;
   const int n = min(peak_count[b], max_peaks);
   const int32_t* ch = peak_chan + (size_t)b * max_peaks;
   const float* xy = peak_xy + (size_t)b * max_peaks * 2;
@@ -406,35 +465,34 @@ paf_score_kernel(const float* __restrict__ pafs, int Hp, int Wp, int E,
 
   const float* paf = pafs + (size_t)b * Hp * Wp * 2 * E;
   const int PC = 2 * E;
-  const int total = E * NP * NP;
+  // candidates of edge k occupy [s_off[k], s_off[k+1]) of a flat list (n_src * n_dst each): only real candidates are walked
+  // (the dense (edge, src, dst) space is 50-100x larger at typical counts)
+  int32_t* s_off = s_list + N * NP;  // [E + 1]
+  __syncthreads();
+  if (tid == 0) {
+    int run = 0;
+    for (int k = 0; k < E; ++k) {
+      s_off[k] = run;
+      run += s_cnt[edges[2 * k]] * s_cnt[edges[2 * k + 1]];
+    }
+    s_off[E] = run;
+  }
+  __syncthreads();
+  const int total = s_off[E];
   bool oob = false;
   for (int idx = tid; idx < total; idx += nt) {
-    const int k = idx / (NP * NP);
-    const int s = (idx / NP) % NP, d = idx % NP;
+    int k = 0;
+    while (idx >= s_off[k + 1]) ++k;
     const int sn = edges[2 * k], dn = edges[2 * k + 1];
-    if (s >= s_cnt[sn] || d >= s_cnt[dn]) continue;
+    const int local = idx - s_off[k], nd_ = s_cnt[dn];
+    const int s = local / nd_, d = local - s * nd_;
     const int ps = s_list[sn * NP + s], pd = s_list[dn * NP + d];
     const float sx = xy[2 * ps], sy = xy[2 * ps + 1], ex = xy[2 * pd], ey = xy[2 * pd + 1];
-    // spatial vector, tf.norm = sqrt(sum(v*v)) (paf_grouping.py:378-383)
-    const float vx = __fsub_rn(ex, sx), vy = __fsub_rn(ey, sy);
-    const float len = __fsqrt_rn(__fadd_rn(__fmul_rn(vx, vx), __fmul_rn(vy, vy)));
-    const float ux = __fdiv_rn(vx, len), uy = __fdiv_rn(vy, len);
-    // tf.linspace: delta = (stop - start) / (n - 1); start + delta * i; exact end points
-    const int steps = max(n_points - 1, 1);
-    const float ddx = __fdiv_rn(vx, (float)steps), ddy = __fdiv_rn(vy, (float)steps);
+    const LineDir ld = line_dir(sx, sy, ex, ey, n_points);
     float acc = 0.0f;
     for (int i = 0; i < n_points; ++i) {
       float px, py;
-      if (i == 0) {
-        px = sx;
-        py = sy;
-      } else if (i == n_points - 1) {
-        px = ex;
-        py = ey;
-      } else {
-        px = __fadd_rn(sx, __fmul_rn(ddx, (float)i));
-        py = __fadd_rn(sy, __fmul_rn(ddy, (float)i));
-      }
+      line_point(ld, sx, sy, ex, ey, i, n_points, px, py);
       // tf.round = half-to-even; no clipping in the reference (paf_grouping.py:192-197)
       const float rx = rintf(__fdiv_rn(px, pafs_stride)), ry = rintf(__fdiv_rn(py, pafs_stride));
       float fx = 0.0f, fy = 0.0f;
@@ -445,19 +503,92 @@ paf_score_kernel(const float* __restrict__ pafs, int Hp, int Wp, int E,
       } else {
         oob = true;  // TF-CPU gather_nd raises; TF-GPU reads 0 -- we read 0 and flag it
       }
-      acc = __fadd_rn(acc, __fadd_rn(__fmul_rn(fx, ux), __fmul_rn(fy, uy)));
+      acc = __fadd_rn(acc, line_dot(ld, fx, fy));
     }
-    const float mean = __fdiv_rn(acc, (float)n_points);
-    // compute_distance_penalty (paf_grouping.py:278-322)
-    const float pen = __fmul_rn(fminf(__fsub_rn(__fdiv_rn(max_edge_length, len), 1.0f), 0.0f),
-                                dist_penalty_weight);
-    line_scores[(((size_t)b * E + k) * NP + s) * NP + d] = __fadd_rn(mean, pen);
+    line_scores[(((size_t)b * E + k) * NP + s) * NP + d] = line_total(ld, acc, n_points, max_edge_length, dist_penalty_weight);
   }
   if (oob) atomicOr(&status[b], SA_STATUS_PAF_OOB);
 }
 
+
+__global__ void __launch_bounds__(256)
+paf_score_kernel(const float* __restrict__ pafs, int Hp, int Wp, int E,
+                 const float* __restrict__ peak_xy, const int32_t* __restrict__ peak_chan,
+                 const int32_t* __restrict__ peak_count, int max_peaks,
+                 const int32_t* __restrict__ edges, int N, int n_points, float pafs_stride,
+                 float max_edge_length, float dist_penalty_weight, int NP,
+                 int32_t* __restrict__ node_count, int32_t* __restrict__ node_peaks,
+                 float* __restrict__ line_scores, int32_t* __restrict__ status) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  frame_score(blockIdx.x, smem_raw, pafs, Hp, Wp, E, peak_xy, peak_chan, peak_count, max_peaks, edges, N, n_points, pafs_stride,
+              max_edge_length, dist_penalty_weight, NP, node_count, node_peaks, line_scores, status);
+}
+
+// ---- stand-alone pieces of the scoring stage (the reference exposes them as module-level functions and tests them one by
+// one; the hot path uses the fused kernel above, which shares the arithmetic)
+// make_line_subs (paf_grouping.py:145-222): subs [K][n_points][2][3] = [row, col, 2*edge + {0, 1}]
+__global__ void __launch_bounds__(256)
+paf_line_subs_kernel(const float* __restrict__ peaks_xy, const int32_t* __restrict__ edge_peak_inds,
+                     const int32_t* __restrict__ edge_inds, int K, int n_points, float pafs_stride, int32_t* __restrict__ subs) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= K * n_points) return;
+  const int k = t / n_points, i = t % n_points;
+  const int ps = edge_peak_inds[2 * k], pd = edge_peak_inds[2 * k + 1];
+  const float sx = peaks_xy[2 * ps], sy = peaks_xy[2 * ps + 1], ex = peaks_xy[2 * pd], ey = peaks_xy[2 * pd + 1];
+  const LineDir ld = line_dir(sx, sy, ex, ey, n_points);
+  float px, py;
+  line_point(ld, sx, sy, ex, ey, i, n_points, px, py);
+  // rounded in float first, converted after an opaque barrier: written as (int)rintf(x) the pair is folded into one
+  // float->int conversion that TRUNCATES (1.5 -> 1; caught by the half-to-even case of the reference-mirroring test)
+  float rx = rintf(__fdiv_rn(px, pafs_stride)), ry = rintf(__fdiv_rn(py, pafs_stride));
+  asm volatile("" : "+v"(rx), "+v"(ry));
+  const int col = (int)rx, row = (int)ry;
+  int32_t* o = subs + (size_t)t * 6;
+  o[0] = row, o[1] = col, o[2] = 2 * edge_inds[k];
+  o[3] = row, o[4] = col, o[5] = 2 * edge_inds[k] + 1;
+}
+
+// tf.gather_nd(pafs_sample, line_subs) (get_paf_lines, :225-275); out-of-range subscripts read 0 and set the flag
+__global__ void __launch_bounds__(256)
+gather_nd3_kernel(const float* __restrict__ src, int H, int W, int C, const int32_t* __restrict__ subs, int n,
+                  float* __restrict__ out, int32_t* __restrict__ status) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  const int r = subs[3 * t], c = subs[3 * t + 1], ch = subs[3 * t + 2];
+  float v = 0.0f;
+  if (r >= 0 && r < H && c >= 0 && c < W && ch >= 0 && ch < C)
+    v = src[((size_t)r * W + c) * C + ch];
+  else if (status)
+    atomicOr(status, SA_STATUS_PAF_OOB);
+  out[t] = v;
+}
+
+// score_paf_lines (:325-403) on already gathered lines [K][n_points][2]
+__global__ void __launch_bounds__(256)
+paf_line_scores_kernel(const float* __restrict__ paf_lines, const float* __restrict__ peaks_xy,
+                       const int32_t* __restrict__ edge_peak_inds, int K, int n_points, float max_edge_length,
+                       float dist_penalty_weight, float* __restrict__ out) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= K) return;
+  const int ps = edge_peak_inds[2 * k], pd = edge_peak_inds[2 * k + 1];
+  const LineDir ld = line_dir(peaks_xy[2 * ps], peaks_xy[2 * ps + 1], peaks_xy[2 * pd], peaks_xy[2 * pd + 1], n_points);
+  float acc = 0.0f;
+  for (int i = 0; i < n_points; ++i)
+    acc = __fadd_rn(acc, line_dot(ld, paf_lines[((size_t)k * n_points + i) * 2], paf_lines[((size_t)k * n_points + i) * 2 + 1]));
+  out[k] = line_total(ld, acc, n_points, max_edge_length, dist_penalty_weight);
+}
+
+__global__ void __launch_bounds__(256)
+distance_penalty_kernel(const float* __restrict__ lengths, int n, float max_edge_length, float dist_penalty_weight,
+                        float* __restrict__ out) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < n) out[t] = distance_penalty(lengths[t], max_edge_length, dist_penalty_weight);
+}
+
 // ------------------------------------------------------------------------------------------------
-// Matching: one thread per (frame, edge) runs the rectangular LSA on its (n_src x n_dst) block.
+// Matching: one WAVEFRONT per (frame, edge) runs the rectangular LSA on its (n_src x n_dst) block (csrc/lsa.h:
+// lsa_solve_wave -- column scans, dual updates and initialisation spread over the 64 lanes, SciPy's tie rule kept by an
+// order-aware reduction; work arrays in LDS).
 // ------------------------------------------------------------------------------------------------
 struct CostView {
   const float* s;  // [NP][NP] scores of this (frame, edge)
@@ -471,139 +602,358 @@ struct CostView {
   }
 };
 
-__global__ void __launch_bounds__(64)
-paf_match_kernel(const float* __restrict__ line_scores, const int32_t* __restrict__ node_count,
-                 const int32_t* __restrict__ edges, int B, int E, int N, int NP,
-                 int32_t* __restrict__ match_dst, float* __restrict__ match_score,
-                 int32_t* __restrict__ status, unsigned char* __restrict__ workspace) {
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= B * E) return;
-  const int b = t / E, k = t % E;
+__host__ __device__ inline size_t score_lds_bytes(int N, int NP, int E) { return sizeof(int32_t) * ((size_t)N + (size_t)N * NP + E + 1); }
+__host__ __device__ inline size_t match_lds_bytes(int NP) { return (sa::LsaWork::bytes(NP) + 15) & ~(size_t)15; }
+
+// one (frame b, edge k) by the calling wave; `mem`: match_lds_bytes(NP) of LDS owned by this wave
+__device__ void edge_match_wave(int b, int k, unsigned char* mem, const float* __restrict__ line_scores,
+                                const int32_t* __restrict__ node_count, const int32_t* __restrict__ edges, int E, int N, int NP,
+                                int32_t* __restrict__ match_dst, float* __restrict__ match_score, int32_t* __restrict__ status) {
+  const int lane = threadIdx.x & 63;
+  const size_t t = (size_t)b * E + k;
   const int n_src = node_count[(size_t)b * N + edges[2 * k]];
   const int n_dst = node_count[(size_t)b * N + edges[2 * k + 1]];
-  int32_t* md = match_dst + (size_t)t * NP;
-  float* ms = match_score + (size_t)t * NP;
-  for (int i = 0; i < NP; ++i) {
+  int32_t* md = match_dst + t * NP;
+  float* ms = match_score + t * NP;
+  for (int i = lane; i < NP; i += 64) {
     md[i] = -1;
     ms[i] = __builtin_nanf("");
   }
-  if (n_src == 0 || n_dst == 0) return;
-  const float* sc = line_scores + (size_t)t * NP * NP;
+  if (n_src == 0 || n_dst == 0) return;  // wave-uniform
+  const float* sc = line_scores + t * NP * NP;
   // SciPy rejects NaN / -inf costs ("matrix contains invalid numeric entries"); NaN scores were
   // mapped to +inf, so only a +inf score (cost -inf) is invalid.
-  for (int i = 0; i < n_src; ++i)
-    for (int j = 0; j < n_dst; ++j)
-      if (sc[i * NP + j] == __builtin_huge_valf()) {
-        atomicOr(&status[b], SA_STATUS_LSA_INFEASIBLE);
-        return;
-      }
-  sa::LsaWork w;
-  w.bind(workspace + (size_t)t * sa::LsaWork::bytes(NP), NP);
-  const bool tr = n_dst < n_src;
-  CostView cv{sc, NP, tr};
-  const int nr = tr ? n_dst : n_src, nc = tr ? n_src : n_dst;
-  if (!sa::lsa_solve(nr, nc, cv, w)) {
-    atomicOr(&status[b], SA_STATUS_LSA_INFEASIBLE);
+  bool bad = false;
+  for (int idx = lane; idx < n_src * n_dst; idx += 64) bad |= (sc[(idx / n_dst) * NP + idx % n_dst] == __builtin_huge_valf());
+  if (__ballot(bad)) {
+    if (lane == 0) atomicOr(&status[b], SA_STATUS_LSA_INFEASIBLE);
     return;
   }
-  for (int r = 0; r < nr; ++r) {
+  sa::LsaWork w;
+  const bool tr = n_dst < n_src;
+  const int nr = tr ? n_dst : n_src, nc = tr ? n_src : n_dst;
+  w.bind(mem, nc);
+  CostView cv{sc, NP, tr};
+  if (!sa::lsa_solve_wave(nr, nc, cv, w)) {
+    if (lane == 0) atomicOr(&status[b], SA_STATUS_LSA_INFEASIBLE);
+    return;
+  }
+  SA_WAVE_SYNC();
+  for (int r = lane; r < nr; r += 64) {
     const int c = w.col4row[r];
-    const int s = tr ? c : r, d = tr ? r : c;
-    md[s] = d;
-    ms[s] = sc[s * NP + d];
+    const int s_ = tr ? c : r, d_ = tr ? r : c;
+    md[s_] = d_;
+    ms[s_] = sc[s_ * NP + d_];
   }
 }
 
-// ------------------------------------------------------------------------------------------------
-// Grouping: one workgroup per frame; lane 0 runs the order-dependent greedy assembly on LDS tables.
-// ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(64)
-paf_group_kernel(const float* __restrict__ peak_xy, const float* __restrict__ peak_val,
-                 const int32_t* __restrict__ node_count, const int32_t* __restrict__ node_peaks,
-                 int max_peaks, const int32_t* __restrict__ match_dst,
-                 const float* __restrict__ match_score, const int32_t* __restrict__ edges,
-                 const int32_t* __restrict__ sorted_edge_inds, int n_sorted, int E, int N, int NP,
-                 float min_line_scores, int min_instance_peaks, int max_instances,
-                 float* __restrict__ instance_peaks, float* __restrict__ instance_peak_vals,
-                 float* __restrict__ instance_scores, int32_t* __restrict__ n_instances,
-                 int32_t* __restrict__ status, int32_t* __restrict__ workspace) {
+__global__ void __launch_bounds__(256)
+paf_match_kernel(const float* __restrict__ line_scores, const int32_t* __restrict__ node_count,
+                 const int32_t* __restrict__ edges, int B, int E, int N, int NP,
+                 int32_t* __restrict__ match_dst, float* __restrict__ match_score,
+                 int32_t* __restrict__ status) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  // tables live in LDS when they fit, otherwise in the caller's global workspace (3*N*NP+1 ints per frame)
-  int32_t* assign = workspace ? workspace + (size_t)blockIdx.x * (3 * (size_t)N * NP + 1)
-                              : reinterpret_cast<int32_t*>(smem_raw);  // [N*NP] instance id or -1
-  int32_t* order = assign + N * NP;                        // [N*NP] peak ids in dict-insertion order
-  int32_t* remap = order + N * NP;                         // [N*NP + 1] id -> contiguous index
-  const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
-  const int NN = N * NP;
-  for (int i = tid; i < NN; i += nt) assign[i] = -1;
-  // NaN-fill outputs (make_predicted_instances: np.full(..., nan))
-  const float qnan = __builtin_nanf("");
-  float* ip = instance_peaks + (size_t)b * max_instances * N * 2;
-  float* iv = instance_peak_vals + (size_t)b * max_instances * N;
-  float* is = instance_scores + (size_t)b * max_instances;
-  for (int i = tid; i < max_instances * N * 2; i += nt) ip[i] = qnan;
-  for (int i = tid; i < max_instances * N; i += nt) iv[i] = qnan;
-  for (int i = tid; i < max_instances; i += nt) is[i] = qnan;
-  __syncthreads();
-  if (tid != 0) return;
+  const int wave = threadIdx.x >> 6, waves = blockDim.x >> 6;
+  const int t = blockIdx.x * waves + wave;
+  if (t >= B * E) return;
+  edge_match_wave(t / E, t % E, smem_raw + (size_t)wave * match_lds_bytes(NP), line_scores, node_count, edges, E, N, NP, match_dst,
+                  match_score, status);
+}
 
-  const int32_t* md = match_dst + (size_t)b * E * NP;
-  const float* msc = match_score + (size_t)b * E * NP;
-  const int32_t* ncnt = node_count + (size_t)b * N;
-  int n_order = 0;
+// ------------------------------------------------------------------------------------------------
+// Grouping: the order-dependent greedy assembly of one frame (assign_connections_to_instances + make_predicted_instances,
+// paf_grouping.py:799-981). The walk over the connections is inherently sequential, but every step of it -- highest
+// instance id, node-set intersection, relabelling a merged instance -- is a scan of the (node, peak) table: ONE WAVE runs the
+// walk with those scans spread over its 64 lanes (tables in LDS). `frame_group_seq` is the single-lane form kept for tables
+// that do not fit in LDS (global workspace).
+// Connections come either from the match tables (hot path: edges in `sorted_edge_inds` order, sources ascending) or from an
+// explicit list (conn_*: edge, src peak, dst peak, score in processing order; the dictionary form of the reference's
+// assign_connections_to_instances). `assign_out` (optional) receives the raw instance id of every (node, peak) slot.
+// ------------------------------------------------------------------------------------------------
+struct GroupIn {
+  const float* peak_xy;
+  const float* peak_val;
+  const int32_t* node_count;
+  const int32_t* node_peaks;
+  int max_peaks;
+  const int32_t* match_dst;
+  const float* match_score;
+  const int32_t* edges;
+  const int32_t* sorted_edge_inds;
+  int n_sorted, E, N, NP;
+  float min_line_scores;
+  int min_instance_peaks, max_instances;
+  float* instance_peaks;
+  float* instance_peak_vals;
+  float* instance_scores;
+  int32_t* n_instances;
+  int32_t* status;
+  // explicit connection list (per frame: conn_count[b] entries of stride conn_stride) or nullptr
+  const int32_t* conn_edge;
+  const int32_t* conn_src;
+  const int32_t* conn_dst;
+  const float* conn_score;
+  const int32_t* conn_count;
+  int conn_stride;
+  int32_t* assign_out;  // [B][N*NP] or nullptr
+  // given assignments instead of the greedy walk (make_predicted_instances on a caller's dictionary): assign_in [B][N*NP]
+  // (-1 = not assigned) and the dictionary's key order order_in [B][N*NP] (order_count[b] slot ids), or nullptr
+  const int32_t* assign_in;
+  const int32_t* order_in;
+  const int32_t* order_count;
+};
 
-  // ---- assign_connections_to_instances (paf_grouping.py:799-914)
-  for (int q = 0; q < n_sorted; ++q) {
-    const int k = sorted_edge_inds[q];
-    const int sn = edges[2 * k], dn = edges[2 * k + 1];
-    const int n_src = ncnt[sn];
-    for (int s = 0; s < n_src; ++s) {
-      const int d = md[k * NP + s];
-      if (d < 0) continue;
-      if (!(msc[k * NP + s] >= min_line_scores)) continue;  // group_instances_sample :1067
-      const int src_id = sn * NP + s, dst_id = dn * NP + d;
-      const int si = assign[src_id], di = assign[dst_id];
-      if (si < 0 && di < 0) {
-        int mx = -1;
-        for (int i = 0; i < NN; ++i) mx = max(mx, assign[i]);
-        assign[src_id] = mx + 1;
-        order[n_order++] = src_id;
-        if (dst_id != src_id) {
-          assign[dst_id] = mx + 1;
-          order[n_order++] = dst_id;
-        }
-      } else if (si >= 0 && di < 0) {
-        assign[dst_id] = si;
-        order[n_order++] = dst_id;
-      } else if (si >= 0 && di >= 0) {
-        assign[dst_id] = si;
-        // node sets AFTER the reassignment above, as the reference computes them
-        bool intersect = false;
-        for (int nd = 0; nd < N && !intersect; ++nd) {
-          bool hs = false, hd = false;
-          for (int p = 0; p < NP; ++p) {
-            const int a = assign[nd * NP + p];
-            hs |= (a == si);
-            hd |= (a == di);
-          }
-          intersect = hs && hd;
-        }
-        if (!intersect)
-          for (int i = 0; i < NN; ++i)
-            if (assign[i] == di) assign[i] = si;
-      }
-      // (src unassigned, dst assigned): the reference has no branch for it -> nothing happens
+// assign, order, remap[+1], cell_last, + the frame's match tables and node counts staged for the sequential walk
+__host__ __device__ inline size_t group_lds_bytes(int N, int NP, int max_instances, int E) {
+  return sizeof(int32_t) * (3 * (size_t)N * NP + 1 + (size_t)max_instances * N + 2 * (size_t)E * NP + N);
+}
+
+__device__ __forceinline__ int wave_max_i32(int v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = max(v, __shfl_xor(v, off, 64));
+  return v;
+}
+
+// connection q of the frame in processing order -> (k, s, d, score); returns false when the walk is over. The table form is
+// walked with a cursor (qe, s).
+struct ConnCursor {
+  int qe, s, q;
+};
+
+// `md`, `msc`, `ncnt`: this frame's match tables / node counts (global, or their LDS copies in the wave form: the walk is a
+// chain of dependent reads, ~0.5 us each from global memory, ~30 ns from LDS)
+__device__ __forceinline__ bool next_conn(const GroupIn& g, int b, const int32_t* md, const float* msc, const int32_t* ncnt,
+                                          ConnCursor& c, int& k, int& s, int& d, float& sc) {
+  if (g.conn_edge) {
+    const int n = g.conn_count[b];
+    if (c.q >= n) return false;
+    const size_t o = (size_t)b * g.conn_stride + c.q++;
+    k = g.conn_edge[o], s = g.conn_src[o], d = g.conn_dst[o], sc = g.conn_score[o];
+    return true;
+  }
+  while (c.qe < g.n_sorted) {
+    const int kk = g.sorted_edge_inds[c.qe];
+    const int n_src = ncnt[g.edges[2 * kk]];
+    while (c.s < n_src) {
+      const int ss = c.s++;
+      const int dd = md[kk * g.NP + ss];
+      if (dd < 0) continue;
+      k = kk, s = ss, d = dd, sc = msc[kk * g.NP + ss];
+      return true;
+    }
+    c.s = 0;
+    ++c.qe;
+  }
+  return false;
+}
+
+__device__ void frame_group_wave(const GroupIn& g, int b, int32_t* assign, int32_t* order, int32_t* remap, int32_t* cell_last) {
+  const int lane = threadIdx.x & 63;
+  const int N = g.N, NP = g.NP, NN = N * NP;
+  // stage the tables the sequential walk reads (match_dst / match_score / node_count of this frame) in LDS
+  int32_t* md = cell_last + g.max_instances * N;
+  float* msc = reinterpret_cast<float*>(md + g.E * NP);
+  int32_t* ncnt = md + 2 * g.E * NP;
+  if (!g.conn_edge) {
+    for (int i = lane; i < g.E * NP; i += 64) {
+      md[i] = g.match_dst[(size_t)b * g.E * NP + i];
+      msc[i] = g.match_score[(size_t)b * g.E * NP + i];
     }
   }
+  for (int i = lane; i < N; i += 64) ncnt[i] = g.node_count[(size_t)b * N + i];
+  for (int i = lane; i < NN; i += 64) assign[i] = g.assign_in ? g.assign_in[(size_t)b * NN + i] : -1;
+  int n_order = 0;
+  if (g.assign_in) {
+    n_order = g.order_count[b];
+    for (int i = lane; i < n_order; i += 64) order[i] = g.order_in[(size_t)b * NN + i];
+  }
+  SA_WAVE_SYNC();
+  // ---- assign_connections_to_instances (paf_grouping.py:799-914)
+  ConnCursor cur = {0, 0, 0};
+  int k, s, d;
+  float sc;
+  while (!g.assign_in && next_conn(g, b, md, msc, ncnt, cur, k, s, d, sc)) {
+    if (!(sc >= g.min_line_scores)) continue;  // group_instances_sample :1067
+    const int src_id = g.edges[2 * k] * NP + s, dst_id = g.edges[2 * k + 1] * NP + d;
+    const int si = assign[src_id], di = assign[dst_id];
+    SA_WAVE_SYNC();
+    if (si < 0 && di < 0) {
+      int mx = -1;
+      for (int i = lane; i < NN; i += 64) mx = max(mx, assign[i]);
+      mx = wave_max_i32(mx);
+      SA_WAVE_SYNC();
+      assign[src_id] = mx + 1;
+      order[n_order++] = src_id;
+      if (dst_id != src_id) {
+        assign[dst_id] = mx + 1;
+        order[n_order++] = dst_id;
+      }
+    } else if (si >= 0 && di < 0) {
+      assign[dst_id] = si;
+      order[n_order++] = dst_id;
+    } else if (si >= 0 && di >= 0) {
+      assign[dst_id] = si;
+      SA_WAVE_SYNC();
+      // node sets AFTER the reassignment above, as the reference computes them
+      bool inter = false;
+      for (int nd = lane; nd < N; nd += 64) {
+        bool hs = false, hd = false;
+        const int cnt = ncnt[nd];
+        for (int p = 0; p < cnt; ++p) {
+          const int a = assign[nd * NP + p];
+          hs |= (a == si);
+          hd |= (a == di);
+        }
+        inter |= hs && hd;
+      }
+      if (!__ballot(inter)) {
+        SA_WAVE_SYNC();
+        for (int i = lane; i < NN; i += 64)
+          if (assign[i] == di) assign[i] = si;
+      }
+    }
+    // (src unassigned, dst assigned): the reference has no branch for it -> nothing happens
+    SA_WAVE_SYNC();
+  }
   // ---- optional min_instance_peaks filter (:887-913)
-  if (min_instance_peaks > 0) {
+  if (g.min_instance_peaks > 0 && !g.assign_in) {
+    for (int i = lane; i < NN; i += 64) remap[i] = 0;
+    SA_WAVE_SYNC();
+    for (int i = lane; i < NN; i += 64)
+      if (assign[i] >= 0) atomicAdd(&remap[assign[i]], 1);
+    SA_WAVE_SYNC();
+    for (int i = lane; i < NN; i += 64)
+      if (assign[i] >= 0 && remap[assign[i]] < g.min_instance_peaks) assign[i] = -1 - NN;  // dropped
+    SA_WAVE_SYNC();
+  }
+  if (g.assign_out)
+    for (int i = lane; i < NN; i += 64) g.assign_out[(size_t)b * NN + i] = assign[i];
+  // ---- make_predicted_instances (:917-981): np.unique -> contiguous ids in ascending id order
+  for (int i = lane; i <= NN; i += 64) remap[i] = 0;
+  SA_WAVE_SYNC();
+  for (int i = lane; i < NN; i += 64)
+    if (assign[i] >= 0) remap[assign[i]] = 1;
+  SA_WAVE_SYNC();
+  int n_inst;
+  {  // exclusive prefix sum of the presence flags: a contiguous chunk per lane + a wave scan of the chunk totals
+    const int chunk = (NN + 1 + 63) / 64, lo = lane * chunk, hi = min(lo + chunk, NN + 1);
+    int cnt = 0;
+    for (int i = lo; i < hi; ++i) cnt += remap[i];
+    int incl = cnt;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const int v = __shfl_up(incl, off, 64);
+      if (lane >= off) incl += v;
+    }
+    n_inst = __shfl(incl, 63, 64);
+    int run = incl - cnt;
+    for (int i = lo; i < hi; ++i) {
+      const int present = remap[i];
+      remap[i] = run;
+      run += present;
+    }
+  }
+  SA_WAVE_SYNC();
+  if (n_inst > g.max_instances && lane == 0) atomicOr(&g.status[b], SA_STATUS_INSTANCE_OVERFLOW);
+  const int n_out = min(n_inst, g.max_instances);
+  if (lane == 0) g.n_instances[b] = n_out;
+  float* ip = g.instance_peaks + (size_t)b * g.max_instances * N * 2;
+  float* iv = g.instance_peak_vals + (size_t)b * g.max_instances * N;
+  float* is = g.instance_scores + (size_t)b * g.max_instances;
+  // instance score = sum of its matched edge scores IN CONNECTION ORDER (fp32): one lane per instance walks the list
+  for (int ii = lane; ii < n_out; ii += 64) {
+    float acc = 0.0f;
+    ConnCursor c2 = {0, 0, 0};
+    int k2, s2, d2;
+    float sc2;
+    while (next_conn(g, b, md, msc, ncnt, c2, k2, s2, d2, sc2)) {
+      if (!(sc2 >= g.min_line_scores)) continue;
+      const int a = assign[g.edges[2 * k2] * NP + s2];
+      if (a >= 0 && remap[a] == ii) acc = __fadd_rn(acc, sc2);
+    }
+    is[ii] = acc;
+  }
+  // peaks: dict iteration order, later entries of the same (instance, node) cell overwrite -> the last one wins
+  for (int i = lane; i < n_out * N; i += 64) cell_last[i] = -1;
+  SA_WAVE_SYNC();
+  for (int o = lane; o < n_order; o += 64) {
+    const int id = order[o], a = assign[id];
+    if (a < 0) continue;
+    const int ii = remap[a];
+    if (ii < n_out) atomicMax(&cell_last[ii * N + id / NP], o);
+  }
+  SA_WAVE_SYNC();
+  const int32_t* np_list = g.node_peaks + (size_t)b * N * NP;
+  const float* xy = g.peak_xy + (size_t)b * g.max_peaks * 2;
+  const float* pv = g.peak_val + (size_t)b * g.max_peaks;
+  for (int cell = lane; cell < n_out * N; cell += 64) {
+    const int o = cell_last[cell];
+    if (o < 0) continue;
+    const int pk = np_list[order[o]];
+    ip[(size_t)cell * 2 + 0] = xy[2 * pk];
+    ip[(size_t)cell * 2 + 1] = xy[2 * pk + 1];
+    iv[cell] = pv[pk];
+  }
+}
+
+// single-lane form (tables in a global workspace when they exceed LDS)
+__device__ void frame_group_seq(const GroupIn& g, int b, int32_t* assign, int32_t* order, int32_t* remap) {
+  const int N = g.N, NP = g.NP, NN = N * NP;
+  const int32_t* ncnt = g.node_count + (size_t)b * N;
+  const int32_t* md = g.match_dst ? g.match_dst + (size_t)b * g.E * NP : nullptr;
+  const float* msc = g.match_score ? g.match_score + (size_t)b * g.E * NP : nullptr;
+  for (int i = 0; i < NN; ++i) assign[i] = g.assign_in ? g.assign_in[(size_t)b * NN + i] : -1;
+  int n_order = 0;
+  if (g.assign_in) {
+    n_order = g.order_count[b];
+    for (int i = 0; i < n_order; ++i) order[i] = g.order_in[(size_t)b * NN + i];
+  }
+  ConnCursor cur = {0, 0, 0};
+  int k, s, d;
+  float sc;
+  while (!g.assign_in && next_conn(g, b, md, msc, ncnt, cur, k, s, d, sc)) {
+    if (!(sc >= g.min_line_scores)) continue;
+    const int sn = g.edges[2 * k], dn = g.edges[2 * k + 1];
+    const int src_id = sn * NP + s, dst_id = dn * NP + d;
+    const int si = assign[src_id], di = assign[dst_id];
+    if (si < 0 && di < 0) {
+      int mx = -1;
+      for (int i = 0; i < NN; ++i) mx = max(mx, assign[i]);
+      assign[src_id] = mx + 1;
+      order[n_order++] = src_id;
+      if (dst_id != src_id) {
+        assign[dst_id] = mx + 1;
+        order[n_order++] = dst_id;
+      }
+    } else if (si >= 0 && di < 0) {
+      assign[dst_id] = si;
+      order[n_order++] = dst_id;
+    } else if (si >= 0 && di >= 0) {
+      assign[dst_id] = si;
+      bool intersect = false;
+      for (int nd = 0; nd < N && !intersect; ++nd) {
+        bool hs = false, hd = false;
+        for (int p = 0; p < ncnt[nd]; ++p) {
+          const int a = assign[nd * NP + p];
+          hs |= (a == si);
+          hd |= (a == di);
+        }
+        intersect = hs && hd;
+      }
+      if (!intersect)
+        for (int i = 0; i < NN; ++i)
+          if (assign[i] == di) assign[i] = si;
+    }
+  }
+  if (g.min_instance_peaks > 0 && !g.assign_in) {
     for (int i = 0; i < NN; ++i) remap[i] = 0;
     for (int i = 0; i < NN; ++i)
       if (assign[i] >= 0) remap[assign[i]]++;
     for (int i = 0; i < NN; ++i)
-      if (assign[i] >= 0 && remap[assign[i]] < min_instance_peaks) assign[i] = -1 - NN;  // dropped
+      if (assign[i] >= 0 && remap[assign[i]] < g.min_instance_peaks) assign[i] = -1 - NN;  // dropped
   }
-  // ---- make_predicted_instances (:917-981): np.unique -> contiguous ids in ascending id order
+  if (g.assign_out)
+    for (int i = 0; i < NN; ++i) g.assign_out[(size_t)b * NN + i] = assign[i];
   for (int i = 0; i <= NN; ++i) remap[i] = 0;
   for (int i = 0; i < NN; ++i)
     if (assign[i] >= 0) remap[assign[i]] = 1;
@@ -613,26 +963,24 @@ paf_group_kernel(const float* __restrict__ peak_xy, const float* __restrict__ pe
     remap[i] = n_inst;
     n_inst += present;
   }
-  if (n_inst > max_instances) atomicOr(&status[b], SA_STATUS_INSTANCE_OVERFLOW);
-  const int n_out = min(n_inst, max_instances);
-  n_instances[b] = n_out;
+  if (n_inst > g.max_instances) atomicOr(&g.status[b], SA_STATUS_INSTANCE_OVERFLOW);
+  const int n_out = min(n_inst, g.max_instances);
+  g.n_instances[b] = n_out;
+  float* ip = g.instance_peaks + (size_t)b * g.max_instances * N * 2;
+  float* iv = g.instance_peak_vals + (size_t)b * g.max_instances * N;
+  float* is = g.instance_scores + (size_t)b * g.max_instances;
   for (int i = 0; i < n_out; ++i) is[i] = 0.0f;
-  for (int q = 0; q < n_sorted; ++q) {
-    const int k = sorted_edge_inds[q];
-    const int sn = edges[2 * k];
-    const int n_src = ncnt[sn];
-    for (int s = 0; s < n_src; ++s) {
-      const int d = md[k * NP + s];
-      if (d < 0 || !(msc[k * NP + s] >= min_line_scores)) continue;
-      const int a = assign[sn * NP + s];
-      if (a < 0) continue;
-      const int ii = remap[a];
-      if (ii < n_out) is[ii] = __fadd_rn(is[ii], msc[k * NP + s]);
-    }
+  ConnCursor c2 = {0, 0, 0};
+  while (next_conn(g, b, md, msc, ncnt, c2, k, s, d, sc)) {
+    if (!(sc >= g.min_line_scores)) continue;
+    const int a = assign[g.edges[2 * k] * NP + s];
+    if (a < 0) continue;
+    const int ii = remap[a];
+    if (ii < n_out) is[ii] = __fadd_rn(is[ii], sc);
   }
-  const int32_t* np_list = node_peaks + (size_t)b * N * NP;
-  const float* xy = peak_xy + (size_t)b * max_peaks * 2;
-  const float* pv = peak_val + (size_t)b * max_peaks;
+  const int32_t* np_list = g.node_peaks + (size_t)b * N * NP;
+  const float* xy = g.peak_xy + (size_t)b * g.max_peaks * 2;
+  const float* pv = g.peak_val + (size_t)b * g.max_peaks;
   for (int o = 0; o < n_order; ++o) {  // dict iteration order: later entries overwrite
     const int id = order[o];
     const int a = assign[id];
@@ -644,6 +992,84 @@ paf_group_kernel(const float* __restrict__ peak_xy, const float* __restrict__ pe
     ip[((size_t)ii * N + nd) * 2 + 0] = xy[2 * pk];
     ip[((size_t)ii * N + nd) * 2 + 1] = xy[2 * pk + 1];
     iv[(size_t)ii * N + nd] = pv[pk];
+  }
+}
+
+// NaN-fill of a frame's outputs (make_predicted_instances: np.full(..., nan)) by the whole workgroup
+__device__ void frame_group_fill(const GroupIn& g, int b) {
+  const int tid = threadIdx.x, nt = blockDim.x;
+  const float qnan = __builtin_nanf("");
+  float* ip = g.instance_peaks + (size_t)b * g.max_instances * g.N * 2;
+  float* iv = g.instance_peak_vals + (size_t)b * g.max_instances * g.N;
+  float* is = g.instance_scores + (size_t)b * g.max_instances;
+  for (int i = tid; i < g.max_instances * g.N * 2; i += nt) ip[i] = qnan;
+  for (int i = tid; i < g.max_instances * g.N; i += nt) iv[i] = qnan;
+  for (int i = tid; i < g.max_instances; i += nt) is[i] = qnan;
+}
+
+__global__ void __launch_bounds__(64)
+paf_group_kernel(const GroupIn g, int32_t* __restrict__ workspace) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int b = blockIdx.x, NN = g.N * g.NP;
+  frame_group_fill(g, b);
+  __syncthreads();
+  if (workspace) {  // tables too large for LDS: single lane on the global workspace
+    int32_t* assign = workspace + (size_t)b * (3 * (size_t)NN + 1);
+    if (threadIdx.x == 0) frame_group_seq(g, b, assign, assign + NN, assign + 2 * NN);
+    return;
+  }
+  int32_t* assign = reinterpret_cast<int32_t*>(smem_raw);
+  frame_group_wave(g, b, assign, assign + NN, assign + 2 * NN, assign + 3 * NN + 1);
+}
+
+// ------------------------------------------------------------------------------------------------
+// The whole per-frame post-processing in ONE launch (one workgroup of 4 waves per frame): sort + refine the NMS survivors,
+// bucket + score the candidate connections, match every edge (one wave per edge, 4 at a time), assemble the instances
+// (wave 0). The stages hand their tables over through global memory (the caller's buffers: they are outputs of the ABI
+// anyway) with workgroup barriers in between; LDS is re-used stage by stage. Replaces four dependent launches
+// (~20 us of dispatch + drain each at small batch sizes).
+// ------------------------------------------------------------------------------------------------
+struct FusedIn {
+  const float* cms;
+  const float* offsets;
+  int H, W, C, mode, patch;
+  float xy_scale;
+  int max_peaks;
+  const uint32_t* keys;
+  int32_t* peak_count;
+  float* peak_xy;
+  float* peak_val;
+  int32_t* peak_chan;
+  const float* pafs;
+  int Hp, Wp, n_points;
+  float pafs_stride, max_edge_length, dist_penalty_weight;
+  int32_t* node_count;
+  int32_t* node_peaks;
+  float* line_scores;
+  int32_t* match_dst;
+  float* match_score;
+};
+
+__global__ void __launch_bounds__(1024)
+bottomup_postproc_kernel(const FusedIn f, const GroupIn g) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int b = blockIdx.x;
+  frame_sort_refine(b, reinterpret_cast<uint32_t*>(smem_raw), f.cms, f.offsets, f.H, f.W, f.C, f.mode, f.patch, f.xy_scale,
+                    f.max_peaks, f.keys, f.peak_count, f.peak_xy, f.peak_val, f.peak_chan);
+  __syncthreads();  // (workgroup-scope release/acquire of the global tables written above)
+  frame_score(b, smem_raw, f.pafs, f.Hp, f.Wp, g.E, f.peak_xy, f.peak_chan, f.peak_count, f.max_peaks, g.edges, g.N, f.n_points,
+              f.pafs_stride, f.max_edge_length, f.dist_penalty_weight, g.NP, f.node_count, f.node_peaks, f.line_scores, g.status);
+  frame_group_fill(g, b);
+  __syncthreads();
+  const int wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
+  for (int k = wave; k < g.E; k += n_waves)
+    edge_match_wave(b, k, smem_raw + (size_t)wave * match_lds_bytes(g.NP), f.line_scores, f.node_count, g.edges, g.E, g.N, g.NP,
+                    f.match_dst, f.match_score, g.status);
+  __syncthreads();
+  if (wave == 0) {
+    const int NN = g.N * g.NP;
+    int32_t* assign = reinterpret_cast<int32_t*>(smem_raw);
+    frame_group_wave(g, b, assign, assign + NN, assign + 2 * NN, assign + 3 * NN + 1);
   }
 }
 
@@ -749,12 +1175,57 @@ int sa_paf_score(const float* pafs, int B, int Hp, int Wp, int E, const float* p
   SA_REQUIRE(B > 0 && E >= 0 && N > 0 && N <= MAXNODES, "sa_paf_score: bad B/E/N (%d/%d/%d)", B, E, N);
   SA_REQUIRE(max_node_peaks > 0 && max_node_peaks <= MAXNP, "sa_paf_score: max_node_peaks must be in [1,%d]", MAXNP);
   SA_REQUIRE(n_points >= 1, "sa_paf_score: n_points must be >= 1");
-  const size_t lds = sizeof(int32_t) * ((size_t)N + (size_t)N * max_node_peaks);
+  const size_t lds = score_lds_bytes(N, max_node_peaks, E);
   SA_REQUIRE(lds <= 64 * 1024, "sa_paf_score: N * max_node_peaks too large for the LDS node tables");
   hipLaunchKernelGGL(paf_score_kernel, dim3(B), dim3(256), lds, (hipStream_t)stream, pafs, Hp, Wp, E,
                      peak_xy, peak_chan, peak_count, max_peaks, edges, N, n_points, pafs_stride,
                      max_edge_length, dist_penalty_weight, max_node_peaks, node_count, node_peaks,
                      line_scores, status);
+  SA_LAUNCH_CHECK();
+  return SA_OK;
+}
+
+int sa_paf_line_subs(const float* peaks_xy, const int32_t* edge_peak_inds, const int32_t* edge_inds, int K, int n_points,
+                     float pafs_stride, int32_t* subs, sa_stream_t stream) {
+  SA_REQUIRE(K >= 0 && n_points >= 1, "sa_paf_line_subs: bad shape");
+  if (K == 0) return SA_OK;
+  SA_REQUIRE(peaks_xy && edge_peak_inds && edge_inds && subs, "sa_paf_line_subs: NULL pointer");
+  const int n = K * n_points;
+  hipLaunchKernelGGL(paf_line_subs_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, peaks_xy, edge_peak_inds,
+                     edge_inds, K, n_points, pafs_stride, subs);
+  SA_LAUNCH_CHECK();
+  return SA_OK;
+}
+
+int sa_gather_nd3(const float* src, int H, int W, int C, const int32_t* subs, int n, float* out, int32_t* status,
+                  sa_stream_t stream) {
+  SA_REQUIRE(n >= 0 && H > 0 && W > 0 && C > 0, "sa_gather_nd3: bad shape");
+  if (n == 0) return SA_OK;
+  SA_REQUIRE(src && subs && out, "sa_gather_nd3: NULL pointer");
+  hipLaunchKernelGGL(gather_nd3_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, src, H, W, C, subs, n, out,
+                     status);
+  SA_LAUNCH_CHECK();
+  return SA_OK;
+}
+
+int sa_paf_line_scores(const float* paf_lines, const float* peaks_xy, const int32_t* edge_peak_inds, int K, int n_points,
+                       float max_edge_length, float dist_penalty_weight, float* line_scores, sa_stream_t stream) {
+  SA_REQUIRE(K >= 0 && n_points >= 1, "sa_paf_line_scores: bad shape");
+  if (K == 0) return SA_OK;
+  SA_REQUIRE(paf_lines && peaks_xy && edge_peak_inds && line_scores, "sa_paf_line_scores: NULL pointer");
+  hipLaunchKernelGGL(paf_line_scores_kernel, dim3((K + 255) / 256), dim3(256), 0, (hipStream_t)stream, paf_lines, peaks_xy,
+                     edge_peak_inds, K, n_points, max_edge_length, dist_penalty_weight, line_scores);
+  SA_LAUNCH_CHECK();
+  return SA_OK;
+}
+
+int sa_distance_penalty(const float* lengths, int n, float max_edge_length, float dist_penalty_weight, float* out,
+                        sa_stream_t stream) {
+  SA_REQUIRE(n >= 0, "sa_distance_penalty: bad shape");
+  if (n == 0) return SA_OK;
+  SA_REQUIRE(lengths && out, "sa_distance_penalty: NULL pointer");
+  hipLaunchKernelGGL(distance_penalty_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, lengths, n,
+                     max_edge_length, dist_penalty_weight, out);
   SA_LAUNCH_CHECK();
   return SA_OK;
 }
@@ -765,17 +1236,39 @@ size_t sa_paf_workspace(int B, int E, int N, int max_node_peaks) {
   return (match > group ? match : group) + 64;
 }
 
+static int launch_match(const float* line_scores, const int32_t* node_count, const int32_t* edges, int B, int E, int N, int NP,
+                        int32_t* match_dst, float* match_score, int32_t* status, hipStream_t st) {
+  const size_t per = match_lds_bytes(NP);
+  const int waves = (4 * per <= 60 * 1024) ? 4 : 1;
+  const int nb = (B * E + waves - 1) / waves;
+  hipLaunchKernelGGL(paf_match_kernel, dim3(nb), dim3(64 * waves), waves * per, st, line_scores, node_count, edges, B, E, N, NP,
+                     match_dst, match_score, status);
+  SA_LAUNCH_CHECK();
+  return SA_OK;
+}
+
 int sa_paf_match(const float* line_scores, const int32_t* node_count, const int32_t* edges, int B,
                  int E, int N, int max_node_peaks, int32_t* match_dst, float* match_score,
                  int32_t* status, void* workspace, size_t ws_bytes, sa_stream_t stream) {
   SA_REQUIRE(max_node_peaks > 0 && max_node_peaks <= MAXNP, "sa_paf_match: max_node_peaks must be in [1,%d]", MAXNP);
+  (void)workspace, (void)ws_bytes;  // the solver's work arrays live in LDS (kept in the signature: ABI v1)
   if (B * E == 0) return SA_OK;
-  if (!workspace || ws_bytes < (size_t)B * E * sa::LsaWork::bytes(max_node_peaks))
-    return sa::fail(SA_ERR_WORKSPACE, "sa_paf_match: workspace too small (see sa_paf_workspace)");
-  const int nb = (B * E + 63) / 64;
-  hipLaunchKernelGGL(paf_match_kernel, dim3(nb), dim3(64), 0, (hipStream_t)stream, line_scores,
-                     node_count, edges, B, E, N, max_node_peaks, match_dst, match_score, status,
-                     (unsigned char*)workspace);
+  return launch_match(line_scores, node_count, edges, B, E, N, max_node_peaks, match_dst, match_score, status, (hipStream_t)stream);
+}
+
+static int launch_group(const GroupIn& g, int B, void* workspace, size_t ws_bytes, hipStream_t st) {
+  SA_REQUIRE(g.N > 0 && g.N <= MAXNODES && g.NP > 0 && g.NP <= MAXNP, "sa_paf_group: bad N/max_node_peaks");
+  SA_REQUIRE(g.max_instances > 0, "sa_paf_group: max_instances must be > 0");
+  size_t lds = group_lds_bytes(g.N, g.NP, g.max_instances, g.E);
+  int32_t* ws = nullptr;
+  if (lds > 60 * 1024) {  // tables too large for LDS: single-lane walk on the global workspace
+    const size_t per = sizeof(int32_t) * (3 * (size_t)g.N * g.NP + 1);
+    if (!workspace || ws_bytes < (size_t)B * per)
+      return sa::fail(SA_ERR_WORKSPACE, "sa_paf_group: workspace too small (see sa_paf_workspace)");
+    ws = (int32_t*)workspace;
+    lds = 0;
+  }
+  hipLaunchKernelGGL(paf_group_kernel, dim3(B), dim3(64), lds, st, g, ws);
   SA_LAUNCH_CHECK();
   return SA_OK;
 }
@@ -787,26 +1280,131 @@ int sa_paf_group(const float* peak_xy, const float* peak_val, const int32_t* nod
                  int min_instance_peaks, int max_instances, float* instance_peaks,
                  float* instance_peak_vals, float* instance_scores, int32_t* n_instances,
                  int32_t* status, void* workspace, size_t ws_bytes, sa_stream_t stream) {
-  SA_REQUIRE(N > 0 && N <= MAXNODES && max_node_peaks > 0 && max_node_peaks <= MAXNP, "sa_paf_group: bad N/max_node_peaks");
-  SA_REQUIRE(max_instances > 0, "sa_paf_group: max_instances must be > 0");
-  const size_t nn = (size_t)N * max_node_peaks;
-  size_t lds = sizeof(int32_t) * (3 * nn + 1);
-  int32_t* ws = nullptr;
-  if (lds > 48 * 1024) {  // tables too large for LDS: use the global workspace
-    if (!workspace || ws_bytes < (size_t)B * lds)
-      return sa::fail(SA_ERR_WORKSPACE, "sa_paf_group: workspace too small (see sa_paf_workspace)");
-    ws = (int32_t*)workspace;
-    lds = 0;
-  }
-  hipLaunchKernelGGL(paf_group_kernel, dim3(B), dim3(64), lds, (hipStream_t)stream, peak_xy, peak_val,
-                     node_count, node_peaks, max_peaks, match_dst, match_score, edges, sorted_edge_inds,
-                     n_sorted, E, N, max_node_peaks, min_line_scores, min_instance_peaks, max_instances,
-                     instance_peaks, instance_peak_vals, instance_scores, n_instances, status, ws);
-  SA_LAUNCH_CHECK();
-  return SA_OK;
+  GroupIn g = {};
+  g.peak_xy = peak_xy, g.peak_val = peak_val, g.node_count = node_count, g.node_peaks = node_peaks, g.max_peaks = max_peaks;
+  g.match_dst = match_dst, g.match_score = match_score, g.edges = edges, g.sorted_edge_inds = sorted_edge_inds;
+  g.n_sorted = n_sorted, g.E = E, g.N = N, g.NP = max_node_peaks, g.min_line_scores = min_line_scores;
+  g.min_instance_peaks = min_instance_peaks, g.max_instances = max_instances, g.instance_peaks = instance_peaks;
+  g.instance_peak_vals = instance_peak_vals, g.instance_scores = instance_scores, g.n_instances = n_instances, g.status = status;
+  return launch_group(g, B, workspace, ws_bytes, (hipStream_t)stream);
 }
 
+int sa_paf_group_connections(const float* peak_xy, const float* peak_val, const int32_t* node_count, const int32_t* node_peaks,
+                             int max_peaks, const int32_t* conn_edge, const int32_t* conn_src, const int32_t* conn_dst,
+                             const float* conn_score, const int32_t* conn_count, int conn_stride, const int32_t* edges, int B,
+                             int E, int N, int max_node_peaks, float min_line_scores, int min_instance_peaks, int max_instances,
+                             float* instance_peaks, float* instance_peak_vals, float* instance_scores, int32_t* n_instances,
+                             int32_t* assign_out, const int32_t* assign_in, const int32_t* order_in, const int32_t* order_count,
+                             int32_t* status, void* workspace, size_t ws_bytes, sa_stream_t stream) {
+  SA_REQUIRE(conn_edge && conn_src && conn_dst && conn_score && conn_count && conn_stride >= 0,
+             "sa_paf_group_connections: NULL connection list");
+  SA_REQUIRE(!assign_in == !order_in && !assign_in == !order_count, "sa_paf_group_connections: assign_in, order_in and order_count come together");
+  GroupIn g = {};
+  g.peak_xy = peak_xy, g.peak_val = peak_val, g.node_count = node_count, g.node_peaks = node_peaks, g.max_peaks = max_peaks;
+  g.edges = edges, g.E = E, g.N = N, g.NP = max_node_peaks, g.min_line_scores = min_line_scores;
+  g.min_instance_peaks = min_instance_peaks, g.max_instances = max_instances, g.instance_peaks = instance_peaks;
+  g.instance_peak_vals = instance_peak_vals, g.instance_scores = instance_scores, g.n_instances = n_instances, g.status = status;
+  g.conn_edge = conn_edge, g.conn_src = conn_src, g.conn_dst = conn_dst, g.conn_score = conn_score, g.conn_count = conn_count;
+  g.conn_stride = conn_stride, g.assign_out = assign_out;
+  g.assign_in = assign_in, g.order_in = order_in, g.order_count = order_count;
+  return launch_group(g, B, workspace, ws_bytes, (hipStream_t)stream);
+}
+
+size_t sa_bottomup_postproc_workspace(int B, int max_peaks, int E, int N, int max_node_peaks) {
+  return ((sa_find_local_peaks_workspace(B, max_peaks) + 255) & ~(size_t)255) + sa_paf_workspace(B, E, N, max_node_peaks);
+}
+
+int sa_bottomup_postproc(const float* cms, const float* offsets, int B, int H, int W, int C, float threshold, int refinement,
+                         int patch_size, float xy_scale, int max_peaks, const float* pafs, int Hp, int Wp, int E,
+                         const int32_t* edges, const int32_t* sorted_edge_inds, int n_sorted, int N, int n_points,
+                         float pafs_stride, float max_edge_length, float dist_penalty_weight, int max_node_peaks,
+                         float min_line_scores, int min_instance_peaks, int max_instances, float* peak_xy, float* peak_val,
+                         int32_t* peak_chan, int32_t* peak_count, int32_t* node_count, int32_t* node_peaks, float* line_scores,
+                         int32_t* match_dst, float* match_score, float* instance_peaks, float* instance_peak_vals,
+                         float* instance_scores, int32_t* n_instances, int32_t* status, void* workspace, size_t ws_bytes,
+                         sa_stream_t stream) {
+  SA_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0, "sa_bottomup_postproc: bad shape %dx%dx%dx%d", B, H, W, C);
+  SA_REQUIRE(C == N, "sa_bottomup_postproc: %d confidence-map channels for %d skeleton nodes", C, N);
+  SA_REQUIRE((uint64_t)H * W * C < 0xFFFFFFFFull, "sa_bottomup_postproc: H*W*C exceeds 32-bit keys");
+  SA_REQUIRE(max_peaks > 0 && max_peaks <= 16384, "sa_bottomup_postproc: max_peaks %d out of range", max_peaks);
+  SA_REQUIRE(refinement >= 0 && refinement <= 3, "sa_bottomup_postproc: bad refinement %d", refinement);
+  SA_REQUIRE(refinement != SA_REFINE_OFFSETS || offsets, "sa_bottomup_postproc: offsets is NULL");
+  SA_REQUIRE(refinement != SA_REFINE_INTEGRAL || (patch_size >= 1 && (patch_size & 1)),
+             "sa_bottomup_postproc: integral patch size must be odd, got %d", patch_size);
+  SA_REQUIRE(E >= 0 && N > 0 && N <= MAXNODES && max_node_peaks > 0 && max_node_peaks <= MAXNP && n_points >= 1 &&
+                 max_instances > 0, "sa_bottomup_postproc: bad skeleton / capacity arguments");
+  if (ws_bytes < sa_bottomup_postproc_workspace(B, max_peaks, E, N, max_node_peaks))
+    return sa::fail(SA_ERR_WORKSPACE, "sa_bottomup_postproc: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  uint32_t* keys = (uint32_t*)workspace;
+  unsigned char* paf_ws = (unsigned char*)workspace + ((sa_find_local_peaks_workspace(B, max_peaks) + 255) & ~(size_t)255);
+  const size_t paf_ws_bytes = sa_paf_workspace(B, E, N, max_node_peaks);
+  SA_HIP_CHECK(hipMemsetAsync(peak_count, 0, sizeof(int32_t) * B, st));
+  const size_t plane = (size_t)H * W * C;
+  const int vec4 = (plane % 4 == 0) && (((uintptr_t)cms) % 16 == 0);
+  const size_t work = vec4 ? plane / 4 : plane;
+  int gx = (int)((work + 255) / 256);
+  if (gx > 2048) gx = 2048;
+  hipLaunchKernelGGL(nms_scan_kernel, dim3(gx, B), dim3(256), 0, st, cms, H, W, C, threshold, max_peaks, keys, peak_count, status,
+                     vec4);
+  SA_LAUNCH_CHECK();
+  int n2 = 1;
+  while (n2 < max_peaks) n2 <<= 1;
+  GroupIn g = {};
+  g.peak_xy = peak_xy, g.peak_val = peak_val, g.node_count = node_count, g.node_peaks = node_peaks, g.max_peaks = max_peaks;
+  g.match_dst = match_dst, g.match_score = match_score, g.edges = edges, g.sorted_edge_inds = sorted_edge_inds;
+  g.n_sorted = n_sorted, g.E = E, g.N = N, g.NP = max_node_peaks, g.min_line_scores = min_line_scores;
+  g.min_instance_peaks = min_instance_peaks, g.max_instances = max_instances, g.instance_peaks = instance_peaks;
+  g.instance_peak_vals = instance_peak_vals, g.instance_scores = instance_scores, g.n_instances = n_instances, g.status = status;
+  // small batches: few workgroups on a 256-CU chip, so each one gets a wave per edge (all edges matched at once); large
+  // batches keep 4 waves per frame
+  int n_waves = 4;
+  if (B <= 16) n_waves = E < 4 ? 4 : (E > 16 ? 16 : E);
+  while (n_waves > 4 && (size_t)n_waves * match_lds_bytes(max_node_peaks) > 60 * 1024) --n_waves;
+  size_t lds = (size_t)n2 * sizeof(uint32_t);
+  const size_t l2 = score_lds_bytes(N, max_node_peaks, E), l3 = (size_t)n_waves * match_lds_bytes(max_node_peaks),
+               l4 = group_lds_bytes(N, max_node_peaks, max_instances, E);
+  lds = lds > l2 ? lds : l2;
+  lds = lds > l3 ? lds : l3;
+  lds = lds > l4 ? lds : l4;
+  static const bool no_fuse = getenv("SA_POSTPROC_UNFUSED") && atoi(getenv("SA_POSTPROC_UNFUSED")) != 0;
+  if (lds <= 60 * 1024 && !no_fuse) {
+    FusedIn f = {};
+    f.cms = cms, f.offsets = offsets, f.H = H, f.W = W, f.C = C, f.mode = refinement, f.patch = patch_size, f.xy_scale = xy_scale;
+    f.max_peaks = max_peaks, f.keys = keys, f.peak_count = peak_count, f.peak_xy = peak_xy, f.peak_val = peak_val;
+    f.peak_chan = peak_chan, f.pafs = pafs, f.Hp = Hp, f.Wp = Wp, f.n_points = n_points, f.pafs_stride = pafs_stride;
+    f.max_edge_length = max_edge_length, f.dist_penalty_weight = dist_penalty_weight, f.node_count = node_count;
+    f.node_peaks = node_peaks, f.line_scores = line_scores, f.match_dst = match_dst, f.match_score = match_score;
+    hipLaunchKernelGGL(bottomup_postproc_kernel, dim3(B), dim3(64 * n_waves), lds, st, f, g);
+    SA_LAUNCH_CHECK();
+    return SA_OK;
+  }
+  // capacities beyond one workgroup's LDS: the same stages as separate launches
+  hipLaunchKernelGGL(peaks_sort_refine_kernel, dim3(B), dim3(256), n2 * sizeof(uint32_t), st, cms, offsets, H, W, C, refinement,
+                     patch_size, xy_scale, max_peaks, keys, peak_count, peak_xy, peak_val, peak_chan);
+  SA_LAUNCH_CHECK();
+  int rc = sa_paf_score(pafs, B, Hp, Wp, E, peak_xy, peak_chan, peak_count, max_peaks, edges, N, n_points, pafs_stride,
+                        max_edge_length, dist_penalty_weight, max_node_peaks, node_count, node_peaks, line_scores, status, stream);
+  if (rc != SA_OK) return rc;
+  if (B * E > 0) {
+    rc = launch_match(line_scores, node_count, edges, B, E, N, max_node_peaks, match_dst, match_score, status, st);
+    if (rc != SA_OK) return rc;
+  }
+  return launch_group(g, B, paf_ws, paf_ws_bytes, st);
+}
+
+static int lsa_host_impl(const double* cost, int nr, int nc, int64_t* row_ind, int64_t* col_ind, bool wave);
+
 int sa_lsa_host(const double* cost, int nr, int nc, int64_t* row_ind, int64_t* col_ind) {
+  return lsa_host_impl(cost, nr, nc, row_ind, col_ind, false);
+}
+
+/* the wave-cooperative solver of the matching kernel (lsa_solve_wave) with its 64 lanes emulated on the host */
+int sa_lsa_host_wave(const double* cost, int nr, int nc, int64_t* row_ind, int64_t* col_ind) {
+  return lsa_host_impl(cost, nr, nc, row_ind, col_ind, true);
+}
+
+static int lsa_host_impl(const double* cost, int nr, int nc, int64_t* row_ind, int64_t* col_ind, bool wave) {
   if (nr <= 0 || nc <= 0) return 0;
   if (nr > 4096 || nc > 4096) return sa::fail(SA_ERR_INVALID_ARG, "sa_lsa_host: matrix too large");
   for (long i = 0; i < (long)nr * nc; ++i)
@@ -819,7 +1417,7 @@ int sa_lsa_host(const double* cost, int nr, int nc, int64_t* row_ind, int64_t* c
   const bool tr = nc < nr;
   const int R = tr ? nc : nr, Cn = tr ? nr : nc;
   auto cf = [=](int i, int j) { return tr ? cost[(size_t)j * nc + i] : cost[(size_t)i * nc + j]; };
-  if (!sa::lsa_solve(R, Cn, cf, *w)) return -1;
+  if (!(wave ? sa::lsa_solve_wave(R, Cn, cf, *w) : sa::lsa_solve(R, Cn, cf, *w))) return -1;
   if (!tr) {
     for (int i = 0; i < R; ++i) {
       row_ind[i] = i;

@@ -17,6 +17,7 @@ With `torch.distributed` initialised, `BottomUpPredictor.predict` shards every g
 contiguous frame ranges and gathers the packed results with ONE all-gather (RCCL) per batch.
 """
 import json
+from collections import deque
 import os
 import time
 import zipfile
@@ -382,10 +383,11 @@ class BottomUpInferenceLayer(InferenceLayer):
         instance_peaks (B, I, N, 2), instance_peak_vals (B, I, N), instance_scores (B, I) NaN-padded along I,
         n_valid (B,), status (B,) [+ confmaps, part_affinity_fields, paf graph tables if requested]."""
         cms, pafs, offsets = self.forward_pass(data)
-        peak_xy, peak_val, peak_chan, peak_count, status = self.find_peaks(cms, offsets)
-        res = self.paf_scorer.predict_padded(pafs, peak_xy, peak_val, peak_chan, peak_count, status,
-                                             return_graph=self.return_paf_graph)
-        inst, vals, scores, n_inst = res[0], res[1], res[2], res[3]
+        refinement = self.refinement if self.refinement in ("integral", "local") else None
+        r = self.paf_scorer.predict_from_maps(cms, offsets, pafs, self.peak_threshold, refinement, self.integral_patch_size,
+                                              self.cm_output_stride, self.max_peaks)
+        inst, vals, scores, n_inst, status = (r["instance_peaks"], r["instance_peak_vals"], r["instance_scores"],
+                                              r["n_instances"], r["status"])
         if self.input_scale != 1.0:
             inst = (inst / np.float32(self.input_scale)) + np.float32(0.5)  # :2980-2984
         out = {"instance_peaks": inst, "instance_peak_vals": vals, "instance_scores": scores, "n_valid": n_inst,
@@ -396,9 +398,9 @@ class BottomUpInferenceLayer(InferenceLayer):
         if self.return_pafs:
             out["part_affinity_fields"] = keep(pafs)
         if self.return_paf_graph:
-            out["peaks"], out["peak_vals"], out["peak_channel_inds"], out["peak_count"] = peak_xy, peak_val, peak_chan, peak_count
-            node_count, node_peaks, line_scores, match_dst, match_score = res[5]
-            out["paf_node_count"], out["paf_node_peaks"], out["line_scores"] = node_count, node_peaks, line_scores
+            out["peaks"], out["peak_vals"], out["peak_channel_inds"], out["peak_count"] = (r["peak_xy"], r["peak_val"],
+                                                                                            r["peak_chan"], r["peak_count"])
+            out["paf_node_count"], out["paf_node_peaks"], out["line_scores"] = r["node_count"], r["node_peaks"], r["line_scores"]
         self.release_outputs()
         return out
 
@@ -688,14 +690,152 @@ class TopDownInferenceModel(InferenceModel):
 
 
 # ----------------------------------------------------------------------------------------------------
+# Data pipeline description and progress reporting of the predictors
+# ----------------------------------------------------------------------------------------------------
+class Pipeline:
+    """What `Predictor.make_pipeline` returns (inference.py:329-371; sleap/nn/data/pipelines.py `Pipeline`): the provider and
+    the transformer chain of the reference's inference pipeline -- [SizeMatcher,] Normalizer(ensure_float=False,
+    ensure_grayscale / ensure_rgb), Batcher(batch_size, drop_remainder=False, unrag=False), Prefetcher -- as a description
+    plus `make_dataset()`, a generator of batched examples (`image (b,H,W,C)`, `raw_image_size`, `video_ind`, `frame_ind`,
+    `scale`). The predict loop does not pull frames through this generator (it reads this rank's shard of every batch ahead
+    into page-locked buffers, io/video.py: FramePrefetcher); channel conversion happens on the device in
+    `InferenceLayer.preprocess`."""
+
+    def __init__(self, providers=None, transformers=None, batch_size: int = 4):
+        self.providers = list(providers or [])
+        self.transformers = list(transformers or [])
+        self.batch_size = int(batch_size)
+
+    def __iadd__(self, other):
+        self.transformers.append(other)
+        return self
+
+    def __len__(self):
+        return len(self.providers[0]) if self.providers else 0
+
+    @property
+    def output_keys(self) -> List[str]:
+        return ["image", "raw_image_size", "video_ind", "frame_ind", "scale"]
+
+    def make_dataset(self) -> Iterator[Dict[str, np.ndarray]]:
+        if not self.providers:
+            raise ValueError("Pipeline has no provider")
+        batch = []
+        for ex in self.providers[0].make_dataset():
+            batch.append(ex)
+            if len(batch) == self.batch_size:
+                yield {k: np.stack([np.asarray(e[k]) for e in batch]) for k in batch[0]}
+                batch = []
+        if batch:  # drop_remainder=False
+            yield {k: np.stack([np.asarray(e[k]) for e in batch]) for k in batch[0]}
+
+
+class ProgressReporter:
+    """Progress reporting of `Predictor._predict_generator` (inference.py:421-491): `verbosity` "rich" (progress bar with
+    percentage, ETA and FPS columns, refreshed manually every `report_period` seconds so that notebooks work), "json" (one
+    line `{"n_processed", "n_total", "elapsed", "rate", "eta"}` per report period, rate over the last 30 batches) or "none".
+    Rank 0 reports; use as a context manager and call `update(n_frames_in_batch)` per batch."""
+
+    def __init__(self, verbosity: str, report_rate: float, n_total: int, enabled: bool = True):
+        if verbosity not in ("none", "rich", "json"):
+            raise ValueError(f"'verbosity' must be in ['none', 'rich', 'json'] (got {verbosity!r})")
+        self.verbosity = verbosity if enabled else "none"
+        self.report_period = 1.0 / max(float(report_rate), 1e-6)
+        self.n_total = int(n_total)
+        self._progress = self._task = None
+
+    def __enter__(self):
+        now = time.time()
+        self._last_report = self._t0_all = self._t0_batch = now
+        self.n_processed = 0
+        self._n_recent, self._elapsed_recent = deque(maxlen=30), deque(maxlen=30)
+        if self.verbosity == "rich":
+            try:
+                import rich.progress as rp
+            except ImportError:  # the reference hard-depends on rich; without it the bar degrades to silence
+                self.verbosity = "none"
+                return self
+
+            class RateColumn(rp.ProgressColumn):  # inference.py:145-153
+                def render(self, task):
+                    if task.speed is None:
+                        return rp.Text("?", style="progress.data.speed")
+                    return rp.Text(f"{task.speed:.1f} FPS", style="progress.data.speed")
+
+            self._progress = rp.Progress("{task.description}", rp.BarColumn(), "[progress.percentage]{task.percentage:>3.0f}%",
+                                         "ETA:", rp.TimeRemainingColumn(), RateColumn(), auto_refresh=False,
+                                         refresh_per_second=1.0 / self.report_period, speed_estimate_period=5)
+            self._progress.__enter__()
+            self._task = self._progress.add_task("Predicting...", total=self.n_total)
+        return self
+
+    def update(self, n_batch: int):
+        now = time.time()
+        self.n_processed += int(n_batch)
+        if self.verbosity == "rich":
+            self._progress.update(self._task, advance=int(n_batch))
+            if now - self._last_report > self.report_period:
+                self._progress.refresh()
+                self._last_report = now
+        elif self.verbosity == "json":
+            self._n_recent.append(int(n_batch))
+            self._elapsed_recent.append(now - self._t0_batch)
+            self._t0_batch = now
+            rate = sum(self._n_recent) / max(sum(self._elapsed_recent), 1e-9)
+            if now - self._last_report > self.report_period:
+                print(json.dumps({"n_processed": self.n_processed, "n_total": self.n_total, "elapsed": now - self._t0_all,
+                                  "rate": rate, "eta": (self.n_total - self.n_processed) / max(rate, 1e-9)}), flush=True)
+                self._last_report = now
+
+    def __exit__(self, *exc):
+        if self._progress is not None:
+            self._progress.refresh()
+            self._progress.__exit__(*exc)
+            self._progress = None
+        return False
+
+
+# ----------------------------------------------------------------------------------------------------
 # Predictors
 # ----------------------------------------------------------------------------------------------------
 class Predictor:
     """inference.py:158-591 (the parts on the bottom-up path)."""
 
-    verbosity = "none"
+    verbosity = "rich"  # inference.py:162-166: one of "none", "rich", "json"
     report_rate = 2.0
     model_paths: List[str] = []
+    pipeline = None
+
+    @property
+    def report_period(self) -> float:
+        """Time between progress reports in seconds (inference.py:170-173)."""
+        return 1.0 / self.report_rate
+
+    def make_pipeline(self, data_provider=None) -> Pipeline:
+        """inference.py:329-371: the data pipeline for `data_provider` (a `VideoReader`, `Video` or array); also stored as
+        `self.pipeline`, and rebuilt automatically when predicting from a new source."""
+        from ..io.video import Video, VideoReader
+
+        if isinstance(data_provider, np.ndarray):
+            data_provider = Video.from_numpy(data_provider)
+        if isinstance(data_provider, Video):
+            data_provider = VideoReader(data_provider)
+        pipeline = Pipeline(providers=[data_provider] if data_provider is not None else [], batch_size=self.batch_size)
+        try:
+            pre = (self.data_config or {}).get("preprocessing", {})
+        except AttributeError:
+            pre = {}
+        if pre.get("resize_and_pad_to_target"):
+            pipeline += ("SizeMatcher", {"max_image_height": pre.get("target_height"), "max_image_width": pre.get("target_width")})
+        try:
+            gray = bool(self.is_grayscale)
+        except AttributeError:  # a model object that does not describe its input (stand-ins): follow the source
+            gray = data_provider is None or data_provider.video.channels == 1
+        pipeline += ("Normalizer", {"ensure_float": False, "ensure_grayscale": gray, "ensure_rgb": not gray})
+        pipeline += ("Batcher", {"batch_size": self.batch_size, "drop_remainder": False, "unrag": False})
+        pipeline += ("Prefetcher", {})
+        self.pipeline = pipeline
+        return pipeline
 
     @classmethod
     def from_model_paths(cls, model_paths, peak_threshold: float = 0.2, integral_refinement: bool = True,
@@ -757,6 +897,11 @@ class Predictor:
         n = len(frames)
         rank, world = parallel.rank_world()
         small = {"instance_peaks", "instance_peak_vals", "instance_scores", "n_valid", "centroids", "centroid_vals"}
+        from ..io.video import Video, VideoReader
+
+        self.make_pipeline(data if isinstance(data, (np.ndarray, Video, VideoReader)) else None)
+        reporter = ProgressReporter(self.verbosity, self.report_rate, n, enabled=rank == 0)
+        reporter.__enter__()
 
         def submit(i0):
             """Queue one batch (everything asynchronous that the model leaves asynchronous) -> a ticket."""
@@ -771,6 +916,7 @@ class Predictor:
         # two-deep pipeline: batch k+1 is queued before batch k is brought to the host (the conversion synchronises), so the
         # GPU works on k+1 while the host waits for, converts and hands out k
         if n == 0:
+            reporter.__exit__(None, None, None)
             return
         tickets = [submit(0)]
         for i_next in list(range(self.batch_size, n, self.batch_size)) + [None]:
@@ -800,6 +946,9 @@ class Predictor:
             ex["frame_ind"] = np.arange(i0, i1, dtype=np.int64)
             ex["scale"] = np.ones((i1 - i0, 2), np.float32)
             ex["image_hw"] = np.asarray(frames[0].shape[:2] if hasattr(frames[0], "shape") else (1, 1), np.int64)
+            reporter.update(i1 - i0)
+            if i_next is None:
+                reporter.__exit__(None, None, None)
             yield ex
 
     def predict(self, data, make_labels: bool = True):
@@ -890,7 +1039,7 @@ class SingleInstancePredictor(Predictor):
 
     def __init__(self, confmap_config: dict, confmap_model: DeviceNetwork, inference_model=None, peak_threshold: float = 0.2,
                  integral_refinement: bool = True, integral_patch_size: int = 5, batch_size: int = 4,
-                 verbosity: str = "none", report_rate: float = 2.0, model_paths=None):
+                 verbosity: str = "rich", report_rate: float = 2.0, model_paths=None):
         self.confmap_config = confmap_config
         self.confmap_model = confmap_model
         self.peak_threshold = peak_threshold
@@ -939,7 +1088,7 @@ class TopDownPredictor(Predictor):
     def __init__(self, centroid_config: dict, centroid_model: DeviceNetwork, confmap_config: dict,
                  confmap_model: DeviceNetwork, inference_model=None, peak_threshold: float = 0.2, batch_size: int = 4,
                  integral_refinement: bool = True, integral_patch_size: int = 5, max_instances: Optional[int] = None,
-                 verbosity: str = "none", report_rate: float = 2.0, model_paths=None):
+                 verbosity: str = "rich", report_rate: float = 2.0, model_paths=None):
         self.centroid_config, self.centroid_model = centroid_config, centroid_model
         self.confmap_config, self.confmap_model = confmap_config, confmap_model
         self.peak_threshold = peak_threshold
@@ -1014,7 +1163,7 @@ class BottomUpPredictor(Predictor):
                  tracker=None, peak_threshold: float = 0.2, batch_size: int = 4, integral_refinement: bool = True,
                  integral_patch_size: int = 5, max_edge_length_ratio: float = 0.25, dist_penalty_weight: float = 1.0,
                  paf_line_points: int = 10, min_line_scores: float = 0.25, max_instances: Optional[int] = None,
-                 verbosity: str = "none", report_rate: float = 2.0, model_paths=None):
+                 verbosity: str = "rich", report_rate: float = 2.0, model_paths=None):
         self.bottomup_config = bottomup_config
         self.bottomup_model = bottomup_model
         self.inference_model = inference_model
@@ -1106,9 +1255,6 @@ class BottomUpPredictor(Predictor):
         image_hw = np.asarray(reader.video.shape[1:3], np.int64)  # raw frame size (tracker similarities; present on every rank)
         layer = self.inference_model.bottomup_layer
         rank, world = parallel.rank_world()
-        t0 = time.time()
-        n_done = 0
-        last_report = t0
         batches = [(i0, min(i0 + self.batch_size, n)) for i0 in range(0, n, self.batch_size)]
         mine = [parallel.shard_range(i0, i1, rank, world) for i0, i1 in batches]
         # This rank's frames are read ahead by a producer thread into page-locked buffers (sleap_amd/io/video.py). The loop is a
@@ -1208,31 +1354,24 @@ class BottomUpPredictor(Predictor):
                 ex["image"] = t["image"]
             return ex
 
-        def report(n_done, last_report):
-            now = time.time()
-            if self.verbosity == "json" and (now - last_report) >= 1.0 / max(self.report_rate, 1e-6) and rank == 0:
-                el = now - t0
-                print(json.dumps({"n_processed": n_done, "n_total": n, "elapsed": el, "rate": n_done / max(el, 1e-9),
-                                  "eta": (n - n_done) / max(n_done / max(el, 1e-9), 1e-9)}), flush=True)
-                return now
-            return last_report
+        self.make_pipeline(reader)
+        reporter = ProgressReporter(self.verbosity, self.report_rate, n, enabled=rank == 0)
 
         pending = []
-        for (i0, i1), (lo, hi) in zip(batches, mine):
-            try:
-                pending.append(submit(i0, i1, lo, hi))
-            except StopIteration:  # the source stopped early ("Unable to load frame"): end like the reference does
-                break
-            if len(pending) > 1:
+        with reporter:
+            for (i0, i1), (lo, hi) in zip(batches, mine):
+                try:
+                    pending.append(submit(i0, i1, lo, hi))
+                except StopIteration:  # the source stopped early ("Unable to load frame"): end like the reference does
+                    break
+                if len(pending) > 1:
+                    ex = finalise(pending.pop(0))
+                    reporter.update(len(ex["frame_ind"]))
+                    yield ex
+            while pending:
                 ex = finalise(pending.pop(0))
-                n_done += len(ex["frame_ind"])
-                last_report = report(n_done, last_report)
+                reporter.update(len(ex["frame_ind"]))
                 yield ex
-        while pending:
-            ex = finalise(pending.pop(0))
-            n_done += len(ex["frame_ind"])
-            last_report = report(n_done, last_report)
-            yield ex
 
     def predict(self, data, make_labels: bool = True):
         """inference.py:496-531. `make_labels=False` -> list of per-batch dicts of NumPy arrays
@@ -1285,6 +1424,6 @@ def load_model(model_path: Union[str, List[str]], batch_size: int = 4, peak_thre
                                                resize_input_layer=resize_input_layer, max_instances=max_instances)
     finally:
         _engine.DEFAULT_DTYPE = prev
-    predictor.verbosity = progress_reporting if progress_reporting in ("json", "none") else "none"
+    predictor.verbosity = progress_reporting  # inference.py:4981: "rich" | "json" | "none"
     predictor.tracker = tracker_obj
     return predictor

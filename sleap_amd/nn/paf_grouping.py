@@ -158,6 +158,16 @@ class PAFScorer:
             out = out + ((node_count, node_peaks, line_scores, match_dst, match_score),)
         return out
 
+    def predict_from_maps(self, cms, offsets, pafs, peak_threshold, refinement, integral_patch_size, cm_output_stride, max_peaks,
+                          status=None):
+        """find_peaks + predict on the network's maps in two launches (sa_bottomup_postproc; the hot path of
+        BottomUpInferenceLayer.call). -> dict with every stage's fixed-shape device tensors (ops.bottomup_postproc)."""
+        edges, sorted_e = self._consts(pafs.device)
+        return ops.bottomup_postproc(cms, offsets, pafs, peak_threshold, refinement, integral_patch_size, float(cm_output_stride),
+                                     max_peaks, edges, sorted_e, self.n_nodes, self.n_points, float(self.pafs_stride),
+                                     self.max_edge_length(pafs.shape), self.dist_penalty_weight, self.max_node_peaks,
+                                     self.min_line_scores, self._min_instance_peaks_int(), self.max_instances, status)
+
     # ------------------------------------------------------------------ ragged helpers
     @staticmethod
     def _pad_peaks(peaks, peak_vals, peak_channel_inds, device):
@@ -232,6 +242,18 @@ class PAFScorer:
             raise IndexError("PAF line subscripts out of bounds (TensorFlow-CPU gather_nd raises here)")
         return st
 
+    def match_candidates(self, edge_inds, edge_peak_inds, line_scores):
+        """paf_grouping.py:1498-1550: `match_candidates_batch(edge_inds, edge_peak_inds, line_scores, self.n_edges)`."""
+        return match_candidates_batch(edge_inds, edge_peak_inds, line_scores, self.n_edges)
+
+    def group_instances(self, peaks, peak_vals, peak_channel_inds, match_edge_inds, match_src_peak_inds,
+                        match_dst_peak_inds, match_line_scores):
+        """paf_grouping.py:1552-1627: `group_instances_batch(...)` with this scorer's skeleton tables and thresholds."""
+        return group_instances_batch(peaks, peak_vals, peak_channel_inds, match_edge_inds, match_src_peak_inds,
+                                     match_dst_peak_inds, match_line_scores, self.n_nodes, self.sorted_edge_inds,
+                                     self.edge_types, self.min_instance_peaks, min_line_scores=self.min_line_scores,
+                                     max_instances=max(self.max_instances, 64))
+
     def predict(self, pafs, peaks, peak_vals, peak_channel_inds):
         """paf_grouping.py:1629-1705.
 
@@ -269,11 +291,203 @@ def _scorer_for(skeleton_edges, n_nodes, n_line_points, pafs_stride, max_edge_le
     return PAFScorer(names, edges, pafs_stride, max_edge_length_ratio, dist_penalty_weight, n_line_points, **kw)
 
 
+def _dev_f32(x):
+    return torch.as_tensor(np.ascontiguousarray(_np(x), dtype=np.float32)).cuda()
+
+
+def _dev_i32(x):
+    return torch.as_tensor(np.ascontiguousarray(_np(x), dtype=np.int32)).cuda()
+
+
+def get_connection_candidates(peak_channel_inds_sample, skeleton_edges, n_nodes):
+    """paf_grouping.py:82-142 -> (edge_inds (K,) int32, edge_peak_inds (K, 2) int32): for every skeleton edge, in order, all
+    (source peak, destination peak) pairs, source-major; peaks of a node in their input order (stable argsort).
+
+    The tables come from the scoring kernel's own bucketing pass (sa_paf_score phase 1: node_count / node_peaks), i.e. from
+    the code the hot path runs; only their expansion into the reference's flat lists happens here."""
+    ops.require_cuda()
+    ch = np.ascontiguousarray(_np(peak_channel_inds_sample), dtype=np.int32).reshape(-1)
+    edges_np = np.ascontiguousarray(_np(skeleton_edges), dtype=np.int32).reshape(-1, 2)
+    n, E = len(ch), len(edges_np)
+    if n == 0 or E == 0:
+        return np.zeros((0,), np.int32), np.zeros((0, 2), np.int32)
+    NP = max(int(np.bincount(ch, minlength=n_nodes).max()), 1)
+    dev = torch.device("cuda")
+    status = torch.zeros((1,), dtype=torch.int32, device=dev)
+    node_count, node_peaks, _ = ops.paf_score(
+        torch.zeros((1, 1, 1, 2 * E), dtype=torch.float32, device=dev), torch.zeros((1, n, 2), dtype=torch.float32, device=dev),
+        torch.from_numpy(ch)[None].to(dev), torch.tensor([n], dtype=torch.int32, device=dev), torch.from_numpy(edges_np).to(dev),
+        int(n_nodes), 1, 1.0, 1.0, 0.0, NP, status)
+    node_count, node_peaks = node_count.cpu().numpy()[0], node_peaks.cpu().numpy()[0]
+    ei, epi = [], []
+    for k, (sn, dn) in enumerate(edges_np):
+        src, dst = node_peaks[sn, : node_count[sn]], node_peaks[dn, : node_count[dn]]
+        if len(src) and len(dst):
+            s, d = np.meshgrid(src, dst, indexing="ij")
+            epi.append(np.stack([s, d], axis=2).reshape(-1, 2))
+            ei.append(np.full((len(src) * len(dst),), k, np.int32))
+    if not ei:
+        return np.zeros((0,), np.int32), np.zeros((0, 2), np.int32)
+    return np.concatenate(ei).astype(np.int32), np.concatenate(epi).astype(np.int32)
+
+
+def make_line_subs(peaks_sample, edge_peak_inds, edge_inds, n_line_points, pafs_stride):
+    """paf_grouping.py:145-222 -> (n_candidates, n_line_points, 2, 3) int32 `[row, col, channel]` subscripts into the PAFs."""
+    ops.require_cuda()
+    epi = _dev_i32(edge_peak_inds).reshape(-1, 2)
+    K = epi.shape[0]
+    subs = torch.empty((K, int(n_line_points), 2, 3), dtype=torch.int32, device="cuda")
+    if K:
+        _lib.check(_lib.lib().sa_paf_line_subs(ops._ptr(_dev_f32(peaks_sample).reshape(-1, 2)), ops._ptr(epi),
+                                               ops._ptr(_dev_i32(edge_inds).reshape(-1)), K, int(n_line_points),
+                                               float(pafs_stride), ops._ptr(subs), ops._stream()), "sa_paf_line_subs")
+    return subs.cpu().numpy()
+
+
+def get_paf_lines(pafs_sample, peaks_sample, edge_peak_inds, edge_inds, n_line_points, pafs_stride):
+    """paf_grouping.py:225-275 -> (n_candidates, n_line_points, 2) float32 PAF vectors along every candidate line.
+    TensorFlow-CPU raises for a subscript outside the tensor (TF-GPU yields 0): here it raises IndexError."""
+    ops.require_cuda()
+    pafs = _dev_f32(pafs_sample)
+    H, W, Cc = pafs.shape
+    subs = torch.as_tensor(make_line_subs(peaks_sample, edge_peak_inds, edge_inds, n_line_points, pafs_stride)).cuda()
+    K = subs.shape[0]
+    out = torch.zeros((K, int(n_line_points), 2), dtype=torch.float32, device="cuda")
+    status = torch.zeros((1,), dtype=torch.int32, device="cuda")
+    if K:
+        _lib.check(_lib.lib().sa_gather_nd3(ops._ptr(pafs), H, W, Cc, ops._ptr(subs), K * int(n_line_points) * 2, ops._ptr(out),
+                                            ops._ptr(status), ops._stream()), "sa_gather_nd3")
+    if int(status.item()) & _lib.STATUS_PAF_OOB:
+        raise IndexError("PAF line subscripts out of bounds (TensorFlow-CPU gather_nd raises here)")
+    return out.cpu().numpy()
+
+
+def compute_distance_penalty(spatial_vec_lengths, max_edge_length, dist_penalty_weight=1.0):
+    """paf_grouping.py:278-322: `min(max_edge_length / length - 1, 0) * dist_penalty_weight`, same shape as the input."""
+    ops.require_cuda()
+    x = _dev_f32(spatial_vec_lengths)
+    out = torch.empty_like(x)
+    _lib.check(_lib.lib().sa_distance_penalty(ops._ptr(x), x.numel(), float(max_edge_length), float(dist_penalty_weight),
+                                              ops._ptr(out), ops._stream()), "sa_distance_penalty")
+    return out.cpu().numpy()
+
+
+def score_paf_lines(paf_lines_sample, peaks_sample, edge_peak_inds_sample, max_edge_length, dist_penalty_weight=1.0):
+    """paf_grouping.py:325-403 -> (n_candidates,) float32: mean projection of the line's PAF vectors on the unit vector of
+    the connection + distance penalty."""
+    ops.require_cuda()
+    lines = _dev_f32(paf_lines_sample)
+    K, n_pts = lines.shape[0], lines.shape[1]
+    out = torch.empty((K,), dtype=torch.float32, device="cuda")
+    if K:
+        _lib.check(_lib.lib().sa_paf_line_scores(ops._ptr(lines), ops._ptr(_dev_f32(peaks_sample).reshape(-1, 2)),
+                                                 ops._ptr(_dev_i32(edge_peak_inds_sample).reshape(-1, 2)), K, n_pts,
+                                                 float(max_edge_length), float(dist_penalty_weight), ops._ptr(out),
+                                                 ops._stream()), "sa_paf_line_scores")
+    return out.cpu().numpy()
+
+
 def score_paf_lines_batch(pafs, peaks, peak_channel_inds, skeleton_edges, n_line_points, pafs_stride,
                           max_edge_length_ratio, dist_penalty_weight, n_nodes):
     """paf_grouping.py:406-550 (ragged in/out as per-sample lists)."""
     sc = _scorer_for(skeleton_edges, n_nodes, n_line_points, pafs_stride, max_edge_length_ratio, dist_penalty_weight)
     return sc.score_paf_lines(pafs, peaks, peak_channel_inds)
+
+
+def _group_connections(connections, n_nodes, peaks=None, peak_scores=None, min_instance_peaks=0, assignments=None,
+                       max_instances=None):
+    """One frame through sa_paf_group_connections: `connections` {EdgeType: [EdgeConnection]} in dictionary order. ->
+    (assign table (N, NP) int32, instances (I, N, 2), peak scores (I, N), instance scores (I,))."""
+    ops.require_cuda()
+    edge_types = list(connections.keys())
+    E = len(edge_types)
+    used_nodes = [n for et in edge_types for n in (int(et[0]), int(et[1]))]
+    N = int(n_nodes) if n_nodes is not None else (max(used_nodes) + 1 if used_nodes else 1)
+    if used_nodes and max(used_nodes) >= N:
+        raise IndexError(f"edge type refers to node {max(used_nodes)} of {N}")
+    conns = [(k, int(c[0]), int(c[1]), float(c[2])) for k, et in enumerate(edge_types) for c in connections[et]]
+    NP = 1 + max([0] + [max(c[1], c[2]) for c in conns])
+    if peaks is not None:
+        NP = max([NP] + [len(p) for p in peaks])
+    if assignments is not None:
+        NP = max([NP] + [int(pid[1]) + 1 for pid in assignments])
+    if NP > 512:
+        raise GroupingOverflowError(f"{NP} peaks of one node type exceed the device tables (512)")
+    I = int(max_instances) if max_instances is not None else max(N * NP, 1)  # the reference has no cap
+    dev = torch.device("cuda")
+    i32, f32 = torch.int32, torch.float32
+    K = max(len(conns), 1)
+    ce = torch.zeros((1, K), dtype=i32)
+    cs, cd, csc = ce.clone(), ce.clone(), torch.zeros((1, K), dtype=f32)
+    for q, (k, a, b_, sc) in enumerate(conns):
+        ce[0, q], cs[0, q], cd[0, q], csc[0, q] = k, a, b_, sc
+    edges = torch.tensor([[int(et[0]), int(et[1])] for et in edge_types] or [[0, 0]], dtype=i32).reshape(-1, 2)
+    xy = torch.zeros((1, N * NP, 2), dtype=f32)
+    val = torch.zeros((1, N * NP), dtype=f32)
+    node_count = torch.full((1, N), NP, dtype=i32)
+    if peaks is not None:
+        for nd in range(N):
+            n = len(peaks[nd]) if nd < len(peaks) else 0
+            node_count[0, nd] = n
+            if n:
+                xy[0, nd * NP: nd * NP + n] = torch.as_tensor(np.asarray(_np(peaks[nd]), np.float32).reshape(n, 2))
+                val[0, nd * NP: nd * NP + n] = torch.as_tensor(np.asarray(_np(peak_scores[nd]), np.float32).reshape(n))
+        if assignments is None:
+            node_count[:] = NP  # the walk may name any slot; unnamed slots stay unassigned
+    node_peaks = torch.arange(N * NP, dtype=i32).reshape(1, N, NP)
+    a_in = o_in = o_cnt = None
+    if assignments is not None:
+        a_in = torch.full((1, N * NP), -1, dtype=i32)
+        o_in = torch.zeros((1, N * NP), dtype=i32)
+        for j, (pid, inst) in enumerate(assignments.items()):
+            a_in[0, int(pid[0]) * NP + int(pid[1])] = int(inst)
+            o_in[0, j] = int(pid[0]) * NP + int(pid[1])
+        o_cnt = torch.tensor([len(assignments)], dtype=i32)
+        a_in, o_in, o_cnt = a_in.to(dev), o_in.to(dev), o_cnt.to(dev)
+    mip = int(min_instance_peaks * N) if isinstance(min_instance_peaks, float) else int(min_instance_peaks)
+    inst = torch.empty((1, I, N, 2), dtype=f32, device=dev)
+    vals = torch.empty((1, I, N), dtype=f32, device=dev)
+    scores = torch.empty((1, I), dtype=f32, device=dev)
+    n_inst = torch.zeros((1,), dtype=i32, device=dev)
+    assign = torch.empty((1, N * NP), dtype=i32, device=dev)
+    status = torch.zeros((1,), dtype=i32, device=dev)
+    h = _lib.lib()
+    ws = torch.empty((h.sa_paf_workspace(1, max(E, 1), N, NP),), dtype=torch.uint8, device=dev)
+    P = ops._ptr
+    t = [x.to(dev) for x in (xy, val, node_count, node_peaks, ce, cs, cd, csc, edges)]
+    cnt = torch.tensor([len(conns)], dtype=i32, device=dev)
+    _lib.check(h.sa_paf_group_connections(P(t[0]), P(t[1]), P(t[2]), P(t[3]), N * NP, P(t[4]), P(t[5]), P(t[6]), P(t[7]), P(cnt),
+                                          K, P(t[8]), 1, E, N, NP, float("-inf"), mip, I, P(inst), P(vals), P(scores), P(n_inst),
+                                          P(assign), P(a_in), P(o_in), P(o_cnt), P(status), P(ws), ws.numel(), ops._stream()),
+               "sa_paf_group_connections")
+    _status_check(status, "group connections")
+    n = int(n_inst.item())
+    return (assign.cpu().numpy().reshape(N, NP), inst.cpu().numpy()[0, :n], vals.cpu().numpy()[0, :n], scores.cpu().numpy()[0, :n])
+
+
+def assign_connections_to_instances(connections, min_instance_peaks=0, n_nodes=None):
+    """paf_grouping.py:799-914: {EdgeType: [EdgeConnection]} (walked in dictionary order) -> {PeakID: instance id}. The greedy
+    walk runs in the grouping kernel (csrc/postproc.hip: frame_group_wave); ids are the reference's raw ids (not re-indexed)."""
+    if isinstance(min_instance_peaks, float) and n_nodes is None:  # :887-896: infer from the edge types
+        n_nodes_thr = len({n for et in connections for n in (et[0], et[1])})
+        min_instance_peaks = int(min_instance_peaks * n_nodes_thr)
+    assign, _, _, _ = _group_connections(connections, n_nodes, min_instance_peaks=min_instance_peaks)
+    out = {}
+    for nd, p in zip(*np.nonzero(assign >= 0)):
+        out[PeakID(int(nd), int(p))] = int(assign[nd, p])
+    return out
+
+
+def make_predicted_instances(peaks, peak_scores, connections, instance_assignments):
+    """paf_grouping.py:917-981: node-grouped peaks / scores + connections + a {PeakID: instance id} dictionary ->
+    (predicted_instances (n, n_nodes, 2), predicted_peak_scores (n, n_nodes), predicted_instance_scores (n,)). Like the
+    reference it re-indexes the dictionary's ids in place (contiguous, ascending)."""
+    _, inst, vals, scores = _group_connections(connections, len(peaks), peaks, peak_scores, assignments=instance_assignments)
+    ids = sorted(set(instance_assignments.values()))
+    lut = {v: i for i, v in enumerate(ids)}
+    for k in instance_assignments:
+        instance_assignments[k] = lut[instance_assignments[k]]
+    return inst, vals, scores
 
 
 def match_candidates_batch(edge_inds, edge_peak_inds, line_scores, n_edges):

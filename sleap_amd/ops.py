@@ -174,15 +174,59 @@ def paf_group(peak_xy, peak_val, node_count, node_peaks, match_dst, match_score,
     return inst, vals, scores, n_inst
 
 
-def lsa_host(cost):
-    """Host Hungarian solve with the library's code (scipy.optimize.linear_sum_assignment semantics)."""
+_PP_WS = {}
+
+
+def bottomup_postproc(cms, offsets, pafs, threshold, refinement, patch_size, xy_scale, max_peaks, edges, sorted_edge_inds, n_nodes,
+                      n_points, pafs_stride, max_edge_length, dist_penalty_weight, max_node_peaks, min_line_scores,
+                      min_instance_peaks, max_instances, status=None):
+    """find_peaks + PAFScorer.predict in two launches (sa_bottomup_postproc: NMS scan, then one workgroup per frame for sort /
+    refine / score / match / group). -> dict of the fixed-shape device tensors of every stage."""
+    B, H, W, Cc = cms.shape
+    _, Hp, Wp, C2 = pafs.shape
+    E = C2 // 2
+    dev = cms.device
+    f32, i32 = torch.float32, torch.int32
+    NP, I, N = int(max_node_peaks), int(max_instances), int(n_nodes)
+    o = {"peak_xy": torch.empty((B, max_peaks, 2), dtype=f32, device=dev), "peak_val": torch.empty((B, max_peaks), dtype=f32, device=dev),
+         "peak_chan": torch.empty((B, max_peaks), dtype=i32, device=dev), "peak_count": torch.empty((B,), dtype=i32, device=dev),
+         "node_count": torch.empty((B, N), dtype=i32, device=dev), "node_peaks": torch.empty((B, N, NP), dtype=i32, device=dev),
+         "line_scores": torch.full((B, E, NP, NP), float("nan"), dtype=f32, device=dev),
+         "match_dst": torch.empty((B, E, NP), dtype=i32, device=dev), "match_score": torch.empty((B, E, NP), dtype=f32, device=dev),
+         "instance_peaks": torch.empty((B, I, N, 2), dtype=f32, device=dev), "instance_peak_vals": torch.empty((B, I, N), dtype=f32, device=dev),
+         "instance_scores": torch.empty((B, I), dtype=f32, device=dev), "n_instances": torch.empty((B,), dtype=i32, device=dev)}
+    if status is None:
+        status = torch.zeros((B,), dtype=i32, device=dev)
+    o["status"] = status
+    h = _lib.lib()
+    key = (B, max_peaks, E, N, NP, str(dev))
+    if key not in _PP_WS:
+        if len(_PP_WS) > 8:
+            _PP_WS.clear()
+        _PP_WS[key] = torch.empty((h.sa_bottomup_postproc_workspace(B, max_peaks, E, N, NP),), dtype=torch.uint8, device=dev)
+    ws = _PP_WS[key]
+    mode = REFINE["offsets"] if offsets is not None else REFINE[refinement]
+    check(h.sa_bottomup_postproc(
+        _ptr(cms), _ptr(offsets), B, H, W, Cc, float(threshold), mode, int(patch_size), float(xy_scale), int(max_peaks), _ptr(pafs),
+        Hp, Wp, E, _ptr(edges), _ptr(sorted_edge_inds), int(sorted_edge_inds.numel()), N, int(n_points), float(pafs_stride),
+        float(max_edge_length), float(dist_penalty_weight), NP, float(min_line_scores), int(min_instance_peaks), I,
+        _ptr(o["peak_xy"]), _ptr(o["peak_val"]), _ptr(o["peak_chan"]), _ptr(o["peak_count"]), _ptr(o["node_count"]),
+        _ptr(o["node_peaks"]), _ptr(o["line_scores"]), _ptr(o["match_dst"]), _ptr(o["match_score"]), _ptr(o["instance_peaks"]),
+        _ptr(o["instance_peak_vals"]), _ptr(o["instance_scores"]), _ptr(o["n_instances"]), _ptr(status), _ptr(ws), ws.numel(),
+        _stream()), "sa_bottomup_postproc")
+    return o
+
+
+def lsa_host(cost, wave: bool = False):
+    """Host Hungarian solve with the library's code (scipy.optimize.linear_sum_assignment semantics). `wave=True` runs the
+    wave-cooperative form the matching kernel uses, its 64 lanes emulated on the host."""
     cost = np.ascontiguousarray(np.asarray(cost, dtype=np.float64))
     nr, nc = cost.shape
     n = min(nr, nc)
     rows = np.zeros((max(n, 1),), np.int64)
     cols = np.zeros((max(n, 1),), np.int64)
-    rc = _lib.lib().sa_lsa_host(cost.ctypes.data_as(C.c_void_p), nr, nc, rows.ctypes.data_as(C.c_void_p),
-                                cols.ctypes.data_as(C.c_void_p))
+    fn = _lib.lib().sa_lsa_host_wave if wave else _lib.lib().sa_lsa_host
+    rc = fn(cost.ctypes.data_as(C.c_void_p), nr, nc, rows.ctypes.data_as(C.c_void_p), cols.ctypes.data_as(C.c_void_p))
     if rc < 0:
         raise ValueError("cost matrix is infeasible")
     return rows[:rc], cols[:rc]

@@ -65,9 +65,13 @@ def render_frames(n_frames, height, width, n_animals=4, seed=0):
 # Same skeleton, template pose, similarity transforms, jitter and background statistics as `render_frames`.
 # ---------------------------------------------------------------------------------------------------------------------------
 _EDGE_IDX = [(FLIES13_NODES.index(a), FLIES13_NODES.index(b)) for a, b in FLIES13_EDGES]
-# per node: (amplitude subtracted from the ~170 background, gaussian radius in px)
-_NODE_CODE = [(150.0, 4.5), (160.0, 6.0), (140.0, 5.0), (70.0, 4.0), (110.0, 4.0), (60.0, 2.5), (100.0, 2.5), (60.0, 3.5),
-              (100.0, 3.5), (80.0, 3.0), (125.0, 3.0), (-70.0, 2.0), (-45.0, 3.0)]
+# per node: (shape, amplitude subtracted from the ~170 background, radius in px). Body parts are large dark discs, wings large
+# faint ones, legs small discs (left 60 / right 120) except the hind legs, which are rings, and the eyes are the only BRIGHT
+# marks (they saturate at 255, which nothing in the background reaches): left / right and fore / mid / hind are told apart by
+# amplitude steps of >= 35 grey levels (pixel noise: 4) or by shape, never by context alone.
+_NODE_CODE = [("dot", 150.0, 4.5), ("dot", 165.0, 6.5), ("dot", 135.0, 5.5), ("dot", 45.0, 6.0), ("dot", 85.0, 6.0),
+              ("dot", 60.0, 2.3), ("dot", 120.0, 2.3), ("dot", 60.0, 3.6), ("dot", 120.0, 3.6), ("ring", 70.0, 3.5),
+              ("ring", 130.0, 3.5), ("dot", -85.0, 2.0), ("dot", -85.0, 3.5)]
 
 
 def render_flies(n_frames, height, width, n_animals=4, seed=0, min_sep=170.0, margin=128.0, return_instances=True):
@@ -94,13 +98,17 @@ def render_flies(n_frames, height, width, n_animals=4, seed=0, min_sep=170.0, ma
                 d2 = (xx - (p0[0] + tt * v[0])) ** 2 + (yy - (p0[1] + tt * v[1])) ** 2
                 img[y0:y1, x0:x1] -= (55.0 - 35.0 * tt) * np.exp(-d2 / (2 * 1.5 ** 2))
             for k, p in enumerate(a):
-                amp, rad = _NODE_CODE[k]
-                r = int(3 * rad) + 1
+                shape, amp, rad = _NODE_CODE[k]
+                r = int(3 * rad) + 2
                 cx, cy = int(round(float(p[0]))), int(round(float(p[1])))
                 x0, x1, y0, y1 = max(cx - r, 0), min(cx + r + 1, width), max(cy - r, 0), min(cy + r + 1, height)
                 if x1 <= x0 or y1 <= y0:
                     continue
                 yy, xx = np.mgrid[y0:y1, x0:x1].astype(np.float32)
-                img[y0:y1, x0:x1] -= amp * np.exp(-((xx - p[0]) ** 2 + (yy - p[1]) ** 2) / (2 * rad ** 2))
+                d2 = (xx - p[0]) ** 2 + (yy - p[1]) ** 2
+                if shape == "ring":
+                    img[y0:y1, x0:x1] -= amp * np.exp(-((np.sqrt(d2) - rad) ** 2) / (2 * 1.2 ** 2))
+                else:
+                    img[y0:y1, x0:x1] -= amp * np.exp(-d2 / (2 * rad ** 2))
         frames[t, :, :, 0] = np.clip(img, 0, 255).astype(np.uint8)
     return frames, insts

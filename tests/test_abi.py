@@ -162,4 +162,4 @@ def test_bottomup_fixture_through_ctypes_only():
             assert k == int(nv[b])
         np.testing.assert_array_equal(ip.cpu().numpy()[b, :k], wp[b, :k])
         np.testing.assert_array_equal(isc.cpu().numpy()[b, :k], want["instance_scores"].cpu().numpy()[b, :k])
-    assert int(stt.cpu().numpy().max()) & ~16 == 0  # at most the out-of-bounds PAF sample flag
+    np.testing.assert_array_equal(stt.cpu().numpy(), want["status"].cpu().numpy())  # the same capacity / OOB flags, frame by frame

@@ -65,3 +65,68 @@ def test_find_head_and_output_stride():  # ref tests/nn/test_inference.py:500-53
     assert get_model_output_stride(m) == 4  # output_ind=-1: the last output
     assert get_model_output_stride(m, output_ind=0) == 2 and get_model_output_stride(m, output_ind=1) == 4
     assert find_head(m, "PartAffinityFieldsHead") == 1
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# Predictor surface: verbosity / progress reporting (inference.py:158-173, 421-491) and make_pipeline (:329-371)
+# ---------------------------------------------------------------------------------------------------------------------------
+def test_verbosity_default_and_validation():
+    from sleap_amd.nn.inference import BottomUpPredictor, Predictor, ProgressReporter, SingleInstancePredictor, TopDownPredictor
+
+    import inspect
+
+    assert Predictor.verbosity == "rich" and Predictor.report_rate == 2.0  # the reference's attrs defaults
+    for cls in (BottomUpPredictor, SingleInstancePredictor, TopDownPredictor):
+        assert inspect.signature(cls.__init__).parameters["verbosity"].default == "rich"
+    p = Predictor()
+    assert p.report_period == 0.5
+    import pytest
+
+    with pytest.raises(ValueError):
+        ProgressReporter("loud", 2.0, 10)
+
+
+def test_json_progress_lines_have_the_reference_fields(capsys):
+    import json
+    import time
+
+    from sleap_amd.nn.inference import ProgressReporter
+
+    with ProgressReporter("json", report_rate=1e6, n_total=12) as r:  # report every batch
+        for _ in range(3):
+            time.sleep(0.002)
+            r.update(4)
+    lines = [json.loads(l) for l in capsys.readouterr().out.strip().splitlines()]
+    assert len(lines) == 3
+    assert set(lines[0]) == {"n_processed", "n_total", "elapsed", "rate", "eta"}
+    assert [l["n_processed"] for l in lines] == [4, 8, 12] and lines[-1]["n_total"] == 12
+    assert lines[-1]["eta"] == 0 and lines[0]["rate"] > 0
+    # rank != 0 (enabled=False) and "none" stay silent; "rich" renders a bar without raising
+    for r in (ProgressReporter("json", 1e6, 4, enabled=False), ProgressReporter("none", 2.0, 4), ProgressReporter("rich", 2.0, 4)):
+        with r:
+            r.update(4)
+    assert "n_processed" not in capsys.readouterr().out
+
+
+def test_make_pipeline_describes_the_reference_chain():
+    import numpy as np
+
+    from sleap_amd.nn.inference import Pipeline, Predictor
+
+    class P(Predictor):
+        batch_size = 3
+        is_grayscale = True
+        data_config = {"preprocessing": {"resize_and_pad_to_target": True, "target_height": 16, "target_width": 20}}
+
+    frames = np.arange(7 * 4 * 5, dtype=np.uint8).reshape(7, 4, 5, 1)
+    p = P()
+    pipe = p.make_pipeline(frames)
+    assert isinstance(pipe, Pipeline) and p.pipeline is pipe and len(pipe) == 7
+    assert [t[0] for t in pipe.transformers] == ["SizeMatcher", "Normalizer", "Batcher", "Prefetcher"]
+    assert pipe.transformers[1][1] == {"ensure_float": False, "ensure_grayscale": True, "ensure_rgb": False}
+    assert pipe.transformers[2][1] == {"batch_size": 3, "drop_remainder": False, "unrag": False}
+    batches = list(pipe.make_dataset())
+    assert [len(b["frame_ind"]) for b in batches] == [3, 3, 1]  # drop_remainder=False
+    np.testing.assert_array_equal(np.concatenate([b["image"] for b in batches]), frames)
+    np.testing.assert_array_equal(np.concatenate([b["frame_ind"] for b in batches]), np.arange(7))
+    assert P().make_pipeline().providers == []

@@ -183,6 +183,7 @@ def main():
         loss = lc + lp + (lm if args.margin else 0.0)
         opt.zero_grad(set_to_none=True)
         loss.backward()
+        torch.nn.utils.clip_grad_norm_(net.parameters(), 1.0)  # a single bad step at the top of the LR cycle once zeroed the PAF branch
         opt.step()
         sched.step()
         if step % 25 == 0 or step == args.steps - 1:
