@@ -169,7 +169,9 @@ int sa_paf_group_connections(const float* peak_xy, const float* peak_val, const 
  * candidate connections, matches every edge (one wavefront per edge) and assembles the instances (sa_find_local_peaks +
  * sa_paf_score + sa_paf_match + sa_paf_group fused; same arithmetic, same outputs, same status bits). All the intermediate
  * tables are outputs (caller-owned, shapes as in the separate entry points). Capacities beyond one workgroup's LDS fall back
- * to the separate kernels inside the call. workspace: sa_bottomup_postproc_workspace bytes. */
+ * to the separate kernels inside the call. workspace: sa_bottomup_postproc_workspace bytes, ZEROED ONCE by the caller after
+ * allocation (it starts with the NMS scan's per-frame counters, which every call hands back zeroed -- no memset launch in front
+ * of the scan); keep one workspace per in-flight call. */
 size_t sa_bottomup_postproc_workspace(int B, int max_peaks, int E, int N, int max_node_peaks);
 int sa_bottomup_postproc(const float* cms, const float* offsets, int B, int H, int W, int C, float threshold, int refinement,
                          int patch_size, float xy_scale, int max_peaks, const float* pafs, int Hp, int Wp, int E,
@@ -428,6 +430,25 @@ int sa_tracker_track_frames(void* tracker, int n_frames, int max_inst, int n_nod
 
 /* connect_single_track_breaks (components.py:419-466) in place on a [F, I] track table (-1 = empty slot). */
 int sa_connect_single_track_breaks(int n_frames, int max_inst, const int* order, int* track, int instance_count);
+
+/* Top-down glue on the device (CentroidCrop / FindInstancePeaks, inference.py:1747-1966, 2059-2200): the number of crops per
+ * frame is data dependent in the reference (ragged); here every frame has K crop slots, so nothing between the centroid
+ * network and the instance network needs the host.
+ *   sa_select_centroids   local peaks of the centroid maps (sa_find_local_peaks outputs, grid x stride units) -> per frame K
+ *     slots: centroids [B,K,2] ((p / input_scale) + 0.5 when input_scale != 1, x precrop_resize; NaN in empty slots),
+ *     centroid_vals [B,K], crop_centres [B,K,2] (= centroids, a finite far-outside point for empty slots: an all-zero crop),
+ *     crop_offsets [B,K,2] = centroid - crop_size / 2, n_valid [B]. Peaks keep their order; with 0 <= max_instances < count
+ *     the max_instances strongest in tf.math.top_k order (value descending, ties by lower index). max_instances < 0 = None.
+ *     More than K -> SA_STATUS_INSTANCE_OVERFLOW in status[b].
+ *   sa_finish_instance_peaks   in place on peaks [B*K,N,2] / vals [B*K,N] from sa_find_global_peaks of the crops: (p /
+ *     input_scale) + 0.5 when input_scale != 1, + crop_offsets / input_scale (crop_offsets may be NULL), NaN for slots >=
+ *     n_valid[b]. */
+int sa_select_centroids(const float* peak_xy, const float* peak_val, const int32_t* peak_count, int B, int max_peaks, int K,
+                        int max_instances, float input_scale, float precrop_resize, int crop_size, float* centroids,
+                        float* centroid_vals, float* crop_centres, float* crop_offsets, int32_t* n_valid, int32_t* status,
+                        sa_stream_t stream);
+int sa_finish_instance_peaks(float* peaks, float* vals, const float* crop_offsets, const int32_t* n_valid, int B, int K, int N,
+                             float input_scale, sa_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Whole network / whole layer in one call -- replaces `keras_model(imgs)` (sleap/nn/inference.py:2864-2890) and

@@ -34,6 +34,8 @@ SIGNATURES = {
     "sa_find_local_peaks_workspace": (_sz, [_i, _i]),
     "sa_find_local_peaks": (_i, [_p, _p, _i, _i, _i, _i, _f, _i, _i, _f, _i, _p, _p, _p, _p, _p, _p, _sz, _p]),
     "sa_find_global_peaks": (_i, [_p, _p, _i, _i, _i, _i, _f, _i, _i, _f, _p, _p, _p]),
+    "sa_select_centroids": (_i, [_p, _p, _p, _i, _i, _i, _i, _f, _f, _i, _p, _p, _p, _p, _p, _p, _p]),
+    "sa_finish_instance_peaks": (_i, [_p, _p, _p, _p, _i, _i, _i, _f, _p]),
     "sa_crop_and_resize": (_i, [_p, _i, _i, _i, _i, _p, _p, _i, _i, _p, _p]),
     "sa_paf_score": (_i, [_p, _i, _i, _i, _i, _p, _p, _p, _i, _p, _i, _i, _f, _f, _f, _i, _p, _p, _p, _p, _p]),
     "sa_paf_match": (_i, [_p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _sz, _p]),

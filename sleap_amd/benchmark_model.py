@@ -1,13 +1,20 @@
-"""Random-weight benchmark models of the reference's shipped training profiles.
+"""Benchmark models of the reference's shipped training profiles.
 
-No trained 1024x1024 checkpoints exist offline, so benchmarks use the architecture of
-`sleap/training_profiles/baseline_medium_rf.bottomup.json` (UNet filters 16, rate 2, max_stride 32,
-output_stride 4, bilinear upsampling; confmaps @ stride 4, PAFs @ stride 8) with the 13-node / 12-edge
-`flies13` skeleton and seeded He-normal weights. Random heads emit noise, which would leave peak finding
-and grouping idle (or overflowing), so the two 1x1 heads are affinely calibrated on a few synthetic frames
-such that every confidence-map channel has about `n_animals` local maxima above the 0.2 threshold and PAF
-values have unit-order magnitude: post-processing then runs on realistic peak / candidate counts.
+Architecture of `sleap/training_profiles/baseline_medium_rf.bottomup.json` (UNet filters 16, rate 2, max_stride 32,
+output_stride 4, bilinear upsampling; confmaps @ stride 4, PAFs @ stride 8) with the 13-node / 12-edge `flies13` skeleton.
+
+`build_benchmark_predictor()` (the default, what bench.py and the configs[3] parity tests use) loads weights FITTED to the
+synthetic fly video of `sleap_amd.synth.render_flies` (`sleap_amd/data/benchmark_unet_flies13.npz`, produced by
+tools/train_benchmark_model.py; fp16-representable values stored as float16): the network detects the 4 rendered animals x 13
+nodes with peaks far above the 0.2 threshold and PAF scores far above the 0.25 cut, so the post-processing runs on real
+instance counts and the end-to-end comparison with the fp32 oracle is well conditioned.
+
+`trained=False` gives the round-1 stand-in: seeded He-normal weights with the two 1x1 heads affinely calibrated so that every
+confidence-map channel has about `n_animals` local maxima above the threshold (noise-like maps: fine for timing the network,
+ill-conditioned for parity).
 """
+import os
+
 import numpy as np
 import torch
 
@@ -80,11 +87,29 @@ def calibrate_heads(net: DeviceNetwork, frames_u8: torch.Tensor, n_animals=4, cm
             weights[f"{name}/kernel"], weights[f"{name}/bias"] = k, b
 
 
-def build_benchmark_predictor(height=1024, width=1024, batch_size=64, n_animals=4, seed=0, calib_frames=2, dtype=None):
+TRAINED_WEIGHTS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "benchmark_unet_flies13.npz")
+
+
+def load_trained_weights(path=TRAINED_WEIGHTS):
+    """-> {"<layer>/kernel|bias": float32 array} of the fitted benchmark model (values are exactly fp16-representable)."""
+    if not os.path.exists(path):
+        raise FileNotFoundError(f"{path} is missing: run `python tools/train_benchmark_model.py` (plain torch, CPU is enough) or "
+                                "pass trained=False for the random-init stand-in")
+    z = np.load(path)
+    return {k: z[k].astype(np.float32) for k in z.files if k != "__model_config__"}
+
+
+def build_benchmark_predictor(height=1024, width=1024, batch_size=64, n_animals=4, seed=0, calib_frames=2, dtype=None,
+                              trained=True):
     """-> (BottomUpPredictor on the current CUDA device, keras-style model_config, weights dict)."""
     cfg, mc, weights = build_benchmark_graph(height, width, seed=seed)
+    if trained:
+        fitted = load_trained_weights()
+        assert set(fitted) == set(weights) and all(fitted[k].shape == weights[k].shape for k in weights)
+        weights = fitted
     net = DeviceNetwork(mc, weights, dtype=dtype)
-    frames, _ = render_frames(calib_frames, height, width, n_animals, seed=1234)
-    calibrate_heads(net, torch.from_numpy(frames).cuda(), n_animals, weights=weights)
+    if not trained:
+        frames, _ = render_frames(calib_frames, height, width, n_animals, seed=1234)
+        calibrate_heads(net, torch.from_numpy(frames).cuda(), n_animals, weights=weights)
     pred = BottomUpPredictor(bottomup_config=cfg, bottomup_model=net, batch_size=batch_size)
     return pred, mc, weights

@@ -193,9 +193,11 @@ __device__ void frame_sort_refine(int b, uint32_t* sk, const float* __restrict__
                                   int W, int C, int mode, int k, float xy_scale, int max_peaks,
                                   const uint32_t* __restrict__ keys, int32_t* __restrict__ counts,
                                   float* __restrict__ peak_xy, float* __restrict__ peak_val,
-                                  int32_t* __restrict__ peak_chan) {
+                                  int32_t* __restrict__ peak_chan, int32_t* __restrict__ scan_counts = nullptr) {
+  // `scan_counts` (optional): the NMS scan's atomic counters when they are not `counts` itself; they are handed back ZEROED
+  // for the next call (no memset launch in front of the scan)
   const int tid = threadIdx.x, nt = blockDim.x;
-  const int n = min(counts[b], max_peaks);
+  const int n = min(scan_counts ? scan_counts[b] : counts[b], max_peaks);
   int n2 = 1;
   while (n2 < n) n2 <<= 1;
   for (int i = tid; i < n2; i += nt) sk[i] = (i < n) ? keys[(size_t)b * max_peaks + i] : 0xFFFFFFFFu;
@@ -232,8 +234,11 @@ __device__ void frame_sort_refine(int b, uint32_t* sk, const float* __restrict__
     peak_val[o] = img[e];
     peak_chan[o] = c;
   }
-  __syncthreads();  // every thread has read counts[b]
-  if (tid == 0) counts[b] = n;
+  __syncthreads();  // every thread has read the counter
+  if (tid == 0) {
+    counts[b] = n;
+    if (scan_counts) scan_counts[b] = 0;
+  }
 }
 
 __global__ void __launch_bounds__(256)
@@ -241,10 +246,10 @@ peaks_sort_refine_kernel(const float* __restrict__ cms, const float* __restrict_
                          int W, int C, int mode, int k, float xy_scale, int max_peaks,
                          const uint32_t* __restrict__ keys, int32_t* __restrict__ counts,
                          float* __restrict__ peak_xy, float* __restrict__ peak_val,
-                         int32_t* __restrict__ peak_chan) {
+                         int32_t* __restrict__ peak_chan, int32_t* __restrict__ scan_counts) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   frame_sort_refine(blockIdx.x, reinterpret_cast<uint32_t*>(smem_raw), cms, offsets, H, W, C, mode, k, xy_scale, max_peaks, keys,
-                    counts, peak_xy, peak_val, peak_chan);
+                    counts, peak_xy, peak_val, peak_chan, scan_counts);
 }
 
 // find_global_peaks_rough (+ refinement): one workgroup per (frame, channel).
@@ -366,6 +371,88 @@ crop_and_resize_kernel(const T* __restrict__ images, int H, int W, int C, const 
       o[c] = (T)v;  // tf.cast(crops, images.dtype): truncation for uint8
     }
   }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Top-down glue kept on the device (no host round trip between the centroid model and the instance model):
+//   select_centroids  CentroidCrop.call after find_local_peaks (inference.py:1822-1916): un-scale the peaks
+//                     ((p / input_scale) + 0.5 when input_scale != 1, x precrop_resize), keep each frame's peaks in their
+//                     order -- or, with max_instances < count, tf.math.top_k's (value descending, ties: lower index first)
+//                     -- into K fixed slots per frame; crop offsets = centroid - crop_size / 2
+//   finish_instance_peaks  FindInstancePeaks.call after find_global_peaks (:2150-2178): (p / input_scale) + 0.5, plus
+//                     crop_offset / input_scale, NaN rows for empty slots
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64)
+select_centroids_kernel(const float* __restrict__ peak_xy, const float* __restrict__ peak_val,
+                        const int32_t* __restrict__ peak_count, int max_peaks, int K, int max_instances, float input_scale,
+                        float precrop_resize, float half_crop, float* __restrict__ cent_xy, float* __restrict__ cent_val,
+                        float* __restrict__ crop_centre, float* __restrict__ crop_offset, int32_t* __restrict__ n_valid,
+                        int32_t* __restrict__ status) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  const int n = min(peak_count[b], max_peaks);
+  const float* xy = peak_xy + (size_t)b * max_peaks * 2;
+  const float* pv = peak_val + (size_t)b * max_peaks;
+  const bool topk = max_instances >= 0 && max_instances < n;
+  const int keep = topk ? max_instances : n;
+  const float qnan = __builtin_nanf("");
+  for (int k = lane; k < K; k += 64) {
+    const size_t o = (size_t)b * K + k;
+    cent_xy[2 * o] = cent_xy[2 * o + 1] = qnan;
+    cent_val[o] = qnan;
+    crop_centre[2 * o] = crop_centre[2 * o + 1] = -8.0f * half_crop - 16.0f;  // a finite centre far outside: an all-zero crop
+    crop_offset[2 * o] = crop_offset[2 * o + 1] = qnan;
+  }
+  __syncthreads();
+  for (int i = lane; i < n; i += 64) {
+    int slot = i;
+    if (topk) {  // rank in (value descending, index ascending): top_k's output order
+      const float v = pv[i];
+      int rank = 0;
+      for (int j = 0; j < n; ++j) rank += (pv[j] > v) || (pv[j] == v && j < i);
+      slot = rank;
+    }
+    if (slot >= keep || slot >= K) continue;
+    float x = xy[2 * i], y = xy[2 * i + 1];
+    if (input_scale != 1.0f) {
+      x = __fadd_rn(__fdiv_rn(x, input_scale), 0.5f);
+      y = __fadd_rn(__fdiv_rn(y, input_scale), 0.5f);
+    }
+    if (precrop_resize != 1.0f) {
+      x = __fmul_rn(x, precrop_resize);
+      y = __fmul_rn(y, precrop_resize);
+    }
+    const size_t o = (size_t)b * K + slot;
+    cent_xy[2 * o] = x, cent_xy[2 * o + 1] = y;
+    crop_centre[2 * o] = x, crop_centre[2 * o + 1] = y;
+    crop_offset[2 * o] = __fsub_rn(x, half_crop), crop_offset[2 * o + 1] = __fsub_rn(y, half_crop);
+    cent_val[o] = pv[i];
+  }
+  if (lane == 0) {
+    n_valid[b] = min(keep, K);
+    if (keep > K) atomicOr(&status[b], SA_STATUS_INSTANCE_OVERFLOW);
+  }
+}
+
+__global__ void __launch_bounds__(256)
+finish_instance_peaks_kernel(float* __restrict__ peaks, float* __restrict__ vals, const float* __restrict__ crop_offset,
+                             const int32_t* __restrict__ n_valid, int B, int K, int N, float input_scale) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= B * K * N) return;
+  const int slot = t / N, b = slot / K, k = slot % K;
+  if (k >= n_valid[b]) {
+    peaks[2 * (size_t)t] = peaks[2 * (size_t)t + 1] = vals[t] = __builtin_nanf("");
+    return;
+  }
+  float x = peaks[2 * (size_t)t], y = peaks[2 * (size_t)t + 1];
+  if (input_scale != 1.0f) {
+    x = __fadd_rn(__fdiv_rn(x, input_scale), 0.5f);
+    y = __fadd_rn(__fdiv_rn(y, input_scale), 0.5f);
+  }
+  if (crop_offset) {
+    x = __fadd_rn(x, __fdiv_rn(crop_offset[2 * (size_t)slot], input_scale));
+    y = __fadd_rn(y, __fdiv_rn(crop_offset[2 * (size_t)slot + 1], input_scale));
+  }
+  peaks[2 * (size_t)t] = x, peaks[2 * (size_t)t + 1] = y;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -538,11 +625,7 @@ paf_line_subs_kernel(const float* __restrict__ peaks_xy, const int32_t* __restri
   const LineDir ld = line_dir(sx, sy, ex, ey, n_points);
   float px, py;
   line_point(ld, sx, sy, ex, ey, i, n_points, px, py);
-  // rounded in float first, converted after an opaque barrier: written as (int)rintf(x) the pair is folded into one
-  // float->int conversion that TRUNCATES (1.5 -> 1; caught by the half-to-even case of the reference-mirroring test)
-  float rx = rintf(__fdiv_rn(px, pafs_stride)), ry = rintf(__fdiv_rn(py, pafs_stride));
-  asm volatile("" : "+v"(rx), "+v"(ry));
-  const int col = (int)rx, row = (int)ry;
+  const int col = (int)rintf(__fdiv_rn(px, pafs_stride)), row = (int)rintf(__fdiv_rn(py, pafs_stride));  // tf.round: half to even
   int32_t* o = subs + (size_t)t * 6;
   o[0] = row, o[1] = col, o[2] = 2 * edge_inds[k];
   o[3] = row, o[4] = col, o[5] = 2 * edge_inds[k] + 1;
@@ -1036,6 +1119,7 @@ struct FusedIn {
   float xy_scale;
   int max_peaks;
   const uint32_t* keys;
+  int32_t* scan_counts;
   int32_t* peak_count;
   float* peak_xy;
   float* peak_val;
@@ -1055,7 +1139,7 @@ bottomup_postproc_kernel(const FusedIn f, const GroupIn g) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int b = blockIdx.x;
   frame_sort_refine(b, reinterpret_cast<uint32_t*>(smem_raw), f.cms, f.offsets, f.H, f.W, f.C, f.mode, f.patch, f.xy_scale,
-                    f.max_peaks, f.keys, f.peak_count, f.peak_xy, f.peak_val, f.peak_chan);
+                    f.max_peaks, f.keys, f.peak_count, f.peak_xy, f.peak_val, f.peak_chan, f.scan_counts);
   __syncthreads();  // (workgroup-scope release/acquire of the global tables written above)
   frame_score(b, smem_raw, f.pafs, f.Hp, f.Wp, g.E, f.peak_xy, f.peak_chan, f.peak_count, f.max_peaks, g.edges, g.N, f.n_points,
               f.pafs_stride, f.max_edge_length, f.dist_penalty_weight, g.NP, f.node_count, f.node_peaks, f.line_scores, g.status);
@@ -1132,7 +1216,7 @@ int sa_find_local_peaks(const float* cms, const float* offsets, int B, int H, in
   while (n2 < max_peaks) n2 <<= 1;
   hipLaunchKernelGGL(peaks_sort_refine_kernel, dim3(B), dim3(256), n2 * sizeof(uint32_t), st, cms,
                      offsets, H, W, C, refinement, patch_size, xy_scale, max_peaks, keys, peak_count,
-                     peak_xy, peak_val, peak_chan);
+                     peak_xy, peak_val, peak_chan, (int32_t*)nullptr);
   SA_LAUNCH_CHECK();
   return SA_OK;
 }
@@ -1162,6 +1246,30 @@ int sa_crop_and_resize(const void* images, int is_u8, int H, int W, int C, const
   else
     hipLaunchKernelGGL((crop_and_resize_kernel<float>), dim3(g), dim3(256), 0, (hipStream_t)stream,
                        (const float*)images, H, W, C, centres_xy, sample_inds, n, crop, (float*)out);
+  SA_LAUNCH_CHECK();
+  return SA_OK;
+}
+
+int sa_select_centroids(const float* peak_xy, const float* peak_val, const int32_t* peak_count, int B, int max_peaks, int K,
+                        int max_instances, float input_scale, float precrop_resize, int crop_size, float* centroids,
+                        float* centroid_vals, float* crop_centres, float* crop_offsets, int32_t* n_valid, int32_t* status,
+                        sa_stream_t stream) {
+  SA_REQUIRE(B > 0 && max_peaks > 0 && K > 0 && crop_size > 0, "sa_select_centroids: bad shape");
+  SA_REQUIRE(peak_xy && peak_val && peak_count && centroids && centroid_vals && crop_centres && crop_offsets && n_valid && status,
+             "sa_select_centroids: NULL pointer");
+  hipLaunchKernelGGL(select_centroids_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, peak_xy, peak_val, peak_count, max_peaks,
+                     K, max_instances, input_scale, precrop_resize, (float)crop_size / 2.0f, centroids, centroid_vals, crop_centres,
+                     crop_offsets, n_valid, status);
+  SA_LAUNCH_CHECK();
+  return SA_OK;
+}
+
+int sa_finish_instance_peaks(float* peaks, float* vals, const float* crop_offsets, const int32_t* n_valid, int B, int K, int N,
+                             float input_scale, sa_stream_t stream) {
+  SA_REQUIRE(B > 0 && K > 0 && N > 0 && peaks && vals && n_valid, "sa_finish_instance_peaks: bad arguments");
+  const int n = B * K * N;
+  hipLaunchKernelGGL(finish_instance_peaks_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, peaks, vals,
+                     crop_offsets, n_valid, B, K, N, input_scale);
   SA_LAUNCH_CHECK();
   return SA_OK;
 }
@@ -1310,8 +1418,11 @@ int sa_paf_group_connections(const float* peak_xy, const float* peak_val, const 
   return launch_group(g, B, workspace, ws_bytes, (hipStream_t)stream);
 }
 
+static size_t pp_keys_bytes(int B, int max_peaks) { return (sa_find_local_peaks_workspace(B, max_peaks) + 255) & ~(size_t)255; }
+static size_t pp_counts_bytes(int B) { return ((size_t)B * sizeof(int32_t) + 255) & ~(size_t)255; }
+
 size_t sa_bottomup_postproc_workspace(int B, int max_peaks, int E, int N, int max_node_peaks) {
-  return ((sa_find_local_peaks_workspace(B, max_peaks) + 255) & ~(size_t)255) + sa_paf_workspace(B, E, N, max_node_peaks);
+  return pp_counts_bytes(B) + pp_keys_bytes(B, max_peaks) + sa_paf_workspace(B, E, N, max_node_peaks);
 }
 
 int sa_bottomup_postproc(const float* cms, const float* offsets, int B, int H, int W, int C, float threshold, int refinement,
@@ -1336,16 +1447,18 @@ int sa_bottomup_postproc(const float* cms, const float* offsets, int B, int H, i
   if (ws_bytes < sa_bottomup_postproc_workspace(B, max_peaks, E, N, max_node_peaks))
     return sa::fail(SA_ERR_WORKSPACE, "sa_bottomup_postproc: workspace too small");
   hipStream_t st = (hipStream_t)stream;
-  uint32_t* keys = (uint32_t*)workspace;
-  unsigned char* paf_ws = (unsigned char*)workspace + ((sa_find_local_peaks_workspace(B, max_peaks) + 255) & ~(size_t)255);
+  // workspace = [scan counters | keys | paf scratch]. The counters are zero on entry BY CONTRACT (zeroed once by the caller
+  // after allocation, handed back zeroed by every call): the scan needs no memset launch in front of it.
+  int32_t* scan_counts = (int32_t*)workspace;
+  uint32_t* keys = (uint32_t*)((unsigned char*)workspace + pp_counts_bytes(B));
+  unsigned char* paf_ws = (unsigned char*)keys + pp_keys_bytes(B, max_peaks);
   const size_t paf_ws_bytes = sa_paf_workspace(B, E, N, max_node_peaks);
-  SA_HIP_CHECK(hipMemsetAsync(peak_count, 0, sizeof(int32_t) * B, st));
   const size_t plane = (size_t)H * W * C;
   const int vec4 = (plane % 4 == 0) && (((uintptr_t)cms) % 16 == 0);
   const size_t work = vec4 ? plane / 4 : plane;
   int gx = (int)((work + 255) / 256);
   if (gx > 2048) gx = 2048;
-  hipLaunchKernelGGL(nms_scan_kernel, dim3(gx, B), dim3(256), 0, st, cms, H, W, C, threshold, max_peaks, keys, peak_count, status,
+  hipLaunchKernelGGL(nms_scan_kernel, dim3(gx, B), dim3(256), 0, st, cms, H, W, C, threshold, max_peaks, keys, scan_counts, status,
                      vec4);
   SA_LAUNCH_CHECK();
   int n2 = 1;
@@ -1371,7 +1484,8 @@ int sa_bottomup_postproc(const float* cms, const float* offsets, int B, int H, i
   if (lds <= 60 * 1024 && !no_fuse) {
     FusedIn f = {};
     f.cms = cms, f.offsets = offsets, f.H = H, f.W = W, f.C = C, f.mode = refinement, f.patch = patch_size, f.xy_scale = xy_scale;
-    f.max_peaks = max_peaks, f.keys = keys, f.peak_count = peak_count, f.peak_xy = peak_xy, f.peak_val = peak_val;
+    f.max_peaks = max_peaks, f.keys = keys, f.scan_counts = scan_counts, f.peak_count = peak_count, f.peak_xy = peak_xy;
+    f.peak_val = peak_val;
     f.peak_chan = peak_chan, f.pafs = pafs, f.Hp = Hp, f.Wp = Wp, f.n_points = n_points, f.pafs_stride = pafs_stride;
     f.max_edge_length = max_edge_length, f.dist_penalty_weight = dist_penalty_weight, f.node_count = node_count;
     f.node_peaks = node_peaks, f.line_scores = line_scores, f.match_dst = match_dst, f.match_score = match_score;
@@ -1381,7 +1495,7 @@ int sa_bottomup_postproc(const float* cms, const float* offsets, int B, int H, i
   }
   // capacities beyond one workgroup's LDS: the same stages as separate launches
   hipLaunchKernelGGL(peaks_sort_refine_kernel, dim3(B), dim3(256), n2 * sizeof(uint32_t), st, cms, offsets, H, W, C, refinement,
-                     patch_size, xy_scale, max_peaks, keys, peak_count, peak_xy, peak_val, peak_chan);
+                     patch_size, xy_scale, max_peaks, keys, peak_count, peak_xy, peak_val, peak_chan, scan_counts);
   SA_LAUNCH_CHECK();
   int rc = sa_paf_score(pafs, B, Hp, Wp, E, peak_xy, peak_chan, peak_count, max_peaks, edges, N, n_points, pafs_stride,
                         max_edge_length, dist_penalty_weight, max_node_peaks, node_count, node_peaks, line_scores, status, stream);

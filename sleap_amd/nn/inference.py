@@ -529,7 +529,25 @@ class CentroidCrop(InferenceLayer):
         self.precrop_resize = precrop_resize
         self.max_peaks = max_peaks
 
-    def call(self, inputs):
+    # crop slots per frame of the device path when max_instances is None: grows on overflow (status bit, like the bottom-up
+    # capacities) and follows the largest count seen so far (`observe`)
+    max_crops = 8
+
+    def _slots(self) -> int:
+        return max(1, int(self.max_instances)) if self.max_instances is not None else max(1, int(self.max_crops))
+
+    def observe(self, n_valid_max: int):
+        """Host feedback once a batch's results are on the host: with max_instances None the slot count follows the largest
+        number of centroids seen in a frame so far (a constant number of animals is the common case), so later batches do
+        not run the instance network on empty slots."""
+        if self.max_instances is None and n_valid_max > 0:
+            self._seen = max(getattr(self, "_seen", 0), int(n_valid_max))
+            self.max_crops = max(self._seen, 1)
+
+    def call_padded(self, inputs):
+        """The device form of `call` (inference.py:1747-1966): K fixed crop slots per frame, nothing is brought to the host.
+        -> centroids (B, K, 2) NaN padded, centroid_vals (B, K), n_valid (B,), crops (B*K, crop, crop, C) (zeros in empty
+        slots), crop_offsets (B*K, 2), status (B,) [SA_STATUS_INSTANCE_OVERFLOW: more centroids than slots], samples, K."""
         full_imgs = _as_device_images(inputs)
         imgs = self.preprocess(full_imgs)
         out = self.keras_model.forward(imgs)
@@ -537,43 +555,56 @@ class CentroidCrop(InferenceLayer):
         offsets = out[self.offsets_ind] if self.offsets_ind is not None else None
         B = cms.shape[0]
         refinement = self.refinement if self.refinement in ("integral", "local") else None
-        while True:
-            pxy, pval, pch, pcnt, status = ops.find_local_peaks(cms, offsets, self.peak_threshold, refinement,
-                                                                self.integral_patch_size, float(self.output_stride),
-                                                                self.max_peaks)
-            bits = int(np.bitwise_or.reduce(status.cpu().numpy()))
-            if bits & _lib.STATUS_NONFINITE:
-                raise FloatingPointError(NONFINITE_MESSAGE)
-            if not (bits & _lib.STATUS_PEAK_OVERFLOW) or self.max_peaks >= 16384:
-                break
-            self.max_peaks *= 2
-        P = pval.shape[1]
-        mask = torch.arange(P, device=pval.device)[None, :] < pcnt[:, None]
-        sample_inds = torch.arange(B, device=pval.device, dtype=torch.int32)[:, None].expand(B, P)[mask]
-        pts, vals = pxy[mask], pval[mask]
-        if self.input_scale != 1.0:
-            pts = (pts / np.float32(self.input_scale)) + np.float32(0.5)
+        pxy, pval, pch, pcnt, status = ops.find_local_peaks(cms, offsets, self.peak_threshold, refinement,
+                                                            self.integral_patch_size, float(self.output_stride), self.max_peaks)
+        K = self._slots()
+        dev = cms.device
+        cent = torch.empty((B, K, 2), dtype=torch.float32, device=dev)
+        cval = torch.empty((B, K), dtype=torch.float32, device=dev)
+        centres = torch.empty((B, K, 2), dtype=torch.float32, device=dev)
+        coff = torch.empty((B, K, 2), dtype=torch.float32, device=dev)
+        n_valid = torch.empty((B,), dtype=torch.int32, device=dev)
+        _lib.check(_lib.lib().sa_select_centroids(
+            ops._ptr(pxy), ops._ptr(pval), ops._ptr(pcnt), B, pxy.shape[1], K, -1 if self.max_instances is None else int(self.max_instances),
+            float(self.input_scale), float(self.precrop_resize), int(self.crop_size), ops._ptr(cent), ops._ptr(cval), ops._ptr(centres),
+            ops._ptr(coff), ops._ptr(n_valid), ops._ptr(status), ops._stream()), "sa_select_centroids")
         if self.precrop_resize != 1.0:
             full_imgs = _resize_image(full_imgs, self.precrop_resize)
-            pts = pts * np.float32(self.precrop_resize)
-        if pts.shape[0] > 0 and self.max_instances is not None:
-            keep = []
-            for b in range(B):  # tf.math.top_k per sample (:1850-1916)
-                sel = torch.nonzero(sample_inds == b).reshape(-1)
-                if self.max_instances < sel.numel():
-                    order = torch.sort(vals[sel], descending=True, stable=True).indices[: self.max_instances]
-                    sel = sel[order]
-                keep.append(sel)
-            keep = torch.cat(keep)
-            pts, vals, sample_inds = pts[keep], vals[keep], sample_inds[keep]
-        crop_offsets = pts - np.float32(self.crop_size / 2)
-        crops = ops.crop_and_resize(full_imgs, pts, sample_inds, self.crop_size)
-        outputs = dict(centroids=pts, centroid_vals=vals, crop_sample_inds=sample_inds, samples=B)
+        sample_inds = torch.arange(B, device=dev, dtype=torch.int32).repeat_interleave(K)
+        crops = ops.crop_and_resize(full_imgs, centres.reshape(B * K, 2), sample_inds, self.crop_size)
+        outputs = dict(centroids=cent, centroid_vals=cval, n_valid=n_valid, status=status, samples=B, K=K, padded=True,
+                       crops=crops, crop_offsets=coff.reshape(B * K, 2))
         if self.return_confmaps:
             outputs["centroid_confmaps"] = cms
+        return outputs
+
+    def call(self, inputs):
+        """inference.py:1747-1966 with the reference's FLAT (ragged) outputs: centroids (n, 2), centroid_vals (n,),
+        crop_sample_inds (n,), crops (n, crop, crop, C), crop_offsets (n, 2). Built from `call_padded` -- sizing a ragged
+        result needs the counts on the host (one small copy); `TopDownInferenceModel` uses the padded form directly."""
+        while True:
+            o = self.call_padded(inputs)
+            bits = int(np.bitwise_or.reduce(o["status"].cpu().numpy())) if o["samples"] else 0
+            if bits & _lib.STATUS_NONFINITE:
+                raise FloatingPointError(NONFINITE_MESSAGE)
+            if bits & _lib.STATUS_PEAK_OVERFLOW and self.max_peaks < 16384:
+                self.max_peaks *= 2
+                continue
+            if bits & _lib.STATUS_INSTANCE_OVERFLOW and self.max_instances is None and self.max_crops < 1024:
+                self.max_crops *= 2
+                continue
+            break
+        B, K = o["samples"], o["K"]
+        nv = o["n_valid"].cpu().numpy()
+        keep = torch.from_numpy((np.arange(K)[None, :] < nv[:, None]).reshape(-1)).to(o["centroids"].device)
+        sample_inds = torch.arange(B, device=keep.device, dtype=torch.int32).repeat_interleave(K)[keep]
+        outputs = dict(centroids=o["centroids"].reshape(B * K, 2)[keep], centroid_vals=o["centroid_vals"].reshape(B * K)[keep],
+                       crop_sample_inds=sample_inds, samples=B)
+        if self.return_confmaps:
+            outputs["centroid_confmaps"] = o["centroid_confmaps"]
         if self.return_crops:
-            outputs["crops"] = crops
-            outputs["crop_offsets"] = crop_offsets
+            outputs["crops"] = o["crops"][keep]
+            outputs["crop_offsets"] = o["crop_offsets"][keep]
         return outputs
 
     __call__ = call
@@ -598,7 +629,34 @@ class FindInstancePeaks(InferenceLayer):
         self.return_confmaps = return_confmaps
         self.resize_input_image = resize_input_image
 
+    def call_padded(self, inputs):
+        """`call` on the fixed-slot output of `CentroidCrop.call_padded`: the instance network runs on all B*K crop slots,
+        empty slots come out as NaN rows; nothing is brought to the host. -> instance_peaks (B, K, N, 2), instance_peak_vals
+        (B, K, N), centroids (B, K, 2), centroid_vals (B, K), n_valid (B,), status (B,)."""
+        crops, B, K = inputs["crops"], inputs["samples"], inputs["K"]
+        x = self.preprocess(crops, resize_img=self.resize_input_image)
+        out = self.keras_model.forward(x)
+        cms = out[self.confmaps_ind]
+        offsets = out[self.offsets_ind] if self.offsets_ind is not None else None
+        refinement = self.refinement if self.refinement in ("integral", "local") else None
+        peak_points, peak_vals = ops.find_global_peaks(cms, offsets, self.peak_threshold, refinement, self.integral_patch_size,
+                                                       float(self.output_stride))
+        N = peak_vals.shape[1]
+        _lib.check(_lib.lib().sa_finish_instance_peaks(ops._ptr(peak_points), ops._ptr(peak_vals), ops._ptr(inputs["crop_offsets"]),
+                                                       ops._ptr(inputs["n_valid"]), B, K, N, float(self.input_scale),
+                                                       ops._stream()), "sa_finish_instance_peaks")
+        outputs = {"instance_peaks": peak_points.reshape(B, K, N, 2), "instance_peak_vals": peak_vals.reshape(B, K, N),
+                   "n_valid": inputs["n_valid"], "centroids": inputs["centroids"], "centroid_vals": inputs["centroid_vals"],
+                   "status": inputs["status"]}
+        if "centroid_confmaps" in inputs:
+            outputs["centroid_confmaps"] = inputs["centroid_confmaps"]
+        if self.return_confmaps:
+            outputs["instance_confmaps"] = cms
+        return outputs
+
     def call(self, inputs):
+        if isinstance(inputs, dict) and inputs.get("padded"):
+            return self.call_padded(inputs)
         if isinstance(inputs, dict):
             crops = inputs["crops"]
         else:
@@ -646,18 +704,57 @@ class TopDownInferenceModel(InferenceModel):
         self.instance_peaks = instance_peaks
 
     def call(self, example):
-        return self.instance_peaks(self.centroid_crop(example))
+        """inference.py:2279-2311. Runs entirely on the device (fixed crop slots per frame, `CentroidCrop.call_padded`):
+        nothing synchronises; `status` carries the overflow / non-finite flags, which `outputs_to_numpy` (or `call_checked`)
+        acts on once the results are on the host anyway."""
+        if isinstance(example, dict):
+            example = example["image"]
+        outs = self.instance_peaks.call_padded(self.centroid_crop.call_padded(example))
+        outs["_input"] = example  # what to re-run if the deferred status words report an overflow
+        return outs
 
     def call_checked(self, data):
-        return self.call(data)
+        """`call` + inspection of the status words: capacities are doubled and the batch re-run on overflow."""
+        while True:
+            outs = self.call(data)
+            if not self._grow_on_status(int(np.bitwise_or.reduce(outs["status"].cpu().numpy())) if len(outs["status"]) else 0):
+                return outs
+
+    def _grow_on_status(self, bits) -> bool:
+        cc = self.centroid_crop
+        if bits & _lib.STATUS_NONFINITE:
+            raise FloatingPointError(NONFINITE_MESSAGE)
+        grown = False
+        if bits & _lib.STATUS_PEAK_OVERFLOW and cc.max_peaks < 16384:
+            cc.max_peaks *= 2
+            grown = True
+        if bits & _lib.STATUS_INSTANCE_OVERFLOW and cc.max_instances is None and cc.max_crops < 1024:
+            cc.max_crops *= 2
+            grown = True
+        return grown
 
     @staticmethod
     def _to_numpy(outs):
         return {k: (v.cpu().numpy() if isinstance(v, torch.Tensor) else v) for k, v in outs.items()}
 
     def outputs_to_numpy(self, outs):
-        res = self._to_numpy(outs)
+        """Device results -> NumPy in the reference's unragged form (instance axis cropped to the batch's bounding shape,
+        data/utils.py:118-146). This is where the deferred status words are looked at: an overflowed batch is re-run (with
+        grown capacities) before anything is returned."""
+        while True:
+            src = outs.pop("_input", None)
+            res = self._to_numpy(outs)
+            status = res.pop("status", None)
+            bits = int(np.bitwise_or.reduce(status)) if status is not None and len(status) else 0
+            if not self._grow_on_status(bits) or src is None:
+                break
+            outs = self.call(src)
         res["n_valid"] = res["n_valid"].astype(np.int64)
+        bound = int(res["n_valid"].max()) if len(res["n_valid"]) else 0
+        self.centroid_crop.observe(bound)
+        for k in ("instance_peaks", "instance_peak_vals", "centroids", "centroid_vals"):
+            if k in res:
+                res[k] = np.ascontiguousarray(res[k][:, :bound])
         return res
 
     def predict_on_batch(self, data, numpy: bool = False, **kwargs):
@@ -665,8 +762,10 @@ class TopDownInferenceModel(InferenceModel):
         return self.outputs_to_numpy(outs) if numpy else outs
 
     def predict(self, data, numpy: bool = True, batch_size: int = 4, **kwargs):
+        """inference.py:989-1045: all batches, concatenated (instance axis padded to the widest batch)."""
         imgs = data["image"] if isinstance(data, dict) else data
-        parts = [self.call(imgs[i : i + batch_size]) for i in range(0, len(imgs), batch_size)]
+        parts = [self.call_checked(imgs[i : i + batch_size]) for i in range(0, len(imgs), batch_size)]
+        parts = [{k: (v.clone() if isinstance(v, torch.Tensor) else v) for k, v in p.items() if k != "_input"} for p in parts]
         imax = max(p["instance_peaks"].shape[1] for p in parts)
         keys = [k for k in ("instance_peaks", "instance_peak_vals", "centroids", "centroid_vals") if k in parts[0]]
         outs = {}
@@ -681,11 +780,13 @@ class TopDownInferenceModel(InferenceModel):
                 padded.append(v)
             outs[k] = torch.cat(padded, dim=0)
         outs["n_valid"] = torch.cat([p["n_valid"] for p in parts], dim=0)
-        return self.predict_on_batch_to_numpy(outs) if numpy else outs
-
-    def predict_on_batch_to_numpy(self, outs):
+        if not numpy:
+            return outs
         res = self._to_numpy(outs)
         res["n_valid"] = res["n_valid"].astype(np.int64)
+        bound = int(res["n_valid"].max()) if len(res["n_valid"]) else 0
+        for k in keys:
+            res[k] = np.ascontiguousarray(res[k][:, :bound])
         return res
 
 
@@ -896,7 +997,7 @@ class Predictor:
         frames = self._frames_of(data)
         n = len(frames)
         rank, world = parallel.rank_world()
-        small = {"instance_peaks", "instance_peak_vals", "instance_scores", "n_valid", "centroids", "centroid_vals"}
+        small = {"instance_peaks", "instance_peak_vals", "instance_scores", "n_valid", "centroids", "centroid_vals", "status", "_input"}
         from ..io.video import Video, VideoReader
 
         self.make_pipeline(data if isinstance(data, (np.ndarray, Video, VideoReader)) else None)

@@ -338,8 +338,9 @@ def make_line_subs(peaks_sample, edge_peak_inds, edge_inds, n_line_points, pafs_
     K = epi.shape[0]
     subs = torch.empty((K, int(n_line_points), 2, 3), dtype=torch.int32, device="cuda")
     if K:
-        _lib.check(_lib.lib().sa_paf_line_subs(ops._ptr(_dev_f32(peaks_sample).reshape(-1, 2)), ops._ptr(epi),
-                                               ops._ptr(_dev_i32(edge_inds).reshape(-1)), K, int(n_line_points),
+        # (named locals: a temporary's device memory goes back to the allocator as soon as its pointer has been taken)
+        peaks, einds = _dev_f32(peaks_sample).reshape(-1, 2), _dev_i32(edge_inds).reshape(-1)
+        _lib.check(_lib.lib().sa_paf_line_subs(ops._ptr(peaks), ops._ptr(epi), ops._ptr(einds), K, int(n_line_points),
                                                float(pafs_stride), ops._ptr(subs), ops._stream()), "sa_paf_line_subs")
     return subs.cpu().numpy()
 
@@ -380,8 +381,8 @@ def score_paf_lines(paf_lines_sample, peaks_sample, edge_peak_inds_sample, max_e
     K, n_pts = lines.shape[0], lines.shape[1]
     out = torch.empty((K,), dtype=torch.float32, device="cuda")
     if K:
-        _lib.check(_lib.lib().sa_paf_line_scores(ops._ptr(lines), ops._ptr(_dev_f32(peaks_sample).reshape(-1, 2)),
-                                                 ops._ptr(_dev_i32(edge_peak_inds_sample).reshape(-1, 2)), K, n_pts,
+        peaks, epi = _dev_f32(peaks_sample).reshape(-1, 2), _dev_i32(edge_peak_inds_sample).reshape(-1, 2)
+        _lib.check(_lib.lib().sa_paf_line_scores(ops._ptr(lines), ops._ptr(peaks), ops._ptr(epi), K, n_pts,
                                                  float(max_edge_length), float(dist_penalty_weight), ops._ptr(out),
                                                  ops._stream()), "sa_paf_line_scores")
     return out.cpu().numpy()

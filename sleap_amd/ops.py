@@ -203,7 +203,8 @@ def bottomup_postproc(cms, offsets, pafs, threshold, refinement, patch_size, xy_
     if key not in _PP_WS:
         if len(_PP_WS) > 8:
             _PP_WS.clear()
-        _PP_WS[key] = torch.empty((h.sa_bottomup_postproc_workspace(B, max_peaks, E, N, NP),), dtype=torch.uint8, device=dev)
+        # zeroed ONCE: the scan counters at its head are handed back zeroed by every call (sleap_amd.h)
+        _PP_WS[key] = torch.zeros((h.sa_bottomup_postproc_workspace(B, max_peaks, E, N, NP),), dtype=torch.uint8, device=dev)
     ws = _PP_WS[key]
     mode = REFINE["offsets"] if offsets is not None else REFINE[refinement]
     check(h.sa_bottomup_postproc(

@@ -58,6 +58,18 @@ def main():
     ls = np.concatenate([np.asarray(x).reshape(-1) for x in out[5]])
     print(f"line scores: {len(ls)} candidates; > 0.25: {int((ls > 0.25).sum())}; in (0.1, 0.4): {int(((ls > 0.1) & (ls < 0.4)).sum())}; "
           f"matched-range min {ls[ls > 0.25].min() if (ls > 0.25).any() else float('nan'):.3f}")
+    # the margins that decide the ASSIGNMENTS: the matched connections vs the 0.25 cut and vs the candidates left unmatched
+    m = opg.match_candidates_batch(out[3], out[4], out[5], len(FLIES13_EDGES))
+    ms = np.concatenate([np.asarray(x).reshape(-1) for x in m[3]])
+    print(f"matched connections: {len(ms)} (expected {len(frames) * 4 * len(FLIES13_EDGES)}); min score {ms.min():.3f}; "
+          f"matched but below 0.25: {int((ms < 0.25).sum())}")
+    unmatched = []
+    for b in range(B):
+        ls, left = np.asarray(out[5][b]).tolist(), np.asarray(m[3][b]).tolist()
+        for v in left:
+            ls.remove(v)
+        unmatched += ls
+    print(f"strongest candidate the matching did NOT choose: {max(unmatched):.3f} (weakest chosen one: {ms.min():.3f})")
     sc = np.concatenate([np.asarray(x).reshape(-1) for x in out[2]])
     print("instance scores:", np.round(sc, 2))
 

@@ -149,3 +149,67 @@ def test_topdown_predict_api(topdown):
     assert outs[0]["instance_peaks"].shape[2:] == (2, 2)
     a = p.inference_model.predict(frames, numpy=True, batch_size=2)
     assert a["instance_peaks"].shape[0] == 3 and a["n_valid"].shape == (3,)
+
+
+@pytest.mark.parametrize("max_instances", [None, 2])
+def test_topdown_device_path_equals_ragged_path_without_host_round_trips(topdown, max_instances):
+    """`TopDownInferenceModel.call` runs on fixed crop slots per frame (sa_select_centroids / sa_finish_instance_peaks: the
+    centroid model's counts never visit the host). Same instances, values and order as the reference-shaped ragged layers,
+    NaN in the empty slots; more centroids than slots raise the overflow flag and the checked call grows the slots."""
+    p, frames = topdown
+    m = p.inference_model
+    cc, ip = m.centroid_crop, m.instance_peaks
+    cc.max_instances = max_instances
+    old = cc.max_crops
+    try:
+        flat = cc(frames)
+        want = ip(flat)
+        n_valid = _n(want["n_valid"])
+        assert n_valid.max() >= 3 or max_instances is not None
+        cc.max_crops = 8
+        got = m.call(torch.from_numpy(frames).cuda())
+        assert got["instance_peaks"].shape[:2] == (3, 8 if max_instances is None else max_instances)
+        assert_array_equal(_n(got["n_valid"]), n_valid)
+        for b in range(3):
+            k = n_valid[b]
+            assert_allclose(_n(got["instance_peaks"])[b, :k], _n(want["instance_peaks"])[b, :k], atol=1e-4, equal_nan=True)
+            assert_array_equal(_n(got["instance_peak_vals"])[b, :k], _n(want["instance_peak_vals"])[b, :k])
+            assert_allclose(_n(got["centroids"])[b, :k], _n(want["centroids"])[b, :k], atol=1e-5)
+            assert_array_equal(_n(got["centroid_vals"])[b, :k], _n(want["centroid_vals"])[b, :k])
+            assert np.isnan(_n(got["instance_peaks"])[b, k:]).all() and np.isnan(_n(got["centroid_vals"])[b, k:]).all()
+        assert int(_n(got["status"]).max()) == 0
+        if max_instances is None:
+            # too few slots: flagged, not silently truncated; the checked call doubles the slots and re-runs
+            cc.max_crops = 1
+            over = m.call(torch.from_numpy(frames).cuda())
+            assert int(_n(over["status"]).max()) & 4 and int(_n(over["n_valid"]).max()) == 1
+            res = m.outputs_to_numpy(over)
+            assert cc.max_crops >= n_valid.max()
+            assert_array_equal(res["n_valid"], n_valid)
+            assert res["instance_peaks"].shape[1] == n_valid.max()  # unragged to the batch's bounding shape
+            assert cc.max_crops == n_valid.max()  # and the slot count now follows what was seen
+    finally:
+        cc.max_instances, cc.max_crops = None, old
+
+
+def test_select_centroids_top_k_order():
+    """tf.math.top_k semantics on the device (inference.py:1884-1896): value descending, ties by lower index; un-scaling
+    (p / input_scale) + 0.5 and precrop_resize as separate fp32 steps."""
+    from sleap_amd import _lib, ops
+
+    xy = torch.tensor([[[10., 20.], [30., 40.], [50., 60.], [70., 80.], [0., 0.]]], device="cuda")
+    val = torch.tensor([[0.5, 0.9, 0.5, 0.7, 0.0]], device="cuda")
+    cnt = torch.tensor([4], dtype=torch.int32, device="cuda")
+    K = 3
+    out = [torch.empty((1, K, 2), device="cuda"), torch.empty((1, K), device="cuda"), torch.empty((1, K, 2), device="cuda"),
+           torch.empty((1, K, 2), device="cuda"), torch.empty((1,), dtype=torch.int32, device="cuda"),
+           torch.zeros((1,), dtype=torch.int32, device="cuda")]
+    _lib.check(_lib.lib().sa_select_centroids(ops._ptr(xy), ops._ptr(val), ops._ptr(cnt), 1, 5, K, 3, 0.5, 2.0, 8,
+                                              *[ops._ptr(t) for t in out], ops._stream()))
+    cent, cval, centre, off, nv, st = [_n(t) for t in out]
+    assert nv[0] == 3 and st[0] == 0
+    assert_array_equal(cval[0], np.array([0.9, 0.7, 0.5], np.float32))  # the first of the two 0.5s
+    want = (np.array([[30., 40.], [70., 80.], [10., 20.]], np.float32) / np.float32(0.5) + np.float32(0.5)) * np.float32(2.0)
+    assert_array_equal(cent[0], want)
+    assert_array_equal(off[0], want - np.float32(4.0))
+    assert_array_equal(centre[0], want)

@@ -128,18 +128,20 @@ def _fake_predictor(max_instances):
     return pred, layer
 
 
-def _predict_worker(rank, world, port, q):
+def _predict_worker(rank, world, port, q, batch_size=4, T=13):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     if world > 1:
         dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        T = 13  # 4 batches, the last one short (1 frame: rank 1 gets an empty shard)
-        ks = [1, 2, 0, 2, 3, 1, 5, 2, 0, 1, 4, 2, 5]
+        # T = 13, batch 4: 4 batches, the last one short (1 frame: rank 1 gets an empty shard)
+        ks = ([1, 2, 0, 2, 3, 1, 5, 2, 0, 1, 4, 2, 5] * 3)[:T]
         frames = np.zeros((T, 4, 4, 1), np.uint8)
         frames[:, 0, 0, 0], frames[:, 0, 1, 0] = ks, np.arange(T)
         pred, layer = _fake_predictor(max_instances=2)
+        pred.batch_size = batch_size
         exs = list(pred._predict_generator(frames))
+        assert [len(e["frame_ind"]) for e in exs] == [min(batch_size, T - i) for i in range(0, T, batch_size)]
         n_valid = np.concatenate([e["n_valid"] for e in exs])
         frame_ind = np.concatenate([e["frame_ind"] for e in exs])
         ok = n_valid.tolist() == ks and frame_ind.tolist() == list(range(T))
@@ -167,6 +169,27 @@ def test_predict_loop_overflow_consensus(world):
     res = sorted(q.get(timeout=10) for _ in range(world))
     assert all(ok for _, ok, _, _ in res), res
     assert [caps for _, _, caps, _ in res] == [8] * world, res  # 2 -> 4 (k = 3) -> 8 (k = 5): the same on every rank
+
+
+def test_predict_loop_world_8_ragged_batches_and_empty_shards():
+    """The 8-GPU layout of BASELINE configs[3] on CPU: 8 gloo ranks, a global batch that is NOT a multiple of 8 (11 frames:
+    ceil-sized shards of 2, 2, 2, 2, 2, 1, 0, 0) and a short last batch of 5 (1, 1, 1, 1, 1, 0, 0, 0) -- every rank ends with the
+    complete, ordered result and the same grown capacities; ranks with empty shards still take part in every gather."""
+    world, ctx = 8, mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_predict_worker, args=(r, world, port, q, 11, 27)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    res = sorted(q.get(timeout=10) for _ in range(world))
+    assert [r for r, _, _, _ in res] == list(range(world))
+    assert all(ok for _, ok, _, _ in res), res
+    assert [caps for _, _, caps, _ in res] == [8] * world, res
+    # shards of rank r in the 11-frame batches: the stand-in model is only called where the shard is non-empty
+    assert res[7][3] == 0 and res[6][3] == 0 and res[0][3] >= 3
 
 
 # The base generator (top-down / single-instance predictors): frame sharding + all_gather_object of ragged NumPy results, with
