@@ -24,6 +24,15 @@ using sa::mfma_h8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 using sa::h16x8_t;
 
+// conv0 weight terms per MFMA group: the fp32 weights (x 1/255 / U8_ACT_SCALE) enter as a sum of 16-bit terms. bf16 (8
+// mantissa bits) needs hi + mid + lo for fp32's 24 bits; fp16 (11 bits) carries 22 in hi + mid -- what is left (2^-22
+// relative) is 2000x below the fp16 rounding of the stored activation, so the fp16 build issues two MFMAs per group, not three.
+#if defined(SA_HALF_FP16)
+#define SA_STEM16_TERMS 2
+#else
+#define SA_STEM16_TERMS 3
+#endif
+
 struct Stem16Params {
   const uint8_t* src;   // [B,H,W,CIN] u8
   const uint16_t* blob;  // sa_stem16_pack: wa[3][64][8] | wb[5][64][8] bf16 | bias0[16] | bias1[16] f32
@@ -122,9 +131,8 @@ stem16_kernel(const Stem16Params p) {
     }
     const mfma_h8 bf = __builtin_bit_cast(mfma_h8, bq);
     f32x4 d = {0.0f, 0.0f, 0.0f, 0.0f};
-    d = SA_MFMA_16x16x32(wa[0], bf, d, 0, 0, 0);
-    d = SA_MFMA_16x16x32(wa[1], bf, d, 0, 0, 0);
-    d = SA_MFMA_16x16x32(wa[2], bf, d, 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < SA_STEM16_TERMS; ++t) d = SA_MFMA_16x16x32(wa[t], bf, d, 0, 0, 0);
     const int gy = y0 + ty - 1, gx = x0 + tx - 1;
     const bool in_img = valid && gy >= 0 && gy < H && gx >= 0 && gx < W;  // outside: conv1's SAME padding = 0
     float v[4];
@@ -304,7 +312,7 @@ stem16_gray_kernel(const Stem16Params p) {
         d[u] = (f32x4){bias0[0], bias0[1], bias0[2], bias0[3]};
       }
 #pragma unroll
-      for (int t = 0; t < 3; ++t)
+      for (int t = 0; t < SA_STEM16_TERMS; ++t)
 #pragma unroll
         for (int u = 0; u < 3; ++u) d[u] = SA_MFMA_16x16x32(wa[t], bf[u], d[u], 0, 0, 0);
 #pragma unroll
@@ -317,7 +325,7 @@ stem16_gray_kernel(const Stem16Params p) {
         const mfma_h8 bf = operand(kb < 3 ? rawt[(ty2 + kb) * RS + tx2] : make_uint2(0u, 0u));
         f32x4 d = {bias0[0], bias0[1], bias0[2], bias0[3]};
 #pragma unroll
-        for (int t = 0; t < 3; ++t) d = SA_MFMA_16x16x32(wa[t], bf, d, 0, 0, 0);
+        for (int t = 0; t < SA_STEM16_TERMS; ++t) d = SA_MFMA_16x16x32(wa[t], bf, d, 0, 0, 0);
         conv0_store(d, (unsigned)(y0 + ty2 - 1) < (unsigned)H && (unsigned)(x0 + tx2 - 1) < (unsigned)W,
                     act + (ty2 * PW + tx2) * 32 + kb * 8);
       }
