@@ -21,7 +21,7 @@ from oracle import peak_finding as opf
 from oracle.keras_graph import KerasGraph, load_npz_model, preprocess
 from sleap_amd.synth import render_frames
 
-torch.set_num_threads(16)
+torch.set_num_threads(int(__import__("os").environ.get("PROBE_THREADS", "8")))
 
 
 def post(cms, pafs, offs, thr, scorer, stride):

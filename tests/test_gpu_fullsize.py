@@ -14,10 +14,11 @@ H = W = 1024
 @pytest.fixture(scope="module")
 def setup():
     from sleap_amd.benchmark_model import build_benchmark_predictor
-    from sleap_amd.synth import render_frames
+    from sleap_amd.synth import render_flies
 
-    pred, mc, weights = build_benchmark_predictor(H, W, batch_size=8, seed=0)
-    frames, _ = render_frames(16, H, W, n_animals=4, seed=100)
+    pred, mc, weights = build_benchmark_predictor(H, W, batch_size=8, seed=0)  # the fitted benchmark model
+    pred.verbosity = "none"
+    frames, _ = render_flies(16, H, W, n_animals=4, seed=100)
     return pred, mc, weights, frames
 
 
@@ -57,11 +58,12 @@ def test_full_size_postprocessing_equals_oracle_on_device_maps(setup):
         np.testing.assert_allclose(out["instance_peaks"][b, :k], o[0][b], atol=1e-4, equal_nan=True)
         np.testing.assert_allclose(out["instance_scores"][b, :k], o[2][b], rtol=1e-4, atol=1e-5)
         total += int(np.isfinite(o[0][b][..., 0]).sum())
-    assert total > 0 and len(pts) > 40 * n  # calibrated heads: a realistic number of peaks, some of them grouped
+    assert total == n * 4 * 13 and len(pts) >= 52 * n  # 4 complete animals per frame
 
 
 def test_full_size_network_vs_fp32_oracle(setup):
-    """bf16 MFMA network vs the fp32 CPU oracle at 1024x1024: heads within 3 % of their range (bf16 storage)."""
+    """16-bit-storage MFMA network vs the fp32 CPU oracle at 1024x1024: heads within 3 % of their range (the bf16 bound;
+    the default fp16 build is held to 4e-3 in tests/test_gpu_benchmark_parity.py)."""
     from oracle.keras_graph import KerasGraph, preprocess
 
     pred, mc, weights, frames = setup
@@ -86,4 +88,4 @@ def test_frames_are_independent_bitwise(setup):
     for k in base:
         np.testing.assert_array_equal(base[k], four[k])
         np.testing.assert_array_equal(base[k][perm], shuf[k])
-    assert int(base["n_valid"].sum()) > 0
+    assert base["n_valid"].tolist() == [4] * 16

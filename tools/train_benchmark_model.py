@@ -144,6 +144,7 @@ def main():
     ap.add_argument("--out", default=os.path.join(ROOT, "sleap_amd", "data", "benchmark_unet_flies13.npz"))
     ap.add_argument("--resume", default=None)
     ap.add_argument("--margin", type=int, default=1, help="add the threshold-margin terms to the loss")
+    ap.add_argument("--bg-weight", type=float, default=20.0, help="weight of the background-margin term")
     args = ap.parse_args()
     if args.threads:
         torch.set_num_threads(args.threads)
@@ -177,7 +178,7 @@ def main():
         # the 0.2 peak threshold, every true peak far above it (the target's own peak value varies between 0.53 and 1 with the
         # sub-grid position of the point at sigma 2.5 px / stride 4)
         bgm = (tc < 0.02).float()
-        lm = 20.0 * ((F.relu(cms - 0.06) ** 2) * bgm)[:, :, m4:-m4, m4:-m4].mean()
+        lm = args.bg_weight * ((F.relu(cms - 0.06) ** 2) * bgm)[:, :, m4:-m4, m4:-m4].mean()
         is_pk = (tc > 0.5) & (tc >= F.max_pool2d(tc, 3, 1, 1))
         lm = lm + 5.0 * ((F.relu(0.5 - cms) ** 2) * is_pk.float())[:, :, m4:-m4, m4:-m4].sum() / max(int(is_pk.sum()), 1)
         loss = lc + lp + (lm if args.margin else 0.0)
