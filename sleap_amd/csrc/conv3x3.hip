@@ -1034,6 +1034,15 @@ static int conv3x3_impl(const void* src0, int C0P, const void* src1, int C1P, in
       SA_REQUIRE(co32_n <= 4, "sa_conv3x3_heads_bf16: fused heads support at most 128 output channels");
       return launch2<4, 16, 8, 2, 2, true>(q, st);
     }
+    // Experiment switch (tools/ab runs): SA_CONV_MT4=n sends plain multi-chunk layers with >= n output channels (a multiple
+    // of 128) to the 128-couts-per-workgroup persistent kernel (one workgroup per CU, half the input re-staging per MFMA).
+    static const int mt4_min = [] {
+      const char* v = getenv("SA_CONV_MT4");
+      return v ? atoi(v) : 0;
+    }();
+    if (mt4_min > 0 && n_heads == 0 && !post_scale && !residual && !relu_last && CoutP % 128 == 0 && CoutP >= mt4_min &&
+        (C0P + C1P) > 16 && !ck32)
+      return launch2<4, 16, 8, 2, 2, false>(q, st);
     if (co32_n >= 2) return ck32 ? launch2_pick<2, 32>(q, st) : launch2_pick<2, 16>(q, st);
     return ck32 ? launch2_pick<1, 32>(q, st) : launch2_pick<1, 16>(q, st);
   }
