@@ -293,6 +293,11 @@ int sa_conv3x3_heads_bf16(const void* src0, int C0P, const void* src1, int C1P, 
  * Returns the previous value. Results do not depend on it (each tile's arithmetic is the same). */
 int sa_conv3x3_set_grid_limit(int n);
 
+/* Activation layout seen by sa_conv3x3_bf16 / sa_conv3x3_heads_bf16 (process-wide, HOST; measurement tool -- networks choose
+ * the layout per plan): 0 = NHWC [B,H,W,CP] (default), 1 = 16-channel planes [B,CP/16,H,W,16] for both sources and the
+ * 16-bit outputs. Returns the previous value. */
+int sa_conv3x3_set_layout(int planar);
+
 /* HOST helper: Keras Conv2D kernel (3,3,Cin,Cout) f32 -> the packed bf16 layout above. The input
  * channel axis is the concatenation [C0 | C1]; each part is zero-padded to C0P / C1P. */
 int sa_pack_conv3x3_weights(const float* keras_kernel, int C0, int C0P, int C1, int C1P, int Cout,

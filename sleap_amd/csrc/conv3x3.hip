@@ -24,6 +24,7 @@
 namespace {
 
 int g_grid_limit = 0;  // sa_conv3x3_set_grid_limit
+int g_layout = 0;      // sa_conv3x3_set_layout (experiments)
 
 using sa::h16x8_t;
 using sa::mfma_h8;
@@ -250,6 +251,12 @@ struct ConvParams2 {
   const float* post_shift;
   const uint16_t* residual;
   int res_mode, relu_last;
+  // activation layout of src0 / src1 / dst / dst_pool: 0 = NHWC ([B,H,W,CP]), 1 = 16-channel planes ([B,CP/16,H,W,16]):
+  // a CK = 16 chunk of a halo-tile row is then ONE contiguous run of 34 x 32 bytes instead of 34 slices of 32 bytes at a
+  // pixel stride of 2 CP bytes, and a store instruction of the epilogue writes 1 KiB contiguously (CK = 16 kernels only)
+  int planar;
+  int pix_bytes0, pix_bytes1;  // bytes between consecutive pixels of src0 / src1 (NHWC: 2 CP; planes: 32)
+  unsigned blk_bytes_in;       // bytes between consecutive 16-channel blocks of a source (NHWC: 32; planes: H W 32)
 };
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -342,8 +349,8 @@ conv3x3_dma_kernel(const ConvParams2 p) {
       const bool ok = (i < N_IN) && (pl < PH * PW) && gy >= 0 && gy < H && gx >= 0 && gx < W;
       const unsigned pix = (unsigned)(gy * W + gx);
       const unsigned q16 = (unsigned)((s ^ swz<CK>(pl)) * 16);
-      v0[j] = ok ? pix * (unsigned)(p.C0P * 2) + q16 : OOB;
-      v1[j] = ok ? pix * (unsigned)(p.C1P * 2) + q16 : OOB;
+      v0[j] = ok ? pix * (unsigned)p.pix_bytes0 + q16 : OOB;
+      v1[j] = ok ? pix * (unsigned)p.pix_bytes1 + q16 : OOB;
     }
   };
   unsigned voff0[IN_PER_WAVE], voff1[IN_PER_WAVE];
@@ -353,7 +360,9 @@ conv3x3_dma_kernel(const ConvParams2 p) {
   auto issue = [&](const Tile& t, const unsigned (&v0)[IN_PER_WAVE], const unsigned (&v1)[IN_PER_WAVE], int chunk, int buf) {
     const int c_lo = chunk * CK;
     const bool from1 = c_lo >= p.C0P;
-    const int cc2 = (from1 ? c_lo - p.C0P : c_lo) * 2;
+    // byte offset of the chunk's first channel inside a pixel record (NHWC: 2 bytes per channel) or of its plane (planes:
+    // H W 32 bytes per 16 channels); 32-bit unsigned arithmetic, a frame is < 4 GiB
+    const int cc2 = (int)((unsigned)((from1 ? c_lo - p.C0P : c_lo) >> 4) * p.blk_bytes_in);
     unsigned char* stage = smem + buf * STAGE;
     const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(STEM_CIN ? reinterpret_cast<const unsigned char*>(p.w) : reinterpret_cast<const unsigned char*>(p.src0) + t.b * f0), 0,
@@ -690,7 +699,9 @@ conv3x3_dma_kernel(const ConvParams2 p) {
       }
       return t;
     };
-    auto store_pieces = [&](uint16_t* row_ptr, bool ok, const uint2 (&pk)[4]) {
+    // `frame` = the output frame of this tile, `pix` = pixel index inside it, `npix` = pixels per frame. NHWC: channel co of
+    // a pixel at pix * CoutP + co; planes: plane co >> 4 at (co >> 4) * npix * 16, 16 channels per pixel inside it
+    auto store_pieces = [&](uint16_t* frame, size_t pix, size_t npix, bool ok, const uint2 (&pk)[4]) {
 #pragma unroll
       for (int pr = 0; pr < 2; ++pr) {
         // lower half-wave: own group 2pr (channels 0-3) + partner's (4-7); upper: partner's group 2pr+1 + own
@@ -698,7 +709,8 @@ conv3x3_dma_kernel(const ConvParams2 p) {
         sa::swap32(a.x, c.x);
         sa::swap32(a.y, c.y);
         const int co = cobase + 16 * pr + 8 * half;
-        if (ok && co < p.CoutP) *reinterpret_cast<uint4*>(row_ptr + co) = make_uint4(a.x, a.y, c.x, c.y);
+        uint16_t* q = frame + (size_t)(co >> 4) * (p.planar ? npix * 16 : (size_t)16) + pix * (p.planar ? 16 : p.CoutP) + 8 * half;
+        if (ok && co < p.CoutP) *reinterpret_cast<uint4*>(q) = make_uint4(a.x, a.y, c.x, c.y);
       }
     };
     if (p.dst) {
@@ -712,7 +724,7 @@ conv3x3_dma_kernel(const ConvParams2 p) {
           pk[g].y = sa::f2h2(act(r, g, 2), act(r, g, 3));
         }
         const bool ok = gy < H && gx < W;
-        store_pieces(p.dst + (((size_t)b * H + (ok ? gy : 0)) * W + (ok ? gx : 0)) * p.CoutP, ok, pk);
+        store_pieces(p.dst + (size_t)b * H * W * p.CoutP, (size_t)(ok ? gy : 0) * W + (ok ? gx : 0), (size_t)H * W, ok, pk);
       }
     }
     if (p.dst_pool) {
@@ -732,7 +744,8 @@ conv3x3_dma_kernel(const ConvParams2 p) {
           pk[g].y = sa::f2h2(t4[2], t4[3]);
         }
         const bool ok = !(lane_e & 1) && gy < H && gx < W;
-        store_pieces(p.dst_pool + (((size_t)b * (H / 2) + (ok ? gy / 2 : 0)) * (W / 2) + (ok ? gx / 2 : 0)) * p.CoutP, ok, pk);
+        store_pieces(p.dst_pool + (size_t)b * (H / 2) * (W / 2) * p.CoutP, (size_t)(ok ? gy / 2 : 0) * (W / 2) + (ok ? gx / 2 : 0),
+                     (size_t)(H / 2) * (W / 2), ok, pk);
       }
     }
   }
@@ -851,6 +864,10 @@ int launch2(const ConvParams2& p, hipStream_t st) {
   q.tiles_y = (p.H + TH - 1) / TH;
   const int co32_n = (p.CoutP + 31) / 32;
   q.co_tiles = (co32_n + MT - 1) / MT;
+  if (p.planar && CK != 16) return sa::fail(SA_ERR_UNSUPPORTED, "sa_conv3x3: the plane layout needs 16-channel chunks");
+  q.pix_bytes0 = p.planar ? 32 : p.C0P * 2;
+  q.pix_bytes1 = p.planar ? 32 : p.C1P * 2;
+  q.blk_bytes_in = p.planar ? (unsigned)((size_t)p.H * p.W * 32) : 32u;
   const size_t nblk = (size_t)q.tiles_x * q.tiles_y * q.co_tiles * p.B;
   if (nblk > 0x7fffffffull) return sa::fail(SA_ERR_INVALID_ARG, "sa_conv3x3_bf16: grid too large");
   if (!STEM_CIN && (size_t)p.H * p.W * (p.C0P > p.C1P ? p.C0P : p.C1P) * 2 >= 0xFFFFFF00ull)
@@ -1017,6 +1034,8 @@ static int conv3x3_impl(const void* src0, int C0P, const void* src1, int C1P, in
     q.residual = (const uint16_t*)residual;
     q.res_mode = res_mode;
     q.relu_last = relu_last;
+    q.planar = g_layout;
+    SA_REQUIRE(!q.planar || (!ck32 && !residual), "sa_conv3x3: the plane layout needs 16-channel chunks and no residual input");
     SA_REQUIRE(!(post_scale || residual || relu_last) || n_heads == 0, "sa_conv3x3: extended epilogue and fused heads are exclusive");
     SA_REQUIRE(!post_scale == !post_shift, "sa_conv3x3: post_scale and post_shift come together");
     SA_REQUIRE(!(residual && res_mode) || (H % 2 == 0 && W % 2 == 0), "sa_conv3x3: half-resolution residual needs even H, W");
@@ -1056,6 +1075,12 @@ static int conv3x3_impl(const void* src0, int C0P, const void* src1, int C1P, in
 
 
 extern "C" {
+
+int sa_conv3x3_set_layout(int planar) {
+  const int prev = g_layout;
+  g_layout = planar;
+  return prev;
+}
 
 int sa_conv3x3_set_grid_limit(int n) {
   const int prev = g_grid_limit;
