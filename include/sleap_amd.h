@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define SA_ABI_VERSION 1
+#define SA_ABI_VERSION 2
 
 #define SA_OK 0
 #define SA_ERR_INVALID_ARG (-1)
@@ -226,7 +226,7 @@ int sa_stem_conv3x3(const void* src, int src_is_u8, int B, int H, int W, int Cin
  *   w1 packed (sa_pack_conv3x3_weights with C0 = first conv's channels), bias1 [CoutP] f32, CoutP <= 64 */
 int sa_stem_conv3x3x2_bf16(const void* src, int src_is_u8, int B, int H, int W, int Cin, const float* w0,
                            const float* bias0, int C0P, int relu0, const void* w1, const float* bias1, int CoutP,
-                           int relu1, void* dst, void* dst_pool, sa_stream_t stream);
+                           int relu1, void* dst, void* dst_pool, int layout, sa_stream_t stream);
 
 /* Specialisation of sa_stem_conv3x3x2_bf16 for uint8 images and <= 16 channels in both convs (the default
  * `filters: 16` of SLEAP's UNet profiles) on v_mfma_f32_16x16x32_bf16, all weights register resident.
@@ -242,6 +242,20 @@ size_t sa_stem16_blob_bytes(void);
 #define SA_SRC1_DIRECT 1     /* Concatenate([src0, src1]) (encoder_decoder.py:360-362) */
 #define SA_SRC1_UPSAMPLE2X 2 /* Concatenate([src0, UpSampling2D(2, bilinear)(src1)]) (:335-339) */
 #define SA_SRC0_POOL2X 4     /* flag OR-ed in: src0 is read through MaxPool2D(2, s2) (:109-114) */
+
+/* Layout of the 16-bit activation tensors (the `layout` argument of the fused-block entry points; OR-ed into `mode` for the
+ * sa_conv3x3_* family, where it applies to src0, src1, dst and dst_pool alike):
+ *   SA_LAYOUT_NHWC      [B,H,W,CP]                                              (default)
+ *   SA_LAYOUT_PLANES16  [B,CP/16,H,W,16]: 16-channel planes. The 3x3 kernels consume the input channels in chunks of 16; with
+ *     planes a chunk of a halo-tile row is ONE contiguous run (34 pixels x 32 bytes) instead of 34 slices of 32 bytes at a
+ *     pixel stride of 2 CP bytes -- every fetched cache line is used completely, once -- and an epilogue store instruction
+ *     writes 1 KiB contiguously. Measured on MI355X (profiles/r02_planar_ab.md): every layer of the benchmark UNet 6-19 %
+ *     faster, bitwise the same values. A tensor with CP = 16 is the same bytes in both layouts. Supported by
+ *     sa_conv3x3_bf16 / _heads_bf16 (modes NONE / DIRECT, 16-channel chunks), sa_conv3x3_pair_bf16, sa_stem_conv3x3x2_bf16,
+ *     sa_stem16_u8_bf16 (16 channels: nothing to do) and sa_upsample2x_bf16 (call it with B*CP/16 frames of 16 channels);
+ *     a network plan (sa_network_create) is in ONE layout throughout. */
+#define SA_LAYOUT_NHWC 0
+#define SA_LAYOUT_PLANES16 0x100
 
 /* Conv2D(k3, s1, same) + bias + optional ReLU on bf16 NHWC activations as an implicit GEMM on
  * MFMA (v_mfma_f32_32x32x16_bf16, fp32 accumulate).
@@ -260,7 +274,7 @@ int sa_conv3x3_bf16(const void* src0, int C0P, const void* src1, int C1P, int mo
  * Only C0P = 16, C1P = C2P = 32 is implemented (SA_ERR_UNSUPPORTED otherwise). */
 int sa_conv3x3_pair_bf16(const void* src, int C0P, const void* wa, const float* bias_a, int relu_a, int C1P,
                          const void* wb, const float* bias_b, int relu_b, int C2P, int B, int H, int W, void* dst,
-                         void* dst_pool, sa_stream_t stream);
+                         void* dst_pool, int layout, sa_stream_t stream);
 
 /* Same convolution with the extended epilogue the hourglass / ResNet graphs need:
  *   v = acc + bias; if relu: v = max(v, 0);
@@ -293,10 +307,6 @@ int sa_conv3x3_heads_bf16(const void* src0, int C0P, const void* src1, int C1P, 
  * Returns the previous value. Results do not depend on it (each tile's arithmetic is the same). */
 int sa_conv3x3_set_grid_limit(int n);
 
-/* Activation layout seen by sa_conv3x3_bf16 / sa_conv3x3_heads_bf16 (process-wide, HOST; measurement tool -- networks choose
- * the layout per plan): 0 = NHWC [B,H,W,CP] (default), 1 = 16-channel planes [B,CP/16,H,W,16] for both sources and the
- * 16-bit outputs. Returns the previous value. */
-int sa_conv3x3_set_layout(int planar);
 
 /* HOST helper: Keras Conv2D kernel (3,3,Cin,Cout) f32 -> the packed bf16 layout above. The input
  * channel axis is the concatenation [C0 | C1]; each part is zero-padded to C0P / C1P. */
@@ -478,6 +488,9 @@ void sa_network_destroy(sa_network_t* net);
 int sa_network_n_outputs(const sa_network_t* net);
 int sa_network_in_channels(const sa_network_t* net);
 int sa_network_max_stride(const sa_network_t* net);
+/* SA_LAYOUT_NHWC or SA_LAYOUT_PLANES16: how the plan's 16-bit tensors lie in the workspace (sa_network_buffer). The plan
+ * compiler picks planes when every launch of the plan supports them (the UNet family); outputs are [B,h,w,c] float32 always. */
+int sa_network_layout(const sa_network_t* net);
 int sa_network_output_shape(const sa_network_t* net, int index, int H, int W, int* h, int* w, int* c);
 size_t sa_network_workspace_bytes(const sa_network_t* net, int B, int H, int W);
 void* sa_network_buffer(const sa_network_t* net, int buf, int B, int H, int W, void* workspace, int* h, int* w, int* cp,

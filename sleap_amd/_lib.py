@@ -19,6 +19,7 @@ STATUS_NONFINITE = 32
 REFINE = {None: 0, "none": 0, "integral": 1, "local": 2, "offsets": 3}
 
 SRC1_NONE, SRC1_DIRECT, SRC1_UPSAMPLE2X, SRC0_POOL2X = 0, 1, 2, 4
+LAYOUT_NHWC, LAYOUT_PLANES16 = 0, 0x100  # SA_LAYOUT_*: 16-bit activation tensors as [B,H,W,CP] or as 16-channel planes [B,CP/16,H,W,16]
 
 _p = C.c_void_p
 _i = C.c_int
@@ -54,7 +55,7 @@ SIGNATURES = {
     "sa_lsa_host_wave": (_i, [_p, _i, _i, _p, _p]),
     "sa_stem_conv3x3": (_i, [_p, _i, _i, _i, _i, _i, _p, _p, _i, _i, _p, _p]),
     "sa_conv3x3_bf16": (_i, [_p, _i, _p, _i, _i, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p]),
-    "sa_stem_conv3x3x2_bf16": (_i, [_p, _i, _i, _i, _i, _i, _p, _p, _i, _i, _p, _p, _i, _i, _p, _p, _p]),
+    "sa_stem_conv3x3x2_bf16": (_i, [_p, _i, _i, _i, _i, _i, _p, _p, _i, _i, _p, _p, _i, _i, _p, _p, _i, _p]),
     "sa_stem16_u8_bf16": (_i, [_p, _i, _i, _i, _i, _p, _i, _i, _p, _p, _p]),
     "sa_stem16_pack": (_i, [_p, _p, _i, _i, _p, _p, _i, _p]),
     "sa_stem16_blob_bytes": (_sz, []),
@@ -63,13 +64,12 @@ SIGNATURES = {
     "sa_pack_conv3x3_weights": (_i, [_p, _i, _i, _i, _i, _i, _i, _p]),
     "sa_conv3x3_packed_elems": (_sz, [_i, _i, _i]),
     "sa_conv3x3_set_grid_limit": (_i, [_i]),
-    "sa_conv3x3_set_layout": (_i, [_i]),
     "sa_convt3x3s2_bf16": (_i, [_p, _i, _p, _p, _i, _i, _i, _i, _i, _p, _p]),
     "sa_image_conv_bf16": (_i, [_p, _i, _i, _i, _i, _i, _i, _p, _i, _i, _i, _i, _i, _i, _i, _p, _p, _i, _i, _p, _p, _p, _p]),
     "sa_imgconv_packed_elems": (C.c_size_t, [_i, _i, _i]),
     "sa_imgconv_pack": (_i, [_p, _i, _i, _i, _i, _p, _p, _p, _p]),
     "sa_imgconv_u8_bf16": (_i, [_p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p, _i, _i, _i, _p, _p, _p, _p]),
-    "sa_conv3x3_pair_bf16": (_i, [_p, _i, _p, _p, _i, _i, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p]),
+    "sa_conv3x3_pair_bf16": (_i, [_p, _i, _p, _p, _i, _i, _p, _p, _i, _i, _i, _i, _i, _p, _p, _i, _p]),
     "sa_add_bf16": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _p, _p]),
     "sa_conv1x1_bf16": (_i, [_p, _i, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p, _p, _i, _p, _p]),
     "sa_convt_s2_bf16": (_i, [_p, _i, _p, _i, _p, _i, _i, _i, _i, _i, _p, _p, _i, _p, _p]),
@@ -95,6 +95,7 @@ SIGNATURES = {
     "sa_network_n_outputs": (_i, [_p]),
     "sa_network_in_channels": (_i, [_p]),
     "sa_network_max_stride": (_i, [_p]),
+    "sa_network_layout": (_i, [_p]),
     "sa_network_output_shape": (_i, [_p, _i, _i, _i, _p, _p, _p]),
     "sa_network_workspace_bytes": (_sz, [_p, _i, _i, _i]),
     "sa_network_buffer": (_p, [_p, _i, _i, _i, _i, _p, _p, _p, _p, _p]),

@@ -24,7 +24,6 @@
 namespace {
 
 int g_grid_limit = 0;  // sa_conv3x3_set_grid_limit
-int g_layout = 0;      // sa_conv3x3_set_layout (experiments)
 
 using sa::h16x8_t;
 using sa::mfma_h8;
@@ -864,7 +863,7 @@ int launch2(const ConvParams2& p, hipStream_t st) {
   q.tiles_y = (p.H + TH - 1) / TH;
   const int co32_n = (p.CoutP + 31) / 32;
   q.co_tiles = (co32_n + MT - 1) / MT;
-  if (p.planar && CK != 16) return sa::fail(SA_ERR_UNSUPPORTED, "sa_conv3x3: the plane layout needs 16-channel chunks");
+  if (p.planar && CK != 16 && !STEM_CIN) return sa::fail(SA_ERR_UNSUPPORTED, "sa_conv3x3: SA_LAYOUT_PLANES16 needs 16-channel chunks");
   q.pix_bytes0 = p.planar ? 32 : p.C0P * 2;
   q.pix_bytes1 = p.planar ? 32 : p.C1P * 2;
   q.blk_bytes_in = p.planar ? (unsigned)((size_t)p.H * p.W * 32) : 32u;
@@ -1001,7 +1000,8 @@ static int conv3x3_impl(const void* src0, int C0P, const void* src1, int C1P, in
     return !v ? 0 : !strcmp(v, "ck16") ? 16 : !strcmp(v, "ck32") ? 32 : 0;
   }();
   const bool can32 = (C0P % 32 == 0) && (C1P % 32 == 0);
-  const bool ck32 = can32 && (force_ck == 32 || (force_ck == 0 && C0P + C1P == 32 && CoutP <= 32));
+  const int planar = (mode & SA_LAYOUT_PLANES16) ? 1 : 0;  // planes are 16 channels: 16-channel chunks only
+  const bool ck32 = can32 && !planar && (force_ck == 32 || (force_ck == 0 && C0P + C1P == 32 && CoutP <= 32));
   const int co32_n = (CoutP + 31) / 32;
   const int src_mode = mode & 7;
   if (src_mode == SA_SRC1_NONE || src_mode == SA_SRC1_DIRECT) {
@@ -1034,8 +1034,8 @@ static int conv3x3_impl(const void* src0, int C0P, const void* src1, int C1P, in
     q.residual = (const uint16_t*)residual;
     q.res_mode = res_mode;
     q.relu_last = relu_last;
-    q.planar = g_layout;
-    SA_REQUIRE(!q.planar || (!ck32 && !residual), "sa_conv3x3: the plane layout needs 16-channel chunks and no residual input");
+    q.planar = planar;
+    SA_REQUIRE(!planar || !residual, "sa_conv3x3: SA_LAYOUT_PLANES16 does not cover the residual input of the extended epilogue");
     SA_REQUIRE(!(post_scale || residual || relu_last) || n_heads == 0, "sa_conv3x3: extended epilogue and fused heads are exclusive");
     SA_REQUIRE(!post_scale == !post_shift, "sa_conv3x3: post_scale and post_shift come together");
     SA_REQUIRE(!(residual && res_mode) || (H % 2 == 0 && W % 2 == 0), "sa_conv3x3: half-resolution residual needs even H, W");
@@ -1065,8 +1065,8 @@ static int conv3x3_impl(const void* src0, int C0P, const void* src1, int C1P, in
     if (co32_n >= 2) return ck32 ? launch2_pick<2, 32>(q, st) : launch2_pick<2, 16>(q, st);
     return ck32 ? launch2_pick<1, 32>(q, st) : launch2_pick<1, 16>(q, st);
   }
-  SA_REQUIRE(dst && !dst_pool && n_heads == 0 && !post_scale && !residual && !relu_last,
-             "sa_conv3x3_bf16: pooled output / fused heads / extended epilogue are not available with pool/upsample source modes");
+  SA_REQUIRE(dst && !dst_pool && n_heads == 0 && !post_scale && !residual && !relu_last && !planar,
+             "sa_conv3x3_bf16: pooled output / fused heads / extended epilogue / SA_LAYOUT_PLANES16 are not available with pool/upsample source modes");
   if (co32_n >= 2) {
     return ck32 ? launch_mode<2, 4, 32>(p, src_mode, st) : launch_mode<2, 4, 16>(p, src_mode, st);
   }
@@ -1075,12 +1075,6 @@ static int conv3x3_impl(const void* src0, int C0P, const void* src1, int C1P, in
 
 
 extern "C" {
-
-int sa_conv3x3_set_layout(int planar) {
-  const int prev = g_layout;
-  g_layout = planar;
-  return prev;
-}
 
 int sa_conv3x3_set_grid_limit(int n) {
   const int prev = g_grid_limit;
@@ -1135,8 +1129,9 @@ int sa_conv3x3_ex_bf16(const void* src0, int C0P, const void* src1, int C1P, int
 
 int sa_stem_conv3x3x2_bf16(const void* src, int src_is_u8, int B, int H, int W, int Cin, const float* w0,
                            const float* bias0, int C0P, int relu0, const void* w1, const float* bias1, int CoutP,
-                           int relu1, void* dst, void* dst_pool, sa_stream_t stream) {
+                           int relu1, void* dst, void* dst_pool, int layout, sa_stream_t stream) {
   SA_REQUIRE(src && w0 && bias0 && w1 && bias1 && (dst || dst_pool), "sa_stem_conv3x3x2_bf16: NULL pointer");
+  SA_REQUIRE(layout == SA_LAYOUT_NHWC || layout == SA_LAYOUT_PLANES16, "sa_stem_conv3x3x2_bf16: bad layout");
   SA_REQUIRE(Cin == 1 || Cin == 3, "sa_stem_conv3x3x2_bf16: Cin must be 1 or 3");
   SA_REQUIRE(C0P == 16 || C0P == 32, "sa_stem_conv3x3x2_bf16: the first conv must have 16 or 32 (padded) output channels");
   SA_REQUIRE(CoutP > 0 && CoutP % 16 == 0 && CoutP <= 64, "sa_stem_conv3x3x2_bf16: CoutP must be a multiple of 16, <= 64");
@@ -1162,6 +1157,7 @@ int sa_stem_conv3x3x2_bf16(const void* src, int src_is_u8, int B, int H, int W, 
   q.stem_b = bias0;
   q.stem_is_u8 = src_is_u8;
   q.stem_relu = relu0;
+  q.planar = layout == SA_LAYOUT_PLANES16;
   hipStream_t st = (hipStream_t)stream;
   const bool two = CoutP > 32;
   if (C0P == 16) {

@@ -18,6 +18,7 @@
 // Phase A: conv-a on all 612 halo pixels (20 groups of 32 over the 8 waves; +20 % conv-a FLOPs for the halo), written to
 // the intermediate tile with zeros outside the image (= conv-b's SAME padding). Phase B: the usual 9-tap loop.
 #include <cstdint>
+#include <cstdlib>
 
 #include "bf16.h"
 #include "sa_common.h"
@@ -38,25 +39,33 @@ struct PairParams {
   uint16_t* dst;        // [B,H,W,32] or NULL
   uint16_t* dst_pool;   // [B,H/2,W/2,32] or NULL
   int B, H, W, relu_a, relu_b, tiles_x, tiles_y;
+  int planar;  // dst / dst_pool as two 16-channel planes [B,2,H,W,16] (SA_LAYOUT_PLANES16) instead of [B,H,W,32]
 };
 
+// Lane mapping (round 2). The first version walked the 612 halo pixels of phase A as 20 groups of 32 CONSECUTIVE pixels; the
+// counters showed it VALU-issue bound (60 % busy against 38 % for the matrix cores, profiles/r01_v8_pmc_sq_counters.md) and the
+// ISA showed why: 146 VALU instructions per 9 MFMAs in phase A -- a lane-dependent row / column walk with a division per
+// group, nine swizzled tap addresses, a per-value select for the padding -- and 100 per 36 in phase B for the swizzled
+// fragment addresses. Now (53 and 36; 0.537 -> 0.497 ms per 64 frames of 512 x 512, same bits; profiles/r02_ab_session.md)
+//   * phase A: wave w walks halo rows w, w + 8, (w + 16) over the 32 columns lane & 31: every per-lane quantity (the nine
+//     tap offsets, the two store offsets, the column validity) is loop invariant up to a compile-time byte stride (the
+//     swizzles are periodic in 8 rows), the row validity is wave uniform, and the SAME padding is one AND per packed dword;
+//     halo columns 32, 33 (36 pixels) are two more groups, taken by waves 2 and 3, which have only two rows;
+//   * phase B: the 24 fragment offsets (4 rows x 3 columns x 2 k-steps) are registers computed once.
 __global__ void __launch_bounds__(512)
 convpair_16_32_32_kernel(const PairParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int NW = 8, R = 2, TH = NW * R, TW = 32;
-  constexpr int PH = TH + 2, PW = TW + 2;    // intermediate halo tile
-  constexpr int QH = TH + 4, QW = TW + 4;    // input halo tile
-  constexpr int INTER_BYTES = PH * PW * 64;  // 39168
-  constexpr int IN_BYTES = QH * QW * 32;     // 23040
-  constexpr int N_IN = (IN_BYTES + 1023) / 1024;  // 23 copies (the last one half used)
+  constexpr int PH = TH + 2, PW = TW + 2;
+  constexpr int QH = TH + 4, QW = TW + 4;
+  constexpr int INTER_BYTES = PH * PW * 64;
+  constexpr int IN_BYTES = QH * QW * 32;
+  constexpr int N_IN = (IN_BYTES + 1023) / 1024;
   constexpr int WA_OFF = INTER_BYTES + N_IN * 1024;
   constexpr unsigned OOB = 0xFFFFFF00u;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* inter = smem;
   unsigned char* in_tile = smem + INTER_BYTES;
-  // conv-a's nine A fragments live in registers, which frees room for conv-b's weights next to the input tile: they are
-  // copied at kernel start with everything else (81152 B, still two workgroups per CU) and phase B starts without a third
-  // barrier or a mid-kernel wait for L2
   unsigned char* wb_tile = smem + WA_OFF;
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -79,7 +88,6 @@ convpair_16_32_32_kernel(const PairParams p) {
       (void*)(reinterpret_cast<const unsigned char*>(p.src) + b * fbytes), 0, (int)fbytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rwb = __builtin_amdgcn_make_buffer_rsrc((void*)p.wb, 0, 18 * 1024, 0x00020000);
 
-  // ---- copies: input halo tile (pixels outside the image -> zeros through the buffer bounds check) + conv-a weights
 #pragma unroll
   for (int j = 0; j < (N_IN + NW - 1) / NW; ++j) {
     const int i = j * NW + wave;
@@ -108,53 +116,93 @@ convpair_16_32_32_kernel(const PairParams p) {
   const float4 ba3 = *reinterpret_cast<const float4*>(p.bias_a + 24 + 4 * half);
   const float bias_a[16] = {ba0.x, ba0.y, ba0.z, ba0.w, ba1.x, ba1.y, ba1.z, ba1.w,
                             ba2.x, ba2.y, ba2.z, ba2.w, ba3.x, ba3.y, ba3.z, ba3.w};
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
 
-  // ---- phase A: conv-a (16 -> 32) on the 612 halo pixels, 32 per group
-  constexpr int NGA = (PH * PW + 31) / 32;  // 20
+  // ---- phase A set-up (overlaps the copies): offsets of halo row `wave`, column lx; row + 8 adds a compile-time stride
+  // (input tile: 8 * 36 pixels * 32 B = 9216, and (pin >> 3) & 1 is unchanged by + 288; intermediate tile: 8 * 34 * 64 B =
+  // 17408, and (pl >> 2) & 3 is unchanged by + 272)
+  unsigned roff[9], woff[2];
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap) {
+    const int pin = (wave + tap / 3) * QW + lx + tap % 3;
+    roff[tap] = (unsigned)(pin * 32 + ((half ^ ((pin >> 3) & 1)) * 16));
+  }
+  {
+    const int pl = wave * PW + lx;
+#pragma unroll
+    for (int pr = 0; pr < 2; ++pr) woff[pr] = (unsigned)(pl * 64 + (((2 * pr + half) ^ ((pl >> 2) & 3)) * 16));
+  }
+  const bool colok = (unsigned)(x0 + lx - 1) < (unsigned)W;
   const float low_a = p.relu_a ? 0.0f : -INFINITY;
-  for (int g = wave; g < NGA; g += NW) {
-    const int pl = g * 32 + lx;
-    const bool valid = pl < PH * PW;
-    const int plc = valid ? pl : 0;
-    const int ty = plc / PW, tx = plc - ty * PW;
+
+  // one group: 9 MFMAs on the fragments at rd[tap] (+ rimm), bias + ReLU, zero outside the image, two 16-byte stores
+  auto group = [&](const unsigned (&rd)[9], int rimm, const unsigned (&wr)[2], int wimm, bool in_img, bool store) {
     f32x16 d;
 #pragma unroll
     for (int i = 0; i < 16; ++i) d[i] = 0.0f;
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
-      const int pin = (ty + tap / 3) * QW + tx + tap % 3;
-      const mfma_h8 a = wa_reg[tap];
-      const mfma_h8 bv = *reinterpret_cast<const mfma_h8*>(in_tile + pin * 32 + ((half ^ ((pin >> 3) & 1)) * 16));
-      d = SA_MFMA_32x32x16(a, bv, d, 0, 0, 0);
+      const mfma_h8 bv = *reinterpret_cast<const mfma_h8*>(in_tile + rd[tap] + rimm);
+      d = SA_MFMA_32x32x16(wa_reg[tap], bv, d, 0, 0, 0);
     }
-    const int gy = y0 + ty - 1, gx = x0 + tx - 1;
-    const bool in_img = valid && gy >= 0 && gy < H && gx >= 0 && gx < W;
-    // lane holds channels (i&3) + 8*(i>>2) + 4*half; one v_permlane32_swap per dword -> 8 consecutive channels per lane
+    const unsigned m = in_img ? 0xFFFFFFFFu : 0u;
     uint2 pk[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      float v[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float t = fmaxf(d[4 * q + j] + bias_a[4 * q + j], low_a);
-        v[j] = in_img ? t : 0.0f;
-      }
-      pk[q].x = sa::f2h2(v[0], v[1]);
-      pk[q].y = sa::f2h2(v[2], v[3]);
+      pk[q].x = sa::f2h2(fmaxf(d[4 * q + 0] + bias_a[4 * q + 0], low_a), fmaxf(d[4 * q + 1] + bias_a[4 * q + 1], low_a)) & m;
+      pk[q].y = sa::f2h2(fmaxf(d[4 * q + 2] + bias_a[4 * q + 2], low_a), fmaxf(d[4 * q + 3] + bias_a[4 * q + 3], low_a)) & m;
     }
 #pragma unroll
     for (int pr = 0; pr < 2; ++pr) {
       uint2 x = pk[2 * pr], y = pk[2 * pr + 1];
       sa::swap32(x.x, y.x);
       sa::swap32(x.y, y.y);
-      const int slot = 2 * pr + half;  // channels 8*slot .. 8*slot+7
-      if (valid) *reinterpret_cast<uint4*>(inter + pl * 64 + ((slot ^ ((pl >> 2) & 3)) * 16)) = make_uint4(x.x, x.y, y.x, y.y);
+      if (store) *reinterpret_cast<uint4*>(inter + wr[pr] + wimm) = make_uint4(x.x, x.y, y.x, y.y);
+    }
+  };
+
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  // ---- phase A: conv-a (16 -> 32) on the 18 x 34 halo pixels
+#pragma unroll
+  for (int it = 0; it < 3; ++it) {
+    const int ty = wave + 8 * it;
+    if (ty < PH) {  // wave uniform (it == 2: waves 0, 1)
+      const bool rowok = (unsigned)(y0 + ty - 1) < (unsigned)H;
+      group(roff, it * (8 * QW * 32), woff, it * (8 * PW * 64), colok && rowok, true);
     }
   }
-  __syncthreads();  // the intermediate tile is complete; the input tile and conv-a weights are dead
+  if (wave == 2 || wave == 3) {  // halo columns 32, 33: pixel q of the 36 -> row q >> 1, column 32 + (q & 1)
+    const int q = (wave - 2) * 32 + lx;
+    const bool valid = q < 2 * PH;
+    const int qc = valid ? q : 0;
+    const int ty = qc >> 1, tx = 32 + (qc & 1);
+    unsigned rd[9], wr[2];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int pin = (ty + tap / 3) * QW + tx + tap % 3;
+      rd[tap] = (unsigned)(pin * 32 + ((half ^ ((pin >> 3) & 1)) * 16));
+    }
+    const int pl = ty * PW + tx;
+#pragma unroll
+    for (int pr = 0; pr < 2; ++pr) wr[pr] = (unsigned)(pl * 64 + (((2 * pr + half) ^ ((pl >> 2) & 3)) * 16));
+    const bool in_img = (unsigned)(y0 + ty - 1) < (unsigned)H && (unsigned)(x0 + tx - 1) < (unsigned)W;
+    group(rd, 0, wr, 0, in_img, valid);
+  }
 
+  // ---- phase B set-up: fragment offsets of halo rows wave*2 .. wave*2+3, columns lx .. lx+2, both k-steps
+  unsigned boff[R + 2][3][2];
+#pragma unroll
+  for (int rr = 0; rr < R + 2; ++rr)
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) {
+      const int pl = (wave * R + rr) * PW + lx + dx;
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        boff[rr][dx][kk] = (unsigned)(pl * 64 + (((kk * 2 + half) ^ ((pl >> 2) & 3)) * 16));
+        asm volatile("" : "+v"(boff[rr][dx][kk]));
+      }
+    }
   float bb[4][4];
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
@@ -164,6 +212,7 @@ convpair_16_32_32_kernel(const PairParams p) {
     bb[g][2] = q.z;
     bb[g][3] = q.w;
   }
+  __syncthreads();  // the intermediate tile is complete
 
   // ---- phase B: conv-b (32 -> 32), wave owns rows wave*2, wave*2+1
   f32x16 acc[R];
@@ -179,9 +228,7 @@ convpair_16_32_32_kernel(const PairParams p) {
       const mfma_h8 a = *reinterpret_cast<const mfma_h8*>(wb_tile + (kk * 9 + tap) * 1024 + lane * 16);
 #pragma unroll
       for (int r = 0; r < R; ++r) {
-        const int pl = (wave * R + r + dy) * PW + lx + dx;
-        const int slot = (kk * 2 + half) ^ ((pl >> 2) & 3);
-        const mfma_h8 bv = *reinterpret_cast<const mfma_h8*>(inter + pl * 64 + slot * 16);
+        const mfma_h8 bv = *reinterpret_cast<const mfma_h8*>(inter + boff[r + dy][dx][kk]);
         acc[r] = SA_MFMA_32x32x16(a, bv, acc[r], 0, 0, 0);
       }
     }
@@ -191,13 +238,15 @@ convpair_16_32_32_kernel(const PairParams p) {
   const float low_b = p.relu_b ? 0.0f : -INFINITY;
   const int gx = x0 + lx;
   auto act = [&](int r, int g, int j) { return fmaxf(acc[r][4 * g + j] + bb[g][j], low_b); };
-  auto store_pieces = [&](uint16_t* row_ptr, bool ok, const uint2 (&pk)[4]) {
+  // `frame`: this tile's output frame, `pix`: pixel inside it, `npix`: pixels per frame; piece pr = channels 16 pr + 8 half ..
+  auto store_pieces = [&](uint16_t* frame, size_t pix, size_t npix, bool ok, const uint2 (&pk)[4]) {
 #pragma unroll
     for (int pr = 0; pr < 2; ++pr) {
       uint2 x = pk[2 * pr], y = pk[2 * pr + 1];
       sa::swap32(x.x, y.x);
       sa::swap32(x.y, y.y);
-      if (ok) *reinterpret_cast<uint4*>(row_ptr + 16 * pr + 8 * half) = make_uint4(x.x, x.y, y.x, y.y);
+      uint16_t* q = p.planar ? frame + ((size_t)pr * npix + pix) * 16 + 8 * half : frame + pix * 32 + 16 * pr + 8 * half;
+      if (ok) *reinterpret_cast<uint4*>(q) = make_uint4(x.x, x.y, y.x, y.y);
     }
   };
   if (p.dst) {
@@ -211,7 +260,7 @@ convpair_16_32_32_kernel(const PairParams p) {
         pk[g].y = sa::f2h2(act(r, g, 2), act(r, g, 3));
       }
       const bool ok = gy < H && gx < W;
-      store_pieces(p.dst + (((size_t)b * H + (ok ? gy : 0)) * W + (ok ? gx : 0)) * 32, ok, pk);
+      store_pieces(p.dst + (size_t)b * H * W * 32, (size_t)(ok ? gy : 0) * W + (ok ? gx : 0), (size_t)H * W, ok, pk);
     }
   }
   if (p.dst_pool) {
@@ -229,7 +278,8 @@ convpair_16_32_32_kernel(const PairParams p) {
       pk[g].y = sa::f2h2(t4[2], t4[3]);
     }
     const bool ok = !(lane & 1) && gy < H && gx < W;
-    store_pieces(p.dst_pool + (((size_t)b * (H / 2) + (ok ? gy / 2 : 0)) * (W / 2) + (ok ? gx / 2 : 0)) * 32, ok, pk);
+    store_pieces(p.dst_pool + (size_t)b * (H / 2) * (W / 2) * 32, (size_t)(ok ? gy / 2 : 0) * (W / 2) + (ok ? gx / 2 : 0),
+                 (size_t)(H / 2) * (W / 2), ok, pk);
   }
 #endif
 }
@@ -238,12 +288,13 @@ convpair_16_32_32_kernel(const PairParams p) {
 
 extern "C" int sa_conv3x3_pair_bf16(const void* src, int C0P, const void* wa, const float* bias_a, int relu_a, int C1P,
                                     const void* wb, const float* bias_b, int relu_b, int C2P, int B, int H, int W, void* dst,
-                                    void* dst_pool, sa_stream_t stream) {
+                                    void* dst_pool, int layout, sa_stream_t stream) {
   SA_REQUIRE(src && wa && wb && bias_a && bias_b && (dst || dst_pool), "sa_conv3x3_pair_bf16: NULL pointer");
   if (C0P != 16 || C1P != 32 || C2P != 32)
     return sa::fail(SA_ERR_UNSUPPORTED, "sa_conv3x3_pair_bf16: only the 16 -> 32 -> 32 block is implemented (got %d -> %d -> %d)",
                     C0P, C1P, C2P);
   SA_REQUIRE(B > 0 && H > 0 && W > 0, "sa_conv3x3_pair_bf16: bad shape");
+  SA_REQUIRE(layout == SA_LAYOUT_NHWC || layout == SA_LAYOUT_PLANES16, "sa_conv3x3_pair_bf16: bad layout");
   SA_REQUIRE(!dst_pool || (H % 2 == 0 && W % 2 == 0), "sa_conv3x3_pair_bf16: pooled output needs even H, W");
   SA_REQUIRE((size_t)H * W * 32 < 0xFFFFFF00ull, "sa_conv3x3_pair_bf16: one frame must be smaller than 4 GiB");
   PairParams p;
@@ -259,6 +310,7 @@ extern "C" int sa_conv3x3_pair_bf16(const void* src, int C0P, const void* wa, co
   p.W = W;
   p.relu_a = relu_a;
   p.relu_b = relu_b;
+  p.planar = layout == SA_LAYOUT_PLANES16;
   p.tiles_x = (W + 31) / 32;
   p.tiles_y = (H + 15) / 16;
   const size_t nblk = (size_t)p.tiles_x * p.tiles_y * B;

@@ -292,6 +292,51 @@ upsample2x_bilinear_block_kernel(const uint16_t* __restrict__ src, int B, int H,
   }
 }
 
+// Bilinear x2 for 16-channel tensors (every tensor of an SA_LAYOUT_PLANES16 plan is a stack of those): one thread per SOURCE
+// row, OUTPUT column and 8-channel group. With 32 bytes per pixel the block kernel above makes every store instruction write
+// 16-byte pieces with gaps (output columns 2j and 2j+1 come from different instructions): measured 0.371 ms where the NHWC
+// tensor of the same size took 0.257. Here consecutive lanes write consecutive 16 bytes -- one instruction = 1 KiB of one output
+// row -- at the price of 6 (mostly L1-hit) loads per thread instead of 9 per two; same operation order, same bits.
+__global__ void __launch_bounds__(256)
+upsample2x_bilinear_c16_kernel(const uint16_t* __restrict__ src, int B, int H, int W, uint16_t* __restrict__ dst) {
+  const int Wo = 2 * W;
+  const size_t total = (size_t)B * H * Wo * 2;
+  for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
+    const int g = (int)(t & 1);
+    const size_t q = t >> 1;
+    const int x = (int)(q % Wo);
+    const int i = (int)((q / Wo) % H);
+    const size_t b = q / ((size_t)Wo * H);
+    const int j = x >> 1, odd = x & 1;
+    // output column 2j: taps (j-1, j), weight 0.75 on j; column 2j+1: taps (j, j+1), weight 0.25 on j+1 (edge clamped)
+    const int xa = odd ? j : max(j - 1, 0), xb = odd ? min(j + 1, W - 1) : j;
+    const float wx = odd ? 0.25f : 0.75f;
+    const int ys[3] = {max(i - 1, 0), i, min(i + 1, H - 1)};
+    const uint16_t* base = src + b * H * W * (size_t)16 + g * 8;
+    float hz[3][8];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const uint16_t* row = base + (size_t)ys[r] * W * 16;
+      const h16x8_t va = *reinterpret_cast<const h16x8_t*>(row + (size_t)xa * 16);
+      const h16x8_t vb = *reinterpret_cast<const h16x8_t*>(row + (size_t)xb * 16);
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        const float m = sa::h2f(va[c]), z = sa::h2f(vb[c]);
+        hz[r][c] = m + (z - m) * wx;
+      }
+    }
+    h16x8_t o0, o1;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      o0[c] = sa::f2h(hz[0][c] + (hz[1][c] - hz[0][c]) * 0.75f);  // row 2i
+      o1[c] = sa::f2h(hz[1][c] + (hz[2][c] - hz[1][c]) * 0.25f);  // row 2i+1
+    }
+    uint16_t* o = dst + (((b * 2 * H + 2 * i) * Wo) + x) * (size_t)16 + g * 8;
+    *reinterpret_cast<h16x8_t*>(o) = o0;
+    *reinterpret_cast<h16x8_t*>(o + (size_t)Wo * 16) = o1;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // 1x1 linear head (heads.py:42-62): bf16 features x f32 weights -> f32 maps with exact channel count.
 // thread = pixel; weights [Cout][CinP] staged in LDS (broadcast reads).
@@ -565,7 +610,11 @@ int sa_maxpool2x2_bf16(const void* src, int B, int H, int W, int CP, void* dst, 
 int sa_upsample2x_bf16(const void* src, int B, int H, int W, int CP, int bilinear, void* dst,
                        sa_stream_t stream) {
   SA_REQUIRE(CP % 8 == 0, "sa_upsample2x_bf16: CP%%8 != 0");
-  if (bilinear) {
+  if (bilinear && CP == 16) {
+    const size_t total = (size_t)B * H * W * 4;
+    hipLaunchKernelGGL(upsample2x_bilinear_c16_kernel, dim3(grid_for(total, 256, 1 << 20)), dim3(256), 0, (hipStream_t)stream,
+                       (const uint16_t*)src, B, H, W, (uint16_t*)dst);
+  } else if (bilinear) {
     const size_t total = (size_t)B * H * W * (CP / 8);
     // one workgroup per 256 items up to 65536 workgroups: measured 4.0-4.3 TB/s vs 3.7 with an 8192-block grid-stride
     // loop (torch's copy kernel: 5.0 TB/s read+write on the same box, tools/bw_probe.py); nontemporal stores: no effect

@@ -16,7 +16,7 @@
 
 namespace {
 
-constexpr int64_t PLAN_MAGIC = 0x53414E4554303031LL;  // "SANET001"
+constexpr int64_t PLAN_MAGIC = 0x53414E4554303032LL;  // "SANET002" (002: + the activation layout word)
 
 enum OpKind : int64_t {
   K_STEM2 = 1, K_STEM = 2, K_CONV = 3, K_PAIR = 4, K_CONV1X1 = 5, K_CONVT2 = 6, K_CONVT = 7, K_POOLG = 8, K_IMGCONV = 9,
@@ -47,6 +47,7 @@ struct sa_network {
   std::vector<Out> outs;
   std::vector<Op> ops;
   int in_channels = 0, max_stride = 1;
+  int layout = SA_LAYOUT_NHWC;  // of every 16-bit plan tensor (SA_LAYOUT_PLANES16: the compiler checked that each launch of the plan supports it)
 };
 
 namespace {
@@ -72,14 +73,22 @@ size_t layout(const sa_network* n, int B, int H, int W, std::vector<size_t>* off
 extern "C" {
 
 int sa_network_create(const int64_t* plan, size_t n_words, sa_network_t** out) {
-  SA_REQUIRE(plan && out && n_words >= 7, "sa_network_create: NULL / short plan");
+  SA_REQUIRE(plan && out && n_words >= 8, "sa_network_create: NULL / short plan");
   SA_REQUIRE(plan[0] == PLAN_MAGIC, "sa_network_create: bad magic (plan words come from DeviceNetwork.plan_words())");
   size_t i = 1;
   const int64_t n_buf = plan[i++], n_out = plan[i++], n_ops = plan[i++];
   auto* n = new sa_network;
   n->in_channels = (int)plan[i++];
   n->max_stride = (int)plan[i++];
-  SA_REQUIRE(n_buf >= 0 && n_out > 0 && n_ops > 0, "sa_network_create: empty plan");
+  n->layout = (int)plan[i++];
+  if (n->layout != SA_LAYOUT_NHWC && n->layout != SA_LAYOUT_PLANES16) {
+    delete n;
+    return sa::fail(SA_ERR_INVALID_ARG, "sa_network_create: unknown activation layout %d", n->layout);
+  }
+  if (!(n_buf >= 0 && n_out > 0 && n_ops > 0)) {
+    delete n;
+    return sa::fail(SA_ERR_INVALID_ARG, "sa_network_create: empty plan");
+  }
   auto need = [&](size_t k) { return i + k <= n_words; };
   bool ok = need((size_t)n_buf * 4);
   for (int64_t b = 0; ok && b < n_buf; ++b, i += 4) n->bufs.push_back({(int)plan[i], (int)plan[i + 1], (int)plan[i + 2], (int)plan[i + 3]});
@@ -106,6 +115,19 @@ int sa_network_create(const int64_t* plan, size_t n_words, sa_network_t** out) {
       delete n;
       return sa::fail(SA_ERR_INVALID_ARG, "sa_network_create: output refers to buffer %d", o.buf);
     }
+  if (n->layout == SA_LAYOUT_PLANES16) {
+    bool fits = true;
+    for (const Op& op : n->ops) {
+      fits = fits && (op.kind == K_STEM2 || op.kind == K_PAIR || op.kind == K_UP || op.kind == K_CONV);
+      if (op.kind == K_CONV && op.a.size() >= 10)  // plain / concat sources, no extended epilogue
+        fits = fits && (op.a[2] == SA_SRC1_NONE || op.a[2] == SA_SRC1_DIRECT) && op.a[10 + 5 * (size_t)op.a[9]] == 0;
+    }
+    for (const Out& o : n->outs) fits = fits && (o.is_f32 || n->bufs[(size_t)o.buf].cp == 16);
+    if (!fits) {
+      delete n;
+      return sa::fail(SA_ERR_UNSUPPORTED, "sa_network_create: SA_LAYOUT_PLANES16 plan holds a launch or an output that only exists for NHWC tensors");
+    }
+  }
   *out = n;
   return SA_OK;
 }
@@ -115,6 +137,7 @@ void sa_network_destroy(sa_network_t* net) { delete net; }
 int sa_network_n_outputs(const sa_network_t* net) { return net ? (int)net->outs.size() : 0; }
 int sa_network_in_channels(const sa_network_t* net) { return net ? net->in_channels : 0; }
 int sa_network_max_stride(const sa_network_t* net) { return net ? net->max_stride : 0; }
+int sa_network_layout(const sa_network_t* net) { return net ? net->layout : 0; }
 
 int sa_network_output_shape(const sa_network_t* net, int index, int H, int W, int* oh, int* ow, int* oc) {
   SA_REQUIRE(net && index >= 0 && index < (int)net->outs.size(), "sa_network_output_shape: bad index");
@@ -167,6 +190,7 @@ int sa_network_forward(const sa_network_t* net, const void* images, int images_a
   auto bh = [&](int64_t id) { const Buf& b = net->bufs[(size_t)id]; return H * b.num / b.den; };
   auto bw = [&](int64_t id) { const Buf& b = net->bufs[(size_t)id]; return W * b.num / b.den; };
   auto bc = [&](int64_t id) { return net->bufs[(size_t)id].cp; };
+  const int lay = net->layout;
 
   for (const Op& op : net->ops) {
     const int64_t* a = op.a.data();
@@ -177,7 +201,7 @@ int sa_network_forward(const sa_network_t* net, const void* images, int images_a
           rc = sa_stem16_u8_bf16(images, B, H, W, (int)a[0], P<void>(a[11]), (int)a[4], (int)a[8], bp(a[9]), bp(a[10]), stream);
         else
           rc = sa_stem_conv3x3x2_bf16(images, images_are_u8, B, H, W, (int)a[0], P<float>(a[1]), P<float>(a[2]), (int)a[3],
-                                      (int)a[4], P<void>(a[5]), P<float>(a[6]), (int)a[7], (int)a[8], bp(a[9]), bp(a[10]), stream);
+                                      (int)a[4], P<void>(a[5]), P<float>(a[6]), (int)a[7], (int)a[8], bp(a[9]), bp(a[10]), lay, stream);
         break;
       }
       case K_STEM:  // [o_buf, w, bias, cin, relu]
@@ -207,13 +231,13 @@ int sa_network_forward(const sa_network_t* net, const void* images, int images_a
             ha[k] = (int)a[13 + 5 * k];
             hd[k] = static_cast<float*>(bp(a[14 + 5 * k]));
           }
-          rc = sa_conv3x3_heads_bf16(bp(s0), bc(s0), src1, c1p, (int)a[2], P<void>(a[3]), P<float>(a[4]), coutp, (int)a[6], B, oh,
+          rc = sa_conv3x3_heads_bf16(bp(s0), bc(s0), src1, c1p, (int)a[2] | lay, P<void>(a[3]), P<float>(a[4]), coutp, (int)a[6], B, oh,
                                      ow, dst, nh, hw, hb, hc, ha, hd, stream);
         } else if (e[0]) {
-          rc = sa_conv3x3_ex_bf16(bp(s0), bc(s0), src1, c1p, (int)a[2], P<void>(a[3]), P<float>(a[4]), coutp, (int)a[6], B, oh, ow,
+          rc = sa_conv3x3_ex_bf16(bp(s0), bc(s0), src1, c1p, (int)a[2] | lay, P<void>(a[3]), P<float>(a[4]), coutp, (int)a[6], B, oh, ow,
                                   dst, bp(a[7]), P<float>(e[1]), P<float>(e[2]), bp(e[3]), (int)e[4], (int)e[5], stream);
         } else {
-          rc = sa_conv3x3_bf16(bp(s0), bc(s0), src1, c1p, (int)a[2], P<void>(a[3]), P<float>(a[4]), coutp, (int)a[6], B, oh, ow,
+          rc = sa_conv3x3_bf16(bp(s0), bc(s0), src1, c1p, (int)a[2] | lay, P<void>(a[3]), P<float>(a[4]), coutp, (int)a[6], B, oh, ow,
                                dst, bp(a[7]), stream);
         }
         break;
@@ -221,7 +245,7 @@ int sa_network_forward(const sa_network_t* net, const void* images, int images_a
       case K_PAIR:  // [s0, wa, ba, relu_a, c1p, wb, bb, relu_b, o_buf, store, opool_buf]
         rc = sa_conv3x3_pair_bf16(bp(a[0]), bc(a[0]), P<void>(a[1]), P<float>(a[2]), (int)a[3], (int)a[4], P<void>(a[5]),
                                   P<float>(a[6]), (int)a[7], bc(a[8]), B, bh(a[8]), bw(a[8]), a[9] ? bp(a[8]) : nullptr, bp(a[10]),
-                                  stream);
+                                  lay, stream);
         break;
       case K_CONV1X1:  // [s0, w, bias, relu, stride, has_ext, ps, pt, res_buf, relu_last, o_buf]
         rc = sa_conv1x1_bf16(bp(a[0]), bc(a[0]), P<void>(a[1]), P<float>(a[2]), bc(a[10]), (int)a[3], B, bh(a[0]), bw(a[0]),
@@ -278,8 +302,11 @@ int sa_network_forward(const sa_network_t* net, const void* images, int images_a
       case K_POOL:  // [s, o]
         rc = sa_maxpool2x2_bf16(bp(a[0]), B, bh(a[0]), bw(a[0]), bc(a[0]), bp(a[1]), stream);
         break;
-      case K_UP:  // [s, o, bilinear]
-        rc = sa_upsample2x_bf16(bp(a[0]), B, bh(a[0]), bw(a[0]), bc(a[0]), (int)a[2], bp(a[1]), stream);
+      case K_UP:  // [s, o, bilinear]; planes: every 16-channel plane of every frame is a frame of 16 channels
+        if (lay == SA_LAYOUT_PLANES16)
+          rc = sa_upsample2x_bf16(bp(a[0]), B * (bc(a[0]) / 16), bh(a[0]), bw(a[0]), 16, (int)a[2], bp(a[1]), stream);
+        else
+          rc = sa_upsample2x_bf16(bp(a[0]), B, bh(a[0]), bw(a[0]), bc(a[0]), (int)a[2], bp(a[1]), stream);
         break;
       default:
         return sa::fail(SA_ERR_INVALID_ARG, "sa_network_forward: unknown op kind %lld", (long long)op.kind);

@@ -79,7 +79,7 @@ DEFAULT_DTYPE = None  # set (temporarily) by load_model(dtype=...); otherwise _l
 class DeviceNetwork:
     def __init__(self, model_config: dict, weights: Dict[str, np.ndarray], device=None, fuse_upsample: bool = False,
                  fuse_heads: bool = True, fuse_stem: bool = True, use_stem16: bool = True, mfma_convt: bool = True,
-                 mfma_stem: bool = True, fuse_pairs: bool = True, dtype: Optional[str] = None):
+                 mfma_stem: bool = True, fuse_pairs: bool = True, dtype: Optional[str] = None, layout: Optional[str] = None):
         """`fuse_upsample=True` folds UpSampling2D(bilinear) into the consuming conv's tile load (register-staged
         v1 kernel); the default materialises the upsampled tensor with the bandwidth-bound standalone kernel and
         feeds the asynchronous-DMA conv kernel (faster overall, measured in profiles/)."""
@@ -91,6 +91,9 @@ class DeviceNetwork:
         self._h = _lib.lib(self.dtype)
         self._tdtype = torch.float16 if self.dtype == "fp16" else torch.bfloat16
         self._range_checked = False
+        # layout of the 16-bit activation tensors: None = 16-channel planes when every launch of the compiled plan supports
+        # them (the UNet family), NHWC otherwise; "nhwc" / "planes16" force one (SA_LAYOUT in the environment likewise)
+        self._layout_request = layout or os.environ.get("SA_LAYOUT") or None
         self.fuse_upsample = fuse_upsample
         self.fuse_heads = fuse_heads
         self.fuse_stem = fuse_stem
@@ -554,8 +557,44 @@ class DeviceNetwork:
         if self.fuse_pairs:
             self.plan = self._fuse_pairs(self.plan)
         self.n_buf = n_buf[0]
+        self.layout = self._pick_layout()
         # reduce fractions for stride bookkeeping
         self.max_stride = max(den // max(num, 1) for (_, num, den, _) in self.buf_meta.values())
+
+    def _pick_layout(self) -> int:
+        """SA_LAYOUT_PLANES16 when every launch of the plan can read and write 16-channel planes (include/sleap_amd.h): the
+        fused stem, the fused encoder block, 3x3 convs on the DMA path (plain / concatenated sources, fused heads, pooled
+        copies) and the materialised upsampling; 16-bit model outputs only with 16 padded channels (the same bytes in both
+        layouts). Anything else in the plan (1x1 / transposed / first-layer convs, residual epilogues, un-fused heads and
+        pools) keeps the whole network NHWC -- one layout per plan, no conversion launches."""
+        req = self._layout_request
+        if req not in (None, "nhwc", "planes16"):
+            raise ValueError(f"layout must be 'nhwc' or 'planes16', got {req!r}")
+
+        def fits(op):
+            k = op[0]
+            if k in ("stem2", "pair", "up"):
+                return True
+            return k == "conv" and op.mode in (_lib.SRC1_NONE, _lib.SRC1_DIRECT) and op.ext is None
+
+        ok = all(fits(op) for op in self.plan) and all(o.kind == "f32out" or o.cp == 16 for o in self.outputs)
+        if req == "planes16" and not ok:
+            raise NotImplementedError("layout='planes16': this plan holds launches that only exist for NHWC tensors")
+        return _lib.LAYOUT_PLANES16 if (ok and req != "nhwc") else _lib.LAYOUT_NHWC
+
+    @property
+    def planar(self) -> bool:
+        return self.layout == _lib.LAYOUT_PLANES16
+
+    def stored_tensor(self, buf_id: int, shape_key=None) -> torch.Tensor:
+        """The plan tensor `buf_id` of the resident workspace as a [B,H,W,CP] tensor (a COPY when the plan is in planes:
+        tests / diagnostics; the kernels read the workspace itself)."""
+        bufs = self._buffers[shape_key] if shape_key is not None else next(iter(self._buffers.values()))
+        t = bufs[buf_id]
+        if not self.planar or t.dtype == torch.float32 or t.shape[3] == 16:
+            return t
+        b, hh, ww, cp = t.shape
+        return t.reshape(b, cp // 16, hh, ww, 16).permute(0, 2, 3, 1, 4).reshape(b, hh, ww, cp)
 
     @staticmethod
     def _writes(op, tensor):
@@ -668,7 +707,7 @@ class DeviceNetwork:
         return [o.den // o.num for o in self.outputs]
 
     # ------------------------------------------------------------------ C executor (include/sleap_amd.h: sa_network_*)
-    PLAN_MAGIC = 0x53414E4554303031  # "SANET001"
+    PLAN_MAGIC = 0x53414E4554303032  # "SANET002"
     _K = {"stem2": 1, "stem": 2, "conv": 3, "pair": 4, "conv1x1": 5, "convt2": 6, "convt": 7, "poolg": 8, "imgconv": 9,
           "add": 10, "head": 11, "pool": 12, "up": 13}
 
@@ -749,7 +788,7 @@ class DeviceNetwork:
             else:
                 raise AssertionError(k)
             ops.append([self._K[k], len(a)] + [int(v) for v in a])
-        words = [self.PLAN_MAGIC, n_ids[0], len(self.outputs), len(ops), int(self.in_channels), int(self.max_stride)]
+        words = [self.PLAN_MAGIC, n_ids[0], len(self.outputs), len(ops), int(self.in_channels), int(self.max_stride), int(self.layout)]
         for i in range(n_ids[0]):
             words += bufs.get(i, [16, 1, 1, 2])  # ids the fusion passes retired: virtual placeholders
         for o in self.outputs:
@@ -960,7 +999,7 @@ class DeviceNetwork:
                     check(h.sa_stem_conv3x3x2_bf16(_ptr(imgs), is_u8, B, H, W, cin, _ptr(w0), _ptr(b0), so.cp, relu0,
                                                    _ptr(w1), _ptr(b1), o.cp, relu1,
                                                    _ptr(bufs[o.buf]) if need_full else None,
-                                                   _ptr(bufs[o_pool.buf]) if o_pool is not None else None, st),
+                                                   _ptr(bufs[o_pool.buf]) if o_pool is not None else None, self.layout, st),
                           "sa_stem_conv3x3x2_bf16")
             elif kind == "stem":
                 _, o, w, bias, cin, relu, _n0 = op
@@ -984,7 +1023,7 @@ class DeviceNetwork:
                 for hd in heads:  # the fused kernel indexes head weights with the producer's padded channel count
                     assert hd[3].shape[1] == o.cp
                 check(h.sa_conv3x3_heads_bf16(_ptr(bufs[s0.buf]), s0.cp, _ptr(bufs[s1.buf]) if s1 is not None else None,
-                                              s1.cp if s1 is not None else 0, mode, _ptr(w), _ptr(bias), o.cp, relu, B, oh,
+                                              s1.cp if s1 is not None else 0, mode | self.layout, _ptr(w), _ptr(bias), o.cp, relu, B, oh,
                                               ow, _ptr(bufs[o.buf]) if need_full else None, n, hw_, hb_, hc_, ha_, hd_, st),
                       "sa_conv3x3_heads_bf16")
             elif kind == "conv" and op.ext is not None:
@@ -1004,7 +1043,8 @@ class DeviceNetwork:
                 oh, ow = hw(o)
                 check(h.sa_conv3x3_pair_bf16(_ptr(bufs[s0.buf]), s0.cp, _ptr(xa[4]), _ptr(xa[5]), xa[7], xa[6].cp, _ptr(yb[4]),
                                              _ptr(yb[5]), yb[7], o.cp, B, oh, ow, _ptr(bufs[o.buf]) if need_full else None,
-                                             _ptr(bufs[o_pool.buf]) if o_pool is not None else None, st), "sa_conv3x3_pair_bf16")
+                                             _ptr(bufs[o_pool.buf]) if o_pool is not None else None, self.layout, st),
+                      "sa_conv3x3_pair_bf16")
             elif kind == "conv1x1":
                 _, s0, _s1, stride, w, bias, o, relu, _op, _nf, _heads, _nm, ext = op
                 sh, sw = hw(s0)
@@ -1066,7 +1106,7 @@ class DeviceNetwork:
                 _, s0, s1, mode, w, bias, o, relu, o_pool, need_full, _heads, _nm, _ext = op
                 oh, ow = hw(o)
                 check(h.sa_conv3x3_bf16(_ptr(bufs[s0.buf]), s0.cp, _ptr(bufs[s1.buf]) if s1 is not None else None,
-                                        s1.cp if s1 is not None else 0, mode, _ptr(w), _ptr(bias), o.cp, relu, B, oh, ow,
+                                        s1.cp if s1 is not None else 0, mode | self.layout, _ptr(w), _ptr(bias), o.cp, relu, B, oh, ow,
                                         _ptr(bufs[o.buf]) if need_full else None,
                                         _ptr(bufs[o_pool.buf]) if o_pool is not None else None, st), "sa_conv3x3_bf16")
             elif kind == "head":
@@ -1081,7 +1121,10 @@ class DeviceNetwork:
             elif kind == "up":
                 _, s, o, bil = op
                 sh, sw = hw(s)
-                check(h.sa_upsample2x_bf16(_ptr(bufs[s.buf]), B, sh, sw, s.cp, bil, _ptr(bufs[o.buf]), st), "sa_upsample2x_bf16")
+                if self.planar:  # every 16-channel plane of every frame is a frame of 16 channels
+                    check(h.sa_upsample2x_bf16(_ptr(bufs[s.buf]), B * (s.cp // 16), sh, sw, 16, bil, _ptr(bufs[o.buf]), st), "sa_upsample2x_bf16")
+                else:
+                    check(h.sa_upsample2x_bf16(_ptr(bufs[s.buf]), B, sh, sw, s.cp, bil, _ptr(bufs[o.buf]), st), "sa_upsample2x_bf16")
             elif kind == "convt":
                 _, s, w, bias, o, relu = op
                 sh, sw = hw(s)

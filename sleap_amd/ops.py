@@ -265,6 +265,19 @@ def from_bf16(x_bf16, c):
     return out
 
 
+def to_planes16(x):
+    """[B,H,W,CP] 16-bit tensor -> the same values as 16-channel planes [B,CP/16,H,W,16], returned in the NHWC SHAPE (the
+    kernels take raw pointers; only the byte order differs)."""
+    b, h, w, c = x.shape
+    return x.reshape(b, h, w, c // 16, 16).permute(0, 3, 1, 2, 4).contiguous().view(b, h, w, c)
+
+
+def from_planes16(x):
+    """inverse of to_planes16"""
+    b, h, w, c = x.shape
+    return x.reshape(b, c // 16, h, w, 16).permute(0, 2, 3, 1, 4).reshape(b, h, w, c)
+
+
 def pack_conv3x3_weights(kernel, c0, c1=0, dtype: str = None):
     """Keras (3,3,c0+c1,cout) f32 numpy -> packed 16-bit MFMA fragments (as int16 CUDA tensor) for the `dtype` library."""
     kernel = np.ascontiguousarray(kernel, dtype=np.float32)
@@ -279,6 +292,8 @@ def pack_conv3x3_weights(kernel, c0, c1=0, dtype: str = None):
 
 
 def conv3x3(src0, src1, mode, packed_w, bias_padded, coutp, relu, out_hw, full=True, pooled=False):
+    """sa_conv3x3_bf16. `mode` may carry _lib.LAYOUT_PLANES16: sources and outputs are then 16-channel planes
+    ([B,CP/16,H,W,16] bytes held in tensors of the NHWC shape; to_planes16 / from_planes16 convert)."""
     B = src0.shape[0]
     H, W = out_hw
     out = torch.empty((B, H, W, coutp), dtype=src0.dtype, device=src0.device) if full else None

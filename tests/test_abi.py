@@ -26,7 +26,7 @@ def test_all_declared_symbols_exported_and_bound(dtype):
         assert hasattr(h, n), f"{n} declared in sleap_amd.h but not exported"
         assert n in _lib.SIGNATURES, f"{n} has no ctypes signature"
     assert set(_lib.SIGNATURES) == set(names)
-    assert h.sa_abi_version() == 1
+    assert h.sa_abi_version() == 2
     assert h.sa_storage_dtype().decode() == dtype
 
 
@@ -48,15 +48,17 @@ def test_network_plan_validation_without_gpu():
 
     h = _lib.lib()
     out = C.c_void_p()
-    bad = np.array([1, 2, 3, 4, 5, 6, 7], np.int64)
+    bad = np.array([1, 2, 3, 4, 5, 6, 7, 8], np.int64)
     assert h.sa_network_create(bad.ctypes.data_as(C.c_void_p), bad.size, C.byref(out)) == -1
     assert b"bad magic" in h.sa_last_error()
-    MAGIC = 0x53414E4554303031
-    # buffers: 0 = 16-bit 16ch @ 1/1, 1 = f32 head 3ch @ 1/2 (virtual ids are shape-only); one head op reading 0 -> 1
-    words = [MAGIC, 2, 1, 1, 1, 2, 16, 1, 1, 0, 3, 1, 2, 1, 1, 3, 1, 11, 6, 0, 0, 0, 3, 0, 1]
+    MAGIC = 0x53414E4554303032
+    # header (magic, buffers, outputs, ops, input channels, max stride, layout); buffers: 0 = 16-bit 16ch @ 1/1, 1 = f32 head
+    # 3ch @ 1/2 (virtual ids are shape-only); one head op reading 0 -> 1
+    words = [MAGIC, 2, 1, 1, 1, 2, 0, 16, 1, 1, 0, 3, 1, 2, 1, 1, 3, 1, 11, 6, 0, 0, 0, 3, 0, 1]
     ok = np.array(words, np.int64)
     assert h.sa_network_create(ok.ctypes.data_as(C.c_void_p), ok.size, C.byref(out)) == 0, h.sa_last_error()
     assert h.sa_network_n_outputs(out) == 1 and h.sa_network_in_channels(out) == 1 and h.sa_network_max_stride(out) == 2
+    assert h.sa_network_layout(out) == _lib.LAYOUT_NHWC
     oh, ow, oc = C.c_int(), C.c_int(), C.c_int()
     assert h.sa_network_output_shape(out, 0, 8, 12, C.byref(oh), C.byref(ow), C.byref(oc)) == 0
     assert (oh.value, ow.value, oc.value) == (4, 6, 3)
@@ -67,6 +69,10 @@ def test_network_plan_validation_without_gpu():
     assert h.sa_network_forward(out, 1, 1, 2, 7, 12, 1, one, 1, 1 << 20, None) == -1 and b"multiple of the model stride" in h.sa_last_error()
     assert h.sa_network_forward(out, 1, 1, 2, 8, 12, 1, one, 1, 16, None) == -4
     h.sa_network_destroy(out)
+    planes = list(words)
+    planes[6] = _lib.LAYOUT_PLANES16  # an un-fused head launch only exists for NHWC tensors
+    planes = np.array(planes, np.int64)
+    assert h.sa_network_create(planes.ctypes.data_as(C.c_void_p), planes.size, C.byref(out)) == -3 and b"PLANES16" in h.sa_last_error()
     trunc = np.array(words[:-2], np.int64)
     assert h.sa_network_create(trunc.ctypes.data_as(C.c_void_p), trunc.size, C.byref(out)) == -1
     assert b"truncated" in h.sa_last_error()

@@ -258,7 +258,7 @@ def test_layerwise_vs_bf16_emulating_oracle():
     net = DeviceNetwork(cfg, w)
     net.forward(torch.from_numpy(x).cuda())
     torch.cuda.synchronize()
-    bufs = net._buffers[(2, 128, 160)]
+    assert net.planar  # the UNet family runs on 16-channel planes; stored_tensor() hands back NHWC views / copies
     _, ref = KerasGraph(cfg, w, emulate_bf16=True)(ensure_float(x), return_all=True)
     conv_layers = [l["name"] for l in cfg["config"]["layers"] if l["class_name"] == "Conv2D"]
     acts = {l["inbound_nodes"][0][0][0]: l["name"] for l in cfg["config"]["layers"] if l["class_name"] == "Activation"}
@@ -280,7 +280,7 @@ def test_layerwise_vs_bf16_emulating_oracle():
         if o.buf is None:  # only the fused max-pooled copy of this layer is stored
             o = op[8]
             r = r.reshape(r.shape[0], r.shape[1] // 2, 2, r.shape[2] // 2, 2, r.shape[3]).max(axis=(2, 4))
-        d = bufs[o.buf].float().cpu().numpy()[..., : o.c]
+        d = net.stored_tensor(o.buf, (2, 128, 160)).float().cpu().numpy()[..., : o.c]
         scale = np.abs(r).max()
         err = np.abs(d - r).max() / scale
         assert err <= 2.0 ** -6, (name, err)
@@ -308,9 +308,10 @@ def test_fusion_variants_agree(fuse):
             assert float((a - b).abs().max()) <= 2e-2 * float(a.abs().max())
 
 
+@pytest.mark.parametrize("layout", ["nhwc", "planes16"])
 @pytest.mark.parametrize("B,H,W,full,pooled", [(2, 32, 64, True, False), (1, 48, 96, False, True), (2, 16, 32, True, True),
                                                 (1, 37, 45, True, False), (1, 18, 34, False, True)])
-def test_conv_pair_is_bitwise_two_convs(B, H, W, full, pooled):
+def test_conv_pair_is_bitwise_two_convs(B, H, W, full, pooled, layout):
     """sa_conv3x3_pair_bf16 (16 -> 32 -> 32 encoder block, intermediate in LDS) == sa_conv3x3_bf16 twice, bit for bit:
     same bf16 rounding of the intermediate, same MFMA accumulation order; ragged tiles and image borders included."""
     from sleap_amd import _lib, ops
@@ -328,12 +329,85 @@ def test_conv_pair_is_bitwise_two_convs(B, H, W, full, pooled):
     ref = ref if isinstance(ref, tuple) else ((ref, None) if full else (None, ref))
     out = torch.full((B, H, W, 32), 7.0, dtype=TD, device="cuda") if full else None
     outp = torch.full((B, H // 2, W // 2, 32), 7.0, dtype=TD, device="cuda") if pooled else None
+    lay = _lib.LAYOUT_PLANES16 if layout == "planes16" else _lib.LAYOUT_NHWC  # a 16-channel input is the same bytes in both
     check(_lib.lib().sa_conv3x3_pair_bf16(_ptr(x), 16, _ptr(wa), _ptr(ba), 1, 32, _ptr(wb), _ptr(bb), 1, 32, B, H, W, _ptr(out),
-                                          _ptr(outp), _stream()), "sa_conv3x3_pair_bf16")
+                                          _ptr(outp), lay, _stream()), "sa_conv3x3_pair_bf16")
+    back = ops.from_planes16 if lay else (lambda t: t)
     if full:
-        assert torch.equal(out, ref[0])
+        assert torch.equal(back(out), ref[0])
     if pooled:
-        assert torch.equal(outp, ref[1])
+        assert torch.equal(back(outp), ref[1])
+
+
+@pytest.mark.parametrize("C0,C1,Cout,B,H,W,full,pooled", [
+    (32, 0, 64, 2, 32, 64, True, True), (64, 0, 64, 1, 48, 96, False, True), (64, 128, 64, 2, 16, 32, True, False),
+    (48, 0, 128, 1, 37, 45, True, False), (128, 256, 128, 1, 18, 34, True, False), (16, 0, 32, 2, 20, 40, True, True),
+    (32, 0, 32, 1, 24, 40, True, False)])
+def test_conv3x3_planes16_is_bitwise_nhwc(C0, C1, Cout, B, H, W, full, pooled):
+    """SA_LAYOUT_PLANES16 changes where the bytes lie, not what they are: sa_conv3x3_bf16 on 16-channel planes (sources,
+    full-resolution and pooled outputs) == the NHWC call, bit for bit -- single- and multi-chunk kernels, concatenated
+    sources, ragged tiles. The one exception is the 32 -> (<= 32) layer, which NHWC runs as ONE 32-channel chunk and planes
+    as two 16-channel chunks (another fp32 summation order): equal to within one rounding of the storage type."""
+    from sleap_amd import _lib, ops
+
+    g = torch.Generator(device="cpu").manual_seed(C0 + 3 * C1 + H)
+    k = (torch.randn((3, 3, C0 + C1, Cout), generator=g) * (2.0 / (9 * (C0 + C1))) ** 0.5).numpy()
+    pw = ops.pack_conv3x3_weights(k, C0, C1)
+    bias = (0.1 * torch.randn((Cout,), generator=g)).cuda()
+    x0 = ops.to_bf16_padded(torch.randn((B, H, W, C0), generator=g).cuda())
+    x1 = ops.to_bf16_padded(torch.randn((B, H, W, C1), generator=g).cuda()) if C1 else None
+    mode = 1 if C1 else 0
+    a = ops.conv3x3(x0, x1, mode, pw, bias, Cout, True, (H, W), full=full, pooled=pooled)
+    b = ops.conv3x3(ops.to_planes16(x0), ops.to_planes16(x1) if C1 else None, mode | _lib.LAYOUT_PLANES16, pw, bias, Cout, True,
+                    (H, W), full=full, pooled=pooled)
+    a = a if isinstance(a, tuple) else (a,)
+    b = b if isinstance(b, tuple) else (b,)
+    for u, v in zip(a, b):
+        if C0 + C1 == 32 and Cout <= 32:
+            assert float((u.float() - ops.from_planes16(v).float()).abs().max()) <= 2.0 ** -8 * float(u.float().abs().max())
+        else:
+            assert torch.equal(u, ops.from_planes16(v))
+
+
+@pytest.mark.parametrize("B,H,W,C", [(2, 8, 12, 16), (1, 5, 7, 48), (3, 16, 16, 128)])
+def test_upsample2x_planes16_is_bitwise_nhwc_and_matches_torch(B, H, W, C):
+    """UpSampling2D(2, bilinear) (encoder_decoder.py:335-339): the 16-channel kernel that serves plane tensors writes the same
+    bits as the NHWC kernel, and both are torch's half-pixel bilinear interpolation up to the storage rounding."""
+    from sleap_amd import _lib, ops
+    from sleap_amd._lib import check
+    from sleap_amd.ops import _ptr, _stream
+
+    g = torch.Generator(device="cpu").manual_seed(B + H + C)
+    xf = torch.randn((B, H, W, C), generator=g).cuda()
+    x = ops.to_bf16_padded(xf)
+    out = torch.empty((B, 2 * H, 2 * W, C), dtype=TD, device="cuda")
+    check(_lib.lib().sa_upsample2x_bf16(_ptr(x), B, H, W, C, 1, _ptr(out), _stream()), "sa_upsample2x_bf16")
+    outp = torch.empty_like(out)
+    check(_lib.lib().sa_upsample2x_bf16(_ptr(ops.to_planes16(x)), B * (C // 16), H, W, 16, 1, _ptr(outp), _stream()), "sa_upsample2x_bf16")
+    assert torch.equal(out, ops.from_planes16(outp))
+    ref = torch.nn.functional.interpolate(x.float().permute(0, 3, 1, 2), scale_factor=2, mode="bilinear", align_corners=False)
+    assert float((out.float() - ref.permute(0, 2, 3, 1)).abs().max()) <= 2.0 ** -7 * float(ref.abs().max())
+
+
+def test_network_layout_is_bitwise_neutral():
+    """The benchmark UNet compiled on 16-channel planes (the default for the UNet family) and forced to NHWC: identical heads;
+    a plan with an un-fused head (fuse_heads=False) or an upsample-on-load conv stays NHWC on its own."""
+    from sleap_amd.nn.engine import DeviceNetwork
+
+    cfg, w = _benchmark_unet(96, 128)
+    x = torch.from_numpy(_fly_frames(2, 96, 128, 7)).cuda()
+    a = DeviceNetwork(cfg, w)
+    b = DeviceNetwork(cfg, w, layout="nhwc")
+    assert a.planar and not b.planar
+    assert not DeviceNetwork(cfg, w, fuse_heads=False).planar and not DeviceNetwork(cfg, w, fuse_upsample=True).planar
+    with pytest.raises(NotImplementedError):
+        DeviceNetwork(cfg, w, fuse_heads=False, layout="planes16")
+    base = [o.clone() for o in a.forward(x)]
+    for p, q in zip(base, b.forward(x)):
+        assert torch.equal(p, q)
+    prof = []
+    for p, q in zip(base, a.forward(x, profile=prof)):  # the per-launch Python loop (bench.py --layers) passes the layout too
+        assert torch.equal(p, q)
 
 
 def test_pair_fusion_switch_is_bitwise_neutral():
@@ -341,9 +415,11 @@ def test_pair_fusion_switch_is_bitwise_neutral():
 
     cfg, w = _benchmark_unet(96, 128)
     x = torch.from_numpy(_fly_frames(2, 96, 128, 6)).cuda()
-    a = DeviceNetwork(cfg, w)
+    # NHWC on both sides: the fused kernel reproduces the un-fused NHWC arithmetic (the 32 -> 32 layer as ONE 32-channel chunk);
+    # on planes the un-fused layer runs as two 16-channel chunks (test_conv3x3_planes16_is_bitwise_nhwc)
+    a = DeviceNetwork(cfg, w, layout="nhwc")
     assert "pair" in [op[0] for op in a.plan]
     base = [o.clone() for o in a.forward(x)]
-    other = [o.clone() for o in DeviceNetwork(cfg, w, fuse_pairs=False).forward(x)]
+    other = [o.clone() for o in DeviceNetwork(cfg, w, fuse_pairs=False, layout="nhwc").forward(x)]
     for p, q in zip(base, other):
         assert torch.equal(p, q)

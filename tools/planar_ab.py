@@ -12,7 +12,6 @@ from sleap_amd import _lib, ops
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 DT = torch.float16
-lib = _lib.lib("fp16")
 
 # (C0, C1, Cout, H, pooled_out, full_out)
 SHAPES = [(32, 0, 64, 256, False, True), (64, 0, 64, 256, True, True), (64, 0, 128, 128, False, True),
@@ -21,22 +20,9 @@ SHAPES = [(32, 0, 64, 256, False, True), (64, 0, 64, 256, True, True), (64, 0, 1
           (256, 0, 256, 64, False, True), (128, 256, 128, 128, False, True), (64, 128, 64, 256, False, True)]
 
 
-def to_planes(x):  # [B,H,W,C] -> [B,C/16,H,W,16] (contiguous)
-    b, h, w, c = x.shape
-    return x.view(b, h, w, c // 16, 16).permute(0, 3, 1, 2, 4).contiguous()
-
-
-def from_planes(x, c):  # storage of [B,C/16,H,W,16] held in a [B,H,W,C] tensor
-    b, h, w, _ = x.shape
-    return x.view(b, c // 16, h, w, 16).permute(0, 2, 3, 1, 4).reshape(b, h, w, c)
-
-
 def run(layout, x0, x1, pw, bias, cout, H, full, pooled):
-    lib.sa_conv3x3_set_layout(layout)
-    try:
-        return ops.conv3x3(x0, x1, 1 if x1 is not None else 0, pw, bias, cout, True, (H, H), full=full, pooled=pooled)
-    finally:
-        lib.sa_conv3x3_set_layout(0)
+    mode = (1 if x1 is not None else 0) | (_lib.LAYOUT_PLANES16 if layout else 0)
+    return ops.conv3x3(x0, x1, mode, pw, bias, cout, True, (H, H), full=full, pooled=pooled)
 
 
 def timeit(fn):
@@ -62,12 +48,12 @@ for (C0, C1, Cout, H, pooled, full) in SHAPES:
     bias = torch.zeros((Cout,), device="cuda")
     x0 = torch.relu(torch.randn((B, H, H, C0), generator=g)).to(DT).cuda()
     x1 = torch.relu(torch.randn((B, H, H, C1), generator=g)).to(DT).cuda() if C1 else None
-    p0, p1 = to_planes(x0).view(B, H, H, C0), (to_planes(x1).view(B, H, H, C1) if C1 else None)
+    p0, p1 = ops.to_planes16(x0), (ops.to_planes16(x1) if C1 else None)
     a = run(0, x0, x1, pw, bias, Cout, H, full, pooled)
     b = run(1, p0, p1, pw, bias, Cout, H, full, pooled)
     a = a if isinstance(a, tuple) else (a,)
     b = b if isinstance(b, tuple) else (b,)
-    same = all(torch.equal(u, from_planes(v, Cout)) for u, v in zip(a, b))
+    same = all(torch.equal(u, ops.from_planes16(v)) for u, v in zip(a, b))
     t = []
     for _ in range(2):
         t.append(timeit(lambda: run(0, x0, x1, pw, bias, Cout, H, full, pooled)))
