@@ -36,8 +36,9 @@ sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2500.0  # dense, fp16 and bf16 alike (/opt/skills/guides/MI355X_MICROARCH.md)
 # HBM bytes of the conv kernel family per step of the DEFAULT workload (64 frames of 1024x1024), from two separate
-# rocprofv3 --pmc passes (FETCH_SIZE doubled per the gfx950 correction, WRITE_SIZE): profiles/r01_v10_pmc_hbm_traffic.md
-MEASURED_CONV_TRAFFIC_BYTES_PER_STEP = 12.66e9
+# rocprofv3 --pmc passes (FETCH_SIZE doubled per the gfx950 correction, WRITE_SIZE uncalibrated): profiles/r02_pmc_hbm_traffic.md
+# (16-channel planes; the NHWC plan of the same network moved 13.15 GB: partially used cache lines fetched more than once)
+MEASURED_CONV_TRAFFIC_BYTES_PER_STEP = 10.92e9
 
 
 def parse():
@@ -259,7 +260,7 @@ def main():
             "kernel": f"conv3x3_dma_kernel + convpair + stem16_gray_kernel (the {n_conv} MFMA conv launches of one step)", "bound": "mfma", "achieved": round(achieved, 2),
             "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
             "traffic": (MEASURED_CONV_TRAFFIC_BYTES_PER_STEP if (B == 64 and H == 1024 and W == 1024) else None),
-            "traffic_unit": "HBM bytes per step over the kernel family's launches (rocprofv3 PMC, profiles/r01_v10_pmc_hbm_traffic.md)",
+            "traffic_unit": "HBM bytes per step over the kernel family's launches (rocprofv3 PMC, profiles/r02_pmc_hbm_traffic.md)",
             "launches_per_step": n_conv, "avg_launch_ms": round(conv_ms / n_conv, 4),
             "algorithmic_gflop_per_frame": round(conv_fl / B / 1e9, 2),
             "network_ms_per_step": round(all_ms, 3), "postproc_ms_per_step": round(post_ms, 3),

@@ -726,7 +726,7 @@ conv3x3_dma_kernel(const ConvParams2 p) {
         store_pieces(p.dst + (size_t)b * H * W * p.CoutP, (size_t)(ok ? gy : 0) * W + (ok ? gx : 0), (size_t)H * W, ok, pk);
       }
     }
-    if (p.dst_pool) {
+    if constexpr (R >= 2) if (p.dst_pool) {
 #pragma unroll
       for (int r = 0; r < R; r += 2) {
         const int gy = y0 + wave * R + r;
@@ -1051,6 +1051,8 @@ static int conv3x3_impl(const void* src0, int C0P, const void* src1, int C1P, in
       // heads need every output channel in one workgroup: 4 cout tiles (<= 128 channels), CK = 16 keeps two LDS
       // stages within 160 KiB
       SA_REQUIRE(co32_n <= 4, "sa_conv3x3_heads_bf16: fused heads support at most 128 output channels");
+      // (16 waves x 1 row on the same tile -- four waves per SIMD in the one workgroup a CU holds -- measured 8 % slower:
+      // 0.327 -> 0.353 ms, profiles/r02_ab_session.md)
       return launch2<4, 16, 8, 2, 2, true>(q, st);
     }
     // Experiment switch (tools/ab runs): SA_CONV_MT4=n sends plain multi-chunk layers with >= n output channels (a multiple

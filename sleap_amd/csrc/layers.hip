@@ -296,27 +296,28 @@ upsample2x_bilinear_block_kernel(const uint16_t* __restrict__ src, int B, int H,
 // row, OUTPUT column and 8-channel group. With 32 bytes per pixel the block kernel above makes every store instruction write
 // 16-byte pieces with gaps (output columns 2j and 2j+1 come from different instructions): measured 0.371 ms where the NHWC
 // tensor of the same size took 0.257. Here consecutive lanes write consecutive 16 bytes -- one instruction = 1 KiB of one output
-// row -- at the price of 6 (mostly L1-hit) loads per thread instead of 9 per two; same operation order, same bits.
+// row; a thread walks K source rows (K + 2 row loads of two columns for 2 K output rows); same operation order, same bits.
+template <int K>  // source rows per thread (2 K output rows)
 __global__ void __launch_bounds__(256)
 upsample2x_bilinear_c16_kernel(const uint16_t* __restrict__ src, int B, int H, int W, uint16_t* __restrict__ dst) {
-  const int Wo = 2 * W;
-  const size_t total = (size_t)B * H * Wo * 2;
+  const int Wo = 2 * W, HB = (H + K - 1) / K;
+  const size_t total = (size_t)B * HB * Wo * 2;
   for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
     const int g = (int)(t & 1);
     const size_t q = t >> 1;
     const int x = (int)(q % Wo);
-    const int i = (int)((q / Wo) % H);
-    const size_t b = q / ((size_t)Wo * H);
+    const int i0 = (int)((q / Wo) % HB) * K;
+    const size_t b = q / ((size_t)Wo * HB);
     const int j = x >> 1, odd = x & 1;
     // output column 2j: taps (j-1, j), weight 0.75 on j; column 2j+1: taps (j, j+1), weight 0.25 on j+1 (edge clamped)
     const int xa = odd ? j : max(j - 1, 0), xb = odd ? min(j + 1, W - 1) : j;
     const float wx = odd ? 0.25f : 0.75f;
-    const int ys[3] = {max(i - 1, 0), i, min(i + 1, H - 1)};
     const uint16_t* base = src + b * H * W * (size_t)16 + g * 8;
-    float hz[3][8];
+    float hz[K + 2][8];  // horizontally interpolated source rows i0-1 .. i0+K (clamped)
 #pragma unroll
-    for (int r = 0; r < 3; ++r) {
-      const uint16_t* row = base + (size_t)ys[r] * W * 16;
+    for (int r = 0; r < K + 2; ++r) {
+      const int y = min(max(i0 + r - 1, 0), H - 1);
+      const uint16_t* row = base + (size_t)y * W * 16;
       const h16x8_t va = *reinterpret_cast<const h16x8_t*>(row + (size_t)xa * 16);
       const h16x8_t vb = *reinterpret_cast<const h16x8_t*>(row + (size_t)xb * 16);
 #pragma unroll
@@ -325,15 +326,19 @@ upsample2x_bilinear_c16_kernel(const uint16_t* __restrict__ src, int B, int H, i
         hz[r][c] = m + (z - m) * wx;
       }
     }
-    h16x8_t o0, o1;
+    uint16_t* o = dst + (((b * 2 * H + 2 * i0) * Wo) + x) * (size_t)16 + g * 8;
 #pragma unroll
-    for (int c = 0; c < 8; ++c) {
-      o0[c] = sa::f2h(hz[0][c] + (hz[1][c] - hz[0][c]) * 0.75f);  // row 2i
-      o1[c] = sa::f2h(hz[1][c] + (hz[2][c] - hz[1][c]) * 0.25f);  // row 2i+1
+    for (int k = 0; k < K; ++k) {
+      if (i0 + k >= H) break;
+      h16x8_t o0, o1;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        o0[c] = sa::f2h(hz[k][c] + (hz[k + 1][c] - hz[k][c]) * 0.75f);      // output row 2 (i0 + k)
+        o1[c] = sa::f2h(hz[k + 1][c] + (hz[k + 2][c] - hz[k + 1][c]) * 0.25f);  // output row 2 (i0 + k) + 1
+      }
+      *reinterpret_cast<h16x8_t*>(o + (size_t)(2 * k) * Wo * 16) = o0;
+      *reinterpret_cast<h16x8_t*>(o + (size_t)(2 * k + 1) * Wo * 16) = o1;
     }
-    uint16_t* o = dst + (((b * 2 * H + 2 * i) * Wo) + x) * (size_t)16 + g * 8;
-    *reinterpret_cast<h16x8_t*>(o) = o0;
-    *reinterpret_cast<h16x8_t*>(o + (size_t)Wo * 16) = o1;
   }
 }
 
@@ -611,8 +616,11 @@ int sa_upsample2x_bf16(const void* src, int B, int H, int W, int CP, int bilinea
                        sa_stream_t stream) {
   SA_REQUIRE(CP % 8 == 0, "sa_upsample2x_bf16: CP%%8 != 0");
   if (bilinear && CP == 16) {
-    const size_t total = (size_t)B * H * W * 4;
-    hipLaunchKernelGGL(upsample2x_bilinear_c16_kernel, dim3(grid_for(total, 256, 1 << 20)), dim3(256), 0, (hipStream_t)stream,
+    // two source rows per thread: 0.494 ms (one row) -> 0.404 (two) / 0.43 (four) over the three upsamplings of a benchmark step
+    // (64 frames, profiles/r02_ab_session.md); the NHWC block kernel below needs 0.465 for the same tensors
+    constexpr int K = 2;
+    const size_t total = (size_t)B * ((H + K - 1) / K) * W * 4;
+    hipLaunchKernelGGL(upsample2x_bilinear_c16_kernel<K>, dim3(grid_for(total, 256, 1 << 20)), dim3(256), 0, (hipStream_t)stream,
                        (const uint16_t*)src, B, H, W, (uint16_t*)dst);
   } else if (bilinear) {
     const size_t total = (size_t)B * H * W * (CP / 8);
