@@ -284,6 +284,7 @@ def main():
                        "parallelism": f"frame-sharded dp{world}, one all-gather of packed results per step",
                        "n_ranks_seen": (dist.get_world_size() if use_dist else 1),
                        "collective_backend": (dist.get_backend() + " (RCCL)" if use_dist else None),
+                       "activation_layout": "planes16" if net.planar else "nhwc",
                        "peak_threshold": 0.2, "refinement": "integral", "mean_peaks_per_frame": round(mean_peaks, 1),
                        "mean_instances_per_frame": round(mean_instances, 2), "status_bits": status_bits},
             "roofline": roofline,

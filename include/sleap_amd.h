@@ -446,6 +446,25 @@ int sa_tracker_track_frames(void* tracker, int n_frames, int max_inst, int n_nod
 /* connect_single_track_breaks (components.py:419-466) in place on a [F, I] track table (-1 = empty slot). */
 int sa_connect_single_track_breaks(int n_frames, int max_inst, const int* order, int* track, int instance_count);
 
+/* ------------------------------------------------------------------------------------------------
+ * Sparse pyramidal Lucas-Kanade optical flow on the device: replaces the cv2.calcOpticalFlowPyrLK call of
+ * FlowCandidateMaker.flow_shift_instances (sleap/nn/tracking.py:258-356; winSize (w, w), maxLevel L, criteria (EPS | COUNT,
+ * 30, 0.01), default flags / minEigThreshold 1e-4). OpenCV's integer conventions are kept (csrc/flow.hip, oracle/optical_flow.py).
+ *   pyramid  one frame's levels (uint8) and Scharr derivatives (int16 x 2) in ONE caller-owned device buffer of
+ *            sa_flow_pyramid_bytes(H, W, win, max_level) bytes; sa_flow_pyramid_levels = how many levels exist (an image must
+ *            stay larger than the window). image: DEVICE [H,W,C] uint8, C = 1, or 3 (gray by cv2's COLOR_BGR2GRAY weights applied
+ *            to the given channel order, as the reference does to its RGB frames). win in 3..31.
+ *   lk       n points: prev_pts [n,2] (x, y; DEVICE) in the frame whose pyramid is pyr_prev[i] (DEVICE array of n device
+ *            pointers -- points of several reference frames can share one launch) -> next_pts [n,2] in the frame of pyr_next,
+ *            status [n] (1 = found), err [n] (mean |J - I| / 32 over the window; 0 where the point left the image). NaN points
+ *            report status 0. All pyramids of one call must come from frames of the same (H, W, win, max_level). */
+int sa_flow_pyramid_levels(int H, int W, int win, int max_level);
+size_t sa_flow_pyramid_bytes(int H, int W, int win, int max_level);
+int sa_flow_pyramid_build(const void* image, int H, int W, int C, int win, int max_level, void* pyramid, sa_stream_t stream);
+int sa_flow_lk(const void* const* pyr_prev, const void* pyr_next, int H, int W, int win, int max_level, int n,
+               const float* prev_pts, float* next_pts, uint8_t* status, float* err, int max_count, float epsilon,
+               sa_stream_t stream);
+
 /* Top-down glue on the device (CentroidCrop / FindInstancePeaks, inference.py:1747-1966, 2059-2200): the number of crops per
  * frame is data dependent in the reference (ragged); here every frame has K crop slots, so nothing between the centroid
  * network and the instance network needs the host.

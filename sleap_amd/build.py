@@ -28,6 +28,8 @@ SOURCES = [
     ("tapconv.hip", ["-fno-honor-nans"]),
     ("convpair.hip", ["-fno-honor-nans"]),
     ("imgconv.hip", ["-fno-honor-nans", "-std=c++20", "-mllvm", "-amdgpu-mfma-vgpr-form"]),
+    # sparse pyramidal Lucas-Kanade flow of the flow tracker: float32 op by op as the scalar CPU code it restates
+    ("flow.hip", ["-ffp-contract=off"]),
     ("tracker.hip", []),
     ("network.hip", []),
 ]

@@ -1,0 +1,368 @@
+// Sparse pyramidal Lucas-Kanade optical flow on the device -- the engine of SLEAP's flow tracker:
+//   FlowCandidateMaker.flow_shift_instances (sleap/nn/tracking.py:258-356) calls
+//   cv2.calcOpticalFlowPyrLK(ref_img, new_img, pts, None, winSize=(w, w), maxLevel=L, criteria=(EPS | COUNT, 30, 0.01)).
+// OpenCV is a third-party dependency of the reference (pypi_requirements.txt:16) and is absent here; what is implemented is the
+// published algorithm (Bouguet 2000) with OpenCV 4.x's integer conventions, as restated in oracle/optical_flow.py, which is
+// the checker for this file (tests/test_gpu_flow.py):
+//   pyramid   level 0 = the uint8 frame (3 channels -> gray by OpenCV's fixed-point BGR2GRAY weights), level l+1 = pyrDown
+//             ([1 4 6 4 1]^2 / 256, integer, BORDER_REFLECT_101), levels end before an image <= the window;
+//   Scharr    Ix = [3 10 3]^T (x) [-1 0 1], Iy = [-1 0 1]^T (x) [3 10 3], int16, reflect-101 inside, ZERO outside a level;
+//   tracker   per point, coarse to fine: 14-bit integer bilinear patches of I, Ix, Iy (window w x w), 2x2 system in float32,
+//             <= 30 Newton steps, OpenCV's stopping rules, status / error outputs.
+// One WAVEFRONT per point: the w*w window pixels are spread over the 64 lanes (7 per lane for w = 21), the I / Ix / Iy patch of
+// the level lives in LDS (int16), every sum over the window is a butterfly reduction (all lanes end with the same bits, so the
+// data-dependent control flow stays wave uniform). Points are independent; a frame pair of the tracker is a few hundred of them.
+// Differences to a CPU OpenCV: the order of the float32 window sums (OpenCV's own SIMD and scalar builds differ in that too).
+#include <cstdint>
+#include <cstdlib>
+#include <vector>
+
+#include "sa_common.h"
+
+namespace {
+
+constexpr int MAX_LEVELS = 8;
+constexpr int MAX_WIN = 31;
+
+struct Level {
+  int h, w;
+  size_t img_off, deriv_off;  // bytes from the pyramid base: uint8 [h][w]; int16 [h][w][2]
+};
+
+struct PyrLayout {
+  int n_levels;
+  Level lv[MAX_LEVELS];
+  size_t bytes;
+};
+
+size_t align256(size_t v) { return (v + 255) & ~size_t(255); }
+
+PyrLayout pyr_layout(int H, int W, int win, int max_level) {
+  PyrLayout p;
+  p.n_levels = 0;
+  size_t off = 0;
+  int h = H, w = W;
+  for (int l = 0; l <= max_level && l < MAX_LEVELS; ++l) {
+    if (l > 0) {
+      h = (h + 1) / 2;
+      w = (w + 1) / 2;
+      if (w <= win || h <= win) break;
+    }
+    Level& L = p.lv[p.n_levels++];
+    L.h = h;
+    L.w = w;
+    L.img_off = off;
+    off += align256((size_t)h * w);
+    L.deriv_off = off;
+    off += align256((size_t)h * w * 4);
+  }
+  p.bytes = off;
+  return p;
+}
+
+__device__ __forceinline__ int reflect101(int i, int n) {
+  if (n == 1) return 0;
+  const int p = 2 * (n - 1);
+  i %= p;
+  if (i < 0) i += p;
+  return i >= n ? p - i : i;
+}
+
+__global__ void __launch_bounds__(256)
+flow_gray_kernel(const uint8_t* __restrict__ src, int n_pix, int C, uint8_t* __restrict__ dst) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_pix; i += gridDim.x * blockDim.x) {
+    if (C == 1) {
+      dst[i] = src[i];
+    } else {  // cv2.COLOR_BGR2GRAY on the caller's channel order: (c0 * 1868 + c1 * 9617 + c2 * 4899 + 8192) >> 14
+      const uint8_t* s = src + (size_t)i * 3;
+      dst[i] = (uint8_t)((s[0] * 1868 + s[1] * 9617 + s[2] * 4899 + 8192) >> 14);
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256)
+flow_pyrdown_kernel(const uint8_t* __restrict__ src, int h, int w, uint8_t* __restrict__ dst, int oh, int ow) {
+  const int n = oh * ow;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const int oy = i / ow, ox = i - oy * ow;
+    const int k[5] = {1, 4, 6, 4, 1};
+    int acc = 0;
+#pragma unroll
+    for (int dy = 0; dy < 5; ++dy) {
+      const uint8_t* row = src + (size_t)reflect101(2 * oy + dy - 2, h) * w;
+      int r = 0;
+#pragma unroll
+      for (int dx = 0; dx < 5; ++dx) r += k[dx] * row[reflect101(2 * ox + dx - 2, w)];
+      acc += k[dy] * r;
+    }
+    dst[i] = (uint8_t)((acc + 128) >> 8);
+  }
+}
+
+__global__ void __launch_bounds__(256)
+flow_scharr_kernel(const uint8_t* __restrict__ src, int h, int w, int16_t* __restrict__ dst) {
+  const int n = h * w;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const int y = i / w, x = i - y * w;
+    const uint8_t* r0 = src + (size_t)reflect101(y - 1, h) * w;
+    const uint8_t* r1 = src + (size_t)y * w;
+    const uint8_t* r2 = src + (size_t)reflect101(y + 1, h) * w;
+    const int xl = reflect101(x - 1, w), xr = reflect101(x + 1, w);
+    // vertical smoothing / difference at columns x-1, x, x+1
+    const int t0l = (r0[xl] + r2[xl]) * 3 + r1[xl] * 10, t0r = (r0[xr] + r2[xr]) * 3 + r1[xr] * 10;
+    const int t1l = r2[xl] - r0[xl], t1c = r2[x] - r0[x], t1r = r2[xr] - r0[xr];
+    dst[2 * (size_t)i] = (int16_t)(t0r - t0l);
+    dst[2 * (size_t)i + 1] = (int16_t)((t1r + t1l) * 3 + t1c * 10);
+  }
+}
+
+struct LkParams {
+  const uint8_t* const* pyr_prev;  // [n] device pointers: the reference frame's pyramid of every point
+  const uint8_t* pyr_next;         // the current frame's pyramid
+  PyrLayout lay;
+  int win, n, max_count;
+  float eps2;
+  const float* prev_pts;  // [n][2]
+  float* next_pts;        // [n][2]
+  uint8_t* status;        // [n]
+  float* err;             // [n]
+};
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int s = 32; s >= 1; s >>= 1) v += __shfl_xor(v, s);
+  return v;
+}
+
+__device__ __forceinline__ int cv_floor(float v) {
+  // cvFloor of a non-finite value is INT_MIN on the reference's platform (cvtsd2si): such points are "outside the image"
+  if (!(v == v) || v > 2.0e9f || v < -2.0e9f) return INT32_MIN;
+  return (int)floorf(v);
+}
+
+__device__ __forceinline__ void lk_weights(float a, float b, int& w00, int& w01, int& w10, int& w11) {
+  const float s = 16384.0f;  // 1 << W_BITS
+  w00 = (int)rintf((1.0f - a) * (1.0f - b) * s);
+  w01 = (int)rintf(a * (1.0f - b) * s);
+  w10 = (int)rintf((1.0f - a) * b * s);
+  w11 = 16384 - w00 - w01 - w10;
+}
+
+// one wave per point; blockDim = 256 (4 points)
+__global__ void __launch_bounds__(256)
+flow_lk_kernel(const LkParams p) {
+  extern __shared__ __attribute__((aligned(16))) int16_t lds[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int k = blockIdx.x * 4 + wave;
+  if (k >= p.n) return;  // wave uniform
+  const int win = p.win, area = win * win;
+  int16_t* ipatch = lds + (size_t)wave * 3 * area;
+  int16_t* ixp = ipatch + area;
+  int16_t* iyp = ixp + area;
+  const uint8_t* base_i = p.pyr_prev[k];
+  const uint8_t* base_j = p.pyr_next;
+  const float half = (float)(win - 1) * 0.5f;
+  const float px = p.prev_pts[2 * k], py = p.prev_pts[2 * k + 1];
+  float nx = 0.0f, ny = 0.0f;  // nextPts[k]
+  int st = 1;
+  float er = 0.0f;
+  const int top = p.lay.n_levels - 1;
+  for (int level = top; level >= 0; --level) {
+    const Level L = p.lay.lv[level];
+    const uint8_t* I = base_i + L.img_off;
+    const int16_t* D = reinterpret_cast<const int16_t*>(base_i + L.deriv_off);
+    const uint8_t* J = base_j + L.img_off;
+    const int h = L.h, w = L.w;
+    const float sc = 1.0f / (float)(1 << level);
+    float prx = px * sc, pry = py * sc;
+    float qx, qy;
+    if (level == top) {
+      qx = prx;
+      qy = pry;
+    } else {
+      qx = nx * 2.0f;
+      qy = ny * 2.0f;
+    }
+    nx = qx;
+    ny = qy;
+    prx -= half;
+    pry -= half;
+    const int ipx = cv_floor(prx), ipy = cv_floor(pry);
+    if (ipx < -win || ipx >= w || ipy < -win || ipy >= h) {
+      if (level == 0) {
+        st = 0;
+        er = 0.0f;
+      }
+      continue;
+    }
+    int w00, w01, w10, w11;
+    lk_weights(prx - (float)ipx, pry - (float)ipy, w00, w01, w10, w11);
+    float a11 = 0.0f, a12 = 0.0f, a22 = 0.0f;
+    for (int i = lane; i < area; i += 64) {
+      const int wy = i / win, wx = i - wy * win;
+      const int y0 = ipy + wy, x0 = ipx + wx;
+      const int ya = reflect101(y0, h), yb = reflect101(y0 + 1, h), xa = reflect101(x0, w), xb = reflect101(x0 + 1, w);
+      const int iv = (I[(size_t)ya * w + xa] * w00 + I[(size_t)ya * w + xb] * w01 + I[(size_t)yb * w + xa] * w10 +
+                      I[(size_t)yb * w + xb] * w11 + (1 << 8)) >> 9;  // CV_DESCALE(., W_BITS - 5)
+      // derivatives are zero outside the level (BORDER_CONSTANT)
+      const bool oa = (unsigned)y0 < (unsigned)h, ob = (unsigned)(y0 + 1) < (unsigned)h;
+      const bool pa = (unsigned)x0 < (unsigned)w, pb = (unsigned)(x0 + 1) < (unsigned)w;
+      int dx00 = 0, dy00 = 0, dx01 = 0, dy01 = 0, dx10 = 0, dy10 = 0, dx11 = 0, dy11 = 0;
+      if (oa && pa) { const int16_t* q = D + 2 * ((size_t)y0 * w + x0); dx00 = q[0]; dy00 = q[1]; }
+      if (oa && pb) { const int16_t* q = D + 2 * ((size_t)y0 * w + x0 + 1); dx01 = q[0]; dy01 = q[1]; }
+      if (ob && pa) { const int16_t* q = D + 2 * ((size_t)(y0 + 1) * w + x0); dx10 = q[0]; dy10 = q[1]; }
+      if (ob && pb) { const int16_t* q = D + 2 * ((size_t)(y0 + 1) * w + x0 + 1); dx11 = q[0]; dy11 = q[1]; }
+      const int ixv = (dx00 * w00 + dx01 * w01 + dx10 * w10 + dx11 * w11 + (1 << 13)) >> 14;
+      const int iyv = (dy00 * w00 + dy01 * w01 + dy10 * w10 + dy11 * w11 + (1 << 13)) >> 14;
+      ipatch[i] = (int16_t)iv;
+      ixp[i] = (int16_t)ixv;
+      iyp[i] = (int16_t)iyv;
+      a11 += (float)(ixv * ixv);
+      a12 += (float)(ixv * iyv);
+      a22 += (float)(iyv * iyv);
+    }
+    const float FLT_SCALE = 1.0f / (float)(1 << 20);
+    a11 = wave_sum(a11) * FLT_SCALE;
+    a12 = wave_sum(a12) * FLT_SCALE;
+    a22 = wave_sum(a22) * FLT_SCALE;
+    float det = a11 * a22 - a12 * a12;
+    const float min_eig = (a22 + a11 - sqrtf((a11 - a22) * (a11 - a22) + 4.0f * a12 * a12)) / (float)(2 * win * win);
+    if (min_eig < 1e-4f || det < 1.1920929e-07f) {
+      if (level == 0) st = 0;
+      continue;
+    }
+    det = 1.0f / det;
+    qx -= half;
+    qy -= half;
+    float pdx = 0.0f, pdy = 0.0f;
+    for (int j = 0; j < p.max_count; ++j) {
+      const int inx = cv_floor(qx), iny = cv_floor(qy);
+      if (inx < -win || inx >= w || iny < -win || iny >= h) {
+        if (level == 0) st = 0;
+        break;
+      }
+      lk_weights(qx - (float)inx, qy - (float)iny, w00, w01, w10, w11);
+      float b1 = 0.0f, b2 = 0.0f;
+      for (int i = lane; i < area; i += 64) {
+        const int wy = i / win, wx = i - wy * win;
+        const int ya = reflect101(iny + wy, h), yb = reflect101(iny + wy + 1, h);
+        const int xa = reflect101(inx + wx, w), xb = reflect101(inx + wx + 1, w);
+        const int jv = (J[(size_t)ya * w + xa] * w00 + J[(size_t)ya * w + xb] * w01 + J[(size_t)yb * w + xa] * w10 +
+                        J[(size_t)yb * w + xb] * w11 + (1 << 8)) >> 9;
+        const int diff = jv - ipatch[i];
+        b1 += (float)(diff * ixp[i]);
+        b2 += (float)(diff * iyp[i]);
+      }
+      b1 = wave_sum(b1) * FLT_SCALE;
+      b2 = wave_sum(b2) * FLT_SCALE;
+      const float dx = (a12 * b2 - a22 * b1) * det, dy = (a12 * b1 - a11 * b2) * det;
+      qx += dx;
+      qy += dy;
+      nx = qx + half;
+      ny = qy + half;
+      if (dx * dx + dy * dy <= p.eps2) break;
+      if (j > 0 && fabsf(dx + pdx) < 0.01f && fabsf(dy + pdy) < 0.01f) {
+        nx -= dx * 0.5f;
+        ny -= dy * 0.5f;
+        break;
+      }
+      pdx = dx;
+      pdy = dy;
+    }
+    if (st && level == 0) {
+      const float ex = nx - half, ey = ny - half;
+      const int inx = cv_floor(ex), iny = cv_floor(ey);
+      if (inx < -win || inx >= w || iny < -win || iny >= h) {
+        st = 0;
+        continue;
+      }
+      lk_weights(ex - (float)inx, ey - (float)iny, w00, w01, w10, w11);
+      float e = 0.0f;
+      for (int i = lane; i < area; i += 64) {
+        const int wy = i / win, wx = i - wy * win;
+        const int ya = reflect101(iny + wy, h), yb = reflect101(iny + wy + 1, h);
+        const int xa = reflect101(inx + wx, w), xb = reflect101(inx + wx + 1, w);
+        const int jv = (J[(size_t)ya * w + xa] * w00 + J[(size_t)ya * w + xb] * w01 + J[(size_t)yb * w + xa] * w10 +
+                        J[(size_t)yb * w + xb] * w11 + (1 << 8)) >> 9;
+        e += fabsf((float)(jv - ipatch[i]));
+      }
+      er = wave_sum(e) * (1.0f / (float)(32 * win * win));
+    }
+  }
+  if (lane == 0) {
+    p.next_pts[2 * k] = nx;
+    p.next_pts[2 * k + 1] = ny;
+    p.status[k] = (uint8_t)st;
+    p.err[k] = er;
+  }
+}
+
+int grid_for(size_t total, int cap = 4096) {
+  size_t g = (total + 255) / 256;
+  if (g > (size_t)cap) g = cap;
+  return g < 1 ? 1 : (int)g;
+}
+
+}  // namespace
+
+extern "C" {
+
+int sa_flow_pyramid_levels(int H, int W, int win, int max_level) {
+  if (H <= 0 || W <= 0 || win < 3 || max_level < 0) return 0;
+  return pyr_layout(H, W, win, max_level).n_levels;
+}
+
+size_t sa_flow_pyramid_bytes(int H, int W, int win, int max_level) {
+  if (H <= 0 || W <= 0 || win < 3 || max_level < 0) return 0;
+  return pyr_layout(H, W, win, max_level).bytes;
+}
+
+int sa_flow_pyramid_build(const void* image, int H, int W, int C, int win, int max_level, void* pyramid, sa_stream_t stream) {
+  SA_REQUIRE(image && pyramid, "sa_flow_pyramid_build: NULL pointer");
+  SA_REQUIRE(H > 0 && W > 0 && (C == 1 || C == 3), "sa_flow_pyramid_build: frames are [H,W,1] or [H,W,3] uint8");
+  SA_REQUIRE(win >= 3 && win <= MAX_WIN && max_level >= 0, "sa_flow_pyramid_build: window must be in 3..%d", MAX_WIN);
+  const PyrLayout lay = pyr_layout(H, W, win, max_level);
+  uint8_t* base = static_cast<uint8_t*>(pyramid);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(flow_gray_kernel, dim3(grid_for((size_t)H * W)), dim3(256), 0, st, (const uint8_t*)image, H * W, C,
+                     base + lay.lv[0].img_off);
+  for (int l = 0; l < lay.n_levels; ++l) {
+    const Level& L = lay.lv[l];
+    if (l > 0) {
+      const Level& P = lay.lv[l - 1];
+      hipLaunchKernelGGL(flow_pyrdown_kernel, dim3(grid_for((size_t)L.h * L.w)), dim3(256), 0, st, base + P.img_off, P.h, P.w,
+                         base + L.img_off, L.h, L.w);
+    }
+    hipLaunchKernelGGL(flow_scharr_kernel, dim3(grid_for((size_t)L.h * L.w)), dim3(256), 0, st, base + L.img_off, L.h, L.w,
+                       reinterpret_cast<int16_t*>(base + L.deriv_off));
+  }
+  SA_LAUNCH_CHECK();
+  return SA_OK;
+}
+
+int sa_flow_lk(const void* const* pyr_prev, const void* pyr_next, int H, int W, int win, int max_level, int n,
+               const float* prev_pts, float* next_pts, uint8_t* status, float* err, int max_count, float epsilon,
+               sa_stream_t stream) {
+  if (n == 0) return SA_OK;
+  SA_REQUIRE(pyr_prev && pyr_next && prev_pts && next_pts && status && err, "sa_flow_lk: NULL pointer");
+  SA_REQUIRE(n > 0 && H > 0 && W > 0 && win >= 3 && win <= MAX_WIN && max_level >= 0, "sa_flow_lk: bad arguments");
+  LkParams p;
+  p.pyr_prev = reinterpret_cast<const uint8_t* const*>(pyr_prev);
+  p.pyr_next = static_cast<const uint8_t*>(pyr_next);
+  p.lay = pyr_layout(H, W, win, max_level);
+  p.win = win;
+  p.n = n;
+  p.max_count = max_count < 0 ? 0 : (max_count > 100 ? 100 : max_count);  // TermCriteria clamps, lkpyramid.cpp
+  const float e = epsilon < 0.0f ? 0.0f : (epsilon > 10.0f ? 10.0f : epsilon);
+  p.eps2 = e * e;
+  p.prev_pts = prev_pts;
+  p.next_pts = next_pts;
+  p.status = status;
+  p.err = err;
+  const size_t lds = (size_t)4 * 3 * win * win * sizeof(int16_t);
+  hipLaunchKernelGGL(flow_lk_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), lds, (hipStream_t)stream, p);
+  SA_LAUNCH_CHECK();
+  return SA_OK;
+}
+
+}  // extern "C"

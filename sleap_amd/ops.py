@@ -304,3 +304,45 @@ def conv3x3(src0, src1, mode, packed_w, bias_padded, coutp, relu, out_hw, full=T
     if full and pooled:
         return out, outp
     return outp if pooled else out
+
+
+# --------------------------------------------------------------------------------------------------
+# sparse pyramidal Lucas-Kanade optical flow (the flow tracker's cv2.calcOpticalFlowPyrLK; csrc/flow.hip)
+# --------------------------------------------------------------------------------------------------
+class FlowPyramid:
+    """One frame's image pyramid + Scharr derivatives on the device (sa_flow_pyramid_build). `image`: (H, W), (H, W, 1) or
+    (H, W, 3) uint8, numpy or CUDA tensor."""
+
+    def __init__(self, image, win: int = 21, max_level: int = 3):
+        if not torch.is_tensor(image):
+            image = torch.from_numpy(np.ascontiguousarray(image))
+        if image.dtype != torch.uint8:
+            raise TypeError("FlowPyramid: uint8 frames only")
+        if image.dim() == 2:
+            image = image[..., None]
+        image = image.contiguous().to(_dev())
+        self.H, self.W, self.C = (int(v) for v in image.shape)
+        self.win, self.max_level = int(win), int(max_level)
+        h = _lib.lib()
+        self.n_levels = h.sa_flow_pyramid_levels(self.H, self.W, self.win, self.max_level)
+        self.buf = torch.empty((max(h.sa_flow_pyramid_bytes(self.H, self.W, self.win, self.max_level), 256),), dtype=torch.uint8,
+                               device=image.device)
+        check(h.sa_flow_pyramid_build(_ptr(image), self.H, self.W, self.C, self.win, self.max_level, _ptr(self.buf), _stream()),
+              "sa_flow_pyramid_build")
+
+
+def optical_flow_pyr_lk(prev: "FlowPyramid", nxt: "FlowPyramid", points, max_count: int = 30, epsilon: float = 0.01):
+    """cv2.calcOpticalFlowPyrLK(prev, next, points) with the window / level count of the pyramids -> (next_points (n, 2) f32,
+    status (n,) uint8, err (n,) f32) as CUDA tensors. `prev` may also be a list of pyramids, one per point."""
+    pts = torch.as_tensor(np.asarray(points, np.float32) if not torch.is_tensor(points) else points, dtype=torch.float32,
+                          device=nxt.buf.device).reshape(-1, 2).contiguous()
+    n = pts.shape[0]
+    prevs = prev if isinstance(prev, (list, tuple)) else [prev] * n
+    assert len(prevs) == n and all((q.H, q.W, q.win, q.max_level) == (nxt.H, nxt.W, nxt.win, nxt.max_level) for q in prevs)
+    ptrs = torch.tensor([q.buf.data_ptr() for q in prevs], dtype=torch.int64, device=pts.device)
+    out = torch.empty_like(pts)
+    status = torch.empty((n,), dtype=torch.uint8, device=pts.device)
+    err = torch.empty((n,), dtype=torch.float32, device=pts.device)
+    check(_lib.lib().sa_flow_lk(_ptr(ptrs), _ptr(nxt.buf), nxt.H, nxt.W, nxt.win, nxt.max_level, n, _ptr(pts), _ptr(out),
+                                _ptr(status), _ptr(err), int(max_count), float(epsilon), _stream()), "sa_flow_lk")
+    return out, status, err
