@@ -397,7 +397,9 @@ int sa_bf16_to_f32(const void* src, int n_pix, int CP, int C, float* dst, sa_str
  * Cross-frame identity tracking (host code). Replaces sleap.nn.tracking.Tracker with the
  * `simple` / `simplemaxtracks` candidate makers (tracking.py:442-507, 542-841) and sleap/nn/tracker/components.py
  * (similarities :33-196, greedy / Hungarian matching :199-226, pre-cull :229-417, FrameMatches :469-640,
- * connect_single_track_breaks :419-466). Optical-flow candidates (cv2) and the Kalman tracker (pykalman) are not covered.
+ * connect_single_track_breaks :419-466), and with the `flow` / `flowmaxtracks` candidate makers (tracking.py:108-440, 1194-1240:
+ * queued instances shifted into the current frame by sparse pyramidal Lucas-Kanade flow -- the sa_flow_* kernels; img_scale = 1
+ * and save_shifted_instances = False only). The Kalman tracker (pykalman) is not covered.
  * Tracks are integers: the index into the tracker's list of spawned tracks (reference name "track_<index>").
  * ------------------------------------------------------------------------------------------------ */
 enum { SA_SIM_INSTANCE = 0, SA_SIM_CENTROID = 1, SA_SIM_IOU = 2, SA_SIM_NORMALIZED_INSTANCE = 3, SA_SIM_OBJECT_KEYPOINT = 4 };
@@ -420,6 +422,9 @@ typedef struct sa_tracker_config {   /* Tracker.make_tracker_by_name arguments, 
   const double* oks_errors;
   int oks_score_weighting;
   int oks_normalization;             /* 0 "all", 1 "ref", 2 "union" */
+  int flow;                          /* 0 = Simple[MaxTracks]CandidateMaker, 1 = Flow[MaxTracks]CandidateMaker (tracking.py:108-440, 1194-1240) */
+  int of_window_size;                /* flow: Lucas-Kanade window (default 21; 3..31) */
+  int of_max_levels;                 /* flow: pyramid levels above the frame (default 3) */
 } sa_tracker_config;
 
 void* sa_tracker_create(const sa_tracker_config* cfg);   /* NULL on invalid configuration (sa_last_error) */
@@ -442,6 +447,17 @@ int sa_tracker_track(void* tracker, int n, int n_nodes, const float* points, con
 int sa_tracker_track_frames(void* tracker, int n_frames, int max_inst, int n_nodes, const float* points,
                             const float* point_scores, const float* inst_scores, const int* n_valid, int img_h, int img_w,
                             int t0, int* out_track, double* out_score, int* out_order);
+
+/* Flow trackers look at the frames (Tracker.uses_image, tracking.py:139-141). sa_tracker_set_image hands over the frame that
+ * the NEXT sa_tracker_track call belongs to: DEVICE [H,W,C] uint8 (C = 1 or 3); its pyramid is built on `stream` and kept by the
+ * tracker (device memory it owns) while a queued instance refers to that time step. A no-op for the simple candidate makers.
+ * sa_tracker_track_frames_images = sa_tracker_track_frames with images [F,frame_h,frame_w,C] (DEVICE; img_h / img_w stay what
+ * normalized_instance_similarity divides by) and, optionally, per-frame time steps frame_t [F] (HOST; NULL: t0 + f or inferred). */
+int sa_tracker_set_image(void* tracker, const void* image, int H, int W, int C, sa_stream_t stream);
+int sa_tracker_track_frames_images(void* tracker, int n_frames, int max_inst, int n_nodes, const float* points,
+                                   const float* point_scores, const float* inst_scores, const int* n_valid, int img_h, int img_w,
+                                   int t0, const int* frame_t, const void* images, int frame_h, int frame_w, int C,
+                                   sa_stream_t stream, int* out_track, double* out_score, int* out_order);
 
 /* connect_single_track_breaks (components.py:419-466) in place on a [F, I] track table (-1 = empty slot). */
 int sa_connect_single_track_breaks(int n_frames, int max_inst, const int* order, int* track, int instance_count);

@@ -7,14 +7,15 @@ Follows, function by function:
     sleap/nn/tracker/components.py:366-466  cull_frame_instances, connect_single_track_breaks
     sleap/nn/tracker/components.py:469-640  Match, FrameMatches
     sleap/nn/tracking.py:442-507            SimpleCandidateMaker, SimpleMaxTracksCandidateMaker
+    sleap/nn/tracking.py:108-440, 1194-1240 FlowCandidateMaker, FlowMaxTracksCandidateMaker (save_shifted_instances=False,
+                                            img_scale=1); the optical flow itself is oracle/optical_flow.py
     sleap/nn/tracking.py:542-841            Tracker.track / spawn_for_untracked_instances / final_pass
     sleap/nn/utils.py:45-76                 compute_iou
     sleap/instance.py:866-901               Instance.centroid / bounding_box / n_visible_points
 
 Instances are plain records of arrays (the reference's `PredictedInstance` is an attrs class over the same numbers;
 coordinates are float64 there: `Point` stores x and y as f8). Tracks are integers: the index into `spawned_tracks`
-(the reference names them f"track_{index}"). Out of scope: optical-flow candidate makers (cv2) and the Kalman tracker
-(pykalman). Pinned by the reference's known-answer tests in tests/test_oracle_tracking.py. One declared divergence:
+(the reference names them f"track_{index}"). Out of scope: the Kalman tracker (pykalman). Pinned by the reference's known-answer tests in tests/test_oracle_tracking.py. One declared divergence:
 `greedy_matching` sorts with a STABLE sort (the reference's `np.argsort` default is an unstable introsort, so the order of
 exactly tied costs is unspecified there -- "ties parity unpinned").
 """
@@ -298,22 +299,29 @@ MATCHERS = {"hungarian": hungarian_matching, "greedy": greedy_matching}
 
 
 class Tracker:
-    """tracking.py:542-841 with the `simple` / `simplemaxtracks` candidate makers (make_tracker_by_name, :844-992)."""
+    """tracking.py:542-841 with the `simple` / `simplemaxtracks` / `flow` / `flowmaxtracks` candidate makers
+    (make_tracker_by_name, :844-992)."""
 
     def __init__(self, tracker="simple", similarity="instance", match="greedy", track_window=5, robust=1.0,
-                 min_new_track_points=0, min_match_points=0, target_instance_count=0, pre_cull_to_target=False,
+                 min_new_track_points=0, min_match_points=0, of_window_size=21, of_max_levels=3, target_instance_count=0,
+                 pre_cull_to_target=False,
                  pre_cull_iou_threshold=None, post_connect_single_breaks=False, max_tracks=None, max_tracking=False,
                  oks_errors=None, oks_score_weighting=False, oks_normalization="all"):
         max_tracking = max_tracking if max_tracks else False
-        if max_tracking and tracker == "simple":
+        if max_tracking and tracker in ("simple", "flow"):
             tracker += "maxtracks"
-        if tracker not in ("simple", "simplemaxtracks"):
+        if tracker not in ("simple", "simplemaxtracks", "flow", "flowmaxtracks"):
             raise ValueError(f"{tracker} is not a valid tracker.")
+        self.uses_flow = tracker.startswith("flow")
+        if tracker != "flow":  # :914-919: only "flow" is configured; "flowmaxtracks" keeps the class defaults
+            of_window_size, of_max_levels = 21, 3
+        self.of_window_size, self.of_max_levels = of_window_size, of_max_levels
+        self._images = {}  # t -> frame (MatchedFrameInstance(s).img_t)
         if similarity not in SIMILARITIES:
             raise ValueError(f"{similarity} is not a valid tracker similarity function.")
         if match not in MATCHERS:
             raise ValueError(f"{match} is not a valid tracker matching function.")
-        self.has_max_tracking = tracker == "simplemaxtracks"
+        self.has_max_tracking = tracker.endswith("maxtracks")
         self.min_match_points = min_match_points
         if similarity == "object_keypoint":
             self.similarity_function = factory_object_keypoint_similarity(oks_errors, oks_score_weighting, oks_normalization)
@@ -335,6 +343,34 @@ class Tracker:
         self.spawned_tracks: List[int] = []
         self.last_matches = None
 
+    def _shift(self, ref_t, ref_instances, img):
+        """FlowCandidateMaker.get_shifted_instances -> flow_shift_instances (:180-208, 258-356)"""
+        from .optical_flow import flow_shift_points
+
+        out = []
+        for i, pts, _score in flow_shift_points([r.points for r in ref_instances], self._images[ref_t], img,
+                                                min_shifted_points=self.min_match_points, window_size=self.of_window_size,
+                                                max_levels=self.of_max_levels):
+            out.append(ref_instances[i].evolve(points=pts.astype(np.float64)))  # ShiftedInstance.from_instance: the reference's track
+        return out
+
+    def _flow_candidates(self, img):
+        out = []
+        if self.has_max_tracking:  # FlowMaxTracksCandidateMaker.get_candidates (:1194-1240)
+            tracks = []
+            for track, matched in self.track_matching_queue_dict.items():
+                if not self.max_tracking or len(tracks) < self.max_tracks:
+                    tracks.append(track)
+                    for (ref_t, _inst) in matched:
+                        refs = [inst for items in self.track_matching_queue_dict.values() for (tt, inst) in items if tt == ref_t]
+                        if refs:
+                            out.extend(self._shift(ref_t, refs, img))
+        else:  # FlowCandidateMaker.get_candidates (:210-237)
+            for (ref_t, insts) in self.track_matching_queue:
+                if len(insts) > 0:
+                    out.extend(self._shift(ref_t, insts, img))
+        return out
+
     def _candidates(self):
         out = []
         if self.has_max_tracking:
@@ -352,7 +388,7 @@ class Tracker:
                         out.append(inst)
         return out
 
-    def track(self, untracked_instances: List[Inst], img_hw=(1, 1), t: Optional[int] = None) -> List[Inst]:
+    def track(self, untracked_instances: List[Inst], img_hw=(1, 1), t: Optional[int] = None, img=None) -> List[Inst]:
         sim = self.similarity_function
         if self.normalized:
             sim = lambda a, b: normalized_instance_similarity(a, b, img_hw=img_hw)  # noqa: E731
@@ -369,7 +405,8 @@ class Tracker:
         if untracked_instances:
             if self.pre_cull:
                 self.pre_cull(untracked_instances)
-            fm = FrameMatches.from_candidate_instances(untracked_instances, self._candidates(), sim, self.matching_function,
+            cands = self._flow_candidates(img) if self.uses_flow else self._candidates()
+            fm = FrameMatches.from_candidate_instances(untracked_instances, cands, sim, self.matching_function,
                                                        self.robust_best_instance)
             self.last_matches = fm
             tracked.extend(m.instance.evolve(track=m.track, tracking_score=m.score) for m in fm.matches)
@@ -383,6 +420,11 @@ class Tracker:
                     self.track_matching_queue_dict[inst.track].append((t, inst))
         else:
             self.track_matching_queue.append((t, tracked))
+        if self.uses_flow:
+            self._images[t] = img
+            live = ({tt for items in self.track_matching_queue_dict.values() for (tt, _i) in items} if self.has_max_tracking
+                    else {tt for (tt, _l) in self.track_matching_queue})
+            self._images = {k: v for k, v in self._images.items() if k in live}
         return tracked
 
     def _spawn(self, unmatched, t):

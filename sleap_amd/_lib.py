@@ -83,6 +83,8 @@ SIGNATURES = {
     "sa_tracker_n_tracks": (_i, [_p]),
     "sa_tracker_track": (_i, [_p, _i, _i, _p, _p, _p, _i, _i, _i, _p, _p, _p, _p]),
     "sa_tracker_track_frames": (_i, [_p, _i, _i, _i, _p, _p, _p, _p, _i, _i, _i, _p, _p, _p]),
+    "sa_tracker_set_image": (_i, [_p, _p, _i, _i, _i, _p]),
+    "sa_tracker_track_frames_images": (_i, [_p, _i, _i, _i, _p, _p, _p, _p, _i, _i, _i, _p, _p, _i, _i, _i, _p, _p, _p, _p]),
     "sa_connect_single_track_breaks": (_i, [_i, _i, _p, _p, _i]),
     "sa_maxpool2x2_bf16": (_i, [_p, _i, _i, _i, _i, _p, _p]),
     "sa_upsample2x_bf16": (_i, [_p, _i, _i, _i, _i, _i, _p, _p]),

@@ -1,5 +1,7 @@
 // Cross-frame identity tracker (host code, no GIL): the `simple` / `simplemaxtracks` candidate makers of
-// sleap/nn/tracking.py:442-507, Tracker.track / spawn_for_untracked_instances (:642-814), FrameMatches
+// sleap/nn/tracking.py:442-507, the `flow` / `flowmaxtracks` ones (:108-440: candidates are the queued instances SHIFTED into
+// the current frame by sparse pyramidal Lucas-Kanade optical flow -- cv2.calcOpticalFlowPyrLK in the reference, the device
+// kernels of csrc/flow.hip here, one launch per frame for the points of every queued frame), Tracker.track / spawn_for_untracked_instances (:642-814), FrameMatches
 // (sleap/nn/tracker/components.py:469-640), the similarity functions (:33-196), greedy / Hungarian matching (:199-226),
 // pre-cull (nms_fast / cull_frame_instances, :229-417) and connect_single_track_breaks (:419-466).
 //
@@ -13,6 +15,7 @@
 #include <cstdint>
 #include <deque>
 #include <limits>
+#include <map>
 #include <numeric>
 #include <utility>
 #include <vector>
@@ -79,6 +82,43 @@ struct Config {
   int max_tracks, max_tracking;
   std::vector<double> kp_precision;  // 1 / (2 err^2); size 1 = scalar
   int oks_score_weighting, oks_normalization;
+  int flow = 0, of_window_size = 21, of_max_levels = 3;  // FlowCandidateMaker (tracking.py:108-137)
+};
+
+// Device side of the flow candidate makers: one image pyramid per queued time step (the reference keeps `img_t` in every
+// MatchedFrameInstances), the pyramid of the frame being tracked, and scratch for one Lucas-Kanade launch.
+struct FlowState {
+  int H = 0, W = 0;
+  std::map<int, void*> pyr;  // t -> device pyramid of that frame
+  void* cur = nullptr;       // pyramid of the current frame (set by sa_tracker_set_image, consumed by the next track call)
+  std::vector<void*> pool;   // free pyramid buffers of the current (H, W)
+  void* scratch = nullptr;
+  size_t scratch_bytes = 0;
+  hipStream_t stream = nullptr;
+
+  void* take(size_t bytes) {
+    if (!pool.empty()) {
+      void* b = pool.back();
+      pool.pop_back();
+      return b;
+    }
+    void* b = nullptr;
+    return hipMalloc(&b, bytes) == hipSuccess ? b : nullptr;
+  }
+  void clear() {
+    for (auto& kv : pyr) pool.push_back(kv.second);
+    pyr.clear();
+    if (cur) pool.push_back(cur);
+    cur = nullptr;
+  }
+  void release_all() {
+    clear();
+    for (void* b : pool) (void)hipFree(b);
+    pool.clear();
+    if (scratch) (void)hipFree(scratch);
+    scratch = nullptr;
+    scratch_bytes = 0;
+  }
 };
 
 struct Tracker {
@@ -86,6 +126,8 @@ struct Tracker {
   std::deque<std::pair<int, std::vector<Inst>>> queue;             // (t, tracked instances)
   std::vector<std::pair<int, std::deque<std::pair<int, Inst>>>> qdict;  // insertion-ordered {track: deque[(t, inst)]}
   int n_spawned = 0;
+  FlowState fs;
+  ~Tracker() { fs.release_all(); }
 
   int find_track(int tr) const {
     for (size_t i = 0; i < qdict.size(); ++i)
@@ -315,6 +357,84 @@ int hungarian_matching(const std::vector<double>& cost, int nr, int nc, std::vec
   return SA_OK;
 }
 
+// FlowCandidateMaker.flow_shift_instances (tracking.py:258-356) for the instance lists of several reference frames at once:
+// refs[g] = (t of the frame, its instances). ONE Lucas-Kanade launch for all points, then per reference instance (in order): a
+// candidate when MORE than min_points of its points were found (`found.sum() > min_shifted_points`), lost points NaN, the
+// reference instance's track. out[g] = the shifted instances of group g.
+int flow_shift(Tracker& T, const std::vector<std::pair<int, std::vector<const Inst*>>>& refs, std::vector<std::vector<Inst>>& out) {
+  FlowState& F = T.fs;
+  const Config& c = T.c;
+  out.assign(refs.size(), {});
+  size_t n = 0;
+  for (const auto& g : refs)
+    for (const Inst* a : g.second) n += a->pts.size() / 2;
+  if (n == 0) return SA_OK;
+  if (!F.cur) return sa::fail(SA_ERR_INVALID_ARG, "flow tracker: no image for the current frame (sa_tracker_set_image / img=...)");
+  // scratch: [n] pyramid pointers | [n][2] points | [n][2] shifted | [n] err | [n] status
+  const size_t need = n * (sizeof(void*) + 2 * sizeof(float) * 2 + sizeof(float) + 1) + 256;
+  if (need > F.scratch_bytes) {
+    if (F.scratch) (void)hipFree(F.scratch);
+    F.scratch = nullptr;
+    F.scratch_bytes = 0;
+    SA_HIP_CHECK(hipMalloc(&F.scratch, need * 2));
+    F.scratch_bytes = need * 2;
+  }
+  std::vector<const void*> ptrs(n);
+  std::vector<float> pts(2 * n);
+  size_t k = 0;
+  for (const auto& g : refs) {
+    const auto it = F.pyr.find(g.first);
+    if (it == F.pyr.end() && !g.second.empty())
+      return sa::fail(SA_ERR_INVALID_ARG, "flow tracker: the frame of time step %d was tracked without an image", g.first);
+    for (const Inst* a : g.second)
+      for (size_t j = 0; j < a->pts.size() / 2; ++j, ++k) {
+        ptrs[k] = it->second;
+        pts[2 * k] = (float)a->pts[2 * j];  // `.astype("float32")`; NaN points stay NaN and come back "not found"
+        pts[2 * k + 1] = (float)a->pts[2 * j + 1];
+      }
+  }
+  unsigned char* d = static_cast<unsigned char*>(F.scratch);
+  void* d_ptrs = d;
+  float* d_pts = reinterpret_cast<float*>(d + n * sizeof(void*));
+  float* d_out = d_pts + 2 * n;
+  float* d_err = d_out + 2 * n;
+  uint8_t* d_st = reinterpret_cast<uint8_t*>(d_err + n);
+  SA_HIP_CHECK(hipMemcpyAsync(d_ptrs, ptrs.data(), n * sizeof(void*), hipMemcpyHostToDevice, F.stream));
+  SA_HIP_CHECK(hipMemcpyAsync(d_pts, pts.data(), 2 * n * sizeof(float), hipMemcpyHostToDevice, F.stream));
+  const int rc = sa_flow_lk(static_cast<const void* const*>(d_ptrs), F.cur, F.H, F.W, c.of_window_size, c.of_max_levels, (int)n, d_pts,
+                            d_out, d_st, d_err, 30, 0.01f, F.stream);
+  if (rc != SA_OK) return rc;
+  std::vector<float> shifted(2 * n);
+  std::vector<uint8_t> st(n);
+  SA_HIP_CHECK(hipMemcpyAsync(shifted.data(), d_out, 2 * n * sizeof(float), hipMemcpyDeviceToHost, F.stream));
+  SA_HIP_CHECK(hipMemcpyAsync(st.data(), d_st, n, hipMemcpyDeviceToHost, F.stream));
+  SA_HIP_CHECK(hipStreamSynchronize(F.stream));
+  k = 0;
+  for (size_t g = 0; g < refs.size(); ++g)
+    for (const Inst* a : refs[g].second) {
+      const size_t m = a->pts.size() / 2;
+      int found = 0;
+      for (size_t j = 0; j < m; ++j) found += st[k + j] ? 1 : 0;
+      if (found > c.min_match_points) {
+        Inst b;
+        b.pts.resize(2 * m);
+        b.scores = a->scores;
+        b.score = a->score;
+        b.track = a->track;
+        b.src = a->src;
+        for (size_t j = 0; j < m; ++j) {
+          const bool ok = st[k + j] != 0;
+          b.pts[2 * j] = ok ? (double)shifted[2 * (k + j)] : NaN;
+          b.pts[2 * j + 1] = ok ? (double)shifted[2 * (k + j) + 1] : NaN;
+          if (ok) ++b.nvis;
+        }
+        out[g].push_back(std::move(b));
+      }
+      k += m;
+    }
+  return SA_OK;
+}
+
 int track_one(Tracker& T, std::vector<Inst> untracked, int img_h, int img_w, int t, std::vector<Inst>& tracked,
               std::vector<double>& tscore) {
   const Config& c = T.c;
@@ -337,9 +457,51 @@ int track_one(Tracker& T, std::vector<Inst> untracked, int img_h, int img_w, int
   if (!untracked.empty()) {
     if (c.target_instance_count && c.pre_cull_to_target)
       cull_frame_instances(untracked, c.target_instance_count, c.pre_cull_iou_threshold);
-    // candidates (SimpleCandidateMaker / SimpleMaxTracksCandidateMaker)
+    // candidates (SimpleCandidateMaker / SimpleMaxTracksCandidateMaker, or their optical-flow counterparts)
     std::vector<const Inst*> cand;
-    if (c.max_tracks_mode) {
+    std::vector<std::vector<Inst>> shifted;  // flow: owns the shifted instances `cand` points to
+    if (c.flow) {
+      // FlowCandidateMaker.get_candidates (tracking.py:210-237): every queued frame's instances shifted into this frame, oldest
+      // frame first. FlowMaxTracksCandidateMaker.get_candidates (:1194-1240): per track (the first max_tracks when max_tracking)
+      // and per queued item of that track, ALL queued instances of the item's time step are shifted -- an instance appears once
+      // per track that holds an item of its time step, exactly as there.
+      std::vector<std::pair<int, std::vector<const Inst*>>> groups;  // distinct reference time steps
+      std::vector<size_t> order;                                      // candidate groups in the reference's order (indices into `groups`)
+      auto group_of = [&](int tr) {
+        for (size_t g = 0; g < groups.size(); ++g)
+          if (groups[g].first == tr) return g;
+        groups.emplace_back(tr, std::vector<const Inst*>());
+        return groups.size() - 1;
+      };
+      if (c.max_tracks_mode) {
+        int n_tracks = 0;
+        for (const auto& kv : T.qdict) {
+          if (!c.max_tracking || n_tracks < c.max_tracks) {
+            ++n_tracks;
+            for (const auto& ti : kv.second) {
+              const size_t before = groups.size();
+              const size_t g = group_of(ti.first);
+              if (groups.size() != before)  // get_ref_instances: every track's items of that time step, dictionary order
+                for (const auto& kv2 : T.qdict)
+                  for (const auto& tj : kv2.second)
+                    if (tj.first == ti.first) groups[g].second.push_back(&tj.second);
+              order.push_back(g);
+            }
+          }
+        }
+      } else {
+        for (const auto& fr : T.queue) {
+          if (fr.second.empty()) continue;
+          const size_t g = group_of(fr.first);
+          for (const Inst& a : fr.second) groups[g].second.push_back(&a);
+          order.push_back(g);
+        }
+      }
+      const int rc = flow_shift(T, groups, shifted);
+      if (rc != SA_OK) return rc;
+      for (size_t g : order)
+        for (const Inst& a : shifted[g]) cand.push_back(&a);
+    } else if (c.max_tracks_mode) {
       int n_tracks = 0;
       for (const auto& kv : T.qdict) {
         if (!c.max_tracking || n_tracks < c.max_tracks) {
@@ -415,6 +577,31 @@ int track_one(Tracker& T, std::vector<Inst> untracked, int img_h, int img_w, int
     T.queue.emplace_back(t, tracked);
     while ((int)T.queue.size() > c.track_window) T.queue.pop_front();
   }
+  if (c.flow) {
+    // the frame's pyramid is kept while a queued item refers to its time step (MatchedFrameInstance(s).img_t)
+    FlowState& F = T.fs;
+    if (F.cur) {
+      auto it = F.pyr.find(t);
+      if (it != F.pyr.end()) F.pool.push_back(it->second);
+      F.pyr[t] = F.cur;
+      F.cur = nullptr;
+    }
+    for (auto it = F.pyr.begin(); it != F.pyr.end();) {
+      bool used = false;
+      if (c.max_tracks_mode) {
+        for (const auto& kv : T.qdict)
+          for (const auto& ti : kv.second) used = used || ti.first == it->first;
+      } else {
+        for (const auto& fr : T.queue) used = used || (fr.first == it->first && !fr.second.empty());
+      }
+      if (used) {
+        ++it;
+      } else {
+        F.pool.push_back(it->second);
+        it = F.pyr.erase(it);
+      }
+    }
+  }
   return SA_OK;
 }
 
@@ -461,6 +648,14 @@ void* sa_tracker_create(const sa_tracker_config* cfg) {
   c.max_tracking = cfg->max_tracks > 0 ? cfg->max_tracking : 0;
   c.oks_score_weighting = cfg->oks_score_weighting;
   c.oks_normalization = cfg->oks_normalization;
+  c.flow = cfg->flow ? 1 : 0;
+  c.of_window_size = cfg->of_window_size > 0 ? cfg->of_window_size : 21;
+  c.of_max_levels = cfg->of_max_levels >= 0 ? cfg->of_max_levels : 3;
+  if (c.flow && (c.of_window_size < 3 || c.of_window_size > 31)) {
+    delete t;
+    sa::fail(SA_ERR_UNSUPPORTED, "sa_tracker_create: of_window_size must be in 3..31");
+    return nullptr;
+  }
   if (cfg->oks_n_errors > 0 && cfg->oks_errors) {
     for (int i = 0; i < cfg->oks_n_errors; ++i) c.kp_precision.push_back(1.0 / (2.0 * cfg->oks_errors[i] * cfg->oks_errors[i]));
   } else {
@@ -479,7 +674,27 @@ int sa_tracker_reset(void* h) {
   // Tracker.reset_candidates (tracking.py:615-620): queues are emptied, spawned tracks are kept
   T->queue.clear();
   for (auto& kv : T->qdict) kv.second.clear();
+  T->fs.clear();
   return SA_OK;
+}
+
+int sa_tracker_set_image(void* h, const void* image, int H, int W, int C, sa_stream_t stream) {
+  SA_REQUIRE(h && image && H > 0 && W > 0 && (C == 1 || C == 3), "sa_tracker_set_image: bad arguments");
+  Tracker* T = static_cast<Tracker*>(h);
+  if (!T->c.flow) return SA_OK;  // the simple candidate makers do not look at frames (uses_image == False)
+  FlowState& F = T->fs;
+  F.stream = (hipStream_t)stream;
+  if (F.H != H || F.W != W) {
+    if (!F.pyr.empty())
+      return sa::fail(SA_ERR_INVALID_ARG, "flow tracker: frame size changed from %dx%d to %dx%d with frames still queued (reset first)",
+                      F.H, F.W, H, W);
+    F.release_all();
+    F.H = H;
+    F.W = W;
+  }
+  if (!F.cur) F.cur = F.take(sa_flow_pyramid_bytes(H, W, T->c.of_window_size, T->c.of_max_levels));
+  if (!F.cur) return sa::fail(SA_ERR_HIP, "flow tracker: out of device memory for the frame pyramid");
+  return sa_flow_pyramid_build(image, H, W, C, T->c.of_window_size, T->c.of_max_levels, F.cur, stream);
 }
 
 int sa_tracker_track(void* h, int n, int n_nodes, const float* points, const float* point_scores, const float* inst_scores,
@@ -533,6 +748,31 @@ int sa_tracker_track_frames(void* h, int n_frames, int max_inst, int n_nodes, co
       if (out_score) out_score[o] = ts[k];
       if (out_order) out_order[o] = (int)k;
     }
+  }
+  return SA_OK;
+}
+
+int sa_tracker_track_frames_images(void* h, int n_frames, int max_inst, int n_nodes, const float* points, const float* point_scores,
+                                   const float* inst_scores, const int* n_valid, int img_h, int img_w, int t0,
+                                   const int* frame_t, const void* images, int frame_h, int frame_w, int C, sa_stream_t stream,
+                                   int* out_track, double* out_score, int* out_order) {
+  SA_REQUIRE(h && n_frames >= 0 && max_inst >= 0 && n_nodes > 0 && n_valid && out_track, "sa_tracker_track_frames_images: bad arguments");
+  Tracker* T = static_cast<Tracker*>(h);
+  SA_REQUIRE(!T->c.flow || images, "sa_tracker_track_frames_images: a flow tracker needs the frames");
+  const size_t stride_f = (size_t)max_inst;
+  for (int f = 0; f < n_frames; ++f) {
+    if (T->c.flow) {
+      const int rc = sa_tracker_set_image(h, static_cast<const uint8_t*>(images) + (size_t)f * frame_h * frame_w * C, frame_h, frame_w, C,
+                                          stream);
+      if (rc != SA_OK) return rc;
+    }
+    const int t = frame_t ? frame_t[f] : (t0 < 0 ? -1 : t0 + f);
+    const int rc = sa_tracker_track_frames(h, 1, max_inst, n_nodes, points + (size_t)f * stride_f * n_nodes * 2,
+                                           point_scores ? point_scores + (size_t)f * stride_f * n_nodes : nullptr,
+                                           inst_scores ? inst_scores + (size_t)f * stride_f : nullptr, n_valid + f, img_h, img_w, t,
+                                           out_track + (size_t)f * stride_f, out_score ? out_score + (size_t)f * stride_f : nullptr,
+                                           out_order ? out_order + (size_t)f * stride_f : nullptr);
+    if (rc != SA_OK) return rc;
   }
   return SA_OK;
 }

@@ -1054,7 +1054,7 @@ class Predictor:
 
     def predict(self, data, make_labels: bool = True):
         """inference.py:496-531 (see BottomUpPredictor.predict for the output contract)."""
-        outs = self._apply_tracker(list(self._predict_generator(data)))
+        outs = self._apply_tracker(list(self._predict_generator(data)), data)
         return self._make_labels(outs, data) if make_labels else outs
 
     def _skeleton_info(self):
@@ -1116,10 +1116,10 @@ class Predictor:
                 ex["instance_scores"] = np.nansum(np.asarray(ex["instance_peak_vals"], np.float32), axis=-1)
         return outs
 
-    def _apply_tracker(self, outs: List[Dict[str, np.ndarray]]) -> List[Dict[str, np.ndarray]]:
+    def _apply_tracker(self, outs: List[Dict[str, np.ndarray]], data=None) -> List[Dict[str, np.ndarray]]:
         """Identity tracking over the gathered per-batch arrays, strictly in frame order, where the reference runs it
         (inference.py:3306-3313, 3345-3346). Adds `track_inds (b, I)` (-1 = no track), `tracking_scores (b, I)` and
-        `track_order (b, I)` (position in the tracker's returned list) to every batch; `predictor.tracker.spawned_tracks`
+        `track_order (b, I)` (position in the tracker's returned list) to every batch (`data`: the source, for flow trackers); `predictor.tracker.spawned_tracks`
         names the tracks. What reaches the tracker is what the reference hands it (`tracking.select_instances`): all-NaN
         instances dropped, and -- bottom-up only (inference.py:3297-3304) -- the `max_instances` best by score, in that
         order. Requires the array tracker of `sleap_amd.nn.tracking`."""
@@ -1127,11 +1127,14 @@ class Predictor:
         trk = self.tracker
         if not trk or not outs or not hasattr(trk, "track_frames"):
             return outs
-        from .tracking import finish_tracks, image_hw_of, track_example
+        from .tracking import finish_tracks, frames_of, image_hw_of, track_example
 
         cap = getattr(self, "max_instances", None) if isinstance(self, BottomUpPredictor) else None
         for ex in outs:
-            track_example(trk, ex, img_hw=image_hw_of(ex), max_instances=cap)
+            # flow trackers look at the frames (tracker.track(..., img=...), inference.py:2662-2668, 3306-3313): the carried
+            # `image`, or re-read from the source on the rank that tracks
+            track_example(trk, ex, img_hw=image_hw_of(ex), max_instances=cap,
+                          images=frames_of(ex, data) if getattr(trk, "uses_image", False) else None)
         return finish_tracks(outs, trk)
 
 
@@ -1479,7 +1482,7 @@ class BottomUpPredictor(Predictor):
         (`instance_peaks (b, Imax, N, 2)` NaN-padded, `instance_peak_vals`, `instance_scores`, `n_valid`,
         `video_ind`, `frame_ind`, ...). `make_labels=True` (the reference's default) returns the array-backed
         `sleap_amd.io.labels.Labels` (`len`, indexing, `.numpy()`, `.save("x.slp")`, `.to_sleap()`)."""
-        outs = self._apply_tracker(list(self._predict_generator(data)))
+        outs = self._apply_tracker(list(self._predict_generator(data)), data)
         return self._make_labels(outs, data) if make_labels else outs
 
 

@@ -1,7 +1,8 @@
 """Cross-frame identity tracking on the predictor's array outputs.
 
-Mirrors `sleap.nn.tracking.Tracker` (sleap/nn/tracking.py:542-992) for the `simple` and `simplemaxtracks` candidate
-makers: same `make_tracker_by_name` keyword arguments, defaults and error messages, same per-frame `track` semantics
+Mirrors `sleap.nn.tracking.Tracker` (sleap/nn/tracking.py:542-992) for the `simple` / `simplemaxtracks` candidate makers and
+the optical-flow ones, `flow` (the reference's default) / `flowmaxtracks` (:108-440, 1194-1240): same `make_tracker_by_name`
+keyword arguments, defaults and error messages, same per-frame `track` semantics
 (candidate pool from the last `track_window` frames, similarity matrix against the best / robust-quantile candidate of
 every track, greedy or Hungarian assignment, new tracks for what is left, optional pre-cull and single-break
 connection). The work happens in `libsleap_amd.so` (`csrc/tracker.hip`, host C++ -- no Python objects per instance, no
@@ -9,7 +10,9 @@ GIL while a batch of frames is tracked); this module only marshals arrays.
 
 Instances are arrays, not `PredictedInstance`s: points (n, N, 2) with NaN for missing nodes, point scores (n, N),
 instance scores (n,). Tracks are integers, `spawned_tracks[i]` is the reference's name for track i.
-Not covered (they need cv2 / pykalman, absent offline): optical-flow candidate makers, the Kalman tracker.
+Flow trackers take the frame with every step (`img=` / `images=`: uint8 arrays or CUDA tensors); the Lucas-Kanade flow that
+the reference gets from `cv2.calcOpticalFlowPyrLK` runs on the device (csrc/flow.hip), with `img_scale=1` and
+`save_shifted_instances=False` only. Not covered: the Kalman tracker (pykalman, absent offline).
 """
 import ctypes as C
 from typing import List, Optional, Sequence
@@ -29,7 +32,8 @@ class _Config(C.Structure):
                 ("robust", C.c_double), ("min_new_track_points", C.c_int), ("min_match_points", C.c_int),
                 ("target_instance_count", C.c_int), ("pre_cull_to_target", C.c_int), ("pre_cull_iou_threshold", C.c_double),
                 ("max_tracks", C.c_int), ("max_tracking", C.c_int), ("oks_n_errors", C.c_int),
-                ("oks_errors", C.POINTER(C.c_double)), ("oks_score_weighting", C.c_int), ("oks_normalization", C.c_int)]
+                ("oks_errors", C.POINTER(C.c_double)), ("oks_score_weighting", C.c_int), ("oks_normalization", C.c_int),
+                ("flow", C.c_int), ("of_window_size", C.c_int), ("of_max_levels", C.c_int)]
 
 
 def _f32(a):
@@ -38,6 +42,27 @@ def _f32(a):
 
 def _ptr(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _device_frames(img, single: bool = False):
+    """uint8 frames for the flow tracker as a contiguous CUDA tensor: (F, H, W, C), or (H, W, C) with `single`. Float frames
+    are converted as `ensure_int` does (normalization.py:52-77)."""
+    import torch
+
+    if not torch.is_tensor(img):
+        img = np.asarray(img)
+        if img.dtype.kind == "f":
+            img = (np.clip(np.floor(img.astype(np.float32) * np.float32(255.5)), 0, 255) if img.size and img.max() <= 1.0
+                   else img).astype(np.uint8)
+        img = torch.from_numpy(np.ascontiguousarray(img))
+    if img.dtype != torch.uint8:
+        raise TypeError("flow tracker: frames must be uint8 (or float arrays in [0, 1])")
+    want = 3 if single else 4
+    if img.dim() == want - 1:
+        img = img[..., None]
+    if img.dim() != want or img.shape[-1] not in (1, 3):
+        raise ValueError(f"flow tracker: unsupported frame shape {tuple(img.shape)}")
+    return img.contiguous().cuda()
 
 
 class Tracker:
@@ -59,7 +84,8 @@ class Tracker:
                              max_tracking: bool = False, oks_errors: Optional[list] = None,
                              oks_score_weighting: bool = False, oks_normalization: str = "all", **kwargs):
         return cls(tracker=tracker, similarity=similarity, match=match, track_window=track_window, robust=robust,
-                   min_new_track_points=min_new_track_points, min_match_points=min_match_points,
+                   min_new_track_points=min_new_track_points, min_match_points=min_match_points, img_scale=img_scale,
+                   of_window_size=of_window_size, of_max_levels=of_max_levels, save_shifted_instances=save_shifted_instances,
                    target_instance_count=target_instance_count, pre_cull_to_target=pre_cull_to_target,
                    pre_cull_iou_threshold=pre_cull_iou_threshold, post_connect_single_breaks=post_connect_single_breaks,
                    clean_instance_count=clean_instance_count, kf_init_frame_count=kf_init_frame_count,
@@ -67,7 +93,8 @@ class Tracker:
                    oks_errors=oks_errors, oks_score_weighting=oks_score_weighting, oks_normalization=oks_normalization)
 
     def _configure(self, tracker="simple", similarity="instance", match="greedy", track_window=5, robust=1.0,
-                   min_new_track_points=0, min_match_points=0, target_instance_count=0, pre_cull_to_target=False,
+                   min_new_track_points=0, min_match_points=0, img_scale=1.0, of_window_size=21, of_max_levels=3,
+                   save_shifted_instances=False, target_instance_count=0, pre_cull_to_target=False,
                    pre_cull_iou_threshold=None, post_connect_single_breaks=False, clean_instance_count=0,
                    kf_init_frame_count=0, kf_node_indices=None, max_tracks=None, max_tracking=False, oks_errors=None,
                    oks_score_weighting=False, oks_normalization="all"):
@@ -80,9 +107,13 @@ class Tracker:
             raise ValueError(f"{similarity} is not a valid tracker similarity function.")
         if match not in MATCH:
             raise ValueError(f"{match} is not a valid tracker matching function.")
-        if tracker.startswith("flow"):
-            raise NotImplementedError("optical-flow candidate makers need cv2.calcOpticalFlowPyrLK; use tracker='simple' "
-                                      "or 'simplemaxtracks'")
+        self.uses_flow = tracker.startswith("flow")
+        if tracker != "flow":  # tracking.py:914-919 configures the candidate maker for "flow" only: "flowmaxtracks" keeps
+            img_scale, of_window_size, of_max_levels, save_shifted_instances = 1.0, 21, 3, False  # the class defaults
+        if self.uses_flow and img_scale != 1:
+            raise NotImplementedError("flow tracker: img_scale != 1 (cv2.resize of the frames) is not implemented")
+        if self.uses_flow and save_shifted_instances:
+            raise NotImplementedError("flow tracker: save_shifted_instances=True (chained flow) is not implemented")
         if kf_init_frame_count:
             if not (max_tracks or target_instance_count):
                 raise ValueError("Kalman filter requires max tracks or target instance count.")
@@ -103,13 +134,14 @@ class Tracker:
         if oks_errors is not None and np.size(oks_errors) > 0:
             errs = np.ascontiguousarray(np.atleast_1d(oks_errors), dtype=np.float64)
         self._oks_errors = errs  # keep alive
-        cfg = _Config(1 if tracker == "simplemaxtracks" else 0, SIMILARITY[similarity], MATCH[match], self.track_window,
+        self.of_window_size, self.of_max_levels = int(of_window_size), int(of_max_levels)
+        cfg = _Config(1 if tracker.endswith("maxtracks") else 0, SIMILARITY[similarity], MATCH[match], self.track_window,
                       self.robust_best_instance, self.min_new_track_points, self.min_match_points,
                       self.target_instance_count, int(bool(pre_cull_to_target)),
                       float(pre_cull_iou_threshold) if pre_cull_iou_threshold else 0.0, int(max_tracks or 0),
                       int(self.max_tracking), 0 if errs is None else errs.size,
                       None if errs is None else errs.ctypes.data_as(C.POINTER(C.c_double)), int(bool(oks_score_weighting)),
-                      OKS_NORM[oks_normalization])
+                      OKS_NORM[oks_normalization], int(self.uses_flow), self.of_window_size, self.of_max_levels)
         h = _lib.lib()
         self._h = h.sa_tracker_create(C.byref(cfg))
         if not self._h:
@@ -130,11 +162,11 @@ class Tracker:
 
     @property
     def uses_image(self) -> bool:
-        return False
+        return self.uses_flow
 
     @property
     def has_max_tracking(self) -> bool:
-        return self.tracker_name == "simplemaxtracks"
+        return self.tracker_name.endswith("maxtracks")
 
     @property
     def spawned_tracks(self) -> List[str]:
@@ -144,7 +176,7 @@ class Tracker:
         check(_lib.lib().sa_tracker_reset(C.c_void_p(self._h)), "sa_tracker_reset")
 
     def get_name(self) -> str:
-        maker = "SimpleMaxTracksCandidateMaker" if self.has_max_tracking else "SimpleCandidateMaker"
+        maker = ("Flow" if self.uses_flow else "Simple") + ("MaxTracksCandidateMaker" if self.has_max_tracking else "CandidateMaker")
         sim = {"instance": "instance_similarity", "centroid": "centroid_distance", "iou": "instance_iou",
                "normalized_instance": "normalized_instance_similarity",
                "object_keypoint": "object_keypoint_similarity"}[self.similarity]
@@ -157,6 +189,14 @@ class Tracker:
         n = 0 if pts is None else pts.shape[0]
         n_nodes = pts.shape[1] if n else 1
         ps, sc = _f32(point_scores), _f32(instance_scores)
+        if self.uses_flow and img is not None:
+            frame = _device_frames(img, single=True)
+            from ..ops import _stream
+
+            check(_lib.lib().sa_tracker_set_image(C.c_void_p(self._h), C.c_void_p(frame.data_ptr()), frame.shape[0], frame.shape[1],
+                                                  frame.shape[2], _stream()), "sa_tracker_set_image")
+        elif self.uses_flow and n:
+            raise ValueError("flow tracker: track() needs the frame (img=...)")
         idx, trk = np.full((max(n, 1),), -1, np.int32), np.full((max(n, 1),), -1, np.int32)
         tsc = np.zeros((max(n, 1),), np.float64)
         n_out = C.c_int(0)
@@ -167,9 +207,11 @@ class Tracker:
         return {"index": idx[:m].copy(), "track": trk[:m].copy(), "tracking_score": tsc[:m].copy()}
 
     def track_frames(self, instance_peaks, instance_peak_vals=None, instance_scores=None, n_valid=None, img_hw=(1, 1),
-                     t0: Optional[int] = None):
+                     t0: Optional[int] = None, images=None, frame_t=None):
         """A run of consecutive frames in the predictor's output layout (F, I, N, 2) NaN padded. ->
-        dict(track (F, I) int32 with -1 for empty / dropped slots, tracking_score (F, I), order (F, I))."""
+        dict(track (F, I) int32 with -1 for empty / dropped slots, tracking_score (F, I), order (F, I)).
+        Flow trackers need `images` (F, H, W, C) uint8 (numpy or CUDA tensor); `frame_t` (F,) gives every frame its own time
+        step (default: t0 + f, or inferred)."""
         pts = _f32(instance_peaks)
         F, I, N = pts.shape[0], pts.shape[1], pts.shape[2]
         if n_valid is None:
@@ -179,6 +221,23 @@ class Tracker:
         trk = np.full((F, I), -1, np.int32)
         tsc = np.full((F, I), np.nan, np.float64)
         order = np.full((F, I), -1, np.int32)
+        if self.uses_flow or frame_t is not None:
+            if self.uses_flow and images is None:
+                raise ValueError("flow tracker: track_frames() needs the frames (images=...)")
+            ft = None if frame_t is None else np.ascontiguousarray(frame_t, dtype=np.int32)
+            dev, fh, fw, ch, st = None, 1, 1, 1, None
+            if self.uses_flow:
+                from ..ops import _stream
+
+                dev = _device_frames(images)
+                assert dev.shape[0] == F
+                fh, fw, ch = (int(v) for v in dev.shape[1:])
+                st = _stream()
+            check(_lib.lib().sa_tracker_track_frames_images(
+                C.c_void_p(self._h), F, I, N, _ptr(pts), _ptr(ps), _ptr(sc), _ptr(nv), int(img_hw[0]), int(img_hw[1]),
+                -1 if t0 is None else int(t0), _ptr(ft), None if dev is None else C.c_void_p(dev.data_ptr()), fh, fw, ch, st,
+                _ptr(trk), _ptr(tsc), _ptr(order)), "sa_tracker_track_frames_images")
+            return {"track": trk, "tracking_score": tsc, "order": order}
         check(_lib.lib().sa_tracker_track_frames(C.c_void_p(self._h), F, I, N, _ptr(pts), _ptr(ps), _ptr(sc), _ptr(nv),
                                                  int(img_hw[0]), int(img_hw[1]), -1 if t0 is None else int(t0), _ptr(trk),
                                                  _ptr(tsc), _ptr(order)), "sa_tracker_track_frames")
@@ -223,9 +282,25 @@ def select_instances(ex, max_instances: Optional[int] = None):
     return sel
 
 
-def track_example(tracker: Tracker, ex, img_hw=(1, 1), max_instances: Optional[int] = None, use_frame_ind: bool = True):
+def frames_of(ex, data=None):
+    """The frames of one prediction dict for a flow tracker: the carried `image` (single-GPU bottom-up runs), else re-read from
+    the source the predictor was given (array, `Video`, `VideoReader`) by `frame_ind`."""
+    if ex.get("image") is not None:
+        return ex["image"]
+    idx = [int(i) for i in np.asarray(ex["frame_ind"])]
+    video = getattr(data, "video", data)  # VideoReader -> its Video
+    if isinstance(video, np.ndarray):
+        return video[idx]
+    if hasattr(video, "get_frames"):
+        return video.get_frames(idx)
+    raise ValueError("flow tracker: the frames of this batch are not available (pass the video / array the predictions came from)")
+
+
+def track_example(tracker: Tracker, ex, img_hw=(1, 1), max_instances: Optional[int] = None, use_frame_ind: bool = True,
+                  images=None):
     """Run `tracker` over the frames of one prediction dict and add `track_inds`, `tracking_scores`, `track_order` (all
-    (F, I), -1 / NaN / -1 for slots that were not tracked). Only the instances `select_instances` picks are tracked (compacted,
+    (F, I), -1 / NaN / -1 for slots that were not tracked). `images` (F, H, W, C): the frames, for flow trackers.
+    Only the instances `select_instances` picks are tracked (compacted,
     with a source-index map back to the slots); `t` follows `frame_ind` frame by frame (non-contiguous readers), as
     inference.py:2662-2668 passes `t=frame_ind`."""
     pts = _f32(ex["instance_peaks"])
@@ -258,7 +333,8 @@ def track_example(tracker: Tracker, ex, img_hw=(1, 1), max_instances: Optional[i
         if fi is None:
             b = F
         r = tracker.track_frames(cp[a:b], None if cv is None else cv[a:b], None if cs is None else cs[a:b], nv[a:b],
-                                 img_hw=img_hw, t0=None if fi is None else int(fi[a]))
+                                 img_hw=img_hw, t0=None if fi is None else int(fi[a]),
+                                 images=None if images is None else images[a:b])
         for f in range(a, b):
             k = nv[f]
             trk[f, sel[f]] = r["track"][f - a, :k]
@@ -296,7 +372,7 @@ def finish_tracks(outs, tracker: Tracker):
     return outs
 
 
-def run_tracker(outs, tracker: Tracker, img_hw=(1, 1)):
+def run_tracker(outs, tracker: Tracker, img_hw=(1, 1), data=None):
     """tracking.py:1542-1581 on per-batch prediction dicts: every frame goes through `tracker.track` in order with the time
     step inferred (the reference does not pass `t` here), existing tracks are discarded; then `final_pass`.
     Adds / replaces `track_inds`, `tracking_scores`, `track_order` in every dict and returns the list."""
@@ -304,7 +380,8 @@ def run_tracker(outs, tracker: Tracker, img_hw=(1, 1)):
     if not outs:
         return outs
     for ex in outs:
-        track_example(tracker, ex, img_hw=image_hw_of(ex, img_hw), use_frame_ind=False)
+        track_example(tracker, ex, img_hw=image_hw_of(ex, img_hw), use_frame_ind=False,
+                      images=frames_of(ex, data) if tracker.uses_image else None)
     return finish_tracks(outs, tracker)
 
 

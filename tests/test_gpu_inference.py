@@ -167,6 +167,36 @@ def test_predict_with_tracker_matches_oracle_tracker(predictor, frames):
     assert n_tracked > 0 and len(p.tracker.spawned_tracks) == len(ot.spawned_tracks)
 
 
+def test_predict_with_flow_tracker_matches_oracle_tracker(predictor, frames):
+    """load_model(tracker="flow") -- the reference's default tracker (tracking.py:847) -- + predict: the frames reach the
+    tracker (device Lucas-Kanade candidates), and the tracks equal the oracle tracker with the CPU flow restatement fed with
+    the same predicted instances and frames."""
+    from oracle import tracking as OT
+    from sleap_amd.nn.inference import load_model
+
+    p = load_model(MODEL_DIR, batch_size=2, progress_reporting="none", tracker="flow", tracker_window=3)
+    p.inference_model.bottomup_layer.peak_threshold = predictor.inference_model.bottomup_layer.peak_threshold
+    assert p.tracker.get_name() == "FlowCandidateMaker.instance_similarity.greedy_matching" and p.tracker.uses_image
+    outs = p.predict(frames, make_labels=False)
+    ot = OT.Tracker(tracker="flow", similarity="instance", match="greedy", track_window=3)
+    n_tracked = 0
+    for ex in outs:
+        for f in range(len(ex["frame_ind"])):
+            nv = int(ex["n_valid"][f])
+            insts = [OT.Inst(ex["instance_peaks"][f, i], ex["instance_peak_vals"][f, i], ex["instance_scores"][f, i], uid=i)
+                     for i in range(nv)]
+            t = int(ex["frame_ind"][f])
+            res = ot.track(insts, img_hw=frames.shape[1:3], t=t, img=frames[t])
+            assert sorted((r.uid, r.track) for r in res) == sorted(
+                (i, int(ex["track_inds"][f, i])) for i in range(ex["track_inds"].shape[1]) if ex["track_inds"][f, i] >= 0)
+            for r in res:
+                assert ex["tracking_scores"][f, r.uid] == pytest.approx(r.tracking_score, abs=2e-3)
+            n_tracked += len(res)
+    assert n_tracked > 0 and len(p.tracker.spawned_tracks) == len(ot.spawned_tracks)
+    labels = p.predict(frames)  # the Labels path with a fresh run of the same tracker object state (tracks keep counting up)
+    assert len(labels) == len(frames)
+
+
 def test_predict_from_video_sources_equals_array_input(predictor, frames, tmp_path):
     """Predictor.predict over a `Video` (memory-mapped .npy through the prefetching feed) and over a `VideoReader` with
     example_indices returns what predict(ndarray) returns for the same frames (providers.py:301-439)."""

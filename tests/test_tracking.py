@@ -164,8 +164,15 @@ def test_errors_like_reference():
         Tracker.make_tracker_by_name(tracker="simple", match="optimal")
     with pytest.raises(ValueError, match="Kalman filter requires max tracks or target instance count"):
         Tracker.make_tracker_by_name(tracker="simple", kf_init_frame_count=10)
+    d = Tracker.make_tracker_by_name()  # the reference's default is the optical-flow tracker
+    assert d.uses_image and d.get_name() == "FlowCandidateMaker.instance_similarity.greedy_matching"
     with pytest.raises(NotImplementedError):
-        Tracker.make_tracker_by_name()  # reference default is the optical-flow tracker
+        Tracker.make_tracker_by_name(tracker="flow", img_scale=0.5)
+    with pytest.raises(NotImplementedError):
+        Tracker.make_tracker_by_name(tracker="flow", save_shifted_instances=True)
+    # tracking.py:914-919: only "flow" (not "flowmaxtracks") takes the of_* / img_scale arguments
+    m = Tracker.make_tracker_by_name(tracker="flowmaxtracks", img_scale=0.5, of_window_size=9, max_tracks=2, max_tracking=True)
+    assert m.of_window_size == 21 and m.has_max_tracking and m.uses_image
     t = Tracker.make_tracker_by_name(tracker="simple", similarity="iou", match="hungarian")
     assert t.get_name() == "SimpleCandidateMaker.instance_iou.hungarian_matching"
 
