@@ -27,7 +27,9 @@ using sa::h16x8_t;
 // conv0 weight terms per MFMA group: the fp32 weights (x 1/255 / U8_ACT_SCALE) enter as a sum of 16-bit terms. bf16 (8
 // mantissa bits) needs hi + mid + lo for fp32's 24 bits; fp16 (11 bits) carries 22 in hi + mid -- what is left (2^-22
 // relative) is 2000x below the fp16 rounding of the stored activation, so the fp16 build issues two MFMAs per group, not three.
-#if defined(SA_HALF_FP16)
+#if defined(SA_STEM16_TERMS_OVERRIDE)
+#define SA_STEM16_TERMS SA_STEM16_TERMS_OVERRIDE
+#elif defined(SA_HALF_FP16)
 #define SA_STEM16_TERMS 2
 #else
 #define SA_STEM16_TERMS 3
