@@ -9,9 +9,9 @@
 //   Scharr    Ix = [3 10 3]^T (x) [-1 0 1], Iy = [-1 0 1]^T (x) [3 10 3], int16, reflect-101 inside, ZERO outside a level;
 //   tracker   per point, coarse to fine: 14-bit integer bilinear patches of I, Ix, Iy (window w x w), 2x2 system in float32,
 //             <= 30 Newton steps, OpenCV's stopping rules, status / error outputs.
-// One WAVEFRONT per point: the w*w window pixels are spread over the 64 lanes (7 per lane for w = 21), the I / Ix / Iy patch of
-// the level lives in LDS (int16), every sum over the window is a butterfly reduction (all lanes end with the same bits, so the
-// data-dependent control flow stays wave uniform). Points are independent; a frame pair of the tracker is a few hundred of them.
+// One WAVEFRONT per point: the w*w window pixels are spread over the 64 lanes (7 per lane for w = 21), a lane keeps its share of the
+// I / Ix / Iy patch in registers, the part of J a level's iteration can touch is staged in LDS, every sum over the window is a
+// butterfly reduction (all lanes end with the same bits, so the data-dependent control flow stays wave uniform). Points are independent; a frame pair of the tracker is a few hundred of them.
 // Differences to a CPU OpenCV: the order of the float32 window sums (OpenCV's own SIMD and scalar builds differ in that too).
 #include <cstdint>
 #include <cstdlib>
@@ -148,17 +148,34 @@ __device__ __forceinline__ void lk_weights(float a, float b, int& w00, int& w01,
   w11 = 16384 - w00 - w01 - w10;
 }
 
-// one wave per point; blockDim = 256 (4 points)
+// one wave per point; blockDim = 256 (4 points). NPL = window pixels per lane (ceil(win^2 / 64)): the lane's share of the I / Ix /
+// Iy patch lives in REGISTERS (a lane only ever reads its own pixels), and the part of J the iteration can touch -- the window
+// box plus a margin of STAGE_MARGIN pixels around the level's starting guess -- is staged in LDS once per level (already
+// reflected), so the <= 30 dependent Newton steps of a level read LDS instead of global memory; a step that leaves the staged box
+// re-stages it around the current position. (First version: patches in LDS, J from global memory inside a rolled loop: 0.447 ms per
+// launch however few the points -- 7 serialised global round trips per step; profiles/r02_flow_tracker.md.)
+constexpr int STAGE_MARGIN = 8;
+
+template <int NPL>
 __global__ void __launch_bounds__(256)
 flow_lk_kernel(const LkParams p) {
-  extern __shared__ __attribute__((aligned(16))) int16_t lds[];
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds_u8[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int k = blockIdx.x * 4 + wave;
   if (k >= p.n) return;  // wave uniform
   const int win = p.win, area = win * win;
-  int16_t* ipatch = lds + (size_t)wave * 3 * area;
-  int16_t* ixp = ipatch + area;
-  int16_t* iyp = ixp + area;
+  const int S = win + 1 + 2 * STAGE_MARGIN;  // staged box edge
+  uint8_t* stage = lds_u8 + (size_t)wave * S * S;
+  int wyk[NPL], wxk[NPL];
+  bool act[NPL];
+#pragma unroll
+  for (int q = 0; q < NPL; ++q) {
+    const int i = lane + 64 * q;
+    act[q] = i < area;
+    const int ic = act[q] ? i : 0;
+    wyk[q] = ic / win;
+    wxk[q] = ic - wyk[q] * win;
+  }
   const uint8_t* base_i = p.pyr_prev[k];
   const uint8_t* base_j = p.pyr_next;
   const float half = (float)(win - 1) * 0.5f;
@@ -166,6 +183,7 @@ flow_lk_kernel(const LkParams p) {
   float nx = 0.0f, ny = 0.0f;  // nextPts[k]
   int st = 1;
   float er = 0.0f;
+  const float FLT_SCALE = 1.0f / (float)(1 << 20);
   const int top = p.lay.n_levels - 1;
   for (int level = top; level >= 0; --level) {
     const Level L = p.lay.lv[level];
@@ -197,31 +215,35 @@ flow_lk_kernel(const LkParams p) {
     }
     int w00, w01, w10, w11;
     lk_weights(prx - (float)ipx, pry - (float)ipy, w00, w01, w10, w11);
+    // ---- the lane's pixels of the I / Ix / Iy patch (registers) and the structure matrix
+    int ipatch[NPL], ixp[NPL], iyp[NPL];
     float a11 = 0.0f, a12 = 0.0f, a22 = 0.0f;
-    for (int i = lane; i < area; i += 64) {
-      const int wy = i / win, wx = i - wy * win;
-      const int y0 = ipy + wy, x0 = ipx + wx;
+#pragma unroll
+    for (int q = 0; q < NPL; ++q) {
+      const int y0 = ipy + wyk[q], x0 = ipx + wxk[q];
       const int ya = reflect101(y0, h), yb = reflect101(y0 + 1, h), xa = reflect101(x0, w), xb = reflect101(x0 + 1, w);
       const int iv = (I[(size_t)ya * w + xa] * w00 + I[(size_t)ya * w + xb] * w01 + I[(size_t)yb * w + xa] * w10 +
                       I[(size_t)yb * w + xb] * w11 + (1 << 8)) >> 9;  // CV_DESCALE(., W_BITS - 5)
-      // derivatives are zero outside the level (BORDER_CONSTANT)
+      // derivatives are zero outside the level (BORDER_CONSTANT); clamped addresses keep the loads unconditional
       const bool oa = (unsigned)y0 < (unsigned)h, ob = (unsigned)(y0 + 1) < (unsigned)h;
       const bool pa = (unsigned)x0 < (unsigned)w, pb = (unsigned)(x0 + 1) < (unsigned)w;
-      int dx00 = 0, dy00 = 0, dx01 = 0, dy01 = 0, dx10 = 0, dy10 = 0, dx11 = 0, dy11 = 0;
-      if (oa && pa) { const int16_t* q = D + 2 * ((size_t)y0 * w + x0); dx00 = q[0]; dy00 = q[1]; }
-      if (oa && pb) { const int16_t* q = D + 2 * ((size_t)y0 * w + x0 + 1); dx01 = q[0]; dy01 = q[1]; }
-      if (ob && pa) { const int16_t* q = D + 2 * ((size_t)(y0 + 1) * w + x0); dx10 = q[0]; dy10 = q[1]; }
-      if (ob && pb) { const int16_t* q = D + 2 * ((size_t)(y0 + 1) * w + x0 + 1); dx11 = q[0]; dy11 = q[1]; }
-      const int ixv = (dx00 * w00 + dx01 * w01 + dx10 * w10 + dx11 * w11 + (1 << 13)) >> 14;
-      const int iyv = (dy00 * w00 + dy01 * w01 + dy10 * w10 + dy11 * w11 + (1 << 13)) >> 14;
-      ipatch[i] = (int16_t)iv;
-      ixp[i] = (int16_t)ixv;
-      iyp[i] = (int16_t)iyv;
-      a11 += (float)(ixv * ixv);
-      a12 += (float)(ixv * iyv);
-      a22 += (float)(iyv * iyv);
+      const int yc0 = min(max(y0, 0), h - 1), yc1 = min(max(y0 + 1, 0), h - 1);
+      const int xc0 = min(max(x0, 0), w - 1), xc1 = min(max(x0 + 1, 0), w - 1);
+      const int d00 = *reinterpret_cast<const int*>(D + 2 * ((size_t)yc0 * w + xc0));
+      const int d01 = *reinterpret_cast<const int*>(D + 2 * ((size_t)yc0 * w + xc1));
+      const int d10 = *reinterpret_cast<const int*>(D + 2 * ((size_t)yc1 * w + xc0));
+      const int d11 = *reinterpret_cast<const int*>(D + 2 * ((size_t)yc1 * w + xc1));
+      const int m00 = (oa && pa) ? w00 : 0, m01 = (oa && pb) ? w01 : 0, m10 = (ob && pa) ? w10 : 0, m11 = (ob && pb) ? w11 : 0;
+      // (int16 x, int16 y) packed little endian: x = low half, y = high half (sign extended)
+      const int ixv = ((int)(int16_t)d00 * m00 + (int)(int16_t)d01 * m01 + (int)(int16_t)d10 * m10 + (int)(int16_t)d11 * m11 + (1 << 13)) >> 14;
+      const int iyv = ((d00 >> 16) * m00 + (d01 >> 16) * m01 + (d10 >> 16) * m10 + (d11 >> 16) * m11 + (1 << 13)) >> 14;
+      ipatch[q] = iv;
+      ixp[q] = act[q] ? ixv : 0;
+      iyp[q] = act[q] ? iyv : 0;
+      a11 += (float)(ixp[q] * ixp[q]);
+      a12 += (float)(ixp[q] * iyp[q]);
+      a22 += (float)(iyp[q] * iyp[q]);
     }
-    const float FLT_SCALE = 1.0f / (float)(1 << 20);
     a11 = wave_sum(a11) * FLT_SCALE;
     a12 = wave_sum(a12) * FLT_SCALE;
     a22 = wave_sum(a22) * FLT_SCALE;
@@ -234,6 +256,24 @@ flow_lk_kernel(const LkParams p) {
     det = 1.0f / det;
     qx -= half;
     qy -= half;
+    // ---- J around the starting guess, reflected, in LDS: stage(y, x) = J(reflect(sy0 + y), reflect(sx0 + x))
+    int sx0 = 0, sy0 = 0;
+    bool staged = false;
+    auto stage_box = [&](int cx, int cy) {
+      sx0 = cx - STAGE_MARGIN;
+      sy0 = cy - STAGE_MARGIN;
+      for (int i = lane; i < S * S; i += 64) {
+        const int yy = i / S, xx = i - yy * S;
+        stage[i] = J[(size_t)reflect101(sy0 + yy, h) * w + reflect101(sx0 + xx, w)];
+      }
+      staged = true;  // the lanes of a wave run in lockstep: no barrier between these stores and the loads below is needed
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    };
+    // sum over the window of f(J patch value - I patch value, lane pixel q) from the staged box
+    auto ensure = [&](int inx, int iny) {
+      if (!staged || inx < sx0 || iny < sy0 || inx + win + 1 > sx0 + S || iny + win + 1 > sy0 + S) stage_box(inx, iny);
+    };
     float pdx = 0.0f, pdy = 0.0f;
     for (int j = 0; j < p.max_count; ++j) {
       const int inx = cv_floor(qx), iny = cv_floor(qy);
@@ -241,17 +281,17 @@ flow_lk_kernel(const LkParams p) {
         if (level == 0) st = 0;
         break;
       }
+      ensure(inx, iny);
       lk_weights(qx - (float)inx, qy - (float)iny, w00, w01, w10, w11);
+      const uint8_t* sb = stage + (iny - sy0) * S + (inx - sx0);
       float b1 = 0.0f, b2 = 0.0f;
-      for (int i = lane; i < area; i += 64) {
-        const int wy = i / win, wx = i - wy * win;
-        const int ya = reflect101(iny + wy, h), yb = reflect101(iny + wy + 1, h);
-        const int xa = reflect101(inx + wx, w), xb = reflect101(inx + wx + 1, w);
-        const int jv = (J[(size_t)ya * w + xa] * w00 + J[(size_t)ya * w + xb] * w01 + J[(size_t)yb * w + xa] * w10 +
-                        J[(size_t)yb * w + xb] * w11 + (1 << 8)) >> 9;
-        const int diff = jv - ipatch[i];
-        b1 += (float)(diff * ixp[i]);
-        b2 += (float)(diff * iyp[i]);
+#pragma unroll
+      for (int q = 0; q < NPL; ++q) {
+        const uint8_t* s0 = sb + wyk[q] * S + wxk[q];
+        const int jv = (s0[0] * w00 + s0[1] * w01 + s0[S] * w10 + s0[S + 1] * w11 + (1 << 8)) >> 9;
+        const int diff = jv - ipatch[q];
+        b1 += (float)(diff * ixp[q]);
+        b2 += (float)(diff * iyp[q]);
       }
       b1 = wave_sum(b1) * FLT_SCALE;
       b2 = wave_sum(b2) * FLT_SCALE;
@@ -276,15 +316,15 @@ flow_lk_kernel(const LkParams p) {
         st = 0;
         continue;
       }
+      ensure(inx, iny);
       lk_weights(ex - (float)inx, ey - (float)iny, w00, w01, w10, w11);
+      const uint8_t* sb = stage + (iny - sy0) * S + (inx - sx0);
       float e = 0.0f;
-      for (int i = lane; i < area; i += 64) {
-        const int wy = i / win, wx = i - wy * win;
-        const int ya = reflect101(iny + wy, h), yb = reflect101(iny + wy + 1, h);
-        const int xa = reflect101(inx + wx, w), xb = reflect101(inx + wx + 1, w);
-        const int jv = (J[(size_t)ya * w + xa] * w00 + J[(size_t)ya * w + xb] * w01 + J[(size_t)yb * w + xa] * w10 +
-                        J[(size_t)yb * w + xb] * w11 + (1 << 8)) >> 9;
-        e += fabsf((float)(jv - ipatch[i]));
+#pragma unroll
+      for (int q = 0; q < NPL; ++q) {
+        const uint8_t* s0 = sb + wyk[q] * S + wxk[q];
+        const int jv = (s0[0] * w00 + s0[1] * w01 + s0[S] * w10 + s0[S + 1] * w11 + (1 << 8)) >> 9;
+        e += act[q] ? fabsf((float)(jv - ipatch[q])) : 0.0f;
       }
       er = wave_sum(e) * (1.0f / (float)(32 * win * win));
     }
@@ -359,8 +399,16 @@ int sa_flow_lk(const void* const* pyr_prev, const void* pyr_next, int H, int W, 
   p.next_pts = next_pts;
   p.status = status;
   p.err = err;
-  const size_t lds = (size_t)4 * 3 * win * win * sizeof(int16_t);
-  hipLaunchKernelGGL(flow_lk_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), lds, (hipStream_t)stream, p);
+  const int S = win + 1 + 2 * STAGE_MARGIN;
+  const size_t lds = (size_t)4 * S * S;
+  const dim3 grid((unsigned)((n + 3) / 4)), block(256);
+  const int npl = (win * win + 63) / 64;
+  if (npl <= 4)
+    hipLaunchKernelGGL(flow_lk_kernel<4>, grid, block, lds, (hipStream_t)stream, p);
+  else if (npl <= 7)
+    hipLaunchKernelGGL(flow_lk_kernel<7>, grid, block, lds, (hipStream_t)stream, p);
+  else
+    hipLaunchKernelGGL(flow_lk_kernel<16>, grid, block, lds, (hipStream_t)stream, p);
   SA_LAUNCH_CHECK();
   return SA_OK;
 }
