@@ -375,9 +375,11 @@ class FramePrefetcher:
         bmax = max((hi - lo for lo, hi in self.ranges), default=0)
         v = reader.video
         for k in range(self.depth):
-            t = torch.empty((bmax, v.height, v.width, v.channels), dtype=torch.uint8 if v.dtype == np.uint8 else torch.float32)
-            if self._pin and bmax:
-                t = t.pin_memory()
+            # page-locked straight from torch's caching host allocator: the blocks of the previous predict() call are handed
+            # out again (no new page locking); `empty().pin_memory()` locked fresh pages AND copied 64 MB per buffer on every
+            # call -- 3 buffers = ~90 ms of a 205 ms predict() over 1280 frames (tools/predict_e2e.py)
+            t = torch.empty((bmax, v.height, v.width, v.channels), dtype=torch.uint8 if v.dtype == np.uint8 else torch.float32,
+                            pin_memory=bool(self._pin and bmax))
             self._bufs.append(t)
             self._free.put(k)
         self._pool, self.copy_threads = None, int(os.environ.get("SLEAP_AMD_COPY_THREADS", "1"))
