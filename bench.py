@@ -232,12 +232,13 @@ def main():
         # ---- instrumented pass: per-op HIP events on the launch stream (outside the timed region)
         descs = net.op_descriptions(H, W)
         acc = np.zeros(len(descs))
-        reps = 3
-        for _ in range(reps):
+        reps = 4
+        for r in range(reps + 1):  # the first pass warms the per-launch Python loop (not counted); mean over the other four
             prof = []
             net.forward(layer.preprocess(frames), profile=prof)
             torch.cuda.synchronize()
-            acc += np.array([a.elapsed_time(b) for a, b in prof])
+            if r:
+                acc += np.array([a.elapsed_time(b) for a, b in prof])
         acc /= reps  # ms per launch
         conv_ms = sum(ms for (k, _, _), ms in zip(descs, acc) if k == "conv")
         conv_fl = sum(f for (k, _, f) in descs if k == "conv") * B

@@ -35,7 +35,7 @@ def main(fetch_csv, write_csv, n_fwd):
             tf += sum(f[key]) / 1024 * 2
             tw += sum(w.get(key, [0])) / 1024
     print(f"\nconv family (conv3x3_dma_kernel + convpair + stem16), all launches of the run: FETCH x2 {tf / 1024:.2f} GB, "
-          f"WRITE {tw / 1024:.2f} GB over {n_fwd} forward passes of 64 frames (bench.py defaults: 3 warm-up + 10 timed steps + 3 instrumented passes + 1 pass for the post-processing timing)")
+          f"WRITE {tw / 1024:.2f} GB over {n_fwd} forward passes of 64 frames (bench.py defaults: 3 warm-up + 10 timed steps + 5 instrumented passes + 1 pass for the post-processing timing)")
     print(f"-> per step (all conv-family launches of one forward pass, 64 frames): {(tf + tw) / 1024 / n_fwd:.2f} GB = "
           f"{(tf + tw) / n_fwd / 64:.0f} MB/frame; algorithmic activations in + out of the current plan: DESIGN.md section 3")
 
