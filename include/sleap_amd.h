@@ -477,9 +477,19 @@ int sa_connect_single_track_breaks(int n_frames, int max_inst, const int* order,
 int sa_flow_pyramid_levels(int H, int W, int win, int max_level);
 size_t sa_flow_pyramid_bytes(int H, int W, int win, int max_level);
 int sa_flow_pyramid_build(const void* image, int H, int W, int C, int win, int max_level, void* pyramid, sa_stream_t stream);
+/* F frames at once (images [F,H,W,C]; pyramids: DEVICE array of F device pointers, one buffer per frame): 2 + 2 levels launches
+ * for the whole batch instead of per frame. */
+int sa_flow_pyramid_build_batch(const void* images, int F, int H, int W, int C, int win, int max_level, void* const* pyramids,
+                                sa_stream_t stream);
 int sa_flow_lk(const void* const* pyr_prev, const void* pyr_next, int H, int W, int win, int max_level, int n,
                const float* prev_pts, float* next_pts, uint8_t* status, float* err, int max_count, float epsilon,
                sa_stream_t stream);
+/* The same with one TARGET pyramid per point (pyr_next: DEVICE array of n device pointers): every (reference frame, target frame)
+ * pair of a whole batch of frames in one launch -- what the flow tracker does for a run of frames (the shifts depend on the
+ * detections only, not on the track assignments, so they need not wait for the frame-by-frame matching). */
+int sa_flow_lk_pairs(const void* const* pyr_prev, const void* const* pyr_next, int H, int W, int win, int max_level, int n,
+                     const float* prev_pts, float* next_pts, uint8_t* status, float* err, int max_count, float epsilon,
+                     sa_stream_t stream);
 
 /* Top-down glue on the device (CentroidCrop / FindInstancePeaks, inference.py:1747-1966, 2059-2200): the number of crops per
  * frame is data dependent in the reference (ragged); here every frame has K crop slots, so nothing between the centroid

@@ -101,7 +101,9 @@ SIGNATURES = {
     "sa_flow_pyramid_levels": (_i, [_i, _i, _i, _i]),
     "sa_flow_pyramid_bytes": (_sz, [_i, _i, _i, _i]),
     "sa_flow_pyramid_build": (_i, [_p, _i, _i, _i, _i, _i, _p, _p]),
+    "sa_flow_pyramid_build_batch": (_i, [_p, _i, _i, _i, _i, _i, _i, _p, _p]),
     "sa_flow_lk": (_i, [_p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _i, _f, _p]),
+    "sa_flow_lk_pairs": (_i, [_p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _i, _f, _p]),
     "sa_network_output_shape": (_i, [_p, _i, _i, _i, _p, _p, _p]),
     "sa_network_workspace_bytes": (_sz, [_p, _i, _i, _i]),
     "sa_network_buffer": (_p, [_p, _i, _i, _i, _i, _p, _p, _p, _p, _p]),

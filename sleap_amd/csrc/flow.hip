@@ -116,9 +116,64 @@ flow_scharr_kernel(const uint8_t* __restrict__ src, int h, int w, int16_t* __res
   }
 }
 
+// ---- the same three kernels for a batch of frames: blockIdx.y = frame, pyr[f] = that frame's pyramid buffer
+__global__ void __launch_bounds__(256)
+flow_gray_batch_kernel(const uint8_t* __restrict__ src, int n_pix, int C, uint8_t* const* __restrict__ pyr, size_t dst_off) {
+  const uint8_t* s0 = src + (size_t)blockIdx.y * n_pix * C;
+  uint8_t* dst = pyr[blockIdx.y] + dst_off;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_pix; i += gridDim.x * blockDim.x) {
+    if (C == 1) {
+      dst[i] = s0[i];
+    } else {
+      const uint8_t* s = s0 + (size_t)i * 3;
+      dst[i] = (uint8_t)((s[0] * 1868 + s[1] * 9617 + s[2] * 4899 + 8192) >> 14);
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256)
+flow_pyrdown_batch_kernel(uint8_t* const* __restrict__ pyr, size_t src_off, int h, int w, size_t dst_off, int oh, int ow) {
+  const uint8_t* src = pyr[blockIdx.y] + src_off;
+  uint8_t* dst = pyr[blockIdx.y] + dst_off;
+  const int n = oh * ow;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const int oy = i / ow, ox = i - oy * ow;
+    const int k[5] = {1, 4, 6, 4, 1};
+    int acc = 0;
+#pragma unroll
+    for (int dy = 0; dy < 5; ++dy) {
+      const uint8_t* row = src + (size_t)reflect101(2 * oy + dy - 2, h) * w;
+      int r = 0;
+#pragma unroll
+      for (int dx = 0; dx < 5; ++dx) r += k[dx] * row[reflect101(2 * ox + dx - 2, w)];
+      acc += k[dy] * r;
+    }
+    dst[i] = (uint8_t)((acc + 128) >> 8);
+  }
+}
+
+__global__ void __launch_bounds__(256)
+flow_scharr_batch_kernel(uint8_t* const* __restrict__ pyr, size_t src_off, int h, int w, size_t dst_off) {
+  const uint8_t* src = pyr[blockIdx.y] + src_off;
+  int16_t* dst = reinterpret_cast<int16_t*>(pyr[blockIdx.y] + dst_off);
+  const int n = h * w;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const int y = i / w, x = i - y * w;
+    const uint8_t* r0 = src + (size_t)reflect101(y - 1, h) * w;
+    const uint8_t* r1 = src + (size_t)y * w;
+    const uint8_t* r2 = src + (size_t)reflect101(y + 1, h) * w;
+    const int xl = reflect101(x - 1, w), xr = reflect101(x + 1, w);
+    const int t0l = (r0[xl] + r2[xl]) * 3 + r1[xl] * 10, t0r = (r0[xr] + r2[xr]) * 3 + r1[xr] * 10;
+    const int t1l = r2[xl] - r0[xl], t1c = r2[x] - r0[x], t1r = r2[xr] - r0[xr];
+    dst[2 * (size_t)i] = (int16_t)(t0r - t0l);
+    dst[2 * (size_t)i + 1] = (int16_t)((t1r + t1l) * 3 + t1c * 10);
+  }
+}
+
 struct LkParams {
-  const uint8_t* const* pyr_prev;  // [n] device pointers: the reference frame's pyramid of every point
-  const uint8_t* pyr_next;         // the current frame's pyramid
+  const uint8_t* const* pyr_prev;    // [n] device pointers: the reference frame's pyramid of every point
+  const uint8_t* pyr_next;           // the target frame's pyramid (all points), or
+  const uint8_t* const* pyr_next_v;  // [n] device pointers: one target pyramid per point (sa_flow_lk_pairs); NULL otherwise
   PyrLayout lay;
   int win, n, max_count;
   float eps2;
@@ -177,7 +232,7 @@ flow_lk_kernel(const LkParams p) {
     wxk[q] = ic - wyk[q] * win;
   }
   const uint8_t* base_i = p.pyr_prev[k];
-  const uint8_t* base_j = p.pyr_next;
+  const uint8_t* base_j = p.pyr_next_v ? p.pyr_next_v[k] : p.pyr_next;
   const float half = (float)(win - 1) * 0.5f;
   const float px = p.prev_pts[2 * k], py = p.prev_pts[2 * k + 1];
   float nx = 0.0f, ny = 0.0f;  // nextPts[k]
@@ -380,15 +435,39 @@ int sa_flow_pyramid_build(const void* image, int H, int W, int C, int win, int m
   return SA_OK;
 }
 
-int sa_flow_lk(const void* const* pyr_prev, const void* pyr_next, int H, int W, int win, int max_level, int n,
-               const float* prev_pts, float* next_pts, uint8_t* status, float* err, int max_count, float epsilon,
-               sa_stream_t stream) {
+int sa_flow_pyramid_build_batch(const void* images, int F, int H, int W, int C, int win, int max_level, void* const* pyramids,
+                                sa_stream_t stream) {
+  if (F == 0) return SA_OK;
+  SA_REQUIRE(images && pyramids && F > 0 && F <= 65535, "sa_flow_pyramid_build_batch: bad arguments");
+  SA_REQUIRE(H > 0 && W > 0 && (C == 1 || C == 3), "sa_flow_pyramid_build_batch: frames are [H,W,1] or [H,W,3] uint8");
+  SA_REQUIRE(win >= 3 && win <= MAX_WIN && max_level >= 0, "sa_flow_pyramid_build_batch: window must be in 3..%d", MAX_WIN);
+  const PyrLayout lay = pyr_layout(H, W, win, max_level);
+  uint8_t* const* pyr = reinterpret_cast<uint8_t* const*>(pyramids);
+  hipStream_t st = (hipStream_t)stream;
+  auto grid = [&](size_t total) { return dim3((unsigned)grid_for(total, 1024), (unsigned)F); };
+  hipLaunchKernelGGL(flow_gray_batch_kernel, grid((size_t)H * W), dim3(256), 0, st, (const uint8_t*)images, H * W, C, pyr, lay.lv[0].img_off);
+  for (int l = 0; l < lay.n_levels; ++l) {
+    const Level& L = lay.lv[l];
+    if (l > 0) {
+      const Level& P = lay.lv[l - 1];
+      hipLaunchKernelGGL(flow_pyrdown_batch_kernel, grid((size_t)L.h * L.w), dim3(256), 0, st, pyr, P.img_off, P.h, P.w, L.img_off, L.h, L.w);
+    }
+    hipLaunchKernelGGL(flow_scharr_batch_kernel, grid((size_t)L.h * L.w), dim3(256), 0, st, pyr, L.img_off, L.h, L.w, L.deriv_off);
+  }
+  SA_LAUNCH_CHECK();
+  return SA_OK;
+}
+
+static int flow_lk_launch(const void* const* pyr_prev, const void* pyr_next, const void* const* pyr_next_v, int H, int W, int win,
+                          int max_level, int n, const float* prev_pts, float* next_pts, uint8_t* status, float* err, int max_count,
+                          float epsilon, sa_stream_t stream) {
   if (n == 0) return SA_OK;
-  SA_REQUIRE(pyr_prev && pyr_next && prev_pts && next_pts && status && err, "sa_flow_lk: NULL pointer");
+  SA_REQUIRE(pyr_prev && (pyr_next || pyr_next_v) && prev_pts && next_pts && status && err, "sa_flow_lk: NULL pointer");
   SA_REQUIRE(n > 0 && H > 0 && W > 0 && win >= 3 && win <= MAX_WIN && max_level >= 0, "sa_flow_lk: bad arguments");
   LkParams p;
   p.pyr_prev = reinterpret_cast<const uint8_t* const*>(pyr_prev);
   p.pyr_next = static_cast<const uint8_t*>(pyr_next);
+  p.pyr_next_v = reinterpret_cast<const uint8_t* const*>(pyr_next_v);
   p.lay = pyr_layout(H, W, win, max_level);
   p.win = win;
   p.n = n;
@@ -411,6 +490,20 @@ int sa_flow_lk(const void* const* pyr_prev, const void* pyr_next, int H, int W, 
     hipLaunchKernelGGL(flow_lk_kernel<16>, grid, block, lds, (hipStream_t)stream, p);
   SA_LAUNCH_CHECK();
   return SA_OK;
+}
+
+int sa_flow_lk(const void* const* pyr_prev, const void* pyr_next, int H, int W, int win, int max_level, int n,
+               const float* prev_pts, float* next_pts, uint8_t* status, float* err, int max_count, float epsilon,
+               sa_stream_t stream) {
+  return flow_lk_launch(pyr_prev, pyr_next, nullptr, H, W, win, max_level, n, prev_pts, next_pts, status, err, max_count, epsilon,
+                        stream);
+}
+
+int sa_flow_lk_pairs(const void* const* pyr_prev, const void* const* pyr_next, int H, int W, int win, int max_level, int n,
+                     const float* prev_pts, float* next_pts, uint8_t* status, float* err, int max_count, float epsilon,
+                     sa_stream_t stream) {
+  return flow_lk_launch(pyr_prev, nullptr, pyr_next, H, W, win, max_level, n, prev_pts, next_pts, status, err, max_count, epsilon,
+                        stream);
 }
 
 }  // extern "C"

@@ -17,6 +17,7 @@
 #include <limits>
 #include <map>
 #include <numeric>
+#include <unordered_map>
 #include <utility>
 #include <vector>
 
@@ -35,7 +36,8 @@ struct Inst {
   double score = 0.0;
   int track = -1;
   int nvis = 0;
-  int src = -1;  // index in the caller's frame
+  int src = -1;       // index in the caller's frame
+  long fserial = -1;  // serial number of the Tracker.track call (= frame) it was detected in
 };
 
 inline bool row_nan(const Inst& a, int k) { return std::isnan(a.pts[2 * k]) || std::isnan(a.pts[2 * k + 1]); }
@@ -126,7 +128,20 @@ struct Tracker {
   std::deque<std::pair<int, std::vector<Inst>>> queue;             // (t, tracked instances)
   std::vector<std::pair<int, std::deque<std::pair<int, Inst>>>> qdict;  // insertion-ordered {track: deque[(t, inst)]}
   int n_spawned = 0;
+  long serial = 0;  // Tracker.track calls so far
   FlowState fs;
+  // Shifts of a whole run of frames computed ahead (sa_tracker_track_frames_images, flow without max-tracks): the optical flow
+  // of a queued instance into a later frame depends on the detections only, never on the track assignments, so all (queued
+  // frame, target frame) pairs of the run go through ONE Lucas-Kanade launch and the frame-by-frame matching that follows only
+  // looks results up: (frame serial, instance index, target frame of the run) -> first point of the instance.
+  struct FlowBatch {
+    bool active = false;
+    long first_serial = 0;
+    std::unordered_map<uint64_t, size_t> at;
+    std::vector<float> shifted;
+    std::vector<uint8_t> st;
+    static uint64_t key(long fserial, int src, int f) { return ((uint64_t)(uint32_t)fserial << 32) | ((uint64_t)(uint16_t)src << 16) | (uint16_t)f; }
+  } fb;
   ~Tracker() { fs.release_all(); }
 
   int find_track(int tr) const {
@@ -438,6 +453,8 @@ int flow_shift(Tracker& T, const std::vector<std::pair<int, std::vector<const In
 int track_one(Tracker& T, std::vector<Inst> untracked, int img_h, int img_w, int t, std::vector<Inst>& tracked,
               std::vector<double>& tscore) {
   const Config& c = T.c;
+  const long my_serial = T.serial++;
+  for (Inst& u : untracked) u.fserial = my_serial;
   if (t < 0) {
     t = 0;
     if (c.max_tracks_mode) {
@@ -497,8 +514,36 @@ int track_one(Tracker& T, std::vector<Inst> untracked, int img_h, int img_w, int
           order.push_back(g);
         }
       }
-      const int rc = flow_shift(T, groups, shifted);
-      if (rc != SA_OK) return rc;
+      if (T.fb.active && !c.max_tracks_mode) {
+        // the shifts were computed for the whole run of frames (see FlowBatch): look them up
+        const int f = (int)(my_serial - T.fb.first_serial);
+        shifted.assign(groups.size(), {});
+        for (size_t g = 0; g < groups.size(); ++g)
+          for (const Inst* a : groups[g].second) {
+            const auto it = T.fb.at.find(Tracker::FlowBatch::key(a->fserial, a->src, f));
+            if (it == T.fb.at.end()) return sa::fail(SA_ERR_INVALID_ARG, "flow tracker: no precomputed shift for a queued instance");
+            const size_t k = it->second, m = a->pts.size() / 2;
+            int found = 0;
+            for (size_t j = 0; j < m; ++j) found += T.fb.st[k + j] ? 1 : 0;
+            if (found <= c.min_match_points) continue;
+            Inst b;
+            b.pts.resize(2 * m);
+            b.scores = a->scores;
+            b.score = a->score;
+            b.track = a->track;
+            b.src = a->src;
+            for (size_t j = 0; j < m; ++j) {
+              const bool ok = T.fb.st[k + j] != 0;
+              b.pts[2 * j] = ok ? (double)T.fb.shifted[2 * (k + j)] : NaN;
+              b.pts[2 * j + 1] = ok ? (double)T.fb.shifted[2 * (k + j) + 1] : NaN;
+              if (ok) ++b.nvis;
+            }
+            shifted[g].push_back(std::move(b));
+          }
+      } else {
+        const int rc = flow_shift(T, groups, shifted);
+        if (rc != SA_OK) return rc;
+      }
       for (size_t g : order)
         for (const Inst& a : shifted[g]) cand.push_back(&a);
     } else if (c.max_tracks_mode) {
@@ -619,6 +664,152 @@ Inst make_inst(const float* pts, const float* ps, float score, int N, int src) {
   a.score = score;
   a.src = src;
   return a;
+}
+
+// One run of frames of a flow tracker without max-tracks: pyramids of all frames, one Lucas-Kanade launch for every (queued frame,
+// target frame) pair -- the queue a frame will see is known in advance: the last track_window entries of (what is queued now,
+// then the earlier frames of the run), and a frame of the run can only queue instances that are among its detections -- then the
+// per-frame matching (track_one) with the shifts looked up.
+int flow_batch_run(Tracker& T, int n_frames, int max_inst, int n_nodes, const float* points, const float* point_scores,
+                   const float* inst_scores, const int* n_valid, int img_h, int img_w, int t0, const int* frame_t,
+                   const uint8_t* images, int frame_h, int frame_w, int C, sa_stream_t stream, int* out_track, double* out_score,
+                   int* out_order) {
+  FlowState& F = T.fs;
+  const Config& c = T.c;
+  F.stream = (hipStream_t)stream;
+  if (F.H != frame_h || F.W != frame_w) {
+    if (!F.pyr.empty())
+      return sa::fail(SA_ERR_INVALID_ARG, "flow tracker: frame size changed from %dx%d to %dx%d with frames still queued (reset first)",
+                      F.H, F.W, frame_h, frame_w);
+    F.release_all();
+    F.H = frame_h;
+    F.W = frame_w;
+  }
+  if (F.cur) {  // an image handed over by sa_tracker_set_image and never used
+    F.pool.push_back(F.cur);
+    F.cur = nullptr;
+  }
+  const size_t pbytes = sa_flow_pyramid_bytes(frame_h, frame_w, c.of_window_size, c.of_max_levels);
+  std::vector<void*> bp((size_t)n_frames, nullptr);
+  for (int f = 0; f < n_frames; ++f) {
+    SA_REQUIRE(n_valid[f] >= 0 && n_valid[f] <= max_inst && max_inst < 65536, "sa_tracker_track_frames_images: n_valid[%d] out of range", f);
+    bp[(size_t)f] = F.take(pbytes);
+    if (!bp[(size_t)f]) return sa::fail(SA_ERR_HIP, "flow tracker: out of device memory for the frame pyramids");
+  }
+  {  // all pyramids of the run in a handful of launches (the table of buffer pointers goes through the scratch area)
+    const size_t need = (size_t)n_frames * sizeof(void*) + 256;
+    if (need > F.scratch_bytes) {
+      if (F.scratch) (void)hipFree(F.scratch);
+      F.scratch = nullptr;
+      F.scratch_bytes = 0;
+      SA_HIP_CHECK(hipMalloc(&F.scratch, need * 2));
+      F.scratch_bytes = need * 2;
+    }
+    SA_HIP_CHECK(hipMemcpyAsync(F.scratch, bp.data(), (size_t)n_frames * sizeof(void*), hipMemcpyHostToDevice, F.stream));
+    const int rc = sa_flow_pyramid_build_batch(images, n_frames, frame_h, frame_w, C, c.of_window_size, c.of_max_levels,
+                                               static_cast<void* const*>(F.scratch), stream);
+    if (rc != SA_OK) return rc;
+    SA_HIP_CHECK(hipStreamSynchronize(F.stream));  // the scratch area is reused for the Lucas-Kanade job tables below
+  }
+  // ---- jobs
+  const int Wq = c.track_window, q0 = (int)T.queue.size();
+  std::vector<const void*> prev, next;
+  std::vector<float> pts;
+  Tracker::FlowBatch& B = T.fb;
+  B.at.clear();
+  B.first_serial = T.serial;
+  auto add_point = [&](const void* pp, const void* pn, float x, float y) {
+    prev.push_back(pp);
+    next.push_back(pn);
+    pts.push_back(x);
+    pts.push_back(y);
+  };
+  for (int f = 0; f < n_frames; ++f) {
+    const int nb = f < Wq ? f : Wq, npre = (Wq - nb) < q0 ? (Wq - nb) : q0;
+    for (int e = q0 - npre; e < q0; ++e) {
+      const auto& fr = T.queue[(size_t)e];
+      if (fr.second.empty()) continue;
+      const auto it = F.pyr.find(fr.first);
+      if (it == F.pyr.end()) return sa::fail(SA_ERR_INVALID_ARG, "flow tracker: the frame of time step %d was tracked without an image", fr.first);
+      for (const Inst& a : fr.second) {
+        B.at[Tracker::FlowBatch::key(a.fserial, a.src, f)] = prev.size();
+        for (size_t j = 0; j < a.pts.size() / 2; ++j) add_point(it->second, bp[(size_t)f], (float)a.pts[2 * j], (float)a.pts[2 * j + 1]);
+      }
+    }
+    for (int fbk = f - nb; fbk < f; ++fbk)
+      for (int i = 0; i < n_valid[fbk]; ++i) {
+        B.at[Tracker::FlowBatch::key(B.first_serial + fbk, i, f)] = prev.size();
+        const float* q = points + ((size_t)fbk * max_inst + i) * n_nodes * 2;
+        for (int j = 0; j < n_nodes; ++j) {
+          const bool nan = std::isnan(q[2 * j]) || std::isnan(q[2 * j + 1]);  // make_inst: such nodes are NaN in both coordinates
+          add_point(bp[(size_t)fbk], bp[(size_t)f], nan ? std::numeric_limits<float>::quiet_NaN() : q[2 * j],
+                    nan ? std::numeric_limits<float>::quiet_NaN() : q[2 * j + 1]);
+        }
+      }
+  }
+  const size_t n = prev.size();
+  B.shifted.assign(2 * n, 0.0f);
+  B.st.assign(n, 0);
+  if (n) {
+    const size_t need = n * (2 * sizeof(void*) + 2 * sizeof(float) * 2 + sizeof(float) + 1) + 256;
+    if (need > F.scratch_bytes) {
+      if (F.scratch) (void)hipFree(F.scratch);
+      F.scratch = nullptr;
+      F.scratch_bytes = 0;
+      SA_HIP_CHECK(hipMalloc(&F.scratch, need * 2));
+      F.scratch_bytes = need * 2;
+    }
+    unsigned char* d = static_cast<unsigned char*>(F.scratch);
+    void* d_prev = d;
+    void* d_next = d + n * sizeof(void*);
+    float* d_pts = reinterpret_cast<float*>(d + 2 * n * sizeof(void*));
+    float* d_out = d_pts + 2 * n;
+    float* d_err = d_out + 2 * n;
+    uint8_t* d_st = reinterpret_cast<uint8_t*>(d_err + n);
+    SA_HIP_CHECK(hipMemcpyAsync(d_prev, prev.data(), n * sizeof(void*), hipMemcpyHostToDevice, F.stream));
+    SA_HIP_CHECK(hipMemcpyAsync(d_next, next.data(), n * sizeof(void*), hipMemcpyHostToDevice, F.stream));
+    SA_HIP_CHECK(hipMemcpyAsync(d_pts, pts.data(), 2 * n * sizeof(float), hipMemcpyHostToDevice, F.stream));
+    const int rc = sa_flow_lk_pairs(static_cast<const void* const*>(d_prev), static_cast<const void* const*>(d_next), F.H, F.W,
+                                    c.of_window_size, c.of_max_levels, (int)n, d_pts, d_out, d_st, d_err, 30, 0.01f, F.stream);
+    if (rc != SA_OK) return rc;
+    SA_HIP_CHECK(hipMemcpyAsync(B.shifted.data(), d_out, 2 * n * sizeof(float), hipMemcpyDeviceToHost, F.stream));
+    SA_HIP_CHECK(hipMemcpyAsync(B.st.data(), d_st, n, hipMemcpyDeviceToHost, F.stream));
+  }
+  SA_HIP_CHECK(hipStreamSynchronize(F.stream));
+  // ---- frame-by-frame matching on the looked-up shifts
+  B.active = true;
+  int rc = SA_OK;
+  std::vector<Inst> tracked;
+  std::vector<double> ts;
+  for (int f = 0; f < n_frames && rc == SA_OK; ++f) {
+    F.cur = bp[(size_t)f];
+    bp[(size_t)f] = nullptr;
+    std::vector<Inst> untracked;
+    for (int i = 0; i < n_valid[f]; ++i) {
+      const size_t o = (size_t)f * max_inst + i;
+      untracked.push_back(make_inst(points + o * n_nodes * 2, point_scores ? point_scores + o * n_nodes : nullptr,
+                                    inst_scores ? inst_scores[o] : 0.0f, n_nodes, i));
+    }
+    for (int i = 0; i < max_inst; ++i) {
+      const size_t o = (size_t)f * max_inst + i;
+      out_track[o] = -1;
+      if (out_score) out_score[o] = NaN;
+      if (out_order) out_order[o] = -1;
+    }
+    rc = track_one(T, std::move(untracked), img_h, img_w, frame_t ? frame_t[f] : (t0 < 0 ? -1 : t0 + f), tracked, ts);
+    if (rc != SA_OK) break;
+    for (size_t k = 0; k < tracked.size(); ++k) {
+      const size_t o = (size_t)f * max_inst + tracked[k].src;
+      out_track[o] = tracked[k].track;
+      if (out_score) out_score[o] = ts[k];
+      if (out_order) out_order[o] = (int)k;
+    }
+  }
+  B.active = false;
+  B.at.clear();
+  for (void* b : bp)
+    if (b) F.pool.push_back(b);
+  return rc;
 }
 
 }  // namespace
@@ -760,6 +951,23 @@ int sa_tracker_track_frames_images(void* h, int n_frames, int max_inst, int n_no
   Tracker* T = static_cast<Tracker*>(h);
   SA_REQUIRE(!T->c.flow || images, "sa_tracker_track_frames_images: a flow tracker needs the frames");
   const size_t stride_f = (size_t)max_inst;
+  if (T->c.flow && !T->c.max_tracks_mode && n_frames > 1) {
+    // ---- the flow of every (queued frame, target frame) pair of this run in ONE Lucas-Kanade launch (FlowBatch), in runs of
+    // <= 128 frames (a 1024 x 1024 pyramid is 6.7 MB)
+    constexpr int RUN = 128;
+    for (int f0 = 0; f0 < n_frames; f0 += RUN) {
+      const int nf = n_frames - f0 < RUN ? n_frames - f0 : RUN;
+      const int rc = flow_batch_run(*T, nf, max_inst, n_nodes, points + (size_t)f0 * stride_f * n_nodes * 2,
+                                    point_scores ? point_scores + (size_t)f0 * stride_f * n_nodes : nullptr,
+                                    inst_scores ? inst_scores + (size_t)f0 * stride_f : nullptr, n_valid + f0, img_h, img_w,
+                                    t0 < 0 ? -1 : t0 + f0, frame_t ? frame_t + f0 : nullptr,
+                                    static_cast<const uint8_t*>(images) + (size_t)f0 * frame_h * frame_w * C, frame_h, frame_w, C, stream,
+                                    out_track + (size_t)f0 * stride_f, out_score ? out_score + (size_t)f0 * stride_f : nullptr,
+                                    out_order ? out_order + (size_t)f0 * stride_f : nullptr);
+      if (rc != SA_OK) return rc;
+    }
+    return SA_OK;
+  }
   for (int f = 0; f < n_frames; ++f) {
     if (T->c.flow) {
       const int rc = sa_tracker_set_image(h, static_cast<const uint8_t*>(images) + (size_t)f * frame_h * frame_w * C, frame_h, frame_w, C,

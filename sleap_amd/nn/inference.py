@@ -89,6 +89,7 @@ class InferenceLayer:
         self._net_stream = None
         self._copy_stream = None
         self.last_upload_done = None  # event: the most recent host batch has been copied to the device
+        self.last_upload = None       # that batch on the device
         self._slot = 0
         self._slot_free = [None, None]
         self._pending_slot = None
@@ -128,6 +129,7 @@ class InferenceLayer:
             ns.wait_event(up)
             data = dict(data, image=dev) if isinstance(data, dict) else dev
             self.last_upload_done = up
+            self.last_upload = dev  # the frames on the device (a flow tracker reads them again; the caller drops the reference)
         if self._slot_free[slot] is not None:
             ns.wait_event(self._slot_free[slot])  # the consumer of this slot's previous outputs has finished
         with torch.cuda.stream(ns):
@@ -1054,7 +1056,7 @@ class Predictor:
 
     def predict(self, data, make_labels: bool = True):
         """inference.py:496-531 (see BottomUpPredictor.predict for the output contract)."""
-        outs = self._apply_tracker(list(self._predict_generator(data)), data)
+        outs = self._apply_tracker(self._predict_generator(data), data)
         return self._make_labels(outs, data) if make_labels else outs
 
     def _skeleton_info(self):
@@ -1116,26 +1118,33 @@ class Predictor:
                 ex["instance_scores"] = np.nansum(np.asarray(ex["instance_peak_vals"], np.float32), axis=-1)
         return outs
 
-    def _apply_tracker(self, outs: List[Dict[str, np.ndarray]], data=None) -> List[Dict[str, np.ndarray]]:
+    def _apply_tracker(self, outs, data=None) -> List[Dict[str, np.ndarray]]:
         """Identity tracking over the gathered per-batch arrays, strictly in frame order, where the reference runs it
-        (inference.py:3306-3313, 3345-3346). Adds `track_inds (b, I)` (-1 = no track), `tracking_scores (b, I)` and
-        `track_order (b, I)` (position in the tracker's returned list) to every batch (`data`: the source, for flow trackers); `predictor.tracker.spawned_tracks`
+        (inference.py:3306-3313, 3345-3346). `outs` may be the predict generator itself: every batch is tracked as soon as it
+        arrives, i.e. while the device already runs the next batch's network (the generator keeps two batches in flight), so
+        the tracker -- host matching, and for flow trackers the Lucas-Kanade launches -- overlaps inference instead of
+        following it. Adds `track_inds (b, I)` (-1 = no track), `tracking_scores (b, I)` and `track_order (b, I)` (position in
+        the tracker's returned list) to every batch (`data`: the source, for flow trackers); `predictor.tracker.spawned_tracks`
         names the tracks. What reaches the tracker is what the reference hands it (`tracking.select_instances`): all-NaN
         instances dropped, and -- bottom-up only (inference.py:3297-3304) -- the `max_instances` best by score, in that
         order. Requires the array tracker of `sleap_amd.nn.tracking`."""
-        outs = self._instance_scores(outs)
         trk = self.tracker
-        if not trk or not outs or not hasattr(trk, "track_frames"):
-            return outs
-        from .tracking import finish_tracks, frames_of, image_hw_of, track_example
+        tracking = bool(trk) and hasattr(trk, "track_frames")
+        if tracking:
+            from .tracking import finish_tracks, frames_of, image_hw_of, track_example
 
-        cap = getattr(self, "max_instances", None) if isinstance(self, BottomUpPredictor) else None
+            cap = getattr(self, "max_instances", None) if isinstance(self, BottomUpPredictor) else None
+        done = []
         for ex in outs:
-            # flow trackers look at the frames (tracker.track(..., img=...), inference.py:2662-2668, 3306-3313): the carried
-            # `image`, or re-read from the source on the rank that tracks
-            track_example(trk, ex, img_hw=image_hw_of(ex), max_instances=cap,
-                          images=frames_of(ex, data) if getattr(trk, "uses_image", False) else None)
-        return finish_tracks(outs, trk)
+            self._instance_scores([ex])
+            if tracking:
+                # flow trackers look at the frames (tracker.track(..., img=...), inference.py:2662-2668, 3306-3313): the
+                # carried `image`, or re-read from the source on the rank that tracks
+                track_example(trk, ex, img_hw=image_hw_of(ex), max_instances=cap,
+                              images=frames_of(ex, data) if getattr(trk, "uses_image", False) else None)
+            ex.pop("image_dev", None)  # the device copy of the frames was only kept for the tracker
+            done.append(ex)
+        return finish_tracks(done, trk) if (tracking and done) else done
 
 
 class SingleInstancePredictor(Predictor):
@@ -1410,6 +1419,9 @@ class BottomUpPredictor(Predictor):
             packed, t["ig"] = run_shard(t["batch"])
             if t["batch"] is not None:
                 t["up"] = layer.last_upload_done
+                if world == 1 and getattr(self.tracker, "uses_image", False):
+                    t["image_dev"] = layer.last_upload  # a flow tracker reads the frames where they already are
+                layer.last_upload = None
                 if world == 1:
                     if src is None:
                         t["image"] = t["batch"].numpy().copy()  # the page-locked buffer is recycled
@@ -1456,6 +1468,8 @@ class BottomUpPredictor(Predictor):
             ex["image_hw"] = image_hw
             if world == 1:
                 ex["image"] = t["image"]
+                if t.get("image_dev") is not None:
+                    ex["image_dev"] = t["image_dev"]
             return ex
 
         self.make_pipeline(reader)
@@ -1482,7 +1496,7 @@ class BottomUpPredictor(Predictor):
         (`instance_peaks (b, Imax, N, 2)` NaN-padded, `instance_peak_vals`, `instance_scores`, `n_valid`,
         `video_ind`, `frame_ind`, ...). `make_labels=True` (the reference's default) returns the array-backed
         `sleap_amd.io.labels.Labels` (`len`, indexing, `.numpy()`, `.save("x.slp")`, `.to_sleap()`)."""
-        outs = self._apply_tracker(list(self._predict_generator(data)), data)
+        outs = self._apply_tracker(self._predict_generator(data), data)
         return self._make_labels(outs, data) if make_labels else outs
 
 

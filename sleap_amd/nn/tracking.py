@@ -285,6 +285,8 @@ def select_instances(ex, max_instances: Optional[int] = None):
 def frames_of(ex, data=None):
     """The frames of one prediction dict for a flow tracker: the carried `image` (single-GPU bottom-up runs), else re-read from
     the source the predictor was given (array, `Video`, `VideoReader`) by `frame_ind`."""
+    if ex.get("image_dev") is not None:  # the batch as the predictor uploaded it (single-GPU runs): nothing to copy
+        return ex["image_dev"]
     if ex.get("image") is not None:
         return ex["image"]
     idx = [int(i) for i in np.asarray(ex["frame_ind"])]

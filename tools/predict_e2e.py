@@ -3,7 +3,7 @@
 The FramePrefetcher stages this rank's batches in page-locked buffers and uploads them on the network stream while the previous
 batch computes. Reported next to the HBM-resident bench line in DESIGN.md section 5 (it is never bench.py's `value`).
 
-    python tools/predict_e2e.py [T] [make_labels]
+    python tools/predict_e2e.py [T] [labels|arrays] [tracker name, e.g. flow]
 """
 import sys
 import time
@@ -17,6 +17,10 @@ from sleap_amd.synth import render_frames
 T = int(sys.argv[1]) if len(sys.argv) > 1 else 1280
 labels = len(sys.argv) > 2 and sys.argv[2] == "labels"
 pred, _, _ = build_benchmark_predictor(1024, 1024, batch_size=64, seed=0)
+if len(sys.argv) > 3:
+    from sleap_amd.nn.tracking import Tracker
+
+    pred.tracker = Tracker.make_tracker_by_name(tracker=sys.argv[3], track_window=5)
 base = render_frames(16, 1024, 1024, n_animals=4, seed=100)[0]
 frames = np.ascontiguousarray(np.tile(base, (T // 16, 1, 1, 1)))
 pred.predict(frames[:128], make_labels=False)  # warm-up: buffers, pinned ring
@@ -25,4 +29,6 @@ for rep in range(3):
     out = pred.predict(frames, make_labels=labels)
     dt = time.perf_counter() - t0
     n = len(out) if labels else sum(len(o["n_valid"]) for o in out)
-    print(f"predict(make_labels={labels}): {T} host frames in {dt * 1e3:.1f} ms = {T / dt:.0f} frames/s ({n} results)", flush=True)
+    if pred.tracker is not None:
+        pred.tracker.reset_candidates()
+    print(f"predict(make_labels={labels}, tracker={sys.argv[3] if len(sys.argv) > 3 else None}): {T} host frames in {dt * 1e3:.1f} ms = {T / dt:.0f} frames/s ({n} results)", flush=True)
