@@ -514,15 +514,23 @@ int track_one(Tracker& T, std::vector<Inst> untracked, int img_h, int img_w, int
           order.push_back(g);
         }
       }
-      if (T.fb.active && !c.max_tracks_mode) {
-        // the shifts were computed for the whole run of frames (see FlowBatch): look them up
+      if (T.fb.active) {
+        // the shifts were computed for the whole run of frames (see FlowBatch): look them up. A group none of whose shifts were
+        // computed ahead (max-tracks mode: a track that went unmatched keeps items older than the run looked back) is shifted now.
         const int f = (int)(my_serial - T.fb.first_serial);
         shifted.assign(groups.size(), {});
-        for (size_t g = 0; g < groups.size(); ++g)
+        std::vector<std::pair<int, std::vector<const Inst*>>> miss;
+        std::vector<size_t> miss_g;
+        for (size_t g = 0; g < groups.size(); ++g) {
+          bool all = true;
+          for (const Inst* a : groups[g].second) all = all && T.fb.at.count(Tracker::FlowBatch::key(a->fserial, a->src, f)) != 0;
+          if (!all) {
+            miss.push_back(groups[g]);
+            miss_g.push_back(g);
+            continue;
+          }
           for (const Inst* a : groups[g].second) {
-            const auto it = T.fb.at.find(Tracker::FlowBatch::key(a->fserial, a->src, f));
-            if (it == T.fb.at.end()) return sa::fail(SA_ERR_INVALID_ARG, "flow tracker: no precomputed shift for a queued instance");
-            const size_t k = it->second, m = a->pts.size() / 2;
+            const size_t k = T.fb.at.find(Tracker::FlowBatch::key(a->fserial, a->src, f))->second, m = a->pts.size() / 2;
             int found = 0;
             for (size_t j = 0; j < m; ++j) found += T.fb.st[k + j] ? 1 : 0;
             if (found <= c.min_match_points) continue;
@@ -540,6 +548,13 @@ int track_one(Tracker& T, std::vector<Inst> untracked, int img_h, int img_w, int
             }
             shifted[g].push_back(std::move(b));
           }
+        }
+        if (!miss.empty()) {
+          std::vector<std::vector<Inst>> late;
+          const int rc = flow_shift(T, miss, late);
+          if (rc != SA_OK) return rc;
+          for (size_t i = 0; i < miss_g.size(); ++i) shifted[miss_g[i]] = std::move(late[i]);
+        }
       } else {
         const int rc = flow_shift(T, groups, shifted);
         if (rc != SA_OK) return rc;
@@ -725,7 +740,22 @@ int flow_batch_run(Tracker& T, int n_frames, int max_inst, int n_nodes, const fl
     pts.push_back(y);
   };
   for (int f = 0; f < n_frames; ++f) {
-    const int nb = f < Wq ? f : Wq, npre = (Wq - nb) < q0 ? (Wq - nb) : q0;
+    const int nb = f < Wq ? f : Wq;
+    if (c.max_tracks_mode) {
+      // per-track queues: which earlier frames a track still holds when frame f arrives depends on the matching; computed ahead
+      // are the likely ones -- everything queued now, into the first track_window frames of the run, and the detections of the
+      // track_window frames before f -- anything else is shifted on demand (track_one)
+      if (f < Wq)
+        for (const auto& kv : T.qdict)
+          for (const auto& ti : kv.second) {
+            const auto it = F.pyr.find(ti.first);
+            if (it == F.pyr.end()) return sa::fail(SA_ERR_INVALID_ARG, "flow tracker: the frame of time step %d was tracked without an image", ti.first);
+            const Inst& a = ti.second;
+            B.at[Tracker::FlowBatch::key(a.fserial, a.src, f)] = prev.size();
+            for (size_t j = 0; j < a.pts.size() / 2; ++j) add_point(it->second, bp[(size_t)f], (float)a.pts[2 * j], (float)a.pts[2 * j + 1]);
+          }
+    }
+    const int npre = c.max_tracks_mode ? 0 : ((Wq - nb) < q0 ? (Wq - nb) : q0);
     for (int e = q0 - npre; e < q0; ++e) {
       const auto& fr = T.queue[(size_t)e];
       if (fr.second.empty()) continue;
@@ -951,7 +981,7 @@ int sa_tracker_track_frames_images(void* h, int n_frames, int max_inst, int n_no
   Tracker* T = static_cast<Tracker*>(h);
   SA_REQUIRE(!T->c.flow || images, "sa_tracker_track_frames_images: a flow tracker needs the frames");
   const size_t stride_f = (size_t)max_inst;
-  if (T->c.flow && !T->c.max_tracks_mode && n_frames > 1) {
+  if (T->c.flow && n_frames > 1) {
     // ---- the flow of every (queued frame, target frame) pair of this run in ONE Lucas-Kanade launch (FlowBatch), in runs of
     // <= 128 frames (a 1024 x 1024 pyramid is 6.7 MB)
     constexpr int RUN = 128;

@@ -151,7 +151,13 @@ def test_flow_tracker_equals_oracle(kw):
         assert len(nat.spawned_tracks) == 3
 
 
-def test_flow_tracker_batched_frames_equal_single_steps():
+@pytest.mark.parametrize("kw", [dict(tracker="flow"), dict(tracker="flow", track_window=2, min_match_points=1),
+                                dict(tracker="flowmaxtracks", max_tracks=3, max_tracking=True),
+                                dict(tracker="flowmaxtracks", max_tracks=2, max_tracking=True, track_window=3)])
+def test_flow_tracker_batched_frames_equal_single_steps(kw):
+    """track_frames(images=...) shifts the queued instances of a whole run of frames in ONE Lucas-Kanade launch before the
+    frame-by-frame matching (max-tracks mode: with an on-demand launch for what was not computed ahead); per-frame track()
+    launches per frame. Same tracks, same scores, also when the run continues a queue filled by earlier calls."""
     from sleap_amd.nn.tracking import Tracker
 
     frames, insts = _moving_scene(seed=3)
@@ -165,12 +171,18 @@ def test_flow_tracker_batched_frames_equal_single_steps():
         nv[f] = len(lst)
         for i, (p, s, c) in enumerate(lst):
             pts[f, i], vals[f, i], sc[f, i] = p, s, c
-    a = Tracker.make_tracker_by_name(tracker="flow")
+    a = Tracker.make_tracker_by_name(**kw)
     one = [a.track(pts[f, :nv[f]], vals[f, :nv[f]], sc[f, :nv[f]], img_hw=(h, w), img=frames[f]) for f in range(F)]
-    b = Tracker.make_tracker_by_name(tracker="flow")
-    r = b.track_frames(pts, vals, sc, nv, img_hw=(h, w), images=frames)
+    b = Tracker.make_tracker_by_name(**kw)
+    cut = 5  # two runs: the second one starts from the queue the first one left
+    r1 = b.track_frames(pts[:cut], vals[:cut], sc[:cut], nv[:cut], img_hw=(h, w), images=frames[:cut])
+    r2 = b.track_frames(pts[cut:], vals[cut:], sc[cut:], nv[cut:], img_hw=(h, w), images=frames[cut:])
+    r = {k: np.concatenate([r1[k], r2[k]]) for k in r1}
     for f in range(F):
-        assert list(r["track"][f, one[f]["index"]]) == list(one[f]["track"])
+        assert list(r["track"][f, one[f]["index"]]) == list(one[f]["track"]), f
+        assert np.array_equal(r["tracking_score"][f, one[f]["index"]], one[f]["tracking_score"]), f
+        assert list(r["order"][f, one[f]["index"]]) == list(range(len(one[f]["index"]))), f
         assert (r["track"][f, nv[f]:] == -1).all()
+    assert a.spawned_tracks == b.spawned_tracks
     with pytest.raises(ValueError):
         Tracker.make_tracker_by_name(tracker="flow").track_frames(pts, vals, sc, nv, img_hw=(h, w))
