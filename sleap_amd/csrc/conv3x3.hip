@@ -256,6 +256,8 @@ struct ConvParams2 {
   int planar;
   int pix_bytes0, pix_bytes1;  // bytes between consecutive pixels of src0 / src1 (NHWC: 2 CP; planes: 32)
   unsigned blk_bytes_in;       // bytes between consecutive 16-channel blocks of a source (NHWC: 32; planes: H W 32)
+  int out_pix_bytes;           // the same for the outputs: pixel stride (NHWC: 2 CoutP; planes: 32),
+  unsigned out_blk_bytes, out_blk_bytes_pool;  // 16-channel block stride of dst / dst_pool (NHWC: 32; planes: pixels per frame x 32)
 };
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -683,7 +685,9 @@ conv3x3_dma_kernel(const ConvParams2 p) {
     }
     const float lowv = p.relu ? 0.0f : -INFINITY;  // ReLU as one v_max against a wave-uniform bound
     auto act = [&](int r, int g, int j) {
-      float t = fmaxf(acc[m][r][4 * g + j] + bb[g][j], lowv);
+      float t = acc[m][r][4 * g + j];
+      if constexpr (!BIAS_INIT) t += bb[g][j];  // (with the bias as the accumulators' initial value there is nothing to add:
+      t = fmaxf(t, lowv);                       //  an `acc + 0.0f` is NOT dropped by the compiler -- 112 dead v_add per tile)
       if constexpr (EXT) {
         t = fmaf(t, ps[g][j], pt[g][j]);
         if (p.residual) {
@@ -698,38 +702,47 @@ conv3x3_dma_kernel(const ConvParams2 p) {
       }
       return t;
     };
-    // `frame` = the output frame of this tile, `pix` = pixel index inside it, `npix` = pixels per frame. NHWC: channel co of
-    // a pixel at pix * CoutP + co; planes: plane co >> 4 at (co >> 4) * npix * 16, 16 channels per pixel inside it
-    auto store_pieces = [&](uint16_t* frame, size_t pix, size_t npix, bool ok, const uint2 (&pk)[4]) {
+    // Store addressing: everything that does not depend on the lane -- frame, 16-channel block, row of the tile -- goes into a
+    // wave-uniform 64-bit base (scalar registers); the lane contributes ONE 32-bit byte offset per tile and output (its column,
+    // its 8-channel half), so a store is `global_store_dwordx4 v_off, v_data, s[base]` with no vector address arithmetic (the
+    // first version rebuilt a 64-bit address per store: ~100 VALU instructions per tile). A frame is < 4 GiB (checked on the host).
+    // base(blk16, row) = frame + blk16 * blk_bytes + row * row_bytes;  NHWC: blk_bytes = 32, planes: npix * 32
+    auto store_pieces = [&](unsigned char* row_base, unsigned blk_bytes, unsigned lane_off, bool ok, const uint2 (&pk)[4]) {
 #pragma unroll
       for (int pr = 0; pr < 2; ++pr) {
         // lower half-wave: own group 2pr (channels 0-3) + partner's (4-7); upper: partner's group 2pr+1 + own
         uint2 a = pk[2 * pr], c = pk[2 * pr + 1];
         sa::swap32(a.x, c.x);
         sa::swap32(a.y, c.y);
-        const int co = cobase + 16 * pr + 8 * half;
-        uint16_t* q = frame + (size_t)(co >> 4) * (p.planar ? npix * 16 : (size_t)16) + pix * (p.planar ? 16 : p.CoutP) + 8 * half;
-        if (ok && co < p.CoutP) *reinterpret_cast<uint4*>(q) = make_uint4(a.x, a.y, c.x, c.y);
+        const int co16 = (cobase >> 4) + pr;  // 16-channel block of this piece (wave uniform)
+        if (ok && co16 * 16 < p.CoutP)
+          *reinterpret_cast<uint4*>(row_base + (size_t)co16 * blk_bytes + lane_off) = make_uint4(a.x, a.y, c.x, c.y);
       }
     };
+    const bool colok = gx < W;
     if (p.dst) {
+      const unsigned pixb = (unsigned)p.out_pix_bytes;
+      unsigned char* frame = reinterpret_cast<unsigned char*>(p.dst) + (size_t)b * H * W * p.CoutP * 2;
+      const unsigned lane_off = (unsigned)gx * pixb + (unsigned)half * 16u;
 #pragma unroll
       for (int r = 0; r < R; ++r) {
-        const int gy = y0 + wave * R + r;
+        const int gy = y0 + wave * R + r;  // wave uniform
         uint2 pk[4];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           pk[g].x = sa::f2h2(act(r, g, 0), act(r, g, 1));
           pk[g].y = sa::f2h2(act(r, g, 2), act(r, g, 3));
         }
-        const bool ok = gy < H && gx < W;
-        store_pieces(p.dst + (size_t)b * H * W * p.CoutP, (size_t)(ok ? gy : 0) * W + (ok ? gx : 0), (size_t)H * W, ok, pk);
+        store_pieces(frame + (size_t)gy * W * pixb, p.out_blk_bytes, lane_off, colok && gy < H, pk);
       }
     }
     if constexpr (R >= 2) if (p.dst_pool) {
+      const unsigned pixb = (unsigned)p.out_pix_bytes;
+      unsigned char* frame = reinterpret_cast<unsigned char*>(p.dst_pool) + (size_t)b * (H / 2) * (W / 2) * p.CoutP * 2;
+      const unsigned lane_off = (unsigned)(gx >> 1) * pixb + (unsigned)half * 16u;
 #pragma unroll
       for (int r = 0; r < R; r += 2) {
-        const int gy = y0 + wave * R + r;
+        const int gy = y0 + wave * R + r;  // wave uniform, even
         uint2 pk[4];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -742,9 +755,7 @@ conv3x3_dma_kernel(const ConvParams2 p) {
           pk[g].x = sa::f2h2(t4[0], t4[1]);
           pk[g].y = sa::f2h2(t4[2], t4[3]);
         }
-        const bool ok = !(lane_e & 1) && gy < H && gx < W;
-        store_pieces(p.dst_pool + (size_t)b * (H / 2) * (W / 2) * p.CoutP, (size_t)(ok ? gy / 2 : 0) * (W / 2) + (ok ? gx / 2 : 0),
-                     (size_t)(H / 2) * (W / 2), ok, pk);
+        store_pieces(frame + (size_t)(gy >> 1) * (W / 2) * pixb, p.out_blk_bytes_pool, lane_off, !(lane_e & 1) && colok && gy < H, pk);
       }
     }
   }
@@ -867,6 +878,10 @@ int launch2(const ConvParams2& p, hipStream_t st) {
   q.pix_bytes0 = p.planar ? 32 : p.C0P * 2;
   q.pix_bytes1 = p.planar ? 32 : p.C1P * 2;
   q.blk_bytes_in = p.planar ? (unsigned)((size_t)p.H * p.W * 32) : 32u;
+  q.out_pix_bytes = p.planar ? 32 : p.CoutP * 2;
+  q.out_blk_bytes = p.planar ? (unsigned)((size_t)p.H * p.W * 32) : 32u;
+  q.out_blk_bytes_pool = p.planar ? (unsigned)((size_t)(p.H / 2) * (p.W / 2) * 32) : 32u;
+  if ((size_t)p.H * p.W * p.CoutP * 2 >= 0xFFFFFF00ull) return sa::fail(SA_ERR_UNSUPPORTED, "sa_conv3x3_bf16: one output frame must be smaller than 4 GiB");
   const size_t nblk = (size_t)q.tiles_x * q.tiles_y * q.co_tiles * p.B;
   if (nblk > 0x7fffffffull) return sa::fail(SA_ERR_INVALID_ARG, "sa_conv3x3_bf16: grid too large");
   if (!STEM_CIN && (size_t)p.H * p.W * (p.C0P > p.C1P ? p.C0P : p.C1P) * 2 >= 0xFFFFFF00ull)
