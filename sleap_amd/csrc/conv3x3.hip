@@ -807,7 +807,8 @@ conv3x3_dma_kernel(const ConvParams2 p) {
             h16x8_t fq;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-              const float t = acc[m][r][8 * s2 + j] + bb[j];
+              float t = acc[m][r][8 * s2 + j];
+              if constexpr (!BIAS_INIT) t += bb[j];
               fq[j] = sa::f2h(p.relu ? fmaxf(t, 0.0f) : t);
             }
             const mfma_h8 bf = __builtin_bit_cast(mfma_h8, fq);

@@ -238,33 +238,40 @@ convpair_16_32_32_kernel(const PairParams p) {
   const float low_b = p.relu_b ? 0.0f : -INFINITY;
   const int gx = x0 + lx;
   auto act = [&](int r, int g, int j) { return fmaxf(acc[r][4 * g + j] + bb[g][j], low_b); };
-  // `frame`: this tile's output frame, `pix`: pixel inside it, `npix`: pixels per frame; piece pr = channels 16 pr + 8 half ..
-  auto store_pieces = [&](uint16_t* frame, size_t pix, size_t npix, bool ok, const uint2 (&pk)[4]) {
+  // store addressing as in conv3x3_dma_kernel: frame, 16-channel block and tile row in a wave-uniform base, ONE 32-bit byte offset
+  // per lane and output (column, 8-channel half); piece pr = channels 16 pr + 8 half ..
+  auto store_pieces = [&](unsigned char* row_base, size_t blk_bytes, unsigned lane_off, bool ok, const uint2 (&pk)[4]) {
 #pragma unroll
     for (int pr = 0; pr < 2; ++pr) {
       uint2 x = pk[2 * pr], y = pk[2 * pr + 1];
       sa::swap32(x.x, y.x);
       sa::swap32(x.y, y.y);
-      uint16_t* q = p.planar ? frame + ((size_t)pr * npix + pix) * 16 + 8 * half : frame + pix * 32 + 16 * pr + 8 * half;
-      if (ok) *reinterpret_cast<uint4*>(q) = make_uint4(x.x, x.y, y.x, y.y);
+      if (ok) *reinterpret_cast<uint4*>(row_base + (size_t)pr * blk_bytes + lane_off) = make_uint4(x.x, x.y, y.x, y.y);
     }
   };
+  const unsigned pixb = p.planar ? 32u : 64u;  // bytes per pixel record: one 16-channel plane, or all 32 channels
+  const bool col_in = gx < W;
   if (p.dst) {
+    unsigned char* frame = reinterpret_cast<unsigned char*>(p.dst) + (size_t)b * H * W * 64;
+    const size_t blk = p.planar ? (size_t)H * W * 32 : (size_t)32;
+    const unsigned lane_off = (unsigned)gx * pixb + (unsigned)half * 16u;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-      const int gy = y0 + wave * R + r;
+      const int gy = y0 + wave * R + r;  // wave uniform
       uint2 pk[4];
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         pk[g].x = sa::f2h2(act(r, g, 0), act(r, g, 1));
         pk[g].y = sa::f2h2(act(r, g, 2), act(r, g, 3));
       }
-      const bool ok = gy < H && gx < W;
-      store_pieces(p.dst + (size_t)b * H * W * 32, (size_t)(ok ? gy : 0) * W + (ok ? gx : 0), (size_t)H * W, ok, pk);
+      store_pieces(frame + (size_t)gy * W * pixb, blk, lane_off, col_in && gy < H, pk);
     }
   }
   if (p.dst_pool) {
-    const int gy = y0 + wave * R;
+    const int gy = y0 + wave * R;  // wave uniform, even
+    unsigned char* frame = reinterpret_cast<unsigned char*>(p.dst_pool) + (size_t)b * (H / 2) * (W / 2) * 64;
+    const size_t blk = p.planar ? (size_t)(H / 2) * (W / 2) * 32 : (size_t)32;
+    const unsigned lane_off = (unsigned)(gx >> 1) * pixb + (unsigned)half * 16u;
     uint2 pk[4];
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
@@ -277,9 +284,7 @@ convpair_16_32_32_kernel(const PairParams p) {
       pk[g].x = sa::f2h2(t4[0], t4[1]);
       pk[g].y = sa::f2h2(t4[2], t4[3]);
     }
-    const bool ok = !(lane & 1) && gy < H && gx < W;
-    store_pieces(p.dst_pool + (size_t)b * (H / 2) * (W / 2) * 32, (size_t)(ok ? gy / 2 : 0) * (W / 2) + (ok ? gx / 2 : 0),
-                 (size_t)(H / 2) * (W / 2), ok, pk);
+    store_pieces(frame + (size_t)(gy >> 1) * (W / 2) * pixb, blk, lane_off, !(lane & 1) && col_in && gy < H, pk);
   }
 #endif
 }
