@@ -14,8 +14,9 @@ launches (include/sleap_amd.h):
                                                            -> sa_conv3x3_ex_bf16 (post-affine + residual epilogue)
     first Conv2D of any kernel size / stride (hourglass stem k7 s2) -> sa_image_conv_bf16
 
-Activations are bf16 NHWC with channels padded to a multiple of 16; accumulation is fp32.
-torch is used for device memory only.
+Activations are 16-bit (fp16 by default, bf16 optional) with channels padded to a multiple of 16, stored as 16-channel planes
+[B, CP/16, H, W, 16] when every launch of the plan supports them (the UNet family) and NHWC otherwise (`DeviceNetwork.layout`);
+accumulation is fp32. torch is used for device memory only.
 """
 import ctypes as C
 import json
