@@ -715,7 +715,7 @@ conv3x3_dma_kernel(const ConvParams2 p) {
         sa::swap32(a.x, c.x);
         sa::swap32(a.y, c.y);
         const int co16 = (cobase >> 4) + pr;  // 16-channel block of this piece (wave uniform)
-        if (ok && co16 * 16 < p.CoutP)
+        if (ok && co16 * 16 < p.CoutP)  // (non-temporal stores: measured, no effect -- profiles/r02_ab_session.md)
           *reinterpret_cast<uint4*>(row_base + (size_t)co16 * blk_bytes + lane_off) = make_uint4(a.x, a.y, c.x, c.y);
       }
     };
