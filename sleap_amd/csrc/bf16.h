@@ -97,6 +97,21 @@ __device__ __forceinline__ float up2_lerp(float tl, float tr, float bl, float br
   return t + (b - t) * wy;
 }
 
+#if defined(__HIP_DEVICE_COMPILE__)
+// max of a packed pair of 16-bit values with a packed bound (ReLU: bound 0, none: -inf): ONE v_pk_max_f16 for two values in the
+// fp16 build. Rounding to 16 bits is monotonic, so max(round(a), bound) == round(max(a, bound)) (up to the sign of a zero).
+#if defined(SA_HALF_FP16)
+#define SA_HAS_PK_MAX 1
+__device__ __forceinline__ uint32_t pk_max(uint32_t v, uint32_t bound) {
+  typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+  return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(h2, v), __builtin_bit_cast(h2, bound)));
+}
+#define SA_PK_NEG_INF 0xFC00FC00u
+#else
+#define SA_HAS_PK_MAX 0
+#endif
+#endif
+
 // four floats at dword alignment: stored with one global_store_dwordx4 (gfx950 global accesses need dword alignment only)
 struct __attribute__((packed, aligned(4))) f32x4_unaligned {
   float x, y, z, w;

@@ -14,6 +14,7 @@
 // conv0 precision: the B operand holds raw pixel values 0..255 (exact in bf16); the fp32 weights times 1/255 are
 // split into three bf16 terms (hi + mid + lo carries the full 24-bit mantissa), three MFMAs with fp32 accumulation.
 #include <cstdint>
+#include <type_traits>
 
 #include "bf16.h"
 #include "sa_common.h"
@@ -298,13 +299,31 @@ stem16_gray_kernel(const Stem16Params p) {
   // lane-dependent row / column walk, and this loop was the VALU-bound half of the kernel: 0.80 -> 0.63-0.68 ms).
   // Columns 32, 33 (36 pixels) are three more groups, done by waves 0-2 afterwards. (Measured and dropped: pairing two
   // groups with v_permlane16_swap into one 16-byte store per lane -- 2-way instead of 2 x 4-way bank conflicts -- 0.60 -> 0.63 ms.)
+  // VALU diet (round 2; the counters put this kernel at 0.72 of its VALU issue slots against 0.45 of the matrix-core cycles, and
+  // this loop held 11.5 VALU instructions per group of two MFMAs):
+  //   * tiles whose whole halo lies inside the image (all but the border ring) skip the per-value padding select;
+  //   * fp16 build: ReLU on the PACKED pair after the conversion (one v_pk_max_f16 for two values instead of two v_max_f32);
+  //   * the MFMA B operand is a register quad whose upper half is zero: kept as three persistent quads whose upper halves are
+  //     zeroed once, the table read fills the lower halves (the compiler re-zeroed two registers per group before).
   const float low0 = p.relu0 ? 0.0f : -__builtin_huge_valf();
-  auto conv0_store = [&](const f32x4 d, bool in_img, unsigned char* dstp) {
-    const unsigned m = in_img ? 0xFFFFFFFFu : 0u;  // outside the image: conv1's SAME padding = 0
-    *reinterpret_cast<uint2*>(dstp) = make_uint2(sa::f2h2(fmaxf(d[0], low0), fmaxf(d[1], low0)) & m,
-                                                 sa::f2h2(fmaxf(d[2], low0), fmaxf(d[3], low0)) & m);
+  const bool interior = x0 >= 1 && y0 >= 1 && x0 + PW - 1 <= W && y0 + PH - 1 <= H;  // wave (workgroup) uniform
+#if SA_HAS_PK_MAX
+  const uint32_t lowpk = p.relu0 ? 0u : SA_PK_NEG_INF;
+#endif
+  auto conv0_store = [&](const f32x4 d, bool masked, bool in_img, unsigned char* dstp) {
+#if SA_HAS_PK_MAX
+    uint32_t a = sa::pk_max(sa::f2h2(d[0], d[1]), lowpk), b = sa::pk_max(sa::f2h2(d[2], d[3]), lowpk);
+#else
+    uint32_t a = sa::f2h2(fmaxf(d[0], low0), fmaxf(d[1], low0)), b = sa::f2h2(fmaxf(d[2], low0), fmaxf(d[3], low0));
+#endif
+    if (masked) {  // (compile-time in the two copies of the loop below) outside the image: conv1's SAME padding = 0
+      const unsigned m = in_img ? 0xFFFFFFFFu : 0u;
+      a &= m;
+      b &= m;
+    }
+    *reinterpret_cast<uint2*>(dstp) = make_uint2(a, b);
   };
-  auto operand = [&](const uint2 tq) { return __builtin_bit_cast(mfma_h8, make_uint4(tq.x, tq.y, 0u, 0u)); };
+  (void)low0;
   {
     const int seg = wave & 1, tx = seg * 16 + n16;
     const bool colok = (unsigned)(x0 + tx - 1) < (unsigned)W;
@@ -321,32 +340,42 @@ stem16_gray_kernel(const Stem16Params p) {
 #endif
     auto rowok = [&](int it) { return (unsigned)(y0 + (wave >> 1) + 2 * it - 1) < (unsigned)H; };  // wave uniform
     // three groups at a time: the hi / mid / lo MFMAs of one group depend on each other, those of different groups do not
+    uint4 opq[3] = {make_uint4(0u, 0u, 0u, 0u), make_uint4(0u, 0u, 0u, 0u), make_uint4(0u, 0u, 0u, 0u)};
+    auto rows = [&](auto masked_c) {  // the loop exists twice: with and without the padding select (a REAL branch on `interior`)
+      constexpr bool MASKED = decltype(masked_c)::value;
 #pragma unroll
-    for (int it = 0; it < PH / 2; it += 3) {
-      mfma_h8 bf[3];
-      f32x4 d[3];
+      for (int it = 0; it < PH / 2; it += 3) {
+        f32x4 d[3];
 #pragma unroll
-      for (int u = 0; u < 3; ++u) {
-        bf[u] = operand(src[(it + u) * sstep]);
-        d[u] = (f32x4){bias0[0], bias0[1], bias0[2], bias0[3]};
+        for (int u = 0; u < 3; ++u) {
+          const uint2 tq = src[(it + u) * sstep];
+          opq[u].x = tq.x;
+          opq[u].y = tq.y;
+          d[u] = (f32x4){bias0[0], bias0[1], bias0[2], bias0[3]};
+        }
+#pragma unroll
+        for (int t = 0; t < SA_STEM16_TERMS; ++t)
+#pragma unroll
+          for (int u = 0; u < 3; ++u) d[u] = SA_MFMA_16x16x32(wa[t], __builtin_bit_cast(mfma_h8, opq[u]), d[u], 0, 0, 0);
+#pragma unroll
+        for (int u = 0; u < 3; ++u) conv0_store(d[u], MASKED, MASKED && colok && rowok(it + u), dstp + (it + u) * (2 * PW * 32));
       }
-#pragma unroll
-      for (int t = 0; t < SA_STEM16_TERMS; ++t)
-#pragma unroll
-        for (int u = 0; u < 3; ++u) d[u] = SA_MFMA_16x16x32(wa[t], bf[u], d[u], 0, 0, 0);
-#pragma unroll
-      for (int u = 0; u < 3; ++u) conv0_store(d[u], colok && rowok(it + u), dstp + (it + u) * (2 * PW * 32));
-    }
+    };
+    if (__builtin_amdgcn_readfirstlane((int)interior))
+      rows(std::false_type{});
+    else
+      rows(std::true_type{});
     if (wave < 3) {  // columns 32, 33: pixel q = 16 * wave + n16 of the 36 -> row q >> 1, column 32 + (q & 1)
       const int q = wave * 16 + n16;
       if (q < 2 * PH) {
         const int ty2 = q >> 1, tx2 = 32 + (q & 1);
-        const mfma_h8 bf = operand(kb < 3 ? rawt[(ty2 + kb) * RS + tx2] : make_uint2(0u, 0u));
+        const uint2 tq = kb < 3 ? rawt[(ty2 + kb) * RS + tx2] : make_uint2(0u, 0u);
+        const mfma_h8 bf = __builtin_bit_cast(mfma_h8, make_uint4(tq.x, tq.y, 0u, 0u));
         f32x4 d = {bias0[0], bias0[1], bias0[2], bias0[3]};
 #pragma unroll
         for (int t = 0; t < SA_STEM16_TERMS; ++t) d = SA_MFMA_16x16x32(wa[t], bf, d, 0, 0, 0);
-        conv0_store(d, (unsigned)(y0 + ty2 - 1) < (unsigned)H && (unsigned)(x0 + tx2 - 1) < (unsigned)W,
-                    act + (ty2 * PW + tx2) * 32 + kb * 8);  // columns 32, 33: bit 2 clear, no swap
+        conv0_store(d, true, (unsigned)(y0 + ty2 - 1) < (unsigned)H && (unsigned)(x0 + tx2 - 1) < (unsigned)W,
+                    act + (ty2 * PW + tx2) * 32 + kb * 8);  // columns 32, 33
       }
     }
   }
