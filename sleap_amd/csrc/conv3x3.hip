@@ -1080,7 +1080,23 @@ static int conv3x3_impl(const void* src0, int C0P, const void* src1, int C1P, in
     if (mt4_min > 0 && n_heads == 0 && !post_scale && !residual && !relu_last && CoutP % 128 == 0 && CoutP >= mt4_min &&
         (C0P + C1P) > 16 && !ck32)
       return launch2<4, 16, 8, 2, 2, false>(q, st);
-    if (co32_n >= 2) return ck32 ? launch2_pick<2, 32>(q, st) : launch2_pick<2, 16>(q, st);
+    // Small launches (few frames, or the 32 x 32 / 64 x 64 layers of a small batch): with 64 output channels per workgroup the
+    // grid does not fill the chip (two workgroups per CU); 32 channels per workgroup double the workgroup count at the price of
+    // staging every input tile twice. Same arithmetic per output channel: bitwise the same results. SA_CONV_SMALL_MT1=0 turns
+    // the rule off (A/B).
+    static const bool small_mt1 = [] {
+      const char* v = getenv("SA_CONV_SMALL_MT1");
+      return !v || atoi(v) != 0;
+    }();
+    static int n_cu = 0;
+    if (!n_cu) {
+      int dev = 0;
+      SA_HIP_CHECK(hipGetDevice(&dev));
+      SA_HIP_CHECK(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+    }
+    const size_t tiles2 = (size_t)B * ((H + 15) / 16) * ((W + 31) / 32) * ((co32_n + 1) / 2);
+    const bool few = small_mt1 && co32_n >= 2 && n_heads == 0 && (C0P + C1P) > 16 && tiles2 < (size_t)2 * n_cu;
+    if (co32_n >= 2 && !few) return ck32 ? launch2_pick<2, 32>(q, st) : launch2_pick<2, 16>(q, st);
     return ck32 ? launch2_pick<1, 32>(q, st) : launch2_pick<1, 16>(q, st);
   }
   SA_REQUIRE(dst && !dst_pool && n_heads == 0 && !post_scale && !residual && !relu_last && !planar,
