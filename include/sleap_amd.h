@@ -431,6 +431,9 @@ void* sa_tracker_create(const sa_tracker_config* cfg);   /* NULL on invalid conf
 void sa_tracker_destroy(void* tracker);
 int sa_tracker_reset(void* tracker);                     /* Tracker.reset_candidates */
 int sa_tracker_n_tracks(void* tracker);                  /* tracks spawned so far */
+/* Tracker.last_matches.has_only_first_choice_matches (components.py:478-480) of the last tracked frame that had instances:
+ * 1 / 0, -1 before the first such frame (the Kalman tracker's test for a "good" initialisation frame, tracking.py:1243-1277) */
+int sa_tracker_last_first_choice(void* tracker);
 
 /* Tracker.track for ONE frame (tracking.py:642-773). points [n, n_nodes, 2] f32 (x, y; NaN = missing node),
  * point_scores [n, n_nodes] or NULL, inst_scores [n] or NULL, t < 0 = infer the time step.

@@ -81,6 +81,7 @@ SIGNATURES = {
     "sa_tracker_destroy": (None, [_p]),
     "sa_tracker_reset": (_i, [_p]),
     "sa_tracker_n_tracks": (_i, [_p]),
+    "sa_tracker_last_first_choice": (_i, [_p]),
     "sa_tracker_track": (_i, [_p, _i, _i, _p, _p, _p, _i, _i, _i, _p, _p, _p, _p]),
     "sa_tracker_track_frames": (_i, [_p, _i, _i, _i, _p, _p, _p, _p, _i, _i, _i, _p, _p, _p]),
     "sa_tracker_set_image": (_i, [_p, _p, _i, _i, _i, _p]),

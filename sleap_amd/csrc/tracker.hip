@@ -129,6 +129,7 @@ struct Tracker {
   std::vector<std::pair<int, std::deque<std::pair<int, Inst>>>> qdict;  // insertion-ordered {track: deque[(t, inst)]}
   int n_spawned = 0;
   long serial = 0;  // Tracker.track calls so far
+  int last_first_choice = -1;  // FrameMatches.has_only_first_choice_matches of the last frame that had instances (-1: none yet)
   FlowState fs;
   // Shifts of a whole run of frames computed ahead (sa_tracker_track_frames_images, flow without max-tracks): the optical flow
   // of a queued instance into a later frame depends on the detections only, never on the track assignments, so all (queued
@@ -602,6 +603,16 @@ int track_one(Tracker& T, std::vector<Inst> untracked, int img_h, int img_w, int
                                                     : greedy_matching(cost, nr, nc, matches);
       if (rc != SA_OK) return rc;
     }
+    {  // Tracker.last_matches.has_only_first_choice_matches (components.py:478-480, 593-607): every match is its row's argmin
+      bool all_first = true;
+      for (const auto& m : matches) {
+        int best = 0;
+        for (int j = 1; j < nc; ++j)
+          if (cost[(size_t)m.first * nc + j] < cost[(size_t)m.first * nc + best]) best = j;
+        all_first = all_first && best == m.second;
+      }
+      T.last_first_choice = all_first ? 1 : 0;
+    }
     std::vector<char> matched(nr, 0);
     for (const auto& m : matches) {
       matched[m.first] = 1;
@@ -888,6 +899,8 @@ void* sa_tracker_create(const sa_tracker_config* cfg) {
 void sa_tracker_destroy(void* h) { delete static_cast<Tracker*>(h); }
 
 int sa_tracker_n_tracks(void* h) { return h ? static_cast<Tracker*>(h)->n_spawned : -1; }
+
+int sa_tracker_last_first_choice(void* h) { return h ? static_cast<Tracker*>(h)->last_first_choice : -1; }
 
 int sa_tracker_reset(void* h) {
   SA_REQUIRE(h, "sa_tracker_reset: NULL handle");

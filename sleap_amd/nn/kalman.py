@@ -1,0 +1,565 @@
+"""Kalman-filter identity tracking on array instances (host code; follows the prediction path like the other trackers).
+
+Mirrors `sleap.nn.tracker.kalman` (BareKalmanTracker :35-445, the match helpers :447-667) and `KalmanInitSet` / `KalmanTracker`
+(sleap/nn/tracking.py:1236-1515): a regular tracker (the native `simple` one; the reference refuses flow trackers here,
+tracking.py:962-966) labels frames until `init_frame_count` consecutive "good" frames exist, one constant-velocity Kalman filter
+per track is fitted to them, and from then on instances are matched to the filters' predicted node positions (mean absolute
+distance weighted by the point scores, second-best / too-close vetoes, modified greedy matching).
+
+The filter itself is `pykalman.KalmanFilter` in the reference (`KalmanFilter(transition_matrices, observation_matrices,
+initial_state_mean).em(X, n_iter=20)`, `.filter(X)`, `.filter_update(mean, cov, obs)`); pykalman is a third-party dependency that
+is absent here, so the standard linear-Gaussian filter / RTS smoother / EM updates it implements are restated below (its defaults:
+identity covariances, zero offsets, EM over transition covariance, observation covariance, initial mean and initial covariance;
+an observation with ANY missing coordinate is skipped entirely, as pykalman does for masked arrays). Parity with pykalman itself is
+unpinned (no reference-held vectors); the tests pin the matching helpers to the reference's known answers
+(tests/nn/test_kalman.py) and the filter to closed-form cases.
+
+Instances are arrays: points (n, N, 2) with NaN for missing nodes, point scores (n, N), instance scores (n,). Tracks are integers
+(`spawned_tracks[i]` names track i); a filter whose identity is replaced after a gap (`replace_track`) gets a NEW integer with the
+OLD name, as the reference makes a new `Track` object with the old name.
+"""
+import itertools
+from typing import Callable, Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+
+# ------------------------------------------------------------------------------------------------ linear-Gaussian filter
+class KalmanFilter:
+    """The subset of pykalman.KalmanFilter the reference uses (standard.py: _filter, _smooth, _smooth_pair, _em)."""
+
+    def __init__(self, transition_matrices, observation_matrices, initial_state_mean):
+        self.A = np.asarray(transition_matrices, np.float64)
+        self.C = np.asarray(observation_matrices, np.float64)
+        n, m = self.A.shape[0], self.C.shape[0]
+        self.Q = np.eye(n)          # transition_covariance
+        self.R = np.eye(m)          # observation_covariance
+        self.mu0 = np.asarray(initial_state_mean, np.float64)
+        self.S0 = np.eye(n)         # initial_state_covariance
+
+    # -- one predict / correct step (standard.py _filter_predict, _filter_correct)
+    def _predict(self, mean, cov):
+        return self.A @ mean, self.A @ cov @ self.A.T + self.Q
+
+    def _correct(self, pmean, pcov, obs):
+        if obs is None or np.any(np.isnan(obs)):  # masked observation: no information
+            return np.zeros((pmean.size, self.C.shape[0])), pmean, pcov
+        pobs_mean = self.C @ pmean
+        pobs_cov = self.C @ pcov @ self.C.T + self.R
+        gain = pcov @ self.C.T @ np.linalg.pinv(pobs_cov)
+        return gain, pmean + gain @ (obs - pobs_mean), pcov - gain @ self.C @ pcov
+
+    def _filter(self, X):
+        T = len(X)
+        n = self.A.shape[0]
+        pm, pc = np.zeros((T, n)), np.zeros((T, n, n))
+        fm, fc = np.zeros((T, n)), np.zeros((T, n, n))
+        gains = np.zeros((T, n, self.C.shape[0]))
+        for t in range(T):
+            if t == 0:
+                pm[t], pc[t] = self.mu0, self.S0
+            else:
+                pm[t], pc[t] = self._predict(fm[t - 1], fc[t - 1])
+            gains[t], fm[t], fc[t] = self._correct(pm[t], pc[t], X[t])
+        return pm, pc, gains, fm, fc
+
+    def filter(self, X):
+        """-> (filtered state means (T, n), covariances (T, n, n))"""
+        X = np.asarray(X, np.float64)
+        _, _, _, fm, fc = self._filter(X)
+        return fm, fc
+
+    def filter_update(self, filtered_state_mean, filtered_state_covariance, observation=None):
+        """One step from time t to t + 1; `observation` None / any NaN = missing."""
+        pm, pc = self._predict(np.asarray(filtered_state_mean, np.float64), np.asarray(filtered_state_covariance, np.float64))
+        obs = None if observation is None else np.asarray(observation, np.float64)
+        _, m, c = self._correct(pm, pc, obs)
+        return m, c
+
+    def _smooth(self, pm, pc, fm, fc):
+        T, n = fm.shape
+        sm, sc = np.zeros_like(fm), np.zeros_like(fc)
+        ks = np.zeros((T - 1, n, n))
+        sm[-1], sc[-1] = fm[-1], fc[-1]
+        for t in reversed(range(T - 1)):
+            ks[t] = fc[t] @ self.A.T @ np.linalg.pinv(pc[t + 1])
+            sm[t] = fm[t] + ks[t] @ (sm[t + 1] - pm[t + 1])
+            sc[t] = fc[t] + ks[t] @ (sc[t + 1] - pc[t + 1]) @ ks[t].T
+        return sm, sc, ks
+
+    def em(self, X, n_iter: int = 20):
+        """Expectation-maximisation over Q, R, mu0, S0 (pykalman's default em_vars), in place; returns self."""
+        X = np.asarray(X, np.float64)
+        T = len(X)
+        observed = ~np.isnan(X).any(axis=1)
+        for _ in range(n_iter):
+            pm, pc, _, fm, fc = self._filter(X)
+            sm, sc, ks = self._smooth(pm, pc, fm, fc)
+            pair = np.zeros_like(sc)  # pair[t] = Cov(x_t, x_{t-1} | all observations), t >= 1
+            for t in range(1, T):
+                pair[t] = sc[t] @ ks[t - 1].T
+            # observation covariance
+            R = np.zeros_like(self.R)
+            n_obs = 0
+            for t in range(T):
+                if observed[t]:
+                    err = X[t] - self.C @ sm[t]
+                    R += np.outer(err, err) + self.C @ sc[t] @ self.C.T
+                    n_obs += 1
+            if n_obs > 0:
+                R /= n_obs
+            # transition covariance
+            Q = np.zeros_like(self.Q)
+            for t in range(T - 1):
+                err = sm[t + 1] - self.A @ sm[t]
+                vt1t_A = pair[t + 1] @ self.A.T
+                Q += np.outer(err, err) + self.A @ sc[t] @ self.A.T + sc[t + 1] - vt1t_A - vt1t_A.T
+            if T > 1:
+                Q /= (T - 1)
+            mu0 = sm[0].copy()
+            S0 = sc[0].copy()  # E[x0 x0^T] - mu0 mu0^T with the new mean
+            self.Q, self.R, self.mu0, self.S0 = Q, R, mu0, S0
+        return self
+
+
+# ------------------------------------------------------------------------------------------------ matching helpers
+def first_choice_matching(cost_matrix) -> List[Tuple[int, int]]:
+    """components.py:643-653: every row with its best column (several rows may share a column)."""
+    cost_matrix = np.asarray(cost_matrix)
+    return list(zip(range(len(cost_matrix)), cost_matrix.argmin(axis=1)))
+
+
+def greedy_matching(cost_matrix) -> List[Tuple[int, int]]:
+    """components.py:209-226 (stable order for exactly tied costs, as the native tracker)."""
+    cost_matrix = np.asarray(cost_matrix, np.float64)
+    order = np.argsort(cost_matrix, axis=None, kind="stable")
+    rows, cols = np.unravel_index(order, cost_matrix.shape)
+    used_r, used_c, out = set(), set(), []
+    for r, c in zip(rows, cols):
+        if r in used_r or c in used_c:
+            continue
+        used_r.add(r)
+        used_c.add(c)
+        out.append((int(r), int(c)))
+    return out
+
+
+class Match:
+    def __init__(self, track, instance, score=None):
+        self.track, self.instance, self.score = track, instance, score
+
+
+def match_dict_from_match_function(cost_matrix, row_items, column_items, match_function, key_by_column: bool = True) -> dict:
+    """kalman.py:530-560: {column item: row item} of the finite-cost matches, the cheaper one when a key repeats."""
+    out, cost_of = {}, {}
+    for i, j in match_function(cost_matrix):
+        c = cost_matrix[i, j]
+        if np.isfinite(c):
+            key, val = (column_items[j], row_items[i]) if key_by_column else (row_items[i], column_items[j])
+            if key not in out or c < cost_of[key]:
+                out[key], cost_of[key] = val, c
+    return out
+
+
+def match_tuples_from_match_function(cost_matrix, row_items, column_items, match_function):
+    """kalman.py:563-573"""
+    return [(row_items[i], column_items[j], cost_matrix[i, j]) for (i, j) in match_function(cost_matrix)
+            if np.isfinite(cost_matrix[i, j])]
+
+
+def matches_from_match_tuples(match_tuples) -> List[Match]:
+    return [Match(instance=inst, track=track, score=score) for (inst, track, score) in match_tuples]
+
+
+def remove_second_bests_from_cost_matrix(cost_matrix, thresh: float, invalid_val: float = np.nan):
+    """kalman.py:585-667: columns whose best match has a rival within `thresh` are cleared, then rows whose best entry is
+    cleared or has a rival within `thresh`."""
+    cost_matrix = np.asarray(cost_matrix, np.float64)
+    valid = np.full(cost_matrix.shape, True)
+    rows, cols = cost_matrix.shape
+    for c in range(cols):
+        col = cost_matrix[:, c]
+        if all(np.isnan(col)):
+            continue
+        with np.errstate(invalid="ignore"):
+            if (col < (col.min() + thresh)).sum() > 1:
+                valid[:, c] = False
+    for r in range(rows):
+        row = cost_matrix[r]
+        if np.all(np.isnan(row)):
+            continue
+        k = row.argmin()
+        with np.errstate(invalid="ignore"):
+            close = (row < (row[k] + thresh)).sum()
+        if close > 1 or not valid[r][k]:
+            valid[r] = False
+    out = np.copy(cost_matrix)
+    out[~valid] = invalid_val
+    return out
+
+
+def get_track_instance_matches(cost_matrix, instances, tracks, are_too_close_function: Callable) -> List[Match]:
+    """kalman.py:447-527: greedy matching, except that an instance that lost its first-choice track to another instance only
+    gets its second choice when the two instances are not "too close"."""
+    first = match_dict_from_match_function(cost_matrix, instances, tracks, first_choice_matching)
+    greedy = matches_from_match_tuples(match_tuples_from_match_function(cost_matrix, instances, tracks, greedy_matching))
+    good = []
+    for m in greedy:
+        if m.track in first:
+            rival = first[m.track]
+            if m.instance != rival and are_too_close_function(m.instance, rival):
+                continue
+        good.append(m)
+    return good
+
+
+# ------------------------------------------------------------------------------------------------ instances
+class _Inst:
+    """One instance of a frame for the Kalman logic: identity = the object (hashable), arrays by reference."""
+
+    __slots__ = ("points", "scores", "score", "track", "index")
+
+    def __init__(self, points, scores, score, index, track=None):
+        self.points, self.scores, self.score, self.index, self.track = points, scores, score, index, track
+
+
+# ------------------------------------------------------------------------------------------------ filters per track
+class BareKalmanTracker:
+    """kalman.py:35-445."""
+
+    def __init__(self, node_indices: Sequence[int], instance_count: int, instance_score_thresh: float = 0.3, reset_gap_size: int = 5):
+        self.node_indices = list(node_indices)
+        self.instance_count = instance_count
+        self.instance_score_thresh = instance_score_thresh
+        self.reset_gap_size = reset_gap_size
+        self.kalman_filters: Dict[int, KalmanFilter] = {}
+        self.last_results: Dict[int, dict] = {}
+        self.tracks: List[int] = []
+        self.last_frame_for_track: Dict[int, int] = {}
+        self.spawned_on: Dict[int, int] = {}
+
+    def init_filters(self, instances: List[_Inst]):
+        """kalman.py:70-147: one constant-velocity filter per track, EM-fitted (20 iterations) to the track's init frames."""
+        if not instances:
+            raise ValueError("Kalman filter must be initialized with instances.")
+        by_track: Dict[int, list] = {}
+        for inst in instances:
+            by_track.setdefault(inst.track, []).append(np.asarray(inst.points, np.float64)[self.node_indices, 0:2].flatten())
+        self.kalman_filters, self.tracks, self.last_results = {}, [], {}
+        for track, frames in by_track.items():
+            X = np.asarray(frames, np.float64)
+            k = X.shape[1]  # coordinates tracked: state = (value, velocity) per coordinate
+            mu0 = np.zeros(2 * k)
+            mu0[0::2] = np.where(np.isnan(X[0]), 0.0, X[0])  # a masked coordinate of the first frame enters as pykalman's fill
+            A = np.zeros((2 * k, 2 * k))
+            C = np.zeros((k, 2 * k))
+            for i in range(k):
+                A[2 * i, 2 * i] = A[2 * i, 2 * i + 1] = 1.0
+                A[2 * i + 1, 2 * i + 1] = 1.0
+                C[i, 2 * i] = 1.0
+            kf = KalmanFilter(A, C, mu0).em(X, n_iter=20)
+            means, covs = kf.filter(X)
+            self.tracks.append(track)
+            self.kalman_filters[track] = kf
+            self.last_results[track] = {"means": means[-1], "covariances": covs[-1]}
+        self.last_frame_for_track = {}
+
+    def replace_track(self, old_track: int, new_track: int):
+        """kalman.py:149-161: the filter lives on under a new identity (same name)."""
+        self.kalman_filters[new_track] = self.kalman_filters.pop(old_track)
+        self.tracks[self.tracks.index(old_track)] = new_track
+        if old_track in self.last_results:
+            self.last_results[new_track] = self.last_results.pop(old_track)
+        self.spawned_on[new_track] = -1
+
+    def update_filters(self, track_instance_matches: Optional[dict] = None, only_update_matches: bool = False) -> dict:
+        """kalman.py:257-325"""
+        results = {}
+        for track, kf in self.kalman_filters.items():
+            if track_instance_matches and track in track_instance_matches:
+                obs = np.asarray(track_instance_matches[track].points, np.float64)[self.node_indices, 0:2].flatten()
+            elif only_update_matches:
+                continue
+            else:
+                obs = None
+            mean, cov = kf.filter_update(self.last_results[track]["means"], self.last_results[track]["covariances"], obs)
+            results[track] = {"means": mean, "covariances": cov, "coordinate_means": np.array(mean[::2])}
+        return results
+
+    def get_instance_points_weight(self, inst: _Inst):
+        """kalman.py:327-348: [x1, y1, x2, y2, ...] of the tracked nodes and the point scores, each twice."""
+        if not self.node_indices:
+            raise ValueError("Kalman tracker must have node_indices set.")
+        pts = np.asarray(inst.points, np.float64)[self.node_indices, 0:2].flatten()
+        w = np.asarray(inst.scores, np.float64)[self.node_indices].flatten().repeat(2)
+        return pts, w
+
+    @staticmethod
+    def instance_points_match_cost(instance_points, instance_weights, expected_points) -> float:
+        """kalman.py:376-390: score-weighted mean absolute distance over the coordinates present"""
+        d = np.absolute(expected_points - instance_points)
+        if all(np.isnan(d)):
+            return np.nan
+        ok = ~np.isnan(d)
+        return float(np.average(d[ok], weights=instance_weights[ok]))
+
+    def get_mean_instance_distances(self, instances: List[_Inst]) -> dict:
+        pts = {id(i): self.get_instance_points_weight(i)[0] for i in instances}
+
+        def pair(a, b):
+            d = np.absolute(pts[id(a)] - pts[id(b)])
+            return np.nanmean(d) if not np.all(np.isnan(d)) else np.nan
+
+        return {(id(a), id(b)): pair(a, b) for a, b in itertools.combinations(instances, 2)}
+
+    def get_too_close_checking_function(self, instances: List[_Inst], dist_thresh: float) -> Callable:
+        look = self.get_mean_instance_distances(instances)
+
+        def too_close(a, b) -> bool:
+            d = look[(id(a), id(b))] if (id(a), id(b)) in look else look[(id(b), id(a))]
+            return bool(d < dist_thresh)
+
+        return too_close
+
+    def frame_cost_matrix(self, untracked: List[_Inst], filter_results: dict) -> np.ndarray:
+        """kalman.py:409-444: instances x tracks; low-scoring instances keep a NaN row"""
+        m = np.full((len(untracked), len(self.kalman_filters)), np.nan)
+        for i, inst in enumerate(untracked):
+            if inst.score is not None and inst.score < self.instance_score_thresh:
+                continue
+            pts, w = self.get_instance_points_weight(inst)
+            for j, track in enumerate(self.tracks):
+                m[i, j] = self.instance_points_match_cost(pts, w, filter_results[track]["coordinate_means"])
+        return m
+
+    def track_frame(self, untracked: List[_Inst], frame_idx: int, new_track: Callable[[int], int]) -> List[_Inst]:
+        """kalman.py:163-244; `new_track(old)` makes the identity that replaces `old` after a gap"""
+        filter_results = self.update_filters(only_update_matches=False)
+        cost = self.frame_cost_matrix(untracked, filter_results)
+        if cost.size == 0 or np.all(np.isnan(cost)):
+            return untracked
+        thresh = float(np.nanmin(cost))
+        cost = remove_second_bests_from_cost_matrix(cost, thresh=thresh)
+        too_close = self.get_too_close_checking_function(untracked, dist_thresh=thresh)
+        matches = get_track_instance_matches(cost, instances=untracked, tracks=self.tracks, are_too_close_function=too_close)
+        self.last_results.update(self.update_filters({m.track: m.instance for m in matches}, only_update_matches=True))
+        for m in matches:
+            m.instance.track = m.track
+            self.last_frame_for_track[m.track] = frame_idx
+            if self.spawned_on.get(m.track, 0) < 0:
+                self.spawned_on[m.track] = int(frame_idx)
+        gap = [t for t, last in self.last_frame_for_track.items() if (frame_idx - last) > self.reset_gap_size]
+        if len(gap) > 1:
+            for t in gap:
+                self.replace_track(t, new_track(t))
+                self.last_frame_for_track.pop(t)
+        return untracked
+
+    @property
+    def last_frame_with_tracks(self):
+        return max(self.last_frame_for_track.values(), default=0)
+
+
+class KalmanInitSet:
+    """tracking.py:1236-1308"""
+
+    def __init__(self, init_frame_count: int, instance_count: int, node_indices: Sequence[int]):
+        self.init_frame_count, self.instance_count, self.node_indices = init_frame_count, instance_count, list(node_indices)
+        self.init_frames: List[List[_Inst]] = []
+
+    def is_usable_instance(self, inst: _Inst) -> bool:
+        if inst.track is None:  # (`if not instance.track` on a Track object: track 0 is a track here)
+            return False
+        return not np.any(np.isnan(np.asarray(inst.points, np.float64)[self.node_indices, 0:2]))
+
+    def add_frame_instances(self, instances: List[_Inst], first_choice_only: Optional[bool]):
+        good = False
+        if first_choice_only is None:
+            good = True
+        elif first_choice_only:
+            good = len([i for i in instances if self.is_usable_instance(i)]) >= self.instance_count
+        if good:
+            self.init_frames.append(instances)
+        else:
+            self.reset()
+
+    def reset(self):
+        self.init_frames = []
+
+    @property
+    def is_set_ready(self) -> bool:
+        return len(self.init_frames) >= self.init_frame_count
+
+    @property
+    def instances(self) -> List[_Inst]:
+        return [i for frame in self.init_frames for i in frame if self.is_usable_instance(i)]
+
+
+class KalmanTracker:
+    """tracking.py:1312-1515 over the array tracker of `sleap_amd.nn.tracking` as the init tracker. Same per-frame surface as that
+    tracker: `track(points, point_scores, instance_scores, ...)` -> dict(index, track, tracking_score) and `track_frames(...)`.
+
+    Track ids are this object's own: `spawned_tracks[id]` is the name. The init tracker's tracks are mapped in as they first
+    appear; an identity replaced after a gap gets a new id that carries the old name."""
+
+    def __init__(self, init_tracker, node_indices: Sequence[int], instance_count: int, instance_iou_threshold: Optional[float] = 0.8,
+                 init_frame_count: int = 10, re_init_cooldown: int = 100, re_init_after: int = 20, verbose: bool = False):
+        self.init_tracker = init_tracker
+        self.kalman_tracker = BareKalmanTracker(node_indices=node_indices, instance_count=instance_count)
+        self.init_set = KalmanInitSet(init_frame_count=init_frame_count, instance_count=instance_count, node_indices=node_indices)
+        self.instance_count, self.instance_iou_threshold = int(instance_count), instance_iou_threshold
+        self.init_frame_count, self.re_init_cooldown, self.re_init_after = init_frame_count, re_init_cooldown, re_init_after
+        self.init_done = False
+        self.last_t = 0
+        self.last_init_t = 0
+        self.verbose = verbose
+        self._names: List[str] = []
+        self._from_init: Dict[int, int] = {}  # init tracker's track id -> id here
+        if verbose:
+            print(f"Using {init_tracker.get_name()} to track {init_frame_count} frames for Kalman filters.")
+
+    @classmethod
+    def make_tracker(cls, init_tracker, node_indices, instance_count, instance_iou_threshold=0.8, init_frame_count=10):
+        return cls(init_tracker, node_indices, instance_count, instance_iou_threshold, init_frame_count)
+
+    # -- reference-shaped surface
+    @property
+    def is_valid(self) -> bool:
+        return self.init_tracker is not None and self.init_tracker.is_valid
+
+    @property
+    def uses_image(self) -> bool:
+        return self.init_tracker.uses_image
+
+    def get_name(self) -> str:
+        return f"kalman.{self.init_tracker.get_name()}"
+
+    @property
+    def spawned_tracks(self) -> List[str]:
+        return list(self._names)
+
+    def reset_candidates(self):
+        self.init_tracker.reset_candidates()
+
+    def final_pass(self, track, order=None):
+        return self.init_tracker.final_pass(track, order)
+
+    def _track_of_init(self, k: int) -> int:
+        if k not in self._from_init:
+            self._from_init[k] = len(self._names)
+            self._names.append(self.init_tracker.spawned_tracks[k])
+        return self._from_init[k]
+
+    def _replacement_for(self, old: int) -> int:
+        self._names.append(self._names[old])
+        return len(self._names) - 1
+
+    def track(self, points, point_scores=None, instance_scores=None, img_hw=(1, 1), img=None, t: Optional[int] = None):
+        """tracking.py:1421-1503 for one frame. -> dict(index (m,), track (m,), tracking_score (m,)); track -1 = the instance is
+        kept but has no identity (the Kalman phase returns every culled-in instance, matched or not)."""
+        pts = np.zeros((0, 1, 2), np.float32) if points is None else np.asarray(points, np.float32)
+        n = pts.shape[0]
+        ps = np.ones(pts.shape[:2], np.float32) if point_scores is None else np.asarray(point_scores, np.float32)
+        sc = np.zeros((n,), np.float32) if instance_scores is None else np.asarray(instance_scores, np.float32)
+        if t is None:
+            t = self.last_t + 1
+        self.last_t = t
+        keep = cull_frame_indices(pts, sc, self.instance_count, self.instance_iou_threshold)
+        insts = [_Inst(pts[i], ps[i], float(sc[i]), int(i)) for i in keep]
+        if not self.init_done:
+            # the reference calls `init_tracker.track(untracked_instances, img, t)` POSITIONALLY on a (instances, img_hw, img, t)
+            # signature: the init tracker infers its own time step and sees no frame
+            r = self.init_tracker.track(pts[keep], ps[keep], sc[keep], img_hw=img_hw, img=None, t=None)
+            out = []
+            for k, tr, s in zip(r["index"], r["track"], r["tracking_score"]):
+                insts[int(k)].track = self._track_of_init(int(tr)) if tr >= 0 else None
+                out.append((insts[int(k)], float(s)))
+            self.init_set.add_frame_instances([i for i, _ in out], self.init_tracker.last_first_choice)
+            if self.init_set.is_set_ready:
+                self.kalman_tracker.init_filters(self.init_set.instances)
+                if self.verbose:
+                    print(f"Kalman filters initialized (frame {t})")
+                self.init_done = True
+                self.last_init_t = t
+        else:
+            res = self.kalman_tracker.track_frame(insts, frame_idx=t, new_track=self._replacement_for)
+            out = [(i, 0.0) for i in res]
+        if self.init_done and (t - self.last_init_t) > self.re_init_cooldown:
+            if self.kalman_tracker.last_frame_with_tracks < t - self.re_init_after:
+                self.init_done = False
+                self.init_set.reset()
+                self.init_tracker.reset_candidates()
+        return {"index": np.array([i.index for i, _ in out], np.int32),
+                "track": np.array([-1 if i.track is None else i.track for i, _ in out], np.int32),
+                "tracking_score": np.array([s for _, s in out], np.float64)}
+
+    def track_frames(self, instance_peaks, instance_peak_vals=None, instance_scores=None, n_valid=None, img_hw=(1, 1),
+                     t0: Optional[int] = None, images=None, frame_t=None):
+        """The batch form the predictor uses (see `Tracker.track_frames`): frame by frame through `track`."""
+        pts = np.asarray(instance_peaks, np.float32)
+        F, I = pts.shape[0], pts.shape[1]
+        if n_valid is None:
+            n_valid = (~np.isnan(pts).all(axis=(2, 3))).sum(axis=1)
+        trk = np.full((F, I), -1, np.int32)
+        tsc = np.full((F, I), np.nan, np.float64)
+        order = np.full((F, I), -1, np.int32)
+        for f in range(F):
+            n = int(n_valid[f])
+            t = int(frame_t[f]) if frame_t is not None else (None if t0 is None else int(t0) + f)
+            r = self.track(pts[f, :n], None if instance_peak_vals is None else np.asarray(instance_peak_vals)[f, :n],
+                           None if instance_scores is None else np.asarray(instance_scores)[f, :n], img_hw=img_hw, t=t)
+            for k, (i, tr, s) in enumerate(zip(r["index"], r["track"], r["tracking_score"])):
+                trk[f, i], tsc[f, i], order[f, i] = tr, s, k
+        return {"track": trk, "tracking_score": tsc, "order": order}
+
+
+# ------------------------------------------------------------------------------------------------ cull (components.py:229-417)
+def bounding_box(points) -> np.ndarray:
+    """instance.py:878-886: [y1, x1, y2, x2] over the visible points"""
+    p = np.asarray(points, np.float64)
+    if np.isnan(p).all():
+        return np.full((4,), np.nan)
+    return np.concatenate([np.nanmin(p, axis=0)[::-1], np.nanmax(p, axis=0)[::-1]])
+
+
+def nms_fast(boxes, scores, iou_threshold, target_count=None) -> List[int]:
+    """components.py:242-311: highest score first; overlap = intersection / area of the OTHER box; when fewer than
+    `target_count` survive, suppressed boxes come back by descending score -- `nms_idxs[:min(len, len(picked) - target)]`, a
+    NEGATIVE slice end in the reference (all but the last |k|), kept as it is."""
+    boxes = np.asarray(boxes, np.float64)
+    scores = np.asarray(scores, np.float64)
+    if len(boxes) == 0:
+        return []
+    if target_count and len(boxes) < target_count:
+        return list(range(len(boxes)))
+    picked, suppressed = [], []
+    x1, y1, x2, y2 = boxes[:, 0], boxes[:, 1], boxes[:, 2], boxes[:, 3]
+    area = (x2 - x1 + 1) * (y2 - y1 + 1)
+    idxs = np.argsort(scores, kind="stable")
+    while len(idxs) > 0:
+        p, rest = idxs[-1], idxs[:-1]
+        picked.append(int(p))
+        w = np.maximum(0, np.minimum(x2[p], x2[rest]) - np.maximum(x1[p], x1[rest]) + 1)
+        h = np.maximum(0, np.minimum(y2[p], y2[rest]) - np.maximum(y1[p], y1[rest]) + 1)
+        with np.errstate(invalid="ignore", divide="ignore"):
+            hit = np.where((w * h) / area[rest] > iou_threshold)[0]
+        suppressed.extend(int(i) for i in idxs[hit])
+        idxs = np.delete(idxs, hit)[:-1]
+    if target_count and suppressed and len(picked) < target_count:
+        suppressed.sort(key=lambda i: -scores[i])
+        picked.extend(suppressed[:min(len(suppressed), len(picked) - target_count)])
+    return picked
+
+
+def cull_frame_indices(points, scores, instance_count: int, iou_threshold: Optional[float] = None) -> List[int]:
+    """cull_frame_instances (components.py:366-417) on arrays: the indices that stay, in their original order"""
+    keep = list(range(len(points)))
+    if len(keep) <= instance_count:
+        return keep
+    if iou_threshold:
+        picks = nms_fast(np.array([bounding_box(points[i]) for i in keep]), scores, iou_threshold, target_count=instance_count)
+        keep = [i for i in keep if i in picks]
+    if len(keep) > instance_count:
+        drop = sorted(keep, key=lambda i: scores[i])[:-instance_count]
+        keep = [i for i in keep if i not in drop]
+    return keep

@@ -12,7 +12,7 @@ Instances are arrays, not `PredictedInstance`s: points (n, N, 2) with NaN for mi
 instance scores (n,). Tracks are integers, `spawned_tracks[i]` is the reference's name for track i.
 Flow trackers take the frame with every step (`img=` / `images=`: uint8 arrays or CUDA tensors); the Lucas-Kanade flow that
 the reference gets from `cv2.calcOpticalFlowPyrLK` runs on the device (csrc/flow.hip), with `img_scale=1` and
-`save_shifted_instances=False` only. Not covered: the Kalman tracker (pykalman, absent offline).
+`save_shifted_instances=False` only. `kf_init_frame_count` / `kf_node_indices` wrap the tracker in the Kalman one (`kalman.py`).
 """
 import ctypes as C
 from typing import List, Optional, Sequence
@@ -83,20 +83,36 @@ class Tracker:
                              kf_node_indices: Optional[list] = None, max_tracks: Optional[int] = None,
                              max_tracking: bool = False, oks_errors: Optional[list] = None,
                              oks_score_weighting: bool = False, oks_normalization: str = "all", **kwargs):
-        return cls(tracker=tracker, similarity=similarity, match=match, track_window=track_window, robust=robust,
-                   min_new_track_points=min_new_track_points, min_match_points=min_match_points, img_scale=img_scale,
-                   of_window_size=of_window_size, of_max_levels=of_max_levels, save_shifted_instances=save_shifted_instances,
-                   target_instance_count=target_instance_count, pre_cull_to_target=pre_cull_to_target,
-                   pre_cull_iou_threshold=pre_cull_iou_threshold, post_connect_single_breaks=post_connect_single_breaks,
-                   clean_instance_count=clean_instance_count, kf_init_frame_count=kf_init_frame_count,
-                   kf_node_indices=kf_node_indices, max_tracks=max_tracks, max_tracking=max_tracking,
-                   oks_errors=oks_errors, oks_score_weighting=oks_score_weighting, oks_normalization=oks_normalization)
+        obj = cls(tracker=tracker, similarity=similarity, match=match, track_window=track_window, robust=robust,
+                  min_new_track_points=min_new_track_points, min_match_points=min_match_points, img_scale=img_scale,
+                  of_window_size=of_window_size, of_max_levels=of_max_levels, save_shifted_instances=save_shifted_instances,
+                  target_instance_count=target_instance_count, pre_cull_to_target=pre_cull_to_target,
+                  pre_cull_iou_threshold=pre_cull_iou_threshold, post_connect_single_breaks=post_connect_single_breaks,
+                  clean_instance_count=clean_instance_count, max_tracks=max_tracks, max_tracking=max_tracking,
+                  oks_errors=oks_errors, oks_score_weighting=oks_score_weighting, oks_normalization=oks_normalization)
+        # tracking.py:955-993: the Kalman tracker wraps the regular one
+        if (max_tracks or target_instance_count) and kf_init_frame_count:
+            if not kf_node_indices:
+                raise ValueError("Kalman filter requires node indices for instance tracking.")
+            if obj.uses_flow:
+                raise ValueError("Kalman filter requires simple tracker for initial tracking.")
+            if similarity == "normalized_instance":
+                raise ValueError("Kalman filter does not support normalized_instance_similarity.")
+            from .kalman import KalmanTracker
+
+            return KalmanTracker.make_tracker(init_tracker=obj, init_frame_count=kf_init_frame_count,
+                                              node_indices=list(kf_node_indices),
+                                              instance_count=target_instance_count or max_tracks,
+                                              instance_iou_threshold=pre_cull_iou_threshold)
+        if kf_init_frame_count:
+            raise ValueError("Kalman filter requires max tracks or target instance count.")
+        return obj
 
     def _configure(self, tracker="simple", similarity="instance", match="greedy", track_window=5, robust=1.0,
                    min_new_track_points=0, min_match_points=0, img_scale=1.0, of_window_size=21, of_max_levels=3,
                    save_shifted_instances=False, target_instance_count=0, pre_cull_to_target=False,
                    pre_cull_iou_threshold=None, post_connect_single_breaks=False, clean_instance_count=0,
-                   kf_init_frame_count=0, kf_node_indices=None, max_tracks=None, max_tracking=False, oks_errors=None,
+                   max_tracks=None, max_tracking=False, oks_errors=None,
                    oks_score_weighting=False, oks_normalization="all"):
         max_tracking = max_tracking if max_tracks else False  # tracking.py:879
         if max_tracking and tracker in ("simple", "flow"):
@@ -114,10 +130,6 @@ class Tracker:
             raise NotImplementedError("flow tracker: img_scale != 1 (cv2.resize of the frames) is not implemented")
         if self.uses_flow and save_shifted_instances:
             raise NotImplementedError("flow tracker: save_shifted_instances=True (chained flow) is not implemented")
-        if kf_init_frame_count:
-            if not (max_tracks or target_instance_count):
-                raise ValueError("Kalman filter requires max tracks or target instance count.")
-            raise NotImplementedError("the Kalman tracker (pykalman) is not implemented")
         if clean_instance_count:
             raise NotImplementedError("clean_instance_count (deprecated TrackCleaner) is not implemented; use "
                                       "target_instance_count with pre_cull_to_target")
@@ -171,6 +183,13 @@ class Tracker:
     @property
     def spawned_tracks(self) -> List[str]:
         return [f"track_{i}" for i in range(_lib.lib().sa_tracker_n_tracks(C.c_void_p(self._h)))]
+
+    @property
+    def last_first_choice(self) -> Optional[bool]:
+        """`FrameMatches.has_only_first_choice_matches` (components.py:560-573) of the last tracked frame: every match was its
+        instance's best column. None before the first frame."""
+        v = _lib.lib().sa_tracker_last_first_choice(C.c_void_p(self._h))
+        return None if v < 0 else bool(v)
 
     def reset_candidates(self):
         check(_lib.lib().sa_tracker_reset(C.c_void_p(self._h)), "sa_tracker_reset")
