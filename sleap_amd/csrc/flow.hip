@@ -60,7 +60,12 @@ PyrLayout pyr_layout(int H, int W, int win, int max_level) {
   return p;
 }
 
+// BORDER_REFLECT_101 index. The common cases -- inside, or one reflection -- cost a few compares; the general form (an integer
+// modulo, ~40 instructions) is only reached by windows larger than the level.
 __device__ __forceinline__ int reflect101(int i, int n) {
+  if ((unsigned)i < (unsigned)n) return i;
+  if (i < 0 && -i < n) return -i;
+  if (i >= n && i <= 2 * n - 2) return 2 * n - 2 - i;
   if (n == 1) return 0;
   const int p = 2 * (n - 1);
   i %= p;
@@ -68,106 +73,154 @@ __device__ __forceinline__ int reflect101(int i, int n) {
   return i >= n ? p - i : i;
 }
 
-__global__ void __launch_bounds__(256)
-flow_gray_kernel(const uint8_t* __restrict__ src, int n_pix, int C, uint8_t* __restrict__ dst) {
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_pix; i += gridDim.x * blockDim.x) {
-    if (C == 1) {
-      dst[i] = src[i];
-    } else {  // cv2.COLOR_BGR2GRAY on the caller's channel order: (c0 * 1868 + c1 * 9617 + c2 * 4899 + 8192) >> 14
-      const uint8_t* s = src + (size_t)i * 3;
-      dst[i] = (uint8_t)((s[0] * 1868 + s[1] * 9617 + s[2] * 4899 + 8192) >> 14);
-    }
-  }
-}
+// Where a pyramid kernel reads and writes: one frame given by pointers (frames == nullptr), or frame blockIdx.z of a batch whose
+// pyramid buffers are listed in `pyr` (offsets inside a buffer are the same for every frame).
+struct PyrIO {
+  const uint8_t* src;
+  uint8_t* dst;
+  uint8_t* const* pyr;
+  size_t src_off, dst_off;
+  __device__ __forceinline__ const uint8_t* in() const { return pyr ? pyr[blockIdx.z] + src_off : src; }
+  __device__ __forceinline__ uint8_t* out() const { return pyr ? pyr[blockIdx.z] + dst_off : dst; }
+};
 
+// level 0: the frame as gray uint8. `frames` of a batch are contiguous ([F][n_pix][C]); 16 bytes per thread when C == 1
 __global__ void __launch_bounds__(256)
-flow_pyrdown_kernel(const uint8_t* __restrict__ src, int h, int w, uint8_t* __restrict__ dst, int oh, int ow) {
-  const int n = oh * ow;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-    const int oy = i / ow, ox = i - oy * ow;
-    const int k[5] = {1, 4, 6, 4, 1};
-    int acc = 0;
-#pragma unroll
-    for (int dy = 0; dy < 5; ++dy) {
-      const uint8_t* row = src + (size_t)reflect101(2 * oy + dy - 2, h) * w;
-      int r = 0;
-#pragma unroll
-      for (int dx = 0; dx < 5; ++dx) r += k[dx] * row[reflect101(2 * ox + dx - 2, w)];
-      acc += k[dy] * r;
-    }
-    dst[i] = (uint8_t)((acc + 128) >> 8);
-  }
-}
-
-__global__ void __launch_bounds__(256)
-flow_scharr_kernel(const uint8_t* __restrict__ src, int h, int w, int16_t* __restrict__ dst) {
-  const int n = h * w;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-    const int y = i / w, x = i - y * w;
-    const uint8_t* r0 = src + (size_t)reflect101(y - 1, h) * w;
-    const uint8_t* r1 = src + (size_t)y * w;
-    const uint8_t* r2 = src + (size_t)reflect101(y + 1, h) * w;
-    const int xl = reflect101(x - 1, w), xr = reflect101(x + 1, w);
-    // vertical smoothing / difference at columns x-1, x, x+1
-    const int t0l = (r0[xl] + r2[xl]) * 3 + r1[xl] * 10, t0r = (r0[xr] + r2[xr]) * 3 + r1[xr] * 10;
-    const int t1l = r2[xl] - r0[xl], t1c = r2[x] - r0[x], t1r = r2[xr] - r0[xr];
-    dst[2 * (size_t)i] = (int16_t)(t0r - t0l);
-    dst[2 * (size_t)i + 1] = (int16_t)((t1r + t1l) * 3 + t1c * 10);
-  }
-}
-
-// ---- the same three kernels for a batch of frames: blockIdx.y = frame, pyr[f] = that frame's pyramid buffer
-__global__ void __launch_bounds__(256)
-flow_gray_batch_kernel(const uint8_t* __restrict__ src, int n_pix, int C, uint8_t* const* __restrict__ pyr, size_t dst_off) {
-  const uint8_t* s0 = src + (size_t)blockIdx.y * n_pix * C;
-  uint8_t* dst = pyr[blockIdx.y] + dst_off;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_pix; i += gridDim.x * blockDim.x) {
-    if (C == 1) {
-      dst[i] = s0[i];
+flow_gray_kernel(const uint8_t* __restrict__ src, int n_pix, int C, PyrIO io) {
+  const uint8_t* s0 = src + (size_t)blockIdx.z * n_pix * C;
+  uint8_t* dst = io.out();
+  const int t0 = blockIdx.x * blockDim.x + threadIdx.x, nt = gridDim.x * blockDim.x;
+  if (C == 1) {
+    if ((n_pix & 15) == 0 && (((uintptr_t)s0 | (uintptr_t)dst) & 15) == 0) {
+      const uint4* s4 = reinterpret_cast<const uint4*>(s0);
+      uint4* d4 = reinterpret_cast<uint4*>(dst);
+      for (int i = t0; i < (n_pix >> 4); i += nt) d4[i] = s4[i];
     } else {
+      for (int i = t0; i < n_pix; i += nt) dst[i] = s0[i];
+    }
+  } else {  // cv2.COLOR_BGR2GRAY on the caller's channel order: (c0 * 1868 + c1 * 9617 + c2 * 4899 + 8192) >> 14
+    for (int i = t0; i < n_pix; i += nt) {
       const uint8_t* s = s0 + (size_t)i * 3;
       dst[i] = (uint8_t)((s[0] * 1868 + s[1] * 9617 + s[2] * 4899 + 8192) >> 14);
     }
   }
 }
 
+// The two stencils run on a 2-D grid: 64 x 4 pixels per workgroup, blockIdx = (column block, row block, frame) -- no index
+// division, and a thread's reflected row / column indices are computed once (first version: a flat index with a division and
+// 10 modulo-based reflections per output; the pyramids of a 64-frame batch cost as much as its Lucas-Kanade launch).
 __global__ void __launch_bounds__(256)
-flow_pyrdown_batch_kernel(uint8_t* const* __restrict__ pyr, size_t src_off, int h, int w, size_t dst_off, int oh, int ow) {
-  const uint8_t* src = pyr[blockIdx.y] + src_off;
-  uint8_t* dst = pyr[blockIdx.y] + dst_off;
-  const int n = oh * ow;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-    const int oy = i / ow, ox = i - oy * ow;
-    const int k[5] = {1, 4, 6, 4, 1};
-    int acc = 0;
+flow_pyrdown_kernel(PyrIO io, int h, int w, int oh, int ow) {
+  const int ox = blockIdx.x * 64 + (threadIdx.x & 63), oy = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (ox >= ow || oy >= oh) return;
+  const uint8_t* src = io.in();
+  int xs[5];
 #pragma unroll
-    for (int dy = 0; dy < 5; ++dy) {
-      const uint8_t* row = src + (size_t)reflect101(2 * oy + dy - 2, h) * w;
-      int r = 0;
+  for (int dx = 0; dx < 5; ++dx) xs[dx] = reflect101(2 * ox + dx - 2, w);
+  const int k[5] = {1, 4, 6, 4, 1};
+  int acc = 0;
 #pragma unroll
-      for (int dx = 0; dx < 5; ++dx) r += k[dx] * row[reflect101(2 * ox + dx - 2, w)];
-      acc += k[dy] * r;
-    }
-    dst[i] = (uint8_t)((acc + 128) >> 8);
+  for (int dy = 0; dy < 5; ++dy) {
+    const uint8_t* row = src + (size_t)reflect101(2 * oy + dy - 2, h) * w;
+    int r = 0;
+#pragma unroll
+    for (int dx = 0; dx < 5; ++dx) r += k[dx] * row[xs[dx]];
+    acc += k[dy] * r;
   }
+  io.out()[(size_t)oy * ow + ox] = (uint8_t)((acc + 128) >> 8);
 }
 
 __global__ void __launch_bounds__(256)
-flow_scharr_batch_kernel(uint8_t* const* __restrict__ pyr, size_t src_off, int h, int w, size_t dst_off) {
-  const uint8_t* src = pyr[blockIdx.y] + src_off;
-  int16_t* dst = reinterpret_cast<int16_t*>(pyr[blockIdx.y] + dst_off);
-  const int n = h * w;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-    const int y = i / w, x = i - y * w;
-    const uint8_t* r0 = src + (size_t)reflect101(y - 1, h) * w;
-    const uint8_t* r1 = src + (size_t)y * w;
-    const uint8_t* r2 = src + (size_t)reflect101(y + 1, h) * w;
-    const int xl = reflect101(x - 1, w), xr = reflect101(x + 1, w);
-    const int t0l = (r0[xl] + r2[xl]) * 3 + r1[xl] * 10, t0r = (r0[xr] + r2[xr]) * 3 + r1[xr] * 10;
-    const int t1l = r2[xl] - r0[xl], t1c = r2[x] - r0[x], t1r = r2[xr] - r0[xr];
-    dst[2 * (size_t)i] = (int16_t)(t0r - t0l);
-    dst[2 * (size_t)i + 1] = (int16_t)((t1r + t1l) * 3 + t1c * 10);
+flow_scharr_kernel(PyrIO io, int h, int w) {
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (x >= w || y >= h) return;
+  const uint8_t* src = io.in();
+  int* dst = reinterpret_cast<int*>(io.out());  // (int16 Ix, int16 Iy) per pixel, one 4-byte store
+  const uint8_t* r0 = src + (size_t)reflect101(y - 1, h) * w;
+  const uint8_t* r1 = src + (size_t)y * w;
+  const uint8_t* r2 = src + (size_t)reflect101(y + 1, h) * w;
+  const int xl = reflect101(x - 1, w), xr = reflect101(x + 1, w);
+  // vertical smoothing / difference at columns x-1, x, x+1
+  const int t0l = (r0[xl] + r2[xl]) * 3 + r1[xl] * 10, t0r = (r0[xr] + r2[xr]) * 3 + r1[xr] * 10;
+  const int t1l = r2[xl] - r0[xl], t1c = r2[x] - r0[x], t1r = r2[xr] - r0[xr];
+  const int ix = t0r - t0l, iy = (t1r + t1l) * 3 + t1c * 10;  // both fit int16: |.| <= 16 * 255
+  dst[(size_t)y * w + x] = (int)(((unsigned)ix & 0xFFFFu) | ((unsigned)iy << 16));
+}
+
+// ---- four pixels per thread (levels whose rows are dword aligned: every level of a 1024 x 1024 frame). The stencils are
+// instruction bound with one pixel per thread (25 byte loads per pyrDown output); here a thread loads aligned dwords and
+// writes its four results with one store. Same integer arithmetic, same results.
+__device__ __forceinline__ int byte_of(unsigned v, int i) { return (int)((v >> (8 * i)) & 0xFFu); }
+
+// w % 8 == 0 (so ow = w / 2 is a multiple of 4); thread -> outputs ox0 .. ox0+3, source columns 2 ox0 - 2 .. 2 ox0 + 8
+__global__ void __launch_bounds__(256)
+flow_pyrdown_x4_kernel(PyrIO io, int h, int w, int oh, int ow) {
+  const int ox0 = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4, oy = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (ox0 >= ow || oy >= oh) return;
+  const uint8_t* src = io.in();
+  const int sx = 2 * ox0;
+  const bool left = sx == 0, right = sx + 8 >= w;  // column -2, -1 reflect to 2, 1; column w reflects to w - 2
+  const int k[5] = {1, 4, 6, 4, 1};
+  int acc[4] = {0, 0, 0, 0};
+#pragma unroll
+  for (int dy = 0; dy < 5; ++dy) {
+    const unsigned* row = reinterpret_cast<const unsigned*>(src + (size_t)reflect101(2 * oy + dy - 2, h) * w + sx);
+    const unsigned v0 = row[0], v1 = row[1];
+    int c[11];
+    if (left) {
+      c[0] = byte_of(v0, 2);
+      c[1] = byte_of(v0, 1);
+    } else {
+      const unsigned vm = row[-1];
+      c[0] = byte_of(vm, 2);
+      c[1] = byte_of(vm, 3);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      c[2 + i] = byte_of(v0, i);
+      c[6 + i] = byte_of(v1, i);
+    }
+    c[10] = right ? byte_of(v1, 2) : byte_of(row[2], 0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      acc[j] += k[dy] * (c[2 * j] + 4 * c[2 * j + 1] + 6 * c[2 * j + 2] + 4 * c[2 * j + 3] + c[2 * j + 4]);
   }
+  unsigned out = 0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) out |= (unsigned)((acc[j] + 128) >> 8) << (8 * j);
+  *reinterpret_cast<unsigned*>(io.out() + (size_t)oy * ow + ox0) = out;
+}
+
+// w % 4 == 0; thread -> pixels x0 .. x0+3 of row y
+__global__ void __launch_bounds__(256)
+flow_scharr_x4_kernel(PyrIO io, int h, int w) {
+  const int x0 = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4, y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (x0 >= w || y >= h) return;
+  const uint8_t* src = io.in();
+  const uint8_t* rows[3] = {src + (size_t)reflect101(y - 1, h) * w, src + (size_t)y * w, src + (size_t)reflect101(y + 1, h) * w};
+  const int xl = x0 == 0 ? 1 : x0 - 1, xr = x0 + 4 >= w ? w - 2 : x0 + 4;  // reflect-101 of x0 - 1 and x0 + 4
+  int c[3][6];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    const unsigned v = *reinterpret_cast<const unsigned*>(rows[r] + x0);
+    c[r][0] = rows[r][xl];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) c[r][1 + i] = byte_of(v, i);
+    c[r][5] = rows[r][xr];
+  }
+  int sm[6], df[6];  // vertical smoothing [3 10 3] and difference [-1 0 1] per column
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    sm[i] = (c[0][i] + c[2][i]) * 3 + c[1][i] * 10;
+    df[i] = c[2][i] - c[0][i];
+  }
+  unsigned o[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int ix = sm[j + 2] - sm[j], iy = (df[j + 2] + df[j]) * 3 + df[j + 1] * 10;
+    o[j] = ((unsigned)ix & 0xFFFFu) | ((unsigned)iy << 16);
+  }
+  *reinterpret_cast<uint4*>(reinterpret_cast<int*>(io.out()) + (size_t)y * w + x0) = make_uint4(o[0], o[1], o[2], o[3]);
 }
 
 struct LkParams {
@@ -209,7 +262,7 @@ __device__ __forceinline__ void lk_weights(float a, float b, int& w00, int& w01,
 // reflected), so the <= 30 dependent Newton steps of a level read LDS instead of global memory; a step that leaves the staged box
 // re-stages it around the current position. (First version: patches in LDS, J from global memory inside a rolled loop: 0.447 ms per
 // launch however few the points -- 7 serialised global round trips per step; profiles/r02_flow_tracker.md.)
-constexpr int STAGE_MARGIN = 8;
+constexpr int STAGE_MARGIN = 4;
 
 template <int NPL>
 __global__ void __launch_bounds__(256)
@@ -221,6 +274,7 @@ flow_lk_kernel(const LkParams p) {
   const int win = p.win, area = win * win;
   const int S = win + 1 + 2 * STAGE_MARGIN;  // staged box edge
   uint8_t* stage = lds_u8 + (size_t)wave * S * S;
+  const int lane_y = lane / S, lane_x = lane - lane_y * S, step_y = 64 / S, step_x = 64 - step_y * S;
   int wyk[NPL], wxk[NPL];
   bool act[NPL];
 #pragma unroll
@@ -317,9 +371,15 @@ flow_lk_kernel(const LkParams p) {
     auto stage_box = [&](int cx, int cy) {
       sx0 = cx - STAGE_MARGIN;
       sy0 = cy - STAGE_MARGIN;
-      for (int i = lane; i < S * S; i += 64) {
-        const int yy = i / S, xx = i - yy * S;
+      // element i = lane + 64 j of the S x S box: (yy, xx) advances by (64 / S, 64 % S) per step -- no division in the loop
+      for (int i = lane, yy = lane_y, xx = lane_x; i < S * S; i += 64) {
         stage[i] = J[(size_t)reflect101(sy0 + yy, h) * w + reflect101(sx0 + xx, w)];
+        xx += step_x;
+        yy += step_y;
+        if (xx >= S) {
+          xx -= S;
+          ++yy;
+        }
       }
       staged = true;  // the lanes of a wave run in lockstep: no barrier between these stores and the loads below is needed
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -398,6 +458,40 @@ int grid_for(size_t total, int cap = 4096) {
   return g < 1 ? 1 : (int)g;
 }
 
+// all levels of F frames (F == 1: `base` is the one pyramid buffer; else `pyr` lists F of them): 1 + 2 n_levels - 1 launches
+int pyramid_launch(const uint8_t* images, int F, int H, int W, int C, const PyrLayout& lay, uint8_t* base, uint8_t* const* pyr,
+                   hipStream_t st) {
+  auto io = [&](size_t src_off, size_t dst_off) {
+    PyrIO v;
+    v.src = base ? base + src_off : nullptr;
+    v.dst = base ? base + dst_off : nullptr;
+    v.pyr = pyr;
+    v.src_off = src_off;
+    v.dst_off = dst_off;
+    return v;
+  };
+  auto tiles = [&](int h, int w) { return dim3((unsigned)((w + 63) / 64), (unsigned)((h + 3) / 4), (unsigned)F); };
+  auto tiles4 = [&](int h, int w) { return dim3((unsigned)((w + 255) / 256), (unsigned)((h + 3) / 4), (unsigned)F); };
+  SA_REQUIRE((H + 3) / 4 <= 65535 && F <= 65535, "sa_flow_pyramid_build: frame too tall for one launch");
+  hipLaunchKernelGGL(flow_gray_kernel, dim3((unsigned)grid_for((size_t)H * W / (C == 1 ? 16 : 1), 1024), 1, (unsigned)F), dim3(256),
+                     0, st, images, H * W, C, io(0, lay.lv[0].img_off));
+  for (int l = 0; l < lay.n_levels; ++l) {
+    const Level& L = lay.lv[l];
+    if (l > 0) {
+      const Level& P = lay.lv[l - 1];
+      if (P.w % 8 == 0 && P.w >= 16 && P.h >= 3)
+        hipLaunchKernelGGL(flow_pyrdown_x4_kernel, tiles4(L.h, L.w), dim3(256), 0, st, io(P.img_off, L.img_off), P.h, P.w, L.h, L.w);
+      else
+        hipLaunchKernelGGL(flow_pyrdown_kernel, tiles(L.h, L.w), dim3(256), 0, st, io(P.img_off, L.img_off), P.h, P.w, L.h, L.w);
+    }
+    if (L.w % 4 == 0 && L.w >= 8)
+      hipLaunchKernelGGL(flow_scharr_x4_kernel, tiles4(L.h, L.w), dim3(256), 0, st, io(L.img_off, L.deriv_off), L.h, L.w);
+    else
+      hipLaunchKernelGGL(flow_scharr_kernel, tiles(L.h, L.w), dim3(256), 0, st, io(L.img_off, L.deriv_off), L.h, L.w);
+  }
+  return SA_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -419,18 +513,8 @@ int sa_flow_pyramid_build(const void* image, int H, int W, int C, int win, int m
   const PyrLayout lay = pyr_layout(H, W, win, max_level);
   uint8_t* base = static_cast<uint8_t*>(pyramid);
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(flow_gray_kernel, dim3(grid_for((size_t)H * W)), dim3(256), 0, st, (const uint8_t*)image, H * W, C,
-                     base + lay.lv[0].img_off);
-  for (int l = 0; l < lay.n_levels; ++l) {
-    const Level& L = lay.lv[l];
-    if (l > 0) {
-      const Level& P = lay.lv[l - 1];
-      hipLaunchKernelGGL(flow_pyrdown_kernel, dim3(grid_for((size_t)L.h * L.w)), dim3(256), 0, st, base + P.img_off, P.h, P.w,
-                         base + L.img_off, L.h, L.w);
-    }
-    hipLaunchKernelGGL(flow_scharr_kernel, dim3(grid_for((size_t)L.h * L.w)), dim3(256), 0, st, base + L.img_off, L.h, L.w,
-                       reinterpret_cast<int16_t*>(base + L.deriv_off));
-  }
+  const int rc = pyramid_launch(static_cast<const uint8_t*>(image), 1, H, W, C, lay, base, nullptr, st);
+  if (rc != SA_OK) return rc;
   SA_LAUNCH_CHECK();
   return SA_OK;
 }
@@ -444,16 +528,8 @@ int sa_flow_pyramid_build_batch(const void* images, int F, int H, int W, int C, 
   const PyrLayout lay = pyr_layout(H, W, win, max_level);
   uint8_t* const* pyr = reinterpret_cast<uint8_t* const*>(pyramids);
   hipStream_t st = (hipStream_t)stream;
-  auto grid = [&](size_t total) { return dim3((unsigned)grid_for(total, 1024), (unsigned)F); };
-  hipLaunchKernelGGL(flow_gray_batch_kernel, grid((size_t)H * W), dim3(256), 0, st, (const uint8_t*)images, H * W, C, pyr, lay.lv[0].img_off);
-  for (int l = 0; l < lay.n_levels; ++l) {
-    const Level& L = lay.lv[l];
-    if (l > 0) {
-      const Level& P = lay.lv[l - 1];
-      hipLaunchKernelGGL(flow_pyrdown_batch_kernel, grid((size_t)L.h * L.w), dim3(256), 0, st, pyr, P.img_off, P.h, P.w, L.img_off, L.h, L.w);
-    }
-    hipLaunchKernelGGL(flow_scharr_batch_kernel, grid((size_t)L.h * L.w), dim3(256), 0, st, pyr, L.img_off, L.h, L.w, L.deriv_off);
-  }
+  const int rc = pyramid_launch(static_cast<const uint8_t*>(images), F, H, W, C, lay, nullptr, pyr, st);
+  if (rc != SA_OK) return rc;
   SA_LAUNCH_CHECK();
   return SA_OK;
 }

@@ -94,8 +94,10 @@ struct FlowState {
   std::map<int, void*> pyr;  // t -> device pyramid of that frame
   void* cur = nullptr;       // pyramid of the current frame (set by sa_tracker_set_image, consumed by the next track call)
   std::vector<void*> pool;   // free pyramid buffers of the current (H, W)
-  void* scratch = nullptr;
+  void* scratch = nullptr;  // Lucas-Kanade job tables and results of one launch
   size_t scratch_bytes = 0;
+  void* ptab = nullptr;     // the pyramid buffers of a run of frames (sa_flow_pyramid_build_batch reads them from the device)
+  size_t ptab_bytes = 0;
   hipStream_t stream = nullptr;
 
   void* take(size_t bytes) {
@@ -120,6 +122,9 @@ struct FlowState {
     if (scratch) (void)hipFree(scratch);
     scratch = nullptr;
     scratch_bytes = 0;
+    if (ptab) (void)hipFree(ptab);
+    ptab = nullptr;
+    ptab_bytes = 0;
   }
 };
 
@@ -722,20 +727,20 @@ int flow_batch_run(Tracker& T, int n_frames, int max_inst, int n_nodes, const fl
     bp[(size_t)f] = F.take(pbytes);
     if (!bp[(size_t)f]) return sa::fail(SA_ERR_HIP, "flow tracker: out of device memory for the frame pyramids");
   }
-  {  // all pyramids of the run in a handful of launches (the table of buffer pointers goes through the scratch area)
-    const size_t need = (size_t)n_frames * sizeof(void*) + 256;
-    if (need > F.scratch_bytes) {
-      if (F.scratch) (void)hipFree(F.scratch);
-      F.scratch = nullptr;
-      F.scratch_bytes = 0;
-      SA_HIP_CHECK(hipMalloc(&F.scratch, need * 2));
-      F.scratch_bytes = need * 2;
+  {  // all pyramids of the run in a handful of launches; no synchronisation here -- the Lucas-Kanade job tables below are built
+     // on the host while these run (the table of buffer pointers has a device area of its own)
+    const size_t need = (size_t)n_frames * sizeof(void*);
+    if (need > F.ptab_bytes) {
+      if (F.ptab) (void)hipFree(F.ptab);  // (hipFree waits for the device: nothing still reads the old table)
+      F.ptab = nullptr;
+      F.ptab_bytes = 0;
+      SA_HIP_CHECK(hipMalloc(&F.ptab, need * 2));
+      F.ptab_bytes = need * 2;
     }
-    SA_HIP_CHECK(hipMemcpyAsync(F.scratch, bp.data(), (size_t)n_frames * sizeof(void*), hipMemcpyHostToDevice, F.stream));
+    SA_HIP_CHECK(hipMemcpyAsync(F.ptab, bp.data(), need, hipMemcpyHostToDevice, F.stream));
     const int rc = sa_flow_pyramid_build_batch(images, n_frames, frame_h, frame_w, C, c.of_window_size, c.of_max_levels,
-                                               static_cast<void* const*>(F.scratch), stream);
+                                               static_cast<void* const*>(F.ptab), stream);
     if (rc != SA_OK) return rc;
-    SA_HIP_CHECK(hipStreamSynchronize(F.stream));  // the scratch area is reused for the Lucas-Kanade job tables below
   }
   // ---- jobs
   const int Wq = c.track_window, q0 = (int)T.queue.size();

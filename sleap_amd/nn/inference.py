@@ -1141,8 +1141,10 @@ class Predictor:
                 # flow trackers look at the frames (tracker.track(..., img=...), inference.py:2662-2668, 3306-3313): the
                 # carried `image`, or re-read from the source on the rank that tracks
                 track_example(trk, ex, img_hw=image_hw_of(ex), max_instances=cap,
-                              images=frames_of(ex, data) if getattr(trk, "uses_image", False) else None)
+                              images=frames_of(ex, data) if getattr(trk, "uses_image", False) else None,
+                              images_ready=ex.get("image_ready") if ex.get("image_dev") is not None else None)
             ex.pop("image_dev", None)  # the device copy of the frames was only kept for the tracker
+            ex.pop("image_ready", None)
             done.append(ex)
         return finish_tracks(done, trk) if (tracking and done) else done
 
@@ -1469,7 +1471,7 @@ class BottomUpPredictor(Predictor):
             if world == 1:
                 ex["image"] = t["image"]
                 if t.get("image_dev") is not None:
-                    ex["image_dev"] = t["image_dev"]
+                    ex["image_dev"], ex["image_ready"] = t["image_dev"], t.get("up")
             return ex
 
         self.make_pipeline(reader)

@@ -25,6 +25,7 @@ from .._lib import check
 SIMILARITY = {"instance": 0, "centroid": 1, "iou": 2, "normalized_instance": 3, "object_keypoint": 4}
 MATCH = {"greedy": 0, "hungarian": 1}
 OKS_NORM = {"all": 0, "ref": 1, "union": 2}
+_FLOW_STREAMS = {}  # device -> the flow trackers' stream
 
 
 class _Config(C.Structure):
@@ -70,7 +71,31 @@ class Tracker:
 
     def __init__(self, **kwargs):
         self._h = None
+        self._flow_stream = None
         self._configure(**kwargs)
+
+    def _stream_for(self, frames, ready=None):
+        """The HIP stream of the flow tracker's device work (pyramids, Lucas-Kanade), as a ctypes handle. It is a stream of the
+        tracker's own: on the caller's current stream that work would queue behind whatever is already there -- inside
+        `Predictor.predict` the NEXT batch's post-processing, which waits for the next batch's network -- and the tracker's
+        stream synchronisations would serialise tracking with inference. `ready`: a CUDA event after which `frames` is
+        complete (default: everything queued on the current stream so far)."""
+        import torch
+
+        if self._flow_stream is None:
+            self._flow_stream = _FLOW_STREAMS.get(frames.device)
+        if self._flow_stream is None:
+            # one per device for all trackers (creating a hardware queue costs milliseconds)
+            # (high priority = a hardware queue of its own on ROCm: normal-priority streams share a few queues, and behind a
+            # stream that is parked on an event the tracker's launches would be parked too -- see InferenceLayer.run_network)
+            self._flow_stream = _FLOW_STREAMS[frames.device] = torch.cuda.Stream(device=frames.device, priority=-1)
+        st = self._flow_stream
+        if ready is not None:
+            st.wait_event(ready)
+        else:
+            st.wait_stream(torch.cuda.current_stream(frames.device))
+        frames.record_stream(st)
+        return C.c_void_p(st.cuda_stream)
 
     @classmethod
     def make_tracker_by_name(cls, tracker: str = "flow", similarity: str = "instance", match: str = "greedy",
@@ -210,10 +235,8 @@ class Tracker:
         ps, sc = _f32(point_scores), _f32(instance_scores)
         if self.uses_flow and img is not None:
             frame = _device_frames(img, single=True)
-            from ..ops import _stream
-
             check(_lib.lib().sa_tracker_set_image(C.c_void_p(self._h), C.c_void_p(frame.data_ptr()), frame.shape[0], frame.shape[1],
-                                                  frame.shape[2], _stream()), "sa_tracker_set_image")
+                                                  frame.shape[2], self._stream_for(frame)), "sa_tracker_set_image")
         elif self.uses_flow and n:
             raise ValueError("flow tracker: track() needs the frame (img=...)")
         idx, trk = np.full((max(n, 1),), -1, np.int32), np.full((max(n, 1),), -1, np.int32)
@@ -226,10 +249,11 @@ class Tracker:
         return {"index": idx[:m].copy(), "track": trk[:m].copy(), "tracking_score": tsc[:m].copy()}
 
     def track_frames(self, instance_peaks, instance_peak_vals=None, instance_scores=None, n_valid=None, img_hw=(1, 1),
-                     t0: Optional[int] = None, images=None, frame_t=None):
+                     t0: Optional[int] = None, images=None, frame_t=None, images_ready=None):
         """A run of consecutive frames in the predictor's output layout (F, I, N, 2) NaN padded. ->
         dict(track (F, I) int32 with -1 for empty / dropped slots, tracking_score (F, I), order (F, I)).
-        Flow trackers need `images` (F, H, W, C) uint8 (numpy or CUDA tensor); `frame_t` (F,) gives every frame its own time
+        Flow trackers need `images` (F, H, W, C) uint8 (numpy or CUDA tensor; `images_ready`: a CUDA event after which a device
+        tensor is complete, default = the current stream's work so far); `frame_t` (F,) gives every frame its own time
         step (default: t0 + f, or inferred)."""
         pts = _f32(instance_peaks)
         F, I, N = pts.shape[0], pts.shape[1], pts.shape[2]
@@ -246,12 +270,10 @@ class Tracker:
             ft = None if frame_t is None else np.ascontiguousarray(frame_t, dtype=np.int32)
             dev, fh, fw, ch, st = None, 1, 1, 1, None
             if self.uses_flow:
-                from ..ops import _stream
-
                 dev = _device_frames(images)
                 assert dev.shape[0] == F
                 fh, fw, ch = (int(v) for v in dev.shape[1:])
-                st = _stream()
+                st = self._stream_for(dev, images_ready)
             check(_lib.lib().sa_tracker_track_frames_images(
                 C.c_void_p(self._h), F, I, N, _ptr(pts), _ptr(ps), _ptr(sc), _ptr(nv), int(img_hw[0]), int(img_hw[1]),
                 -1 if t0 is None else int(t0), _ptr(ft), None if dev is None else C.c_void_p(dev.data_ptr()), fh, fw, ch, st,
@@ -318,7 +340,7 @@ def frames_of(ex, data=None):
 
 
 def track_example(tracker: Tracker, ex, img_hw=(1, 1), max_instances: Optional[int] = None, use_frame_ind: bool = True,
-                  images=None):
+                  images=None, images_ready=None):
     """Run `tracker` over the frames of one prediction dict and add `track_inds`, `tracking_scores`, `track_order` (all
     (F, I), -1 / NaN / -1 for slots that were not tracked). `images` (F, H, W, C): the frames, for flow trackers.
     Only the instances `select_instances` picks are tracked (compacted,
@@ -355,7 +377,8 @@ def track_example(tracker: Tracker, ex, img_hw=(1, 1), max_instances: Optional[i
             b = F
         r = tracker.track_frames(cp[a:b], None if cv is None else cv[a:b], None if cs is None else cs[a:b], nv[a:b],
                                  img_hw=img_hw, t0=None if fi is None else int(fi[a]),
-                                 images=None if images is None else images[a:b])
+                                 images=None if images is None else images[a:b],
+                                 **({} if images_ready is None else {"images_ready": images_ready}))
         for f in range(a, b):
             k = nv[f]
             trk[f, sel[f]] = r["track"][f - a, :k]

@@ -24,7 +24,7 @@ def _device_pyramid_levels(p):
     return out
 
 
-@pytest.mark.parametrize("shape,C", [((160, 200), 1), ((97, 131), 3), ((64, 50), 1)])
+@pytest.mark.parametrize("shape,C", [((160, 200), 1), ((97, 131), 3), ((64, 50), 1), ((128, 256), 1), ((200, 192), 3), ((70, 72), 1)])
 def test_pyramid_and_derivatives_are_exact(shape, C):
     from oracle import optical_flow as of
     from sleap_amd import ops
@@ -37,6 +37,31 @@ def test_pyramid_and_derivatives_are_exact(shape, C):
     for (g, ix, iy), r in zip(_device_pyramid_levels(p), ref):
         rx, ry = of.scharr_deriv(r)
         assert np.array_equal(g, r) and np.array_equal(ix, rx) and np.array_equal(iy, ry)
+
+
+@pytest.mark.parametrize("shape,C", [((128, 256), 1), ((97, 131), 3), ((160, 200), 1)])
+def test_batched_pyramid_build_equals_single_builds(shape, C):
+    """sa_flow_pyramid_build_batch (blockIdx.z = frame, buffers listed in a device table) == sa_flow_pyramid_build per frame"""
+    import ctypes as ct
+
+    from sleap_amd import _lib, ops
+
+    rng = np.random.default_rng(7)
+    frames = torch.from_numpy(rng.integers(0, 256, (5,) + shape + (C,), dtype=np.uint8)).cuda()
+    single = [ops.FlowPyramid(frames[f], win=21, max_level=3) for f in range(5)]
+    bufs = [torch.zeros_like(single[0].buf) for _ in range(5)]
+    table = torch.tensor([b.data_ptr() for b in bufs], dtype=torch.int64, device="cuda")
+    rc = _lib.lib().sa_flow_pyramid_build_batch(ct.c_void_p(frames.data_ptr()), 5, shape[0], shape[1], C, 21, 3,
+                                                ct.c_void_p(table.data_ptr()), ops._stream())
+    assert rc == 0
+    torch.cuda.synchronize()
+    for f in range(5):
+        p, q = single[f], bufs[f]
+        # (alignment gaps between the levels are never written: compare the level contents)
+        ref = _device_pyramid_levels(p)
+        p.buf = q
+        for a, b in zip(ref, _device_pyramid_levels(p)):
+            assert all(np.array_equal(x, y) for x, y in zip(a, b))
 
 
 @pytest.mark.parametrize("shift,win,levels", [((0.0, 0.0), 21, 3), ((1.5, -0.75), 21, 3), ((5.25, 3.5), 21, 3), ((-9.0, 6.0), 15, 2),
