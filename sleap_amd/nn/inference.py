@@ -120,7 +120,9 @@ class InferenceLayer:
             # page-locked host batch (the FramePrefetcher's): upload on a copy stream of its own so that the DMA of batch
             # k+1 runs under the network of batch k instead of queueing behind it on the network stream
             if self._copy_stream is None:
-                self._copy_stream = torch.cuda.Stream()
+                # high priority for the same reason as the network stream: a queue of its own -- in a shared hardware queue the
+                # upload of batch k+2 can sit behind the post-processing of batch k+1, which waits for network k+1
+                self._copy_stream = torch.cuda.Stream(priority=int(os.environ.get("SLEAP_AMD_COPY_STREAM_PRIORITY", "-1")))
             with torch.cuda.stream(self._copy_stream):
                 dev = src.cuda(non_blocking=True)
                 up = torch.cuda.Event()
