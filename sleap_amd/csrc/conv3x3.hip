@@ -256,6 +256,7 @@ struct ConvParams2 {
   int planar;
   int pix_bytes0, pix_bytes1;  // bytes between consecutive pixels of src0 / src1 (NHWC: 2 CP; planes: 32)
   unsigned blk_bytes_in;       // bytes between consecutive 16-channel blocks of a source (NHWC: 32; planes: H W 32)
+  unsigned blk_bytes_in1;      // the same for src1 when it is read at half resolution (UPS kernels: planes of H/2 x W/2 pixels)
   int out_pix_bytes;           // the same for the outputs: pixel stride (NHWC: 2 CoutP; planes: 32),
   unsigned out_blk_bytes, out_blk_bytes_pool;  // 16-channel block stride of dst / dst_pool (NHWC: 32; planes: pixels per frame x 32)
 };
@@ -275,7 +276,18 @@ __device__ __forceinline__ int swz(int p) {
 // pixel that lies outside the image is set beyond num_records, for which the hardware writes zeros to LDS
 // (verified by tools/probes/buffer_lds_oob.hip) -- SAME padding costs nothing; the chunk's channel offset and
 // the weight-slab offset travel in the scalar offset, so issuing a copy is one SALU add + one VMEM instruction.
-template <int MT, int CK, int NW, int R, int NBUF, bool HEADS, int STEM_CIN, bool EXT>
+//
+// UPS (SA_SRC1_UPSAMPLE2X on 16-channel planes): src1 is stored at HALF resolution and enters the convolution through
+// UpSampling2D(2, bilinear) -- the decoder's Concatenate([skip, upsampled]) without the upsampled tensor ever existing in
+// HBM (it is 4x the size of its source: a quarter of the plan's activation bytes, and 0.4 ms of bandwidth-bound upsampling
+// kernels per 64-frame step). A src1 chunk is copied as the LOW-resolution tile that the halo tile touches ((TH/2 + 2) x
+// (TW/2 + 2) pixels x 32 bytes = 6 one-KiB pieces instead of 20, edge pixels clamped in the copy's addresses) into the TAIL of
+// the stage's input area; when the chunk's turn comes the workgroup expands it in place: every thread reads the 2 x 2
+// low-resolution pixels of one 2 x 2 block of halo-tile pixels (one 8-channel half), barrier, then writes the four interpolated
+// pixels (fp32 arithmetic in the operation order of upsample2x_bilinear_c16_kernel, rounded once: the SAME bits the
+// materialised tensor would hold; halo pixels outside the image are the convolution's zero padding) where the copy engine
+// would have put them. Two extra barriers per src1 chunk, no extra LDS.
+template <int MT, int CK, int NW, int R, int NBUF, bool HEADS, int STEM_CIN, bool EXT, bool UPS>
 __global__ void __launch_bounds__(NW * 64, (NW == 8 && MT <= 2 && NBUF == 2 && !EXT && CK == 16 && STEM_CIN == 0) ? 4 : 1)
 conv3x3_dma_kernel(const ConvParams2 p) {
 #if defined(__HIP_DEVICE_COMPILE__)  // the body uses device-only types (buffer resources); the host pass only needs the stub
@@ -290,6 +302,11 @@ conv3x3_dma_kernel(const ConvParams2 p) {
   constexpr int IN_PER_WAVE = (N_IN + NW - 1) / NW;
   constexpr int W_PER_WAVE = (N_W + NW - 1) / NW;
   constexpr unsigned OOB = 0xFFFFFF00u;
+  // UPS: the low-resolution tile under the halo tile, copied to the last N_LOW KiB of the stage's input area
+  constexpr int LH = TH / 2 + 2, LW = TW / 2 + 2, N_LOW = (LH * LW * 32 + 1023) / 1024, LOW_OFF = IN_BYTES - N_LOW * 1024;
+  static_assert(!UPS || (CK == 16 && NBUF == 2 && STEM_CIN == 0 && !EXT && !HEADS && N_LOW <= NW && LOW_OFF >= 0 && TH % 2 == 0),
+                "UPS: 16-channel chunks, two stages, plain epilogue");
+  static_assert(!UPS || ((PH / 2) * (PW / 2) * 2 <= NW * 64 && PH % 2 == 0 && PW % 2 == 0), "UPS: one 2x2 block and half per thread");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -332,7 +349,7 @@ conv3x3_dma_kernel(const ConvParams2 p) {
   Tile cur = decode(L);
 
   // ---- buffer descriptors (wave-uniform): one frame of each source, the packed weights
-  const size_t f0 = (size_t)H * W * p.C0P * 2, f1 = (size_t)H * W * p.C1P * 2;
+  const size_t f0 = (size_t)H * W * p.C0P * 2, f1 = UPS ? (size_t)(H / 2) * (W / 2) * p.C1P * 2 : (size_t)H * W * p.C1P * 2;
   const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(
       (void*)p.w, 0, (int)((size_t)co32_n * K16 * 9 * 1024), 0x00020000);
 
@@ -354,8 +371,17 @@ conv3x3_dma_kernel(const ConvParams2 p) {
       v1[j] = ok ? pix * (unsigned)p.pix_bytes1 + q16 : OOB;
     }
   };
+  // UPS: byte offset of this lane's 16-byte piece of the low-resolution tile inside a src1 plane (wave w copies piece w)
+  auto make_voff_low = [&](const Tile& t, int ln) -> unsigned {
+    const int i = wave * 64 + ln, lp = i >> 1, hf = i & 1;
+    const int ly = lp / LW, lx = lp - ly * LW;
+    const int gy = min(max((t.y0 >> 1) - 1 + ly, 0), (H >> 1) - 1), gx = min(max((t.x0 >> 1) - 1 + lx, 0), (W >> 1) - 1);
+    return (wave < N_LOW && lp < LH * LW) ? (unsigned)(gy * (W >> 1) + gx) * (unsigned)p.pix_bytes1 + (unsigned)hf * 16u : OOB;
+  };
   unsigned voff0[IN_PER_WAVE], voff1[IN_PER_WAVE];
   make_voff(cur, lane, voff0, voff1);
+  unsigned voff_low = 0;
+  if constexpr (UPS) voff_low = make_voff_low(cur, lane);
   const unsigned wv = (unsigned)lane * 16;
 
   auto issue = [&](const Tile& t, const unsigned (&v0)[IN_PER_WAVE], const unsigned (&v1)[IN_PER_WAVE], int chunk, int buf) {
@@ -363,7 +389,7 @@ conv3x3_dma_kernel(const ConvParams2 p) {
     const bool from1 = c_lo >= p.C0P;
     // byte offset of the chunk's first channel inside a pixel record (NHWC: 2 bytes per channel) or of its plane (planes:
     // H W 32 bytes per 16 channels); 32-bit unsigned arithmetic, a frame is < 4 GiB
-    const int cc2 = (int)((unsigned)((from1 ? c_lo - p.C0P : c_lo) >> 4) * p.blk_bytes_in);
+    const int cc2 = (int)((unsigned)((from1 ? c_lo - p.C0P : c_lo) >> 4) * ((UPS && from1) ? p.blk_bytes_in1 : p.blk_bytes_in));
     unsigned char* stage = smem + buf * STAGE;
     const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(STEM_CIN ? reinterpret_cast<const unsigned char*>(p.w) : reinterpret_cast<const unsigned char*>(p.src0) + t.b * f0), 0,
@@ -371,14 +397,19 @@ conv3x3_dma_kernel(const ConvParams2 p) {
     const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(p.C1P ? reinterpret_cast<const unsigned char*>(p.src1) + t.b * f1 : reinterpret_cast<const unsigned char*>(p.w)), 0,
         (int)f1, 0x00020000);
+    if (UPS && from1) {  // wave-uniform: the low-resolution tile, one piece per wave
+      if (wave < N_LOW)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, (lds_ptr_t)(stage + LOW_OFF + wave * 1024), 16, voff_low, cc2, 0, 0);
+    } else {
 #pragma unroll
-    for (int j = 0; j < IN_PER_WAVE; ++j) {
-      const int i = j * NW + wave;
-      if (STEM_CIN == 0 && i < N_IN) {
-        if (from1)
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, (lds_ptr_t)(stage + i * 1024), 16, v1[j], cc2, 0, 0);
-        else
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, (lds_ptr_t)(stage + i * 1024), 16, v0[j], cc2, 0, 0);
+      for (int j = 0; j < IN_PER_WAVE; ++j) {
+        const int i = j * NW + wave;
+        if (STEM_CIN == 0 && i < N_IN) {
+          if (from1)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, (lds_ptr_t)(stage + i * 1024), 16, v1[j], cc2, 0, 0);
+          else
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, (lds_ptr_t)(stage + i * 1024), 16, v0[j], cc2, 0, 0);
+        }
       }
     }
 #pragma unroll
@@ -618,6 +649,77 @@ conv3x3_dma_kernel(const ConvParams2 p) {
     }
     const unsigned char* in_tile = smem + buf * STAGE;
     const unsigned char* w_tile = in_tile + IN_BYTES;
+    if constexpr (UPS) {
+      if (chunk * CK >= p.C0P) {  // wave-uniform: this chunk arrived as a low-resolution tile -- expand it in place
+        unsigned char* tile = smem + buf * STAGE;
+        int t_id = tid;
+        asm volatile("" : "+v"(t_id));  // (derived per chunk, not kept in registers across the MFMA loop)
+        constexpr int NBX = PW / 2, NBLK = (PH / 2) * NBX;  // 2x2 blocks of the halo tile: 9 rows of 17
+        const bool actv = t_id < NBLK * 2;
+        const int u = actv ? t_id : 0, hf = u & 1, blk = u >> 1;
+        const int rp = blk / NBX, cp = blk - rp * NBX;
+        // halo-tile rows 2rp, 2rp+1 are image rows y0-1+2rp (odd: weight 0.25 on the lower source row) and y0+2rp (even: 0.75);
+        // both read low-resolution tile rows rp, rp+1; columns alike
+        const unsigned char* lo = tile + LOW_OFF + ((rp * LW + cp) * 2 + hf) * 16;
+        const h16x8_t tA = *reinterpret_cast<const h16x8_t*>(lo), tB = *reinterpret_cast<const h16x8_t*>(lo + 32);
+        const h16x8_t uA = *reinterpret_cast<const h16x8_t*>(lo + LW * 32), uB = *reinterpret_cast<const h16x8_t*>(lo + LW * 32 + 32);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();  // every read of the low-resolution tile is done: its bytes may be overwritten
+        asm volatile("" ::: "memory");
+        // four channels at a time, in order (scheduling barriers: interleaving all eight channels for ILP costs ~20 more live
+        // registers than this kernel has left next to its 64 accumulators), each quad stored as soon as it is complete
+        unsigned woff[2][2];
+        bool in_img[2][2];
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+          for (int dx = 0; dx < 2; ++dx) {
+            const int ty = 2 * rp + dy, tx = 2 * cp + dx, pl = ty * PW + tx;
+            const int gy = cur.y0 - 1 + ty, gx = cur.x0 - 1 + tx;
+            in_img[dy][dx] = gy >= 0 && gy < H && gx >= 0 && gx < W;  // outside: the convolution's SAME padding
+            woff[dy][dx] = (unsigned)(pl * PIXB + ((hf ^ swz<CK>(pl)) * 16));
+          }
+#pragma unroll
+        for (int q4 = 0; q4 < 2; ++q4) {
+          uint2 o[2][2];
+#pragma unroll
+          for (int pr2 = 0; pr2 < 2; ++pr2) {
+            float r[2][2][2];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+              const int c = q4 * 4 + pr2 * 2 + e;
+              const float a = sa::h2f(tA[c]), b_ = sa::h2f(tB[c]), cc = sa::h2f(uA[c]), d = sa::h2f(uB[c]);
+              const float t25 = a + (b_ - a) * 0.25f, t75 = a + (b_ - a) * 0.75f;   // source row rp at the odd / even image column
+              const float u25 = cc + (d - cc) * 0.25f, u75 = cc + (d - cc) * 0.75f;  // source row rp+1
+              r[0][0][e] = t25 + (u25 - t25) * 0.25f;
+              r[0][1][e] = t75 + (u75 - t75) * 0.25f;
+              r[1][0][e] = t25 + (u25 - t25) * 0.75f;
+              r[1][1][e] = t75 + (u75 - t75) * 0.75f;
+            }
+#pragma unroll
+            for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+              for (int dx = 0; dx < 2; ++dx) {
+                const unsigned v = sa::f2h2(r[dy][dx][0], r[dy][dx][1]);
+                if (pr2 == 0)
+                  o[dy][dx].x = v;
+                else
+                  o[dy][dx].y = v;
+              }
+            __builtin_amdgcn_sched_barrier(0);
+          }
+#pragma unroll
+          for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx)
+              if (actv) *reinterpret_cast<uint2*>(tile + woff[dy][dx] + q4 * 8) = in_img[dy][dx] ? o[dy][dx] : make_uint2(0u, 0u);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+      }
+    }
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
       const int dy = tap / 3, dx = tap % 3;
@@ -864,7 +966,7 @@ conv3x3_dma_kernel(const ConvParams2 p) {
 #endif
 }
 
-template <int MT, int CK, int NW, int R, int NBUF, bool HEADS, int STEM_CIN = 0, bool EXT = false>
+template <int MT, int CK, int NW, int R, int NBUF, bool HEADS, int STEM_CIN = 0, bool EXT = false, bool UPS = false>
 int launch2(const ConvParams2& p, hipStream_t st) {
   constexpr int TH = NW * R;
   constexpr int N_IN = ((TH + 2) * 34 * CK * 2 + 1023) / 1024;
@@ -879,6 +981,9 @@ int launch2(const ConvParams2& p, hipStream_t st) {
   q.pix_bytes0 = p.planar ? 32 : p.C0P * 2;
   q.pix_bytes1 = p.planar ? 32 : p.C1P * 2;
   q.blk_bytes_in = p.planar ? (unsigned)((size_t)p.H * p.W * 32) : 32u;
+  q.blk_bytes_in1 = (unsigned)((size_t)(p.H / 2) * (p.W / 2) * 32);
+  if (UPS && !(p.planar && CK == 16 && p.C1P > 0 && p.C0P > 0 && p.H % 2 == 0 && p.W % 2 == 0))
+    return sa::fail(SA_ERR_UNSUPPORTED, "sa_conv3x3: the upsampling source mode of the DMA kernels needs SA_LAYOUT_PLANES16 and even H, W");
   q.out_pix_bytes = p.planar ? 32 : p.CoutP * 2;
   q.out_blk_bytes = p.planar ? (unsigned)((size_t)p.H * p.W * 32) : 32u;
   q.out_blk_bytes_pool = p.planar ? (unsigned)((size_t)(p.H / 2) * (p.W / 2) * 32) : 32u;
@@ -889,7 +994,7 @@ int launch2(const ConvParams2& p, hipStream_t st) {
     return sa::fail(SA_ERR_UNSUPPORTED, "sa_conv3x3_bf16: one frame must be smaller than 4 GiB");
   static bool attr_set = false;
   if (!attr_set && lds > 64 * 1024) {
-    SA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_dma_kernel<MT, CK, NW, R, NBUF, HEADS, STEM_CIN, EXT>),
+    SA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_dma_kernel<MT, CK, NW, R, NBUF, HEADS, STEM_CIN, EXT, UPS>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
@@ -915,7 +1020,7 @@ int launch2(const ConvParams2& p, hipStream_t st) {
       SA_HIP_CHECK(hipGetDevice(&dev));
       SA_HIP_CHECK(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
       SA_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(
-          &nb, reinterpret_cast<const void*>(&conv3x3_dma_kernel<MT, CK, NW, R, NBUF, HEADS, STEM_CIN, EXT>), NW * 64, lds));
+          &nb, reinterpret_cast<const void*>(&conv3x3_dma_kernel<MT, CK, NW, R, NBUF, HEADS, STEM_CIN, EXT, UPS>), NW * 64, lds));
       per_cu = nb > 0 ? nb : 1;
     }
     if (g_grid_limit > 0) {
@@ -925,7 +1030,7 @@ int launch2(const ConvParams2& p, hipStream_t st) {
       if (cap < grid) grid = cap;
     }
   }
-  hipLaunchKernelGGL((conv3x3_dma_kernel<MT, CK, NW, R, NBUF, HEADS, STEM_CIN, EXT>), dim3((unsigned)grid), dim3(NW * 64), lds, st, q);
+  hipLaunchKernelGGL((conv3x3_dma_kernel<MT, CK, NW, R, NBUF, HEADS, STEM_CIN, EXT, UPS>), dim3((unsigned)grid), dim3(NW * 64), lds, st, q);
   SA_LAUNCH_CHECK();
   return SA_OK;
 }
@@ -1020,7 +1125,10 @@ static int conv3x3_impl(const void* src0, int C0P, const void* src1, int C1P, in
   const bool ck32 = can32 && !planar && (force_ck == 32 || (force_ck == 0 && C0P + C1P == 32 && CoutP <= 32));
   const int co32_n = (CoutP + 31) / 32;
   const int src_mode = mode & 7;
-  if (src_mode == SA_SRC1_NONE || src_mode == SA_SRC1_DIRECT) {
+  // On 16-channel planes the upsampling source mode runs on the DMA pipeline too (UPS kernels: the half-resolution tile is
+  // expanded in LDS); on NHWC tensors it stays with the register-staged first-generation kernel below.
+  const bool ups = src_mode == SA_SRC1_UPSAMPLE2X && planar;
+  if (src_mode == SA_SRC1_NONE || src_mode == SA_SRC1_DIRECT || ups) {
     // v2 DMA pipeline; the pooled output (SA_DST_POOL2X) is only implemented here
     static const uint16_t* zeros = nullptr;
     if (!zeros) {
@@ -1096,6 +1204,12 @@ static int conv3x3_impl(const void* src0, int C0P, const void* src1, int C1P, in
     }
     const size_t tiles2 = (size_t)B * ((H + 15) / 16) * ((W + 31) / 32) * ((co32_n + 1) / 2);
     const bool few = small_mt1 && co32_n >= 2 && n_heads == 0 && (C0P + C1P) > 16 && tiles2 < (size_t)2 * n_cu;
+    if (ups) {
+      SA_REQUIRE(n_heads == 0 && !post_scale && !residual && !relu_last,
+                 "sa_conv3x3: fused heads / the extended epilogue are not available with the upsampling source mode");
+      if (co32_n >= 2 && !few) return launch2<2, 16, 8, 2, 2, false, 0, false, true>(q, st);
+      return launch2<1, 16, 8, 2, 2, false, 0, false, true>(q, st);
+    }
     if (co32_n >= 2 && !few) return ck32 ? launch2_pick<2, 32>(q, st) : launch2_pick<2, 16>(q, st);
     return ck32 ? launch2_pick<1, 32>(q, st) : launch2_pick<1, 16>(q, st);
   }

@@ -119,8 +119,10 @@ int sa_network_create(const int64_t* plan, size_t n_words, sa_network_t** out) {
     bool fits = true;
     for (const Op& op : n->ops) {
       fits = fits && (op.kind == K_STEM2 || op.kind == K_PAIR || op.kind == K_UP || op.kind == K_CONV);
-      if (op.kind == K_CONV && op.a.size() >= 10)  // plain / concat sources, no extended epilogue
-        fits = fits && (op.a[2] == SA_SRC1_NONE || op.a[2] == SA_SRC1_DIRECT) && op.a[10 + 5 * (size_t)op.a[9]] == 0;
+      if (op.kind == K_CONV && op.a.size() >= 10)  // plain / concat sources (the second one also through the upsampling
+        fits = fits &&                            // source mode, without fused heads), no extended epilogue
+               (op.a[2] == SA_SRC1_NONE || op.a[2] == SA_SRC1_DIRECT || (op.a[2] == SA_SRC1_UPSAMPLE2X && op.a[9] == 0)) &&
+               op.a[10 + 5 * (size_t)op.a[9]] == 0;
     }
     for (const Out& o : n->outs) fits = fits && (o.is_f32 || n->bufs[(size_t)o.buf].cp == 16);
     if (!fits) {

@@ -78,12 +78,13 @@ DEFAULT_DTYPE = None  # set (temporarily) by load_model(dtype=...); otherwise _l
 
 
 class DeviceNetwork:
-    def __init__(self, model_config: dict, weights: Dict[str, np.ndarray], device=None, fuse_upsample: bool = False,
+    def __init__(self, model_config: dict, weights: Dict[str, np.ndarray], device=None, fuse_upsample: Optional[bool] = None,
                  fuse_heads: bool = True, fuse_stem: bool = True, use_stem16: bool = True, mfma_convt: bool = True,
                  mfma_stem: bool = True, fuse_pairs: bool = True, dtype: Optional[str] = None, layout: Optional[str] = None):
-        """`fuse_upsample=True` folds UpSampling2D(bilinear) into the consuming conv's tile load (register-staged
-        v1 kernel); the default materialises the upsampled tensor with the bandwidth-bound standalone kernel and
-        feeds the asynchronous-DMA conv kernel (faster overall, measured in profiles/)."""
+        """`fuse_upsample=True` folds UpSampling2D(bilinear) into the consuming conv: on 16-channel planes the DMA kernel copies
+        the half-resolution tile and expands it in LDS (the upsampled tensor never exists in HBM); on NHWC tensors the
+        register-staged first-generation kernel does it on load (slower than materialising the tensor for the DMA kernel).
+        None = SA_FUSE_UPSAMPLE from the environment (default 0), and only when the plan ends up on planes."""
         require_cuda()
         # 16-bit storage type of activations and conv weights: "fp16" (default; 11-bit mantissa: heads within 0.1-0.5 % of an
         # fp32 network, finite range 65504) or "bf16" (fp32 range, 8-bit mantissa: 1-4 %). SLEAP_AMD_DTYPE sets the default.
@@ -95,7 +96,8 @@ class DeviceNetwork:
         # layout of the 16-bit activation tensors: None = 16-channel planes when every launch of the compiled plan supports
         # them (the UNet family), NHWC otherwise; "nhwc" / "planes16" force one (SA_LAYOUT in the environment likewise)
         self._layout_request = layout or os.environ.get("SA_LAYOUT") or None
-        self.fuse_upsample = fuse_upsample
+        auto_up = fuse_upsample is None
+        self.fuse_upsample = (os.environ.get("SA_FUSE_UPSAMPLE", "0") == "1") if auto_up else bool(fuse_upsample)
         self.fuse_heads = fuse_heads
         self.fuse_stem = fuse_stem
         self.use_stem16 = use_stem16
@@ -114,6 +116,9 @@ class DeviceNetwork:
             if l["class_name"] == "InputLayer":
                 self.in_channels = l["config"]["batch_input_shape"][-1]
         self._compile()
+        if auto_up and self.fuse_upsample and not self.planar:  # (only the plane kernels gain from it)
+            self.fuse_upsample = False
+            self._compile()
         self._buffers = {}
 
     # ------------------------------------------------------------------ compile
@@ -576,7 +581,9 @@ class DeviceNetwork:
             k = op[0]
             if k in ("stem2", "pair", "up"):
                 return True
-            return k == "conv" and op.mode in (_lib.SRC1_NONE, _lib.SRC1_DIRECT) and op.ext is None
+            if k != "conv" or op.ext is not None:
+                return False
+            return op.mode in (_lib.SRC1_NONE, _lib.SRC1_DIRECT) or (op.mode == _lib.SRC1_UPSAMPLE2X and not op.heads)
 
         ok = all(fits(op) for op in self.plan) and all(o.kind == "f32out" or o.cp == 16 for o in self.outputs)
         if req == "planes16" and not ok:

@@ -290,7 +290,7 @@ def test_layerwise_vs_bf16_emulating_oracle():
 
 
 @pytest.mark.parametrize("fuse", [dict(fuse_stem=False), dict(use_stem16=False), dict(fuse_heads=False), dict(fuse_upsample=True),
-                                  dict(fuse_stem=False, fuse_heads=False)])
+                                  dict(fuse_upsample=True, layout="nhwc"), dict(fuse_stem=False, fuse_heads=False)])
 def test_fusion_variants_agree(fuse):
     """Every fusion switch of the engine computes the same network up to bf16 rounding flips: the fused stem
     evaluates the first conv on the matrix cores (3-term bf16 split of the fp32 weights, fp32-accurate), fused
@@ -369,6 +369,52 @@ def test_conv3x3_planes16_is_bitwise_nhwc(C0, C1, Cout, B, H, W, full, pooled):
             assert torch.equal(u, ops.from_planes16(v))
 
 
+@pytest.mark.parametrize("C0,C1,Cout,B,H,W,full,pooled", [
+    (64, 128, 64, 2, 32, 64, True, False), (256, 512, 256, 1, 16, 32, True, False), (128, 256, 128, 1, 48, 96, True, True),
+    (16, 32, 32, 2, 18, 34, True, False), (64, 64, 128, 1, 12, 20, True, False), (32, 48, 16, 1, 64, 32, True, False),
+    (64, 128, 64, 1, 2, 2, True, False)])
+def test_conv3x3_upsampling_source_on_planes_is_bitwise_the_materialised_path(C0, C1, Cout, B, H, W, full, pooled):
+    """SA_SRC1_UPSAMPLE2X on 16-channel planes (the half-resolution tile expanded in LDS) == sa_upsample2x_bf16 followed by the
+    SA_SRC1_DIRECT convolution, bit for bit: same interpolation arithmetic, one rounding, same accumulation order. Ragged
+    tiles, image borders (clamped sources, zero padding of the halo), one and two 32-channel output tiles per workgroup."""
+    from sleap_amd import _lib, ops
+    from sleap_amd._lib import check
+    from sleap_amd.ops import _ptr, _stream
+
+    g = torch.Generator(device="cpu").manual_seed(C0 + 3 * C1 + H)
+    k = (torch.randn((3, 3, C0 + C1, Cout), generator=g) * (2.0 / (9 * (C0 + C1))) ** 0.5).numpy()
+    pw = ops.pack_conv3x3_weights(k, C0, C1)
+    bias = (0.1 * torch.randn((Cout,), generator=g)).cuda()
+    x0 = ops.to_planes16(ops.to_bf16_padded(torch.randn((B, H, W, C0), generator=g).cuda()))
+    low = ops.to_planes16(ops.to_bf16_padded(torch.randn((B, H // 2, W // 2, C1), generator=g).cuda()))
+    up = torch.empty((B, H, W, low.shape[3]), dtype=TD, device="cuda")
+    check(_lib.lib().sa_upsample2x_bf16(_ptr(low), B * (low.shape[3] // 16), H // 2, W // 2, 16, 1, _ptr(up), _stream()), "sa_upsample2x_bf16")
+    P = _lib.LAYOUT_PLANES16
+    a = ops.conv3x3(x0, up, _lib.SRC1_DIRECT | P, pw, bias, Cout, True, (H, W), full=full, pooled=pooled)
+    b = ops.conv3x3(x0, low, _lib.SRC1_UPSAMPLE2X | P, pw, bias, Cout, True, (H, W), full=full, pooled=pooled)
+    a = a if isinstance(a, tuple) else (a,)
+    b = b if isinstance(b, tuple) else (b,)
+    for u, v in zip(a, b):
+        assert torch.equal(u, v)
+
+
+def test_fused_upsampling_network_is_bitwise_the_materialised_one():
+    """DeviceNetwork(fuse_upsample=True) on planes: no upsampling launches, same outputs bit for bit (C executor and the
+    per-launch Python loop)."""
+    from sleap_amd.nn.engine import DeviceNetwork
+
+    cfg, w = _benchmark_unet(96, 128)
+    x = torch.from_numpy(_fly_frames(3, 96, 128, 11)).cuda()
+    a, b = DeviceNetwork(cfg, w), DeviceNetwork(cfg, w, fuse_upsample=True)
+    assert a.planar and b.planar and any(op[0] == "up" for op in a.plan) and not any(op[0] == "up" for op in b.plan)
+    base = [o.clone() for o in a.forward(x)]
+    for p, q in zip(base, b.forward(x)):
+        assert torch.equal(p, q)
+    prof = []
+    for p, q in zip(base, b.forward(x, profile=prof)):
+        assert torch.equal(p, q)
+
+
 @pytest.mark.parametrize("B,H,W,C", [(2, 8, 12, 16), (1, 5, 7, 48), (3, 16, 16, 128)])
 def test_upsample2x_planes16_is_bitwise_nhwc_and_matches_torch(B, H, W, C):
     """UpSampling2D(2, bilinear) (encoder_decoder.py:335-339): the 16-channel kernel that serves plane tensors writes the same
@@ -399,7 +445,7 @@ def test_network_layout_is_bitwise_neutral():
     a = DeviceNetwork(cfg, w)
     b = DeviceNetwork(cfg, w, layout="nhwc")
     assert a.planar and not b.planar
-    assert not DeviceNetwork(cfg, w, fuse_heads=False).planar and not DeviceNetwork(cfg, w, fuse_upsample=True).planar
+    assert not DeviceNetwork(cfg, w, fuse_heads=False).planar and DeviceNetwork(cfg, w, fuse_upsample=True).planar
     with pytest.raises(NotImplementedError):
         DeviceNetwork(cfg, w, fuse_heads=False, layout="planes16")
     base = [o.clone() for o in a.forward(x)]
