@@ -263,7 +263,10 @@ size_t sa_stem16_blob_bytes(void);
  *   w packed by sa_pack_conv3x3_weights: [ceil(CoutP/32)][(C0P+C1P)/16][9 taps][64 lanes][8] bf16 (MFMA
  *   A-fragment order);  bias [CoutP] f32
  *   dst [B,H,W,CoutP] bf16 and/or dst_pool [B,H/2,W/2,CoutP] bf16 = MaxPool2D(2,s2) of the same output fused
- *   into the epilogue (either may be NULL; dst_pool only with mode NONE/DIRECT) */
+ *   into the epilogue (either may be NULL; dst_pool only with mode NONE/DIRECT, or SA_SRC1_UPSAMPLE2X on planes)
+ *   SA_SRC1_UPSAMPLE2X: src1 is [B,H/2,W/2,C1P] and enters through UpSampling2D(2, bilinear), the values a stored upsampled
+ *   tensor would hold (bitwise). With SA_LAYOUT_PLANES16 the half-resolution tile is copied by the DMA pipeline and expanded
+ *   in LDS; on NHWC tensors the register-staged first-generation kernel does it (no pooled output, no fused heads there). */
 int sa_conv3x3_bf16(const void* src0, int C0P, const void* src1, int C1P, int mode, const void* w,
                     const float* bias, int CoutP, int relu, int B, int H, int W, void* dst, void* dst_pool,
                     sa_stream_t stream);
