@@ -287,7 +287,14 @@ __device__ __forceinline__ int swz(int p) {
 // pixels (fp32 arithmetic in the operation order of upsample2x_bilinear_c16_kernel, rounded once: the SAME bits the
 // materialised tensor would hold; halo pixels outside the image are the convolution's zero padding) where the copy engine
 // would have put them. Two extra barriers per src1 chunk, no extra LDS.
-template <int MT, int CK, int NW, int R, int NBUF, bool HEADS, int STEM_CIN, bool EXT, bool UPS>
+//
+// ITAP: where in a chunk the copies of the NEXT chunk are queued. -1: right after the chunk's barrier -- the most time to land,
+// what the HBM-bound few-chunk layers want. t >= 0: after tap t of the chunk's nine -- by then the wave has MFMAs in flight and
+// its copy instructions (a few SALU + one VMEM each, ~60-180 cycles of issue apiece) go out under its own matrix-core work
+// instead of in front of it. Measured on MI355X (profiles/r02_ab_session.md section 13): t = 2..4 takes 3-7 % off every layer with
+// >= 8 chunks (512->512 @32: 0.196 -> 0.182 ms, 768->256 @64: 0.557 -> 0.525), t >= 6 leaves the copy too little time, and the
+// 2-4 chunk 256 x 256 layers lose 3-5 % with any t > 0.
+template <int MT, int CK, int NW, int R, int NBUF, bool HEADS, int STEM_CIN, bool EXT, bool UPS, int ITAP>
 __global__ void __launch_bounds__(NW * 64, (NW == 8 && MT <= 2 && NBUF == 2 && !EXT && CK == 16 && STEM_CIN == 0) ? 4 : 1)
 conv3x3_dma_kernel(const ConvParams2 p) {
 #if defined(__HIP_DEVICE_COMPILE__)  // the body uses device-only types (buffer resources); the host pass only needs the stub
@@ -384,7 +391,9 @@ conv3x3_dma_kernel(const ConvParams2 p) {
   if constexpr (UPS) voff_low = make_voff_low(cur, lane);
   const unsigned wv = (unsigned)lane * 16;
 
-  auto issue = [&](const Tile& t, const unsigned (&v0)[IN_PER_WAVE], const unsigned (&v1)[IN_PER_WAVE], int chunk, int buf) {
+  // part < 0: all of this wave's pieces; part = q: only its q-th (inputs first, then weights) -- SA_CONV_ISSUE_SPREAD builds
+  auto issue = [&](const Tile& t, const unsigned (&v0)[IN_PER_WAVE], const unsigned (&v1)[IN_PER_WAVE], int chunk, int buf,
+                   int part = -1) {
     const int c_lo = chunk * CK;
     const bool from1 = c_lo >= p.C0P;
     // byte offset of the chunk's first channel inside a pixel record (NHWC: 2 bytes per channel) or of its plane (planes:
@@ -398,13 +407,13 @@ conv3x3_dma_kernel(const ConvParams2 p) {
         (void*)(p.C1P ? reinterpret_cast<const unsigned char*>(p.src1) + t.b * f1 : reinterpret_cast<const unsigned char*>(p.w)), 0,
         (int)f1, 0x00020000);
     if (UPS && from1) {  // wave-uniform: the low-resolution tile, one piece per wave
-      if (wave < N_LOW)
+      if (wave < N_LOW && part <= 0)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, (lds_ptr_t)(stage + LOW_OFF + wave * 1024), 16, voff_low, cc2, 0, 0);
     } else {
 #pragma unroll
       for (int j = 0; j < IN_PER_WAVE; ++j) {
         const int i = j * NW + wave;
-        if (STEM_CIN == 0 && i < N_IN) {
+        if (STEM_CIN == 0 && i < N_IN && (part < 0 || part == j)) {
           if (from1)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, (lds_ptr_t)(stage + i * 1024), 16, v1[j], cc2, 0, 0);
           else
@@ -415,7 +424,7 @@ conv3x3_dma_kernel(const ConvParams2 p) {
 #pragma unroll
     for (int j = 0; j < W_PER_WAVE; ++j) {
       const int k = j * NW + wave;  // (m, kk, tap) slab index
-      if (k < N_W) {
+      if (k < N_W && (part < 0 || part == IN_PER_WAVE + j)) {
         const int m = k / (KK * 9), rest = k - m * (KK * 9);
         // cout tiles beyond CoutP read out of range -> zeros
         const int soff = (t.co32_0 + m < co32_n) ? (((t.co32_0 + m) * K16 + chunk * KK) * 9 + rest) * 1024 : (int)0x7FFFF000;
@@ -636,17 +645,24 @@ conv3x3_dma_kernel(const ConvParams2 p) {
   for (int chunk = 0; chunk < n_chunks; ++chunk) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if constexpr (NBUF == 2) {
-      if (chunk + 1 < n_chunks) {
-        issue(cur, voff0, voff1, chunk + 1, buf ^ 1);
-      } else if (more) {  // cross-tile prefetch: chunk 0 of the next tile lands while this tile's epilogue runs
-        nxt = decode(L_next);
-        int ln = lane;
-        asm volatile("" : "+v"(ln));
-        make_voff(nxt, ln, voff0, voff1);  // this tile issues no more copies: its offsets are dead
-        issue(nxt, voff0, voff1, 0, buf ^ 1);
+    // the copies of the next chunk: queued right after the barrier (ITAP < 0) or after tap ITAP of the MFMA sequence below
+    auto prefetch = [&](int part) {
+      if constexpr (NBUF == 2) {
+        if (chunk + 1 < n_chunks) {
+          issue(cur, voff0, voff1, chunk + 1, buf ^ 1, part);
+        } else if (more) {  // cross-tile prefetch: chunk 0 of the next tile lands while this tile's epilogue runs
+          if (part <= 0) {
+            nxt = decode(L_next);
+            int ln = lane;
+            asm volatile("" : "+v"(ln));
+            make_voff(nxt, ln, voff0, voff1);  // this tile issues no more copies: its offsets are dead
+          }
+          issue(nxt, voff0, voff1, 0, buf ^ 1, part);
+        }
       }
-    }
+    };
+    constexpr int ISSUE_TAP = (NBUF == 2 && !UPS) ? ITAP : -1;
+    if constexpr (ISSUE_TAP < 0) prefetch(-1);
     const unsigned char* in_tile = smem + buf * STAGE;
     const unsigned char* w_tile = in_tile + IN_BYTES;
     if constexpr (UPS) {
@@ -736,6 +752,24 @@ conv3x3_dma_kernel(const ConvParams2 p) {
           for (int m = 0; m < MT; ++m)
             acc[m][r] = SA_MFMA_32x32x16(a[m], bv, acc[m][r], 0, 0, 0);
         }
+      }
+      if constexpr (ISSUE_TAP >= 0) {
+#if defined(SA_CONV_ISSUE_SPREAD)  // experiment: one piece per tap from ISSUE_TAP on (the last tap takes what is left)
+        constexpr int NP = IN_PER_WAVE + W_PER_WAVE;
+#pragma unroll
+        for (int q = 0; q < NP; ++q)
+          if (tap == (ISSUE_TAP + q < 8 ? ISSUE_TAP + q : 8)) {
+            __builtin_amdgcn_sched_barrier(0);
+            prefetch(q);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+#else
+        if (tap == ISSUE_TAP) {
+          __builtin_amdgcn_sched_barrier(0);
+          prefetch(-1);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+#endif
       }
     }
     if (NBUF == 2) {
@@ -966,7 +1000,7 @@ conv3x3_dma_kernel(const ConvParams2 p) {
 #endif
 }
 
-template <int MT, int CK, int NW, int R, int NBUF, bool HEADS, int STEM_CIN = 0, bool EXT = false, bool UPS = false>
+template <int MT, int CK, int NW, int R, int NBUF, bool HEADS, int STEM_CIN = 0, bool EXT = false, bool UPS = false, int ITAP = -1>
 int launch2(const ConvParams2& p, hipStream_t st) {
   constexpr int TH = NW * R;
   constexpr int N_IN = ((TH + 2) * 34 * CK * 2 + 1023) / 1024;
@@ -994,7 +1028,7 @@ int launch2(const ConvParams2& p, hipStream_t st) {
     return sa::fail(SA_ERR_UNSUPPORTED, "sa_conv3x3_bf16: one frame must be smaller than 4 GiB");
   static bool attr_set = false;
   if (!attr_set && lds > 64 * 1024) {
-    SA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_dma_kernel<MT, CK, NW, R, NBUF, HEADS, STEM_CIN, EXT, UPS>),
+    SA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_dma_kernel<MT, CK, NW, R, NBUF, HEADS, STEM_CIN, EXT, UPS, ITAP>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
@@ -1020,7 +1054,7 @@ int launch2(const ConvParams2& p, hipStream_t st) {
       SA_HIP_CHECK(hipGetDevice(&dev));
       SA_HIP_CHECK(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
       SA_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(
-          &nb, reinterpret_cast<const void*>(&conv3x3_dma_kernel<MT, CK, NW, R, NBUF, HEADS, STEM_CIN, EXT, UPS>), NW * 64, lds));
+          &nb, reinterpret_cast<const void*>(&conv3x3_dma_kernel<MT, CK, NW, R, NBUF, HEADS, STEM_CIN, EXT, UPS, ITAP>), NW * 64, lds));
       per_cu = nb > 0 ? nb : 1;
     }
     if (g_grid_limit > 0) {
@@ -1030,9 +1064,24 @@ int launch2(const ConvParams2& p, hipStream_t st) {
       if (cap < grid) grid = cap;
     }
   }
-  hipLaunchKernelGGL((conv3x3_dma_kernel<MT, CK, NW, R, NBUF, HEADS, STEM_CIN, EXT, UPS>), dim3((unsigned)grid), dim3(NW * 64), lds, st, q);
+  hipLaunchKernelGGL((conv3x3_dma_kernel<MT, CK, NW, R, NBUF, HEADS, STEM_CIN, EXT, UPS, ITAP>), dim3((unsigned)grid), dim3(NW * 64), lds, st, q);
   SA_LAUNCH_CHECK();
   return SA_OK;
+}
+
+#if !defined(SA_CONV_ITAP)
+#define SA_CONV_ITAP 3
+#endif
+#if !defined(SA_CONV_ITAP_MIN_CHUNKS)
+#define SA_CONV_ITAP_MIN_CHUNKS 5
+#endif
+// SA_CONV_LATE_ISSUE=0 queues every layer's copies right after the barrier (A/B runs)
+bool late_issue(int n_chunks) {
+  static const bool on = [] {
+    const char* v = getenv("SA_CONV_LATE_ISSUE");
+    return !v || atoi(v) != 0;
+  }();
+  return on && n_chunks >= SA_CONV_ITAP_MIN_CHUNKS;
 }
 
 template <int MT, int CK>
@@ -1041,11 +1090,13 @@ int launch2_pick(const ConvParams2& p, hipStream_t st) {
     if ((p.C0P + p.C1P) == CK) return launch2<MT, CK, 4, 2, 1, false, 0, true>(p, st);
     return launch2<MT, CK, 8, 2, 2, false, 0, true>(p, st);
   }
-  if (p.n_heads > 0) return launch2<MT, CK, 8, 2, 2, true>(p, st);
+  // many-chunk layers queue the next chunk's copies in the middle of the chunk (ITAP, see the kernel)
+  const bool mid = late_issue((p.C0P + p.C1P) / CK);
+  if (p.n_heads > 0) return mid ? launch2<MT, CK, 8, 2, 2, true, 0, false, false, SA_CONV_ITAP>(p, st) : launch2<MT, CK, 8, 2, 2, true>(p, st);
   // single-chunk layers (Cin <= CK) are HBM-bound: small single-stage tiles, many workgroups per CU
   if ((p.C0P + p.C1P) == CK) return launch2<MT, CK, 4, 2, 1, false>(p, st);
   // (4-wave / 8x32 and 4-wave / 16x32 tiles were measured 4-6 % slower than 8 waves x 2 rows on every multi-chunk layer)
-  return launch2<MT, CK, 8, 2, 2, false>(p, st);
+  return mid ? launch2<MT, CK, 8, 2, 2, false, 0, false, false, SA_CONV_ITAP>(p, st) : launch2<MT, CK, 8, 2, 2, false>(p, st);
 }
 
 template <int MT, int R, int CK, int MODE>
@@ -1177,7 +1228,8 @@ static int conv3x3_impl(const void* src0, int C0P, const void* src1, int C1P, in
       SA_REQUIRE(co32_n <= 4, "sa_conv3x3_heads_bf16: fused heads support at most 128 output channels");
       // (16 waves x 1 row on the same tile -- four waves per SIMD in the one workgroup a CU holds -- measured 8 % slower:
       // 0.327 -> 0.353 ms, profiles/r02_ab_session.md)
-      return launch2<4, 16, 8, 2, 2, true>(q, st);
+      return late_issue((C0P + C1P) / 16) ? launch2<4, 16, 8, 2, 2, true, 0, false, false, SA_CONV_ITAP>(q, st)
+                                          : launch2<4, 16, 8, 2, 2, true>(q, st);
     }
     // Experiment switch (tools/ab runs): SA_CONV_MT4=n sends plain multi-chunk layers with >= n output channels (a multiple
     // of 128) to the 128-couts-per-workgroup persistent kernel (one workgroup per CU, half the input re-staging per MFMA).
