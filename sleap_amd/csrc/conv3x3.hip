@@ -1088,7 +1088,8 @@ template <int MT, int CK>
 int launch2_pick(const ConvParams2& p, hipStream_t st) {
   if (p.post_scale || p.residual || p.relu_last) {  // extended epilogue
     if ((p.C0P + p.C1P) == CK) return launch2<MT, CK, 4, 2, 1, false, 0, true>(p, st);
-    return launch2<MT, CK, 8, 2, 2, false, 0, true>(p, st);
+    return late_issue((p.C0P + p.C1P) / CK) ? launch2<MT, CK, 8, 2, 2, false, 0, true, false, SA_CONV_ITAP>(p, st)
+                                            : launch2<MT, CK, 8, 2, 2, false, 0, true>(p, st);
   }
   // many-chunk layers queue the next chunk's copies in the middle of the chunk (ITAP, see the kernel)
   const bool mid = late_issue((p.C0P + p.C1P) / CK);
