@@ -391,9 +391,9 @@ conv3x3_dma_kernel(const ConvParams2 p) {
   if constexpr (UPS) voff_low = make_voff_low(cur, lane);
   const unsigned wv = (unsigned)lane * 16;
 
-  // part < 0: all of this wave's pieces; part = q: only its q-th (inputs first, then weights) -- SA_CONV_ISSUE_SPREAD builds
+  // this wave's pieces lo <= q < hi of the chunk (inputs are pieces 0 .. IN_PER_WAVE-1, the weights follow)
   auto issue = [&](const Tile& t, const unsigned (&v0)[IN_PER_WAVE], const unsigned (&v1)[IN_PER_WAVE], int chunk, int buf,
-                   int part = -1) {
+                   int lo = 0, int hi = 99) {
     const int c_lo = chunk * CK;
     const bool from1 = c_lo >= p.C0P;
     // byte offset of the chunk's first channel inside a pixel record (NHWC: 2 bytes per channel) or of its plane (planes:
@@ -407,13 +407,13 @@ conv3x3_dma_kernel(const ConvParams2 p) {
         (void*)(p.C1P ? reinterpret_cast<const unsigned char*>(p.src1) + t.b * f1 : reinterpret_cast<const unsigned char*>(p.w)), 0,
         (int)f1, 0x00020000);
     if (UPS && from1) {  // wave-uniform: the low-resolution tile, one piece per wave
-      if (wave < N_LOW && part <= 0)
+      if (wave < N_LOW && lo <= 0)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, (lds_ptr_t)(stage + LOW_OFF + wave * 1024), 16, voff_low, cc2, 0, 0);
     } else {
 #pragma unroll
       for (int j = 0; j < IN_PER_WAVE; ++j) {
         const int i = j * NW + wave;
-        if (STEM_CIN == 0 && i < N_IN && (part < 0 || part == j)) {
+        if (STEM_CIN == 0 && i < N_IN && lo <= j && j < hi) {
           if (from1)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, (lds_ptr_t)(stage + i * 1024), 16, v1[j], cc2, 0, 0);
           else
@@ -424,7 +424,7 @@ conv3x3_dma_kernel(const ConvParams2 p) {
 #pragma unroll
     for (int j = 0; j < W_PER_WAVE; ++j) {
       const int k = j * NW + wave;  // (m, kk, tap) slab index
-      if (k < N_W && (part < 0 || part == IN_PER_WAVE + j)) {
+      if (k < N_W && lo <= IN_PER_WAVE + j && IN_PER_WAVE + j < hi) {
         const int m = k / (KK * 9), rest = k - m * (KK * 9);
         // cout tiles beyond CoutP read out of range -> zeros
         const int soff = (t.co32_0 + m < co32_n) ? (((t.co32_0 + m) * K16 + chunk * KK) * 9 + rest) * 1024 : (int)0x7FFFF000;
@@ -646,23 +646,28 @@ conv3x3_dma_kernel(const ConvParams2 p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     // the copies of the next chunk: queued right after the barrier (ITAP < 0) or after tap ITAP of the MFMA sequence below
-    auto prefetch = [&](int part) {
+    auto prefetch = [&](int lo, int hi) {
       if constexpr (NBUF == 2) {
         if (chunk + 1 < n_chunks) {
-          issue(cur, voff0, voff1, chunk + 1, buf ^ 1, part);
+          issue(cur, voff0, voff1, chunk + 1, buf ^ 1, lo, hi);
         } else if (more) {  // cross-tile prefetch: chunk 0 of the next tile lands while this tile's epilogue runs
-          if (part <= 0) {
+          if (lo <= 0) {
             nxt = decode(L_next);
             int ln = lane;
             asm volatile("" : "+v"(ln));
             make_voff(nxt, ln, voff0, voff1);  // this tile issues no more copies: its offsets are dead
           }
-          issue(nxt, voff0, voff1, 0, buf ^ 1, part);
+          issue(nxt, voff0, voff1, 0, buf ^ 1, lo, hi);
         }
       }
     };
+    // inputs (HBM) after tap ISSUE_TAP, weights (L2) after tap W_TAP; -1 = right after the barrier
     constexpr int ISSUE_TAP = (NBUF == 2 && !UPS) ? ITAP : -1;
-    if constexpr (ISSUE_TAP < 0) prefetch(-1);
+    // (the weights' copies at a tap of their own -- earlier or later than the inputs' -- measured within noise of this on
+    // few- and many-chunk layers alike, gpurun_out/r02v)
+    constexpr int W_TAP = ISSUE_TAP;
+    if constexpr (ISSUE_TAP < 0) prefetch(0, W_TAP < 0 ? 99 : IN_PER_WAVE);
+    if constexpr (ISSUE_TAP >= 0 && W_TAP < 0) prefetch(IN_PER_WAVE, 99);
     const unsigned char* in_tile = smem + buf * STAGE;
     const unsigned char* w_tile = in_tile + IN_BYTES;
     if constexpr (UPS) {
@@ -753,23 +758,13 @@ conv3x3_dma_kernel(const ConvParams2 p) {
             acc[m][r] = SA_MFMA_32x32x16(a[m], bv, acc[m][r], 0, 0, 0);
         }
       }
-      if constexpr (ISSUE_TAP >= 0) {
-#if defined(SA_CONV_ISSUE_SPREAD)  // experiment: one piece per tap from ISSUE_TAP on (the last tap takes what is left)
-        constexpr int NP = IN_PER_WAVE + W_PER_WAVE;
-#pragma unroll
-        for (int q = 0; q < NP; ++q)
-          if (tap == (ISSUE_TAP + q < 8 ? ISSUE_TAP + q : 8)) {
-            __builtin_amdgcn_sched_barrier(0);
-            prefetch(q);
-            __builtin_amdgcn_sched_barrier(0);
-          }
-#else
-        if (tap == ISSUE_TAP) {
+      if constexpr (ISSUE_TAP >= 0 || W_TAP >= 0) {
+        if (tap == ISSUE_TAP || tap == W_TAP) {
           __builtin_amdgcn_sched_barrier(0);
-          prefetch(-1);
+          if (tap == ISSUE_TAP) prefetch(0, W_TAP == ISSUE_TAP ? 99 : IN_PER_WAVE);
+          if (tap == W_TAP && W_TAP != ISSUE_TAP) prefetch(IN_PER_WAVE, 99);
           __builtin_amdgcn_sched_barrier(0);
         }
-#endif
       }
     }
     if (NBUF == 2) {
