@@ -38,7 +38,7 @@ PEAK_BF16_TFLOPS = 2500.0  # dense, fp16 and bf16 alike (/opt/skills/guides/MI35
 # HBM bytes of the conv kernel family per step of the DEFAULT workload (64 frames of 1024x1024), from two separate
 # rocprofv3 --pmc passes (FETCH_SIZE doubled per the gfx950 correction, WRITE_SIZE uncalibrated): profiles/r02_pmc_hbm_traffic.md
 # (16-channel planes; the NHWC plan of the same network moved 13.15 GB: partially used cache lines fetched more than once)
-MEASURED_CONV_TRAFFIC_BYTES_PER_STEP = 10.92e9
+MEASURED_CONV_TRAFFIC_BYTES_PER_STEP = 10.94e9
 
 
 def parse():
