@@ -63,6 +63,37 @@ def _as_device_images(data) -> torch.Tensor:
     return t.cuda(non_blocking=True).contiguous()
 
 
+def start_download(outs):
+    """Queue asynchronous copies of the CUDA tensors of a result dict (all but the carried input frames) into page-locked memory
+    on the CURRENT stream -> (host tensors, event recorded behind them). With `finish_download` this is how a pipelined loop
+    brings batch k to the host: the copies are queued right behind batch k's kernels, BEFORE batch k+1 is queued, and the host
+    later waits for the event only. (`.cpu()` / a stream synchronisation at conversion time waits for everything queued on the
+    stream by then -- batch k+1 included -- which turned the two-deep loop of the top-down predictor into a one-deep one:
+    uploads and compute strictly in series, tools/timeline_gaps.py, tools/copy_issue_vs_run.py.)"""
+    host = {k: torch.empty(v.shape, dtype=v.dtype, pin_memory=True) for k, v in outs.items()
+            if isinstance(v, torch.Tensor) and v.is_cuda and k != "_input"}
+    if not host:  # nothing on a device (CPU stand-ins in the multi-process tests)
+        return host, None
+    for k, h in host.items():
+        h.copy_(outs[k], non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record()
+    return host, ev
+
+
+def finish_download(host, ev):
+    """-> NumPy copies of the tensors `start_download` queued (waits for its event only)."""
+    if ev is not None:
+        ev.synchronize()
+    return {k: h.numpy().copy() for k, h in host.items()}
+
+
+def results_to_numpy(outs, host=None):
+    """A result dict as NumPy: `host` (from `finish_download`) where given, a download now for what is still on a device."""
+    got = host if host is not None else finish_download(*start_download(outs))
+    return {k: (got[k] if k in got else (v.cpu().numpy() if isinstance(v, torch.Tensor) else v)) for k, v in outs.items()}
+
+
 class InferenceLayer:
     """Wraps the network with the reference's preprocessing (inference.py:897-978).
 
@@ -502,8 +533,9 @@ class SingleInstanceInferenceModel(InferenceModel):
         return {k: v.cpu().numpy() for k, v in outs.items()} if numpy else outs
 
     @staticmethod
-    def outputs_to_numpy(outs):
-        return {k: v.cpu().numpy() for k, v in outs.items()}
+    def outputs_to_numpy(outs, host=None):
+        """`host`: what `finish_download` returned for these outputs (a pipelined loop started the copies earlier)."""
+        return results_to_numpy(outs, host)
 
     def predict_on_batch(self, data, numpy: bool = False, **kwargs):
         outs = self.call(data)
@@ -738,16 +770,18 @@ class TopDownInferenceModel(InferenceModel):
         return grown
 
     @staticmethod
-    def _to_numpy(outs):
-        return {k: (v.cpu().numpy() if isinstance(v, torch.Tensor) else v) for k, v in outs.items()}
+    def _to_numpy(outs, host=None):
+        """Device tensors -> NumPy (asynchronous copies into page-locked memory, one event wait); `host`: already downloaded."""
+        return results_to_numpy(outs, host)
 
-    def outputs_to_numpy(self, outs):
+    def outputs_to_numpy(self, outs, host=None):
         """Device results -> NumPy in the reference's unragged form (instance axis cropped to the batch's bounding shape,
         data/utils.py:118-146). This is where the deferred status words are looked at: an overflowed batch is re-run (with
-        grown capacities) before anything is returned."""
+        grown capacities) before anything is returned. `host`: `finish_download` of these outputs (pipelined loops)."""
         while True:
             src = outs.pop("_input", None)
-            res = self._to_numpy(outs)
+            res = self._to_numpy(outs, host)
+            host = None  # (a re-run's outputs are downloaded here)
             status = res.pop("status", None)
             bits = int(np.bitwise_or.reduce(status)) if status is not None and len(status) else 0
             if not self._grow_on_status(bits) or src is None:
@@ -1008,30 +1042,99 @@ class Predictor:
         reporter = ProgressReporter(self.verbosity, self.report_rate, n, enabled=rank == 0)
         reporter.__enter__()
 
+        # Frame sources the prefetcher can read (arrays, Video, VideoReader): this rank's batches are staged into page-locked
+        # buffers by a producer thread and uploaded on a copy stream of their own, so the host copy and the DMA of batch k+1
+        # run under the device work of batch k (from a pageable array, `frames[lo:hi].cuda()` is a synchronous staged copy on
+        # the compute stream: top-down at 1024 x 1024 ran at 82 % of its HBM-resident rate, tools/predict_e2e_topdown.py)
+        feed = feeder = copy_stream = None
+        if isinstance(data, (np.ndarray, Video, VideoReader)) and torch.cuda.is_available() and n > 0 \
+                and not (isinstance(data, np.ndarray) and data.ndim == 3):
+            from ..io.video import FramePrefetcher
+
+            ranges = [parallel.shard_range(i0, min(i0 + self.batch_size, n), rank, world) for i0 in range(0, n, self.batch_size)]
+            feeder = FramePrefetcher(data, [r for r in ranges if r[1] > r[0]], depth=4)
+            feed = iter(feeder)
+            copy_stream = getattr(self, "_upload_stream", None)  # (kept: creating a hardware queue costs milliseconds)
+            if copy_stream is None:
+                copy_stream = self._upload_stream = torch.cuda.Stream(priority=int(os.environ.get("SLEAP_AMD_COPY_STREAM_PRIORITY", "-1")))
+
+        # With prefetched sources the device work runs on a stream of the predictor's own instead of the default stream (as the
+        # bottom-up layer does): on the default stream the uploads of the copy stream did not overlap it -- the top-down rate
+        # from host frames was that of upload + compute in series (7.2 k frames/s against 8.6 k from a CUDA tensor).
+        compute_stream = None
+        if feed is not None:
+            compute_stream = getattr(self, "_compute_stream", None)
+            if compute_stream is None:
+                compute_stream = self._compute_stream = torch.cuda.Stream(priority=-1)
+
+        import inspect
+
+        # (an inference model whose outputs_to_numpy does not take the early-downloaded arrays converts at hand-out time)
+        early_download = "host" in inspect.signature(self.inference_model.outputs_to_numpy).parameters
+
+        def on_compute():
+            import contextlib
+
+            return torch.cuda.stream(compute_stream) if compute_stream is not None else contextlib.nullcontext()
+
+        def batch_of(lo, hi):
+            """This rank's frames of one batch on the device (prefetched sources) or as the source hands them out."""
+            if feed is None:
+                return frames[lo:hi], None
+            try:
+                _lo, _hi, _inds, pinned = next(feed)
+            except StopIteration:  # the producer stops at a frame the source cannot deliver (inference.py:3333-3339)
+                raise KeyError(f"Unable to load frame: the source ended before frames {lo}..{hi - 1}") from None
+            key = feeder.hold()
+            with torch.cuda.stream(copy_stream):
+                dev_frames = pinned.cuda(non_blocking=True)
+                up = torch.cuda.Event()
+                up.record(copy_stream)
+            cur = torch.cuda.current_stream()
+            cur.wait_event(up)
+            dev_frames.record_stream(cur)
+            feeder.release_key(key, up)
+            return dev_frames, up
+
         def submit(i0):
             """Queue one batch (everything asynchronous that the model leaves asynchronous) -> a ticket."""
             i1 = min(i0 + self.batch_size, n)
             lo, hi = parallel.shard_range(i0, i1, rank, world)
-            dev = self.inference_model.predict_on_batch(frames[lo:hi], numpy=False) if hi > lo else None
-            if dev is not None and not set(dev) <= small:
-                # maps / crops may alias network buffers that the next batch overwrites: convert before anything else runs
-                dev = self.inference_model.outputs_to_numpy(dev)
-            return i0, i1, dev
+            dev = None
+            with on_compute():
+                if hi > lo:
+                    batch, _up = batch_of(lo, hi)
+                    dev = self.inference_model.predict_on_batch(batch, numpy=False)
+                pre = None
+                if dev is not None and not set(dev) <= small:
+                    # maps / crops may alias network buffers that the next batch overwrites: convert before anything else runs
+                    dev = self.inference_model.outputs_to_numpy(dev)
+                elif dev is not None and early_download:
+                    pre = start_download(dev)  # queued behind this batch's kernels, before the next batch's
+            return i0, i1, dev, pre
 
         # two-deep pipeline: batch k+1 is queued before batch k is brought to the host (the conversion synchronises), so the
         # GPU works on k+1 while the host waits for, converts and hands out k
         if n == 0:
             reporter.__exit__(None, None, None)
             return
+        f0 = frames[0]
+        image_hw = np.asarray(f0.shape[:2] if hasattr(f0, "shape") else (1, 1), np.int64)
         tickets = [submit(0)]
         for i_next in list(range(self.batch_size, n, self.batch_size)) + [None]:
             nxt = submit(i_next) if i_next is not None else None
-            i0, i1, dev = tickets.pop(0)
+            i0, i1, dev, pre = tickets.pop(0)
             if nxt is not None:
                 tickets.append(nxt)
             ex = None
             if dev is not None:
-                ex = dev if isinstance(next(iter(dev.values())), np.ndarray) else self.inference_model.outputs_to_numpy(dev)
+                with on_compute():
+                    if isinstance(next(iter(dev.values())), np.ndarray):
+                        ex = dev
+                    elif pre is None:
+                        ex = self.inference_model.outputs_to_numpy(dev)
+                    else:
+                        ex = self.inference_model.outputs_to_numpy(dev, host=finish_download(*pre))
             if world > 1:
                 parts = [None] * world
                 dist.all_gather_object(parts, ex)
@@ -1050,7 +1153,7 @@ class Predictor:
             ex["video_ind"] = np.zeros((i1 - i0,), np.int64)
             ex["frame_ind"] = np.arange(i0, i1, dtype=np.int64)
             ex["scale"] = np.ones((i1 - i0, 2), np.float32)
-            ex["image_hw"] = np.asarray(frames[0].shape[:2] if hasattr(frames[0], "shape") else (1, 1), np.int64)
+            ex["image_hw"] = image_hw
             reporter.update(i1 - i0)
             if i_next is None:
                 reporter.__exit__(None, None, None)
