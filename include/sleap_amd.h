@@ -428,6 +428,8 @@ typedef struct sa_tracker_config {   /* Tracker.make_tracker_by_name arguments, 
   int flow;                          /* 0 = Simple[MaxTracks]CandidateMaker, 1 = Flow[MaxTracks]CandidateMaker (tracking.py:108-440, 1194-1240) */
   int of_window_size;                /* flow: Lucas-Kanade window (default 21; 3..31) */
   int of_max_levels;                 /* flow: pyramid levels above the frame (default 3) */
+  int save_shifted_instances;        /* flow (not flowmaxtracks): chain the flow through the latest shifted copy of a queued frame's
+                                        instances (FlowCandidateMaker.save_shifted_instances, tracking.py:146-208, 239-256) */
 } sa_tracker_config;
 
 void* sa_tracker_create(const sa_tracker_config* cfg);   /* NULL on invalid configuration (sa_last_error) */

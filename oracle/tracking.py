@@ -7,8 +7,7 @@ Follows, function by function:
     sleap/nn/tracker/components.py:366-466  cull_frame_instances, connect_single_track_breaks
     sleap/nn/tracker/components.py:469-640  Match, FrameMatches
     sleap/nn/tracking.py:442-507            SimpleCandidateMaker, SimpleMaxTracksCandidateMaker
-    sleap/nn/tracking.py:108-440, 1194-1240 FlowCandidateMaker, FlowMaxTracksCandidateMaker (save_shifted_instances=False,
-                                            img_scale=1); the optical flow itself is oracle/optical_flow.py
+    sleap/nn/tracking.py:108-440, 1194-1240 FlowCandidateMaker, FlowMaxTracksCandidateMaker (img_scale=1); the optical flow itself is oracle/optical_flow.py
     sleap/nn/tracking.py:542-841            Tracker.track / spawn_for_untracked_instances / final_pass
     sleap/nn/utils.py:45-76                 compute_iou
     sleap/instance.py:866-901               Instance.centroid / bounding_box / n_visible_points
@@ -303,8 +302,8 @@ class Tracker:
     (make_tracker_by_name, :844-992)."""
 
     def __init__(self, tracker="simple", similarity="instance", match="greedy", track_window=5, robust=1.0,
-                 min_new_track_points=0, min_match_points=0, of_window_size=21, of_max_levels=3, target_instance_count=0,
-                 pre_cull_to_target=False,
+                 min_new_track_points=0, min_match_points=0, of_window_size=21, of_max_levels=3, save_shifted_instances=False,
+                 target_instance_count=0, pre_cull_to_target=False,
                  pre_cull_iou_threshold=None, post_connect_single_breaks=False, max_tracks=None, max_tracking=False,
                  oks_errors=None, oks_score_weighting=False, oks_normalization="all"):
         max_tracking = max_tracking if max_tracks else False
@@ -314,8 +313,10 @@ class Tracker:
             raise ValueError(f"{tracker} is not a valid tracker.")
         self.uses_flow = tracker.startswith("flow")
         if tracker != "flow":  # :914-919: only "flow" is configured; "flowmaxtracks" keeps the class defaults
-            of_window_size, of_max_levels = 21, 3
+            of_window_size, of_max_levels, save_shifted_instances = 21, 3, False
         self.of_window_size, self.of_max_levels = of_window_size, of_max_levels
+        self.save_shifted_instances = bool(save_shifted_instances)
+        self._shifted = {}  # (ref_t, t) -> (shifted instances, frame t)   (FlowCandidateMaker.shifted_instances, :136-138)
         self._images = {}  # t -> frame (MatchedFrameInstance(s).img_t)
         if similarity not in SIMILARITIES:
             raise ValueError(f"{similarity} is not a valid tracker similarity function.")
@@ -343,18 +344,18 @@ class Tracker:
         self.spawned_tracks: List[int] = []
         self.last_matches = None
 
-    def _shift(self, ref_t, ref_instances, img):
+    def _shift(self, ref_t, ref_instances, img, ref_img=None):
         """FlowCandidateMaker.get_shifted_instances -> flow_shift_instances (:180-208, 258-356)"""
         from .optical_flow import flow_shift_points
 
         out = []
-        for i, pts, _score in flow_shift_points([r.points for r in ref_instances], self._images[ref_t], img,
+        for i, pts, _score in flow_shift_points([r.points for r in ref_instances], self._images[ref_t] if ref_img is None else ref_img, img,
                                                 min_shifted_points=self.min_match_points, window_size=self.of_window_size,
                                                 max_levels=self.of_max_levels):
             out.append(ref_instances[i].evolve(points=pts.astype(np.float64)))  # ShiftedInstance.from_instance: the reference's track
         return out
 
-    def _flow_candidates(self, img):
+    def _flow_candidates(self, img, t=None):
         out = []
         if self.has_max_tracking:  # FlowMaxTracksCandidateMaker.get_candidates (:1194-1240)
             tracks = []
@@ -366,9 +367,20 @@ class Tracker:
                         if refs:
                             out.extend(self._shift(ref_t, refs, img))
         else:  # FlowCandidateMaker.get_candidates (:210-237)
+            if self.save_shifted_instances:  # prune_shifted_instances (:239-256)
+                self._shifted = {k: v for k, v in self._shifted.items() if not (t - k[0] > self.track_window)}
             for (ref_t, insts) in self.track_matching_queue:
+                ref_img = None
+                if self.save_shifted_instances:  # get_shifted_instances_from_earlier_time (:146-166)
+                    for ti in reversed(range(ref_t, t)):
+                        if (ref_t, ti) in self._shifted and len(self._shifted[(ref_t, ti)][0]) > 0:
+                            insts, ref_img = self._shifted[(ref_t, ti)]
+                            break
                 if len(insts) > 0:
-                    out.extend(self._shift(ref_t, insts, img))
+                    shifted = self._shift(ref_t, insts, img, ref_img)
+                    if self.save_shifted_instances:
+                        self._shifted[(ref_t, t)] = (shifted, img)
+                    out.extend(shifted)
         return out
 
     def _candidates(self):
@@ -405,7 +417,7 @@ class Tracker:
         if untracked_instances:
             if self.pre_cull:
                 self.pre_cull(untracked_instances)
-            cands = self._flow_candidates(img) if self.uses_flow else self._candidates()
+            cands = self._flow_candidates(img, t) if self.uses_flow else self._candidates()
             fm = FrameMatches.from_candidate_instances(untracked_instances, cands, sim, self.matching_function,
                                                        self.robust_best_instance)
             self.last_matches = fm

@@ -85,6 +85,7 @@ struct Config {
   std::vector<double> kp_precision;  // 1 / (2 err^2); size 1 = scalar
   int oks_score_weighting, oks_normalization;
   int flow = 0, of_window_size = 21, of_max_levels = 3;  // FlowCandidateMaker (tracking.py:108-137)
+  int save_shifted = 0;  // FlowCandidateMaker.save_shifted_instances: chain the flow through the latest shifted copy (:146-166)
 };
 
 // Device side of the flow candidate makers: one image pyramid per queued time step (the reference keeps `img_t` in every
@@ -134,6 +135,9 @@ struct Tracker {
   std::vector<std::pair<int, std::deque<std::pair<int, Inst>>>> qdict;  // insertion-ordered {track: deque[(t, inst)]}
   int n_spawned = 0;
   long serial = 0;  // Tracker.track calls so far
+  // FlowCandidateMaker.shifted_instances (tracking.py:136-138): (reference time step, time step shifted to) -> the shifted
+  // instances; their image is the pyramid of the second time step
+  std::map<std::pair<int, int>, std::vector<Inst>> saved;
   int last_first_choice = -1;  // FrameMatches.has_only_first_choice_matches of the last frame that had instances (-1: none yet)
   FlowState fs;
   // Shifts of a whole run of frames computed ahead (sa_tracker_track_frames_images, flow without max-tracks): the optical flow
@@ -490,6 +494,7 @@ int track_one(Tracker& T, std::vector<Inst> untracked, int img_h, int img_w, int
       // per track that holds an item of its time step, exactly as there.
       std::vector<std::pair<int, std::vector<const Inst*>>> groups;  // distinct reference time steps
       std::vector<size_t> order;                                      // candidate groups in the reference's order (indices into `groups`)
+      std::vector<int> saved_ref_t;                                   // save_shifted: the queued frame every group stands for
       auto group_of = [&](int tr) {
         for (size_t g = 0; g < groups.size(); ++g)
           if (groups[g].first == tr) return g;
@@ -511,6 +516,28 @@ int track_one(Tracker& T, std::vector<Inst> untracked, int img_h, int img_w, int
               order.push_back(g);
             }
           }
+        }
+      } else if (c.save_shifted) {
+        // prune_shifted_instances (:239-256), then per queued frame get_shifted_instances_from_earlier_time (:146-166): the latest
+        // non-empty shifted copy of that frame's instances (and ITS image) is what gets shifted into the current frame
+        for (auto it = T.saved.begin(); it != T.saved.end();)
+          it = (t - it->first.first > c.track_window) ? T.saved.erase(it) : std::next(it);
+        for (const auto& fr : T.queue) {
+          int img_t = fr.first;
+          const std::vector<Inst>* refs = &fr.second;
+          for (int ti = t - 1; ti >= fr.first; --ti) {
+            const auto it = T.saved.find({fr.first, ti});
+            if (it != T.saved.end() && !it->second.empty()) {
+              img_t = ti;
+              refs = &it->second;
+              break;
+            }
+          }
+          if (refs->empty()) continue;
+          groups.emplace_back(img_t, std::vector<const Inst*>());  // one group per queued frame (two may share an image)
+          for (const Inst& a : *refs) groups.back().second.push_back(&a);
+          order.push_back(groups.size() - 1);
+          saved_ref_t.push_back(fr.first);
         }
       } else {
         for (const auto& fr : T.queue) {
@@ -565,6 +592,8 @@ int track_one(Tracker& T, std::vector<Inst> untracked, int img_h, int img_w, int
         const int rc = flow_shift(T, groups, shifted);
         if (rc != SA_OK) return rc;
       }
+      if (c.save_shifted && !c.max_tracks_mode)  // get_shifted_instances (:197-206): kept for the frames to come
+        for (size_t g = 0; g < groups.size(); ++g) T.saved[{saved_ref_t[g], t}] = shifted[g];
       for (size_t g : order)
         for (const Inst& a : shifted[g]) cand.push_back(&a);
     } else if (c.max_tracks_mode) {
@@ -669,6 +698,7 @@ int track_one(Tracker& T, std::vector<Inst> untracked, int img_h, int img_w, int
           for (const auto& ti : kv.second) used = used || ti.first == it->first;
       } else {
         for (const auto& fr : T.queue) used = used || (fr.first == it->first && !fr.second.empty());
+        for (const auto& kv : T.saved) used = used || kv.first.second == it->first;  // the image of a saved shifted copy
       }
       if (used) {
         ++it;
@@ -888,6 +918,7 @@ void* sa_tracker_create(const sa_tracker_config* cfg) {
   c.flow = cfg->flow ? 1 : 0;
   c.of_window_size = cfg->of_window_size > 0 ? cfg->of_window_size : 21;
   c.of_max_levels = cfg->of_max_levels >= 0 ? cfg->of_max_levels : 3;
+  c.save_shifted = cfg->save_shifted_instances != 0 && c.flow && !c.max_tracks_mode;  // (the reference configures it for "flow" only)
   if (c.flow && (c.of_window_size < 3 || c.of_window_size > 31)) {
     delete t;
     sa::fail(SA_ERR_UNSUPPORTED, "sa_tracker_create: of_window_size must be in 3..31");
@@ -912,6 +943,7 @@ int sa_tracker_reset(void* h) {
   Tracker* T = static_cast<Tracker*>(h);
   // Tracker.reset_candidates (tracking.py:615-620): queues are emptied, spawned tracks are kept
   T->queue.clear();
+  T->saved.clear();
   for (auto& kv : T->qdict) kv.second.clear();
   T->fs.clear();
   return SA_OK;
@@ -999,7 +1031,7 @@ int sa_tracker_track_frames_images(void* h, int n_frames, int max_inst, int n_no
   Tracker* T = static_cast<Tracker*>(h);
   SA_REQUIRE(!T->c.flow || images, "sa_tracker_track_frames_images: a flow tracker needs the frames");
   const size_t stride_f = (size_t)max_inst;
-  if (T->c.flow && n_frames > 1) {
+  if (T->c.flow && n_frames > 1 && !T->c.save_shifted) {  // (chained flow depends on the earlier frames' results: frame by frame)
     // ---- the flow of every (queued frame, target frame) pair of this run in ONE Lucas-Kanade launch (FlowBatch), in runs of
     // <= 128 frames (a 1024 x 1024 pyramid is 6.7 MB)
     constexpr int RUN = 128;

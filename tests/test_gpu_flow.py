@@ -142,7 +142,9 @@ def _moving_scene(n_frames=14, h=192, w=224, n_animals=3, n_nodes=5, seed=0):
 @pytest.mark.parametrize("kw", [dict(tracker="flow"), dict(tracker="flow", similarity="iou", match="hungarian", track_window=3),
                                 dict(tracker="flow", similarity="centroid", min_match_points=2, of_window_size=15, of_max_levels=2),
                                 dict(tracker="flowmaxtracks", max_tracks=3, max_tracking=True),
-                                dict(tracker="flowmaxtracks", max_tracks=2, max_tracking=True, similarity="object_keypoint", robust=0.8)])
+                                dict(tracker="flowmaxtracks", max_tracks=2, max_tracking=True, similarity="object_keypoint", robust=0.8),
+                                dict(tracker="flow", save_shifted_instances=True),
+                                dict(tracker="flow", save_shifted_instances=True, track_window=3, min_match_points=1, similarity="iou")])
 def test_flow_tracker_equals_oracle(kw):
     """The native tracker with device Lucas-Kanade candidates against the oracle tracker with the CPU restatement: the same
     tracks for every instance of every frame, tracking scores to 1e-3 (the shifted points differ by < 2e-3 px)."""
@@ -171,12 +173,13 @@ def test_flow_tracker_equals_oracle(kw):
         assert np.allclose(r["tracking_score"], [s for _, _, s in want[t]], atol=1e-3), (t, r, want[t])
         n_spawn_checked += len(lst)
     assert len(nat.spawned_tracks) == len(ref.spawned_tracks) and n_spawn_checked > 30
-    if kw["tracker"] == "flow" and len(kw) == 1:
+    if kw["tracker"] == "flow" and len(kw) <= 2 and "similarity" not in kw:
         # the scene is easy: identities must actually be carried (3 animals -> 3 tracks, despite the shuffled detection order)
         assert len(nat.spawned_tracks) == 3
 
 
 @pytest.mark.parametrize("kw", [dict(tracker="flow"), dict(tracker="flow", track_window=2, min_match_points=1),
+                                dict(tracker="flow", save_shifted_instances=True),
                                 dict(tracker="flowmaxtracks", max_tracks=3, max_tracking=True),
                                 dict(tracker="flowmaxtracks", max_tracks=2, max_tracking=True, track_window=3)])
 def test_flow_tracker_batched_frames_equal_single_steps(kw):

@@ -168,8 +168,7 @@ def test_errors_like_reference():
     assert d.uses_image and d.get_name() == "FlowCandidateMaker.instance_similarity.greedy_matching"
     with pytest.raises(NotImplementedError):
         Tracker.make_tracker_by_name(tracker="flow", img_scale=0.5)
-    with pytest.raises(NotImplementedError):
-        Tracker.make_tracker_by_name(tracker="flow", save_shifted_instances=True)
+    assert Tracker.make_tracker_by_name(tracker="flow", save_shifted_instances=True).uses_image
     # tracking.py:914-919: only "flow" (not "flowmaxtracks") takes the of_* / img_scale arguments
     m = Tracker.make_tracker_by_name(tracker="flowmaxtracks", img_scale=0.5, of_window_size=9, max_tracks=2, max_tracking=True)
     assert m.of_window_size == 21 and m.has_max_tracking and m.uses_image
