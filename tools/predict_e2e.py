@@ -16,7 +16,9 @@ from sleap_amd.synth import render_frames
 
 T = int(sys.argv[1]) if len(sys.argv) > 1 else 1280
 labels = len(sys.argv) > 2 and sys.argv[2] == "labels"
-pred, _, _ = build_benchmark_predictor(1024, 1024, batch_size=64, seed=0)
+import os
+BATCH = int(os.environ.get("PRED_BATCH", "64"))
+pred, _, _ = build_benchmark_predictor(1024, 1024, batch_size=BATCH, seed=0)
 if len(sys.argv) > 3:
     from sleap_amd.nn.tracking import Tracker
 
