@@ -84,3 +84,25 @@ def test_flow_shift_points_follows_the_reference_call_site():
     assert of.flow_shift_points([a, b], i0, i1, min_shifted_points=2) == []
     with pytest.raises(NotImplementedError):
         of.flow_shift_points([a], i0, i1, scale=0.5)
+
+
+def test_flow_tracker_saved_shifted_instances_are_pruned_to_the_track_window():
+    """The reference's test_flow_tracker (tests/nn/test_inference.py:1963-1997) on the oracle tracker: with
+    save_shifted_instances the keys (reference time, shifted-to time) never reach back further than track_window, and the
+    identities of an easy scene are still carried."""
+    from oracle import tracking as T
+    from tests.test_gpu_flow import _moving_scene
+
+    frames, insts = _moving_scene()
+    h, w = frames.shape[1:3]
+    track_window = 3
+    trk = T.Tracker(tracker="flow", track_window=track_window, save_shifted_instances=True)
+    seen = 0
+    for t, lst in enumerate(insts[:9]):
+        trk.track([T.Inst(p, s, sc, uid=i) for i, (p, s, sc) in enumerate(lst)], img_hw=(h, w), img=frames[t], t=t)
+        for (ref_t, to_t) in trk._shifted:
+            assert t - ref_t <= track_window and abs(ref_t - to_t) <= track_window
+        seen += len(trk._shifted)
+    assert seen > 0 and len(trk.spawned_tracks) == 3
+    # flowmaxtracks keeps the class default (no saving), tracking.py:914-919
+    assert not T.Tracker(tracker="flowmaxtracks", max_tracks=2, max_tracking=True, save_shifted_instances=True).save_shifted_instances
