@@ -1067,6 +1067,7 @@ class Predictor:
             if compute_stream is None:
                 compute_stream = self._compute_stream = torch.cuda.Stream(priority=-1)
 
+        keep_frames = world == 1 and bool(getattr(getattr(self, "tracker", None), "uses_image", False))
         import inspect
 
         # (an inference model whose outputs_to_numpy does not take the early-downloaded arrays converts at hand-out time)
@@ -1100,18 +1101,20 @@ class Predictor:
             """Queue one batch (everything asynchronous that the model leaves asynchronous) -> a ticket."""
             i1 = min(i0 + self.batch_size, n)
             lo, hi = parallel.shard_range(i0, i1, rank, world)
-            dev = None
+            dev, kept = None, None
             with on_compute():
                 if hi > lo:
                     batch, _up = batch_of(lo, hi)
                     dev = self.inference_model.predict_on_batch(batch, numpy=False)
+                    if keep_frames and _up is not None:
+                        kept = (batch, _up)  # a flow tracker reads the frames where they already are
                 pre = None
                 if dev is not None and not set(dev) <= small:
                     # maps / crops may alias network buffers that the next batch overwrites: convert before anything else runs
                     dev = self.inference_model.outputs_to_numpy(dev)
                 elif dev is not None and early_download:
                     pre = start_download(dev)  # queued behind this batch's kernels, before the next batch's
-            return i0, i1, dev, pre
+            return i0, i1, dev, pre, kept
 
         # two-deep pipeline: batch k+1 is queued before batch k is brought to the host (the conversion synchronises), so the
         # GPU works on k+1 while the host waits for, converts and hands out k
@@ -1123,7 +1126,7 @@ class Predictor:
         tickets = [submit(0)]
         for i_next in list(range(self.batch_size, n, self.batch_size)) + [None]:
             nxt = submit(i_next) if i_next is not None else None
-            i0, i1, dev, pre = tickets.pop(0)
+            i0, i1, dev, pre, kept = tickets.pop(0)
             if nxt is not None:
                 tickets.append(nxt)
             ex = None
@@ -1154,6 +1157,8 @@ class Predictor:
             ex["frame_ind"] = np.arange(i0, i1, dtype=np.int64)
             ex["scale"] = np.ones((i1 - i0, 2), np.float32)
             ex["image_hw"] = image_hw
+            if kept is not None:
+                ex["image_dev"], ex["image_ready"] = kept
             reporter.update(i1 - i0)
             if i_next is None:
                 reporter.__exit__(None, None, None)

@@ -151,6 +151,26 @@ def test_topdown_predict_api(topdown):
     assert a["instance_peaks"].shape[0] == 3 and a["n_valid"].shape == (3,)
 
 
+def test_topdown_predict_with_flow_tracker_uses_the_uploaded_frames(topdown):
+    """The generic predict loop hands a flow tracker the batch it uploaded (no second host-to-device copy): the same tracks as
+    tracking the finished predictions with the frames re-read from the array."""
+    from sleap_amd.nn.tracking import Tracker, run_tracker
+
+    p, frames = topdown
+    frames = np.concatenate([frames, frames[::-1]])  # 6 frames, 3 batches of 2
+    try:
+        p.tracker = Tracker.make_tracker_by_name(tracker="flow", track_window=3)
+        outs = p.predict(frames, make_labels=False)
+    finally:
+        p.tracker = None
+    assert all("image_dev" not in ex and "image_ready" not in ex for ex in outs)
+    plain = p.predict(frames, make_labels=False)
+    again = run_tracker([dict(ex) for ex in plain], Tracker.make_tracker_by_name(tracker="flow", track_window=3), data=frames)
+    for a, b in zip(outs, again):
+        assert np.array_equal(a["track_inds"], b["track_inds"])
+    assert max(int(ex["track_inds"].max()) for ex in outs) >= 0
+
+
 @pytest.mark.parametrize("max_instances", [None, 2])
 def test_topdown_device_path_equals_ragged_path_without_host_round_trips(topdown, max_instances):
     """`TopDownInferenceModel.call` runs on fixed crop slots per frame (sa_select_centroids / sa_finish_instance_peaks: the
