@@ -391,6 +391,11 @@ int sa_conv1x1_head(const void* src, int CinP, const float* w, const float* bias
  * image (InferenceLayer.preprocess applies ensure_float first). src [B,H,W,C] f32 -> dst [B,Ho,Wo,C] f32 */
 int sa_resize_bilinear_f32(const float* src, int B, int H, int W, int C, int Ho, int Wo, float* dst,
                            sa_stream_t stream);
+/* The same resize on uint8 frames whose taps enter as float(v) * in_scale: ensure_float (x * 1/255, normalization.py:49) folded
+ * into the resize that follows it in InferenceLayer.preprocess (inference.py:940-967); same float32 operations, same results as
+ * converting first. */
+int sa_resize_bilinear_u8_f32(const void* src, int B, int H, int W, int C, int Ho, int Wo, float in_scale, float* dst,
+                              sa_stream_t stream);
 
 /* dtype plumbing: f32 NHWC [.., C] <-> bf16 NHWC [.., CP] (zero padded) */
 int sa_f32_to_bf16_padded(const float* src, int n_pix, int C, int CP, void* dst, sa_stream_t stream);

@@ -91,6 +91,7 @@ SIGNATURES = {
     "sa_upsample2x_bf16": (_i, [_p, _i, _i, _i, _i, _i, _p, _p]),
     "sa_conv1x1_head": (_i, [_p, _i, _p, _p, _i, _i, _i, _i, _i, _p, _p]),
     "sa_resize_bilinear_f32": (_i, [_p, _i, _i, _i, _i, _i, _i, _p, _p]),
+    "sa_resize_bilinear_u8_f32": (_i, [_p, _i, _i, _i, _i, _i, _i, _f, _p, _p]),
     "sa_f32_to_bf16_padded": (_i, [_p, _i, _i, _i, _p, _p]),
     "sa_bf16_to_f32": (_i, [_p, _i, _i, _i, _p, _p]),
     "sa_network_create": (_i, [_p, _sz, _p]),

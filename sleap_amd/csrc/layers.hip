@@ -486,8 +486,11 @@ convt3x3s2_kernel(const uint16_t* __restrict__ src, int CinP, const uint16_t* __
 
 // tf.image.resize(method="bilinear", antialias=False) with half-pixel centres (resizing.py:97-103):
 // src = (dst + 0.5) * in/out - 0.5; taps clamp to the image; value = top + (bottom - top) * ylerp.
+// SRC = float: the image as it is; SRC = uint8_t: every tap enters as float(v) * in_scale -- ensure_float's `x * 1/255`
+// (normalization.py:49) folded into the resize that follows it (resizing.py:71-105), same float32 operations in the same order
+template <typename SRC>
 __global__ void __launch_bounds__(256)
-resize_bilinear_f32_kernel(const float* __restrict__ src, int B, int H, int W, int C, int Ho, int Wo,
+resize_bilinear_f32_kernel(const SRC* __restrict__ src, int B, int H, int W, int C, int Ho, int Wo, float in_scale,
                            float* __restrict__ dst) {
   const float sy = (float)H / (float)Ho, sx = (float)W / (float)Wo;
   const size_t total = (size_t)B * Ho * Wo * C;
@@ -503,9 +506,17 @@ resize_bilinear_f32_kernel(const float* __restrict__ src, int B, int H, int W, i
     const int y0 = max((int)fly, 0), y1 = min((int)ceilf(fy), H - 1);
     const int x0 = max((int)flx, 0), x1 = min((int)ceilf(fx), W - 1);
     const float ly = fy - fly, lx = fx - flx;
-    const float* im = src + b * H * W * C + c;
-    const float tl = im[((size_t)y0 * W + x0) * C], tr = im[((size_t)y0 * W + x1) * C];
-    const float bl = im[((size_t)y1 * W + x0) * C], br = im[((size_t)y1 * W + x1) * C];
+    const SRC* im = src + b * H * W * C + c;
+    auto tap = [&](int yy, int xx) {
+      const SRC v = im[((size_t)yy * W + xx) * C];
+      if constexpr (sizeof(SRC) == 1)
+        return __builtin_fmaf((float)v, in_scale, 0.0f);  // the product rounded on its own: as an FMA it cannot be contracted into
+                                                           // the interpolation's FMAs (a plain `*`, also __fmul_rn, can)
+      else
+        return (float)v;
+    };
+    const float tl = tap(y0, x0), tr = tap(y0, x1);
+    const float bl = tap(y1, x0), br = tap(y1, x1);
     const float top = tl + (tr - tl) * lx, bot = bl + (br - bl) * lx;
     dst[t] = top + (bot - top) * ly;
   }
@@ -675,8 +686,17 @@ int sa_convt3x3s2_bf16(const void* src, int CinP, const void* w, const float* bi
 int sa_resize_bilinear_f32(const float* src, int B, int H, int W, int C, int Ho, int Wo, float* dst,
                            sa_stream_t stream) {
   SA_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && Ho > 0 && Wo > 0, "sa_resize_bilinear_f32: bad shape");
-  hipLaunchKernelGGL(resize_bilinear_f32_kernel, dim3(grid_for((size_t)B * Ho * Wo * C)), dim3(256), 0,
-                     (hipStream_t)stream, src, B, H, W, C, Ho, Wo, dst);
+  hipLaunchKernelGGL(resize_bilinear_f32_kernel<float>, dim3(grid_for((size_t)B * Ho * Wo * C)), dim3(256), 0,
+                     (hipStream_t)stream, src, B, H, W, C, Ho, Wo, 1.0f, dst);
+  SA_LAUNCH_CHECK();
+  return SA_OK;
+}
+
+int sa_resize_bilinear_u8_f32(const void* src, int B, int H, int W, int C, int Ho, int Wo, float in_scale, float* dst,
+                              sa_stream_t stream) {
+  SA_REQUIRE(src && dst && B > 0 && H > 0 && W > 0 && C > 0 && Ho > 0 && Wo > 0, "sa_resize_bilinear_u8_f32: bad arguments");
+  hipLaunchKernelGGL(resize_bilinear_f32_kernel<uint8_t>, dim3(grid_for((size_t)B * Ho * Wo * C)), dim3(256), 0,
+                     (hipStream_t)stream, static_cast<const uint8_t*>(src), B, H, W, C, Ho, Wo, in_scale, dst);
   SA_LAUNCH_CHECK();
   return SA_OK;
 }

@@ -196,9 +196,8 @@ class InferenceLayer:
         else:
             x = _ensure_rgb(x)
         if resize_img and self.input_scale != 1.0:
-            if self.ensure_float and x.dtype == torch.uint8:
-                x = x.to(torch.float32) * np.float32(1.0 / 255.0)
-            x = _resize_image(x, self.input_scale)
+            # (uint8 frames: ensure_float's `* 1/255` happens inside the resize kernel, tap by tap -- one launch, no torch arithmetic)
+            x = _resize_image(x, self.input_scale, to_float=self.ensure_float)
         if self.pad_to_stride > 1:
             x = _pad_to_stride(x, self.pad_to_stride)
         return x
@@ -227,16 +226,21 @@ def _ensure_rgb(x):
     return x
 
 
-def _resize_image(x, scale):
-    """resizing.py:71-105: bilinear, half-pixel centres, no antialias; size = int(dim * scale)."""
+def _resize_image(x, scale, to_float: bool = False):
+    """resizing.py:71-105: bilinear, half-pixel centres, no antialias; size = int(dim * scale). `to_float` with uint8 frames:
+    ensure_float (normalization.py:49) applied to every tap inside the kernel -> float32 result, as converting first gives."""
     B, H, W, Cc = x.shape
     nh, nw = int(H * scale), int(W * scale)
-    xf = x.to(torch.float32).contiguous()
     y = torch.empty((B, nh, nw, Cc), dtype=torch.float32, device=x.device)
+    if x.dtype == torch.uint8:
+        xc = x.contiguous()
+        _lib.check(_lib.lib().sa_resize_bilinear_u8_f32(ops._ptr(xc), B, H, W, Cc, nh, nw,
+                                                        float(np.float32(1.0 / 255.0)) if to_float else 1.0, ops._ptr(y),
+                                                        ops._stream()), "sa_resize_bilinear_u8_f32")
+        return y if to_float else y.to(torch.uint8)  # (tf.cast back to the input dtype truncates)
+    xf = x.to(torch.float32).contiguous()
     _lib.check(_lib.lib().sa_resize_bilinear_f32(ops._ptr(xf), B, H, W, Cc, nh, nw, ops._ptr(y), ops._stream()),
                "sa_resize_bilinear_f32")
-    if x.dtype == torch.uint8:  # tf.cast back to the input dtype truncates
-        return y.to(torch.uint8)
     return y
 
 

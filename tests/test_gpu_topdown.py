@@ -51,6 +51,19 @@ def test_resize_kernel_vs_oracle():
         assert_allclose(got, oracle_resize(x, scale), atol=2e-6)
 
 
+def test_fused_uint8_resize_is_bitwise_convert_then_resize():
+    """sa_resize_bilinear_u8_f32 (ensure_float folded into the resize, one launch) == float32(x) * float32(1/255) followed by
+    sa_resize_bilinear_f32, bit for bit; without the scale it is the plain uint8 resize."""
+    from sleap_amd.nn.inference import _resize_image
+
+    rng = np.random.default_rng(5)
+    x = torch.from_numpy(rng.integers(0, 256, (3, 37, 52, 1), dtype=np.uint8)).cuda()
+    for scale in (0.5, 0.75, 1.5):
+        two_step = _resize_image(x.to(torch.float32) * np.float32(1.0 / 255.0), scale)
+        assert torch.equal(_resize_image(x, scale, to_float=True), two_step)
+        assert torch.equal(_resize_image(x, scale), _resize_image(x.to(torch.float32), scale).to(torch.uint8))
+
+
 def test_single_instance_predictor_robot_fixture():
     """RGB model with input_scaling 0.5 (resize kernel, +0.5 un-scaling) -- BASELINE configs[0]/[1] layer path."""
     from sleap_amd.nn.inference import SingleInstancePredictor, load_model
