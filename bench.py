@@ -16,7 +16,13 @@ A step = preprocessing (u8 -> float fused into the first conv) -> UNet forward -
 integral refinement -> PAF scoring -> Hungarian matching -> instance assembly -> packed fixed-shape
 results (all-gathered over ranks when N > 1), on frames already resident in HBM.
 
-Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
+`python bench.py --gpus N` launches its N ranks itself (torch.distributed.run, one process per GPU, 127.0.0.1 rendezvous) and
+refuses to run when fewer than N GPUs are visible or the process group ends up with a different rank count; under torchrun it
+joins the group it was started in.
+
+Rank 0 prints ONE JSON line (contract in the task statement): `value` = EXACTLY K timed steps between two barrier + synchronize
+fences, MAX over ranks. Measured after that region, reported beside it: `sustained` (the same step repeated for >= 1 s),
+`literal_split_8_per_gpu` (8 frames per GPU per step: configs[3]'s global batch of 64 over 8 GPUs), and two extra objects:
   roofline      conv3x3 MFMA kernel family: algorithmic TFLOP/s (2*H*W*Cin*Cout*9 over its launches) over
                 its HIP-event-measured time inside this process, vs the 2.5 PFLOP/s dense fp16 / bf16 MFMA peak
   cpu_baseline  the CPU oracle (torch-CPU fp32 convs + NumPy/SciPy post-processing; "port") timed on the
@@ -35,10 +41,24 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2500.0  # dense, fp16 and bf16 alike (/opt/skills/guides/MI355X_MICROARCH.md)
-# HBM bytes of the conv kernel family per step of the DEFAULT workload (64 frames of 1024x1024), from two separate
-# rocprofv3 --pmc passes (FETCH_SIZE doubled per the gfx950 correction, WRITE_SIZE uncalibrated): profiles/r02_pmc_hbm_traffic.md
-# (16-channel planes; the NHWC plan of the same network moved 13.15 GB: partially used cache lines fetched more than once)
-MEASURED_CONV_TRAFFIC_BYTES_PER_STEP = 10.94e9
+# HBM bytes of the conv kernel family per step of the DEFAULT workload (64 frames of 1024x1024) are NOT measured by this process
+# (PMC counters need a rocprofv3 run of their own): `roofline.traffic` is read at run time from the newest
+# profiles/r*_pmc_hbm_traffic.json (written by tools/pmc_traffic.py from two separate --pmc passes, FETCH_SIZE doubled per the
+# gfx950 correction, WRITE_SIZE uncalibrated) and labelled with that file in `roofline.traffic_source`; null without one.
+
+
+def profiled_traffic(batch, size):
+    """-> (HBM bytes per step of the conv family, source label) from the newest tracked PMC summary matching this workload."""
+    import glob
+
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_traffic.json")), reverse=True):
+        try:
+            d = json.load(open(f))
+        except (OSError, ValueError):
+            continue
+        if d.get("frames_per_step") == batch and d.get("size") == size:
+            return float(d["conv_family_bytes_per_step"]), f"profile file {os.path.relpath(f, ROOT)} (not measured by this run)"
+    return None, "no PMC summary for this workload under profiles/"
 
 
 def parse():
@@ -60,6 +80,11 @@ def parse():
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise the RCCL process group and run the gather / barrier / max-reduce path even with one rank "
                          "(exercises the N > 1 code on a 1-GPU box)")
+    ap.add_argument("--dry-run-cpu", action="store_true",
+                    help="launcher / process-group check without a GPU: the ranks meet over gloo, gather a packed result block "
+                         "and print the line's distributed fields (tests/test_bench_launcher.py)")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the blocks measured after the timed region (sustained run, strong-scaling block, dense-activation pass)")
     ap.add_argument("--dtype", choices=("bf16", "fp16"), default=None,
                     help="16-bit storage type of activations / conv weights (one library build each; accumulation is fp32). "
                          "Default: the package default (fp16, SLEAP_AMD_DTYPE)")
@@ -147,13 +172,70 @@ def cpu_baseline(mc, weights, scorer_args, frames_u8, budget_s, device_result=No
     return out
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` without torchrun: start the N ranks ourselves (one process per GPU, the command line the
+    task statement gives for the driver) and hand their exit code back. No-op inside a launched rank or for N = 1."""
+    if args.gpus <= 1 or "RANK" in os.environ or "WORLD_SIZE" in os.environ:
+        return
+    if not args.dry_run_cpu:
+        n = torch.cuda.device_count()
+        if n < args.gpus:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} but only {n} GPU(s) are visible -- refusing to report a "
+                             f"{args.gpus}-GPU number from fewer devices")
+    import socket
+    import subprocess
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on these hosts (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", str(max(1, cpu_budget() // args.gpus)))
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
+def dry_run_cpu(args, world, rank):
+    """The distributed skeleton of a step on CPU tensors over gloo: shard arithmetic, one all-gather of the packed rows,
+    barrier, max-reduce of the time -- everything `main` does around the GPU work. Prints the same distributed fields."""
+    import torch.distributed as dist
+    from sleap_amd import parallel
+
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    if dist.get_world_size() != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the process group has {dist.get_world_size()} rank(s)")
+    B = (args.global_batch // world) if args.global_batch else args.batch
+    width = parallel.packed_width(32, 13)
+    packed = torch.full((B, width), float(rank), dtype=torch.float32)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        got = parallel.gather_batch_results(packed, B * world, 32, 13, world)
+    dist.barrier()
+    tmax = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    ok = bool(all(float(got[r * B, 0]) == float(r) for r in range(world)))
+    if rank == 0:
+        print(json.dumps({"dry_run": True, "n_gpus": world, "steps": args.steps, "rows_in_rank_order": ok,
+                          "config": {"n_ranks_seen": dist.get_world_size(), "collective_backend": dist.get_backend(),
+                                     "frames_per_gpu_per_step": B, "global_batch": B * world}}), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def main():
     args = parse()
+    self_launch(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE is {world}: launch with `python bench.py --gpus N` "
+                         "(self-launching) or torchrun --nproc-per-node N")
+    if args.dry_run_cpu:
+        return dry_run_cpu(args, world, rank)
     torch.cuda.set_device(local_rank)
     # torch's CPU kernels spin in OpenMP regions sized by the VISIBLE core count; under a container CPU quota that throttles
     # the whole process (DESIGN.md section 5). The timed loop has no torch CPU ops, this keeps stray ones harmless.
@@ -166,6 +248,8 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group(backend="nccl", rank=rank, world_size=world,
                                 device_id=torch.device("cuda", local_rank))
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} but the process group has {dist.get_world_size()} rank(s)")
 
     from sleap_amd import parallel
     from sleap_amd.benchmark_model import build_benchmark_predictor
@@ -194,15 +278,29 @@ def main():
     host_out = torch.empty((world * B, width), dtype=torch.float32).pin_memory()
     gathered = torch.empty((world * B, width), dtype=torch.float32, device="cuda")
 
-    def step():
-        outs = pred.inference_model.call(frames)
+    def step(fr=frames, g=gathered, h=host_out):
+        outs = pred.inference_model.call(fr)
         packed = parallel.pack_results(outs)
         if use_dist:
-            dist.all_gather_into_tensor(gathered, packed)
-            host_out.copy_(gathered, non_blocking=True)
+            dist.all_gather_into_tensor(g, packed)
+            h.copy_(g, non_blocking=True)
         else:
-            host_out.copy_(packed, non_blocking=True)
+            h.copy_(packed, non_blocking=True)
         return outs
+
+    def timed(n, **kw):
+        """n steps between two fences -> seconds, the MAX over ranks."""
+        fence()
+        t = time.perf_counter()
+        for _ in range(n):
+            step(**kw)
+        fence()
+        t = time.perf_counter() - t
+        if use_dist:
+            tm = torch.tensor([t], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+            t = float(tm.item())
+        return t
 
     def fence():
         torch.cuda.synchronize()
@@ -227,6 +325,28 @@ def main():
     status_bits = int(np.bitwise_or.reduce(res["status"].numpy().astype(np.int64)))
     mean_instances = float(res["n_valid"].float().mean())
 
+    # ---- after the contract's K-step region (every rank takes part: the gather is in the step)
+    sustained = small = None
+    if not args.no_extras:
+        # (1) the same step repeated until >= 1 s of wall clock, so that an SMI sample of the run sees a busy GPU
+        n_sus = max(args.steps, int(np.ceil(1.2 * args.steps / max(dt, 1e-6))))
+        t_sus = timed(n_sus)
+        sustained = {"steps_effective": n_sus, "seconds": round(t_sus, 3), "value": round(world * B * n_sus / t_sus, 2),
+                     "ms_per_step": round(t_sus / n_sus * 1e3, 3)}
+        # (2) configs[3] read literally -- a global batch of 64 over 8 GPUs = 8 frames per GPU per step -- on however many
+        # ranks this run has (at N = 8 this IS the strong-scaling point of a 64-frame global batch)
+        b8 = 8
+        if B > b8:
+            g8 = torch.empty((world * b8, width), dtype=torch.float32, device="cuda")
+            h8 = torch.empty((world * b8, width), dtype=torch.float32).pin_memory()
+            f8 = frames[:b8].contiguous()
+            kw = dict(fr=f8, g=g8, h=h8)
+            timed(3, **kw)
+            n8 = max(args.steps, 50)
+            t8 = timed(n8, **kw)
+            small = {"frames_per_gpu_per_step": b8, "global_batch": b8 * world, "steps": n8,
+                     "value": round(world * b8 * n8 / t8, 2), "ms_per_step": round(t8 / n8 * 1e3, 3)}
+
     out = None
     if rank == 0:
         # ---- instrumented pass: per-op HIP events on the launch stream (outside the timed region)
@@ -244,6 +364,25 @@ def main():
         conv_fl = sum(f for (k, _, f) in descs if k == "conv") * B
         n_conv = sum(1 for (k, _, _) in descs if k == "conv")
         all_ms = float(acc.sum())
+        # the same instrumented pass on DENSE activations (seeded random-init weights: the fitted network's post-ReLU maps are
+        # sparse, the chip draws less power per MFMA and clocks higher -- the fitted-model fraction is data dependent)
+        dense = None
+        if not args.no_extras and not args.random_init and world == 1:
+            from sleap_amd.benchmark_model import build_benchmark_graph
+            from sleap_amd.nn.engine import DeviceNetwork
+
+            _, mc_r, w_r = build_benchmark_graph(H, W, seed=0)
+            net_r = DeviceNetwork(mc_r, w_r, dtype=args.dtype)
+            accr = np.zeros(len(descs))
+            for r in range(3):
+                prof = []
+                net_r.forward(layer.preprocess(frames), profile=prof)
+                torch.cuda.synchronize()
+                if r:
+                    accr += np.array([a.elapsed_time(b) for a, b in prof])
+            accr /= 2
+            dense = {"conv_ms": float(sum(ms for (k, _, _), ms in zip(descs, accr) if k == "conv")), "all_ms": float(accr.sum())}
+            del net_r
         # post-processing time
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         cms, pafs, offs = layer.forward_pass(frames)
@@ -260,8 +399,13 @@ def main():
         roofline = {
             "kernel": f"conv3x3_dma_kernel + convpair + stem16_gray_kernel (the {n_conv} MFMA conv launches of one step)", "bound": "mfma", "achieved": round(achieved, 2),
             "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
-            "traffic": (MEASURED_CONV_TRAFFIC_BYTES_PER_STEP if (B == 64 and H == 1024 and W == 1024) else None),
-            "traffic_unit": "HBM bytes per step over the kernel family's launches (rocprofv3 PMC, profiles/r02_pmc_hbm_traffic.md)",
+            # the WHOLE network forward (the conv family + the launches without FLOPs: materialised upsampling) by the same FLOPs
+            "frac_forward": round(conv_fl / (all_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
+            "frac_dense": (round(conv_fl / (dense["conv_ms"] * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4) if dense else None),
+            "frac_forward_dense": (round(conv_fl / (dense["all_ms"] * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4) if dense else None),
+            "traffic": profiled_traffic(B, H)[0] if H == W else None,
+            "traffic_source": profiled_traffic(B, H)[1] if H == W else None,
+            "traffic_unit": "HBM bytes per step over the kernel family's launches (FETCH_SIZE x 2 + WRITE_SIZE)",
             "launches_per_step": n_conv, "avg_launch_ms": round(conv_ms / n_conv, 4),
             "algorithmic_gflop_per_frame": round(conv_fl / B / 1e9, 2),
             "network_ms_per_step": round(all_ms, 3), "postproc_ms_per_step": round(post_ms, 3),
@@ -289,6 +433,7 @@ def main():
                        "peak_threshold": 0.2, "refinement": "integral", "mean_peaks_per_frame": round(mean_peaks, 1),
                        "mean_instances_per_frame": round(mean_instances, 2), "status_bits": status_bits},
             "roofline": roofline,
+            "sustained": sustained, "literal_split_8_per_gpu": small,
         }
         if world == 1 and not args.no_cpu_baseline:
             sample = frames_np if args.parity_frames <= 0 else frames_np[: args.parity_frames]

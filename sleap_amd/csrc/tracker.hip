@@ -752,6 +752,14 @@ int flow_batch_run(Tracker& T, int n_frames, int max_inst, int n_nodes, const fl
   }
   const size_t pbytes = sa_flow_pyramid_bytes(frame_h, frame_w, c.of_window_size, c.of_max_levels);
   std::vector<void*> bp((size_t)n_frames, nullptr);
+  struct PoolGuard {  // every exit path hands the pyramid buffers it did not consume back to the tracker's pool
+    std::vector<void*>& v;
+    std::vector<void*>& pool;
+    ~PoolGuard() {
+      for (void*& b : v)
+        if (b) pool.push_back(b), b = nullptr;
+    }
+  } bp_guard{bp, F.pool};
   for (int f = 0; f < n_frames; ++f) {
     SA_REQUIRE(n_valid[f] >= 0 && n_valid[f] <= max_inst && max_inst < 65536, "sa_tracker_track_frames_images: n_valid[%d] out of range", f);
     bp[(size_t)f] = F.take(pbytes);
@@ -883,9 +891,7 @@ int flow_batch_run(Tracker& T, int n_frames, int max_inst, int n_nodes, const fl
   }
   B.active = false;
   B.at.clear();
-  for (void* b : bp)
-    if (b) F.pool.push_back(b);
-  return rc;
+  return rc;  // (bp_guard returns what is left of bp)
 }
 
 }  // namespace

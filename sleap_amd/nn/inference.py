@@ -1045,128 +1045,128 @@ class Predictor:
         self.make_pipeline(data if isinstance(data, (np.ndarray, Video, VideoReader)) else None)
         reporter = ProgressReporter(self.verbosity, self.report_rate, n, enabled=rank == 0)
         reporter.__enter__()
+        try:
 
-        # Frame sources the prefetcher can read (arrays, Video, VideoReader): this rank's batches are staged into page-locked
-        # buffers by a producer thread and uploaded on a copy stream of their own, so the host copy and the DMA of batch k+1
-        # run under the device work of batch k (from a pageable array, `frames[lo:hi].cuda()` is a synchronous staged copy on
-        # the compute stream: top-down at 1024 x 1024 ran at 82 % of its HBM-resident rate, tools/predict_e2e_topdown.py)
-        feed = feeder = copy_stream = None
-        if isinstance(data, (np.ndarray, Video, VideoReader)) and torch.cuda.is_available() and n > 0 \
-                and not (isinstance(data, np.ndarray) and data.ndim == 3):
-            from ..io.video import FramePrefetcher
+            # Frame sources the prefetcher can read (arrays, Video, VideoReader): this rank's batches are staged into page-locked
+            # buffers by a producer thread and uploaded on a copy stream of their own, so the host copy and the DMA of batch k+1
+            # run under the device work of batch k (from a pageable array, `frames[lo:hi].cuda()` is a synchronous staged copy on
+            # the compute stream: top-down at 1024 x 1024 ran at 82 % of its HBM-resident rate, tools/predict_e2e_topdown.py)
+            feed = feeder = copy_stream = None
+            if isinstance(data, (np.ndarray, Video, VideoReader)) and torch.cuda.is_available() and n > 0 \
+                    and not (isinstance(data, np.ndarray) and data.ndim == 3):
+                from ..io.video import FramePrefetcher
 
-            ranges = [parallel.shard_range(i0, min(i0 + self.batch_size, n), rank, world) for i0 in range(0, n, self.batch_size)]
-            feeder = FramePrefetcher(data, [r for r in ranges if r[1] > r[0]], depth=4)
-            feed = iter(feeder)
-            copy_stream = getattr(self, "_upload_stream", None)  # (kept: creating a hardware queue costs milliseconds)
-            if copy_stream is None:
-                copy_stream = self._upload_stream = torch.cuda.Stream(priority=int(os.environ.get("SLEAP_AMD_COPY_STREAM_PRIORITY", "-1")))
+                ranges = [parallel.shard_range(i0, min(i0 + self.batch_size, n), rank, world) for i0 in range(0, n, self.batch_size)]
+                feeder = FramePrefetcher(data, [r for r in ranges if r[1] > r[0]], depth=4)
+                feed = iter(feeder)
+                copy_stream = getattr(self, "_upload_stream", None)  # (kept: creating a hardware queue costs milliseconds)
+                if copy_stream is None:
+                    copy_stream = self._upload_stream = torch.cuda.Stream(priority=int(os.environ.get("SLEAP_AMD_COPY_STREAM_PRIORITY", "-1")))
 
-        # With prefetched sources the device work runs on a stream of the predictor's own instead of the default stream (as the
-        # bottom-up layer does): on the default stream the uploads of the copy stream did not overlap it -- the top-down rate
-        # from host frames was that of upload + compute in series (7.2 k frames/s against 8.6 k from a CUDA tensor).
-        compute_stream = None
-        if feed is not None:
-            compute_stream = getattr(self, "_compute_stream", None)
-            if compute_stream is None:
-                compute_stream = self._compute_stream = torch.cuda.Stream(priority=-1)
+            # With prefetched sources the device work runs on a stream of the predictor's own instead of the default stream (as the
+            # bottom-up layer does): on the default stream the uploads of the copy stream did not overlap it -- the top-down rate
+            # from host frames was that of upload + compute in series (7.2 k frames/s against 8.6 k from a CUDA tensor).
+            compute_stream = None
+            if feed is not None:
+                compute_stream = getattr(self, "_compute_stream", None)
+                if compute_stream is None:
+                    compute_stream = self._compute_stream = torch.cuda.Stream(priority=-1)
 
-        keep_frames = world == 1 and bool(getattr(getattr(self, "tracker", None), "uses_image", False))
-        import inspect
+            keep_frames = world == 1 and bool(getattr(getattr(self, "tracker", None), "uses_image", False))
+            import inspect
 
-        # (an inference model whose outputs_to_numpy does not take the early-downloaded arrays converts at hand-out time)
-        early_download = "host" in inspect.signature(self.inference_model.outputs_to_numpy).parameters
+            # (an inference model whose outputs_to_numpy does not take the early-downloaded arrays converts at hand-out time)
+            early_download = "host" in inspect.signature(self.inference_model.outputs_to_numpy).parameters
 
-        def on_compute():
-            import contextlib
+            def on_compute():
+                import contextlib
 
-            return torch.cuda.stream(compute_stream) if compute_stream is not None else contextlib.nullcontext()
+                return torch.cuda.stream(compute_stream) if compute_stream is not None else contextlib.nullcontext()
 
-        def batch_of(lo, hi):
-            """This rank's frames of one batch on the device (prefetched sources) or as the source hands them out."""
-            if feed is None:
-                return frames[lo:hi], None
-            try:
-                _lo, _hi, _inds, pinned = next(feed)
-            except StopIteration:  # the producer stops at a frame the source cannot deliver (inference.py:3333-3339)
-                raise KeyError(f"Unable to load frame: the source ended before frames {lo}..{hi - 1}") from None
-            key = feeder.hold()
-            with torch.cuda.stream(copy_stream):
-                dev_frames = pinned.cuda(non_blocking=True)
-                up = torch.cuda.Event()
-                up.record(copy_stream)
-            cur = torch.cuda.current_stream()
-            cur.wait_event(up)
-            dev_frames.record_stream(cur)
-            feeder.release_key(key, up)
-            return dev_frames, up
+            def batch_of(lo, hi):
+                """This rank's frames of one batch on the device (prefetched sources) or as the source hands them out."""
+                if feed is None:
+                    return frames[lo:hi], None
+                try:
+                    _lo, _hi, _inds, pinned = next(feed)
+                except StopIteration:  # the producer stops at a frame the source cannot deliver (inference.py:3333-3339)
+                    raise KeyError(f"Unable to load frame: the source ended before frames {lo}..{hi - 1}") from None
+                key = feeder.hold()
+                with torch.cuda.stream(copy_stream):
+                    dev_frames = pinned.cuda(non_blocking=True)
+                    up = torch.cuda.Event()
+                    up.record(copy_stream)
+                cur = torch.cuda.current_stream()
+                cur.wait_event(up)
+                dev_frames.record_stream(cur)
+                feeder.release_key(key, up)
+                return dev_frames, up
 
-        def submit(i0):
-            """Queue one batch (everything asynchronous that the model leaves asynchronous) -> a ticket."""
-            i1 = min(i0 + self.batch_size, n)
-            lo, hi = parallel.shard_range(i0, i1, rank, world)
-            dev, kept = None, None
-            with on_compute():
-                if hi > lo:
-                    batch, _up = batch_of(lo, hi)
-                    dev = self.inference_model.predict_on_batch(batch, numpy=False)
-                    if keep_frames and _up is not None:
-                        kept = (batch, _up)  # a flow tracker reads the frames where they already are
-                pre = None
-                if dev is not None and not set(dev) <= small:
-                    # maps / crops may alias network buffers that the next batch overwrites: convert before anything else runs
-                    dev = self.inference_model.outputs_to_numpy(dev)
-                elif dev is not None and early_download:
-                    pre = start_download(dev)  # queued behind this batch's kernels, before the next batch's
-            return i0, i1, dev, pre, kept
-
-        # two-deep pipeline: batch k+1 is queued before batch k is brought to the host (the conversion synchronises), so the
-        # GPU works on k+1 while the host waits for, converts and hands out k
-        if n == 0:
-            reporter.__exit__(None, None, None)
-            return
-        f0 = frames[0]
-        image_hw = np.asarray(f0.shape[:2] if hasattr(f0, "shape") else (1, 1), np.int64)
-        tickets = [submit(0)]
-        for i_next in list(range(self.batch_size, n, self.batch_size)) + [None]:
-            nxt = submit(i_next) if i_next is not None else None
-            i0, i1, dev, pre, kept = tickets.pop(0)
-            if nxt is not None:
-                tickets.append(nxt)
-            ex = None
-            if dev is not None:
+            def submit(i0):
+                """Queue one batch (everything asynchronous that the model leaves asynchronous) -> a ticket."""
+                i1 = min(i0 + self.batch_size, n)
+                lo, hi = parallel.shard_range(i0, i1, rank, world)
+                dev, kept = None, None
                 with on_compute():
-                    if isinstance(next(iter(dev.values())), np.ndarray):
-                        ex = dev
-                    elif pre is None:
-                        ex = self.inference_model.outputs_to_numpy(dev)
-                    else:
-                        ex = self.inference_model.outputs_to_numpy(dev, host=finish_download(*pre))
-            if world > 1:
-                parts = [None] * world
-                dist.all_gather_object(parts, ex)
-                parts = [p for p in parts if p is not None]
-                imax = max(p["instance_peaks"].shape[1] for p in parts)
-                ex = {}
-                for k in parts[0]:
-                    vs = []
-                    for p in parts:
-                        v = p[k]
-                        if v.ndim >= 2 and k != "n_valid" and v.shape[1] < imax:
-                            pad = np.full((v.shape[0], imax - v.shape[1]) + v.shape[2:], np.nan, v.dtype)
-                            v = np.concatenate([v, pad], axis=1)
-                        vs.append(v)
-                    ex[k] = np.concatenate(vs, axis=0)
-            ex["video_ind"] = np.zeros((i1 - i0,), np.int64)
-            ex["frame_ind"] = np.arange(i0, i1, dtype=np.int64)
-            ex["scale"] = np.ones((i1 - i0, 2), np.float32)
-            ex["image_hw"] = image_hw
-            if kept is not None:
-                ex["image_dev"], ex["image_ready"] = kept
-            reporter.update(i1 - i0)
-            if i_next is None:
-                reporter.__exit__(None, None, None)
-            yield ex
+                    if hi > lo:
+                        batch, _up = batch_of(lo, hi)
+                        dev = self.inference_model.predict_on_batch(batch, numpy=False)
+                        if keep_frames and _up is not None:
+                            kept = (batch, _up)  # a flow tracker reads the frames where they already are
+                    pre = None
+                    if dev is not None and not set(dev) <= small:
+                        # maps / crops may alias network buffers that the next batch overwrites: convert before anything else runs
+                        dev = self.inference_model.outputs_to_numpy(dev)
+                    elif dev is not None and early_download:
+                        pre = start_download(dev)  # queued behind this batch's kernels, before the next batch's
+                return i0, i1, dev, pre, kept
+
+            # two-deep pipeline: batch k+1 is queued before batch k is brought to the host (the conversion synchronises), so the
+            # GPU works on k+1 while the host waits for, converts and hands out k
+            if n == 0:
+                return
+            f0 = frames[0]
+            image_hw = np.asarray(f0.shape[:2] if hasattr(f0, "shape") else (1, 1), np.int64)
+            tickets = [submit(0)]
+            for i_next in list(range(self.batch_size, n, self.batch_size)) + [None]:
+                nxt = submit(i_next) if i_next is not None else None
+                i0, i1, dev, pre, kept = tickets.pop(0)
+                if nxt is not None:
+                    tickets.append(nxt)
+                ex = None
+                if dev is not None:
+                    with on_compute():
+                        if isinstance(next(iter(dev.values())), np.ndarray):
+                            ex = dev
+                        elif pre is None:
+                            ex = self.inference_model.outputs_to_numpy(dev)
+                        else:
+                            ex = self.inference_model.outputs_to_numpy(dev, host=finish_download(*pre))
+                if world > 1:
+                    parts = [None] * world
+                    dist.all_gather_object(parts, ex)
+                    parts = [p for p in parts if p is not None]
+                    imax = max(p["instance_peaks"].shape[1] for p in parts)
+                    ex = {}
+                    for k in parts[0]:
+                        vs = []
+                        for p in parts:
+                            v = p[k]
+                            if v.ndim >= 2 and k != "n_valid" and v.shape[1] < imax:
+                                pad = np.full((v.shape[0], imax - v.shape[1]) + v.shape[2:], np.nan, v.dtype)
+                                v = np.concatenate([v, pad], axis=1)
+                            vs.append(v)
+                        ex[k] = np.concatenate(vs, axis=0)
+                ex["video_ind"] = np.zeros((i1 - i0,), np.int64)
+                ex["frame_ind"] = np.arange(i0, i1, dtype=np.int64)
+                ex["scale"] = np.ones((i1 - i0, 2), np.float32)
+                ex["image_hw"] = image_hw
+                if kept is not None:
+                    ex["image_dev"], ex["image_ready"] = kept
+                reporter.update(i1 - i0)
+                yield ex
+        finally:  # also when the generator raises or is abandoned before its last batch (rich keeps the cursor hidden otherwise)
+            reporter.__exit__(None, None, None)
 
     def predict(self, data, make_labels: bool = True):
         """inference.py:496-531 (see BottomUpPredictor.predict for the output contract)."""

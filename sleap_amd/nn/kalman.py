@@ -301,7 +301,10 @@ class BareKalmanTracker:
         if all(np.isnan(d)):
             return np.nan
         ok = ~np.isnan(d)
-        return float(np.average(d[ok], weights=instance_weights[ok]))
+        w = np.asarray(instance_weights, np.float64)[ok]
+        if not w.sum() > 0:  # no point score on the nodes present (e.g. scores missing): no cost, the pair is skipped
+            return np.nan
+        return float(np.average(d[ok], weights=w))
 
     def get_mean_instance_distances(self, instances: List[_Inst]) -> dict:
         pts = {id(i): self.get_instance_points_weight(i)[0] for i in instances}

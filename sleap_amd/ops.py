@@ -3,6 +3,7 @@
 Every function takes/returns torch CUDA tensors (contiguous) and enqueues work on the current
 torch stream. Shapes and meanings follow include/sleap_amd.h.
 """
+import collections
 import ctypes as C
 
 import numpy as np
@@ -174,7 +175,13 @@ def paf_group(peak_xy, peak_val, node_count, node_peaks, match_dst, match_score,
     return inst, vals, scores, n_inst
 
 
-_PP_WS = {}
+# Scratch of the fused post-processing, one per (shape, device, STREAM): two layers (or threads) with equal shapes on different
+# streams must not share scan counters / keys / PAF scratch, and a buffer is only ever used -- and therefore only ever handed
+# back to torch's caching allocator -- on the stream it was allocated under, so evicting one entry cannot free memory under a
+# kernel queued elsewhere. The scan counters at its head are zeroed at allocation and handed back zeroed by every SUCCESSFUL
+# call (sleap_amd.h); a failed call drops its entry, so the next call starts from a freshly zeroed one.
+_PP_WS = collections.OrderedDict()
+_PP_WS_MAX = 8
 
 
 def bottomup_postproc(cms, offsets, pafs, threshold, refinement, patch_size, xy_scale, max_peaks, edges, sorted_edge_inds, n_nodes,
@@ -199,14 +206,28 @@ def bottomup_postproc(cms, offsets, pafs, threshold, refinement, patch_size, xy_
         status = torch.zeros((B,), dtype=i32, device=dev)
     o["status"] = status
     h = _lib.lib()
-    key = (B, max_peaks, E, N, NP, str(dev))
-    if key not in _PP_WS:
-        if len(_PP_WS) > 8:
-            _PP_WS.clear()
-        # zeroed ONCE: the scan counters at its head are handed back zeroed by every call (sleap_amd.h)
-        _PP_WS[key] = torch.zeros((h.sa_bottomup_postproc_workspace(B, max_peaks, E, N, NP),), dtype=torch.uint8, device=dev)
-    ws = _PP_WS[key]
+    key = (B, max_peaks, E, N, NP, str(dev), int(torch.cuda.current_stream().cuda_stream))
+    ws = _PP_WS.get(key)
+    if ws is None:
+        while len(_PP_WS) >= _PP_WS_MAX:
+            _PP_WS.popitem(last=False)  # the least recently used entry only
+        ws = _PP_WS[key] = torch.zeros((h.sa_bottomup_postproc_workspace(B, max_peaks, E, N, NP),), dtype=torch.uint8, device=dev)
+    else:
+        _PP_WS.move_to_end(key)
     mode = REFINE["offsets"] if offsets is not None else REFINE[refinement]
+    try:
+        _bottomup_postproc_call(h, cms, offsets, B, H, W, Cc, threshold, mode, patch_size, xy_scale, max_peaks, pafs, Hp, Wp, E,
+                                edges, sorted_edge_inds, N, n_points, pafs_stride, max_edge_length, dist_penalty_weight, NP,
+                                min_line_scores, min_instance_peaks, I, o, status, ws)
+    except Exception:
+        _PP_WS.pop(key, None)  # its counters may be left non-zero: never reuse it
+        raise
+    return o
+
+
+def _bottomup_postproc_call(h, cms, offsets, B, H, W, Cc, threshold, mode, patch_size, xy_scale, max_peaks, pafs, Hp, Wp, E, edges,
+                            sorted_edge_inds, N, n_points, pafs_stride, max_edge_length, dist_penalty_weight, NP, min_line_scores,
+                            min_instance_peaks, I, o, status, ws):
     check(h.sa_bottomup_postproc(
         _ptr(cms), _ptr(offsets), B, H, W, Cc, float(threshold), mode, int(patch_size), float(xy_scale), int(max_peaks), _ptr(pafs),
         Hp, Wp, E, _ptr(edges), _ptr(sorted_edge_inds), int(sorted_edge_inds.numel()), N, int(n_points), float(pafs_stride),
@@ -215,7 +236,6 @@ def bottomup_postproc(cms, offsets, pafs, threshold, refinement, patch_size, xy_
         _ptr(o["node_peaks"]), _ptr(o["line_scores"]), _ptr(o["match_dst"]), _ptr(o["match_score"]), _ptr(o["instance_peaks"]),
         _ptr(o["instance_peak_vals"]), _ptr(o["instance_scores"]), _ptr(o["n_instances"]), _ptr(status), _ptr(ws), ws.numel(),
         _stream()), "sa_bottomup_postproc")
-    return o
 
 
 def lsa_host(cost, wave: bool = False):

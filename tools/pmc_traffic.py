@@ -1,7 +1,10 @@
 """HBM traffic of the conv kernel family from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) over bench.py.
 FETCH_SIZE is doubled (gfx950 reports half the bytes of wide coalesced reads, MI355X_MICROARCH.md §HBM).
 
-    python tools/pmc_traffic.py <fetch counter_collection.csv> <write counter_collection.csv> <n B=64 forwards>
+    python tools/pmc_traffic.py <fetch counter_collection.csv> <write counter_collection.csv> <n B=64 forwards> [out.json]
+
+With `out.json` the per-step total is also written as the small JSON file bench.py reads `roofline.traffic` from
+(profiles/r<NN>_pmc_hbm_traffic.json: {"conv_family_bytes_per_step", "frames_per_step", "size", "source"}).
 """
 import csv
 import re
@@ -22,7 +25,7 @@ def load(path, counter):
     return a
 
 
-def main(fetch_csv, write_csv, n_fwd):
+def main(fetch_csv, write_csv, n_fwd, out_json=None):
     f, w = load(fetch_csv, "FETCH_SIZE"), load(write_csv, "WRITE_SIZE")
     print("| kernel | grid | launches | FETCH_SIZE x2 [MB/launch] | WRITE_SIZE [MB/launch] |")
     print("|---|---|---|---|---|")
@@ -40,5 +43,14 @@ def main(fetch_csv, write_csv, n_fwd):
           f"{(tf + tw) / n_fwd / 64:.0f} MB/frame; algorithmic activations in + out of the current plan: DESIGN.md section 3")
 
 
+    if out_json:
+        import json
+
+        json.dump({"conv_family_bytes_per_step": (tf + tw) * 1024 / n_fwd, "fetch_x2_bytes_per_step": tf * 1024 / n_fwd,
+                   "write_bytes_per_step": tw * 1024 / n_fwd, "frames_per_step": 64, "size": 1024, "forward_passes": n_fwd,
+                   "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH doubled (gfx950), WRITE uncalibrated"},
+                  open(out_json, "w"))
+
+
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2], int(sys.argv[3]))
+    main(sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4] if len(sys.argv) > 4 else None)
