@@ -19,6 +19,7 @@
 // the intermediate tile with zeros outside the image (= conv-b's SAME padding). Phase B: the usual 9-tap loop.
 #include <cstdint>
 #include <cstdlib>
+#include <type_traits>
 
 #include "bf16.h"
 #include "sa_common.h"
@@ -289,6 +290,287 @@ convpair_16_32_32_kernel(const PairParams p) {
 #endif
 }
 
+
+// ---- round 3: the same block as a PERSISTENT workgroup with the next tile's input prefetched ------------------------------------
+// What the one-tile-per-workgroup kernel above spends per tile besides its 58 MFMAs per wave (profiles/r02_pmc_sq_counters.md:
+// matrix cores 48 % busy, VALU issue 62 %): a launch, ~150 VALU instructions of address set-up (DMA offsets, nine tap offsets,
+// 24 fragment offsets), the reload of conv-a's nine A fragments and of conv-b's 18 KiB weight slab, and -- the largest part --
+// an HBM round trip for the input tile with nothing to do meanwhile but the partner workgroup's work. Here a workgroup keeps
+// everything tile-independent (both weight sets, every LDS offset) for its whole life and walks the tiles of its XCD's range;
+// the input tile of tile t+1 is requested right after phase A of tile t has finished reading the input area (which phase B does
+// not touch) and lands under phase B's 36 MFMAs per wave. The one wait for those copies sits BEFORE the epilogue's stores, so it
+// never waits for a store (gfx9 counts loads and stores in one vmcnt; the stores of tile t then drain under phase A of t+1).
+// Arithmetic and rounding are those of the kernel above (same bits). The biases live in LDS (256 B) instead of 32 registers.
+__global__ void __launch_bounds__(512, 4)
+convpair_persist_kernel(const PairParams p, int n_tiles) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int NW = 8, R = 2, TH = NW * R, TW = 32;
+  constexpr int PH = TH + 2, PW = TW + 2;
+  constexpr int QH = TH + 4, QW = TW + 4;
+  constexpr int INTER_BYTES = PH * PW * 64;
+  constexpr int IN_BYTES = QH * QW * 32;
+  constexpr int N_IN = (IN_BYTES + 1023) / 1024;
+  constexpr int WA_OFF = INTER_BYTES + N_IN * 1024;
+  constexpr int BIAS_OFF = WA_OFF + 18 * 1024;
+  constexpr int IN_PER_WAVE = (N_IN + NW - 1) / NW;
+  constexpr unsigned OOB = 0xFFFFFF00u;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* inter = smem;
+  unsigned char* in_tile = smem + INTER_BYTES;
+  unsigned char* wb_tile = smem + WA_OFF;
+  const float* bias_lds = reinterpret_cast<const float*>(smem + BIAS_OFF);  // [0, 32): conv-a, [32, 64): conv-b
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5, lx = lane & 31;
+  const int H = p.H, W = p.W;
+  // tile schedule: contiguous range per XCD (block i runs on XCD i % 8), the j-th workgroup of an XCD walks start + j, + g8, ...
+  int L, L_end, L_step;
+  {
+    const int q = n_tiles >> 3, r = n_tiles & 7, xcd = blockIdx.x & 7, k = blockIdx.x >> 3;
+    const int start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    L_step = ((int)gridDim.x - xcd + 7) >> 3;
+    L = start + k;
+    L_end = start + q + (xcd < r ? 1 : 0);
+  }
+  if (L >= L_end) return;  // workgroup uniform
+  const size_t fbytes = (size_t)H * W * 32;
+  const __amdgpu_buffer_rsrc_t rwb = __builtin_amdgcn_make_buffer_rsrc((void*)p.wb, 0, 18 * 1024, 0x00020000);
+
+  // ---- once per workgroup: conv-b weights -> LDS, conv-a fragments -> registers, biases -> LDS, every tile-independent offset
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const int k = j * NW + wave;
+    if (k < 18) __builtin_amdgcn_raw_ptr_buffer_load_lds(rwb, (lds_ptr_t)(wb_tile + k * 1024), 16, (unsigned)lane * 16, k * 1024, 0, 0);
+  }
+  if (tid < 64) reinterpret_cast<float*>(smem + BIAS_OFF)[tid] = tid < 32 ? p.bias_a[tid] : p.bias_b[tid - 32];
+  mfma_h8 wa_reg[9];
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap)
+    wa_reg[tap] = *reinterpret_cast<const mfma_h8*>(p.wa + ((size_t)tap * 64 + lane) * 8);
+  // LDS layouts: as in the kernel above, but the 16-byte-slot swizzles depend on the tile COLUMN only ((column >> 3) & 1 for
+  // the 32-byte input records, (column >> 2) & 3 for the 64-byte intermediate records): the lanes of a ds_read_b128 /
+  // ds_write_b128 group always share their row, so this is as conflict-free as the pixel-index form, and a fragment offset
+  // becomes (per-lane column part) + (compile-time row part) -- 3 + 6 + 2 offset registers instead of 9 + 24 + 2, which is what
+  // lets everything tile-independent stay resident next to the 36 registers of conv-a's A fragments without spilling.
+  // phase B fragment offsets of halo row wave*2, columns lx + dx, both k-steps (row rr adds rr * PW * 64)
+  unsigned boff[3][2];
+#pragma unroll
+  for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      boff[dx][kk] = (unsigned)(((wave * R) * PW + lx + dx) * 64 + (((2 * kk + half) ^ (((lx + dx) >> 2) & 3)) * 16));
+      asm volatile("" : "+v"(boff[dx][kk]));
+    }
+  const float low_a = p.relu_a ? 0.0f : -INFINITY, low_b = p.relu_b ? 0.0f : -INFINITY;
+  const unsigned pixb = p.planar ? 32u : 64u;
+
+  struct Tile {
+    int x0, y0, b;
+  };
+  auto decode = [&](int l) {
+    Tile t;
+    t.x0 = (l % p.tiles_x) * TW;
+    l /= p.tiles_x;
+    t.y0 = (l % p.tiles_y) * TH;
+    t.b = l / p.tiles_y;
+    return t;
+  };
+  auto issue_input = [&](const Tile& t) {
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(reinterpret_cast<const unsigned char*>(p.src) + t.b * fbytes), 0, (int)fbytes, 0x00020000);
+    int ln = lane;  // (per-lane piece coordinates are re-derived per tile: nothing of them stays in registers across the phases)
+    asm volatile("" : "+v"(ln));
+#pragma unroll
+    for (int j = 0; j < IN_PER_WAVE; ++j) {
+      const int i = j * NW + wave;
+      if (i < N_IN) {  // wave uniform
+        const int o = i * 1024 + ln * 16;
+        const int pl = o >> 5, s = (o >> 4) & 1;
+        const int ty = pl / QW, tx = pl - ty * QW;
+        const int gy = t.y0 + ty - 2, gx = t.x0 + tx - 2;
+        const bool ok = pl < QH * QW && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+        const unsigned voff = ok ? (unsigned)(gy * W + gx) * 32u + (unsigned)((s ^ ((tx >> 3) & 1)) * 16) : OOB;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(in_tile + i * 1024), 16, voff, 0, 0, 0);
+      }
+    }
+  };
+
+  // one phase-A group: 9 MFMAs on the fragments at rd[tap] (+ rimm), bias + ReLU, zero outside the image, two 16-byte stores
+  auto group = [&](const unsigned (&rd)[3], int rimm, const unsigned (&wr)[2], int wimm, auto masked_c, bool in_img, bool store,
+                   int hoff4) {
+    constexpr bool MASKED = decltype(masked_c)::value;
+    f32x16 d;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) d[i] = 0.0f;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const mfma_h8 bv = *reinterpret_cast<const mfma_h8*>(in_tile + rd[tap % 3] + (tap / 3) * (QW * 32) + rimm);
+      d = SA_MFMA_32x32x16(wa_reg[tap], bv, d, 0, 0, 0);
+    }
+    const unsigned m = (!MASKED || in_img) ? 0xFFFFFFFFu : 0u;
+    uint2 pk[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float4 bq = *reinterpret_cast<const float4*>(bias_lds + 8 * q + hoff4);  // (one quad at a time: 4 registers, not 16)
+      const float bj[4] = {bq.x, bq.y, bq.z, bq.w};
+      pk[q].x = sa::f2h2(fmaxf(d[4 * q + 0] + bj[0], low_a), fmaxf(d[4 * q + 1] + bj[1], low_a));
+      pk[q].y = sa::f2h2(fmaxf(d[4 * q + 2] + bj[2], low_a), fmaxf(d[4 * q + 3] + bj[3], low_a));
+      if (MASKED) pk[q].x &= m, pk[q].y &= m;
+    }
+#pragma unroll
+    for (int pr = 0; pr < 2; ++pr) {
+      uint2 x = pk[2 * pr], y = pk[2 * pr + 1];
+      sa::swap32(x.x, y.x);
+      sa::swap32(x.y, y.y);
+      if (store) *reinterpret_cast<uint4*>(inter + wr[pr] + wimm) = make_uint4(x.x, x.y, y.x, y.y);
+    }
+  };
+  auto phase_a = [&](const Tile& t, auto masked_c) {
+    // per-lane offsets of halo row `wave`, column lx: derived per tile from an opaque copy of the lane id, so that they are not
+    // kept in 11 registers across phase B (with them the kernel needs > 128 registers and spills)
+    int ln = lane;
+    asm volatile("" : "+v"(ln));
+    const int half = ln >> 5, lx = ln & 31;
+    unsigned roff[3], woff[2];  // halo row `wave`, columns lx + dx; a tap's row dy adds dy * QW * 32
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) roff[dx] = (unsigned)((wave * QW + lx + dx) * 32 + ((half ^ (((lx + dx) >> 3) & 1)) * 16));
+#pragma unroll
+    for (int pr = 0; pr < 2; ++pr) woff[pr] = (unsigned)((wave * PW + lx) * 64 + (((2 * pr + half) ^ ((lx >> 2) & 3)) * 16));
+    const bool colok = (unsigned)(t.x0 + lx - 1) < (unsigned)W;
+#pragma unroll
+    for (int it = 0; it < 3; ++it) {
+      const int ty = wave + 8 * it;
+      if (ty < PH) {  // wave uniform (it == 2: waves 0, 1)
+        const bool rowok = (unsigned)(t.y0 + ty - 1) < (unsigned)H;
+        group(roff, it * (8 * QW * 32), woff, it * (8 * PW * 64), masked_c, colok && rowok, true, 4 * half);
+      }
+    }
+    if (wave == 2 || wave == 3) {  // halo columns 32, 33: pixel q of the 36 -> row q >> 1, column 32 + (q & 1)
+      const int q2 = (wave - 2) * 32 + lx;
+      const bool valid2 = q2 < 2 * PH;
+      const int qc2 = valid2 ? q2 : 0, ty2 = qc2 >> 1, tx2 = 32 + (qc2 & 1);
+      unsigned rd[3], wr[2];
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) rd[dx] = (unsigned)((ty2 * QW + tx2 + dx) * 32 + ((half ^ (((tx2 + dx) >> 3) & 1)) * 16));
+#pragma unroll
+      for (int pr = 0; pr < 2; ++pr) wr[pr] = (unsigned)((ty2 * PW + tx2) * 64 + (((2 * pr + half) ^ ((tx2 >> 2) & 3)) * 16));
+      const bool in_img = (unsigned)(t.y0 + ty2 - 1) < (unsigned)H && (unsigned)(t.x0 + tx2 - 1) < (unsigned)W;
+      group(rd, 0, wr, 0, masked_c, in_img, valid2, 4 * half);
+    }
+  };
+
+  Tile cur = decode(L);
+  issue_input(cur);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // first tile: weights + input (later tiles wait before their epilogue's stores)
+#pragma clang loop unroll(disable)
+  for (;;) {
+    const int L_next = L + L_step;
+    const bool more = L_next < L_end;  // workgroup uniform
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __syncthreads();  // every wave's copies of this tile's input landed (each waited for its own); phase B of the previous tile is done
+
+    // ---- phase A: conv-a (16 -> 32) on the 18 x 34 halo pixels; tiles whose halo lies inside the image skip the padding mask
+    const bool interior = cur.x0 >= 1 && cur.y0 >= 1 && cur.x0 + PW - 1 <= W && cur.y0 + PH - 1 <= H;
+    if (__builtin_amdgcn_readfirstlane((int)interior))
+      phase_a(cur, std::false_type{});
+    else
+      phase_a(cur, std::true_type{});
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __syncthreads();  // the intermediate tile is complete; nobody reads the input tile any more
+    Tile nxt = cur;
+    if (more) {
+      nxt = decode(L_next);
+      issue_input(nxt);  // lands under phase B
+    }
+
+    // ---- phase B: conv-b (32 -> 32), wave owns rows wave*2, wave*2+1
+    f32x16 acc[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[r][i] = 0.0f;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int dy = tap / 3, dx = tap % 3;
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        const mfma_h8 a = *reinterpret_cast<const mfma_h8*>(wb_tile + (kk * 9 + tap) * 1024 + lane * 16);
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          const mfma_h8 bv = *reinterpret_cast<const mfma_h8*>(inter + boff[dx][kk] + (r + dy) * (PW * 64));
+          acc[r] = SA_MFMA_32x32x16(a, bv, acc[r], 0, 0, 0);
+        }
+      }
+    }
+
+    // ---- epilogue. The prefetched copies were queued a whole phase B ago: waiting for them HERE, before the first store is
+    // issued, costs next to nothing and keeps the stores out of every later wait.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    int ln_e = lane;
+    asm volatile("" : "+v"(ln_e));
+    const int half_e = ln_e >> 5;
+    const unsigned lane16 = (unsigned)half_e * 16u;
+    const int gx = cur.x0 + (ln_e & 31);
+    auto bias4 = [&](int g, float (&bj)[4]) {  // conv-b bias of this lane's channels 8g + 4 half .. +3
+      const float4 q = *reinterpret_cast<const float4*>(bias_lds + 32 + 8 * g + 4 * half_e);
+      bj[0] = q.x, bj[1] = q.y, bj[2] = q.z, bj[3] = q.w;
+    };
+    auto store_pieces = [&](unsigned char* row_base, size_t blk_bytes, unsigned lane_off, bool ok, const uint2 (&pk)[4]) {
+#pragma unroll
+      for (int pr = 0; pr < 2; ++pr) {
+        uint2 x = pk[2 * pr], y = pk[2 * pr + 1];
+        sa::swap32(x.x, y.x);
+        sa::swap32(x.y, y.y);
+        if (ok) *reinterpret_cast<uint4*>(row_base + (size_t)pr * blk_bytes + lane_off) = make_uint4(x.x, x.y, y.x, y.y);
+      }
+    };
+    const bool col_in = gx < W;
+    if (p.dst) {
+      unsigned char* frame = reinterpret_cast<unsigned char*>(p.dst) + (size_t)cur.b * H * W * 64;
+      const size_t blk = p.planar ? (size_t)H * W * 32 : (size_t)32;
+      const unsigned lane_off = (unsigned)gx * pixb + lane16;
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const int gy = cur.y0 + wave * R + r;  // wave uniform
+        uint2 pk[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          float bj[4];
+          bias4(g, bj);
+          pk[g].x = sa::f2h2(fmaxf(acc[r][4 * g + 0] + bj[0], low_b), fmaxf(acc[r][4 * g + 1] + bj[1], low_b));
+          pk[g].y = sa::f2h2(fmaxf(acc[r][4 * g + 2] + bj[2], low_b), fmaxf(acc[r][4 * g + 3] + bj[3], low_b));
+        }
+        store_pieces(frame + (size_t)gy * W * pixb, blk, lane_off, col_in && gy < H, pk);
+      }
+    }
+    if (p.dst_pool) {
+      const int gy = cur.y0 + wave * R;  // wave uniform, even
+      unsigned char* frame = reinterpret_cast<unsigned char*>(p.dst_pool) + (size_t)cur.b * (H / 2) * (W / 2) * 64;
+      const size_t blk = p.planar ? (size_t)(H / 2) * (W / 2) * 32 : (size_t)32;
+      const unsigned lane_off = (unsigned)(gx >> 1) * pixb + lane16;
+      uint2 pk[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        float t4[4], bj[4];
+        bias4(g, bj);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float t = fmaxf(fmaxf(acc[0][4 * g + j] + bj[j], low_b), fmaxf(acc[1][4 * g + j] + bj[j], low_b));
+          t4[j] = fmaxf(t, sa::dpp_xor1(t));
+        }
+        pk[g].x = sa::f2h2(t4[0], t4[1]);
+        pk[g].y = sa::f2h2(t4[2], t4[3]);
+      }
+      store_pieces(frame + (size_t)(gy >> 1) * (W / 2) * pixb, blk, lane_off, !(ln_e & 1) && col_in && gy < H, pk);
+    }
+    if (!more) break;
+    cur = nxt;
+    L = L_next;
+  }
+#endif
+}
+
 }  // namespace
 
 extern "C" int sa_conv3x3_pair_bf16(const void* src, int C0P, const void* wa, const float* bias_a, int relu_a, int C1P,
@@ -321,6 +603,29 @@ extern "C" int sa_conv3x3_pair_bf16(const void* src, int C0P, const void* wa, co
   const size_t nblk = (size_t)p.tiles_x * p.tiles_y * B;
   if (nblk > 0x7fffffffull) return sa::fail(SA_ERR_INVALID_ARG, "sa_conv3x3_pair_bf16: grid too large");
   constexpr int lds = 18 * 34 * 64 + 23 * 1024 + 18 * 1024;  // 81152: intermediate tile + input tile + conv-b weights
+  // SA_CONVPAIR_PERSIST=0: one workgroup per tile (the round-2 kernel, kept for A/B runs); n > 0: n workgroups per CU
+  static const int persist = [] {
+    const char* v = getenv("SA_CONVPAIR_PERSIST");
+    return v ? atoi(v) : -1;
+  }();
+  if (persist != 0) {
+    constexpr int ldsp = lds + 256;  // + both bias vectors
+    static int n_cu = 0, per_cu = 0;
+    if (!n_cu) {
+      int dev = 0, nb = 0;
+      SA_HIP_CHECK(hipGetDevice(&dev));
+      SA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&convpair_persist_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, ldsp));
+      SA_HIP_CHECK(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+      SA_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(&convpair_persist_kernel), 512, ldsp));
+      per_cu = nb > 0 ? nb : 1;
+    }
+    size_t grid = (size_t)(persist > 0 ? persist : per_cu) * (size_t)n_cu;
+    if (grid > nblk) grid = nblk;
+    hipLaunchKernelGGL(convpair_persist_kernel, dim3((unsigned)grid), dim3(512), ldsp, (hipStream_t)stream, p, (int)nblk);
+    SA_LAUNCH_CHECK();
+    return SA_OK;
+  }
   static bool attr_set = false;
   if (!attr_set) {
     SA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&convpair_16_32_32_kernel),
