@@ -14,7 +14,6 @@
 // conv0 precision: the B operand holds raw pixel values 0..255 (exact in bf16); the fp32 weights times 1/255 are
 // split into three bf16 terms (hi + mid + lo carries the full 24-bit mantissa), three MFMAs with fp32 accumulation.
 #include <cstdint>
-#include <cstdlib>
 #include <type_traits>
 
 #include "bf16.h"
@@ -452,265 +451,6 @@ stem16_gray_kernel(const Stem16Params p) {
 #endif
 }
 
-// ---- round 3: the grayscale kernel as a PERSISTENT workgroup. One tile per workgroup costs, besides the tile's 60 MFMAs per
-// wave: a launch (131072 of them per 64 frames of 1024 x 1024), the reload of the eight register-resident weight fragments, ~60
-// VALU instructions of per-lane address set-up, and an exposed HBM round trip for the tile's pixels in front of the first
-// barrier (profiles/r02_pmc_sq_counters.md: 44 % of the wave cycles parked). Here a workgroup walks the tiles of its XCD's
-// range with everything tile-independent resident; the pixels of tile t+1 are requested (two dwords per thread) while tile t's
-// table is complete and wait in registers through conv0 / conv1 of tile t; the one vmcnt wait sits before the epilogue's
-// stores, so no wait ever covers a store. Same arithmetic as stem16_gray_kernel (same bits).
-__global__ void __launch_bounds__(256)
-stem16_gray_persist_kernel(const Stem16Params p, int n_tiles) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  constexpr int TH = SA_STEM16_TH, TW = SA_STEM16_TW, PH = TH + 2, PW = TW + 2, RH = TH + 4;
-  constexpr int RS = 48;  // triplet-table row stride in entries: 96 dwords = 32 (mod 64) banks between kernel rows
-  __shared__ __attribute__((aligned(16))) uint2 rawt[(RH + 1) * RS];  // row RH: entry 0 is the zero operand
-  __shared__ __attribute__((aligned(16))) unsigned char act[(PH * PW + 16) * 32];
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int n16 = lane & 15, kb = lane >> 4;
-  const int H = p.H, W = p.W;
-  int L, L_end, L_step;  // tile schedule: contiguous range per XCD, the j-th workgroup of an XCD walks start + j, + g8, ...
-  {
-    const int q = n_tiles >> 3, r = n_tiles & 7, xcd = blockIdx.x & 7, k = blockIdx.x >> 3;
-    const int start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-    L_step = ((int)gridDim.x - xcd + 7) >> 3;
-    L = start + k;
-    L_end = start + q + (xcd < r ? 1 : 0);
-  }
-  if (L >= L_end) return;  // workgroup uniform
-  struct Tile {
-    int x0, y0, b;
-  };
-  auto decode = [&](int l) {
-    Tile t;
-    t.x0 = (l % p.tiles_x) * TW;
-    l /= p.tiles_x;
-    t.y0 = (l % p.tiles_y) * TH;
-    t.b = l / p.tiles_y;
-    return t;
-  };
-  // this thread's share of a tile's pixels: the two aligned dwords covering image columns x0 - 4 + 4 dq .. + 7 of halo row lty
-  const int lty = tid / 9, ldq = tid - lty * 9;
-  unsigned nv0 = 0, nv1 = 0;
-  auto load_pixels = [&](const Tile& t) {
-    nv0 = nv1 = 0;
-    if (tid < RH * 9) {
-      const int gy = t.y0 + lty - 2, gx = t.x0 - 4 + ldq * 4;
-      if (gy >= 0 && gy < H) {
-        const uint8_t* row = p.src + ((size_t)t.b * H + gy) * W;
-        if (gx >= 0 && gx < W) nv0 = *reinterpret_cast<const unsigned*>(row + gx);
-        if (gx + 4 >= 0 && gx + 4 < W) nv1 = *reinterpret_cast<const unsigned*>(row + gx + 4);
-      }
-    }
-  };
-  if (tid == 255) rawt[RH * RS] = make_uint2(0u, 0u);
-  auto write_table = [&]() {  // the entries of raw columns tx = 4dq-2 .. 4dq+1 (raw column tx <-> image column x0 - 2 + tx)
-    if (tid < RH * 9) {
-      unsigned h[6];  // storage bits of pixels 0..5 of the 8 (0..255 x U8_ACT_SCALE: exact in bf16 and fp16)
-#pragma unroll
-      for (int e = 0; e < 6; ++e) {
-        const unsigned byte = e < 4 ? (nv0 >> (8 * e)) & 0xFF : (nv1 >> (8 * (e - 4))) & 0xFF;
-        h[e] = sa::f2h((float)byte * sa::U8_ACT_SCALE);
-      }
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int tx = ldq * 4 - 2 + e;
-        if (tx >= 0 && tx < PW) rawt[lty * RS + tx] = make_uint2(h[e] | (h[e + 1] << 16), h[e + 2]);
-      }
-    }
-  };
-  const uint4* blob4 = reinterpret_cast<const uint4*>(p.blob);
-  mfma_h8 wa[3], wb[5];
-#pragma unroll
-  for (int i = 0; i < 3; ++i) wa[i] = __builtin_bit_cast(mfma_h8, blob4[i * 64 + lane]);
-#pragma unroll
-  for (int i = 0; i < 5; ++i) wb[i] = __builtin_bit_cast(mfma_h8, blob4[(3 + i) * 64 + lane]);
-  const float* biases = reinterpret_cast<const float*>(p.blob + 8 * 64 * 8);
-  const float4 q0 = *reinterpret_cast<const float4*>(biases + kb * 4);
-  const float4 q1 = *reinterpret_cast<const float4*>(biases + 16 + kb * 4);
-  const float bias0[4] = {q0.x, q0.y, q0.z, q0.w}, bias1[4] = {q1.x, q1.y, q1.z, q1.w};
-  Tile cur = decode(L);
-  load_pixels(cur);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma clang loop unroll(disable)
-  for (;;) {  // ---- tiles of this workgroup
-  const int x0 = cur.x0, y0 = cur.y0, b = cur.b;
-  const int L_next = L + L_step;
-  const bool more = L_next < L_end;  // workgroup uniform
-  write_table();  // from the registers filled a tile ago (conv0 of the previous tile -- the table's only reader -- is behind a barrier)
-  Tile nxt = cur;
-  if (more) {
-    nxt = decode(L_next);
-    load_pixels(nxt);  // in flight through conv0 and conv1 of this tile
-  }
-  __syncthreads();
-
-  // ---- conv0 on the (PH x PW) halo tile. Columns 0..31 of every halo row are two 16-pixel groups: wave w takes column
-  // segment w & 1 of rows (w >> 1), (w >> 1) + 2, ... -- every per-lane quantity (table address, output address, column
-  // validity) is loop invariant up to a compile-time stride and the row validity is wave uniform, so a group costs its three
-  // MFMAs plus ~10 VALU instructions (the former "16 consecutive halo pixels per group" mapping needed 34 for its
-  // lane-dependent row / column walk, and this loop was the VALU-bound half of the kernel: 0.80 -> 0.63-0.68 ms).
-  // Columns 32, 33 (36 pixels) are three more groups, done by waves 0-2 afterwards. (Measured and dropped: pairing two
-  // groups with v_permlane16_swap into one 16-byte store per lane -- 2-way instead of 2 x 4-way bank conflicts -- 0.60 -> 0.63 ms.)
-  // VALU diet (round 2; the counters put this kernel at 0.72 of its VALU issue slots against 0.45 of the matrix-core cycles, and
-  // this loop held 11.5 VALU instructions per group of two MFMAs):
-  //   * tiles whose whole halo lies inside the image (all but the border ring) skip the per-value padding select;
-  //   * fp16 build: ReLU on the PACKED pair after the conversion (one v_pk_max_f16 for two values instead of two v_max_f32);
-  //   * the MFMA B operand is a register quad whose upper half is zero: kept as three persistent quads whose upper halves are
-  //     zeroed once, the table read fills the lower halves (the compiler re-zeroed two registers per group before).
-  const float low0 = p.relu0 ? 0.0f : -__builtin_huge_valf();
-  const bool interior = x0 >= 1 && y0 >= 1 && x0 + PW - 1 <= W && y0 + PH - 1 <= H;  // wave (workgroup) uniform
-#if SA_HAS_PK_MAX
-  const uint32_t lowpk = p.relu0 ? 0u : SA_PK_NEG_INF;
-#endif
-  auto conv0_store = [&](const f32x4 d, bool masked, bool in_img, unsigned char* dstp) {
-#if SA_HAS_PK_MAX
-    uint32_t a = sa::pk_max(sa::f2h2(d[0], d[1]), lowpk), b = sa::pk_max(sa::f2h2(d[2], d[3]), lowpk);
-#else
-    uint32_t a = sa::f2h2(fmaxf(d[0], low0), fmaxf(d[1], low0)), b = sa::f2h2(fmaxf(d[2], low0), fmaxf(d[3], low0));
-#endif
-    if (masked) {  // (compile-time in the two copies of the loop below) outside the image: conv1's SAME padding = 0
-      const unsigned m = in_img ? 0xFFFFFFFFu : 0u;
-      a &= m;
-      b &= m;
-    }
-    *reinterpret_cast<uint2*>(dstp) = make_uint2(a, b);
-  };
-  (void)low0;
-  {
-    const int seg = wave & 1, tx = seg * 16 + n16;
-    const bool colok = (unsigned)(x0 + tx - 1) < (unsigned)W;
-    // lanes kb == 3 carry K slots 24..31 (no taps): they read the zero entry with stride 0
-    const uint2* src = kb < 3 ? rawt + ((wave >> 1) + kb) * RS + tx : rawt + RH * RS;
-    const int sstep = kb < 3 ? 2 * RS : 0;
-#if defined(SA_STEM16_SWZ)
-    // the two 16-byte halves of a pixel record swap places for columns with bit 2 set: the 16 lanes of a ds_write_b64 group
-    // (16 consecutive columns, one kb) then fall on 16 distinct bank pairs twice instead of 8 four times (2-way instead of
-    // 4-way conflicts), and conv1's ds_read_b128 groups stay conflict-free (brute-forced over every row / column phase)
-    unsigned char* dstp = act + ((wave >> 1) * PW + tx) * 32 + (((kb >> 1) ^ ((tx >> 2) & 1)) * 16) + (kb & 1) * 8;
-#else
-    unsigned char* dstp = act + ((wave >> 1) * PW + tx) * 32 + kb * 8;
-#endif
-    auto rowok = [&](int it) { return (unsigned)(y0 + (wave >> 1) + 2 * it - 1) < (unsigned)H; };  // wave uniform
-    // three groups at a time: the hi / mid / lo MFMAs of one group depend on each other, those of different groups do not
-    uint4 opq[3] = {make_uint4(0u, 0u, 0u, 0u), make_uint4(0u, 0u, 0u, 0u), make_uint4(0u, 0u, 0u, 0u)};
-    auto rows = [&](auto masked_c) {  // the loop exists twice: with and without the padding select (a REAL branch on `interior`)
-      constexpr bool MASKED = decltype(masked_c)::value;
-#pragma unroll
-      for (int it = 0; it < PH / 2; it += 3) {
-        f32x4 d[3];
-#pragma unroll
-        for (int u = 0; u < 3; ++u) {
-          const uint2 tq = src[(it + u) * sstep];
-          opq[u].x = tq.x;
-          opq[u].y = tq.y;
-          d[u] = (f32x4){bias0[0], bias0[1], bias0[2], bias0[3]};
-        }
-#pragma unroll
-        for (int t = 0; t < SA_STEM16_TERMS; ++t)
-#pragma unroll
-          for (int u = 0; u < 3; ++u) d[u] = SA_MFMA_16x16x32(wa[t], __builtin_bit_cast(mfma_h8, opq[u]), d[u], 0, 0, 0);
-#pragma unroll
-        for (int u = 0; u < 3; ++u) conv0_store(d[u], MASKED, MASKED && colok && rowok(it + u), dstp + (it + u) * (2 * PW * 32));
-      }
-    };
-    if (__builtin_amdgcn_readfirstlane((int)interior))
-      rows(std::false_type{});
-    else
-      rows(std::true_type{});
-    if (wave < 3) {  // columns 32, 33: pixel q = 16 * wave + n16 of the 36 -> row q >> 1, column 32 + (q & 1)
-      const int q = wave * 16 + n16;
-      if (q < 2 * PH) {
-        const int ty2 = q >> 1, tx2 = 32 + (q & 1);
-        const uint2 tq = kb < 3 ? rawt[(ty2 + kb) * RS + tx2] : make_uint2(0u, 0u);
-        const mfma_h8 bf = __builtin_bit_cast(mfma_h8, make_uint4(tq.x, tq.y, 0u, 0u));
-        f32x4 d = {bias0[0], bias0[1], bias0[2], bias0[3]};
-#pragma unroll
-        for (int t = 0; t < SA_STEM16_TERMS; ++t) d = SA_MFMA_16x16x32(wa[t], bf, d, 0, 0, 0);
-        conv0_store(d, true, (unsigned)(y0 + ty2 - 1) < (unsigned)H && (unsigned)(x0 + tx2 - 1) < (unsigned)W,
-                    act + (ty2 * PW + tx2) * 32 + kb * 8);  // columns 32, 33
-      }
-    }
-  }
-  __syncthreads();
-
-  // ---- conv1: wave w owns rows 4w..4w+3, two 16-pixel groups per row; step s covers taps 2s (lanes kb 0,1) and 2s+1
-  // (lanes kb 2,3); tap 9 is zero-weight padding and reads tap 0's address
-  f32x4 acc[4][2];
-#pragma unroll
-  for (int r = 0; r < 4; ++r)
-#pragma unroll
-    for (int h = 0; h < 2; ++h) acc[r][h] = (f32x4){bias1[0], bias1[1], bias1[2], bias1[3]};
-#if defined(SA_STEM16_SWZ)
-  const unsigned char* abase = act + ((wave * 4) * PW + n16) * 32;
-  int hoff[3];  // byte offset of this lane's half (channels 8 (kb & 1) ..) in the pixel record of column n16 + dx (+16 h)
-#pragma unroll
-  for (int dx = 0; dx < 3; ++dx) hoff[dx] = ((kb & 1) ^ (((n16 + dx) >> 2) & 1)) * 16;
-#else
-  const unsigned char* abase = act + ((wave * 4) * PW + n16) * 32 + (kb & 1) * 16;
-#endif
-#pragma unroll
-  for (int s = 0; s < 5; ++s) {
-    constexpr int dummy = 0;
-    (void)dummy;
-    const int ta = 2 * s, tb = 2 * s + 1 < 9 ? 2 * s + 1 : 0;
-    const int off = (kb >> 1) ? ((tb / 3) * PW + tb % 3) : ((ta / 3) * PW + ta % 3);
-#if defined(SA_STEM16_SWZ)
-    const unsigned char* sb = abase + off * 32 + ((kb >> 1) ? hoff[tb % 3] : hoff[ta % 3]);
-#else
-    const unsigned char* sb = abase + off * 32;
-#endif
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const mfma_h8 bv = *reinterpret_cast<const mfma_h8*>(sb + (r * PW + h * 16) * 32);
-        acc[r][h] = SA_MFMA_16x16x32(wb[s], bv, acc[r][h], 0, 0, 0);
-      }
-  }
-
-  // ---- epilogue: lane holds couts kb*4..+3 of pixel (row, h*16 + n16). ReLU is one v_max against a uniform bound
-  // (0 or -inf); every address is one 64-bit base per lane plus compile-time offsets.
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the next tile's pixels (requested two phases ago) -- BEFORE the first store
-  const float low1 = p.relu1 ? 0.0f : -__builtin_huge_valf();
-  const int gy0 = y0 + wave * 4, gx0 = x0 + n16;
-  if (p.dst) {
-    uint16_t* dp = p.dst + (((size_t)b * H + gy0) * W + gx0) * 16 + kb * 4;
-#pragma unroll
-    for (int h = 0; h < 2; ++h)
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-        if (gy0 + r < H && gx0 + h * 16 < W)
-          *reinterpret_cast<uint2*>(dp + ((size_t)r * W + h * 16) * 16) =
-              make_uint2(sa::f2h2(fmaxf(acc[r][h][0], low1), fmaxf(acc[r][h][1], low1)),
-                         sa::f2h2(fmaxf(acc[r][h][2], low1), fmaxf(acc[r][h][3], low1)));
-  }
-  if (p.dst_pool) {
-    uint16_t* pp = p.dst_pool + (((size_t)b * (H / 2) + gy0 / 2) * (W / 2) + gx0 / 2) * 16 + kb * 4;
-#pragma unroll
-    for (int h = 0; h < 2; ++h)
-#pragma unroll
-      for (int r = 0; r < 4; r += 2) {
-        float t4[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const float t = fmaxf(fmaxf(acc[r][h][j], acc[r + 1][h][j]), low1);  // relu(max(.)) == max(relu(.))
-          t4[j] = fmaxf(t, sa::dpp_xor1(t));
-        }
-        if (!(lane & 1) && gy0 + r < H && gx0 + h * 16 < W)
-          *reinterpret_cast<uint2*>(pp + ((size_t)(r / 2) * (W / 2) + h * 8) * 16) =
-              make_uint2(sa::f2h2(t4[0], t4[1]), sa::f2h2(t4[2], t4[3]));
-      }
-  }
-  if (!more) break;
-  cur = nxt;
-  L = L_next;
-  }  // tiles
-#endif
-}
-
-
-
 }  // namespace
 
 extern "C" {
@@ -783,24 +523,7 @@ int sa_stem16_u8_bf16(const void* src, int B, int H, int W, int Cin, const void*
   p.tiles_y = (H + SA_STEM16_TH - 1) / SA_STEM16_TH;
   const size_t nblk = (size_t)p.tiles_x * p.tiles_y * B;
   if (nblk > 0x7fffffffull) return sa::fail(SA_ERR_INVALID_ARG, "sa_stem16_u8_bf16: grid too large");
-  // SA_STEM16_PERSIST=0: one workgroup per tile (the round-2 kernel, kept for A/B runs); n > 0: n workgroups per CU
-  static const int persist = [] {
-    const char* v = getenv("SA_STEM16_PERSIST");
-    return v ? atoi(v) : -1;
-  }();
-  if (Cin == 1 && (W & 3) == 0 && ((uintptr_t)src & 3) == 0 && persist != 0) {
-    static int n_cu = 0, per_cu = 0;
-    if (!n_cu) {
-      int dev = 0, nb = 0;
-      SA_HIP_CHECK(hipGetDevice(&dev));
-      SA_HIP_CHECK(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
-      SA_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(&stem16_gray_persist_kernel), 256, 0));
-      per_cu = nb > 0 ? nb : 1;
-    }
-    size_t grid = (size_t)(persist > 0 ? persist : per_cu) * (size_t)n_cu;
-    if (grid > nblk) grid = nblk;
-    hipLaunchKernelGGL(stem16_gray_persist_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, p, (int)nblk);
-  } else if (Cin == 1 && (W & 3) == 0 && ((uintptr_t)src & 3) == 0)
+  if (Cin == 1 && (W & 3) == 0 && ((uintptr_t)src & 3) == 0)
     hipLaunchKernelGGL(stem16_gray_kernel, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, p);
   else if (Cin == 1)
     hipLaunchKernelGGL((stem16_kernel<1>), dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, p);

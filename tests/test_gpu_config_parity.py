@@ -1,0 +1,236 @@
+"""End-to-end parity at the NAMED SHAPES of BASELINE.json configs[0], [1], [2] and [4] (configs[3] is
+tests/test_gpu_benchmark_parity.py): the device path (16-bit-storage MFMA network + device post-processing, through the
+reference-shaped predictors) against the fp32 CPU oracle running ITS OWN networks (torch-CPU Keras graph + restated peak
+finding / cropping / PAF grouping) on the SAME uint8 frames with the SAME float32 weights, compared POSITIONALLY as SURVEY.md
+8(d) prescribes: same number of instances per frame, same NaN mask, every peak within north_star's 0.5 px.
+
+The networks are the architectures of the reference's shipped training profiles, fitted to the synthetic videos of
+`sleap_amd.synth.render_animals` (sleap_amd/config_models.py, tools/train_config_models.py) and stored as float32 masters: the
+oracle computes with the fp32 values, the device rounds them to fp16 itself -- as it would real SLEAP weights. Frames are
+rendered with seeds the models were not fitted to.
+
+    configs[0]  256 x 256, 5 nodes: UNet (baseline.centroid profile, input x0.5) through SingleInstanceInferenceLayer /
+                find_global_peaks (inference.py:1319-1380), and the centroid model through CentroidCrop / find_local_peaks
+    configs[1]  512 x 512, 13 nodes, batch 32: single-instance UNet (baseline_medium_rf.single)
+    configs[2]  1024 x 1024 top-down, 2 animals: centroid UNet (x0.5) -> crops -> centered-instance UNet (f24)
+                (inference.py:1747-1966, 2059-2200)
+    configs[4]  1024 x 1024 bottom-up ResNet-50 + UpsamplingStack + PAFs, 24 nodes / 23 edges, 8 animals (resnet.py:467-541)
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import inference as oinf
+from oracle import paf_grouping as opg
+from oracle import peak_finding as opf
+from oracle.keras_graph import KerasGraph, preprocess
+
+pytestmark = pytest.mark.gpu
+
+TOL_PX = 0.5
+
+
+def _net(task, h, w, dtype="fp16"):
+    from sleap_amd import config_models as C
+    from sleap_amd.nn.engine import DeviceNetwork
+
+    mc, wts = C.load_task_weights(task, h, w)
+    return DeviceNetwork(mc, wts, dtype=dtype), mc, wts
+
+
+def _compare(got, want, what):
+    """positional comparison of two (.., 2) point arrays -> (n finite, worst distance)."""
+    got, want = np.asarray(got, np.float32), np.asarray(want, np.float32)
+    assert got.shape == want.shape, (what, got.shape, want.shape)
+    assert np.array_equal(np.isnan(got), np.isnan(want)), f"{what}: different NaN mask (a different set of detected nodes)"
+    d = np.linalg.norm(got - want, axis=-1)
+    ok = np.isfinite(d)
+    return int(ok.sum()), (float(d[ok].max()) if ok.any() else 0.0)
+
+
+def _single_instance_case(task, n_frames, batch, seed):
+    from sleap_amd import config_models as C
+    from sleap_amd.nn.inference import SingleInstancePredictor
+
+    t = C.TASKS[task]
+    frames, insts = C.render(task, n_frames, seed)
+    x = preprocess(frames, input_scale=t["input_scale"], pad_stride=t["unet"][2])
+    net, mc, wts = _net(task, x.shape[1], x.shape[2])
+    cms = KerasGraph(mc, wts)(x)[0]
+    want, want_vals = oinf.single_instance_peaks(cms, None, 0.2, "integral", 5, t["heads"][0][2], t["input_scale"])
+    # the oracle detects every node of the one animal, close to the rendered truth (the comparison is about real peaks)
+    assert not np.isnan(want).any() and float(want_vals.min()) > 0.4
+    truth = np.stack([a[0] for a in insts])
+    assert float(np.linalg.norm(want[:, 0] - truth, axis=-1).mean()) < 2.0
+    pred = SingleInstancePredictor(confmap_config=C.training_config(task), confmap_model=net, batch_size=batch, verbosity="none")
+    outs = pred.predict(frames, make_labels=False)
+    assert len(outs) == -(-n_frames // batch)
+    got = np.concatenate([o["instance_peaks"] for o in outs])
+    got_vals = np.concatenate([o["instance_peak_vals"] for o in outs])
+    n, worst = _compare(got, want, task)
+    print(f"{task}: {n} peaks, max delta {worst:.4f} px, max |peak value delta| {np.abs(got_vals - want_vals).max():.5f}")
+    assert n == n_frames * len(C.skeleton(task).nodes)
+    assert worst <= TOL_PX and worst <= 0.1, worst  # measured ~0.01 px: the tolerance with a wide margin
+    assert float(np.abs(got_vals - want_vals).max()) <= 5e-3
+
+
+def test_configs0_single_instance_unet_256_5_nodes():
+    """configs[0] read as SURVEY.md 8(d) reads it: the centroid-profile UNet (f16 r2 s16 -> 2, input_scaling 0.5) on 256 x 256
+    frames, 5 nodes, through SingleInstanceInferenceLayer (global peak per node, integral refinement, un-scaling + 0.5)."""
+    _single_instance_case("c0_single5", 16, 4, seed=300)
+
+
+def test_configs1_single_instance_unet_512_13_nodes_batch_32():
+    """configs[1]: baseline_medium_rf.single (UNet f16 r2 s16 -> 2) on 512 x 512 frames, 13-node fly, ONE batch of 32."""
+    _single_instance_case("c1_single13", 32, 32, seed=301)
+
+
+def _topdown_oracle(frames, crop_size):
+    from sleap_amd import config_models as C
+
+    x = preprocess(frames, input_scale=0.5, pad_stride=16)
+    mc, w = C.load_task_weights("c2_centroid", x.shape[1], x.shape[2])
+    cms = KerasGraph(mc, w)(x)[0]
+    cc = oinf.centroid_crop(frames, cms, None, 0.2, "integral", 5, 2, 0.5, crop_size)
+    mc2, w2 = C.load_task_weights("c2_centered", crop_size, crop_size)
+    cm2 = KerasGraph(mc2, w2)(preprocess(cc["crops"]))[0]
+    pk, vals = oinf.find_instance_peaks(cm2, None, cc["crop_offsets"], 0.2, "integral", 5, 4, 1.0)
+    return cc, pk, vals
+
+
+def test_configs0_centroid_model_through_centroid_crop_256():
+    """configs[0]'s other reading ("centroid model"): the centroid UNet (input x0.5) through CentroidCrop / find_local_peaks on
+    256 x 256 frames with one animal: same centroids (count, order, <= 0.5 px) and the same crops up to the resampling of a
+    sub-0.01-px centroid difference."""
+    from sleap_amd import config_models as C
+    from sleap_amd.nn.inference import CentroidCrop
+
+    frames, insts = C.render("c0_single5", 8, seed=302, skeleton=C.skeleton("c2_centroid"))  # a whole 13-node fly per 256 x 256 frame
+    x = preprocess(frames, input_scale=0.5, pad_stride=16)
+    net, mc, w = _net("c2_centroid", x.shape[1], x.shape[2])
+    cms = KerasGraph(mc, w)(x)[0]
+    want = oinf.centroid_crop(frames, cms, None, 0.2, "integral", 5, 2, 0.5, 160)
+    assert np.bincount(want["crop_sample_inds"], minlength=8).tolist() == [1] * 8
+    layer = CentroidCrop(net, crop_size=160, input_scale=0.5, pad_to_stride=16, output_stride=2, peak_threshold=0.2,
+                         refinement="integral", integral_patch_size=5)
+    got = layer(frames)
+    g = {k: (v.cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)) for k, v in got.items()}
+    assert g["crop_sample_inds"].tolist() == want["crop_sample_inds"].tolist()
+    n, worst = _compare(g["centroids"], want["centroids"], "centroids")
+    print(f"configs[0] centroid path: {n} centroids, max delta {worst:.4f} px")
+    assert worst <= TOL_PX and worst <= 0.1
+    assert float(np.abs(g["centroid_vals"] - want["centroid_vals"]).max()) <= 5e-3
+    assert g["crops"].shape == want["crops"].shape and g["crops"].dtype == np.uint8
+    # uint8 crops resampled at centroids that differ by < 0.1 px: grey levels within a few counts, most of them identical
+    diff = np.abs(g["crops"].astype(np.int16) - want["crops"].astype(np.int16))
+    assert diff.max() <= 24 and float((diff <= 1).mean()) > 0.9, (diff.max(), float((diff <= 1).mean()))
+
+
+def test_configs2_topdown_1024_two_animals_oracle_runs_its_own_networks():
+    """configs[2]: centroid UNet (baseline.centroid, x0.5) + centered-instance UNet (baseline_medium_rf.topdown, f24) on
+    160 x 160 crops, 1024 x 1024 frames with 2 animals. The ORACLE runs both of its own networks (centroids from its fp32
+    centroid maps, crops at its own centroids, peaks from its fp32 crop maps) -- nothing of the device path enters it."""
+    from sleap_amd import config_models as C
+    from sleap_amd.nn.engine import DeviceNetwork
+    from sleap_amd.nn.inference import TopDownPredictor
+
+    n_frames, crop = 8, C.TASKS["c2_centered"]["crop"]
+    frames, insts = C.render("c2_centroid", n_frames, seed=303)
+    cc, want, want_vals = _topdown_oracle(frames, crop)
+    counts = np.bincount(cc["crop_sample_inds"], minlength=n_frames)
+    assert counts.tolist() == [2] * n_frames, counts  # the oracle finds both animals in every frame ...
+    assert not np.isnan(want).any() and float(want_vals.min()) > 0.3  # ... and all 13 nodes of each
+    truth = np.concatenate(insts)
+    j = np.linalg.norm(cc["centroids"][:, None] - truth[None, :, C.ANCHOR], axis=-1).argmin(axis=1)
+    assert float(np.linalg.norm(want - truth[j], axis=-1).mean()) < 2.0
+    mc_c, w_c = C.load_task_weights("c2_centroid", 512, 512)
+    mc_i, w_i = C.load_task_weights("c2_centered", crop, crop)
+    pred = TopDownPredictor(centroid_config=C.training_config("c2_centroid"), centroid_model=DeviceNetwork(mc_c, w_c),
+                            confmap_config=C.training_config("c2_centered"), confmap_model=DeviceNetwork(mc_i, w_i),
+                            batch_size=4, verbosity="none")
+    outs = pred.predict(frames, make_labels=False)
+    nv = np.concatenate([o["n_valid"] for o in outs])
+    assert nv.tolist() == counts.tolist()
+    got = np.concatenate([o["instance_peaks"][:, :2] for o in outs]).reshape(-1, 13, 2)
+    got_vals = np.concatenate([o["instance_peak_vals"][:, :2] for o in outs]).reshape(-1, 13)
+    got_c = np.concatenate([o["centroids"][:, :2] for o in outs]).reshape(-1, 2)
+    n, worst = _compare(got, want, "instance peaks")
+    _, worst_c = _compare(got_c, cc["centroids"], "centroids")
+    print(f"configs[2]: {n} peaks, max delta {worst:.4f} px; centroids max delta {worst_c:.4f} px; "
+          f"max |peak value delta| {np.abs(got_vals - want_vals).max():.5f}")
+    assert n == n_frames * 2 * 13
+    assert worst <= TOL_PX and worst_c <= TOL_PX and worst <= 0.15, (worst, worst_c)
+
+
+@pytest.fixture(scope="module")
+def resnet_workload():
+    from sleap_amd import config_models as C
+
+    task, n_frames = "c4_resnet", 3
+    sk = C.skeleton(task)
+    frames, insts = C.render(task, n_frames, seed=304)
+    mc, w = C.load_task_weights(task, 1024, 1024)
+    cms, pafs = KerasGraph(mc, w)(preprocess(frames))[:2]
+    pts, vals, si, ci = opf.find_local_peaks(cms, 0.2, "integral", 5)
+    pts = pts * np.float32(4)
+    sc = opg.PAFScorer(sk.nodes, sk.edges, 8, oob="zero")
+    B = n_frames
+    ref = sc.predict(pafs, [pts[si == b] for b in range(B)], [vals[si == b] for b in range(B)], [ci[si == b] for b in range(B)])
+    return dict(task=task, frames=frames, insts=insts, mc=mc, w=w, ref=ref, cms=cms, pafs=pafs,
+                n_peaks=[int((si == b).sum()) for b in range(B)])
+
+
+def test_configs4_oracle_detects_the_eight_animals(resnet_workload):
+    """The workload is what configs[4] names for the ORACLE: 8 animals per 1024 x 1024 frame, (nearly) all 24 nodes each."""
+    ref, insts = resnet_workload["ref"], resnet_workload["insts"]
+    for b, inst in enumerate(ref[0]):
+        inst = np.asarray(inst).reshape(-1, 24, 2)
+        big = (~np.isnan(inst[..., 0])).sum(axis=1) >= 20
+        assert int(big.sum()) == 8, (b, (~np.isnan(inst[..., 0])).sum(axis=1))
+        for gt in insts[b]:
+            d = np.nanmean(np.linalg.norm(inst - gt[None], axis=-1), axis=1)
+            assert float(np.nanmin(d)) < 3.0
+    assert all(n >= 8 * 22 for n in resnet_workload["n_peaks"]), resnet_workload["n_peaks"]
+
+
+def test_configs4_resnet50_bottomup_every_peak_within_half_a_pixel(resnet_workload):
+    """configs[4]: ResNet-50 (imagenet preprocessing Lambdas folded into the stem) + transposed-conv UpsamplingStack with
+    concatenated skips + PAF head, 24 nodes / 23 edges, 8 animals, fp16 storage -- the fitted network's BatchNormalization keeps
+    its activations in fp16's range, which the engine's first-batch range scan confirms (it raises otherwise)."""
+    from sleap_amd import config_models as C
+    from sleap_amd.nn.engine import DeviceNetwork
+    from sleap_amd.nn.inference import BottomUpPredictor
+
+    wl = resnet_workload
+    net = DeviceNetwork(wl["mc"], wl["w"], dtype="fp16")
+    pred = BottomUpPredictor(bottomup_config=C.training_config(wl["task"]), bottomup_model=net, batch_size=len(wl["frames"]),
+                             verbosity="none")
+    outs = pred.predict(wl["frames"], make_labels=False)
+    ref = wl["ref"]
+    got_n = np.concatenate([o["n_valid"] for o in outs])
+    assert got_n.tolist() == [len(x) for x in ref[0]]
+    n_pk, worst, worst_val, worst_score, f = 0, 0.0, 0.0, 0.0, 0
+    for o in outs:
+        for b in range(len(o["n_valid"])):
+            want = np.asarray(ref[0][f]).reshape(-1, 24, 2)
+            n, w_ = _compare(o["instance_peaks"][b, : len(want)], want, f"frame {f}")
+            n_pk, worst = n_pk + n, max(worst, w_)
+            worst_val = max(worst_val, float(np.nanmax(np.abs(o["instance_peak_vals"][b, : len(want)] - np.asarray(ref[1][f])))))
+            worst_score = max(worst_score, float(np.abs(o["instance_scores"][b, : len(want)] - np.asarray(ref[2][f])).max()))
+            f += 1
+    print(f"configs[4]: {n_pk} peaks, max delta {worst:.4f} px, max |peak value delta| {worst_val:.5f}, "
+          f"max |instance score delta| {worst_score:.5f}")
+    assert n_pk >= len(wl["frames"]) * 8 * 22
+    assert worst <= TOL_PX, worst
+
+
+def test_configs4_network_maps_vs_fp32_oracle(resnet_workload):
+    from sleap_amd.nn.engine import DeviceNetwork
+
+    wl = resnet_workload
+    net = DeviceNetwork(wl["mc"], wl["w"], dtype="fp16")
+    outs = net.forward(torch.from_numpy(wl["frames"][:2]).cuda())
+    for o, r in zip(outs, (wl["cms"][:2], wl["pafs"][:2])):
+        o = o.cpu().numpy()
+        assert np.isfinite(o).all()
+        assert float(np.abs(o - r).max()) <= 1e-2 * float(np.abs(r).max())

@@ -38,37 +38,7 @@ sys.path.insert(0, ROOT)
 from sleap_amd.nn import architectures as A  # noqa: E402  (plain data, no GPU)
 from sleap_amd import synth  # noqa: E402
 
-OUT_DIR = os.path.join(ROOT, "sleap_amd", "data")
-
-TASKS = {
-    "c0_single5": dict(kind="single", skeleton="FLIES5", frame=256, n_animals=1, input_scale=0.5, crop=None, render_margin=96.0,
-                       unet=(16, 2.0, 16, 2), heads=[("SingleInstanceConfmapsHead", 5, 2)], steps=1200, batch=16, pool=512),
-    "c1_single13": dict(kind="single", skeleton="FLIES13", frame=512, n_animals=1, input_scale=1.0, crop=256, render_margin=128.0,
-                        unet=(16, 2.0, 16, 2), heads=[("SingleInstanceConfmapsHead", 13, 2)], steps=1500, batch=8, pool=256),
-    "c2_centroid": dict(kind="centroid", skeleton="FLIES13", frame=1024, n_animals=2, input_scale=0.5, crop=256, render_margin=128.0,
-                        unet=(16, 2.0, 16, 2), heads=[("CentroidConfmapsHead", 1, 2)], steps=1000, batch=8, pool=96),
-    "c2_centered": dict(kind="centered", skeleton="FLIES13", frame=1024, n_animals=2, input_scale=1.0, crop=160, render_margin=128.0,
-                        unet=(24, 2.0, 16, 4), heads=[("CenteredInstanceConfmapsHead", 13, 4)], steps=1500, batch=12, pool=96),
-    "c4_resnet": dict(kind="multi", skeleton="MOUSE24", frame=1024, n_animals=8, input_scale=1.0, crop=256, render_margin=128.0,
-                      body=(60.0, 90.0), min_sep=200.0,
-                      resnet=dict(version="ResNet50", features_output_stride=32, pretrained=True,
-                                  upsampling=dict(output_stride=4, method="transposed_conv", skip_connections="concatenate",
-                                                  filters=64, refine_convs=2)),
-                      heads=[("MultiInstanceConfmapsHead", 24, 4), ("PartAffinityFieldsHead", 46, 8)],
-                      freeze=r"^conv[45]_", steps=2000, batch=8, pool=64),
-}
-ANCHOR = 1  # centroid = the thorax node of the fly (instance_centroids.py: anchor part)
-
-
-def task_graph(task, height, width):
-    """-> (model_config, weight shapes) of a task's network at the given input size (after input scaling)."""
-    t = TASKS[task] if isinstance(task, str) else task
-    if "unet" in t:
-        f, r, ms, os_ = t["unet"]
-        return A.build_unet_model_config((height, width, 1), f, r, ms, os_, True, True, None, heads=t["heads"])
-    r = t["resnet"]
-    return A.build_resnet_model_config((height, width, 1), r["version"], r["features_output_stride"], r["pretrained"],
-                                       upsampling=r["upsampling"], heads=t["heads"])
+from sleap_amd.config_models import ANCHOR, DATA_DIR as OUT_DIR, TASKS, load_task_weights, task_graph  # noqa: E402
 
 
 class TorchGraph(torch.nn.Module):
@@ -253,24 +223,6 @@ def make_targets(t, skel, insts, crop):
         pts[b, :, :len(al)] = al.transpose(1, 0, 2)
     return [cm_targets(pts, crop, crop, t["heads"][0][2]),
             paf_targets([al for al, _ in insts], skel.edge_idx, crop, crop, t["heads"][1][2])]
-
-
-def load_task_weights(task, height, width, path=None, seed=0):
-    """-> (model_config, weights dict float32) of a fitted task network at the given input size."""
-    mc, shapes = task_graph(task, height, width)
-    path = path or os.path.join(OUT_DIR, f"config_{task}.npz")
-    z = np.load(path)
-    stored = {k: z[k] for k in z.files if not k.startswith("__")}
-    if "__frozen_checksum__" in z.files:
-        w = A.he_normal_weights(shapes, seed=seed)
-        frozen = [k for k in sorted(w) if k not in stored]
-        chk = float(sum(np.abs(w[k].astype(np.float64)).sum() for k in frozen))
-        assert abs(chk - float(z["__frozen_checksum__"])) <= 1e-6 * abs(chk), "seeded frozen weights do not reproduce"
-        w.update(stored)
-    else:
-        w = stored
-    assert set(w) == set(shapes) and all(tuple(w[k].shape) == tuple(shapes[k]) for k in shapes)
-    return mc, {k: np.asarray(v, np.float32) for k, v in w.items()}
 
 
 def fit(task, steps=None, threads=0, seed=0, lr=2e-3, resume=False):
