@@ -80,7 +80,8 @@ DEFAULT_DTYPE = None  # set (temporarily) by load_model(dtype=...); otherwise _l
 class DeviceNetwork:
     def __init__(self, model_config: dict, weights: Dict[str, np.ndarray], device=None, fuse_upsample: Optional[bool] = None,
                  fuse_heads: bool = True, fuse_stem: bool = True, use_stem16: bool = True, mfma_convt: bool = True,
-                 mfma_stem: bool = True, fuse_pairs: bool = True, dtype: Optional[str] = None, layout: Optional[str] = None):
+                 mfma_stem: bool = True, fuse_pairs: bool = True, dtype: Optional[str] = None, layout: Optional[str] = None,
+                 range_safe: Optional[bool] = None):
         """`fuse_upsample=True` folds UpSampling2D(bilinear) into the consuming conv: on 16-channel planes the DMA kernel copies
         the half-resolution tile and expands it in LDS (the upsampled tensor never exists in HBM); on NHWC tensors the
         register-staged first-generation kernel does it on load (slower than materialising the tensor for the DMA kernel).
@@ -93,6 +94,12 @@ class DeviceNetwork:
         self._h = _lib.lib(self.dtype)
         self._tdtype = torch.float16 if self.dtype == "fp16" else torch.bfloat16
         self._range_checked = False
+        # fp16 storage only: a network whose activations leave fp16's range on the first batch of an input shape is
+        # re-compiled with per-tensor power-of-two scales folded into its weights (nn/range_scaling.py) instead of raising;
+        # SA_RANGE_SAFE=0 / range_safe=False restore the FloatingPointError. `range_log2_scale`: None = unscaled.
+        self.range_safe = (os.environ.get("SA_RANGE_SAFE", "1") != "0") if range_safe is None else bool(range_safe)
+        self.range_log2_scale = None
+        self.model_config = model_config
         # layout of the 16-bit activation tensors: None = 16-channel planes when every launch of the compiled plan supports
         # them (the UNet family), NHWC otherwise; "nhwc" / "planes16" force one (SA_LAYOUT in the environment likewise)
         self._layout_request = layout or os.environ.get("SA_LAYOUT") or None
@@ -562,6 +569,7 @@ class DeviceNetwork:
             self.outputs.append(o)
         if self.fuse_pairs:
             self.plan = self._fuse_pairs(self.plan)
+        self._tensor_of = t
         self.n_buf = n_buf[0]
         self.layout = self._pick_layout()
         # reduce fractions for stride bookkeeping
@@ -977,8 +985,8 @@ class DeviceNetwork:
             ws = self._workspace
             check(h.sa_network_forward(self._handle(), _ptr(imgs), 1 if imgs.dtype == torch.uint8 else 0, B, H, W, Cin, arr,
                                        _ptr(ws), ws.numel(), st), "sa_network_forward")
-            if self.dtype == "fp16" and not self._range_checked:
-                self._check_fp16_range(bufs)
+            if self.dtype == "fp16" and not self._range_checked and self._range_gate(bufs, imgs):
+                return self.forward(imgs, profile, slot)
             return outs
 
         def hw(tt):
@@ -1142,12 +1150,75 @@ class DeviceNetwork:
                 raise AssertionError(kind)
             if profile is not None:
                 ev1.record()
-        if self.dtype == "fp16" and not self._range_checked and profile is None:
-            self._check_fp16_range(bufs)
+        if self.dtype == "fp16" and not self._range_checked and profile is None and self._range_gate(bufs, imgs):
+            return self.forward(imgs, profile, slot)
         from ..ops import from_bf16
         return [bufs[o.buf] if o.kind == "f32out" else from_bf16(bufs[o.buf], o.c) for o in self.outputs]
 
-    def _check_fp16_range(self, bufs):
+    # ------------------------------------------------------------------ range-safe fp16 (nn/range_scaling.py)
+    def layer_aliases(self) -> List[List[str]]:
+        """Layer names whose outputs live in ONE stored tensor of this plan (a conv with its fused epilogue layers)."""
+        groups: Dict[int, List[str]] = {}
+        for name, v in self._tensor_of.items():
+            if v.kind in ("real", "f32out"):
+                groups.setdefault(id(v), []).append(name)
+        return [g for g in groups.values() if len(g) > 1]
+
+    def layer_ranges(self, imgs: torch.Tensor) -> Dict[str, float]:
+        """max |activation| of every layer whose output this plan stores in HBM, on the given batch (one forward + one
+        reduction per stored tensor; calibration, not a hot path). Layers sharing a tensor (`layer_aliases`) report the same
+        value; outputs that only ever live in LDS / registers (fused stem, fused encoder block) are absent."""
+        self.forward(imgs)
+        bufs = next(iter(self._buffers.values()))
+        out, seen = {}, {}
+        for name, v in self._tensor_of.items():
+            if v.kind not in ("real", "f32out") or v.buf is None or v.buf not in bufs:
+                continue
+            if v.buf not in seen:
+                lo, hi = torch.aminmax(bufs[v.buf].float())
+                seen[v.buf] = max(abs(float(lo)), abs(float(hi)))
+            out[name] = seen[v.buf]
+        return out
+
+    def _range_gate(self, bufs, imgs) -> bool:
+        """First batch of an input shape under fp16 storage: scan the stored tensors. -> True when the plan was re-compiled
+        with range scales (the caller runs the batch again), False when the network fits; raises FloatingPointError when it
+        does not fit and scaling is off, was already applied, or cannot help (a model input / output out of range)."""
+        try:
+            worst = self._check_fp16_range(bufs, warn=not self.range_safe or self.range_log2_scale is not None)
+            if worst <= 65504.0 / 4 or not self.range_safe or self.range_log2_scale is not None:
+                return False
+        except FloatingPointError:
+            if not self.range_safe or self.range_log2_scale is not None:
+                raise
+        self._apply_range_scaling(imgs)
+        return True
+
+    def _apply_range_scaling(self, imgs):
+        from . import range_scaling as RS
+
+        base = self.weights
+        # ranges come from a bf16-storage twin (fp32's range) with every layer output stored (no LDS-only intermediates)
+        twin = DeviceNetwork(self.model_config, base, device=self.device, fuse_heads=False, fuse_stem=False, fuse_pairs=False,
+                             fuse_upsample=False, mfma_convt=self.mfma_convt, mfma_stem=self.mfma_stem, dtype="bf16")
+        n = min(int(imgs.shape[0]), 8)
+        ranges = twin.layer_ranges(imgs[:n].contiguous())
+        ks = RS.plan_scales(self.model_config, ranges, twin.layer_aliases())
+        del twin
+        if not any(ks.values()):
+            raise FloatingPointError(
+                "activations left the range of fp16 storage (65504) in a tensor that cannot be rescaled (a model input or "
+                "output): load the model with dtype='bf16' (or SLEAP_AMD_DTYPE=bf16), which has fp32's range")
+        self.weights = RS.fold_scales(self.model_config, base, ks)
+        self.range_log2_scale = ks
+        net, self._net = getattr(self, "_net", None), None
+        if net:
+            torch.cuda.synchronize(self.device)
+            self._h.sa_network_destroy(net)
+        self._buffers = {}
+        self._compile()
+
+    def _check_fp16_range(self, bufs, warn=True):
         """fp16 storage has a finite range. Once per input shape (after the first forward; one synchronisation) every stored
         activation tensor is scanned: inf / NaN -> FloatingPointError, more than a quarter of the range used -> a warning.
         Why here and not only at the outputs: ReLU is a v_max, which returns the non-NaN operand, so the NaNs that an
@@ -1169,11 +1240,12 @@ class DeviceNetwork:
                     f"activations left the range of fp16 storage (65504) in plan tensor {i}: load the model with dtype='bf16' "
                     "(or SLEAP_AMD_DTYPE=bf16), which has fp32's range")
             worst = max(worst, m)
-        if worst > 65504.0 / 4:
+        if worst > 65504.0 / 4 and warn:
             import warnings
 
             warnings.warn(f"fp16 storage: the largest activation of the first batch is {worst:.0f}, within 4x of the format's "
                           "range (65504); consider dtype='bf16' for this model")
+        return worst
 
     def conv_flops(self, H, W):
         """2*H*W*Cin*Cout*k*k over all convs for ONE frame (logical channels)."""

@@ -1,0 +1,97 @@
+"""Host logic of the range-safe fp16 mode (sleap_amd/nn/range_scaling.py), checked on the CPU against the fp32 oracle graph:
+the folded weights compute 2^k(layer) x the original layer outputs, the heads come out unchanged, and the planned exponents
+bring every scaled tensor under the limit."""
+import numpy as np
+import pytest
+
+from oracle.keras_graph import KerasGraph, ensure_float
+from sleap_amd.nn import architectures as A
+from sleap_amd.nn import range_scaling as R
+
+
+def _ranges(all_t):
+    return {k: float(np.abs(v).max()) for k, v in all_t.items()}
+
+
+def _check(mc, w, x, expect_scaled, aliases=None, trigger=R.TRIGGER, limit=R.LIMIT):
+    outs, all_t = KerasGraph(mc, w)(x, return_all=True)
+    rng = _ranges(all_t)
+    ks = R.plan_scales(mc, rng, aliases, limit=limit, trigger=trigger)
+    assert (max(abs(k) for k in ks.values()) > 0) == expect_scaled
+    w2 = R.fold_scales(mc, w, ks)
+    assert set(w2) == set(w)
+    outs2, all2 = KerasGraph(mc, w2)(x, return_all=True)
+    for a, b in zip(outs, outs2):
+        assert float(np.abs(a - b).max()) <= 2e-5 * float(np.abs(a).max())
+    worst = 0.0
+    cats = {l["name"] for l in mc["config"]["layers"] if l["class_name"] == "Concatenate"}
+    for name, k in ks.items():
+        if name not in all_t or name in cats:  # (a Concatenate output carries one scale per segment)
+            continue
+        ref = all_t[name] * np.float32(2.0 ** k)
+        assert float(np.abs(all2[name] - ref).max()) <= 2e-5 * max(float(np.abs(ref).max()), 1e-30), name
+        if k:
+            worst = max(worst, float(np.abs(all2[name]).max()))
+            assert rng[name] * 2.0 ** k <= limit * 1.0001
+    return ks, rng, worst
+
+
+def test_plain_he_resnet50_is_brought_into_range():
+    """Plain He-normal ResNet-50 + transposed-conv upsampling stack with concatenated skips (configs[4]'s architecture,
+    BatchNormalization at its initial statistics): activations pass fp16's 65504 at depth; the folded network keeps every
+    scaled tensor under the limit and the heads bit-comparable."""
+    mc, shapes = A.build_resnet_model_config((96, 96, 1), "ResNet50", 32, True,
+                                             upsampling=dict(output_stride=4, method="transposed_conv",
+                                                             skip_connections="concatenate"),
+                                             heads=[("MultiInstanceConfmapsHead", 5, 4), ("PartAffinityFieldsHead", 8, 8)])
+    w = A.he_normal_weights(shapes, seed=3)
+    x = ensure_float(np.random.default_rng(0).integers(0, 256, (1, 96, 96, 1), dtype=np.uint8))
+    ks, rng, worst = _check(mc, w, x, expect_scaled=True)
+    assert max(rng.values()) > 65504.0  # the reason the mode exists
+    assert worst <= R.LIMIT * 1.0001
+    # model inputs and outputs keep scale 1
+    cfg = mc["config"]
+    for n in [cfg["input_layers"][0][0]] + [o[0] for o in cfg["output_layers"]]:
+        assert ks[n] == 0
+
+
+def test_network_inside_the_range_is_left_alone():
+    mc, shapes = A.build_unet_model_config((64, 64, 1), 8, 2.0, 16, 2, True, True, None,
+                                           heads=[("SingleInstanceConfmapsHead", 3, 2)])
+    w = A.he_normal_weights(shapes, seed=1)
+    x = ensure_float(np.random.default_rng(1).integers(0, 256, (1, 64, 64, 1), dtype=np.uint8))
+    outs, all_t = KerasGraph(mc, w)(x, return_all=True)
+    ks = R.plan_scales(mc, _ranges(all_t))
+    assert set(ks.values()) == {0}
+    w2 = R.fold_scales(mc, w, ks)
+    assert all(np.array_equal(w[k], w2[k]) for k in w)
+
+
+def test_unet_concatenate_segments_with_different_scales():
+    """A UNet whose decoder concatenates a skip and an upsampled tensor that got DIFFERENT exponents (low trigger): the
+    consuming conv scales its kernel rows per segment."""
+    mc, shapes = A.build_unet_model_config((64, 64, 1), 8, 2.0, 16, 2, True, True, None,
+                                           heads=[("SingleInstanceConfmapsHead", 3, 2)])
+    w = A.he_normal_weights(shapes, seed=2)
+    for k in w:  # inflate the activations with depth
+        if k.endswith("/kernel") and "head" not in k.lower():
+            w[k] = w[k] * np.float32(2.5)
+    x = ensure_float(np.random.default_rng(2).integers(0, 256, (1, 64, 64, 1), dtype=np.uint8))
+    ks, rng, _ = _check(mc, w, x, expect_scaled=True, trigger=4.0, limit=1.0)
+    cats = [l for l in mc["config"]["layers"] if l["class_name"] == "Concatenate"]
+    assert cats and any(len({ks[n[0]] for n in l["inbound_nodes"][0]}) > 1 for l in cats)
+
+
+def test_hourglass_add_operands_share_a_scale():
+    mc, shapes = A.build_hourglass_model_config((64, 64, 1), stem_stride=4, max_stride=32, output_stride=4, stem_filters=16, filters=16,
+                                                filter_increase=8, stacks=1,
+                                                heads=[("SingleInstanceConfmapsHead", 3, 4)])
+    w = A.he_normal_weights(shapes, seed=4)
+    for k in w:
+        if k.endswith("/kernel"):
+            w[k] = w[k] * np.float32(1.6)
+    x = ensure_float(np.random.default_rng(3).integers(0, 256, (1, 64, 64, 1), dtype=np.uint8))
+    ks, _, _ = _check(mc, w, x, expect_scaled=True, trigger=8.0, limit=2.0)
+    for l in mc["config"]["layers"]:
+        if l["class_name"] == "Add":
+            assert len({ks[n[0]] for n in l["inbound_nodes"][0]} | {ks[l["name"]]}) == 1
