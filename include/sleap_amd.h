@@ -358,6 +358,16 @@ int sa_conv1x1_bf16(const void* src, int CinP, const void* w, const float* bias,
                     int stride, const float* post_scale, const float* post_shift, const void* residual, int relu_last,
                     void* dst, sa_stream_t stream);
 
+/* Conv2D(k x k, stride 1, padding "same") [+ BatchNormalization] [+ residual] [+ ReLU] on a feature tensor, k up to 9: the
+ * 7 x 7 convolutions of the UNet stem blocks (unet.py:105-127: SimpleConvBlock with kernel_size = stem_kernel_size;
+ * encoder_decoder.py:113-121). The k*k taps run through the tap GEMM of sa_conv1x1_bf16 (tap t = ky*k + kx at offset
+ * (ky, kx) - (k-1)/2, TF SAME), zero fill outside the image by the hardware.
+ *   src [B,H,W,CinP] bf16; w from sa_pack_tapconv_weights(n_taps = k*k) of keras_kernel.reshape(k*k, Cin, Cout);
+ *   dst / residual [B,H,W,CoutP] bf16 */
+int sa_convk_bf16(const void* src, int CinP, const void* w, int ksize, const float* bias, int CoutP, int relu, int B, int H, int W,
+                  const float* post_scale, const float* post_shift, const void* residual, int relu_last, void* dst,
+                  sa_stream_t stream);
+
 /* Conv2DTranspose(k4 | k3, stride 2, padding "same") [+ BatchNormalization] [+ ReLU] on the matrix cores
  * (upsampling.py:177-191; encoder_decoder.py:304-310): one GEMM launch per output phase (oy & 1, ox & 1).
  *   w_phase[4]: per phase a*2+b the packed weights (sa_pack_tapconv_weights) of the kernel taps listed by

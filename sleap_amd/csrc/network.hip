@@ -250,9 +250,15 @@ int sa_network_forward(const sa_network_t* net, const void* images, int images_a
                                   lay, stream);
         break;
       case K_CONV1X1:  // [s0, w, bias, relu, stride, has_ext, ps, pt, res_buf, relu_last, o_buf]
-        rc = sa_conv1x1_bf16(bp(a[0]), bc(a[0]), P<void>(a[1]), P<float>(a[2]), bc(a[10]), (int)a[3], B, bh(a[0]), bw(a[0]),
-                             (int)a[4], a[5] ? P<float>(a[6]) : nullptr, a[5] ? P<float>(a[7]) : nullptr, bp(a[8]),
+        // (stride word: bits 0-7 the stride of a 1x1 conv, bits 8+ the window size k of a stride-1 "same" k x k conv)
+        if ((a[4] >> 8) > 1)
+          rc = sa_convk_bf16(bp(a[0]), bc(a[0]), P<void>(a[1]), (int)(a[4] >> 8), P<float>(a[2]), bc(a[10]), (int)a[3], B, bh(a[0]),
+                             bw(a[0]), a[5] ? P<float>(a[6]) : nullptr, a[5] ? P<float>(a[7]) : nullptr, bp(a[8]),
                              a[5] ? (int)a[9] : 0, bp(a[10]), stream);
+        else
+          rc = sa_conv1x1_bf16(bp(a[0]), bc(a[0]), P<void>(a[1]), P<float>(a[2]), bc(a[10]), (int)a[3], B, bh(a[0]), bw(a[0]),
+                               (int)(a[4] & 255), a[5] ? P<float>(a[6]) : nullptr, a[5] ? P<float>(a[7]) : nullptr, bp(a[8]),
+                               a[5] ? (int)a[9] : 0, bp(a[10]), stream);
         break;
       case K_CONVT2: {  // [s, w0, w1, w2, w3, ksz, bias, relu, has_ext, ps, pt, relu_last, o_buf]
         const void* wp[4] = {P<void>(a[1]), P<void>(a[2]), P<void>(a[3]), P<void>(a[4])};

@@ -28,6 +28,7 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
 constexpr int MAX_TAPS = 16;
+constexpr int MAX_WINDOW_TAPS = 81;  // sa_convk_bf16: up to 9 x 9 windows (their offsets are computed, not listed)
 constexpr int CK = 64;  // channels per chunk
 
 struct TapParams {
@@ -45,6 +46,9 @@ struct TapParams {
   int in_stride, out_stride, oy0, ox0;
   int n_taps;
   int tap_dy[MAX_TAPS], tap_dx[MAX_TAPS];
+  // ksize > 0: the taps are the ksize x ksize window of a stride-1 "same" Conv2D, tap t = (ky, kx) = (t / ksize, t % ksize) at
+  // offset (ky - kpad, kx - kpad) with kpad = (ksize - 1) / 2 (TF SAME: pad_before = pad_total / 2); the lists are ignored
+  int ksize, kpad;
   int relu, relu_last;
   int m_tiles, co_tiles;
   // n_phases > 1: the output phases of a stride-2 transposed conv as ONE grid (phase = fastest block index): per phase its
@@ -132,7 +136,15 @@ tapconv_kernel(const TapParams p) {
 
   auto issue = [&](int chunk, int buf) {
     const int tap = chunk / chunks_per_tap, kc = chunk - tap * chunks_per_tap;
-    const int dy = multi ? p.ph_dy[ph][tap] : p.tap_dy[tap], dx = multi ? p.ph_dx[ph][tap] : p.tap_dx[tap];
+    int dy, dx;
+    if (p.ksize > 0) {
+      const int ky = tap / p.ksize;
+      dy = ky - p.kpad;
+      dx = tap - ky * p.ksize - p.kpad;
+    } else {
+      dy = multi ? p.ph_dy[ph][tap] : p.tap_dy[tap];
+      dx = multi ? p.ph_dx[ph][tap] : p.tap_dx[tap];
+    }
     unsigned char* stage = smem + buf * STAGE;
 #pragma unroll
     for (int j = 0; j < IN_PER_WAVE; ++j) {
@@ -314,7 +326,7 @@ size_t sa_tapconv_packed_elems(int n_taps, int CinP, int CoutP) {
 }
 
 int sa_pack_tapconv_weights(const float* w, int n_taps, int Cin, int CinP, int Cout, int CoutP, uint16_t* packed) {
-  SA_REQUIRE(w && packed && n_taps > 0 && n_taps <= MAX_TAPS, "sa_pack_tapconv_weights: bad arguments");
+  SA_REQUIRE(w && packed && n_taps > 0 && n_taps <= MAX_WINDOW_TAPS, "sa_pack_tapconv_weights: bad arguments");
   SA_REQUIRE(CinP % 16 == 0 && CoutP % 16 == 0 && Cin <= CinP && Cout <= CoutP, "sa_pack_tapconv_weights: bad channel padding");
   const int K16 = CinP / 16, co32_n = (CoutP + 31) / 32;
   for (int c32 = 0; c32 < co32_n; ++c32)
@@ -345,6 +357,24 @@ int sa_conv1x1_bf16(const void* src, int CinP, const void* w, const float* bias,
   p.in_stride = stride;
   p.out_stride = 1;
   p.n_taps = 1;
+  return launch_tap_pick(p, (hipStream_t)stream);
+}
+
+int sa_convk_bf16(const void* src, int CinP, const void* w, int ksize, const float* bias, int CoutP, int relu, int B, int H, int W,
+                  const float* post_scale, const float* post_shift, const void* residual, int relu_last, void* dst,
+                  sa_stream_t stream) {
+  TapParams p = {};
+  const int rc = fill_common(p, src, CinP, w, bias, CoutP, relu, B, post_scale, post_shift, residual, relu_last, dst);
+  if (rc != SA_OK) return rc;
+  SA_REQUIRE(H > 0 && W > 0 && ksize >= 1 && ksize * ksize <= MAX_WINDOW_TAPS, "sa_convk_bf16: bad shape / kernel size");
+  SA_REQUIRE((size_t)H * W * CinP * 2 < 0x7fffffffull, "sa_convk_bf16: one frame of the source must stay below 2 GiB");
+  p.Hs = p.Hl = p.Ho = H;
+  p.Ws = p.Wl = p.Wo = W;
+  p.in_stride = 1;
+  p.out_stride = 1;
+  p.n_taps = ksize * ksize;
+  p.ksize = ksize;
+  p.kpad = (ksize - 1) / 2;
   return launch_tap_pick(p, (hipStream_t)stream);
 }
 

@@ -45,16 +45,35 @@ def _relu(g, x, name):
 def build_unet_model_config(input_shape: Tuple[int, int, int], filters: int = 16, filters_rate: float = 2.0,
                             max_stride: int = 32, output_stride: int = 4, middle_block: bool = True,
                             up_interpolate: bool = True, stem_stride: Optional[int] = None,
-                            heads: Sequence[Tuple[str, int, int]] = ()) -> Tuple[dict, Dict[str, tuple]]:
+                            heads: Sequence[Tuple[str, int, int]] = (), stacks: int = 1, stem_kernel_size: int = 7,
+                            stem_blocks: Optional[int] = None, down_blocks: Optional[int] = None,
+                            up_blocks: Optional[int] = None) -> Tuple[dict, Dict[str, tuple]]:
     """`heads` = [(head_class_name, channels, output_stride), ...] in model-output order.
+
+    `stem_stride` / `max_stride` / `output_stride` / `stacks` are UNetConfig's fields (UNet.from_config, unet.py:250-278:
+    stem_blocks = log2(stem_stride), down_blocks = log2(max_stride) - stem_blocks, up_blocks = log2(max_stride / output_stride),
+    stem_kernel_size 7); `stem_blocks` / `down_blocks` / `up_blocks` / `stem_kernel_size` override them for graphs built from
+    the UNet class directly (what tests/nn/architectures/test_unet.py does).
+
+    Stem (unet.py:105-127, encoder_decoder.py:484-505): `stem_blocks` SimpleConvBlocks of two k x k convs ("stem{i}_conv{j}",
+    pooling BEFORE the convs from the second block on) + a pooling-only block "stem{n}_last_pool"; built once, not repeated
+    per stack; its output is the FIRST skip source at its stride (make_decoder takes the first source with a matching stride,
+    encoder_decoder.py:589-593, so the same-stride output of encoder block 0 is not used as a skip).
 
     Returns (model_config, weight_shapes) where weight_shapes maps "<layer>/kernel|bias" to shapes.
     """
-    if stem_stride is not None:
-        raise NotImplementedError("UNet stem blocks (stem_stride) are not implemented")
     convs_per_block, kernel = 2, 3  # UNet.from_config fixes these (unet.py:266-278)
-    down_blocks = int(math.log2(max_stride))
-    up_blocks = int(math.log2(max_stride / output_stride))
+    if stem_blocks is None:
+        stem_blocks = 0 if stem_stride is None else int(math.log2(stem_stride))
+    if down_blocks is None:
+        down_blocks = int(math.log2(max_stride)) - stem_blocks
+    if up_blocks is None:
+        up_blocks = int(math.log2(max_stride / output_stride))
+    if stacks > 1 and down_blocks != up_blocks:  # encoder_decoder.py:632-639
+        raise ValueError("If using a stacked configuration, the backbone must define symmetric encoder and decoder. "
+                         "Create a stem for initial downsampling if an output stride > 1 is desired.")
+    if stacks > 1 and heads:
+        raise ValueError(f'The name "{heads[0][0]}" is used {stacks} times in the model. All layer names should be unique.')
     g = _G()
     shapes = {}
     x = g.add("InputLayer", "input", {"batch_input_shape": [None, input_shape[0], input_shape[1], input_shape[2]]}, [])
@@ -65,61 +84,90 @@ def build_unet_model_config(input_shape: Tuple[int, int, int], filters: int = 16
         shapes[f"{name}/bias"] = (int(f),)
         return _conv(g, x, name, f, k)
 
-    # ---- encoder (unet.py:136-205; SimpleConvBlock.make_block encoder_decoder.py:92-144)
-    prefix = "stack0_enc"
-    skips = {}  # stride -> (tensor name, channels)
+    def pool(x, name):
+        return g.add("MaxPooling2D", name, {"pool_size": [2, 2], "strides": [2, 2], "padding": "same"}, [x])
+
+    # ---- stem
     stride = 1
-    for block in range(down_blocks):
-        f = int(filters * (filters_rate ** block))
-        if block > 0:
-            x = g.add("MaxPooling2D", f"{prefix}{block}_pool", {"pool_size": [2, 2], "strides": [2, 2], "padding": "same"}, [x])
-            stride *= 2
-        for i in range(convs_per_block):
-            x = conv(x, f"{prefix}{block}_conv{i}", f, cur_c)
-            cur_c = f
-            x = _relu(g, x, f"{prefix}{block}_act{i}_relu")
-        skips[stride] = (x, cur_c)
-    x = g.add("MaxPooling2D", f"{prefix}{down_blocks}_last_pool", {"pool_size": [2, 2], "strides": [2, 2], "padding": "same"}, [x])
-    stride *= 2
-    bi = down_blocks + 1
-    if middle_block:
-        f = int(filters * (filters_rate ** down_blocks))
-        if convs_per_block > 1:
-            name = f"{prefix}{bi}_middle_expand"
+    stem_skip = None
+    if stem_blocks > 0:
+        for block in range(stem_blocks):
+            f = int(filters * (filters_rate ** block))
+            if block > 0:
+                x = pool(x, f"stem{block}_pool")
+                stride *= 2
+            for i in range(convs_per_block):
+                x = conv(x, f"stem{block}_conv{i}", f, cur_c, k=stem_kernel_size)
+                cur_c = f
+                x = _relu(g, x, f"stem{block}_act{i}_relu")
+        x = pool(x, f"stem{stem_blocks}_last_pool")
+        stride *= 2
+        stem_skip = (stride, x, cur_c)
+    stem_out_stride = stride
+    stack_outs = []
+    for st in range(stacks):
+        # ---- encoder (unet.py:136-205; SimpleConvBlock.make_block encoder_decoder.py:92-144)
+        prefix = f"stack{st}_enc"
+        stride = stem_out_stride
+        skips = {}  # stride -> (tensor name, channels); the FIRST source of a stride wins
+        if stem_skip is not None:
+            skips[stem_skip[0]] = (stem_skip[1], stem_skip[2])
+        enc_feats = []
+        for block in range(down_blocks):
+            f = int(filters * (filters_rate ** (block + stem_blocks)))
+            if block > 0:
+                x = pool(x, f"{prefix}{block}_pool")
+                stride *= 2
+            for i in range(convs_per_block):
+                x = conv(x, f"{prefix}{block}_conv{i}", f, cur_c)
+                cur_c = f
+                x = _relu(g, x, f"{prefix}{block}_act{i}_relu")
+            if stride not in [q[0] for q in enc_feats]:
+                enc_feats.append((stride, x, cur_c))
+        x = pool(x, f"{prefix}{down_blocks}_last_pool")
+        stride *= 2
+        for s_, t_, c_ in enc_feats:  # (make_encoder drops the LAST feature: the pooled / middle output is the decoder input)
+            skips.setdefault(s_, (t_, c_))
+        bi = down_blocks + 1
+        if middle_block:
+            f = int(filters * (filters_rate ** (down_blocks + stem_blocks)))
+            if convs_per_block > 1:
+                name = f"{prefix}{bi}_middle_expand"
+                x = conv(x, f"{name}_conv0", f, cur_c)
+                cur_c = f
+                x = _relu(g, x, f"{name}_act0_relu")
+                bi += 1
+            name = f"{prefix}{bi}_middle_contract"
             x = conv(x, f"{name}_conv0", f, cur_c)
             cur_c = f
             x = _relu(g, x, f"{name}_act0_relu")
-            bi += 1
-        name = f"{prefix}{bi}_middle_contract"
-        x = conv(x, f"{name}_conv0", f, cur_c)
-        cur_c = f
-        x = _relu(g, x, f"{name}_act0_relu")
-    # ---- decoder (unet.py:207-247; SimpleUpsamplingBlock.make_block encoder_decoder.py:275-399)
-    mids = {stride: (x, cur_c)}
-    for block in range(up_blocks):
-        f = int(filters * (filters_rate ** (down_blocks - 1 - block)))
-        nxt = stride // 2
-        name = f"stack0_dec{block}_s{stride}_to_s{nxt}"
-        if up_interpolate:
-            x = g.add("UpSampling2D", f"{name}_interp_bilinear", {"size": [2, 2], "interpolation": "bilinear"}, [x])
-        else:
-            shapes[f"{name}_trans_conv/kernel"] = (kernel, kernel, int(f), cur_c)
-            shapes[f"{name}_trans_conv/bias"] = (int(f),)
-            x = g.add("Conv2DTranspose", f"{name}_trans_conv",
-                      {"filters": int(f), "kernel_size": [3, 3], "strides": [2, 2], "padding": "same",
-                       "activation": "linear", "use_bias": True, "dilation_rate": [1, 1], "output_padding": None}, [x])
-            cur_c = f
-            x = _relu(g, x, f"{name}_trans_conv_act_relu")
-        if nxt in skips:
-            sk, sc = skips[nxt]
-            x = g.add("Concatenate", f"{name}_skip_concat", {"axis": -1}, [sk, x])
-            cur_c += sc
-        for i in range(convs_per_block):
-            x = conv(x, f"{name}_refine_conv{i}", f, cur_c)
-            cur_c = f
-            x = _relu(g, x, f"{name}_refine_conv{i}_act_relu")
-        stride = nxt
-        mids[stride] = (x, cur_c)
+        # ---- decoder (unet.py:207-247; SimpleUpsamplingBlock.make_block encoder_decoder.py:275-399)
+        mids = {stride: (x, cur_c)}
+        for block in range(up_blocks):
+            f = int(filters * (filters_rate ** (down_blocks + stem_blocks - 1 - block)))
+            nxt = stride // 2
+            name = f"stack{st}_dec{block}_s{stride}_to_s{nxt}"
+            if up_interpolate:
+                x = g.add("UpSampling2D", f"{name}_interp_bilinear", {"size": [2, 2], "interpolation": "bilinear"}, [x])
+            else:
+                shapes[f"{name}_trans_conv/kernel"] = (kernel, kernel, int(f), cur_c)
+                shapes[f"{name}_trans_conv/bias"] = (int(f),)
+                x = g.add("Conv2DTranspose", f"{name}_trans_conv",
+                          {"filters": int(f), "kernel_size": [3, 3], "strides": [2, 2], "padding": "same",
+                           "activation": "linear", "use_bias": True, "dilation_rate": [1, 1], "output_padding": None}, [x])
+                cur_c = f
+                x = _relu(g, x, f"{name}_trans_conv_act_relu")
+            if nxt in skips:
+                sk, sc = skips[nxt]
+                x = g.add("Concatenate", f"{name}_skip_concat", {"axis": -1}, [sk, x])
+                cur_c += sc
+            for i in range(convs_per_block):
+                x = conv(x, f"{name}_refine_conv{i}", f, cur_c)
+                cur_c = f
+                x = _relu(g, x, f"{name}_refine_conv{i}_act_relu")
+            stride = nxt
+            mids[stride] = (x, cur_c)
+        stack_outs.append(x)
     # ---- heads (model.py:336-359): main output if strides match, else the decoder feature of that stride
     outs = []
     for head_name, channels, hs in heads:
@@ -129,6 +177,8 @@ def build_unet_model_config(input_shape: Tuple[int, int, int], filters: int = 16
         shapes[f"{head_name}/kernel"] = (1, 1, sc, int(channels))
         shapes[f"{head_name}/bias"] = (int(channels),)
         outs.append(_conv(g, src, head_name, channels, k=1))
+    if not heads:  # a backbone graph (what the architecture tests build): the stack outputs
+        outs = stack_outs if stacks > 1 else stack_outs[:1]
     cfg = {"class_name": "Functional",
            "config": {"name": "model", "layers": g.layers, "input_layers": [["input", 0, 0]],
                       "output_layers": [[o, 0, 0] for o in outs]}}

@@ -71,7 +71,11 @@ def _slot(i):
 
 for _i, _f in enumerate(ConvOp.FIELDS):
     setattr(ConvOp, _f, _slot(_i))
-ConvOp.stride = ConvOp.mode  # the same slot, read as what it means for a 1x1 conv
+# the same slot read as what it means for a "conv1x1" op: bits 0-7 the stride of a 1x1 conv, bits 8+ the window size k of a
+# stride-1 "same" k x k conv run through the same tap GEMM (sa_convk_bf16: the 7x7 convs of the UNet stem blocks)
+ConvOp.stride_word = ConvOp.mode
+ConvOp.stride = property(lambda self: self[3] & 255)
+ConvOp.ksize = property(lambda self: max(self[3] >> 8, 1))
 
 
 DEFAULT_DTYPE = None  # set (temporarily) by load_model(dtype=...); otherwise _lib.DEFAULT_DTYPE (SLEAP_AMD_DTYPE or "fp16")
@@ -263,7 +267,9 @@ class DeviceNetwork:
                     raise NotImplementedError(f"Conv2D {name}: padding='valid' is only implemented for 1x1 kernels")
                 if strides[0] != strides[1] or strides[0] not in (1, 2):
                     raise NotImplementedError(f"Conv2D {name}: stride {strides}")
-                if not on_image and not (k == (3, 3) and strides == (1, 1)) and k != (1, 1):
+                window = not on_image and k not in ((1, 1), (3, 3)) and k[0] == k[1] and k[0] <= 9 and strides == (1, 1) \
+                    and c["padding"] == "same"  # k x k on a feature tensor (UNet stem blocks, unet.py:105-127): tap GEMM
+                if not on_image and not (k == (3, 3) and strides == (1, 1)) and k != (1, 1) and not window:
                     raise NotImplementedError(f"Conv2D {name}: kernel {k} stride {strides} is only implemented on the input image")
                 kern = np.asarray(self.weights[f"{name}/kernel"], np.float32)
                 cin, cout = kern.shape[2], kern.shape[3]
@@ -343,18 +349,21 @@ class DeviceNetwork:
                               "has_mean": int(img.preproc)}
                     plan.append(["imgconv", o, upload_f32(np.ascontiguousarray(w)), upload_f32(b_np), src_c, relu, name, k, st,
                                  ps, pt, cin, in_affine, pads, mf])
-                elif k == (1, 1):
-                    # Conv2D(k1, stride 1|2) on the matrix cores (ResNet bottleneck convs, skip projections)
+                elif k == (1, 1) or window:
+                    # Conv2D(k1, stride 1|2) on the matrix cores (ResNet bottleneck convs, skip projections); Conv2D(k x k,
+                    # stride 1, same) through the same tap GEMM with k*k taps
                     s0 = materialize(x)
                     st = strides[0]
                     o = _T("real", cout, x.num, x.den * st, buf=new_buf(coutp, x.num, x.den * st, "bf16"))
                     h = self._h
-                    packed = np.zeros((h.sa_tapconv_packed_elems(1, s0.cp, coutp),), np.uint16)
-                    kc = np.ascontiguousarray(kern[0, 0])
-                    check(h.sa_pack_tapconv_weights(kc.ctypes.data_as(C.c_void_p), 1, cin, s0.cp, cout, coutp,
+                    nt = k[0] * k[1]
+                    packed = np.zeros((h.sa_tapconv_packed_elems(nt, s0.cp, coutp),), np.uint16)
+                    kc = np.ascontiguousarray(kern.reshape(nt, cin, cout))
+                    check(h.sa_pack_tapconv_weights(kc.ctypes.data_as(C.c_void_p), nt, cin, s0.cp, cout, coutp,
                                                     packed.ctypes.data_as(C.c_void_p)), "sa_pack_tapconv_weights")
                     wdev = torch.from_numpy(packed.view(np.int16)).to(dev)
-                    plan.append(ConvOp(["conv1x1", s0, None, st, wdev, bias, o, relu, None, True, [], name, ext]))
+                    plan.append(ConvOp(["conv1x1", s0, None, st | ((k[0] << 8) if window else 0), wdev, bias, o, relu, None, True,
+                                        [], name, ext]))
                     conv_of[id(o)] = plan[-1]
                 elif x.kind == "input":
                     w = np.zeros((3, 3, cin, coutp), np.float32)
@@ -774,7 +783,7 @@ class DeviceNetwork:
                      1 if yb.need_full else 0, bid(yb.out_pool)]
             elif k == "conv1x1":
                 e = op.ext
-                a = [bid(op.src0), dp(op.w), dp(op.bias), op.relu, op.stride, 1 if e else 0, dp(e["ps"]) if e else 0,
+                a = [bid(op.src0), dp(op.w), dp(op.bias), op.relu, op.stride_word, 1 if e else 0, dp(e["ps"]) if e else 0,
                      dp(e["pt"]) if e else 0, bid(e["res"]) if e else -1, e["relu_last"] if e else 0, bid(op.out)]
             elif k == "convt2":
                 _, s_, phases, bias, o, relu, ksz, ext, _cin = op
@@ -927,8 +936,8 @@ class DeviceNetwork:
                 out.append(("conv", f"conv3x3 pair {s0.c}->{mid.c}->{o.c} @{hh}", f))
             elif k == "conv1x1":
                 s0, o = op.src0, op.out
-                f = 2 * (H * o.num // o.den) * (W * o.num // o.den) * s0.c * o.c
-                nm = f"conv1x1s{op.stride} {s0.c}->{o.c} @{H * o.num // o.den}"
+                f = 2 * (H * o.num // o.den) * (W * o.num // o.den) * s0.c * o.c * op.ksize ** 2
+                nm = f"conv{op.ksize}x{op.ksize}s{op.stride} {s0.c}->{o.c} @{H * o.num // o.den}"
                 if op.ext is not None:
                     nm += " +affine" + (" +res" if op.ext["res"] is not None else "")
                 out.append(("conv", nm, f))
@@ -1062,13 +1071,20 @@ class DeviceNetwork:
                                              _ptr(bufs[o_pool.buf]) if o_pool is not None else None, self.layout, st),
                       "sa_conv3x3_pair_bf16")
             elif kind == "conv1x1":
-                _, s0, _s1, stride, w, bias, o, relu, _op, _nf, _heads, _nm, ext = op
+                _, s0, _s1, _sw, w, bias, o, relu, _op, _nf, _heads, _nm, ext = op
                 sh, sw = hw(s0)
                 res = ext["res"] if ext else None
-                check(h.sa_conv1x1_bf16(_ptr(bufs[s0.buf]), s0.cp, _ptr(w), _ptr(bias), o.cp, relu, B, sh, sw, stride,
-                                        _ptr(ext["ps"]) if ext else None, _ptr(ext["pt"]) if ext else None,
-                                        _ptr(bufs[res.buf]) if res is not None else None, ext["relu_last"] if ext else 0,
-                                        _ptr(bufs[o.buf]), st), "sa_conv1x1_bf16")
+                stride = op.stride
+                if op.ksize > 1:
+                    check(h.sa_convk_bf16(_ptr(bufs[s0.buf]), s0.cp, _ptr(w), op.ksize, _ptr(bias), o.cp, relu, B, sh, sw,
+                                          _ptr(ext["ps"]) if ext else None, _ptr(ext["pt"]) if ext else None,
+                                          _ptr(bufs[res.buf]) if res is not None else None, ext["relu_last"] if ext else 0,
+                                          _ptr(bufs[o.buf]), st), "sa_convk_bf16")
+                else:
+                    check(h.sa_conv1x1_bf16(_ptr(bufs[s0.buf]), s0.cp, _ptr(w), _ptr(bias), o.cp, relu, B, sh, sw, stride,
+                                            _ptr(ext["ps"]) if ext else None, _ptr(ext["pt"]) if ext else None,
+                                            _ptr(bufs[res.buf]) if res is not None else None, ext["relu_last"] if ext else 0,
+                                            _ptr(bufs[o.buf]), st), "sa_conv1x1_bf16")
             elif kind == "convt2":
                 _, s, phases, bias, o, relu, ksz, ext, _cin = op
                 sh, sw = hw(s)
@@ -1265,7 +1281,7 @@ class DeviceNetwork:
                 total += 2 * (H * o.num // o.den) * (W * o.num // o.den) * (s0.c * mid.c + mid.c * o.c) * 9
             elif op[0] == "conv1x1":
                 s0, o = op.src0, op.out
-                total += 2 * (H * o.num // o.den) * (W * o.num // o.den) * s0.c * o.c
+                total += 2 * (H * o.num // o.den) * (W * o.num // o.den) * s0.c * o.c * op.ksize ** 2
             elif op[0] == "convt2":
                 s, o, ksz = op[1], op[4], op[6]
                 total += 2 * (H * s.num // s.den) * (W * s.num // s.den) * s.c * o.c * ksz * ksz

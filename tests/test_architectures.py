@@ -42,6 +42,46 @@ def test_builder_reproduces_bilinear_fixture_backbone():
     assert _sig(cfg) == ref_backbone
 
 
+def test_stacked_unet_with_stem_reference_counts():
+    """tests/nn/architectures/test_unet.py:159-196 (`test_stacked_unet_with_stem`): UNet(stem_blocks=2, stacks=3, filters=16,
+    filters_rate=2, kernel_size=3, down_blocks=3, up_blocks=3, up_interpolate=True) on a 160 x 160 x 1 input -> 122 layers,
+    92 trainable weights, 23 396 592 parameters, three stack outputs of 64 channels at stride 4 (:187-196)."""
+    cfg, shapes = build_unet_model_config((160, 160, 1), filters=16, filters_rate=2, middle_block=True, up_interpolate=True,
+                                          stacks=3, stem_blocks=2, down_blocks=3, up_blocks=3, stem_kernel_size=3)
+    assert len(cfg["config"]["layers"]) == 122
+    assert len(shapes) == 92
+    assert sum(int(np.prod(s)) for s in shapes.values()) == 23396592
+    assert len(cfg["config"]["output_layers"]) == 3
+    names = [l["name"] for l in cfg["config"]["layers"]]
+    # the stem is built once (not per stack), ends with a pooling-only block, and pools BEFORE the convs from block 1 on
+    assert [n for n in names if n.startswith("stem")] == [
+        "stem0_conv0", "stem0_act0_relu", "stem0_conv1", "stem0_act1_relu", "stem1_pool", "stem1_conv0", "stem1_act0_relu",
+        "stem1_conv1", "stem1_act1_relu", "stem2_last_pool"]
+    g = KerasGraph(cfg, he_normal_weights(shapes))
+    outs = g(np.zeros((1, 160, 160, 1), np.float32))
+    assert [o.shape for o in outs] == [(1, 40, 40, 64)] * 3  # stride 4 (the stem's), filters * rate^(stem_blocks + 0)
+    # the decoder block that returns to the stem's stride concatenates the STEM output, not encoder block 0's
+    # (make_decoder: the first skip source with a matching stride, encoder_decoder.py:589-593)
+    by = {l["name"]: l for l in cfg["config"]["layers"]}
+    cat = by["stack0_dec2_s8_to_s4_skip_concat"]
+    assert [n[0] for n in cat["inbound_nodes"][0]] == ["stem2_last_pool", "stack0_dec2_s8_to_s4_interp_bilinear"]
+    with pytest.raises(ValueError, match="symmetric"):
+        build_unet_model_config((160, 160, 1), stacks=2, stem_blocks=0, down_blocks=3, up_blocks=2)
+
+
+def test_unet_from_config_with_stem_stride():
+    """UNet.from_config (unet.py:250-278) with stem_stride=4, max_stride=32, output_stride=4: 2 stem blocks with 7 x 7 kernels,
+    3 down blocks whose filters continue the progression (filters * rate^(block + stem_blocks)), 3 up blocks."""
+    cfg, shapes = build_unet_model_config((128, 128, 1), filters=8, filters_rate=2, max_stride=32, output_stride=4,
+                                          stem_stride=4, heads=[("SingleInstanceConfmapsHead", 3, 4)])
+    assert shapes["stem0_conv0/kernel"] == (7, 7, 1, 8) and shapes["stem1_conv1/kernel"] == (7, 7, 16, 16)
+    assert shapes["stack0_enc0_conv0/kernel"] == (3, 3, 16, 32) and shapes["stack0_enc2_conv1/kernel"] == (3, 3, 128, 128)
+    assert shapes["stack0_enc4_middle_expand_conv0/kernel"] == (3, 3, 128, 256)
+    assert shapes["SingleInstanceConfmapsHead/kernel"] == (1, 1, 32, 3)
+    out = KerasGraph(cfg, he_normal_weights(shapes))(np.zeros((1, 128, 128, 1), np.float32))[0]
+    assert out.shape == (1, 32, 32, 3)
+
+
 def test_benchmark_model_params_and_flops():
     # baseline_medium_rf.bottomup + flies13: 7.82 M params, 99.56 GFLOP/frame (SURVEY.md §8d, BASELINE.md §2)
     cfg, shapes = build_unet_model_config((1024, 1024, 1), 16, 2, 32, 4, True, True,

@@ -358,6 +358,78 @@ def test_maxpool_general_vs_torch(k, stride, pad, pad_zero, H, W):
     assert torch.equal(out.float().cpu(), ref)
 
 
+@pytest.mark.parametrize("B,H,W,Cin,Cout,ksize,affine,relu", [
+    (2, 40, 56, 16, 16, 7, False, True),     # stem0_conv1 of a UNet stem (unet.py:105-127): k7, 16 -> 16
+    (1, 33, 47, 32, 32, 7, False, True),     # odd sizes: every border case of the hardware zero fill
+    (1, 24, 24, 24, 40, 5, True, True),      # channel padding on both sides, k5, BatchNormalization after the ReLU
+    (1, 20, 28, 64, 128, 9, False, False),   # the largest window, two 64-channel cout tiles, linear
+    (1, 18, 22, 16, 16, 4, False, True),     # even window: TF SAME pads (k - 1) // 2 before, k // 2 after
+])
+def test_convk_window_conv_vs_torch(B, H, W, Cin, Cout, ksize, affine, relu):
+    """Conv2D(k x k, stride 1, same) on a feature tensor through the tap GEMM (sa_convk_bf16) vs fp32 torch on the same
+    16-bit-rounded operands."""
+    from sleap_amd import _lib, ops
+    from sleap_amd._lib import check
+    from sleap_amd.ops import _ptr, _stream
+
+    g = torch.Generator(device="cpu").manual_seed(H + Cin + Cout + ksize)
+    k = torch.randn((ksize, ksize, Cin, Cout), generator=g) * (2.0 / (Cin * ksize * ksize)) ** 0.5
+    bias = 0.1 * torch.randn((Cout,), generator=g)
+    x = torch.randn((B, H, W, Cin), generator=g)
+    scale = 1.0 + 0.3 * torch.randn((Cout,), generator=g)
+    shift = 0.2 * torch.randn((Cout,), generator=g)
+    pb, pa = (ksize - 1) // 2, ksize // 2
+    xp = F.pad(_bf(x).permute(0, 3, 1, 2), (pb, pa, pb, pa))
+    y = F.conv2d(xp, _bf(k).permute(3, 2, 0, 1), bias).permute(0, 2, 3, 1)
+    if relu:
+        y = torch.relu(y)
+    if affine:
+        y = y * scale + shift
+    cinp, coutp = ops.pad16(Cin), ops.pad16(Cout)
+    dx = ops.to_bf16_padded(x.cuda().contiguous())
+    pw = _pack_taps(k.reshape(ksize * ksize, Cin, Cout), cinp, coutp)
+    bp = _padded(bias, coutp)
+    ps = _padded(scale, coutp, 1.0) if affine else None
+    pt = _padded(shift, coutp) if affine else None
+    out = torch.full((B, H, W, coutp), 7.0, dtype=TD, device="cuda")
+    check(_lib.lib().sa_convk_bf16(_ptr(dx), cinp, _ptr(pw), ksize, _ptr(bp), coutp, int(relu), B, H, W, _ptr(ps), _ptr(pt), None, 0,
+                                   _ptr(out), _stream()), "sa_convk_bf16")
+    got = ops.from_bf16(out, Cout).cpu()
+    lim = 1e-2 * float(y.abs().max())
+    assert float((got - y).abs().max()) <= lim, (float((got - y).abs().max()), lim)
+    if coutp > Cout:
+        assert float(out.float()[..., Cout:].abs().max()) == 0.0
+
+
+def test_unet_with_stem_blocks_vs_oracle():
+    """UNet.from_config with stem_stride=4 (unet.py:105-127, 250-278): two stem blocks of 7 x 7 convs (the first on the uint8
+    image on the matrix cores, the others through the tap GEMM), pooled stem output as encoder input AND as the skip source at
+    stride 4, bilinear decoder back to stride 4, a confidence-map head -- vs the fp32 oracle and the 16-bit-rounding oracle."""
+    from sleap_amd.nn.architectures import build_unet_model_config, he_normal_weights
+
+    cfg, shapes = build_unet_model_config((128, 160, 1), filters=8, filters_rate=2, max_stride=32, output_stride=4,
+                                          stem_stride=4, heads=[("MultiInstanceConfmapsHead", 5, 4)])
+    w = he_normal_weights(shapes, seed=5)
+    rng = np.random.default_rng(5)
+    net, res = _parity(cfg, w, rng.integers(0, 256, (2, 128, 160, 1), dtype=np.uint8), 3e-2, 2e-2)
+    kinds = [op[0] for op in net.plan]
+    assert kinds.count("imgconv") == 1 and sum(1 for op in net.plan if op[0] == "conv1x1" and op.ksize == 7) == 3, kinds
+    print("UNet with stem blocks:", res)
+
+
+def test_stacked_unet_with_stem_features_vs_oracle():
+    """The reference's own stacked-UNet-with-stem architecture test shape (tests/nn/architectures/test_unet.py:159-196) at a
+    smaller width: 2 stem blocks (k3 there), 2 stacks, both stack outputs."""
+    from sleap_amd.nn.architectures import build_unet_model_config, he_normal_weights
+
+    cfg, shapes = build_unet_model_config((96, 96, 1), filters=8, filters_rate=2, middle_block=True, up_interpolate=True,
+                                          stacks=2, stem_blocks=2, down_blocks=3, up_blocks=3, stem_kernel_size=3)
+    w = he_normal_weights(shapes, seed=6)
+    rng = np.random.default_rng(6)
+    net, _ = _parity(cfg, w, rng.integers(0, 256, (1, 96, 96, 1), dtype=np.uint8), 4e-2, 2e-2)
+    assert len(net.outputs) == 2
+
+
 # ------------------------------------------------------------------------------------------------
 # ResNet backbones + UpsamplingStack (SURVEY.md §8a row a2'')
 # ------------------------------------------------------------------------------------------------
