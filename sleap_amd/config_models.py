@@ -42,7 +42,7 @@ TASKS = {
                                   upsampling=dict(output_stride=4, method="transposed_conv", skip_connections="concatenate",
                                                   filters=64, refine_convs=2)),
                       heads=[("MultiInstanceConfmapsHead", 24, 4), ("PartAffinityFieldsHead", 46, 8)],
-                      freeze=r"^conv[45]_", steps=2000, batch=8, pool=64),
+                      freeze=r"^conv[45]_", steps=2000, batch=8, pool=64, loss_margin=0),
 }
 
 
@@ -84,6 +84,11 @@ def load_task_weights(task, height, width, path=None, seed=0):
     if "__frozen_checksum__" in z.files:
         w = A.he_normal_weights(shapes, seed=seed)
         frozen = [k for k in sorted(w) if k not in stored]
+        for k in frozen:  # the fit starts every BatchNormalization neutral (tools/train_config_models.py: gamma 1, beta 0)
+            if k.endswith("/gamma"):
+                w[k][:] = 1.0
+            elif k.endswith("/beta"):
+                w[k][:] = 0.0
         chk = float(sum(np.abs(w[k].astype(np.float64)).sum() for k in frozen))
         if abs(chk - float(z["__frozen_checksum__"])) > 1e-6 * abs(chk):
             raise RuntimeError("the seeded (not stored) weights of this model do not reproduce on this NumPy build")

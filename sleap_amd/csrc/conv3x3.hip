@@ -21,6 +21,12 @@
 #include "bf16.h"
 #include "sa_common.h"
 
+// UPS kernels: the tap of a chunk's nine after which the low-resolution tile of chunk c+2 is requested (a rendezvous of the
+// workgroup's waves precedes it; the copy must land before the next chunk's barrier)
+#if !defined(SA_UPS_LOW_TAP)
+#define SA_UPS_LOW_TAP 5
+#endif
+
 namespace {
 
 int g_grid_limit = 0;  // sa_conv3x3_set_grid_limit
@@ -309,11 +315,25 @@ conv3x3_dma_kernel(const ConvParams2 p) {
   constexpr int IN_PER_WAVE = (N_IN + NW - 1) / NW;
   constexpr int W_PER_WAVE = (N_W + NW - 1) / NW;
   constexpr unsigned OOB = 0xFFFFFF00u;
-  // UPS: the low-resolution tile under the halo tile, copied to the last N_LOW KiB of the stage's input area
-  constexpr int LH = TH / 2 + 2, LW = TW / 2 + 2, N_LOW = (LH * LW * 32 + 1023) / 1024, LOW_OFF = IN_BYTES - N_LOW * 1024;
-  static_assert(!UPS || (CK == 16 && NBUF == 2 && STEM_CIN == 0 && !EXT && !HEADS && N_LOW <= NW && LOW_OFF >= 0 && TH % 2 == 0),
+  // UPS: the low-resolution tile under the halo tile (LH x LW pixels of 32 bytes = 360 sixteen-byte pieces) has a buffer of its
+  // own, so that the tile of chunk c+1 can be expanded into the idle stage WHILE chunk c is being multiplied (round 3; the round-2
+  // form copied it into the stage it belonged to and expanded it in place between two extra barriers: ~2.6 k cycles per
+  // source chunk without an MFMA). Two workgroups per CU leave 80 KiB each = the two stages + 4 KiB, and the tile needs
+  // 5760 bytes: pieces 0..255 live in those 4 KiB (segment A, behind the stages), pieces 256..311 in the unused 896-byte tail
+  // of stage 0's input area (B) and pieces 312..359 in the tail of stage 1's (C).
+  constexpr int LH = TH / 2 + 2, LW = TW / 2 + 2, LOW_PIECES = LH * LW * 2;
+  constexpr int IN_USED = PH * PW * PIXB, IN_TAIL = IN_BYTES - IN_USED;
+  constexpr int LOW_A = NBUF * STAGE, LOW_NA = 256, LOW_NB = IN_TAIL / 16, LOW_NC = LOW_PIECES - LOW_NA - LOW_NB;
+  constexpr int LOW_B = IN_USED, LOW_C = STAGE + IN_USED;
+  static_assert(!UPS || (CK == 16 && NBUF == 2 && STEM_CIN == 0 && !EXT && !HEADS && TH % 2 == 0 && NW >= 6),
                 "UPS: 16-channel chunks, two stages, plain epilogue");
+  static_assert(!UPS || (LOW_NB > 0 && LOW_NB <= 64 && LOW_NC > 0 && LOW_NC <= LOW_NB), "UPS: the low tile's three segments");
   static_assert(!UPS || ((PH / 2) * (PW / 2) * 2 <= NW * 64 && PH % 2 == 0 && PW % 2 == 0), "UPS: one 2x2 block and half per thread");
+  // LDS byte address of piece q of the low-resolution tile
+  auto low_addr = [&](int q) -> int {
+    return q < LOW_NA ? LOW_A + q * 16 : (q < LOW_NA + LOW_NB ? LOW_B + (q - LOW_NA) * 16 : LOW_C + (q - LOW_NA - LOW_NB) * 16);
+  };
+  (void)low_addr;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -340,6 +360,14 @@ conv3x3_dma_kernel(const ConvParams2 p) {
     L_end = start + q + (xcd < r ? 1 : 0);
   }
   if (L >= L_end) return;  // wave-uniform
+#if defined(SA_UPS_STAGGER)
+  // UPS: the two workgroups of a CU start together, run the same code and stay in lockstep -- both expand (no MFMA) and then
+  // both compete for the matrix pipe. Delaying every second resident workgroup by about half an expansion puts the pair in
+  // anti-phase (one expands while the other multiplies), which is self-sustaining as well.
+  if constexpr (UPS) {
+    if (((blockIdx.x >> 3) >> 5) & 1) __builtin_amdgcn_s_sleep(SA_UPS_STAGGER);
+  }
+#endif
   struct Tile {
     int co32_0, x0, y0, b;
   };
@@ -375,15 +403,18 @@ conv3x3_dma_kernel(const ConvParams2 p) {
       const unsigned pix = (unsigned)(gy * W + gx);
       const unsigned q16 = (unsigned)((s ^ swz<CK>(pl)) * 16);
       v0[j] = ok ? pix * (unsigned)p.pix_bytes0 + q16 : OOB;
-      v1[j] = ok ? pix * (unsigned)p.pix_bytes1 + q16 : OOB;
+      v1[j] = UPS ? 0u : (ok ? pix * (unsigned)p.pix_bytes1 + q16 : OOB);  // (UPS: src1 never arrives at full resolution)
     }
   };
-  // UPS: byte offset of this lane's 16-byte piece of the low-resolution tile inside a src1 plane (wave w copies piece w)
+  // UPS: byte offset of this lane's 16-byte piece of the low-resolution tile inside a src1 plane. Waves 0-3 copy pieces
+  // 64 w + lane (segment A), wave 4 pieces 256 + lane (lane < LOW_NB: segment B), wave 5 pieces 256 + LOW_NB + lane (segment C).
   auto make_voff_low = [&](const Tile& t, int ln) -> unsigned {
-    const int i = wave * 64 + ln, lp = i >> 1, hf = i & 1;
+    const int q = wave < 4 ? wave * 64 + ln : (wave == 4 ? LOW_NA + ln : LOW_NA + LOW_NB + ln);
+    const bool mine = wave < 4 || (wave == 4 && ln < LOW_NB) || (wave == 5 && ln < LOW_NC);
+    const int lp = q >> 1, hf = q & 1;
     const int ly = lp / LW, lx = lp - ly * LW;
     const int gy = min(max((t.y0 >> 1) - 1 + ly, 0), (H >> 1) - 1), gx = min(max((t.x0 >> 1) - 1 + lx, 0), (W >> 1) - 1);
-    return (wave < N_LOW && lp < LH * LW) ? (unsigned)(gy * (W >> 1) + gx) * (unsigned)p.pix_bytes1 + (unsigned)hf * 16u : OOB;
+    return mine ? (unsigned)(gy * (W >> 1) + gx) * (unsigned)p.pix_bytes1 + (unsigned)hf * 16u : OOB;
   };
   unsigned voff0[IN_PER_WAVE], voff1[IN_PER_WAVE];
   make_voff(cur, lane, voff0, voff1);
@@ -406,18 +437,23 @@ conv3x3_dma_kernel(const ConvParams2 p) {
     const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(p.C1P ? reinterpret_cast<const unsigned char*>(p.src1) + t.b * f1 : reinterpret_cast<const unsigned char*>(p.w)), 0,
         (int)f1, 0x00020000);
-    if (UPS && from1) {  // wave-uniform: the low-resolution tile, one piece per wave
-      if (wave < N_LOW && lo <= 0)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, (lds_ptr_t)(stage + LOW_OFF + wave * 1024), 16, voff_low, cc2, 0, 0);
+    if (UPS && from1) {
+      // (wave-uniform) the input of this chunk is expanded from the low-resolution tile (issue_low / the chunk loop)
     } else {
 #pragma unroll
       for (int j = 0; j < IN_PER_WAVE; ++j) {
         const int i = j * NW + wave;
         if (STEM_CIN == 0 && i < N_IN && lo <= j && j < hi) {
-          if (from1)
+          if (!UPS && from1) {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, (lds_ptr_t)(stage + i * 1024), 16, v1[j], cc2, 0, 0);
-          else
+          } else if (UPS && IN_TAIL > 0 && i == N_IN - 1) {
+            // the tail of the input area belongs to the low-resolution tile: the last piece's lanes beyond the halo tile
+            // stay switched off (an out-of-range offset would write zeros there)
+            if (lane * 16 < IN_USED - (N_IN - 1) * 1024)
+              __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, (lds_ptr_t)(stage + i * 1024), 16, v0[j], cc2, 0, 0);
+          } else {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, (lds_ptr_t)(stage + i * 1024), 16, v0[j], cc2, 0, 0);
+          }
         }
       }
     }
@@ -462,6 +498,24 @@ conv3x3_dma_kernel(const ConvParams2 p) {
 
   const int n_chunks = CinP / CK;
   issue(cur, voff0, voff1, 0, 0);
+  // UPS: the low-resolution tile of source chunk `chunk` (>= C0P / CK) -> its own buffer, six wave-instructions
+  auto issue_low = [&](const Tile& t, int chunk) {
+    if constexpr (UPS) {
+      const int cc2 = (int)((unsigned)((chunk * CK - p.C0P) >> 4) * p.blk_bytes_in1);
+      const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(
+          (void*)(reinterpret_cast<const unsigned char*>(p.src1) + t.b * f1), 0, (int)f1, 0x00020000);
+      if (wave < 4) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, (lds_ptr_t)(smem + LOW_A + wave * 1024), 16, voff_low, cc2, 0, 0);
+      } else if (wave == 4) {
+        if (lane < LOW_NB) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, (lds_ptr_t)(smem + LOW_B), 16, voff_low, cc2, 0, 0);
+      } else if (wave == 5) {
+        if (lane < LOW_NC) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, (lds_ptr_t)(smem + LOW_C), 16, voff_low, cc2, 0, 0);
+      }
+    }
+  };
+  if constexpr (UPS) {
+    if (n_chunks > 1 && CK >= p.C0P) issue_low(cur, 1);  // chunk 1 is a source chunk already: expanded during chunk 0
+  }
   const int x0 = cur.x0, y0 = cur.y0, b = cur.b;  // the fused first layer (STEM_CIN > 0) is never persistent
   (void)x0, (void)y0, (void)b;
   if constexpr (STEM_CIN > 0) {
@@ -662,7 +716,7 @@ conv3x3_dma_kernel(const ConvParams2 p) {
       }
     };
     // inputs (HBM) after tap ISSUE_TAP, weights (L2) after tap W_TAP; -1 = right after the barrier
-    constexpr int ISSUE_TAP = (NBUF == 2 && !UPS) ? ITAP : -1;
+    constexpr int ISSUE_TAP = (NBUF == 2) ? ITAP : -1;
     // (the weights' copies at a tap of their own -- earlier or later than the inputs' -- measured within noise of this on
     // few- and many-chunk layers alike, gpurun_out/r02v)
     constexpr int W_TAP = ISSUE_TAP;
@@ -671,75 +725,115 @@ conv3x3_dma_kernel(const ConvParams2 p) {
     const unsigned char* in_tile = smem + buf * STAGE;
     const unsigned char* w_tile = in_tile + IN_BYTES;
     if constexpr (UPS) {
-      if (chunk * CK >= p.C0P) {  // wave-uniform: this chunk arrived as a low-resolution tile -- expand it in place
-        unsigned char* tile = smem + buf * STAGE;
-        int t_id = tid;
-        asm volatile("" : "+v"(t_id));  // (derived per chunk, not kept in registers across the MFMA loop)
-        constexpr int NBX = PW / 2, NBLK = (PH / 2) * NBX;  // 2x2 blocks of the halo tile: 9 rows of 17
-        const bool actv = t_id < NBLK * 2;
-        const int u = actv ? t_id : 0, hf = u & 1, blk = u >> 1;
-        const int rp = blk / NBX, cp = blk - rp * NBX;
+      // Source chunk c+1 is expanded NOW, from the low-resolution tile that landed before this chunk's barrier, into the idle
+      // stage -- no barrier of its own: a wave goes on to its MFMAs of chunk c as soon as its share is written, and the waves
+      // without a share (5-7) start at once, so the matrix pipe is never idle workgroup-wide. The expanded tile is read after
+      // the next chunk's barrier.
+#if !defined(SA_UPS_DBG_SKIP_EXPAND)
+      if (chunk + 1 < n_chunks && (chunk + 1) * CK >= p.C0P) {  // wave-uniform
+        unsigned char* tile = smem + (buf ^ 1) * STAGE;
         // halo-tile rows 2rp, 2rp+1 are image rows y0-1+2rp (odd: weight 0.25 on the lower source row) and y0+2rp (even: 0.75);
-        // both read low-resolution tile rows rp, rp+1; columns alike
-        const unsigned char* lo = tile + LOW_OFF + ((rp * LW + cp) * 2 + hf) * 16;
-        const h16x8_t tA = *reinterpret_cast<const h16x8_t*>(lo), tB = *reinterpret_cast<const h16x8_t*>(lo + 32);
-        const h16x8_t uA = *reinterpret_cast<const h16x8_t*>(lo + LW * 32), uB = *reinterpret_cast<const h16x8_t*>(lo + LW * 32 + 32);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();  // every read of the low-resolution tile is done: its bytes may be overwritten
-        asm volatile("" ::: "memory");
-        // four channels at a time, in order (scheduling barriers: interleaving all eight channels for ILP costs ~20 more live
-        // registers than this kernel has left next to its 64 accumulators), each quad stored as soon as it is complete
-        unsigned woff[2][2];
-        bool in_img[2][2];
+        // both read low-resolution tile rows rp, rp+1; columns alike. (Source addresses are re-derived per chunk: the kernel
+        // has no registers left to keep them.)
+        int la[4];          // LDS addresses of the four source pieces (this thread's half of the low-resolution pixels)
+        unsigned woff[4];   // (swizzled) offsets of the four pixels of the 2 x 2 block in the stage
+        unsigned keepbits = 0;
+        bool actv;
+        // tiles whose whole halo lies inside the image (all but the border ring) skip the padding masks (wave-uniform)
+        const bool interior = __builtin_amdgcn_readfirstlane((int)(cur.x0 >= 1 && cur.y0 >= 1 && cur.x0 + PW - 1 <= W && cur.y0 + PH - 1 <= H));
+        {
+          int t_id = tid;
+          asm volatile("" : "+v"(t_id));  // (derived per chunk, not kept in registers across the MFMA loop)
+          constexpr int NBX = PW / 2, NBLK = (PH / 2) * NBX;  // 2x2 blocks of the halo tile: 9 rows of 17
+          const int u = t_id < NBLK * 2 ? t_id : 0, hf = u & 1, blk = u >> 1;
+          const int rp = blk / NBX, cp = blk - rp * NBX;
+          const int q0 = (rp * LW + cp) * 2 + hf;
+          la[0] = low_addr(q0), la[1] = low_addr(q0 + 2), la[2] = low_addr(q0 + 2 * LW), la[3] = low_addr(q0 + 2 * LW + 2);
 #pragma unroll
-        for (int dy = 0; dy < 2; ++dy)
-#pragma unroll
-          for (int dx = 0; dx < 2; ++dx) {
-            const int ty = 2 * rp + dy, tx = 2 * cp + dx, pl = ty * PW + tx;
-            const int gy = cur.y0 - 1 + ty, gx = cur.x0 - 1 + tx;
-            in_img[dy][dx] = gy >= 0 && gy < H && gx >= 0 && gx < W;  // outside: the convolution's SAME padding
-            woff[dy][dx] = (unsigned)(pl * PIXB + ((hf ^ swz<CK>(pl)) * 16));
-          }
-#pragma unroll
-        for (int q4 = 0; q4 < 2; ++q4) {
-          uint2 o[2][2];
-#pragma unroll
-          for (int pr2 = 0; pr2 < 2; ++pr2) {
-            float r[2][2][2];
-#pragma unroll
-            for (int e = 0; e < 2; ++e) {
-              const int c = q4 * 4 + pr2 * 2 + e;
-              const float a = sa::h2f(tA[c]), b_ = sa::h2f(tB[c]), cc = sa::h2f(uA[c]), d = sa::h2f(uB[c]);
-              const float t25 = a + (b_ - a) * 0.25f, t75 = a + (b_ - a) * 0.75f;   // source row rp at the odd / even image column
-              const float u25 = cc + (d - cc) * 0.25f, u75 = cc + (d - cc) * 0.75f;  // source row rp+1
-              r[0][0][e] = t25 + (u25 - t25) * 0.25f;
-              r[0][1][e] = t75 + (u75 - t75) * 0.25f;
-              r[1][0][e] = t25 + (u25 - t25) * 0.75f;
-              r[1][1][e] = t75 + (u75 - t75) * 0.75f;
+          for (int k = 0; k < 4; ++k) {
+            const int ty = 2 * rp + (k >> 1), tx = 2 * cp + (k & 1), pl = ty * PW + tx;
+            woff[k] = (unsigned)(pl * PIXB + ((hf ^ swz<CK>(pl)) * 16));
+            if (!interior) {
+              const int gy = cur.y0 - 1 + ty, gx = cur.x0 - 1 + tx;
+              if (gy >= 0 && gy < H && gx >= 0 && gx < W) keepbits |= 1u << k;  // outside the image: the conv's SAME padding
             }
-#pragma unroll
-            for (int dy = 0; dy < 2; ++dy)
-#pragma unroll
-              for (int dx = 0; dx < 2; ++dx) {
-                const unsigned v = sa::f2h2(r[dy][dx][0], r[dy][dx][1]);
-                if (pr2 == 0)
-                  o[dy][dx].x = v;
-                else
-                  o[dy][dx].y = v;
-              }
-            __builtin_amdgcn_sched_barrier(0);
           }
+          actv = t_id < NBLK * 2;
+        }
+        // (memcpy, not __builtin_bit_cast: bit-casting an ELEMENT of an ext_vector to a half pair miscompiles with this
+        // hipcc -- every element reads element 0; found in the ISA, reproduced in a ten-line kernel)
+#if defined(SA_HALF_FP16) && !defined(SA_UPS_FP32)
+        // Packed fp16 interpolation (round 3): the four source pieces stay packed pairs, every lerp is a v_pk_add_f16 +
+        // v_pk_fma_f16 on two channels -- 12 packed operations per output dword quad instead of 8 conversions in, 24 fp32
+        // operations and 4 conversions out. The horizontal blend is rounded to fp16 before the vertical one (the stand-alone
+        // kernel rounds once, from fp32): values differ from the materialised tensor by <= 1.5 fp16 ulp, the size of the
+        // storage rounding itself.
+        typedef _Float16 hp2 __attribute__((ext_vector_type(2)));
+        const hp2 q25 = {(_Float16)0.25f, (_Float16)0.25f}, q75 = {(_Float16)0.75f, (_Float16)0.75f};
+        auto as_h2 = [](unsigned u) {
+          hp2 h;
+          __builtin_memcpy(&h, &u, 4);
+          return h;
+        };
+        auto as_u = [](hp2 h) {
+          unsigned u;
+          __builtin_memcpy(&u, &h, 4);
+          return u;
+        };
+        auto blend = [&](int dx, unsigned ua, unsigned ub, unsigned uc, unsigned ud, unsigned (&r)[2]) {
+          const hp2 a = as_h2(ua), b_ = as_h2(ub), cc = as_h2(uc), d = as_h2(ud);
+          const hp2 wx = dx ? q75 : q25;                             // odd / even image column
+          const hp2 t = a + (b_ - a) * wx, u_ = cc + (d - cc) * wx;  // source rows rp, rp + 1 at this column
+          const hp2 dv = u_ - t;
+          r[0] = as_u(t + dv * q25), r[1] = as_u(t + dv * q75);
+        };
+#else
+        // fp32 interpolation in the order of the stand-alone kernel, one rounding: bitwise the materialised tensor
+        auto blend = [&](int dx, unsigned ua, unsigned ub, unsigned uc, unsigned ud, unsigned (&r)[2]) {
+          float v[2][2];
+          const float wx = dx ? 0.75f : 0.25f;
 #pragma unroll
-          for (int dy = 0; dy < 2; ++dy)
+          for (int e = 0; e < 2; ++e) {
+            const float a = sa::h2f((uint16_t)(ua >> (16 * e))), b_ = sa::h2f((uint16_t)(ub >> (16 * e)));
+            const float cc = sa::h2f((uint16_t)(uc >> (16 * e))), d = sa::h2f((uint16_t)(ud >> (16 * e)));
+            const float t = a + (b_ - a) * wx, u_ = cc + (d - cc) * wx;
+            v[0][e] = t + (u_ - t) * 0.25f;
+            v[1][e] = t + (u_ - t) * 0.75f;
+          }
+          r[0] = sa::f2h2(v[0][0], v[0][1]), r[1] = sa::f2h2(v[1][0], v[1][1]);
+        };
+#endif
+        // Whole 16-byte pieces in and out: ds_read_b128 of the four source pieces (16 consecutive lanes read 256 contiguous
+        // bytes: conflict-free) and ONE ds_write_b128 per output pixel (the 8 lanes of a write group cover 4 blocks: 2-way on
+        // 32 banks). Measured on the way here (profiles/r03_ab_session.md): four-byte accesses (8-way conflicts on the writes)
+        // cost 0.27 ms per decoder layer even though no barrier surrounds the expansion any more -- the LDS, not the VALU or
+        // the barriers, is what the expansion competes with the MFMA loop for.
+        typedef __attribute__((ext_vector_type(4))) unsigned u32x4v;
+        const u32x4v xa = *reinterpret_cast<const u32x4v*>(smem + la[0]), xb = *reinterpret_cast<const u32x4v*>(smem + la[1]);
+        const u32x4v xc = *reinterpret_cast<const u32x4v*>(smem + la[2]), xd = *reinterpret_cast<const u32x4v*>(smem + la[3]);
 #pragma unroll
-            for (int dx = 0; dx < 2; ++dx)
-              if (actv) *reinterpret_cast<uint2*>(tile + woff[dy][dx] + q4 * 8) = in_img[dy][dx] ? o[dy][dx] : make_uint2(0u, 0u);
+        for (int dx = 0; dx < 2; ++dx) {  // the two output columns in turn: they share nothing but the sources
+          u32x4v top, bot;                // output rows 2rp (dy = 0) and 2rp + 1 (dy = 1) at this column
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            unsigned r[2];
+            blend(dx, xa[i], xb[i], xc[i], xd[i], r);
+            top[i] = r[0];
+            bot[i] = r[1];
+          }
+          if (!interior) {  // (wave-uniform) border tiles: pixels outside the image are the convolution's SAME padding
+            const unsigned m0 = (unsigned)(((int)(keepbits << (31 - dx))) >> 31), m1 = (unsigned)(((int)(keepbits << (29 - dx))) >> 31);
+            top &= m0;
+            bot &= m1;
+          }
+          if (actv) {
+            *reinterpret_cast<u32x4v*>(tile + woff[dx]) = top;
+            *reinterpret_cast<u32x4v*>(tile + woff[2 + dx]) = bot;
+          }
           __builtin_amdgcn_sched_barrier(0);
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
       }
+#endif
     }
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
@@ -763,6 +857,20 @@ conv3x3_dma_kernel(const ConvParams2 p) {
           __builtin_amdgcn_sched_barrier(0);
           if (tap == ISSUE_TAP) prefetch(0, W_TAP == ISSUE_TAP ? 99 : IN_PER_WAVE);
           if (tap == W_TAP && W_TAP != ISSUE_TAP) prefetch(IN_PER_WAVE, 99);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      if constexpr (UPS) {
+        // the low-resolution tile of chunk c+2 may replace the one expanded at the top of this chunk once EVERY wave has read
+        // its share: a rendezvous in the middle of the MFMA sequence (no memory wait attached), then six copies
+        if (tap == SA_UPS_LOW_TAP && chunk + 2 < n_chunks && (chunk + 2) * CK >= p.C0P) {  // wave-uniform
+          __builtin_amdgcn_sched_barrier(0);
+#if !defined(SA_UPS_DBG_NO_MIDBAR)
+          if ((chunk + 1) * CK >= p.C0P) __builtin_amdgcn_s_barrier();
+#endif
+#if !defined(SA_UPS_DBG_NO_LOWDMA)
+          issue_low(cur, chunk + 2);
+#endif
           __builtin_amdgcn_sched_barrier(0);
         }
       }
@@ -1000,7 +1108,8 @@ int launch2(const ConvParams2& p, hipStream_t st) {
   constexpr int TH = NW * R;
   constexpr int N_IN = ((TH + 2) * 34 * CK * 2 + 1023) / 1024;
   constexpr size_t lds = NBUF * ((size_t)N_IN * 1024 + (size_t)MT * (CK / 16) * 9 * 1024) +
-                         (STEM_CIN ? ((size_t)(TH + 4) * 36 * STEM_CIN + (size_t)(9 * STEM_CIN + 1) * CK) * 4 : 0);
+                         (STEM_CIN ? ((size_t)(TH + 4) * 36 * STEM_CIN + (size_t)(9 * STEM_CIN + 1) * CK) * 4 : 0) +
+                         (UPS ? 4096 : 0);  // segment A of the low-resolution tile
   ConvParams2 q = p;
   q.tiles_x = (p.W + 31) / 32;
   q.tiles_y = (p.H + TH - 1) / TH;
@@ -1255,8 +1364,8 @@ static int conv3x3_impl(const void* src0, int C0P, const void* src1, int C1P, in
     if (ups) {
       SA_REQUIRE(n_heads == 0 && !post_scale && !residual && !relu_last,
                  "sa_conv3x3: fused heads / the extended epilogue are not available with the upsampling source mode");
-      if (co32_n >= 2 && !few) return launch2<2, 16, 8, 2, 2, false, 0, false, true>(q, st);
-      return launch2<1, 16, 8, 2, 2, false, 0, false, true>(q, st);
+      if (co32_n >= 2 && !few) return launch2<2, 16, 8, 2, 2, false, 0, false, true, SA_CONV_ITAP>(q, st);
+      return launch2<1, 16, 8, 2, 2, false, 0, false, true, SA_CONV_ITAP>(q, st);
     }
     if (co32_n >= 2 && !few) return ck32 ? launch2_pick<2, 32>(q, st) : launch2_pick<2, 16>(q, st);
     return ck32 ? launch2_pick<1, 32>(q, st) : launch2_pick<1, 16>(q, st);

@@ -86,10 +86,15 @@ class DeviceNetwork:
                  fuse_heads: bool = True, fuse_stem: bool = True, use_stem16: bool = True, mfma_convt: bool = True,
                  mfma_stem: bool = True, fuse_pairs: bool = True, dtype: Optional[str] = None, layout: Optional[str] = None,
                  range_safe: Optional[bool] = None):
-        """`fuse_upsample=True` folds UpSampling2D(bilinear) into the consuming conv: on 16-channel planes the DMA kernel copies
-        the half-resolution tile and expands it in LDS (the upsampled tensor never exists in HBM); on NHWC tensors the
-        register-staged first-generation kernel does it on load (slower than materialising the tensor for the DMA kernel).
-        None = SA_FUSE_UPSAMPLE from the environment (default 0), and only when the plan ends up on planes."""
+        """`fuse_upsample`: UpSampling2D(bilinear) folded into the consuming conv. On 16-channel planes the DMA kernel copies the
+        half-resolution tile of source chunk c+1 and expands it in LDS into the idle stage while chunk c is multiplied (the
+        upsampled tensor never exists in HBM); on NHWC tensors the register-staged first-generation kernel does it on load
+        (slower than materialising the tensor for the DMA kernel). True = every such conv, False = none, None / "auto" = the
+        environment's SA_FUSE_UPSAMPLE ("1" / "0") or, by default, PER LAYER: only where the expansion is cheaper than the
+        upsampling launch it replaces. Measured (round 3, profiles/r03_ab_session.md): the expansion costs ~0.11 ms per layer
+        of the benchmark decoder whatever its shape (its work grows with tiles x source chunks x output-channel tiles), the
+        stand-alone upsampling 0.06 / 0.12 / 0.24 ms at 64^2 / 128^2 / 256^2 -- so it pays for convs with <= 64 output
+        channels (the full-resolution end of the decoder) and only with fp16 storage on planes (packed-fp16 interpolation)."""
         require_cuda()
         # 16-bit storage type of activations and conv weights: "fp16" (default; 11-bit mantissa: heads within 0.1-0.5 % of an
         # fp32 network, finite range 65504) or "bf16" (fp32 range, 8-bit mantissa: 1-4 %). SLEAP_AMD_DTYPE sets the default.
@@ -107,8 +112,11 @@ class DeviceNetwork:
         # layout of the 16-bit activation tensors: None = 16-channel planes when every launch of the compiled plan supports
         # them (the UNet family), NHWC otherwise; "nhwc" / "planes16" force one (SA_LAYOUT in the environment likewise)
         self._layout_request = layout or os.environ.get("SA_LAYOUT") or None
-        auto_up = fuse_upsample is None
-        self.fuse_upsample = (os.environ.get("SA_FUSE_UPSAMPLE", "0") == "1") if auto_up else bool(fuse_upsample)
+        auto_up = fuse_upsample is None or fuse_upsample == "auto"
+        env_up = os.environ.get("SA_FUSE_UPSAMPLE", "auto")
+        # True / False = all / none; "auto" = per layer (self._fuse_up)
+        self.fuse_upsample = ({"1": True, "0": False}.get(env_up, "auto")) if auto_up else bool(fuse_upsample)
+        self.fuse_upsample_max_cout = int(os.environ.get("SA_FUSE_UPSAMPLE_MAX_COUT", "64"))
         self.fuse_heads = fuse_heads
         self.fuse_stem = fuse_stem
         self.use_stem16 = use_stem16
@@ -127,12 +135,19 @@ class DeviceNetwork:
             if l["class_name"] == "InputLayer":
                 self.in_channels = l["config"]["batch_input_shape"][-1]
         self._compile()
-        if auto_up and self.fuse_upsample and not self.planar:  # (only the plane kernels gain from it)
+        if auto_up and self.fuse_upsample and not self.planar and any(
+                op[0] == "conv" and op.mode == _lib.SRC1_UPSAMPLE2X for op in self.plan):  # (only the plane kernels gain from it)
             self.fuse_upsample = False
             self._compile()
         self._buffers = {}
 
     # ------------------------------------------------------------------ compile
+    def _fuse_up(self, cout: int) -> bool:
+        """Does the conv with `cout` output channels read its bilinear-upsampled source at half resolution (see __init__)?"""
+        if self.fuse_upsample == "auto":
+            return self.dtype == "fp16" and self._layout_request != "nhwc" and _pad16(cout) <= self.fuse_upsample_max_cout
+        return bool(self.fuse_upsample)
+
     def _consumers(self):
         cons = {}
         for l in self.layers:
@@ -377,7 +392,7 @@ class DeviceNetwork:
                             raise NotImplementedError("Concatenate with != 2 inputs")
                         s0 = materialize(x.parts[0])
                         p1 = x.parts[1]
-                        if p1.kind == "up" and p1.interp == "bilinear" and self.fuse_upsample:
+                        if p1.kind == "up" and p1.interp == "bilinear" and self._fuse_up(cout):
                             s1, mode = materialize(p1.src), _lib.SRC1_UPSAMPLE2X
                         else:
                             s1, mode = materialize(p1), _lib.SRC1_DIRECT

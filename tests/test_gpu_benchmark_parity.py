@@ -167,11 +167,14 @@ def test_configs3_float32_master_weights_oracle_unrounded_device_rounds(workload
     assert n_pk == n * 52 and worst <= TOL_PX and worst <= 0.1, worst
 
 
-HARD = dict(noise=7.0, contrast=0.75, min_sep=100.0)  # the model was fitted at noise 4, contrast 1, min_sep 170
+# the model was fitted at noise 4, contrast 1, min_sep 170. "hard": ~4 borderline maxima per frame; "very hard": the network is
+# far outside what it was fitted to and reports ~200 maxima per frame, ~90 of them within 0.05 of the threshold
+HARD = {"hard": (8, dict(noise=7.0, contrast=0.75, min_sep=100.0)), "very_hard": (4, dict(noise=8.0, contrast=0.6, min_sep=110.0))}
 MAP_EPS = 5e-3  # what fp16 storage moves a confidence-map value by (test_configs3_network_maps_vs_fp32_oracle: 4e-3 of ~1)
 
 
-def test_configs3_hard_frames_differences_are_threshold_decisions(workload):
+@pytest.mark.parametrize("variant", list(HARD))
+def test_configs3_hard_frames_differences_are_threshold_decisions(workload, variant):
     """The "hard" variant: noisier, lower-contrast frames with animals closer than the fitted distribution, float32 master
     weights. The maps now hold borderline local maxima (a dozen per frame within 0.05 of the 0.2 threshold), i.e. the detected
     SET is decided by comparisons of nearly equal numbers and can legitimately differ between an fp32 and a 16-bit-storage
@@ -187,8 +190,8 @@ def test_configs3_hard_frames_differences_are_threshold_decisions(workload):
     from sleap_amd.nn.inference import BottomUpPredictor
     from sleap_amd.synth import render_animals
 
-    n = 8
-    frames, _ = render_animals(n, 1024, 1024, 4, seed=400, **HARD)
+    n, how = HARD[variant]
+    frames, _ = render_animals(n, 1024, 1024, 4, seed=400, **how)
     w32 = _float32_master(workload["w"])
     ref, (pts, vals, si, ci) = _oracle_bottomup(workload["mc"], w32, frames)
     near = int((np.abs(vals - 0.2) < 0.05).sum())
@@ -232,6 +235,6 @@ def test_configs3_hard_frames_differences_are_threshold_decisions(workload):
         assert np.array_equal(np.isnan(got), np.isnan(want)), f"frame {b}: same peaks, different node assignment"
         if np.isfinite(got).any():
             assert float(np.nanmax(np.linalg.norm(got - want, axis=-1))) <= TOL_PX
-    print(f"hard variant: {n_common} common peaks (max delta {worst:.4f} px), {near} oracle peaks within 0.05 of the threshold, "
+    print(f"{variant} variant ({n} frames): {n_common} common peaks (max delta {worst:.4f} px), {near} oracle peaks within 0.05 of the threshold, "
           f"{n_only} peaks detected by one path only (all within {MAP_EPS} of the threshold), frames that differ: {differing}")
     assert worst <= TOL_PX

@@ -122,7 +122,7 @@ class TorchGraph(torch.nn.Module):
                 if name == "tile_channels":
                     y = ins[0].repeat(1, 3, 1, 1)
                 elif name == "imagenet_preproc_v1":
-                    y = (ins[0] * 255.0).flip(1) - torch.tensor([103.939, 116.779, 123.68]).view(1, 3, 1, 1)
+                    y = (ins[0] * 255.0).flip(1) - torch.tensor([103.939, 116.779, 123.68], device=ins[0].device).view(1, 3, 1, 1)
                 else:
                     raise NotImplementedError(name)
             else:
@@ -225,9 +225,13 @@ def make_targets(t, skel, insts, crop):
             paf_targets([al for al, _ in insts], skel.edge_idx, crop, crop, t["heads"][1][2])]
 
 
-def fit(task, steps=None, threads=0, seed=0, lr=2e-3, resume=False):
+def fit(task, steps=None, threads=0, seed=0, lr=2e-3, resume=False, device="cpu", out_dir=None, batch=0):
+    """`device="cuda"`: the same fit on a GPU (plain torch; used for the ResNet-50 task, 45 minutes on 8 CPU cores). The stored
+    weights then depend on the GPU's convolution algorithms: reproducible in distribution, not bit for bit."""
     t = dict(TASKS[task])
     steps = steps or t["steps"]
+    if batch:
+        t["batch"] = batch
     if threads:
         torch.set_num_threads(threads)
     torch.manual_seed(seed)
@@ -240,7 +244,7 @@ def fit(task, steps=None, threads=0, seed=0, lr=2e-3, resume=False):
     pool_insts = [scale_points(a, t["input_scale"]) for a in insts]
     crop = t["crop"] or pool_x.shape[2]
     mc, shapes = task_graph(t, crop, crop)
-    out = os.path.join(OUT_DIR, f"config_{task}.npz")
+    out = os.path.join(out_dir or OUT_DIR, f"config_{task}.npz")
     if resume and os.path.exists(out):
         _, weights = load_task_weights(task, crop, crop, out, seed)
     else:
@@ -250,20 +254,23 @@ def fit(task, steps=None, threads=0, seed=0, lr=2e-3, resume=False):
                 weights[k][:] = 1.0
             elif k.endswith("/beta") or k.endswith("/moving_mean"):
                 weights[k][:] = 0.0
-    net = TorchGraph(mc, weights, freeze=t.get("freeze"))
+    net = TorchGraph(mc, weights, freeze=t.get("freeze")).to(device)
     n_fit = sum(p.numel() for p in net.parameters())
     print(f"[{task}] {n_fit} fitted parameters ({len(net.frozen)} frozen tensors), crop {crop}, {steps} steps", flush=True)
     opt = torch.optim.Adam(net.parameters(), lr=lr)
     sched = torch.optim.lr_scheduler.OneCycleLR(opt, max_lr=lr, total_steps=steps, pct_start=0.1)
-    margin = 16 if t["crop"] else 0
+    # pixels of a crop's border ring left out of the loss. 0 for tasks whose network sees whole frames at inference with a large
+    # receptive field (the ResNet: with a free border ring its confidence maps reached 4.0 along the frame edges -- 1100 false
+    # peaks per 1024 x 1024 frame -- because a crop edge and a frame edge are the same zero padding to the network)
+    margin = t.get("loss_margin", 16 if t["crop"] else 0)
     has_bn = any(l["class_name"] == "BatchNormalization" for l in net.layers)
     t0 = time.time()
     for step in range(steps):
         if has_bn and step == int(steps * 0.7):
             net.bn_batch_stats = False  # the last 30 %: the inference-time function (moving statistics) is what gets fitted
         xs, ins = sample(rng, t, pool_x, pool_insts, t["batch"])
-        tg = make_targets(t, skel, ins, crop)
-        outs = net(xs)
+        tg = [y.to(device) for y in make_targets(t, skel, ins, crop)]
+        outs = net(xs.to(device))
         loss, parts = 0.0, []
         for i, (o, y) in enumerate(zip(outs, tg)):
             m = margin // t["heads"][i][2]
@@ -317,6 +324,9 @@ if __name__ == "__main__":
     ap.add_argument("--threads", type=int, default=0)
     ap.add_argument("--lr", type=float, default=2e-3)
     ap.add_argument("--resume", action="store_true")
+    ap.add_argument("--device", default="cpu")
+    ap.add_argument("--out-dir", default=None)
+    ap.add_argument("--batch", type=int, default=0)
     a = ap.parse_args()
     for task in a.tasks:
-        fit(task, a.steps, a.threads, lr=a.lr, resume=a.resume)
+        fit(task, a.steps, a.threads, lr=a.lr, resume=a.resume, device=a.device, out_dir=a.out_dir, batch=a.batch)
