@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define SA_ABI_VERSION 2
+#define SA_ABI_VERSION 3
 
 #define SA_OK 0
 #define SA_ERR_INVALID_ARG (-1)
@@ -445,6 +445,7 @@ typedef struct sa_tracker_config {   /* Tracker.make_tracker_by_name arguments, 
   int of_max_levels;                 /* flow: pyramid levels above the frame (default 3) */
   int save_shifted_instances;        /* flow (not flowmaxtracks): chain the flow through the latest shifted copy of a queued frame's
                                         instances (FlowCandidateMaker.save_shifted_instances, tracking.py:146-208, 239-256) */
+  double img_scale;                  /* flow: FlowCandidateMaker.img_scale (tracking.py:116-131); 0 or 1 = frames as they are (ABI 3) */
 } sa_tracker_config;
 
 void* sa_tracker_create(const sa_tracker_config* cfg);   /* NULL on invalid configuration (sa_last_error) */
@@ -504,6 +505,15 @@ int sa_flow_pyramid_build(const void* image, int H, int W, int C, int win, int m
  * for the whole batch instead of per frame. */
 int sa_flow_pyramid_build_batch(const void* images, int F, int H, int W, int C, int win, int max_level, void* const* pyramids,
                                 sa_stream_t stream);
+/* FlowCandidateMaker.img_scale != 1 (tracking.py:116-131, 311-314, 321, 333): both frames go through
+ * cv2.resize(img, None, None, scale, scale) (INTER_LINEAR on the gray uint8 frame, OpenCV's 11-bit fixed-point form) before
+ * the pyramid, points are multiplied by the scale before and divided by it after the flow. sa_flow_scaled_size = cv::resize's
+ * dsize (cvRound(size * scale)); sa_flow_pyramid_build_scaled builds the pyramids of F frames [F,H,W,C] at that size
+ * (`pyramid` for F == 1, else `pyramids` = DEVICE array of F buffers of sa_flow_pyramid_bytes(Hs, Ws, ...) bytes); the
+ * Lucas-Kanade calls then take (Hs, Ws). */
+int sa_flow_scaled_size(int H, int W, double img_scale, int* Hs, int* Ws);
+int sa_flow_pyramid_build_scaled(const void* images, int F, int H, int W, int C, double img_scale, int win, int max_level,
+                                 void* pyramid, void* const* pyramids, sa_stream_t stream);
 int sa_flow_lk(const void* const* pyr_prev, const void* pyr_next, int H, int W, int win, int max_level, int n,
                const float* prev_pts, float* next_pts, uint8_t* status, float* err, int max_count, float epsilon,
                sa_stream_t stream);

@@ -32,7 +32,8 @@ status 0, NaN points report status 0 as `cvFloor(NaN)` = INT_MIN does). OpenCV's
 order than its scalar code (float32 lane sums), so even two OpenCV builds agree only to ~1e-4 px; the scalar order is used here.
 Also restated: `cv2.cvtColor(img, cv2.COLOR_BGR2GRAY)` for 3-channel frames (fixed point: (B 1868 + G 9617 + R 4899 + 8192) >> 14,
 applied to whatever channel order the caller has, as the reference does to its RGB frames) and `ensure_int`
-(sleap/nn/data/normalization.py:52-77). `cv2.resize` for img_scale != 1 is NOT restated (NotImplementedError).
+(sleap/nn/data/normalization.py:52-77), and `cv2.resize(img, None, None, scale, scale)` for img_scale != 1 (tracking.py:311-314:
+INTER_LINEAR on uint8 -- `cv_resize_linear_u8` below, OpenCV's 11-bit fixed-point form; parity unpinned like the rest).
 """
 import numpy as np
 
@@ -243,17 +244,70 @@ def calc_optical_flow_pyr_lk(prev_img, next_img, prev_pts, win=21, max_level=3, 
     return nxt, status, err
 
 
+def cv_round(x):
+    """cvRound / saturate_cast<int>(double): round half to even (lrint)."""
+    return int(np.rint(x))
+
+
+def cv_resize_linear_u8(img, fx, fy):
+    """cv2.resize(img, None, None, fx, fy) (interpolation = INTER_LINEAR, the default) of a rank-2 uint8 image, as OpenCV's
+    imgproc/resize.cpp computes it for 8-bit data (published algorithm, restated; OpenCV is absent: parity unpinned):
+
+      dsize = (cvRound(W fx), cvRound(H fy)); scale = 1 / f (double)
+      per destination column dx:  x = float((dx + 0.5) scale_x - 0.5); sx = floor(x); a = x - sx  (float32);
+                                  sx < 0 -> (0, a = 0);  sx >= W - 1 -> (W - 1, a = 0)
+                                  coefficients cvRound((1 - a) 2048), cvRound(a 2048)  (INTER_RESIZE_COEF_BITS = 11)
+      per destination row dy:     the same for (sy, b) without the clipping of b; the two source rows are clip(sy), clip(sy + 1)
+      horizontal pass (int32):    D_r[dx] = S_r[sx] a0 + S_r[sx + 1] a1          (S_r[sx] 2048 where sx + 1 is outside)
+      vertical pass:              dst = (((b0 (D0 >> 4)) >> 16) + ((b1 (D1 >> 4)) >> 16) + 2) >> 2     (VResizeLinear, uchar)
+    """
+    img = np.asarray(img)
+    assert img.ndim == 2 and img.dtype == np.uint8
+    H, W = img.shape
+    dw, dh = cv_round(W * fx), cv_round(H * fy)
+    sx_scale, sy_scale = 1.0 / fx, 1.0 / fy
+
+    def axis(n_dst, n_src, scale, clip_coef):
+        d = np.arange(n_dst, dtype=np.float64)
+        x = ((d + 0.5) * scale - 0.5).astype(np.float32)
+        s = np.floor(x).astype(np.int64)
+        a = (x - s.astype(np.float32)).astype(np.float32)
+        if clip_coef:
+            lo, hi = s < 0, s >= n_src - 1
+            a = np.where(lo | hi, np.float32(0), a)
+            s = np.where(lo, 0, np.where(hi, n_src - 1, s))
+        c0 = np.rint((np.float32(1) - a) * np.float32(2048)).astype(np.int64)
+        c1 = np.rint(a * np.float32(2048)).astype(np.int64)
+        return s, c0, c1
+
+    sx, a0, a1 = axis(dw, W, sx_scale, True)
+    sy, b0, b1 = axis(dh, H, sy_scale, False)
+    src = img.astype(np.int64)
+    sx1 = np.minimum(sx + 1, W - 1)
+    a0 = np.where(sx + 1 >= W, 2048, a0)
+    a1 = np.where(sx + 1 >= W, 0, a1)
+    r0, r1 = np.clip(sy, 0, H - 1), np.clip(sy + 1, 0, H - 1)
+    D0 = src[r0][:, sx] * a0[None, :] + src[r0][:, sx1] * a1[None, :]
+    D1 = src[r1][:, sx] * a0[None, :] + src[r1][:, sx1] * a1[None, :]
+    out = (((b0[:, None] * (D0 >> 4)) >> 16) + ((b1[:, None] * (D1 >> 4)) >> 16) + 2) >> 2
+    return np.clip(out, 0, 255).astype(np.uint8)
+
+
 def flow_shift_points(ref_points, ref_img, new_img, min_shifted_points=0, scale=1.0, window_size=21, max_levels=3):
     """FlowCandidateMaker.flow_shift_instances (tracking.py:258-356) on point arrays: `ref_points` = list of (N, 2) arrays (one
     per reference instance). -> list of (index of the reference instance, shifted points with NaN where the flow was lost,
     shift_score = -mean error of the points found), only for instances with MORE than `min_shifted_points` points found."""
-    if scale != 1:
-        raise NotImplementedError("img_scale != 1 needs cv2.resize (not restated)")
     ref_img, new_img = to_gray(ref_img), to_gray(new_img)
+    if scale != 1:  # tracking.py:311-314
+        ref_img, new_img = cv_resize_linear_u8(ref_img, scale, scale), cv_resize_linear_u8(new_img, scale, scale)
     if not ref_points:
         return []
     allp = np.concatenate([np.asarray(p, np.float64) for p in ref_points], axis=0).astype(np.float32)
+    if scale != 1:
+        allp = (allp * np.float32(scale)).astype(np.float32)  # `.astype("float32") * scale` (:321)
     shifted, status, errs = calc_optical_flow_pyr_lk(ref_img, new_img, allp, win=window_size, max_level=max_levels)
+    if scale != 1:
+        shifted = (shifted / np.float32(scale)).astype(np.float32)  # `shifted_pts /= scale` (:333)
     out, o = [], 0
     for i, p in enumerate(ref_points):
         m = len(p)

@@ -7,7 +7,7 @@ Follows, function by function:
     sleap/nn/tracker/components.py:366-466  cull_frame_instances, connect_single_track_breaks
     sleap/nn/tracker/components.py:469-640  Match, FrameMatches
     sleap/nn/tracking.py:442-507            SimpleCandidateMaker, SimpleMaxTracksCandidateMaker
-    sleap/nn/tracking.py:108-440, 1194-1240 FlowCandidateMaker, FlowMaxTracksCandidateMaker (img_scale=1); the optical flow itself is oracle/optical_flow.py
+    sleap/nn/tracking.py:108-440, 1194-1240 FlowCandidateMaker, FlowMaxTracksCandidateMaker; the optical flow itself is oracle/optical_flow.py
     sleap/nn/tracking.py:542-841            Tracker.track / spawn_for_untracked_instances / final_pass
     sleap/nn/utils.py:45-76                 compute_iou
     sleap/instance.py:866-901               Instance.centroid / bounding_box / n_visible_points
@@ -303,7 +303,7 @@ class Tracker:
 
     def __init__(self, tracker="simple", similarity="instance", match="greedy", track_window=5, robust=1.0,
                  min_new_track_points=0, min_match_points=0, of_window_size=21, of_max_levels=3, save_shifted_instances=False,
-                 target_instance_count=0, pre_cull_to_target=False,
+                 img_scale=1.0, target_instance_count=0, pre_cull_to_target=False,
                  pre_cull_iou_threshold=None, post_connect_single_breaks=False, max_tracks=None, max_tracking=False,
                  oks_errors=None, oks_score_weighting=False, oks_normalization="all"):
         max_tracking = max_tracking if max_tracks else False
@@ -313,8 +313,8 @@ class Tracker:
             raise ValueError(f"{tracker} is not a valid tracker.")
         self.uses_flow = tracker.startswith("flow")
         if tracker != "flow":  # :914-919: only "flow" is configured; "flowmaxtracks" keeps the class defaults
-            of_window_size, of_max_levels, save_shifted_instances = 21, 3, False
-        self.of_window_size, self.of_max_levels = of_window_size, of_max_levels
+            of_window_size, of_max_levels, save_shifted_instances, img_scale = 21, 3, False, 1.0
+        self.of_window_size, self.of_max_levels, self.img_scale = of_window_size, of_max_levels, img_scale
         self.save_shifted_instances = bool(save_shifted_instances)
         self._shifted = {}  # (ref_t, t) -> (shifted instances, frame t)   (FlowCandidateMaker.shifted_instances, :136-138)
         self._images = {}  # t -> frame (MatchedFrameInstance(s).img_t)
@@ -350,8 +350,8 @@ class Tracker:
 
         out = []
         for i, pts, _score in flow_shift_points([r.points for r in ref_instances], self._images[ref_t] if ref_img is None else ref_img, img,
-                                                min_shifted_points=self.min_match_points, window_size=self.of_window_size,
-                                                max_levels=self.of_max_levels):
+                                                min_shifted_points=self.min_match_points, scale=self.img_scale,
+                                                window_size=self.of_window_size, max_levels=self.of_max_levels):
             out.append(ref_instances[i].evolve(points=pts.astype(np.float64)))  # ShiftedInstance.from_instance: the reference's track
         return out
 

@@ -72,6 +72,8 @@ SIGNATURES = {
     "sa_conv3x3_pair_bf16": (_i, [_p, _i, _p, _p, _i, _i, _p, _p, _i, _i, _i, _i, _i, _p, _p, _i, _p]),
     "sa_add_bf16": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _p, _p]),
     "sa_conv1x1_bf16": (_i, [_p, _i, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p, _p, _i, _p, _p]),
+    "sa_flow_scaled_size": (_i, [_i, _i, C.c_double, _p, _p]),
+    "sa_flow_pyramid_build_scaled": (_i, [_p, _i, _i, _i, _i, C.c_double, _i, _i, _p, _p, _p]),
     "sa_convk_bf16": (_i, [_p, _i, _p, _i, _p, _i, _i, _i, _i, _i, _p, _p, _p, _i, _p, _p]),
     "sa_convt_s2_bf16": (_i, [_p, _i, _p, _i, _p, _i, _i, _i, _i, _i, _p, _p, _i, _p, _p]),
     "sa_convt_s2_phase_taps": (_i, [_i, _i, _p, _p]),

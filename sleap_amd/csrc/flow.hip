@@ -106,6 +106,40 @@ flow_gray_kernel(const uint8_t* __restrict__ src, int n_pix, int C, PyrIO io) {
   }
 }
 
+// level 0 for img_scale != 1: gray conversion, then cv2.resize(img, None, None, fx, fy) with INTER_LINEAR on uint8 (tracking.py:
+// 311-314) -- OpenCV's 11-bit fixed-point form (imgproc/resize.cpp, restated in oracle/optical_flow.py cv_resize_linear_u8):
+// x = float((dx + 0.5) / fx - 0.5), sx = floor(x), a = x - sx, clamped with a = 0 at both ends; coefficients
+// cvRound((1 - a) 2048), cvRound(a 2048); rows likewise (indices clipped, coefficient kept); horizontal pass in int32,
+// vertical pass (((b0 (D0 >> 4)) >> 16) + ((b1 (D1 >> 4)) >> 16) + 2) >> 2. One thread per destination pixel.
+__device__ __forceinline__ int gray_at(const uint8_t* s0, int C, size_t i) {
+  if (C == 1) return s0[i];
+  const uint8_t* s = s0 + i * 3;
+  return (s[0] * 1868 + s[1] * 9617 + s[2] * 4899 + 8192) >> 14;
+}
+
+__global__ void __launch_bounds__(256)
+flow_gray_resize_kernel(const uint8_t* __restrict__ src, int H, int W, int C, int Hs, int Ws, double scale_x, double scale_y,
+                        PyrIO io) {
+  const int dx = blockIdx.x * 64 + (threadIdx.x & 63), dy = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (dx >= Ws || dy >= Hs) return;
+  const uint8_t* s0 = src + (size_t)blockIdx.z * H * W * C;
+  const float x = (float)(((double)dx + 0.5) * scale_x - 0.5), y = (float)(((double)dy + 0.5) * scale_y - 0.5);
+  int sx = (int)floorf(x), sy = (int)floorf(y);
+  float a = x - (float)sx;
+  const float b = y - (float)sy;
+  if (sx < 0) sx = 0, a = 0.0f;
+  if (sx >= W - 1) sx = W - 1, a = 0.0f;
+  int a0 = (int)rintf((1.0f - a) * 2048.0f), a1 = (int)rintf(a * 2048.0f);
+  const int b0 = (int)rintf((1.0f - b) * 2048.0f), b1 = (int)rintf(b * 2048.0f);
+  const int sx1 = min(sx + 1, W - 1);
+  if (sx + 1 >= W) a0 = 2048, a1 = 0;
+  const int r0 = min(max(sy, 0), H - 1), r1 = min(max(sy + 1, 0), H - 1);
+  const int D0 = gray_at(s0, C, (size_t)r0 * W + sx) * a0 + gray_at(s0, C, (size_t)r0 * W + sx1) * a1;
+  const int D1 = gray_at(s0, C, (size_t)r1 * W + sx) * a0 + gray_at(s0, C, (size_t)r1 * W + sx1) * a1;
+  const int v = (((b0 * (D0 >> 4)) >> 16) + ((b1 * (D1 >> 4)) >> 16) + 2) >> 2;
+  io.out()[(size_t)dy * Ws + dx] = (uint8_t)min(max(v, 0), 255);
+}
+
 // The two stencils run on a 2-D grid: 64 x 4 pixels per workgroup, blockIdx = (column block, row block, frame) -- no index
 // division, and a thread's reflected row / column indices are computed once (first version: a flat index with a division and
 // 10 modulo-based reflections per output; the pyramids of a 64-frame batch cost as much as its Lucas-Kanade launch).
@@ -459,8 +493,10 @@ int grid_for(size_t total, int cap = 4096) {
 }
 
 // all levels of F frames (F == 1: `base` is the one pyramid buffer; else `pyr` lists F of them): 1 + 2 n_levels - 1 launches
+// (H, W) = the size of the pyramid's level 0; (Hsrc, Wsrc) = the size of the frames: different when the flow tracker's img_scale
+// is not 1 (the frames are resized on the way into level 0)
 int pyramid_launch(const uint8_t* images, int F, int H, int W, int C, const PyrLayout& lay, uint8_t* base, uint8_t* const* pyr,
-                   hipStream_t st) {
+                   hipStream_t st, int Hsrc = 0, int Wsrc = 0, double fscale = 1.0) {
   auto io = [&](size_t src_off, size_t dst_off) {
     PyrIO v;
     v.src = base ? base + src_off : nullptr;
@@ -473,8 +509,12 @@ int pyramid_launch(const uint8_t* images, int F, int H, int W, int C, const PyrL
   auto tiles = [&](int h, int w) { return dim3((unsigned)((w + 63) / 64), (unsigned)((h + 3) / 4), (unsigned)F); };
   auto tiles4 = [&](int h, int w) { return dim3((unsigned)((w + 255) / 256), (unsigned)((h + 3) / 4), (unsigned)F); };
   SA_REQUIRE((H + 3) / 4 <= 65535 && F <= 65535, "sa_flow_pyramid_build: frame too tall for one launch");
-  hipLaunchKernelGGL(flow_gray_kernel, dim3((unsigned)grid_for((size_t)H * W / (C == 1 ? 16 : 1), 1024), 1, (unsigned)F), dim3(256),
-                     0, st, images, H * W, C, io(0, lay.lv[0].img_off));
+  if (Hsrc > 0 && (Hsrc != H || Wsrc != W || fscale != 1.0))
+    hipLaunchKernelGGL(flow_gray_resize_kernel, tiles(H, W), dim3(256), 0, st, images, Hsrc, Wsrc, C, H, W, 1.0 / fscale, 1.0 / fscale,
+                       io(0, lay.lv[0].img_off));
+  else
+    hipLaunchKernelGGL(flow_gray_kernel, dim3((unsigned)grid_for((size_t)H * W / (C == 1 ? 16 : 1), 1024), 1, (unsigned)F), dim3(256),
+                       0, st, images, H * W, C, io(0, lay.lv[0].img_off));
   for (int l = 0; l < lay.n_levels; ++l) {
     const Level& L = lay.lv[l];
     if (l > 0) {
@@ -514,6 +554,31 @@ int sa_flow_pyramid_build(const void* image, int H, int W, int C, int win, int m
   uint8_t* base = static_cast<uint8_t*>(pyramid);
   hipStream_t st = (hipStream_t)stream;
   const int rc = pyramid_launch(static_cast<const uint8_t*>(image), 1, H, W, C, lay, base, nullptr, st);
+  if (rc != SA_OK) return rc;
+  SA_LAUNCH_CHECK();
+  return SA_OK;
+}
+
+int sa_flow_scaled_size(int H, int W, double img_scale, int* Hs, int* Ws) {
+  SA_REQUIRE(Hs && Ws && H > 0 && W > 0 && img_scale > 0.0, "sa_flow_scaled_size: bad arguments");
+  *Hs = (int)rint((double)H * img_scale);  // cv::resize: dsize = saturate_cast<int>(size * f) = cvRound (half to even)
+  *Ws = (int)rint((double)W * img_scale);
+  SA_REQUIRE(*Hs > 0 && *Ws > 0, "sa_flow_scaled_size: the scaled frame is empty");
+  return SA_OK;
+}
+
+int sa_flow_pyramid_build_scaled(const void* images, int F, int H, int W, int C, double img_scale, int win, int max_level,
+                                 void* pyramid, void* const* pyramids, sa_stream_t stream) {
+  if (F == 0) return SA_OK;
+  SA_REQUIRE(images && (pyramid || pyramids) && F > 0 && F <= 65535 && (F == 1 || pyramids), "sa_flow_pyramid_build_scaled: bad arguments");
+  SA_REQUIRE(H > 0 && W > 0 && (C == 1 || C == 3), "sa_flow_pyramid_build_scaled: frames are [H,W,1] or [H,W,3] uint8");
+  SA_REQUIRE(win >= 3 && win <= MAX_WIN && max_level >= 0, "sa_flow_pyramid_build_scaled: window must be in 3..%d", MAX_WIN);
+  int Hs = 0, Ws = 0;
+  const int rs = sa_flow_scaled_size(H, W, img_scale, &Hs, &Ws);
+  if (rs != SA_OK) return rs;
+  const PyrLayout lay = pyr_layout(Hs, Ws, win, max_level);
+  const int rc = pyramid_launch(static_cast<const uint8_t*>(images), F, Hs, Ws, C, lay, pyramids ? nullptr : static_cast<uint8_t*>(pyramid),
+                                reinterpret_cast<uint8_t* const*>(pyramids), (hipStream_t)stream, H, W, img_scale);
   if (rc != SA_OK) return rc;
   SA_LAUNCH_CHECK();
   return SA_OK;

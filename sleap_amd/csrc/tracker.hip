@@ -85,13 +85,15 @@ struct Config {
   std::vector<double> kp_precision;  // 1 / (2 err^2); size 1 = scalar
   int oks_score_weighting, oks_normalization;
   int flow = 0, of_window_size = 21, of_max_levels = 3;  // FlowCandidateMaker (tracking.py:108-137)
+  double img_scale = 1.0;                                // frames resized by cv2.resize before the flow (tracking.py:311-314)
   int save_shifted = 0;  // FlowCandidateMaker.save_shifted_instances: chain the flow through the latest shifted copy (:146-166)
 };
 
 // Device side of the flow candidate makers: one image pyramid per queued time step (the reference keeps `img_t` in every
 // MatchedFrameInstances), the pyramid of the frame being tracked, and scratch for one Lucas-Kanade launch.
 struct FlowState {
-  int H = 0, W = 0;
+  int H = 0, W = 0;    // frame size
+  int Hs = 0, Ws = 0;  // size of the pyramids' level 0: the frame resized by img_scale (== H, W without)
   std::map<int, void*> pyr;  // t -> device pyramid of that frame
   void* cur = nullptr;       // pyramid of the current frame (set by sa_tracker_set_image, consumed by the next track call)
   std::vector<void*> pool;   // free pyramid buffers of the current (H, W)
@@ -406,6 +408,7 @@ int flow_shift(Tracker& T, const std::vector<std::pair<int, std::vector<const In
   }
   std::vector<const void*> ptrs(n);
   std::vector<float> pts(2 * n);
+  const float fscale = (float)c.img_scale;  // (1 without: x * 1.0f and x / 1.0f are exact)
   size_t k = 0;
   for (const auto& g : refs) {
     const auto it = F.pyr.find(g.first);
@@ -414,8 +417,8 @@ int flow_shift(Tracker& T, const std::vector<std::pair<int, std::vector<const In
     for (const Inst* a : g.second)
       for (size_t j = 0; j < a->pts.size() / 2; ++j, ++k) {
         ptrs[k] = it->second;
-        pts[2 * k] = (float)a->pts[2 * j];  // `.astype("float32")`; NaN points stay NaN and come back "not found"
-        pts[2 * k + 1] = (float)a->pts[2 * j + 1];
+        pts[2 * k] = (float)a->pts[2 * j] * fscale;  // `.astype("float32") * scale`; NaN points stay NaN and come back "not found"
+        pts[2 * k + 1] = (float)a->pts[2 * j + 1] * fscale;
       }
   }
   unsigned char* d = static_cast<unsigned char*>(F.scratch);
@@ -426,7 +429,7 @@ int flow_shift(Tracker& T, const std::vector<std::pair<int, std::vector<const In
   uint8_t* d_st = reinterpret_cast<uint8_t*>(d_err + n);
   SA_HIP_CHECK(hipMemcpyAsync(d_ptrs, ptrs.data(), n * sizeof(void*), hipMemcpyHostToDevice, F.stream));
   SA_HIP_CHECK(hipMemcpyAsync(d_pts, pts.data(), 2 * n * sizeof(float), hipMemcpyHostToDevice, F.stream));
-  const int rc = sa_flow_lk(static_cast<const void* const*>(d_ptrs), F.cur, F.H, F.W, c.of_window_size, c.of_max_levels, (int)n, d_pts,
+  const int rc = sa_flow_lk(static_cast<const void* const*>(d_ptrs), F.cur, F.Hs, F.Ws, c.of_window_size, c.of_max_levels, (int)n, d_pts,
                             d_out, d_st, d_err, 30, 0.01f, F.stream);
   if (rc != SA_OK) return rc;
   std::vector<float> shifted(2 * n);
@@ -449,8 +452,8 @@ int flow_shift(Tracker& T, const std::vector<std::pair<int, std::vector<const In
         b.src = a->src;
         for (size_t j = 0; j < m; ++j) {
           const bool ok = st[k + j] != 0;
-          b.pts[2 * j] = ok ? (double)shifted[2 * (k + j)] : NaN;
-          b.pts[2 * j + 1] = ok ? (double)shifted[2 * (k + j) + 1] : NaN;
+          b.pts[2 * j] = ok ? (double)(shifted[2 * (k + j)] / fscale) : NaN;  // `shifted_pts /= scale` (float32)
+          b.pts[2 * j + 1] = ok ? (double)(shifted[2 * (k + j) + 1] / fscale) : NaN;
           if (ok) ++b.nvis;
         }
         out[g].push_back(std::move(b));
@@ -575,8 +578,8 @@ int track_one(Tracker& T, std::vector<Inst> untracked, int img_h, int img_w, int
             b.src = a->src;
             for (size_t j = 0; j < m; ++j) {
               const bool ok = T.fb.st[k + j] != 0;
-              b.pts[2 * j] = ok ? (double)T.fb.shifted[2 * (k + j)] : NaN;
-              b.pts[2 * j + 1] = ok ? (double)T.fb.shifted[2 * (k + j) + 1] : NaN;
+              b.pts[2 * j] = ok ? (double)(T.fb.shifted[2 * (k + j)] / (float)c.img_scale) : NaN;
+              b.pts[2 * j + 1] = ok ? (double)(T.fb.shifted[2 * (k + j) + 1] / (float)c.img_scale) : NaN;
               if (ok) ++b.nvis;
             }
             shifted[g].push_back(std::move(b));
@@ -745,12 +748,14 @@ int flow_batch_run(Tracker& T, int n_frames, int max_inst, int n_nodes, const fl
     F.release_all();
     F.H = frame_h;
     F.W = frame_w;
+    const int rs = sa_flow_scaled_size(frame_h, frame_w, c.img_scale, &F.Hs, &F.Ws);
+    if (rs != SA_OK) return rs;
   }
   if (F.cur) {  // an image handed over by sa_tracker_set_image and never used
     F.pool.push_back(F.cur);
     F.cur = nullptr;
   }
-  const size_t pbytes = sa_flow_pyramid_bytes(frame_h, frame_w, c.of_window_size, c.of_max_levels);
+  const size_t pbytes = sa_flow_pyramid_bytes(F.Hs, F.Ws, c.of_window_size, c.of_max_levels);
   std::vector<void*> bp((size_t)n_frames, nullptr);
   struct PoolGuard {  // every exit path hands the pyramid buffers it did not consume back to the tracker's pool
     std::vector<void*>& v;
@@ -776,8 +781,11 @@ int flow_batch_run(Tracker& T, int n_frames, int max_inst, int n_nodes, const fl
       F.ptab_bytes = need * 2;
     }
     SA_HIP_CHECK(hipMemcpyAsync(F.ptab, bp.data(), need, hipMemcpyHostToDevice, F.stream));
-    const int rc = sa_flow_pyramid_build_batch(images, n_frames, frame_h, frame_w, C, c.of_window_size, c.of_max_levels,
-                                               static_cast<void* const*>(F.ptab), stream);
+    const int rc = c.img_scale != 1.0
+                       ? sa_flow_pyramid_build_scaled(images, n_frames, frame_h, frame_w, C, c.img_scale, c.of_window_size,
+                                                      c.of_max_levels, nullptr, static_cast<void* const*>(F.ptab), stream)
+                       : sa_flow_pyramid_build_batch(images, n_frames, frame_h, frame_w, C, c.of_window_size, c.of_max_levels,
+                                                     static_cast<void* const*>(F.ptab), stream);
     if (rc != SA_OK) return rc;
   }
   // ---- jobs
@@ -787,11 +795,12 @@ int flow_batch_run(Tracker& T, int n_frames, int max_inst, int n_nodes, const fl
   Tracker::FlowBatch& B = T.fb;
   B.at.clear();
   B.first_serial = T.serial;
+  const float fscale = (float)c.img_scale;
   auto add_point = [&](const void* pp, const void* pn, float x, float y) {
     prev.push_back(pp);
     next.push_back(pn);
-    pts.push_back(x);
-    pts.push_back(y);
+    pts.push_back(x * fscale);
+    pts.push_back(y * fscale);
   };
   for (int f = 0; f < n_frames; ++f) {
     const int nb = f < Wq ? f : Wq;
@@ -853,7 +862,7 @@ int flow_batch_run(Tracker& T, int n_frames, int max_inst, int n_nodes, const fl
     SA_HIP_CHECK(hipMemcpyAsync(d_prev, prev.data(), n * sizeof(void*), hipMemcpyHostToDevice, F.stream));
     SA_HIP_CHECK(hipMemcpyAsync(d_next, next.data(), n * sizeof(void*), hipMemcpyHostToDevice, F.stream));
     SA_HIP_CHECK(hipMemcpyAsync(d_pts, pts.data(), 2 * n * sizeof(float), hipMemcpyHostToDevice, F.stream));
-    const int rc = sa_flow_lk_pairs(static_cast<const void* const*>(d_prev), static_cast<const void* const*>(d_next), F.H, F.W,
+    const int rc = sa_flow_lk_pairs(static_cast<const void* const*>(d_prev), static_cast<const void* const*>(d_next), F.Hs, F.Ws,
                                     c.of_window_size, c.of_max_levels, (int)n, d_pts, d_out, d_st, d_err, 30, 0.01f, F.stream);
     if (rc != SA_OK) return rc;
     SA_HIP_CHECK(hipMemcpyAsync(B.shifted.data(), d_out, 2 * n * sizeof(float), hipMemcpyDeviceToHost, F.stream));
@@ -924,6 +933,7 @@ void* sa_tracker_create(const sa_tracker_config* cfg) {
   c.flow = cfg->flow ? 1 : 0;
   c.of_window_size = cfg->of_window_size > 0 ? cfg->of_window_size : 21;
   c.of_max_levels = cfg->of_max_levels >= 0 ? cfg->of_max_levels : 3;
+  c.img_scale = cfg->img_scale > 0.0 ? cfg->img_scale : 1.0;
   c.save_shifted = cfg->save_shifted_instances != 0 && c.flow && !c.max_tracks_mode;  // (the reference configures it for "flow" only)
   if (c.flow && (c.of_window_size < 3 || c.of_window_size > 31)) {
     delete t;
@@ -968,9 +978,13 @@ int sa_tracker_set_image(void* h, const void* image, int H, int W, int C, sa_str
     F.release_all();
     F.H = H;
     F.W = W;
+    const int rs = sa_flow_scaled_size(H, W, T->c.img_scale, &F.Hs, &F.Ws);
+    if (rs != SA_OK) return rs;
   }
-  if (!F.cur) F.cur = F.take(sa_flow_pyramid_bytes(H, W, T->c.of_window_size, T->c.of_max_levels));
+  if (!F.cur) F.cur = F.take(sa_flow_pyramid_bytes(F.Hs, F.Ws, T->c.of_window_size, T->c.of_max_levels));
   if (!F.cur) return sa::fail(SA_ERR_HIP, "flow tracker: out of device memory for the frame pyramid");
+  if (T->c.img_scale != 1.0)
+    return sa_flow_pyramid_build_scaled(image, 1, H, W, C, T->c.img_scale, T->c.of_window_size, T->c.of_max_levels, F.cur, nullptr, stream);
   return sa_flow_pyramid_build(image, H, W, C, T->c.of_window_size, T->c.of_max_levels, F.cur, stream);
 }
 

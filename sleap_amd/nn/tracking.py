@@ -11,7 +11,7 @@ GIL while a batch of frames is tracked); this module only marshals arrays.
 Instances are arrays, not `PredictedInstance`s: points (n, N, 2) with NaN for missing nodes, point scores (n, N),
 instance scores (n,). Tracks are integers, `spawned_tracks[i]` is the reference's name for track i.
 Flow trackers take the frame with every step (`img=` / `images=`: uint8 arrays or CUDA tensors); the Lucas-Kanade flow that
-the reference gets from `cv2.calcOpticalFlowPyrLK` runs on the device (csrc/flow.hip), with `img_scale=1` only. `kf_init_frame_count` / `kf_node_indices` wrap the tracker in the Kalman one (`kalman.py`).
+the reference gets from `cv2.calcOpticalFlowPyrLK` runs on the device (csrc/flow.hip; `img_scale != 1`: the frames pass through the device restatement of `cv2.resize`, INTER_LINEAR on uint8). `kf_init_frame_count` / `kf_node_indices` wrap the tracker in the Kalman one (`kalman.py`).
 """
 import ctypes as C
 from typing import List, Optional, Sequence
@@ -34,7 +34,7 @@ class _Config(C.Structure):
                 ("max_tracks", C.c_int), ("max_tracking", C.c_int), ("oks_n_errors", C.c_int),
                 ("oks_errors", C.POINTER(C.c_double)), ("oks_score_weighting", C.c_int), ("oks_normalization", C.c_int),
                 ("flow", C.c_int), ("of_window_size", C.c_int), ("of_max_levels", C.c_int),
-                ("save_shifted_instances", C.c_int)]
+                ("save_shifted_instances", C.c_int), ("img_scale", C.c_double)]
 
 
 def _f32(a):
@@ -151,8 +151,8 @@ class Tracker:
         self.uses_flow = tracker.startswith("flow")
         if tracker != "flow":  # tracking.py:914-919 configures the candidate maker for "flow" only: "flowmaxtracks" keeps
             img_scale, of_window_size, of_max_levels, save_shifted_instances = 1.0, 21, 3, False  # the class defaults
-        if self.uses_flow and img_scale != 1:
-            raise NotImplementedError("flow tracker: img_scale != 1 (cv2.resize of the frames) is not implemented")
+        if self.uses_flow and not (img_scale and float(img_scale) > 0):
+            raise ValueError("flow tracker: img_scale must be positive")
         if clean_instance_count:
             raise NotImplementedError("clean_instance_count (deprecated TrackCleaner) is not implemented; use "
                                       "target_instance_count with pre_cull_to_target")
@@ -177,7 +177,8 @@ class Tracker:
                       int(self.max_tracking), 0 if errs is None else errs.size,
                       None if errs is None else errs.ctypes.data_as(C.POINTER(C.c_double)), int(bool(oks_score_weighting)),
                       OKS_NORM[oks_normalization], int(self.uses_flow), self.of_window_size, self.of_max_levels,
-                      int(bool(save_shifted_instances) and tracker == "flow"))
+                      int(bool(save_shifted_instances) and tracker == "flow"), float(img_scale))
+        self.img_scale = float(img_scale)
         h = _lib.lib()
         self._h = h.sa_tracker_create(C.byref(cfg))
         if not self._h:

@@ -333,7 +333,9 @@ class FlowPyramid:
     """One frame's image pyramid + Scharr derivatives on the device (sa_flow_pyramid_build). `image`: (H, W), (H, W, 1) or
     (H, W, 3) uint8, numpy or CUDA tensor."""
 
-    def __init__(self, image, win: int = 21, max_level: int = 3):
+    def __init__(self, image, win: int = 21, max_level: int = 3, img_scale: float = 1.0):
+        """`img_scale != 1`: the (gray) frame passes through the device restatement of cv2.resize(img, None, None, s, s) first
+        (FlowCandidateMaker.img_scale, tracking.py:311-314); H, W are then the scaled size."""
         if not torch.is_tensor(image):
             image = torch.from_numpy(np.ascontiguousarray(image))
         if image.dtype != torch.uint8:
@@ -341,14 +343,22 @@ class FlowPyramid:
         if image.dim() == 2:
             image = image[..., None]
         image = image.contiguous().to(_dev())
-        self.H, self.W, self.C = (int(v) for v in image.shape)
-        self.win, self.max_level = int(win), int(max_level)
+        src_h, src_w, self.C = (int(v) for v in image.shape)
+        self.win, self.max_level, self.img_scale = int(win), int(max_level), float(img_scale)
         h = _lib.lib()
+        hs, ws = C.c_int(src_h), C.c_int(src_w)
+        if self.img_scale != 1.0:
+            check(h.sa_flow_scaled_size(src_h, src_w, self.img_scale, C.byref(hs), C.byref(ws)), "sa_flow_scaled_size")
+        self.H, self.W = hs.value, ws.value
         self.n_levels = h.sa_flow_pyramid_levels(self.H, self.W, self.win, self.max_level)
         self.buf = torch.empty((max(h.sa_flow_pyramid_bytes(self.H, self.W, self.win, self.max_level), 256),), dtype=torch.uint8,
                                device=image.device)
-        check(h.sa_flow_pyramid_build(_ptr(image), self.H, self.W, self.C, self.win, self.max_level, _ptr(self.buf), _stream()),
-              "sa_flow_pyramid_build")
+        if self.img_scale != 1.0:
+            check(h.sa_flow_pyramid_build_scaled(_ptr(image), 1, src_h, src_w, self.C, self.img_scale, self.win, self.max_level,
+                                                 _ptr(self.buf), None, _stream()), "sa_flow_pyramid_build_scaled")
+        else:
+            check(h.sa_flow_pyramid_build(_ptr(image), self.H, self.W, self.C, self.win, self.max_level, _ptr(self.buf), _stream()),
+                  "sa_flow_pyramid_build")
 
 
 def optical_flow_pyr_lk(prev: "FlowPyramid", nxt: "FlowPyramid", points, max_count: int = 30, epsilon: float = 0.01):

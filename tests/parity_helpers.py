@@ -1,0 +1,49 @@
+"""Shared comparison of a device bottom-up result with the oracle's when the maps hold borderline local maxima."""
+import numpy as np
+
+
+def compare_with_threshold_decisions(oracle_peaks, device_peaks, ref, o, n_nodes, map_eps, tol_px, threshold=0.2):
+    """oracle_peaks = (pts (n, 2) image px, vals, sample_inds, channel_inds) of find_local_peaks; device_peaks = (peak_xy [B, P, 2],
+    peak_val, peak_chan, peak_count) of the device layer; ref = the oracle's PAFScorer.predict result; o = the device layer's
+    outputs (numpy). Asserts:
+
+      * every peak only ONE path detects has a confidence within `map_eps` of the threshold (a threshold decision on a map
+        value that differs by the storage precision) -- nothing else may differ;
+      * frames whose peak sets agree give the same instances: count, node assignment, every coordinate within `tol_px`.
+
+    -> (frames whose peak sets differ, number of common peaks, their largest distance, number of one-sided peaks)."""
+    pts, vals, si, ci = oracle_peaks
+    g_xy, g_val, g_ch, g_n = device_peaks
+    n = len(g_n)
+    differing, n_common, worst, n_only = [], 0, 0.0, 0
+    for b in range(n):
+        wp, wv, wc = pts[si == b], vals[si == b], ci[si == b]
+        gp, gv, gc = g_xy[b, : g_n[b]], g_val[b, : g_n[b]], g_ch[b, : g_n[b]]
+        used = np.zeros(len(gp), bool)
+        same = True
+        for p, v, c in zip(wp, wv, wc):
+            cand = np.where((gc == c) & ~used)[0]
+            d = np.linalg.norm(gp[cand] - p, axis=-1) if len(cand) else np.zeros(0)
+            if len(cand) and d.min() <= 2.0:  # the same local maximum (grid cells are >= 2 px apart)
+                j = cand[int(d.argmin())]
+                used[j] = True
+                n_common += 1
+                worst = max(worst, float(d.min()))
+            else:
+                same = False
+                n_only += 1
+                assert abs(float(v) - threshold) <= map_eps, f"frame {b}: oracle-only peak with value {v} (channel {c})"
+        for j in np.where(~used)[0]:
+            same = False
+            n_only += 1
+            assert abs(float(gv[j]) - threshold) <= map_eps, f"frame {b}: device-only peak with value {gv[j]} (channel {gc[j]})"
+        if not same:
+            differing.append(b)
+            continue
+        want = np.asarray(ref[0][b]).reshape(-1, n_nodes, 2)
+        assert int(o["n_valid"][b]) == len(want), f"frame {b}: same peaks, different instance count"
+        got = o["instance_peaks"][b, : len(want)]
+        assert np.array_equal(np.isnan(got), np.isnan(want)), f"frame {b}: same peaks, different node assignment"
+        if np.isfinite(got).any():
+            assert float(np.nanmax(np.linalg.norm(got - want, axis=-1))) <= tol_px
+    return differing, n_common, worst, n_only

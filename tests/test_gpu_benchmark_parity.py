@@ -15,6 +15,7 @@ import torch
 from oracle import paf_grouping as opg
 from oracle import peak_finding as opf
 from oracle.keras_graph import KerasGraph, preprocess
+from parity_helpers import compare_with_threshold_decisions
 
 pytestmark = pytest.mark.gpu
 
@@ -204,37 +205,8 @@ def test_configs3_hard_frames_differences_are_threshold_decisions(workload, vari
          if isinstance(v, torch.Tensor)}
     assert not int(np.bitwise_or.reduce(o["status"])), "capacity overflow / non-finite status"
     g_xy, g_val, g_ch, g_n = (o[k] for k in ("peaks", "peak_vals", "peak_channel_inds", "peak_count"))
-    differing, n_common, worst, n_only = [], 0, 0.0, 0
-    for b in range(n):
-        wp, wv, wc = pts[si == b], vals[si == b], ci[si == b]
-        gp, gv, gc = g_xy[b, : g_n[b]], g_val[b, : g_n[b]], g_ch[b, : g_n[b]]
-        used = np.zeros(len(gp), bool)
-        same = True
-        for p, v, c in zip(wp, wv, wc):
-            cand = np.where((gc == c) & ~used)[0]
-            d = np.linalg.norm(gp[cand] - p, axis=-1) if len(cand) else np.zeros(0)
-            if len(cand) and d.min() <= 2.0:  # the same local maximum (grid cells are 4 px apart)
-                j = cand[int(d.argmin())]
-                used[j] = True
-                n_common += 1
-                worst = max(worst, float(d.min()))
-            else:
-                same = False
-                n_only += 1
-                assert abs(float(v) - 0.2) <= MAP_EPS, f"frame {b}: oracle-only peak with value {v} (channel {c})"
-        for j in np.where(~used)[0]:
-            same = False
-            n_only += 1
-            assert abs(float(gv[j]) - 0.2) <= MAP_EPS, f"frame {b}: device-only peak with value {gv[j]} (channel {gc[j]})"
-        if not same:
-            differing.append(b)
-            continue
-        want = np.asarray(ref[0][b]).reshape(-1, 13, 2)
-        assert int(o["n_valid"][b]) == len(want), f"frame {b}: same peaks, different instance count"
-        got = o["instance_peaks"][b, : len(want)]
-        assert np.array_equal(np.isnan(got), np.isnan(want)), f"frame {b}: same peaks, different node assignment"
-        if np.isfinite(got).any():
-            assert float(np.nanmax(np.linalg.norm(got - want, axis=-1))) <= TOL_PX
+    differing, n_common, worst, n_only = compare_with_threshold_decisions(
+        (pts, vals, si, ci), (g_xy, g_val, g_ch, g_n), ref, o, n_nodes=13, map_eps=MAP_EPS, tol_px=TOL_PX)
     print(f"{variant} variant ({n} frames): {n_common} common peaks (max delta {worst:.4f} px), {near} oracle peaks within 0.05 of the threshold, "
           f"{n_only} peaks detected by one path only (all within {MAP_EPS} of the threshold), frames that differ: {differing}")
     assert worst <= TOL_PX

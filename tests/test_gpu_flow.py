@@ -39,6 +39,26 @@ def test_pyramid_and_derivatives_are_exact(shape, C):
         assert np.array_equal(g, r) and np.array_equal(ix, rx) and np.array_equal(iy, ry)
 
 
+@pytest.mark.parametrize("shape,C,scale", [((160, 200), 1, 0.5), ((97, 131), 3, 0.5), ((128, 256), 1, 0.75), ((111, 143), 1, 0.6),
+                                           ((64, 80), 3, 2.0), ((97, 131), 1, 0.25)])
+def test_scaled_pyramid_is_the_oracles_resize_then_pyramid(shape, C, scale):
+    """FlowCandidateMaker.img_scale != 1 (tracking.py:311-314): gray, then cv2.resize(INTER_LINEAR, uint8), then the pyramid --
+    the device's level 0 equals the oracle's restatement of cv2.resize bit for bit, and so do all levels and derivatives."""
+    from oracle import optical_flow as of
+    from sleap_amd import ops
+
+    rng = np.random.default_rng(sum(shape) + C)
+    img = rng.integers(0, 256, shape + (C,), dtype=np.uint8)
+    small = of.cv_resize_linear_u8(of.to_gray(img), scale, scale)
+    p = ops.FlowPyramid(img, win=21, max_level=3, img_scale=scale)
+    assert (p.H, p.W) == small.shape
+    ref = of.build_pyramid(small, 21, 3)
+    assert p.n_levels == len(ref)
+    for (g, ix, iy), r in zip(_device_pyramid_levels(p), ref):
+        rx, ry = of.scharr_deriv(r)
+        assert np.array_equal(g, r) and np.array_equal(ix, rx) and np.array_equal(iy, ry)
+
+
 @pytest.mark.parametrize("shape,C", [((128, 256), 1), ((97, 131), 3), ((160, 200), 1)])
 def test_batched_pyramid_build_equals_single_builds(shape, C):
     """sa_flow_pyramid_build_batch (blockIdx.z = frame, buffers listed in a device table) == sa_flow_pyramid_build per frame"""
@@ -144,7 +164,8 @@ def _moving_scene(n_frames=14, h=192, w=224, n_animals=3, n_nodes=5, seed=0):
                                 dict(tracker="flowmaxtracks", max_tracks=3, max_tracking=True),
                                 dict(tracker="flowmaxtracks", max_tracks=2, max_tracking=True, similarity="object_keypoint", robust=0.8),
                                 dict(tracker="flow", save_shifted_instances=True),
-                                dict(tracker="flow", save_shifted_instances=True, track_window=3, min_match_points=1, similarity="iou")])
+                                dict(tracker="flow", save_shifted_instances=True, track_window=3, min_match_points=1, similarity="iou"),
+                                dict(tracker="flow", img_scale=0.5), dict(tracker="flow", img_scale=0.75, of_window_size=15)])
 def test_flow_tracker_equals_oracle(kw):
     """The native tracker with device Lucas-Kanade candidates against the oracle tracker with the CPU restatement: the same
     tracks for every instance of every frame, tracking scores to 1e-3 (the shifted points differ by < 2e-3 px)."""
@@ -179,7 +200,7 @@ def test_flow_tracker_equals_oracle(kw):
 
 
 @pytest.mark.parametrize("kw", [dict(tracker="flow"), dict(tracker="flow", track_window=2, min_match_points=1),
-                                dict(tracker="flow", save_shifted_instances=True),
+                                dict(tracker="flow", save_shifted_instances=True), dict(tracker="flow", img_scale=0.5),
                                 dict(tracker="flowmaxtracks", max_tracks=3, max_tracking=True),
                                 dict(tracker="flowmaxtracks", max_tracks=2, max_tracking=True, track_window=3)])
 def test_flow_tracker_batched_frames_equal_single_steps(kw):

@@ -82,8 +82,43 @@ def test_flow_shift_points_follows_the_reference_call_site():
     _, pts, score = out[0]
     assert np.isnan(pts[2]).all() and np.abs(pts[:2] - a[:2] - [2.0, -1.0]).max() < 0.05 and score <= 0
     assert of.flow_shift_points([a, b], i0, i1, min_shifted_points=2) == []
-    with pytest.raises(NotImplementedError):
-        of.flow_shift_points([a], i0, i1, scale=0.5)
+    # img_scale (tracking.py:311-314, 321, 333): frames through cv2.resize, points x scale before and / scale after the flow
+    out = of.flow_shift_points([a], i0, i1, scale=0.5)
+    assert [i for i, _, _ in out] == [0]
+    assert np.abs(out[0][1][:2] - a[:2] - [2.0, -1.0]).max() < 0.15 and np.isnan(out[0][1][2]).all()
+
+
+def test_cv_resize_linear_u8_conventions():
+    """cv2.resize(img, None, None, f, f) with INTER_LINEAR on uint8, OpenCV's documented conventions (imgproc/resize.cpp;
+    OpenCV is absent, so these pin the restatement to the published algorithm, not to a build):
+      * dsize = cvRound(size * f), round half to even (37 x 0.5 -> 18, 53 x 0.5 -> 26);
+      * pixel centres: source x = (dx + 0.5) / f - 0.5 -- at f = 0.5 every output is the mean of a 2 x 2 block, rounded half up
+        ((sum + 2) >> 2, which the two fixed-point passes reproduce exactly);
+      * f = 1 is the identity; constant images stay constant at any f; the borders clamp (f = 2 keeps the corner pixels);
+      * 11-bit coefficients: the weights of an output sum to 2048 and the result is within one grey level of the
+        real-valued bilinear sample."""
+    rng = np.random.default_rng(0)
+    img = rng.integers(0, 256, (37, 53), dtype=np.uint8)
+    half = of.cv_resize_linear_u8(img, 0.5, 0.5)
+    assert half.shape == (18, 26)
+    i = img.astype(int)
+    ref = (i[:36:2, :52:2] + i[:36:2, 1:53:2] + i[1:37:2, :52:2] + i[1:37:2, 1:53:2] + 2) // 4
+    assert np.array_equal(half, ref)
+    assert np.array_equal(of.cv_resize_linear_u8(img, 1.0, 1.0), img)
+    assert np.unique(of.cv_resize_linear_u8(np.full((20, 30), 137, np.uint8), 0.7, 0.7)).tolist() == [137]
+    up = of.cv_resize_linear_u8(img, 2.0, 2.0)
+    assert up.shape == (74, 106) and up[0, 0] == img[0, 0] and up[-1, -1] == img[-1, -1]
+    # real-valued bilinear sample (half-pixel centres, clamped) at an arbitrary scale
+    f = 0.6
+    out = of.cv_resize_linear_u8(img, f, f)
+    assert out.shape == (int(np.rint(37 * f)), int(np.rint(53 * f)))
+    ys = np.clip((np.arange(out.shape[0]) + 0.5) / f - 0.5, 0, 36)
+    xs = np.clip((np.arange(out.shape[1]) + 0.5) / f - 0.5, 0, 52)
+    y0, x0 = np.floor(ys).astype(int), np.floor(xs).astype(int)
+    y1, x1 = np.minimum(y0 + 1, 36), np.minimum(x0 + 1, 52)
+    wy, wx = (ys - y0)[:, None], (xs - x0)[None, :]
+    real = (i[y0][:, x0] * (1 - wx) + i[y0][:, x1] * wx) * (1 - wy) + (i[y1][:, x0] * (1 - wx) + i[y1][:, x1] * wx) * wy
+    assert np.abs(out.astype(float) - real).max() <= 1.0
 
 
 def test_flow_tracker_saved_shifted_instances_are_pruned_to_the_track_window():

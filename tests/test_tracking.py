@@ -166,8 +166,9 @@ def test_errors_like_reference():
         Tracker.make_tracker_by_name(tracker="simple", kf_init_frame_count=10)
     d = Tracker.make_tracker_by_name()  # the reference's default is the optical-flow tracker
     assert d.uses_image and d.get_name() == "FlowCandidateMaker.instance_similarity.greedy_matching"
-    with pytest.raises(NotImplementedError):
-        Tracker.make_tracker_by_name(tracker="flow", img_scale=0.5)
+    assert Tracker.make_tracker_by_name(tracker="flow", img_scale=0.5).img_scale == 0.5
+    with pytest.raises(ValueError, match="img_scale"):
+        Tracker.make_tracker_by_name(tracker="flow", img_scale=0.0)
     assert Tracker.make_tracker_by_name(tracker="flow", save_shifted_instances=True).uses_image
     # tracking.py:914-919: only "flow" (not "flowmaxtracks") takes the of_* / img_scale arguments
     m = Tracker.make_tracker_by_name(tracker="flowmaxtracks", img_scale=0.5, of_window_size=9, max_tracks=2, max_tracking=True)
