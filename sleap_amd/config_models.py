@@ -36,6 +36,12 @@ TASKS = {
                         unet=(16, 2.0, 16, 2), heads=[("CentroidConfmapsHead", 1, 2)], steps=1000, batch=8, pool=96),
     "c2_centered": dict(kind="centered", skeleton="FLIES13", frame=1024, n_animals=2, input_scale=1.0, crop=160, render_margin=128.0,
                         unet=(24, 2.0, 16, 4), heads=[("CenteredInstanceConfmapsHead", 13, 4)], steps=1500, batch=12, pool=96),
+    # not a BASELINE config: the hourglass row of SURVEY.md 8(a) (a2') end to end -- a ONE-stack hourglass of the reference's
+    # structure (hourglass.py:17-316: stem k7 s2 + pooling, Conv -> ReLU -> BatchNormalization everywhere, nearest-neighbour
+    # upsampling with additive skips) at a quarter of its default width, single-instance head at stride 4
+    "hg_single13": dict(kind="single", skeleton="FLIES13", frame=512, n_animals=1, input_scale=1.0, crop=256, render_margin=128.0,
+                        hourglass=dict(stem_stride=4, max_stride=32, output_stride=4, stem_filters=32, filters=64, filter_increase=32,
+                                       stacks=1), heads=[("SingleInstanceConfmapsHead", 13, 4)], steps=1500, batch=8, pool=256, loss_margin=0),
     "c4_resnet": dict(kind="multi", skeleton="MOUSE24", frame=1024, n_animals=8, input_scale=1.0, crop=256, render_margin=128.0,
                       body=(60.0, 90.0), min_sep=200.0,
                       resnet=dict(version="ResNet50", features_output_stride=32, pretrained=True,
@@ -64,6 +70,8 @@ def task_graph(task, height, width):
     if "unet" in t:
         f, r, ms, os_ = t["unet"]
         return A.build_unet_model_config((height, width, 1), f, r, ms, os_, True, True, None, heads=t["heads"])
+    if "hourglass" in t:
+        return A.build_hourglass_model_config((height, width, 1), heads=t["heads"], **t["hourglass"])
     r = t["resnet"]
     return A.build_resnet_model_config((height, width, 1), r["version"], r["features_output_stride"], r["pretrained"],
                                        upsampling=r["upsampling"], heads=t["heads"])
@@ -123,6 +131,8 @@ def training_config(task, nodes=None, edges=None):
         f, r, ms, os_ = t["unet"]
         backbone["unet"] = {"stem_stride": None, "max_stride": ms, "output_stride": os_, "filters": f, "filters_rate": r,
                             "middle_block": True, "up_interpolate": True, "stacks": 1}
+    elif "hourglass" in t:
+        backbone["hourglass"] = dict(t["hourglass"])
     else:
         backbone["resnet"] = {"version": t["resnet"]["version"], "weights": "frozen", "upsampling": dict(t["resnet"]["upsampling"]),
                               "max_stride": t["resnet"]["features_output_stride"], "output_stride": t["resnet"]["upsampling"]["output_stride"]}

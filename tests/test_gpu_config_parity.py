@@ -54,7 +54,7 @@ def _single_instance_case(task, n_frames, batch, seed):
 
     t = C.TASKS[task]
     frames, insts = C.render(task, n_frames, seed)
-    x = preprocess(frames, input_scale=t["input_scale"], pad_stride=t["unet"][2])
+    x = preprocess(frames, input_scale=t["input_scale"], pad_stride=t["unet"][2] if "unet" in t else t["hourglass"]["max_stride"])
     net, mc, wts = _net(task, x.shape[1], x.shape[2])
     cms = KerasGraph(mc, wts)(x)[0]
     want, want_vals = oinf.single_instance_peaks(cms, None, 0.2, "integral", 5, t["heads"][0][2], t["input_scale"])
@@ -83,6 +83,15 @@ def test_configs0_single_instance_unet_256_5_nodes():
 def test_configs1_single_instance_unet_512_13_nodes_batch_32():
     """configs[1]: baseline_medium_rf.single (UNet f16 r2 s16 -> 2) on 512 x 512 frames, 13-node fly, ONE batch of 32."""
     _single_instance_case("c1_single13", 32, 32, seed=301)
+
+
+def test_hourglass_single_instance_end_to_end_512_13_nodes():
+    """SURVEY.md 8(a) row a2' end to end (not a BASELINE config): a one-stack hourglass of the reference's structure
+    (hourglass.py:17-316: k7 s2 stem + pooling, Conv -> ReLU -> BatchNormalization, nearest-neighbour upsampling with additive
+    skips; a quarter of the default width), fitted to the fly video, through SingleInstanceInferenceLayer on 512 x 512 frames:
+    the fp32 oracle runs its own network on the float32 master weights, the device path its fp16 one -- same NaN mask, every
+    peak within 0.5 px."""
+    _single_instance_case("hg_single13", 16, 8, seed=305)
 
 
 def _topdown_oracle(frames, crop_size):

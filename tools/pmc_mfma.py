@@ -16,7 +16,7 @@ import re
 import sys
 from collections import defaultdict
 
-PAT = re.compile(r"(conv3x3_dma_kernel<[^>]*>|conv3x3_mfma_kernel<[^>]*>|stem16_kernel<\d>|stem16_gray_kernel|convpair_16_32_32_kernel|tapconv_kernel<[^>]*>)")
+PAT = re.compile(r"(conv3x3_dma_kernel<[^>]*>|conv3x3_mfma_kernel<[^>]*>|stem16_kernel<\d>|stem16_gray_kernel|convpair_16_32_32_kernel|convpair_persist_kernel|tapconv_kernel<[^>]*>)")
 
 
 def main(path, trace=None):

@@ -11,7 +11,7 @@ import re
 import sys
 from collections import defaultdict
 
-PAT = re.compile(r"(conv3x3_dma_kernel<[^>]*>|stem16_kernel<\d>|stem16_gray_kernel|convpair_16_32_32_kernel|upsample2x_kernel|upsample2x_bilinear_block_kernel)")
+PAT = re.compile(r"(conv3x3_dma_kernel<[^>]*>|stem16_kernel<\d>|stem16_gray_kernel|convpair_16_32_32_kernel|convpair_persist_kernel|upsample2x_kernel|upsample2x_bilinear_block_kernel|upsample2x_bilinear_c16_kernel<\d>)")
 
 
 def load(path, counter):
@@ -46,8 +46,8 @@ def main(fetch_csv, write_csv, n_fwd, out_json=None):
     if out_json:
         import json
 
-        json.dump({"conv_family_bytes_per_step": (tf + tw) * 1024 / n_fwd, "fetch_x2_bytes_per_step": tf * 1024 / n_fwd,
-                   "write_bytes_per_step": tw * 1024 / n_fwd, "frames_per_step": 64, "size": 1024, "forward_passes": n_fwd,
+        json.dump({"conv_family_bytes_per_step": (tf + tw) * 1048576 / n_fwd, "fetch_x2_bytes_per_step": tf * 1048576 / n_fwd,
+                   "write_bytes_per_step": tw * 1048576 / n_fwd, "frames_per_step": 64, "size": 1024, "forward_passes": n_fwd,
                    "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH doubled (gfx950), WRITE uncalibrated"},
                   open(out_json, "w"))
 
