@@ -661,6 +661,37 @@ class DeviceNetwork:
             return [op[1], op[2]]
         return []
 
+    def op_bytes(self, H, W):
+        """Algorithmic HBM bytes of every launch of the plan for ONE frame, in `op_descriptions` order: each input tensor read
+        once + each output tensor written once (16-bit activations with padded channels, float32 model outputs, the uint8
+        image; weights not counted: they stay in L2). What a launch's GB/s is quoted on in tools/net_profile.py."""
+        def tb(t):
+            if t is None or getattr(t, "buf", None) is None and t.kind != "input":
+                return 0
+            if t.kind == "input":
+                return H * W * t.c
+            h, w = H * t.num // t.den, W * t.num // t.den
+            return h * w * (t.c * 4 if t.kind == "f32out" else t.cp * 2)
+
+        out = []
+        for op in self.plan:
+            k = op[0]
+            rd = list(self._reads(op))
+            if k in ("stem2", "pair"):
+                wr = ([op[2].out] if op[2].need_full else []) + ([op[2].out_pool] if op[2].out_pool is not None else [])
+                n = sum(tb(t) for t in rd) + sum(tb(t) for t in wr) + (H * W * self.in_channels if k == "stem2" else 0)
+            else:
+                idx = {"conv": (6, 8), "conv1x1": (6,), "stem": (1,), "imgconv": (1,), "pool": (2,), "poolg": (2,), "up": (2,),
+                       "convt": (4,), "convt2": (4,), "add": (5,), "head": (2,)}[k]
+                wr = [op[i] for i in idx if op[i] is not None]
+                if k == "conv":
+                    if not op.need_full:
+                        wr = [t for t in wr if t is not op.out]
+                    wr += [hd[2] for hd in op.heads]
+                n = sum(tb(t) for t in rd) + sum(tb(t) for t in wr) + (H * W * self.in_channels if k in ("stem", "imgconv") else 0)
+            out.append(int(n))
+        return out
+
     def _fuse_heads(self, plan):
         """Move 1x1 heads into the epilogue of the conv that produces their input (<= 2 heads, <= 32 channels each,
         producer with <= 128 padded output channels on the DMA path). If the heads were the only readers the bf16

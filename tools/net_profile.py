@@ -32,6 +32,8 @@ for _ in range(2):
     net.forward(x)
 torch.cuda.synchronize()
 descs = net.op_descriptions(H, H)
+nbytes = net.op_bytes(H, H)  # algorithmic HBM bytes per frame and launch (every input read once, every output written once)
+assert len(nbytes) == len(descs)
 acc = np.zeros(len(descs))
 reps = 3
 for _ in range(reps):
@@ -41,17 +43,19 @@ for _ in range(reps):
     acc += np.array([a.elapsed_time(b) for a, b in prof])
 acc /= reps
 agg = {}
-for (k, nm, f), ms in zip(descs, acc):
+for (k, nm, f), ms, nb in zip(descs, acc, nbytes):
     key = nm.split(" @")[0].split(" ")[0] if k != "conv" else nm.split(" ")[0]
-    a = agg.setdefault(key, [0.0, 0.0, 0])
+    a = agg.setdefault(key, [0.0, 0.0, 0, 0.0])
     a[0] += ms
     a[1] += f * B
     a[2] += 1
+    a[3] += nb * B
     if ms > float(sys.argv[4] if len(sys.argv) > 4 else 0.03) * acc.sum():
-        print(f"{nm:52s} {ms:8.3f} ms {f * B / ms / 1e9 if ms else 0:8.1f} TFLOP/s")
-print("---- by kind")
-for key, (ms, fl, n) in sorted(agg.items(), key=lambda kv: -kv[1][0]):
-    print(f"{key:20s} n={n:3d} {ms:8.3f} ms {fl / ms / 1e9 if ms else 0:8.1f} TFLOP/s")
+        print(f"{nm:52s} {ms:8.3f} ms {f * B / ms / 1e9 if ms else 0:8.1f} TFLOP/s {nb * B / ms / 1e9 if ms else 0:7.2f} TB/s  "
+              f"({f / max(nb, 1):5.0f} FLOP/B)")
+print("---- by kind (TB/s = algorithmic bytes: every input read once, every output written once)")
+for key, (ms, fl, n, nb) in sorted(agg.items(), key=lambda kv: -kv[1][0]):
+    print(f"{key:20s} n={n:3d} {ms:8.3f} ms {fl / ms / 1e9 if ms else 0:8.1f} TFLOP/s {nb / ms / 1e9 if ms else 0:7.2f} TB/s")
 tot_f = sum(f for _, _, f in descs) * B
 print(f"total {acc.sum():.3f} ms for {B} frames of {H}x{H}: {B / acc.sum() * 1e3:.1f} frames/s, {tot_f / acc.sum() / 1e9:.1f} TFLOP/s, "
       f"{tot_f / B / 1e9:.1f} GFLOP/frame")
