@@ -16,6 +16,7 @@
 // the buffer bounds check), the 16-byte channel slots of a pixel are XOR-swizzled with (pixel >> 1) & 7 on the copy's
 // SOURCE side so that the ds_read_b128 of a B fragment touches all 64 banks once per 16 lanes.
 #include <cstdint>
+#include <cstdlib>
 
 #include "bf16.h"
 #include "sa_common.h"
@@ -27,6 +28,9 @@ using sa::mfma_h8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
+#if !defined(SA_TAP_PREFETCH_RES)
+#define SA_TAP_PREFETCH_RES 1
+#endif
 constexpr int MAX_TAPS = 16;
 constexpr int MAX_WINDOW_TAPS = 81;  // sa_convk_bf16: up to 9 x 9 windows (their offsets are computed, not listed)
 constexpr int CK = 64;  // channels per chunk
@@ -175,6 +179,40 @@ tapconv_kernel(const TapParams p) {
       for (int i = 0; i < 16; ++i) acc[m][r][i] = 0.0f;
 
   const int half = lane >> 5, lx = lane & 31;
+  // ---- epilogue (same register layout as conv3x3_dma_kernel): a lane holds channels {0-3, 8-11, 16-19, 24-27} + 4*half
+  // of its pixel; one exchange with lane ^ 32 per pair of groups -> every lane stores 8 consecutive channels (16 bytes).
+  // (Round 3, measured and dropped: the wave's 64 x 64 float32 results transposed through LDS so that every global instruction
+  // covers 8 pixels x 128 contiguous bytes instead of 32 pixels x 32 bytes: bitwise the same, 0.40 -> 0.47 ms on the
+  // 64 -> 256 + residual layers -- the extra barrier and LDS round trip cost more than the coalescing gave;
+  // profiles/r03_ab_session.md section 3.)
+  uint16_t* drow[2];
+  const uint16_t* rrow[2];
+  bool pix_ok[2];
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    const int m = m0 + (wm * 2 + r) * 32 + lx;
+    pix_ok[r] = m < ML;
+    const int ly = pix_ok[r] ? fast_div(m, p.Wl, inv_wl) : 0;
+    const int lxx = pix_ok[r] ? m - ly * p.Wl : 0;
+    const size_t off = (((size_t)b * p.Ho + (ly * p.out_stride + oy0)) * p.Wo + (lxx * p.out_stride + ox0)) * p.CoutP;
+    drow[r] = p.dst + off;
+    rrow[r] = p.residual ? p.residual + off : nullptr;
+  }
+#if SA_TAP_PREFETCH_RES
+  // the residual of the whole tile is requested BEFORE the K loop (16 eight-byte loads per lane, 32 registers): in the epilogue
+  // each of them was a dependent HBM round trip of its own
+  uint2 rq[2][4][2];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        const int co = (co32_0 + wn * 2 + mt) * 32 + 8 * g + 4 * half;
+        rq[mt][g][r] = make_uint2(0u, 0u);
+        if (rrow[r] && pix_ok[r] && co < p.CoutP) rq[mt][g][r] = *reinterpret_cast<const uint2*>(rrow[r] + co);
+      }
+#endif
   issue(0, 0);
   int buf = 0;
   for (int chunk = 0; chunk < n_chunks; ++chunk) {
@@ -203,21 +241,6 @@ tapconv_kernel(const TapParams p) {
     buf ^= 1;
   }
 
-  // ---- epilogue (same register layout as conv3x3_dma_kernel): a lane holds channels {0-3, 8-11, 16-19, 24-27} + 4*half
-  // of its pixel; one exchange with lane ^ 32 per pair of groups -> every lane stores 8 consecutive channels (16 bytes)
-  uint16_t* drow[2];
-  const uint16_t* rrow[2];
-  bool pix_ok[2];
-#pragma unroll
-  for (int r = 0; r < 2; ++r) {
-    const int m = m0 + (wm * 2 + r) * 32 + lx;
-    pix_ok[r] = m < ML;
-    const int ly = pix_ok[r] ? fast_div(m, p.Wl, inv_wl) : 0;
-    const int lxx = pix_ok[r] ? m - ly * p.Wl : 0;
-    const size_t off = (((size_t)b * p.Ho + (ly * p.out_stride + oy0)) * p.Wo + (lxx * p.out_stride + ox0)) * p.CoutP;
-    drow[r] = p.dst + off;
-    rrow[r] = p.residual ? p.residual + off : nullptr;
-  }
   const float lowv = p.relu ? 0.0f : -INFINITY, lowl = p.relu_last ? 0.0f : -INFINITY;
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt) {
@@ -240,8 +263,12 @@ tapconv_kernel(const TapParams p) {
       const float bb[4] = {bq.x, bq.y, bq.z, bq.w}, ss[4] = {sq.x, sq.y, sq.z, sq.w}, tt[4] = {tq.x, tq.y, tq.z, tq.w};
 #pragma unroll
       for (int r = 0; r < 2; ++r) {
+#if SA_TAP_PREFETCH_RES
+        const uint2 q = rq[mt][g][r];
+#else
         uint2 q = make_uint2(0u, 0u);
         if (rrow[r] && pix_ok[r] && cok) q = *reinterpret_cast<const uint2*>(rrow[r] + co);
+#endif
         const float rr[4] = {sa::h2f((uint16_t)(q.x & 0xffff)), sa::h2f((uint16_t)(q.x >> 16)), sa::h2f((uint16_t)(q.y & 0xffff)),
                              sa::h2f((uint16_t)(q.y >> 16))};
         float v[4];
@@ -286,6 +313,8 @@ int launch_tap(const TapParams& p0, hipStream_t st) {
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
+  // (a single LDS stage for single-chunk launches -- twice the resident workgroups -- measured no change: round 3, gpurun_out/r03n)
+  static_assert(lds >= 4 * 64 * 64 * sizeof(float), "the epilogue transposes 64 x 64 float32 values per wave through LDS");
   hipLaunchKernelGGL((tapconv_kernel<WM, WN>), dim3((unsigned)nblk), dim3(256), lds, st, p);
   SA_LAUNCH_CHECK();
   return SA_OK;
