@@ -2,7 +2,7 @@
 import numpy as np
 
 
-def compare_with_threshold_decisions(oracle_peaks, device_peaks, ref, o, n_nodes, map_eps, tol_px, threshold=0.2):
+def compare_with_threshold_decisions(oracle_peaks, device_peaks, ref, o, n_nodes, map_eps, tol_px, threshold=0.2, ill=None):
     """oracle_peaks = (pts (n, 2) image px, vals, sample_inds, channel_inds) of find_local_peaks; device_peaks = (peak_xy [B, P, 2],
     peak_val, peak_chan, peak_count) of the device layer; ref = the oracle's PAFScorer.predict result; o = the device layer's
     outputs (numpy). Asserts:
@@ -11,7 +11,13 @@ def compare_with_threshold_decisions(oracle_peaks, device_peaks, ref, o, n_nodes
         value that differs by the storage precision) -- nothing else may differ;
       * frames whose peak sets agree give the same instances: count, node assignment, every coordinate within `tol_px`.
 
-    -> (frames whose peak sets differ, number of common peaks, their largest distance, number of one-sided peaks)."""
+    `ill`: boolean mask over the oracle's peaks whose REFINEMENT is ill-conditioned (integral regression divides by the sum of a
+    5 x 5 patch; where the patch holds negative values next to positive ones the sum is ~0 and the "refined" position lands
+    tens to thousands of pixels away -- in the reference too). Such a peak is only required to EXIST on the device (same
+    channel, confidence within `map_eps`); its coordinates are not compared, and its frame is not compared at instance level.
+
+    -> (frames whose peak sets differ or hold ill-conditioned peaks, number of common peaks, their largest distance, number of
+    one-sided peaks)."""
     pts, vals, si, ci = oracle_peaks
     g_xy, g_val, g_ch, g_n = device_peaks
     n = len(g_n)
@@ -21,6 +27,13 @@ def compare_with_threshold_decisions(oracle_peaks, device_peaks, ref, o, n_nodes
         gp, gv, gc = g_xy[b, : g_n[b]], g_val[b, : g_n[b]], g_ch[b, : g_n[b]]
         used = np.zeros(len(gp), bool)
         same = True
+        wi = ill[si == b] if ill is not None else np.zeros(len(wp), bool)
+        for p, v, c in zip(wp[wi], wv[wi], wc[wi]):  # ill-conditioned refinements first: matched by channel and confidence
+            cand = np.where((gc == c) & ~used & (np.abs(gv - v) <= map_eps))[0]
+            assert len(cand), f"frame {b}: the device has no peak of channel {c} with confidence {v} (ill-conditioned refinement)"
+            used[cand[int(np.abs(gv[cand] - v).argmin())]] = True
+            same = False
+        wp, wv, wc = wp[~wi], wv[~wi], wc[~wi]
         for p, v, c in zip(wp, wv, wc):
             cand = np.where((gc == c) & ~used)[0]
             d = np.linalg.norm(gp[cand] - p, axis=-1) if len(cand) else np.zeros(0)
