@@ -48,7 +48,7 @@ TASKS = {
                                   upsampling=dict(output_stride=4, method="transposed_conv", skip_connections="concatenate",
                                                   filters=64, refine_convs=2)),
                       heads=[("MultiInstanceConfmapsHead", 24, 4), ("PartAffinityFieldsHead", 46, 8)],
-                      freeze=r"^conv[45]_", steps=2000, batch=8, pool=64, loss_margin=0),
+                      freeze=r"^conv[45]_", steps=3000, batch=8, pool=64, loss_margin=0, nonneg=50.0),
 }
 
 

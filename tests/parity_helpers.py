@@ -60,3 +60,19 @@ def compare_with_threshold_decisions(oracle_peaks, device_peaks, ref, o, n_nodes
         if np.isfinite(got).any():
             assert float(np.nanmax(np.linalg.norm(got - want, axis=-1))) <= tol_px
     return differing, n_common, worst, n_only
+
+
+def integral_refinement_is_ill_conditioned(cms, refined_grid, rough_grid, sample_inds, channel_inds, min_ratio=0.6, max_offset=1.0):
+    """Which peaks of find_local_peaks(cms, refinement="integral") (grid units, before the stride multiplication) have an
+    ill-conditioned refinement: integral regression (peak_finding.py:78-132) is the centroid of a 5 x 5 patch, i.e. a division by
+    the patch SUM -- where the map has negative lobes around a maximum the sum is small against the sum of magnitudes and the
+    quotient amplifies any difference in the map values (the reference behaves the same way). Flagged: patch sum below
+    `min_ratio` of the sum of magnitudes, or a centroid further than `max_offset` cells from the patch centre."""
+    cp = np.pad(np.asarray(cms), ((0, 0), (2, 2), (2, 2), (0, 0)))
+    ratio = np.empty(len(rough_grid))
+    for k, (p, b, c) in enumerate(zip(rough_grid, sample_inds, channel_inds)):
+        x, y = int(p[0]), int(p[1])
+        patch = cp[b, y:y + 5, x:x + 5, c]
+        ratio[k] = patch.sum() / max(float(np.abs(patch).sum()), 1e-30)
+    off = np.abs(np.asarray(refined_grid) - np.asarray(rough_grid)).max(axis=1)
+    return (ratio < min_ratio) | (off > max_offset)

@@ -281,6 +281,10 @@ def fit(task, steps=None, threads=0, seed=0, lr=2e-3, resume=False, device="cpu"
                 l = l + 20.0 * ((F.relu(o - 0.06) ** 2) * bg)[sl].mean()
                 pk = (y > 0.5) & (y >= F.max_pool2d(y, 3, 1, 1))
                 l = l + 5.0 * ((F.relu(0.6 - o) ** 2) * pk.float())[sl].sum() / max(int(pk[sl].sum()), 1)
+                if t.get("nonneg"):
+                    # confidence maps with negative lobes make integral refinement (centroid of a 5 x 5 patch = a division by
+                    # the patch sum) ill-conditioned wherever the lobes cancel the peak: keep the maps (nearly) non-negative
+                    l = l + float(t["nonneg"]) * (F.relu(-o) ** 2)[sl].mean()
             else:
                 l = ((1.0 + 5.0 * y.abs()) * (o - y) ** 2)[sl].mean()
             parts.append(float(l.detach()))
