@@ -1,0 +1,48 @@
+"""Diagnostic (not a test): for the configs[4] ResNet task model, list the oracle peaks without a device peak of the same channel
+within 2 px, with the nearest device peak and the map values of both paths at both grid cells.   python tests/diagnostics/c4_unmatched_peaks.py"""
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, ".")
+sys.path.insert(0, "tests")
+from oracle import peak_finding as opf  # noqa: E402
+from oracle.keras_graph import KerasGraph, preprocess  # noqa: E402
+from sleap_amd import config_models as C  # noqa: E402
+from sleap_amd.nn.engine import DeviceNetwork  # noqa: E402
+from sleap_amd.nn.inference import BottomUpPredictor  # noqa: E402
+
+task = "c4_resnet"
+frames, _ = C.render(task, 3, seed=304)
+mc, w = C.load_task_weights(task, 1024, 1024)
+cms = KerasGraph(mc, w)(preprocess(frames))[0]
+pts, vals, si, ci = opf.find_local_peaks(cms, 0.2, "integral", 5)
+rough = opf.find_local_peaks_rough(cms, 0.2)[0]
+pts4 = pts * np.float32(4)
+net = DeviceNetwork(mc, w, dtype="fp16")
+pred = BottomUpPredictor(bottomup_config=C.training_config(task), bottomup_model=net, batch_size=3, verbosity="none")
+layer = pred.inference_model.bottomup_layer
+layer.return_paf_graph = True
+layer.return_confmaps = True
+o = {k: v.cpu().numpy() for k, v in pred.inference_model.call_checked(torch.from_numpy(frames).cuda()).items() if isinstance(v, torch.Tensor)}
+dcm = o["confmaps"]
+print("max |device map - oracle map|:", float(np.abs(dcm - cms).max()), "range", float(cms.max()))
+g_xy, g_val, g_ch, g_n = (o[k] for k in ("peaks", "peak_vals", "peak_channel_inds", "peak_count"))
+n_un = 0
+for b in range(3):
+    gp, gv, gc = g_xy[b, : g_n[b]], g_val[b, : g_n[b]], g_ch[b, : g_n[b]]
+    m = si == b
+    for p, v, c, r in zip(pts4[m], vals[m], ci[m], rough[m]):
+        cand = np.where(gc == c)[0]
+        d = np.linalg.norm(gp[cand] - p, axis=-1)
+        if not len(cand) or d.min() > 2.0:
+            n_un += 1
+            j = cand[int(d.argmin())] if len(cand) else -1
+            x, y = int(r[0]), int(r[1])
+            gx, gy = (int(round(gp[j][0] / 4)), int(round(gp[j][1] / 4))) if j >= 0 else (x, y)
+            gx, gy = min(max(gx, 0), 255), min(max(gy, 0), 255)
+            print(f"frame {b} ch {c}: oracle peak {p} val {v:.4f} grid ({x},{y}); nearest device peak {gp[j] if j >= 0 else None} "
+                  f"val {gv[j] if j >= 0 else None} dist {d.min() if len(cand) else -1:.2f}; oracle map at (oracle cell, device cell) "
+                  f"{cms[b, y, x, c]:.4f} {cms[b, gy, gx, c]:.4f}; device map {dcm[b, y, x, c]:.4f} {dcm[b, gy, gx, c]:.4f}")
+print("unmatched oracle peaks:", n_un, "of", len(pts))

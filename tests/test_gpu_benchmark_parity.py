@@ -205,8 +205,9 @@ def test_configs3_hard_frames_differences_are_threshold_decisions(workload, vari
          if isinstance(v, torch.Tensor)}
     assert not int(np.bitwise_or.reduce(o["status"])), "capacity overflow / non-finite status"
     g_xy, g_val, g_ch, g_n = (o[k] for k in ("peaks", "peak_vals", "peak_channel_inds", "peak_count"))
-    differing, n_common, worst, n_only = compare_with_threshold_decisions(
+    differing, n_common, worst, n_only, n_tie = compare_with_threshold_decisions(
         (pts, vals, si, ci), (g_xy, g_val, g_ch, g_n), ref, o, n_nodes=13, map_eps=MAP_EPS, tol_px=TOL_PX)
+    assert n_tie == 0  # (no maps handed over: near ties are not excused here)
     print(f"{variant} variant ({n} frames): {n_common} common peaks (max delta {worst:.4f} px), {near} oracle peaks within 0.05 of the threshold, "
           f"{n_only} peaks detected by one path only (all within {MAP_EPS} of the threshold), frames that differ: {differing}")
     assert worst <= TOL_PX
