@@ -410,13 +410,15 @@ def main():
             net_m = DeviceNetwork(mc, weights, dtype=args.dtype, fuse_upsample=False)
             descs_m = net_m.op_descriptions(H, W)
             accm = np.zeros(len(descs_m))
-            for r in range(3):
+            for _ in range(3):  # (its buffers are new: a few un-instrumented passes first)
+                net_m.forward(layer.preprocess(frames))
+            for r in range(reps + 1):  # same protocol as the default plan's pass above
                 prof = []
                 net_m.forward(layer.preprocess(frames), profile=prof)
                 torch.cuda.synchronize()
                 if r:
                     accm += np.array([a.elapsed_time(b) for a, b in prof])
-            accm /= 2
+            accm /= reps
             mat = {"conv_ms": float(sum(ms for (k, _, _), ms in zip(descs_m, accm) if k == "conv")), "all_ms": float(accm.sum())}
             del net_m
         # post-processing time
