@@ -392,15 +392,19 @@ conv1x1_head_kernel(const uint16_t* __restrict__ src, int CinP, const float* __r
 typedef sa::mfma_h8 head_bf16x8;
 typedef __attribute__((ext_vector_type(16))) float head_f32x16;
 
+// NT = 32-channel output tiles per pixel group (1: Cout <= 32; 2: Cout <= 64 -- round 3: the 46-channel PAF head of a 23-edge
+// skeleton (BASELINE configs[4]) ran on the VALU kernel at 0.56 TB/s)
+template <int NT>
 __global__ void __launch_bounds__(256)
 conv1x1_head_mfma_kernel(const uint16_t* __restrict__ src, int CinP, const float* __restrict__ w,
                          const float* __restrict__ bias, int Cout, int act, size_t n_pix, float* __restrict__ dst) {
 #if defined(__HIP_DEVICE_COMPILE__)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  h16x8_t* frag = reinterpret_cast<h16x8_t*>(smem_raw);  // [K16][2 terms][64 lanes]
+  h16x8_t* frag = reinterpret_cast<h16x8_t*>(smem_raw);  // [K16][NT tiles][2 terms][64 lanes]
   const int K16 = CinP / 16;
-  for (int i = threadIdx.x; i < K16 * 64; i += blockDim.x) {
-    const int k16 = i >> 6, l = i & 63, n = l & 31, k0 = k16 * 16 + (l >> 5) * 8;
+  for (int i = threadIdx.x; i < K16 * NT * 64; i += blockDim.x) {
+    const int l = i & 63, t = (i >> 6) % NT, k16 = (i >> 6) / NT;
+    const int n = t * 32 + (l & 31), k0 = k16 * 16 + (l >> 5) * 8;
     h16x8_t hi, lo;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -408,8 +412,8 @@ conv1x1_head_mfma_kernel(const uint16_t* __restrict__ src, int CinP, const float
       hi[j] = sa::f2h(v);
       lo[j] = sa::f2h(v - sa::h2f(hi[j]));
     }
-    frag[(k16 * 2 + 0) * 64 + l] = hi;
-    frag[(k16 * 2 + 1) * 64 + l] = lo;
+    frag[((k16 * NT + t) * 2 + 0) * 64 + l] = hi;
+    frag[((k16 * NT + t) * 2 + 1) * 64 + l] = lo;
   }
   __syncthreads();
   const int lane = threadIdx.x & 63, half = lane >> 5, lx = lane & 31;
@@ -419,27 +423,34 @@ conv1x1_head_mfma_kernel(const uint16_t* __restrict__ src, int CinP, const float
     const size_t p = g * 32 + lx;
     const bool ok = p < n_pix;
     const uint16_t* s = src + (ok ? p : 0) * CinP + half * 8;
-    head_f32x16 acc;
+    head_f32x16 acc[NT];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[t][i] = 0.0f;
     for (int k16 = 0; k16 < K16; ++k16) {
       const head_bf16x8 b = *reinterpret_cast<const head_bf16x8*>(s + k16 * 16);
-      const head_bf16x8 a0 = __builtin_bit_cast(head_bf16x8, frag[(k16 * 2 + 0) * 64 + lane]);
-      const head_bf16x8 a1 = __builtin_bit_cast(head_bf16x8, frag[(k16 * 2 + 1) * 64 + lane]);
-      acc = SA_MFMA_32x32x16(a0, b, acc, 0, 0, 0);
-      acc = SA_MFMA_32x32x16(a1, b, acc, 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const head_bf16x8 a0 = __builtin_bit_cast(head_bf16x8, frag[((k16 * NT + t) * 2 + 0) * 64 + lane]);
+        const head_bf16x8 a1 = __builtin_bit_cast(head_bf16x8, frag[((k16 * NT + t) * 2 + 1) * 64 + lane]);
+        acc[t] = SA_MFMA_32x32x16(a0, b, acc[t], 0, 0, 0);
+        acc[t] = SA_MFMA_32x32x16(a1, b, acc[t], 0, 0, 0);
+      }
     }
     if (ok) {
       float* o = dst + p * Cout;
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int n = (i & 3) + 8 * (i >> 2) + 4 * half;
-        if (n < Cout) {
-          float v = acc[i] + bias[n];
-          if (act == 1) v = 1.0f / (1.0f + __expf(-v));
-          o[n] = v;
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int n = t * 32 + (i & 3) + 8 * (i >> 2) + 4 * half;
+          if (n < Cout) {
+            float v = acc[t][i] + bias[n];
+            if (act == 1) v = 1.0f / (1.0f + __expf(-v));
+            o[n] = v;
+          }
         }
-      }
     }
   }
 #endif
@@ -653,12 +664,17 @@ int sa_conv1x1_head(const void* src, int CinP, const float* w, const float* bias
   SA_REQUIRE(CinP % 8 == 0 && Cout > 0, "sa_conv1x1_head: CinP%%8 != 0 or Cout <= 0");
   SA_REQUIRE(act == 0 || act == 1, "sa_conv1x1_head: act must be 0 (linear) or 1 (sigmoid)");
   const size_t n_pix_all = (size_t)B * H * W;
-  if (Cout <= 32 && CinP % 16 == 0 && (size_t)CinP / 16 * 2048 <= 64 * 1024) {
-    const size_t lds_m = (size_t)CinP / 16 * 2048;
+  const int nt = Cout <= 32 ? 1 : 2;
+  if (Cout <= 64 && CinP % 16 == 0 && (size_t)CinP / 16 * 2048 * nt <= 64 * 1024) {
+    const size_t lds_m = (size_t)CinP / 16 * 2048 * nt;
     const size_t groups = (n_pix_all + 31) / 32;
     const int grid = (int)std::min<size_t>((groups + 3) / 4, 256 * 8);
-    hipLaunchKernelGGL(conv1x1_head_mfma_kernel, dim3(grid), dim3(256), lds_m, (hipStream_t)stream, (const uint16_t*)src,
-                       CinP, w, bias, Cout, act, n_pix_all, dst);
+    if (nt == 1)
+      hipLaunchKernelGGL(conv1x1_head_mfma_kernel<1>, dim3(grid), dim3(256), lds_m, (hipStream_t)stream, (const uint16_t*)src,
+                         CinP, w, bias, Cout, act, n_pix_all, dst);
+    else
+      hipLaunchKernelGGL(conv1x1_head_mfma_kernel<2>, dim3(grid), dim3(256), lds_m, (hipStream_t)stream, (const uint16_t*)src,
+                         CinP, w, bias, Cout, act, n_pix_all, dst);
     SA_LAUNCH_CHECK();
     return SA_OK;
   }

@@ -168,6 +168,15 @@ def test_small_layers_vs_torch():
     o = torch.empty((2, 12, 20, 13), dtype=torch.float32, device="cuda")
     check(h.sa_conv1x1_head(_ptr(xd), 32, _ptr(d_w), _ptr(d_b), 13, 0, 2, 12, 20, _ptr(o), _stream()), "head")
     _close(o.cpu(), _bf(x) @ wk.T + bk, 1e-4, 1e-5)
+    # ... with 33-64 output channels (the 46-channel PAF head of a 23-edge skeleton, BASELINE configs[4]): two 32-channel tiles
+    # of the matrix-core kernel; > 64 channels: the VALU kernel
+    for cout in (46, 64, 70):
+        wk2 = torch.randn((cout, 32), generator=g)
+        bk2 = torch.randn((cout,), generator=g)
+        o2 = torch.empty((2, 12, 20, cout), dtype=torch.float32, device="cuda")
+        d_w2, d_b2 = wk2.cuda(), bk2.cuda()  # (kept alive: a temporary's memory would be handed to the next allocation)
+        check(h.sa_conv1x1_head(_ptr(xd), 32, _ptr(d_w2), _ptr(d_b2), cout, 0, 2, 12, 20, _ptr(o2), _stream()), "head")
+        _close(o2.cpu(), _bf(x) @ wk2.T + bk2, 1e-4, 1e-5)
     # transposed conv k3 s2 same == full transposed conv cropped at the end
     kt = torch.randn((3, 3, 16, 32), generator=g) * 0.1  # (kh, kw, Cout, Cin)
     bt = torch.randn((16,), generator=g)
