@@ -3,7 +3,7 @@ import numpy as np
 
 
 def compare_with_threshold_decisions(oracle_peaks, device_peaks, ref, o, n_nodes, map_eps, tol_px, threshold=0.2, ill=None,
-                                     cms=None, stride=4, strict_instances=True, stats=None):
+                                     cms=None, stride=4, strict_instances=True, stats=None, rough_grid=None):
     """oracle_peaks = (pts (n, 2) image px, vals, sample_inds, channel_inds) of find_local_peaks; device_peaks = (peak_xy [B, P, 2],
     peak_val, peak_chan, peak_count) of the device layer; ref = the oracle's PAFScorer.predict result; o = the device layer's
     outputs (numpy). The two paths compute the same maps up to the storage precision (`map_eps`); every DECISION taken on
@@ -15,6 +15,9 @@ def compare_with_threshold_decisions(oracle_peaks, device_peaks, ref, o, n_nodes
       * NEAR TIE (needs the oracle's maps `cms`): the device's maximum sits in a NEIGHBOURING grid cell of the oracle's and the
         oracle's own map values at the two cells differ by <= `map_eps` (which of two nearly equal cells is "the" local maximum
         is decided by the last bits; the refined positions then differ by up to a cell). Counted, not compared;
+      * RIDGE (needs `cms` and the oracle's grid maxima `rough_grid`): an oracle maximum that exceeds one of its eight neighbours
+        by <= 2 `map_eps` need not be a strict local maximum of the device's map at all (and vice versa) -- excused, counted
+        with the near ties;
       * `ill`: boolean mask over the oracle's peaks whose REFINEMENT is ill-conditioned (integral regression divides by the
         sum of a 5 x 5 patch; where negative lobes cancel the peak the "refined" position lands anywhere -- in the reference
         too). Such a peak is only required to EXIST on the device (same channel, confidence within `map_eps`);
@@ -68,6 +71,14 @@ def compare_with_threshold_decisions(oracle_peaks, device_peaks, ref, o, n_nodes
             if not len(cand) and abs(float(v) - threshold) <= map_eps:
                 n_only += 1
                 continue
+            if not len(cand) and cms is not None and rough_grid is not None:
+                x, y = (int(q) for q in rough_grid[np.where(m)[0][k]])
+                nb = np.pad(cms[b, :, :, c], 1, constant_values=-np.inf)[y:y + 3, x:x + 3].copy()
+                centre = nb[1, 1]
+                nb[1, 1] = -np.inf
+                if centre - nb.max() <= 2 * map_eps:  # a ridge: not necessarily a strict maximum of the other path's map
+                    n_tie += 1
+                    continue
             assert len(cand), f"frame {b}: the device has no peak of channel {c} with confidence {v} (ill-conditioned refinement)"
             dd = np.linalg.norm(gp[cand] - p, axis=-1)
             used[cand[int(dd.argmin())]] = True
