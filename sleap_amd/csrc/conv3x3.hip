@@ -923,20 +923,42 @@ conv3x3_dma_kernel(const ConvParams2 p) {
       }
     }
     const float lowv = p.relu ? 0.0f : -INFINITY;  // ReLU as one v_max against a wave-uniform bound
+    // EXT: the residual of this lane's outputs, four channels (8 bytes) per load, all R x 4 loads of the cout tile in flight
+    // together (round 3: it was one 2-byte load per VALUE, each behind its own address arithmetic -- the residual 3x3 convs of
+    // the hourglass ran at 0.79 PFLOP/s against 0.99 without a residual)
+    float rres[EXT ? R : 1][4][4];
+    if constexpr (EXT) {
+      if (p.residual) {
+        uint2 q[R][4];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          const int gy = y0 + wave * R + r;
+          const size_t ri = p.res_mode ? (((size_t)b * (H / 2) + (gy >> 1)) * (W / 2) + (gx >> 1)) : (((size_t)b * H + gy) * W + gx);
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const int co = cobase + 8 * g + 4 * half;
+            q[r][g] = make_uint2(0u, 0u);
+            if (gy < H && gx < W && co < p.CoutP) q[r][g] = *reinterpret_cast<const uint2*>(p.residual + ri * p.CoutP + co);
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            rres[r][g][0] = sa::h2f((uint16_t)(q[r][g].x & 0xffff));
+            rres[r][g][1] = sa::h2f((uint16_t)(q[r][g].x >> 16));
+            rres[r][g][2] = sa::h2f((uint16_t)(q[r][g].y & 0xffff));
+            rres[r][g][3] = sa::h2f((uint16_t)(q[r][g].y >> 16));
+          }
+      }
+    }
     auto act = [&](int r, int g, int j) {
       float t = acc[m][r][4 * g + j];
       if constexpr (!BIAS_INIT) t += bb[g][j];  // (with the bias as the accumulators' initial value there is nothing to add:
       t = fmaxf(t, lowv);                       //  an `acc + 0.0f` is NOT dropped by the compiler -- 112 dead v_add per tile)
       if constexpr (EXT) {
         t = fmaf(t, ps[g][j], pt[g][j]);
-        if (p.residual) {
-          const int gy = y0 + wave * R + r, co = cobase + 8 * g + 4 * half + j;
-          if (gy < H && gx < W && co < p.CoutP) {
-            const size_t ri = p.res_mode ? (((size_t)b * (H / 2) + (gy >> 1)) * (W / 2) + (gx >> 1))
-                                         : (((size_t)b * H + gy) * W + gx);
-            t += sa::h2f(p.residual[ri * p.CoutP + co]);
-          }
-        }
+        if (p.residual) t += rres[r][g][j];
         if (p.relu_last) t = fmaxf(t, 0.0f);
       }
       return t;
