@@ -328,7 +328,8 @@ int sa_convt3x3s2_bf16(const void* src, int CinP, const void* w, const float* bi
  * tile_channels, in_affine = {scale[CinW], shift[CinW]} applied to every in-bounds tap is imagenet_preproc_v1
  * (the BGR flip is a permutation of the weight channels done by the caller).
  *   src [B,H,W,Cin] u8|f32; w [kh][kw][CinW][CoutP] f32; post_scale/post_shift [CoutP] or NULL (BN after ReLU);
- *   dst [B,Ho,Wo,CoutP] bf16 */
+ *   dst [B,Ho,Wo,CoutP] bf16.  `relu`: bit 0 = ReLU; `relu | SA_LAYOUT_PLANES16` writes dst as 16-channel planes
+ *   [B,CoutP/16,Ho,Wo,16] (sa_imgconv_u8_bf16 alike) -- the first launch of a plan that runs on planes */
 int sa_image_conv_bf16(const void* src, int src_is_u8, int B, int H, int W, int Cin, int CinW, const float* in_affine,
                        int kh, int kw, int stride, int pad_top, int pad_left, int Ho, int Wo, const float* w, const float* bias, int CoutP, int relu,
                        const float* post_scale, const float* post_shift, void* dst, sa_stream_t stream);
@@ -393,7 +394,8 @@ int sa_upsample2x_bf16(const void* src, int B, int H, int W, int CP, int bilinea
                        sa_stream_t stream);
 
 /* Head.make_head: Conv2D(k1, activation) (heads.py:42-62).  w [Cout][CinP] f32, dst [B,H,W,Cout] f32
- * act: 0 linear (all pose heads), 1 sigmoid (ClassMapsHead; identity heads are otherwise out of scope) */
+ * act: 0 linear (all pose heads), 1 sigmoid (ClassMapsHead; identity heads are otherwise out of scope);
+ * `act | SA_LAYOUT_PLANES16`: src is 16-channel planes [B,CinP/16,H,W,16] (Cout <= 64: the matrix-core kernel; dst NHWC f32) */
 int sa_conv1x1_head(const void* src, int CinP, const float* w, const float* bias, int Cout, int act,
                     int B, int H, int W, float* dst, sa_stream_t stream);
 

@@ -300,8 +300,13 @@ __device__ __forceinline__ int swz(int p) {
 // instead of in front of it. Measured on MI355X (profiles/r02_ab_session.md section 13): t = 2..4 takes 3-7 % off every layer with
 // >= 8 chunks (512->512 @32: 0.196 -> 0.182 ms, 768->256 @64: 0.557 -> 0.525), t >= 6 leaves the copy too little time, and the
 // 2-4 chunk 256 x 256 layers lose 3-5 % with any t > 0.
+// SA_CONV_EXT_WG2: the extended-epilogue kernels on 16-channel chunks keep to 128 registers (two workgroups per CU) like the
+// plain ones (0: 148 registers, one workgroup per CU -- A/B builds)
+#if !defined(SA_CONV_EXT_WG2)
+#define SA_CONV_EXT_WG2 1
+#endif
 template <int MT, int CK, int NW, int R, int NBUF, bool HEADS, int STEM_CIN, bool EXT, bool UPS, int ITAP>
-__global__ void __launch_bounds__(NW * 64, (NW == 8 && MT <= 2 && NBUF == 2 && !EXT && CK == 16 && STEM_CIN == 0) ? 4 : 1)
+__global__ void __launch_bounds__(NW * 64, (NW == 8 && MT <= 2 && NBUF == 2 && (!EXT || SA_CONV_EXT_WG2) && CK == 16 && STEM_CIN == 0) ? 4 : 1)
 conv3x3_dma_kernel(const ConvParams2 p) {
 #if defined(__HIP_DEVICE_COMPILE__)  // the body uses device-only types (buffer resources); the host pass only needs the stub
   constexpr int TH = NW * R, TW = 32, PH = TH + 2, PW = TW + 2;
@@ -933,12 +938,19 @@ conv3x3_dma_kernel(const ConvParams2 p) {
 #pragma unroll
         for (int r = 0; r < R; ++r) {
           const int gy = y0 + wave * R + r;
-          const size_t ri = p.res_mode ? (((size_t)b * (H / 2) + (gy >> 1)) * (W / 2) + (gx >> 1)) : (((size_t)b * H + gy) * W + gx);
+          // the residual has the output's layout (NHWC or 16-channel planes: pixel stride / 16-channel-block stride), at the
+          // output's resolution or at half of it (res_mode 1: UpSampling2D(nearest) folded in)
+          const int hr = p.res_mode ? H / 2 : H, wr = p.res_mode ? W / 2 : W;
+          const size_t pix = p.res_mode ? (size_t)(gy >> 1) * wr + (gx >> 1) : (size_t)gy * wr + gx;
+          const unsigned char* rf = reinterpret_cast<const unsigned char*>(p.residual) + (size_t)b * hr * wr * p.CoutP * 2 +
+                                    pix * p.out_pix_bytes;
+          const unsigned rblk = p.res_mode ? p.out_blk_bytes_pool : p.out_blk_bytes;
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
             const int co = cobase + 8 * g + 4 * half;
             q[r][g] = make_uint2(0u, 0u);
-            if (gy < H && gx < W && co < p.CoutP) q[r][g] = *reinterpret_cast<const uint2*>(p.residual + ri * p.CoutP + co);
+            if (gy < H && gx < W && co < p.CoutP)
+              q[r][g] = *reinterpret_cast<const uint2*>(rf + (size_t)(co >> 4) * rblk + (co & 15) * 2);
           }
         }
 #pragma unroll
@@ -1214,6 +1226,9 @@ template <int MT, int CK>
 int launch2_pick(const ConvParams2& p, hipStream_t st) {
   if (p.post_scale || p.residual || p.relu_last) {  // extended epilogue
     if ((p.C0P + p.C1P) == CK) return launch2<MT, CK, 4, 2, 1, false, 0, true>(p, st);
+    // (CK == 16, planes: the mid-chunk variant holds 2 workgroups per CU -- 128 registers -- without spills, the other one
+    //  spills 21, so every multi-chunk layer takes it; hourglass 3x3 convs: 1.0 -> see profiles/r03_ab_session.md section 5)
+    if constexpr (CK == 16) return launch2<MT, CK, 8, 2, 2, false, 0, true, false, SA_CONV_ITAP>(p, st);
     return late_issue((p.C0P + p.C1P) / CK) ? launch2<MT, CK, 8, 2, 2, false, 0, true, false, SA_CONV_ITAP>(p, st)
                                             : launch2<MT, CK, 8, 2, 2, false, 0, true>(p, st);
   }
@@ -1337,7 +1352,6 @@ static int conv3x3_impl(const void* src0, int C0P, const void* src1, int C1P, in
     q.res_mode = res_mode;
     q.relu_last = relu_last;
     q.planar = planar;
-    SA_REQUIRE(!planar || !residual, "sa_conv3x3: SA_LAYOUT_PLANES16 does not cover the residual input of the extended epilogue");
     SA_REQUIRE(!(post_scale || residual || relu_last) || n_heads == 0, "sa_conv3x3: extended epilogue and fused heads are exclusive");
     SA_REQUIRE(!post_scale == !post_shift, "sa_conv3x3: post_scale and post_shift come together");
     SA_REQUIRE(!(residual && res_mode) || (H % 2 == 0 && W % 2 == 0), "sa_conv3x3: half-resolution residual needs even H, W");

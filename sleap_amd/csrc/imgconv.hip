@@ -34,6 +34,7 @@ struct ImgConvParams {
   const float* post_shift;
   uint16_t* dst;         // [B,Ho,Wo,CoutP] bf16
   int B, H, W, Ho, Wo, CoutP, pad_t, pad_l, relu, has_mean, src_c;
+  int planar;            // dst in 16-channel planes [B, CoutP/16, Ho, Wo, 16] instead of NHWC
   int tiles_x, tiles_y;
 };
 
@@ -167,8 +168,11 @@ imgconv_mfma_kernel(const ImgConvParams p) {
           sa::swap32(x.x, y.x);
           sa::swap32(x.y, y.y);
           const int co = cobase + 16 * pr + 8 * half;
-          if (ok && co < p.CoutP)
-            *reinterpret_cast<uint4*>(p.dst + (((size_t)b * p.Ho + gy) * p.Wo + gx) * p.CoutP + co) = make_uint4(x.x, x.y, y.x, y.y);
+          if (ok && co < p.CoutP) {
+            uint16_t* o = p.planar ? p.dst + (((size_t)b * (p.CoutP >> 4) + (co >> 4)) * p.Ho * p.Wo + (size_t)gy * p.Wo + gx) * 16 + (co & 15)
+                                   : p.dst + (((size_t)b * p.Ho + gy) * p.Wo + gx) * p.CoutP + co;
+            *reinterpret_cast<uint4*>(o) = make_uint4(x.x, x.y, y.x, y.y);
+          }
         }
       }
     }
@@ -265,7 +269,8 @@ int sa_imgconv_u8_bf16(const void* src, int B, int H, int W, int Cin, int CinW, 
   p.CoutP = CoutP;
   p.pad_t = pad_top;
   p.pad_l = pad_left;
-  p.relu = relu;
+  p.relu = relu & 1;  // (`relu`: bit 0 = ReLU, SA_LAYOUT_PLANES16 = write 16-channel planes)
+  p.planar = (relu & SA_LAYOUT_PLANES16) ? 1 : 0;
   p.has_mean = has_mean;
   p.src_c = Cin;
   hipStream_t st = (hipStream_t)stream;

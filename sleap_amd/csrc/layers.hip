@@ -78,7 +78,7 @@ image_conv_kernel(const void* __restrict__ src_, int is_u8, int B, int H, int W,
                   const float* __restrict__ in_affine, int kh, int kw, int stride,
                   int pad_t, int pad_l, int Ho, int Wo, const float* __restrict__ w, const float* __restrict__ bias,
                   int CoutP, int relu, const float* __restrict__ post_scale, const float* __restrict__ post_shift,
-                  uint16_t* __restrict__ dst) {
+                  uint16_t* __restrict__ dst, int planar) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   float* sw = reinterpret_cast<float*>(smem_raw);
   const int nw = kh * kw * CinW * CoutP;
@@ -120,7 +120,10 @@ image_conv_kernel(const void* __restrict__ src_, int is_u8, int B, int H, int W,
       if (post_scale) v = fmaf(v, post_scale[g * 8 + j], post_shift[g * 8 + j]);
       o[j] = sa::f2h(v);
     }
-    *reinterpret_cast<h16x8_t*>(dst + p * CoutP + g * 8) = o;
+    if (planar)  // 16-channel planes [B, CoutP/16, Ho, Wo, 16]
+      *reinterpret_cast<h16x8_t*>(dst + ((b * (CoutP / 16) + (g >> 1)) * (size_t)Ho * Wo + (size_t)y * Wo + x) * 16 + (g & 1) * 8) = o;
+    else
+      *reinterpret_cast<h16x8_t*>(dst + p * CoutP + g * 8) = o;
   }
 }
 
@@ -397,7 +400,7 @@ typedef __attribute__((ext_vector_type(16))) float head_f32x16;
 template <int NT>
 __global__ void __launch_bounds__(256)
 conv1x1_head_mfma_kernel(const uint16_t* __restrict__ src, int CinP, const float* __restrict__ w,
-                         const float* __restrict__ bias, int Cout, int act, size_t n_pix, float* __restrict__ dst) {
+                         const float* __restrict__ bias, int Cout, int act, size_t n_pix, float* __restrict__ dst, int hw_planar) {
 #if defined(__HIP_DEVICE_COMPILE__)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   h16x8_t* frag = reinterpret_cast<h16x8_t*>(smem_raw);  // [K16][NT tiles][2 terms][64 lanes]
@@ -422,14 +425,25 @@ conv1x1_head_mfma_kernel(const uint16_t* __restrict__ src, int CinP, const float
   for (size_t g = wave0; g < n_groups; g += n_waves) {
     const size_t p = g * 32 + lx;
     const bool ok = p < n_pix;
-    const uint16_t* s = src + (ok ? p : 0) * CinP + half * 8;
+    // source: NHWC rows of CinP channels, or (hw_planar = pixels per frame > 0) 16-channel planes [B, CinP/16, H*W, 16]
+    const size_t pc = ok ? p : 0;
+    const uint16_t* s;
+    size_t kstep;
+    if (hw_planar > 0) {
+      const size_t fr = pc / (size_t)hw_planar, px = pc - fr * (size_t)hw_planar;
+      s = src + (fr * K16 * (size_t)hw_planar + px) * 16 + half * 8;
+      kstep = (size_t)hw_planar * 16;
+    } else {
+      s = src + pc * CinP + half * 8;
+      kstep = 16;
+    }
     head_f32x16 acc[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[t][i] = 0.0f;
     for (int k16 = 0; k16 < K16; ++k16) {
-      const head_bf16x8 b = *reinterpret_cast<const head_bf16x8*>(s + k16 * 16);
+      const head_bf16x8 b = *reinterpret_cast<const head_bf16x8*>(s + (size_t)k16 * kstep);
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
         const head_bf16x8 a0 = __builtin_bit_cast(head_bf16x8, frag[((k16 * NT + t) * 2 + 0) * 64 + lane]);
@@ -591,6 +605,9 @@ int sa_image_conv_bf16(const void* src, int src_is_u8, int B, int H, int W, int 
   SA_REQUIRE(src && w && bias && dst, "sa_image_conv_bf16: NULL pointer");
   SA_REQUIRE(B > 0 && H > 0 && W > 0 && Cin > 0 && kh > 0 && kw > 0 && stride > 0 && Ho > 0 && Wo > 0, "sa_image_conv_bf16: bad shape");
   SA_REQUIRE(CoutP % 8 == 0, "sa_image_conv_bf16: CoutP must be a multiple of 8");
+  const int planar = (relu & SA_LAYOUT_PLANES16) ? 1 : 0;  // (`relu`: bit 0 = ReLU, SA_LAYOUT_PLANES16 = write 16-channel planes)
+  relu &= 1;
+  SA_REQUIRE(!planar || CoutP % 16 == 0, "sa_image_conv_bf16: SA_LAYOUT_PLANES16 needs CoutP % 16 == 0");
   SA_REQUIRE(CinW == Cin || Cin == 1, "sa_image_conv_bf16: CinW != Cin needs a single-channel image (tiled)");
   SA_REQUIRE(!post_scale == !post_shift, "sa_image_conv_bf16: post_scale and post_shift come together");
   const size_t lds = sizeof(float) * (size_t)kh * kw * CinW * CoutP;
@@ -598,7 +615,7 @@ int sa_image_conv_bf16(const void* src, int src_is_u8, int B, int H, int W, int 
   const size_t total = (size_t)B * Ho * Wo * (CoutP / 8);
   hipLaunchKernelGGL(image_conv_kernel, dim3(grid_for(total)), dim3(256), lds, (hipStream_t)stream, src, src_is_u8, B, H,
                      W, Cin, CinW, in_affine, kh, kw, stride, pad_top, pad_left, Ho, Wo, w, bias, CoutP, relu, post_scale, post_shift,
-                     (uint16_t*)dst);
+                     (uint16_t*)dst, planar);
   SA_LAUNCH_CHECK();
   return SA_OK;
 }
@@ -662,8 +679,11 @@ int sa_upsample2x_bf16(const void* src, int B, int H, int W, int CP, int bilinea
 int sa_conv1x1_head(const void* src, int CinP, const float* w, const float* bias, int Cout, int act,
                     int B, int H, int W, float* dst, sa_stream_t stream) {
   SA_REQUIRE(CinP % 8 == 0 && Cout > 0, "sa_conv1x1_head: CinP%%8 != 0 or Cout <= 0");
+  const int planar = (act & SA_LAYOUT_PLANES16) ? 1 : 0;  // (`act`: bit 0 = sigmoid, SA_LAYOUT_PLANES16 = src in 16-channel planes)
+  act &= ~SA_LAYOUT_PLANES16;
   SA_REQUIRE(act == 0 || act == 1, "sa_conv1x1_head: act must be 0 (linear) or 1 (sigmoid)");
   const size_t n_pix_all = (size_t)B * H * W;
+  const int hw_planar = planar ? H * W : 0;
   const int nt = Cout <= 32 ? 1 : 2;
   if (Cout <= 64 && CinP % 16 == 0 && (size_t)CinP / 16 * 2048 * nt <= 64 * 1024) {
     const size_t lds_m = (size_t)CinP / 16 * 2048 * nt;
@@ -671,13 +691,14 @@ int sa_conv1x1_head(const void* src, int CinP, const float* w, const float* bias
     const int grid = (int)std::min<size_t>((groups + 3) / 4, 256 * 8);
     if (nt == 1)
       hipLaunchKernelGGL(conv1x1_head_mfma_kernel<1>, dim3(grid), dim3(256), lds_m, (hipStream_t)stream, (const uint16_t*)src,
-                         CinP, w, bias, Cout, act, n_pix_all, dst);
+                         CinP, w, bias, Cout, act, n_pix_all, dst, hw_planar);
     else
       hipLaunchKernelGGL(conv1x1_head_mfma_kernel<2>, dim3(grid), dim3(256), lds_m, (hipStream_t)stream, (const uint16_t*)src,
-                         CinP, w, bias, Cout, act, n_pix_all, dst);
+                         CinP, w, bias, Cout, act, n_pix_all, dst, hw_planar);
     SA_LAUNCH_CHECK();
     return SA_OK;
   }
+  SA_REQUIRE(!planar, "sa_conv1x1_head: SA_LAYOUT_PLANES16 sources need the matrix-core kernel (Cout <= 64, CinP % 16 == 0)");
   constexpr int CO = 8;
   const int CoutR = (Cout + CO - 1) / CO * CO;
   const size_t lds = sizeof(float) * (size_t)CoutR * CinP;

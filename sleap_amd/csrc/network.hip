@@ -118,11 +118,16 @@ int sa_network_create(const int64_t* plan, size_t n_words, sa_network_t** out) {
   if (n->layout == SA_LAYOUT_PLANES16) {
     bool fits = true;
     for (const Op& op : n->ops) {
-      fits = fits && (op.kind == K_STEM2 || op.kind == K_PAIR || op.kind == K_UP || op.kind == K_CONV);
-      if (op.kind == K_CONV && op.a.size() >= 10)  // plain / concat sources (the second one also through the upsampling
-        fits = fits &&                            // source mode, without fused heads), no extended epilogue
-               (op.a[2] == SA_SRC1_NONE || op.a[2] == SA_SRC1_DIRECT || (op.a[2] == SA_SRC1_UPSAMPLE2X && op.a[9] == 0)) &&
-               op.a[10 + 5 * (size_t)op.a[9]] == 0;
+      fits = fits && (op.kind == K_STEM2 || op.kind == K_PAIR || op.kind == K_UP || op.kind == K_CONV || op.kind == K_IMGCONV ||
+                      op.kind == K_HEAD);
+      if (op.kind == K_CONV && op.a.size() >= 10) {  // plain / concat sources; the upsampling source mode without fused heads
+        const bool ext = op.a[10 + 5 * (size_t)op.a[9]] != 0;  // and without the extended (BN / residual) epilogue
+        fits = fits && (op.a[2] == SA_SRC1_NONE || op.a[2] == SA_SRC1_DIRECT ||
+                        (op.a[2] == SA_SRC1_UPSAMPLE2X && op.a[9] == 0 && !ext));
+      }
+      if (op.kind == K_IMGCONV) fits = fits && n->bufs[(size_t)op.a[0]].cp % 16 == 0;
+      if (op.kind == K_HEAD)  // the matrix-core head kernel (<= 64 maps); the launch itself checks its LDS budget
+        fits = fits && op.a[3] <= 64 && n->bufs[(size_t)op.a[0]].cp % 16 == 0;
     }
     for (const Out& o : n->outs) fits = fits && (o.is_f32 || n->bufs[(size_t)o.buf].cp == 16);
     if (!fits) {
@@ -293,10 +298,10 @@ int sa_network_forward(const sa_network_t* net, const void* images, int images_a
         }
         if (images_are_u8 && a[15])
           rc = sa_imgconv_u8_bf16(images, B, H, W, (int)a[3], (int)a[10], kh, st, pt, pl, oh, ow, P<void>(a[15]), P<float>(a[16]),
-                                  bc(a[0]), (int)a[4], (int)a[17], P<float>(a[8]), P<float>(a[9]), bp(a[0]), stream);
+                                  bc(a[0]), (int)a[4] | lay, (int)a[17], P<float>(a[8]), P<float>(a[9]), bp(a[0]), stream);
         else
           rc = sa_image_conv_bf16(images, images_are_u8, B, H, W, (int)a[3], (int)a[10], P<float>(a[11]), kh, kw, st, pt, pl, oh, ow,
-                                  P<float>(a[1]), P<float>(a[2]), bc(a[0]), (int)a[4], P<float>(a[8]), P<float>(a[9]), bp(a[0]),
+                                  P<float>(a[1]), P<float>(a[2]), bc(a[0]), (int)a[4] | lay, P<float>(a[8]), P<float>(a[9]), bp(a[0]),
                                   stream);
         break;
       }
@@ -304,7 +309,7 @@ int sa_network_forward(const sa_network_t* net, const void* images, int images_a
         rc = sa_add_bf16(bp(a[0]), bp(a[1]), B, bh(a[4]), bw(a[4]), bc(a[4]), (int)a[2], (int)a[3], bp(a[4]), stream);
         break;
       case K_HEAD:  // [s, w, bias, c, act, o]
-        rc = sa_conv1x1_head(bp(a[0]), bc(a[0]), P<float>(a[1]), P<float>(a[2]), (int)a[3], (int)a[4], B, bh(a[0]), bw(a[0]),
+        rc = sa_conv1x1_head(bp(a[0]), bc(a[0]), P<float>(a[1]), P<float>(a[2]), (int)a[3], (int)a[4] | lay, B, bh(a[0]), bw(a[0]),
                              static_cast<float*>(bp(a[5])), stream);
         break;
       case K_POOL:  // [s, o]

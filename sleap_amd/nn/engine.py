@@ -602,9 +602,11 @@ class DeviceNetwork:
     def _pick_layout(self) -> int:
         """SA_LAYOUT_PLANES16 when every launch of the plan can read and write 16-channel planes (include/sleap_amd.h): the
         fused stem, the fused encoder block, 3x3 convs on the DMA path (plain / concatenated sources, fused heads, pooled
-        copies) and the materialised upsampling; 16-bit model outputs only with 16 padded channels (the same bytes in both
-        layouts). Anything else in the plan (1x1 / transposed / first-layer convs, residual epilogues, un-fused heads and
-        pools) keeps the whole network NHWC -- one layout per plan, no conversion launches."""
+        copies, BatchNormalization / residual epilogues), the materialised upsampling, first-layer convs on the image and
+        un-fused 1x1 heads of <= 64 channels (the last three since round 3: the whole hourglass family); 16-bit model outputs
+        only with 16 padded channels (the same bytes in both layouts). Anything else in the plan (1x1 / transposed convs,
+        stand-alone pools and adds: the ResNet family) keeps the whole network NHWC -- one layout per plan, no conversion
+        launches."""
         req = self._layout_request
         if req not in (None, "nhwc", "planes16"):
             raise ValueError(f"layout must be 'nhwc' or 'planes16', got {req!r}")
@@ -613,8 +615,15 @@ class DeviceNetwork:
             k = op[0]
             if k in ("stem2", "pair", "up"):
                 return True
-            if k != "conv" or op.ext is not None:
+            if k == "imgconv":  # first-layer conv on the raw image (hourglass / ResNet stems): writes planes (round 3)
+                return op[1].cp % 16 == 0
+            if k == "head":  # un-fused 1x1 head on the matrix cores: reads planes (round 3); <= 64 output channels
+                s_, o_ = op[1], op[2]
+                return o_.c <= 64 and s_.cp % 16 == 0 and s_.cp // 16 * 2048 * (1 if o_.c <= 32 else 2) <= 64 * 1024
+            if k != "conv":
                 return False
+            if op.ext is not None:  # BatchNormalization / residual epilogue: plane-capable since round 3 (plain sources only)
+                return op.mode in (_lib.SRC1_NONE, _lib.SRC1_DIRECT)
             return op.mode in (_lib.SRC1_NONE, _lib.SRC1_DIRECT) or (op.mode == _lib.SRC1_UPSAMPLE2X and not op.heads)
 
         ok = all(fits(op) for op in self.plan) and all(o.kind == "f32out" or o.cp == 16 for o in self.outputs)
@@ -1164,7 +1173,7 @@ class DeviceNetwork:
                     pt_, pl_ = pads
                 if is_u8 and mf is not None:
                     check(h.sa_imgconv_u8_bf16(_ptr(imgs), B, H, W, cin, cin_w, k[0], stride, pt_, pl_, oh, ow, _ptr(mf["w"]),
-                                               _ptr(mf["bias"]), o.cp, relu, mf["has_mean"],
+                                               _ptr(mf["bias"]), o.cp, relu | self.layout, mf["has_mean"],
                                                _ptr(ps) if ps is not None else None, _ptr(pt) if pt is not None else None,
                                                _ptr(bufs[o.buf]), st), "sa_imgconv_u8_bf16")
                     if profile is not None:
@@ -1173,7 +1182,7 @@ class DeviceNetwork:
                 check(h.sa_image_conv_bf16(_ptr(imgs), is_u8, B, H, W, cin, cin_w,
                                            _ptr(in_affine) if in_affine is not None else None, k[0], k[1], stride, pt_, pl_,
                                            oh, ow, _ptr(w),
-                                           _ptr(bias), o.cp, relu, _ptr(ps) if ps is not None else None,
+                                           _ptr(bias), o.cp, relu | self.layout, _ptr(ps) if ps is not None else None,
                                            _ptr(pt) if pt is not None else None, _ptr(bufs[o.buf]), st), "sa_image_conv_bf16")
             elif kind == "add":
                 _, a, b, half, relu, o = op
@@ -1190,7 +1199,7 @@ class DeviceNetwork:
             elif kind == "head":
                 _, s, o, w, bias, act = op
                 sh, sw = hw(s)
-                check(h.sa_conv1x1_head(_ptr(bufs[s.buf]), s.cp, _ptr(w), _ptr(bias), o.c, act, B, sh, sw,
+                check(h.sa_conv1x1_head(_ptr(bufs[s.buf]), s.cp, _ptr(w), _ptr(bias), o.c, act | self.layout, B, sh, sw,
                                         _ptr(bufs[o.buf]), st), "sa_conv1x1_head")
             elif kind == "pool":
                 _, s, o = op

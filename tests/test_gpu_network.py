@@ -476,9 +476,13 @@ def test_network_layout_is_bitwise_neutral():
     a = DeviceNetwork(cfg, w, fuse_upsample=False)  # (the per-layer default expands one upsampling in LDS, on planes only)
     b = DeviceNetwork(cfg, w, layout="nhwc")
     assert a.planar and not b.planar
-    assert not DeviceNetwork(cfg, w, fuse_heads=False).planar and DeviceNetwork(cfg, w, fuse_upsample=True).planar
-    with pytest.raises(NotImplementedError):
-        DeviceNetwork(cfg, w, fuse_heads=False, layout="planes16")
+    assert DeviceNetwork(cfg, w, fuse_upsample=True).planar
+    # round 3: un-fused 1x1 heads read planes too (the matrix-core head kernel) -- same bits as the fused heads' NHWC twin
+    c = DeviceNetwork(cfg, w, fuse_heads=False, fuse_upsample=False)
+    d = DeviceNetwork(cfg, w, fuse_heads=False, fuse_upsample=False, layout="nhwc")
+    assert c.planar and not d.planar
+    for p_, q_ in zip([o.clone() for o in c.forward(x)], d.forward(x)):
+        assert torch.equal(p_, q_)
     base = [o.clone() for o in a.forward(x)]
     for p, q in zip(base, b.forward(x)):
         assert torch.equal(p, q)
