@@ -44,6 +44,12 @@ struct Stem16Params {
   int B, H, W, relu0, relu1, tiles_x, tiles_y;
 };
 
+#if !defined(SA_STEM16_FOLD)
+#define SA_STEM16_FOLD 1  // gray kernel: hi + mid weight terms of conv0 in one MFMA (0: one MFMA per term, A/B)
+#endif
+#if !defined(SA_STEM16_PLANES8)
+#define SA_STEM16_PLANES8 1  // gray kernel: conv0 activation tile as two 8-channel planes in LDS (0: pixel-major records, A/B)
+#endif
 // tile: 16 rows x 32 columns of output per workgroup (4 waves x 4 rows)
 #define SA_STEM16_TH 16
 #define SA_STEM16_TW 32
@@ -235,7 +241,18 @@ stem16_gray_kernel(const Stem16Params p) {
   constexpr int TH = SA_STEM16_TH, TW = SA_STEM16_TW, PH = TH + 2, PW = TW + 2, RH = TH + 4;
   constexpr int RS = 48;  // triplet-table row stride in entries: 96 dwords = 32 (mod 64) banks between kernel rows
   __shared__ __attribute__((aligned(16))) uint2 rawt[(RH + 1) * RS];  // row RH: entry 0 is the zero operand
+#if SA_STEM16_PLANES8
+  // conv0 activation tile as TWO planes of 8 channels, 16 bytes per pixel (round 3). The pixel-major record of 32 bytes put the
+  // 16 lanes of a ds_write_b64 group (16 consecutive columns, one group of 4 couts) 8 banks apart: 4 distinct bank pairs, a
+  // 4-way conflict on every conv0 store (16 LDS cycles instead of 6) -- the largest single item on the most loaded unit of this
+  // kernel. With 16-byte records the group spans 64 banks (2-way: 8 cycles), and conv1's ds_read_b128 groups
+  // ({0-3,12-15 | 20-27}: one k-half from plane 0, the other from plane 1) stay conflict-free because a plane is a
+  // multiple of 256 bytes.
+  constexpr int APLANE = ((PH * PW + 16) * 16 + 255) / 256 * 256;
+  __shared__ __attribute__((aligned(16))) unsigned char act[2 * APLANE];
+#else
   __shared__ __attribute__((aligned(16))) unsigned char act[(PH * PW + 16) * 32];
+#endif
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int n16 = lane & 15, kb = lane >> 4;
 #if defined(SA_STEM16_XCD)
@@ -290,6 +307,22 @@ stem16_gray_kernel(const Stem16Params p) {
   const float4 q0 = *reinterpret_cast<const float4*>(biases + kb * 4);
   const float4 q1 = *reinterpret_cast<const float4*>(biases + 16 + kb * 4);
   const float bias0[4] = {q0.x, q0.y, q0.z, q0.w}, bias1[4] = {q1.x, q1.y, q1.z, q1.w};
+#if SA_STEM16_FOLD
+  // A lane's conv0 K block holds one kernel row: 3 taps in 8 slots. The hi and the mid term of the weight split share ONE MFMA:
+  // hi in slots 0-2, mid in slots 4-6, the pixel triplet in both halves of the B operand (products and fp32 accumulation are
+  // the same, only their order inside the matrix core differs). fp16 build: 1 MFMA per 16 halo pixels instead of 2 (a third of
+  // this kernel's matrix-core cycles went to conv0's 6 % of its FLOPs); bf16 build: 2 (hi+mid, lo) instead of 3.
+  constexpr int NMF0 = SA_STEM16_TERMS > 1 ? SA_STEM16_TERMS - 1 : 1;
+  mfma_h8 wf[NMF0];
+  {
+    const uint4 wh = __builtin_bit_cast(uint4, wa[0]), wm = __builtin_bit_cast(uint4, wa[SA_STEM16_TERMS > 1 ? 1 : 0]);
+    wf[0] = SA_STEM16_TERMS > 1 ? __builtin_bit_cast(mfma_h8, make_uint4(wh.x, wh.y, wm.x, wm.y)) : wa[0];
+    if constexpr (NMF0 > 1) wf[NMF0 - 1] = wa[2];
+  }
+#else
+  constexpr int NMF0 = SA_STEM16_TERMS;
+  const mfma_h8(&wf)[3] = wa;
+#endif
   __syncthreads();
 
   // ---- conv0 on the (PH x PW) halo tile. Columns 0..31 of every halo row are two 16-pixel groups: wave w takes column
@@ -335,9 +368,12 @@ stem16_gray_kernel(const Stem16Params p) {
     // (16 consecutive columns, one kb) then fall on 16 distinct bank pairs twice instead of 8 four times (2-way instead of
     // 4-way conflicts), and conv1's ds_read_b128 groups stay conflict-free (brute-forced over every row / column phase)
     unsigned char* dstp = act + ((wave >> 1) * PW + tx) * 32 + (((kb >> 1) ^ ((tx >> 2) & 1)) * 16) + (kb & 1) * 8;
+#elif SA_STEM16_PLANES8
+    unsigned char* dstp = act + (kb >> 1) * APLANE + ((wave >> 1) * PW + tx) * 16 + (kb & 1) * 8;
 #else
     unsigned char* dstp = act + ((wave >> 1) * PW + tx) * 32 + kb * 8;
 #endif
+    constexpr int APIX = SA_STEM16_PLANES8 ? 16 : 32;  // bytes between neighbouring pixels of the activation tile
     auto rowok = [&](int it) { return (unsigned)(y0 + (wave >> 1) + 2 * it - 1) < (unsigned)H; };  // wave uniform
     // three groups at a time: the hi / mid / lo MFMAs of one group depend on each other, those of different groups do not
     uint4 opq[3] = {make_uint4(0u, 0u, 0u, 0u), make_uint4(0u, 0u, 0u, 0u), make_uint4(0u, 0u, 0u, 0u)};
@@ -351,14 +387,18 @@ stem16_gray_kernel(const Stem16Params p) {
           const uint2 tq = src[(it + u) * sstep];
           opq[u].x = tq.x;
           opq[u].y = tq.y;
+#if SA_STEM16_FOLD
+          opq[u].z = tq.x;
+          opq[u].w = tq.y;
+#endif
           d[u] = (f32x4){bias0[0], bias0[1], bias0[2], bias0[3]};
         }
 #pragma unroll
-        for (int t = 0; t < SA_STEM16_TERMS; ++t)
+        for (int t = 0; t < NMF0; ++t)
 #pragma unroll
-          for (int u = 0; u < 3; ++u) d[u] = SA_MFMA_16x16x32(wa[t], __builtin_bit_cast(mfma_h8, opq[u]), d[u], 0, 0, 0);
+          for (int u = 0; u < 3; ++u) d[u] = SA_MFMA_16x16x32(wf[t], __builtin_bit_cast(mfma_h8, opq[u]), d[u], 0, 0, 0);
 #pragma unroll
-        for (int u = 0; u < 3; ++u) conv0_store(d[u], MASKED, MASKED && colok && rowok(it + u), dstp + (it + u) * (2 * PW * 32));
+        for (int u = 0; u < 3; ++u) conv0_store(d[u], MASKED, MASKED && colok && rowok(it + u), dstp + (it + u) * (2 * PW * APIX));
       }
     };
     if (__builtin_amdgcn_readfirstlane((int)interior))
@@ -370,12 +410,13 @@ stem16_gray_kernel(const Stem16Params p) {
       if (q < 2 * PH) {
         const int ty2 = q >> 1, tx2 = 32 + (q & 1);
         const uint2 tq = kb < 3 ? rawt[(ty2 + kb) * RS + tx2] : make_uint2(0u, 0u);
-        const mfma_h8 bf = __builtin_bit_cast(mfma_h8, make_uint4(tq.x, tq.y, 0u, 0u));
+        const mfma_h8 bf = __builtin_bit_cast(mfma_h8, SA_STEM16_FOLD ? make_uint4(tq.x, tq.y, tq.x, tq.y) : make_uint4(tq.x, tq.y, 0u, 0u));
         f32x4 d = {bias0[0], bias0[1], bias0[2], bias0[3]};
 #pragma unroll
-        for (int t = 0; t < SA_STEM16_TERMS; ++t) d = SA_MFMA_16x16x32(wa[t], bf, d, 0, 0, 0);
+        for (int t = 0; t < NMF0; ++t) d = SA_MFMA_16x16x32(wf[t], bf, d, 0, 0, 0);
         conv0_store(d, true, (unsigned)(y0 + ty2 - 1) < (unsigned)H && (unsigned)(x0 + tx2 - 1) < (unsigned)W,
-                    act + (ty2 * PW + tx2) * 32 + kb * 8);  // columns 32, 33
+                    SA_STEM16_PLANES8 ? act + (kb >> 1) * (sizeof(act) / 2) + (ty2 * PW + tx2) * 16 + (kb & 1) * 8
+                                      : act + (ty2 * PW + tx2) * 32 + kb * 8);  // columns 32, 33
       }
     }
   }
@@ -393,9 +434,12 @@ stem16_gray_kernel(const Stem16Params p) {
   int hoff[3];  // byte offset of this lane's half (channels 8 (kb & 1) ..) in the pixel record of column n16 + dx (+16 h)
 #pragma unroll
   for (int dx = 0; dx < 3; ++dx) hoff[dx] = ((kb & 1) ^ (((n16 + dx) >> 2) & 1)) * 16;
+#elif SA_STEM16_PLANES8
+  const unsigned char* abase = act + (kb & 1) * APLANE + ((wave * 4) * PW + n16) * 16;
 #else
   const unsigned char* abase = act + ((wave * 4) * PW + n16) * 32 + (kb & 1) * 16;
 #endif
+  constexpr int APIX1 = SA_STEM16_PLANES8 ? 16 : 32;
 #pragma unroll
   for (int s = 0; s < 5; ++s) {
     constexpr int dummy = 0;
@@ -405,13 +449,13 @@ stem16_gray_kernel(const Stem16Params p) {
 #if defined(SA_STEM16_SWZ)
     const unsigned char* sb = abase + off * 32 + ((kb >> 1) ? hoff[tb % 3] : hoff[ta % 3]);
 #else
-    const unsigned char* sb = abase + off * 32;
+    const unsigned char* sb = abase + off * APIX1;
 #endif
 #pragma unroll
     for (int r = 0; r < 4; ++r)
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
-        const mfma_h8 bv = *reinterpret_cast<const mfma_h8*>(sb + (r * PW + h * 16) * 32);
+        const mfma_h8 bv = *reinterpret_cast<const mfma_h8*>(sb + (r * PW + h * 16) * APIX1);
         acc[r][h] = SA_MFMA_16x16x32(wb[s], bv, acc[r][h], 0, 0, 0);
       }
   }

@@ -70,9 +70,15 @@ def test_network_plan_validation_without_gpu():
     assert h.sa_network_forward(out, 1, 1, 2, 8, 12, 1, one, 1, 16, None) == -4
     h.sa_network_destroy(out)
     planes = list(words)
-    planes[6] = _lib.LAYOUT_PLANES16  # an un-fused head launch only exists for NHWC tensors
+    planes[6] = _lib.LAYOUT_PLANES16  # round 3: the un-fused matrix-core head reads 16-channel planes (<= 64 maps)
     planes = np.array(planes, np.int64)
-    assert h.sa_network_create(planes.ctypes.data_as(C.c_void_p), planes.size, C.byref(out)) == -3 and b"PLANES16" in h.sa_last_error()
+    assert h.sa_network_create(planes.ctypes.data_as(C.c_void_p), planes.size, C.byref(out)) == 0, h.sa_last_error()
+    assert h.sa_network_layout(out) == _lib.LAYOUT_PLANES16
+    h.sa_network_destroy(out)
+    pool = list(words[:18]) + [12, 2, 0, 0]  # a stand-alone MaxPool2D launch only exists for NHWC tensors
+    pool[6] = _lib.LAYOUT_PLANES16
+    pool = np.array(pool, np.int64)
+    assert h.sa_network_create(pool.ctypes.data_as(C.c_void_p), pool.size, C.byref(out)) == -3 and b"PLANES16" in h.sa_last_error()
     trunc = np.array(words[:-2], np.int64)
     assert h.sa_network_create(trunc.ctypes.data_as(C.c_void_p), trunc.size, C.byref(out)) == -1
     assert b"truncated" in h.sa_last_error()
