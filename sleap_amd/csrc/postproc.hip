@@ -57,9 +57,6 @@ __device__ __forceinline__ void nms_emit(uint32_t e, int b, int max_peaks, uint3
 
 // One pass over the confidence maps: threshold test on coalesced float4 loads, the (rare)
 // survivors do the 8-neighbour test and append their flat (y,x,c) key to the frame's list.
-#if !defined(NMS_ILP)
-#define NMS_ILP 4
-#endif
 __global__ void __launch_bounds__(256)
 nms_scan_kernel(const float* __restrict__ cms, int H, int W, int C, float thr, int max_peaks,
                 uint32_t* __restrict__ keys, int32_t* __restrict__ counts,
@@ -69,37 +66,24 @@ nms_scan_kernel(const float* __restrict__ cms, int H, int W, int C, float thr, i
   const float* img = cms + (size_t)b * plane;
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   if (vec4) {
-    // NMS_ILP float4 loads of a thread are in flight together (one 16-byte load per thread and exit was latency-bound:
-    // 2.5 TB/s on the 218 MB of a 64-frame batch; the host sizes the grid for NMS_ILP loads per thread)
     const size_t n4 = plane / 4;
     const float4* img4 = reinterpret_cast<const float4*>(img);
-    for (size_t i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i0 < n4; i0 += stride * NMS_ILP) {
-      float4 qv[NMS_ILP];
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+      const float4 q = img4[i];
+      // inf - inf and NaN - NaN are NaN: one test for "any of the four is not finite"
+      const float qs = __fadd_rn(__fadd_rn(q.x, q.y), __fadd_rn(q.z, q.w));
+      if (__fsub_rn(qs, qs) != 0.0f) atomicOr(&status[b], SA_STATUS_NONFINITE);
+      if (!(q.x > thr || q.y > thr || q.z > thr || q.w > thr)) continue;
+      const float vals[4] = {q.x, q.y, q.z, q.w};
 #pragma unroll
-      for (int u = 0; u < NMS_ILP; ++u) {
-        const size_t i = i0 + (size_t)u * stride;
-        qv[u] = i < n4 ? img4[i] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-      }
-#pragma unroll
-      for (int u = 0; u < NMS_ILP; ++u) {
-        const size_t i = i0 + (size_t)u * stride;
-        if (i >= n4) break;
-        const float4 q = qv[u];
-        // inf - inf and NaN - NaN are NaN: one test for "any of the four is not finite"
-        const float qs = __fadd_rn(__fadd_rn(q.x, q.y), __fadd_rn(q.z, q.w));
-        if (__fsub_rn(qs, qs) != 0.0f) atomicOr(&status[b], SA_STATUS_NONFINITE);
-        if (!(q.x > thr || q.y > thr || q.z > thr || q.w > thr)) continue;
-        const float vals[4] = {q.x, q.y, q.z, q.w};
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const float v = vals[j];
-          if (!(v > thr)) continue;
-          const size_t e = i * 4 + j;
-          const int c = (int)(e % C);
-          const size_t p = e / C;
-          const int x = (int)(p % W), y = (int)(p / W);
-          if (nms_is_peak(img, H, W, C, y, x, c, v)) nms_emit((uint32_t)e, b, max_peaks, keys, counts, status);
-        }
+      for (int j = 0; j < 4; ++j) {
+        const float v = vals[j];
+        if (!(v > thr)) continue;
+        const size_t e = i * 4 + j;
+        const int c = (int)(e % C);
+        const size_t p = e / C;
+        const int x = (int)(p % W), y = (int)(p / W);
+        if (nms_is_peak(img, H, W, C, y, x, c, v)) nms_emit((uint32_t)e, b, max_peaks, keys, counts, status);
       }
     }
   } else {
@@ -1223,7 +1207,7 @@ int sa_find_local_peaks(const float* cms, const float* offsets, int B, int H, in
   const size_t plane = (size_t)H * W * C;
   const int vec4 = (plane % 4 == 0) && (((uintptr_t)cms) % 16 == 0);
   const size_t work = vec4 ? plane / 4 : plane;
-  int gx = (int)((work + 256 * (vec4 ? NMS_ILP : 1) - 1) / (256 * (vec4 ? NMS_ILP : 1)));
+  int gx = (int)((work + 255) / 256);
   if (gx > 2048) gx = 2048;
   hipLaunchKernelGGL(nms_scan_kernel, dim3(gx, B), dim3(256), 0, st, cms, H, W, C, threshold, max_peaks,
                      keys, peak_count, status, vec4);
@@ -1472,7 +1456,7 @@ int sa_bottomup_postproc(const float* cms, const float* offsets, int B, int H, i
   const size_t plane = (size_t)H * W * C;
   const int vec4 = (plane % 4 == 0) && (((uintptr_t)cms) % 16 == 0);
   const size_t work = vec4 ? plane / 4 : plane;
-  int gx = (int)((work + 256 * (vec4 ? NMS_ILP : 1) - 1) / (256 * (vec4 ? NMS_ILP : 1)));
+  int gx = (int)((work + 255) / 256);
   if (gx > 2048) gx = 2048;
   hipLaunchKernelGGL(nms_scan_kernel, dim3(gx, B), dim3(256), 0, st, cms, H, W, C, threshold, max_peaks, keys, scan_counts, status,
                      vec4);
