@@ -28,7 +28,7 @@ done
 f=$(find $O/mfma -name "*counter_collection.csv" | head -1); k=$(find $O/mfma -name "*kernel_trace.csv" | head -1)
 [ -n "$f" ] && python tools/pmc_mfma.py $f $k > $O/pmc_mfma_util.md 2>&1
 ff=$(find $O/fetch -name "*counter_collection.csv" | head -1); fw=$(find $O/write -name "*counter_collection.csv" | head -1)
-[ -n "$ff" ] && [ -n "$fw" ] && python tools/pmc_traffic.py $ff $fw 19 $O/pmc_hbm_traffic.json > $O/pmc_hbm_traffic.md 2>&1
+[ -n "$ff" ] && [ -n "$fw" ] && python tools/pmc_traffic.py $ff $fw 0 $O/pmc_hbm_traffic.json > $O/pmc_hbm_traffic.md 2>&1
 rm -rf $O/kt $O/kt_b8 $O/mfma $O/fetch $O/write
 du -sh $O; ls $O
 cut -c1-900 $O/bench_line.json

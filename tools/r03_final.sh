@@ -18,6 +18,6 @@ for d in kt kt_b8; do db=$(find $O/$d -name "*.db" | head -1); [ -n "$db" ] && p
 f=$(find $O/mfma -name "*counter_collection.csv" | head -1); k=$(find $O/mfma -name "*kernel_trace.csv" | head -1)
 [ -n "$f" ] && python tools/pmc_mfma.py $f $k > $O/pmc_mfma_util.md 2>&1
 ff=$(find $O/fetch -name "*counter_collection.csv" | head -1); fw=$(find $O/write -name "*counter_collection.csv" | head -1)
-[ -n "$ff" ] && [ -n "$fw" ] && python tools/pmc_traffic.py $ff $fw 19 $O/pmc_hbm_traffic.json > $O/pmc_hbm_traffic.md 2>&1
+[ -n "$ff" ] && [ -n "$fw" ] && python tools/pmc_traffic.py $ff $fw 0 $O/pmc_hbm_traffic.json > $O/pmc_hbm_traffic.md 2>&1
 rm -rf $O/kt $O/kt_b8 $O/mfma $O/fetch $O/write; ls $O; head -30 $O/kt_kernel_stats.md | cut -c1-200
 fi
