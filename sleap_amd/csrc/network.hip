@@ -126,8 +126,10 @@ int sa_network_create(const int64_t* plan, size_t n_words, sa_network_t** out) {
                         (op.a[2] == SA_SRC1_UPSAMPLE2X && op.a[9] == 0 && !ext));
       }
       if (op.kind == K_IMGCONV) fits = fits && n->bufs[(size_t)op.a[0]].cp % 16 == 0;
-      if (op.kind == K_HEAD)  // the matrix-core head kernel (<= 64 maps); the launch itself checks its LDS budget
-        fits = fits && op.a[3] <= 64 && n->bufs[(size_t)op.a[0]].cp % 16 == 0;
+      if (op.kind == K_HEAD) {  // the matrix-core head kernel: <= 64 maps, weights within its 64 KiB of LDS (sa_conv1x1_head)
+        const int cp = n->bufs[(size_t)op.a[0]].cp;
+        fits = fits && op.a[3] <= 64 && cp % 16 == 0 && (size_t)cp / 16 * 2048 * (op.a[3] <= 32 ? 1 : 2) <= 64 * 1024;
+      }
     }
     for (const Out& o : n->outs) fits = fits && (o.is_f32 || n->bufs[(size_t)o.buf].cp == 16);
     if (!fits) {

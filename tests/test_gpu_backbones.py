@@ -207,6 +207,28 @@ def test_hourglass_heads_vs_oracle():
     assert "add" not in kinds and "up" not in kinds and "pool" not in kinds, kinds
 
 
+@pytest.mark.parametrize("interp,cin", [("nearest", 1), ("bilinear", 3)])
+def test_hourglass_plan_on_planes_is_the_nhwc_plan_bit_for_bit(interp, cin):
+    """Round 3: hourglass plans compile to 16-channel planes (k7 first-layer convolution storing planes, 3x3 convolutions with
+    the BatchNormalization / residual epilogue, un-fused heads reading planes). Same launches, same arithmetic, another
+    address map: the NHWC twin of the plan gives identical bits."""
+    from sleap_amd.nn.engine import DeviceNetwork
+
+    from sleap_amd.nn.architectures import build_hourglass_model_config, he_normal_weights
+
+    # (no 32 -> <= 32 channel convolution in this one: that shape takes a single 32-channel chunk on NHWC tensors and two
+    #  16-channel chunks on planes -- another accumulation order, the one legitimate difference between the two plans)
+    cfg, shapes = build_hourglass_model_config((128, 160, cin), stem_stride=4, max_stride=32, output_stride=4, stem_filters=32, filters=64,
+                                               filter_increase=32, stacks=1, interp_method=interp,
+                                               heads=[("MultiInstanceConfmapsHead", 13, 4), ("PartAffinityFieldsHead", 24, 4)])
+    w = he_normal_weights(shapes, seed=1)
+    x = torch.from_numpy(np.random.default_rng(5).integers(0, 256, (3, 128, 160, cin), dtype=np.uint8)).cuda()
+    a, b = DeviceNetwork(cfg, w), DeviceNetwork(cfg, w, layout="nhwc")
+    assert a.planar and not b.planar
+    for p_, q_ in zip([o.clone() for o in a.forward(x)], b.forward(x)):
+        assert torch.equal(p_, q_)
+
+
 def test_hourglass_stacked_features_vs_oracle():
     """2-stack hourglass without heads (what the reference's own architecture test builds): both stack outputs."""
     cfg, w = _hourglass(96, 96, 2, [])
