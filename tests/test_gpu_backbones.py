@@ -227,6 +227,12 @@ def test_hourglass_plan_on_planes_is_the_nhwc_plan_bit_for_bit(interp, cin):
     assert a.planar and not b.planar
     for p_, q_ in zip([o.clone() for o in a.forward(x)], b.forward(x)):
         assert torch.equal(p_, q_)
+    # float32 frames take the other first-layer kernel (sa_image_conv_bf16 instead of the matrix-core u8 one): its plane store
+    xf = x.float() / 255.0  # ensure_float: float frames are taken as they are, uint8 ones are scaled by 1/255
+    ref = [o.clone() for o in a.forward(x)]
+    for p_, q_, r_ in zip([o.clone() for o in a.forward(xf)], b.forward(xf), ref):
+        assert torch.equal(p_, q_)
+        assert float((p_ - r_).abs().max()) <= 2e-2 * float(r_.abs().max())
 
 
 def test_hourglass_stacked_features_vs_oracle():
