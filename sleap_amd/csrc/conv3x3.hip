@@ -365,14 +365,6 @@ conv3x3_dma_kernel(const ConvParams2 p) {
     L_end = start + q + (xcd < r ? 1 : 0);
   }
   if (L >= L_end) return;  // wave-uniform
-#if defined(SA_UPS_STAGGER)
-  // UPS: the two workgroups of a CU start together, run the same code and stay in lockstep -- both expand (no MFMA) and then
-  // both compete for the matrix pipe. Delaying every second resident workgroup by about half an expansion puts the pair in
-  // anti-phase (one expands while the other multiplies), which is self-sustaining as well.
-  if constexpr (UPS) {
-    if (((blockIdx.x >> 3) >> 5) & 1) __builtin_amdgcn_s_sleep(SA_UPS_STAGGER);
-  }
-#endif
   struct Tile {
     int co32_0, x0, y0, b;
   };
@@ -734,7 +726,6 @@ conv3x3_dma_kernel(const ConvParams2 p) {
       // stage -- no barrier of its own: a wave goes on to its MFMAs of chunk c as soon as its share is written, and the waves
       // without a share (5-7) start at once, so the matrix pipe is never idle workgroup-wide. The expanded tile is read after
       // the next chunk's barrier.
-#if !defined(SA_UPS_DBG_SKIP_EXPAND)
       if (chunk + 1 < n_chunks && (chunk + 1) * CK >= p.C0P) {  // wave-uniform
         unsigned char* tile = smem + (buf ^ 1) * STAGE;
         // halo-tile rows 2rp, 2rp+1 are image rows y0-1+2rp (odd: weight 0.25 on the lower source row) and y0+2rp (even: 0.75);
@@ -838,7 +829,6 @@ conv3x3_dma_kernel(const ConvParams2 p) {
           __builtin_amdgcn_sched_barrier(0);
         }
       }
-#endif
     }
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
@@ -870,12 +860,8 @@ conv3x3_dma_kernel(const ConvParams2 p) {
         // its share: a rendezvous in the middle of the MFMA sequence (no memory wait attached), then six copies
         if (tap == SA_UPS_LOW_TAP && chunk + 2 < n_chunks && (chunk + 2) * CK >= p.C0P) {  // wave-uniform
           __builtin_amdgcn_sched_barrier(0);
-#if !defined(SA_UPS_DBG_NO_MIDBAR)
           if ((chunk + 1) * CK >= p.C0P) __builtin_amdgcn_s_barrier();
-#endif
-#if !defined(SA_UPS_DBG_NO_LOWDMA)
           issue_low(cur, chunk + 2);
-#endif
           __builtin_amdgcn_sched_barrier(0);
         }
       }

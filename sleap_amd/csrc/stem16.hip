@@ -255,17 +255,7 @@ stem16_gray_kernel(const Stem16Params p) {
 #endif
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int n16 = lane & 15, kb = lane >> 4;
-#if defined(SA_STEM16_XCD)
-  // block i runs on XCD i % 8: give every XCD a contiguous range of tiles, so that the 4 column tiles sharing a 128-byte
-  // line of the u8 frame (and the row tiles sharing halo rows) meet in ONE L2 instead of being fetched by several
-  int bid;
-  {
-    const int nblk = gridDim.x, q = nblk >> 3, r = nblk & 7, xcd = blockIdx.x & 7, k = blockIdx.x >> 3;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
-  }
-#else
   int bid = blockIdx.x;
-#endif
   const int tx_i = bid % p.tiles_x;
   bid /= p.tiles_x;
   const int ty_i = bid % p.tiles_y;
@@ -363,12 +353,7 @@ stem16_gray_kernel(const Stem16Params p) {
     // lanes kb == 3 carry K slots 24..31 (no taps): they read the zero entry with stride 0
     const uint2* src = kb < 3 ? rawt + ((wave >> 1) + kb) * RS + tx : rawt + RH * RS;
     const int sstep = kb < 3 ? 2 * RS : 0;
-#if defined(SA_STEM16_SWZ)
-    // the two 16-byte halves of a pixel record swap places for columns with bit 2 set: the 16 lanes of a ds_write_b64 group
-    // (16 consecutive columns, one kb) then fall on 16 distinct bank pairs twice instead of 8 four times (2-way instead of
-    // 4-way conflicts), and conv1's ds_read_b128 groups stay conflict-free (brute-forced over every row / column phase)
-    unsigned char* dstp = act + ((wave >> 1) * PW + tx) * 32 + (((kb >> 1) ^ ((tx >> 2) & 1)) * 16) + (kb & 1) * 8;
-#elif SA_STEM16_PLANES8
+#if SA_STEM16_PLANES8
     unsigned char* dstp = act + (kb >> 1) * APLANE + ((wave >> 1) * PW + tx) * 16 + (kb & 1) * 8;
 #else
     unsigned char* dstp = act + ((wave >> 1) * PW + tx) * 32 + kb * 8;
@@ -429,12 +414,7 @@ stem16_gray_kernel(const Stem16Params p) {
   for (int r = 0; r < 4; ++r)
 #pragma unroll
     for (int h = 0; h < 2; ++h) acc[r][h] = (f32x4){bias1[0], bias1[1], bias1[2], bias1[3]};
-#if defined(SA_STEM16_SWZ)
-  const unsigned char* abase = act + ((wave * 4) * PW + n16) * 32;
-  int hoff[3];  // byte offset of this lane's half (channels 8 (kb & 1) ..) in the pixel record of column n16 + dx (+16 h)
-#pragma unroll
-  for (int dx = 0; dx < 3; ++dx) hoff[dx] = ((kb & 1) ^ (((n16 + dx) >> 2) & 1)) * 16;
-#elif SA_STEM16_PLANES8
+#if SA_STEM16_PLANES8
   const unsigned char* abase = act + (kb & 1) * APLANE + ((wave * 4) * PW + n16) * 16;
 #else
   const unsigned char* abase = act + ((wave * 4) * PW + n16) * 32 + (kb & 1) * 16;
@@ -446,11 +426,7 @@ stem16_gray_kernel(const Stem16Params p) {
     (void)dummy;
     const int ta = 2 * s, tb = 2 * s + 1 < 9 ? 2 * s + 1 : 0;
     const int off = (kb >> 1) ? ((tb / 3) * PW + tb % 3) : ((ta / 3) * PW + ta % 3);
-#if defined(SA_STEM16_SWZ)
-    const unsigned char* sb = abase + off * 32 + ((kb >> 1) ? hoff[tb % 3] : hoff[ta % 3]);
-#else
     const unsigned char* sb = abase + off * APIX1;
-#endif
 #pragma unroll
     for (int r = 0; r < 4; ++r)
 #pragma unroll
