@@ -255,13 +255,24 @@ stem16_gray_kernel(const Stem16Params p) {
 #endif
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int n16 = lane & 15, kb = lane >> 4;
-  int bid = blockIdx.x;
-  const int tx_i = bid % p.tiles_x;
-  bid /= p.tiles_x;
-  const int ty_i = bid % p.tiles_y;
-  const int b = bid / p.tiles_y;
+  // (3-D grid: tile column, tile row, frame -- two runtime divisions per workgroup, each a dependent ~100-cycle reciprocal
+  //  sequence in FRONT of the first load, were the first thing every tile did)
+  const int tx_i = blockIdx.x, ty_i = blockIdx.y, b = blockIdx.z;
   const int x0 = tx_i * TW, y0 = ty_i * TH;
   const int H = p.H, W = p.W;
+
+  // ---- weights and biases first: the requests go out before the pixel loads below and come back under them. (They used to
+  // follow the table build in program order, i.e. a second, serialized L2 round trip in every tile's prologue.)
+  const uint4* blob4 = reinterpret_cast<const uint4*>(p.blob);
+  mfma_h8 wa[3], wb[5];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) wa[i] = __builtin_bit_cast(mfma_h8, blob4[i * 64 + lane]);
+#pragma unroll
+  for (int i = 0; i < 5; ++i) wb[i] = __builtin_bit_cast(mfma_h8, blob4[(3 + i) * 64 + lane]);
+  const float* biases = reinterpret_cast<const float*>(p.blob + 8 * 64 * 8);
+  const float4 q0 = *reinterpret_cast<const float4*>(biases + kb * 4);
+  const float4 q1 = *reinterpret_cast<const float4*>(biases + 16 + kb * 4);
+  const float bias0[4] = {q0.x, q0.y, q0.z, q0.w}, bias1[4] = {q1.x, q1.y, q1.z, q1.w};
 
   // ---- triplet table: thread (row, dq) loads the two aligned dwords covering image columns x0-4+4dq .. +7 and emits
   // the entries of raw columns tx = 4dq-2 .. 4dq+1 (raw column tx <-> image column x0 - 2 + tx; zero outside the image)
@@ -287,16 +298,6 @@ stem16_gray_kernel(const Stem16Params p) {
       if (tx >= 0 && tx < PW) rawt[ty * RS + tx] = make_uint2(h[e] | (h[e + 1] << 16), h[e + 2]);
     }
   }
-  const uint4* blob4 = reinterpret_cast<const uint4*>(p.blob);
-  mfma_h8 wa[3], wb[5];
-#pragma unroll
-  for (int i = 0; i < 3; ++i) wa[i] = __builtin_bit_cast(mfma_h8, blob4[i * 64 + lane]);
-#pragma unroll
-  for (int i = 0; i < 5; ++i) wb[i] = __builtin_bit_cast(mfma_h8, blob4[(3 + i) * 64 + lane]);
-  const float* biases = reinterpret_cast<const float*>(p.blob + 8 * 64 * 8);
-  const float4 q0 = *reinterpret_cast<const float4*>(biases + kb * 4);
-  const float4 q1 = *reinterpret_cast<const float4*>(biases + 16 + kb * 4);
-  const float bias0[4] = {q0.x, q0.y, q0.z, q0.w}, bias1[4] = {q1.x, q1.y, q1.z, q1.w};
 #if SA_STEM16_FOLD
   // A lane's conv0 K block holds one kernel row: 3 taps in 8 slots. The hi and the mid term of the weight split share ONE MFMA:
   // hi in slots 0-2, mid in slots 4-6, the pixel triplet in both halves of the B operand (products and fp32 accumulation are
@@ -543,8 +544,8 @@ int sa_stem16_u8_bf16(const void* src, int B, int H, int W, int Cin, const void*
   p.tiles_y = (H + SA_STEM16_TH - 1) / SA_STEM16_TH;
   const size_t nblk = (size_t)p.tiles_x * p.tiles_y * B;
   if (nblk > 0x7fffffffull) return sa::fail(SA_ERR_INVALID_ARG, "sa_stem16_u8_bf16: grid too large");
-  if (Cin == 1 && (W & 3) == 0 && ((uintptr_t)src & 3) == 0)
-    hipLaunchKernelGGL(stem16_gray_kernel, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, p);
+  if (Cin == 1 && (W & 3) == 0 && ((uintptr_t)src & 3) == 0 && p.tiles_y <= 65535 && B <= 65535)
+    hipLaunchKernelGGL(stem16_gray_kernel, dim3((unsigned)p.tiles_x, (unsigned)p.tiles_y, (unsigned)B), dim3(256), 0, (hipStream_t)stream, p);
   else if (Cin == 1)
     hipLaunchKernelGGL((stem16_kernel<1>), dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, p);
   else
