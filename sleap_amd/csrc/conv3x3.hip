@@ -265,6 +265,7 @@ struct ConvParams2 {
   unsigned blk_bytes_in1;      // the same for src1 when it is read at half resolution (UPS kernels: planes of H/2 x W/2 pixels)
   int out_pix_bytes;           // the same for the outputs: pixel stride (NHWC: 2 CoutP; planes: 32),
   unsigned out_blk_bytes, out_blk_bytes_pool;  // 16-channel block stride of dst / dst_pool (NHWC: 32; planes: pixels per frame x 32)
+  int nt_in;  // input copies carry the non-temporal hint (layers whose input tiles are read by ONE cout tile: streamed once)
 };
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -442,12 +443,17 @@ conv3x3_dma_kernel(const ConvParams2 p) {
         const int i = j * NW + wave;
         if (STEM_CIN == 0 && i < N_IN && lo <= j && j < hi) {
           if (!UPS && from1) {
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, (lds_ptr_t)(stage + i * 1024), 16, v1[j], cc2, 0, 0);
+            if (p.nt_in)  // (wave-uniform; the cache policy is an immediate of the instruction)
+              __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, (lds_ptr_t)(stage + i * 1024), 16, v1[j], cc2, 0, 2);
+            else
+              __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, (lds_ptr_t)(stage + i * 1024), 16, v1[j], cc2, 0, 0);
           } else if (UPS && IN_TAIL > 0 && i == N_IN - 1) {
             // the tail of the input area belongs to the low-resolution tile: the last piece's lanes beyond the halo tile
             // stay switched off (an out-of-range offset would write zeros there)
             if (lane * 16 < IN_USED - (N_IN - 1) * 1024)
               __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, (lds_ptr_t)(stage + i * 1024), 16, v0[j], cc2, 0, 0);
+          } else if (p.nt_in) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, (lds_ptr_t)(stage + i * 1024), 16, v0[j], cc2, 0, 2);
           } else {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, (lds_ptr_t)(stage + i * 1024), 16, v0[j], cc2, 0, 0);
           }
@@ -1135,6 +1141,14 @@ int launch2(const ConvParams2& p, hipStream_t st) {
   q.tiles_y = (p.H + TH - 1) / TH;
   const int co32_n = (p.CoutP + 31) / 32;
   q.co_tiles = (co32_n + MT - 1) / MT;
+  // Non-temporal input copies (SA_CONV_NT=0 turns them off, A/B): a layer whose cout tiles all sit in ONE workgroup reads every
+  // input tile once (plus the halo its neighbours share) -- streamed data. The guide measures issue -> landed -18 % for `nt` on
+  // once-read LDS-DMA streams and a LOSS where several CUs re-read the same lines from L2, hence the co_tiles == 1 rule.
+  static const bool nt_on = [] {
+    const char* v = getenv("SA_CONV_NT");
+    return !v || atoi(v) != 0;
+  }();
+  q.nt_in = (nt_on && q.co_tiles == 1 && !STEM_CIN) ? 1 : 0;
   if (p.planar && CK != 16 && !STEM_CIN) return sa::fail(SA_ERR_UNSUPPORTED, "sa_conv3x3: SA_LAYOUT_PLANES16 needs 16-channel chunks");
   q.pix_bytes0 = p.planar ? 32 : p.C0P * 2;
   q.pix_bytes1 = p.planar ? 32 : p.C1P * 2;
