@@ -890,6 +890,122 @@ conv3x3_dma_kernel(const ConvParams2 p) {
   // channels, i.e. one 16-byte store per pair instead of two 8-byte stores (fewer store instructions, full 64-byte
   // runs per pixel instead of interleaved partial writes).
   const int gx = x0 + lx;
+  if constexpr (EXT) {
+    // Extended epilogue, one PAIR of 4-channel groups (= one 16-byte store piece) at a time: post-scale, post-shift and the
+    // residual of a whole cout tile live together cost 80 registers beside the accumulators (29 spilled at the 128 of two
+    // workgroups per CU); per pair they cost 32. Same operations in the same order as before: same bits.
+    const float lowv = p.relu ? 0.0f : -INFINITY;
+    const bool colok = gx < W;
+    const unsigned pixb = (unsigned)p.out_pix_bytes;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      const int cobase = (co32_0 + m) * 32;
+      if (cobase >= p.CoutP) continue;
+#pragma unroll
+      for (int pr = 0; pr < 2; ++pr) {
+        float bb[2][4], ps[2][4], pt[2][4];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const int co = cobase + 8 * (2 * pr + e) + 4 * half;
+          float4 bq = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+          if (!BIAS_INIT && co < p.CoutP) bq = *reinterpret_cast<const float4*>(p.bias + co);
+          float4 sq = make_float4(1.0f, 1.0f, 1.0f, 1.0f), tq = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+          if (p.post_scale && co < p.CoutP) {
+            sq = *reinterpret_cast<const float4*>(p.post_scale + co);
+            tq = *reinterpret_cast<const float4*>(p.post_shift + co);
+          }
+          bb[e][0] = bq.x, bb[e][1] = bq.y, bb[e][2] = bq.z, bb[e][3] = bq.w;
+          ps[e][0] = sq.x, ps[e][1] = sq.y, ps[e][2] = sq.z, ps[e][3] = sq.w;
+          pt[e][0] = tq.x, pt[e][1] = tq.y, pt[e][2] = tq.z, pt[e][3] = tq.w;
+        }
+        // the residual of this lane's outputs: four channels (8 bytes) per load, the R x 2 loads of the pair in flight together;
+        // it has the output's layout (NHWC or 16-channel planes), at the output's resolution or at half of it (res_mode 1:
+        // UpSampling2D(nearest) folded in)
+        float rres[R][2][4];
+        if (p.residual) {
+          uint2 q[R][2];
+#pragma unroll
+          for (int r = 0; r < R; ++r) {
+            const int gy = y0 + wave * R + r;
+            const int hr = p.res_mode ? H / 2 : H, wr = p.res_mode ? W / 2 : W;
+            const size_t pix = p.res_mode ? (size_t)(gy >> 1) * wr + (gx >> 1) : (size_t)gy * wr + gx;
+            const unsigned char* rf = reinterpret_cast<const unsigned char*>(p.residual) + (size_t)b * hr * wr * p.CoutP * 2 +
+                                      pix * p.out_pix_bytes;
+            const unsigned rblk = p.res_mode ? p.out_blk_bytes_pool : p.out_blk_bytes;
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+              const int co = cobase + 8 * (2 * pr + e) + 4 * half;
+              q[r][e] = make_uint2(0u, 0u);
+              if (gy < H && gx < W && co < p.CoutP)
+                q[r][e] = *reinterpret_cast<const uint2*>(rf + (size_t)(co >> 4) * rblk + (co & 15) * 2);
+            }
+          }
+#pragma unroll
+          for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+              rres[r][e][0] = sa::h2f((uint16_t)(q[r][e].x & 0xffff));
+              rres[r][e][1] = sa::h2f((uint16_t)(q[r][e].x >> 16));
+              rres[r][e][2] = sa::h2f((uint16_t)(q[r][e].y & 0xffff));
+              rres[r][e][3] = sa::h2f((uint16_t)(q[r][e].y >> 16));
+            }
+        }
+        auto act = [&](int r, int e, int j) {
+          float t = acc[m][r][4 * (2 * pr + e) + j];
+          if constexpr (!BIAS_INIT) t += bb[e][j];
+          t = fmaxf(t, lowv);
+          t = fmaf(t, ps[e][j], pt[e][j]);
+          if (p.residual) t += rres[r][e][j];
+          if (p.relu_last) t = fmaxf(t, 0.0f);
+          return t;
+        };
+        // lower half-wave: own group 2pr (channels 0-3) + partner's (4-7); upper: partner's group 2pr+1 + own
+        auto store_piece = [&](unsigned char* row_base, unsigned blk_bytes, unsigned lane_off, bool ok, uint2 a, uint2 c) {
+          sa::swap32(a.x, c.x);
+          sa::swap32(a.y, c.y);
+          const int co16 = (cobase >> 4) + pr;  // 16-channel block of this piece (wave uniform)
+          if (ok && co16 * 16 < p.CoutP)
+            *reinterpret_cast<uint4*>(row_base + (size_t)co16 * blk_bytes + lane_off) = make_uint4(a.x, a.y, c.x, c.y);
+        };
+        if (p.dst) {
+          unsigned char* frame = reinterpret_cast<unsigned char*>(p.dst) + (size_t)b * H * W * p.CoutP * 2;
+          const unsigned lane_off = (unsigned)gx * pixb + (unsigned)half * 16u;
+#pragma unroll
+          for (int r = 0; r < R; ++r) {
+            const int gy = y0 + wave * R + r;  // wave uniform
+            uint2 pk[2];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+              pk[e].x = sa::f2h2(act(r, e, 0), act(r, e, 1));
+              pk[e].y = sa::f2h2(act(r, e, 2), act(r, e, 3));
+            }
+            store_piece(frame + (size_t)gy * W * pixb, p.out_blk_bytes, lane_off, colok && gy < H, pk[0], pk[1]);
+          }
+        }
+        if constexpr (R >= 2) if (p.dst_pool) {
+          unsigned char* frame = reinterpret_cast<unsigned char*>(p.dst_pool) + (size_t)b * (H / 2) * (W / 2) * p.CoutP * 2;
+          const unsigned lane_off = (unsigned)(gx >> 1) * pixb + (unsigned)half * 16u;
+#pragma unroll
+          for (int r = 0; r < R; r += 2) {
+            const int gy = y0 + wave * R + r;  // wave uniform, even
+            uint2 pk[2];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+              float t4[4];
+#pragma unroll
+              for (int j = 0; j < 4; ++j) {
+                const float t = fmaxf(act(r, e, j), act(r + 1, e, j));
+                t4[j] = fmaxf(t, sa::dpp_xor1(t));
+              }
+              pk[e].x = sa::f2h2(t4[0], t4[1]);
+              pk[e].y = sa::f2h2(t4[2], t4[3]);
+            }
+            store_piece(frame + (size_t)(gy >> 1) * (W / 2) * pixb, p.out_blk_bytes_pool, lane_off, !(lane_e & 1) && colok && gy < H, pk[0], pk[1]);
+          }
+        }
+      }
+    }
+  } else {
 #pragma unroll
   for (int m = 0; m < MT; ++m) {
     const int cobase = (co32_0 + m) * 32;
@@ -1023,6 +1139,7 @@ conv3x3_dma_kernel(const ConvParams2 p) {
         store_pieces(frame + (size_t)(gy >> 1) * (W / 2) * pixb, p.out_blk_bytes_pool, lane_off, !(lane_e & 1) && colok && gy < H, pk);
       }
     }
+  }
   }
 
   // ---- fused 1x1 heads on the matrix cores: out[n, pixel] = act(b[n] + sum_co Wh[n][co] * f[co, pixel]) with
