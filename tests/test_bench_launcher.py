@@ -50,3 +50,15 @@ def test_more_gpus_than_visible_is_refused():
     # no GPU in the CPU container (and at most 1 on the test box): asking for 64 must fail loudly before anything is launched
     r = _run(["--gpus", "64", "--steps", "1"])
     assert r.returncode != 0 and "visible" in (r.stderr + r.stdout)
+
+
+def test_literal_configs3_split_8_ranks_of_8_frames():
+    """SCALE-day readiness: configs[3] read literally -- a global batch of 64 over the 8 GPUs of a node -- as the driver would
+    launch it (`python bench.py --gpus 8 --global-batch 64`), over gloo."""
+    r = _run(["--gpus", "8", "--steps", "2", "--dry-run-cpu", "--global-batch", "64"], env={"OMP_NUM_THREADS": "1"}, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = _json_lines(r.stdout)
+    assert len(lines) == 1, r.stdout
+    d = lines[0]
+    assert d["n_gpus"] == 8 and d["config"]["n_ranks_seen"] == 8 and d["scaling"] == "strong"
+    assert d["config"]["frames_per_gpu_per_step"] == 8 and d["config"]["global_batch"] == 64 and d["rows_in_rank_order"]

@@ -34,7 +34,7 @@ def passes(a):
 def main(fetch_csv, write_csv, n_fwd=0, out_json=None):
     f, w = load(fetch_csv, "FETCH_SIZE"), load(write_csv, "WRITE_SIZE")
     nf, nw = (n_fwd, n_fwd) if n_fwd else (passes(f), passes(w))
-    print("| kernel | grid | launches (FETCH pass) | FETCH_SIZE x2 [MB/launch] | WRITE_SIZE [MB/launch] |")
+    print("| kernel | grid | launches (FETCH pass) | FETCH_SIZE x2 [MiB/launch] | WRITE_SIZE [MiB/launch] |")
     print("|---|---|---|---|---|")
     tf = tw = 0.0
     for key in sorted(f, key=lambda k: -sum(f[k])):
@@ -46,8 +46,10 @@ def main(fetch_csv, write_csv, n_fwd=0, out_json=None):
             tw += sum(w.get(key, [0])) / 1024 / nw
     print(f"\nconv family (conv3x3_dma_kernel + convpair + stem16): {nf} forward passes of 64 frames in the FETCH run, {nw} in the WRITE run "
           "(bench.py --no-cpu-baseline --no-extras: time-based pre-warm + 3 warm-up + 10 timed steps + instrumented passes)")
-    print(f"-> per step (all conv-family launches of one forward pass, 64 frames): FETCH x2 {tf / 1024:.2f} GB + WRITE {tw / 1024:.2f} GB = "
-          f"{(tf + tw) / 1024:.2f} GB = {(tf + tw) / 64:.0f} MB/frame; algorithmic activations in + out of the current plan: DESIGN.md section 3")
+    gb = 1048576 / 1e9  # the counters are KiB; the table is MiB; these sums are decimal GB / MB, as the bench line's `traffic`
+    print(f"-> per step (all conv-family launches of one forward pass, 64 frames): FETCH x2 {tf * gb:.2f} GB + WRITE {tw * gb:.2f} GB = "
+          f"{(tf + tw) * gb:.2f} GB = {(tf + tw) * gb * 1000 / 64:.0f} MB/frame (decimal; = {(tf + tw) / 1024:.2f} GiB); algorithmic bytes of the "
+          "current plan: DeviceNetwork.op_bytes (DESIGN.md section 5)")
 
     if out_json:
         import json

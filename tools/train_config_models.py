@@ -225,13 +225,16 @@ def make_targets(t, skel, insts, crop):
             paf_targets([al for al, _ in insts], skel.edge_idx, crop, crop, t["heads"][1][2])]
 
 
-def fit(task, steps=None, threads=0, seed=0, lr=2e-3, resume=False, device="cpu", out_dir=None, batch=0):
+def fit(task, steps=None, threads=0, seed=0, lr=2e-3, resume=False, device="cpu", out_dir=None, batch=0, hard_neg=0.0,
+        bn_inference=False, crop=0):
     """`device="cuda"`: the same fit on a GPU (plain torch; used for the ResNet-50 task, 45 minutes on 8 CPU cores). The stored
     weights then depend on the GPU's convolution algorithms: reproducible in distribution, not bit for bit."""
     t = dict(TASKS[task])
     steps = steps or t["steps"]
     if batch:
         t["batch"] = batch
+    if crop:
+        t["crop"] = crop
     if threads:
         torch.set_num_threads(threads)
     torch.manual_seed(seed)
@@ -265,6 +268,8 @@ def fit(task, steps=None, threads=0, seed=0, lr=2e-3, resume=False, device="cpu"
     margin = t.get("loss_margin", 16 if t["crop"] else 0)
     has_bn = any(l["class_name"] == "BatchNormalization" for l in net.layers)
     t0 = time.time()
+    if bn_inference:
+        net.bn_batch_stats = False  # a resumed fit: the moving statistics are calibrated, fit the inference-time function only
     for step in range(steps):
         if has_bn and step == int(steps * 0.7):
             net.bn_batch_stats = False  # the last 30 %: the inference-time function (moving statistics) is what gets fitted
@@ -281,6 +286,12 @@ def fit(task, steps=None, threads=0, seed=0, lr=2e-3, resume=False, device="cpu"
                 l = l + 20.0 * ((F.relu(o - 0.06) ** 2) * bg)[sl].mean()
                 pk = (y > 0.5) & (y >= F.max_pool2d(y, 3, 1, 1))
                 l = l + 5.0 * ((F.relu(0.6 - o) ** 2) * pk.float())[sl].sum() / max(int(pk[sl].sum()), 1)
+                if hard_neg:
+                    # hard-negative mining: the mean-squared background term above barely sees a handful of cross-type
+                    # responses of 0.2-0.4 (ten cells in a 64 x 64 x 24 map); the strongest 0.05 % of the background cells of
+                    # the batch are pushed below 0.05 directly -- what decides whether a false maximum crosses the 0.2 threshold
+                    v = (F.relu(o - 0.05) * bg)[sl].flatten()
+                    l = l + hard_neg * (v.topk(max(1, v.numel() // 2000)).values ** 2).mean()
                 if t.get("nonneg"):
                     # confidence maps with negative lobes make integral refinement (centroid of a 5 x 5 patch = a division by
                     # the patch sum) ill-conditioned wherever the lobes cancel the peak: keep the maps (nearly) non-negative
@@ -331,6 +342,10 @@ if __name__ == "__main__":
     ap.add_argument("--device", default="cpu")
     ap.add_argument("--out-dir", default=None)
     ap.add_argument("--batch", type=int, default=0)
+    ap.add_argument("--hard-neg", type=float, default=0.0, help="weight of the hard-negative term (strongest 0.05 %% of background cells)")
+    ap.add_argument("--bn-inference", action="store_true", help="BatchNormalization on the moving statistics from step 0 (resumed fits)")
+    ap.add_argument("--crop", type=int, default=0, help="override the task's training crop size")
     a = ap.parse_args()
     for task in a.tasks:
-        fit(task, a.steps, a.threads, lr=a.lr, resume=a.resume, device=a.device, out_dir=a.out_dir, batch=a.batch)
+        fit(task, a.steps, a.threads, lr=a.lr, resume=a.resume, device=a.device, out_dir=a.out_dir, batch=a.batch, hard_neg=a.hard_neg,
+            bn_inference=a.bn_inference, crop=a.crop)
