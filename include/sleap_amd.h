@@ -412,6 +412,12 @@ int sa_resize_bilinear_u8_f32(const void* src, int B, int H, int W, int C, int H
 /* dtype plumbing: f32 NHWC [.., C] <-> bf16 NHWC [.., CP] (zero padded) */
 int sa_f32_to_bf16_padded(const float* src, int n_pix, int C, int CP, void* dst, sa_stream_t stream);
 int sa_bf16_to_f32(const void* src, int n_pix, int CP, int C, float* dst, sa_stream_t stream);
+/* Range scan of one stored activation tensor (no reference counterpart: the reference computes and stores float32,
+ * sleap/nn/inference.py:1047-1090 hands tf.float32 tensors around; fp16 storage has a finite range).
+ * x: n elements of this library's 16-bit storage type (is_f32 = 0) or float32 (is_f32 = 1), 16-byte aligned, on the device.
+ * out2 (device, 2 dwords, written asynchronously on `stream`): out2[0] = the largest FINITE |x| as float,
+ * ((uint32_t*)out2)[1] = flags, bit 0: an infinity was seen, bit 1: a NaN was seen. One wave-reduced atomic per wavefront. */
+int sa_tensor_absmax(const void* x, size_t n, int is_f32, float* out2, sa_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Cross-frame identity tracking (host code). Replaces sleap.nn.tracking.Tracker with the

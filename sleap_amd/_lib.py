@@ -97,6 +97,7 @@ SIGNATURES = {
     "sa_resize_bilinear_u8_f32": (_i, [_p, _i, _i, _i, _i, _i, _i, _f, _p, _p]),
     "sa_f32_to_bf16_padded": (_i, [_p, _i, _i, _i, _p, _p]),
     "sa_bf16_to_f32": (_i, [_p, _i, _i, _i, _p, _p]),
+    "sa_tensor_absmax": (_i, [_p, _sz, _i, _p, _p]),
     "sa_network_create": (_i, [_p, _sz, _p]),
     "sa_network_destroy": (None, [_p]),
     "sa_network_n_outputs": (_i, [_p]),

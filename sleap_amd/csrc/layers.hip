@@ -567,6 +567,52 @@ __global__ void bf16_to_f32_kernel(const uint16_t* __restrict__ src, size_t n_pi
   }
 }
 
+
+// max |x| over a tensor of the 16-bit storage type (or float32) + non-finite flags: the range scan of fp16 storage
+// (DeviceNetwork._check_fp16_range / layer_ranges). HBM-bound: 16-byte loads, the magnitude bits of a non-negative IEEE value
+// order like the value, so the reduction runs on integers; one atomicMax / atomicOr per wavefront.
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
+template <bool F32>
+__global__ __launch_bounds__(256) void tensor_absmax_kernel(const u32x4_t* __restrict__ x, size_t n_vec, const void* __restrict__ tail,
+                                                            int n_tail, uint32_t* __restrict__ out) {
+#if defined(SA_HALF_FP16)
+  constexpr uint32_t HINF = 0x7c00u;
+#else
+  constexpr uint32_t HINF = 0x7f80u;
+#endif
+  uint32_t m = 0, flags = 0;  // m: largest finite magnitude (bits), flags: 1 = inf seen, 2 = NaN seen
+  auto take = [&](uint32_t a, uint32_t inf) {
+    if (a < inf) m = max(m, a);
+    else flags |= (a == inf) ? 1u : 2u;
+  };
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n_vec; i += (size_t)gridDim.x * blockDim.x) {
+    const u32x4_t v = __builtin_nontemporal_load(x + i);
+    const uint32_t w[4] = {v[0], v[1], v[2], v[3]};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (F32) {
+        take(w[j] & 0x7fffffffu, 0x7f800000u);
+      } else {
+        take(w[j] & 0x7fffu, HINF);
+        take((w[j] >> 16) & 0x7fffu, HINF);
+      }
+    }
+  }
+  if (blockIdx.x == 0 && (int)threadIdx.x < n_tail) {
+    if (F32) take(((const uint32_t*)tail)[threadIdx.x] & 0x7fffffffu, 0x7f800000u);
+    else take(((const uint16_t*)tail)[threadIdx.x] & 0x7fffu, HINF);
+  }
+#pragma unroll
+  for (int o = 32; o; o >>= 1) {
+    m = max(m, (uint32_t)__shfl_xor((int)m, o));
+    flags |= (uint32_t)__shfl_xor((int)flags, o);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    if (m) atomicMax(out, F32 ? m : __float_as_uint(sa::h2f((uint16_t)m)));  // float bits of non-negative values order like the values
+    if (flags) atomicOr(out + 1, flags);
+  }
+}
+
 inline int grid_for(size_t total, int block = 256, int cap = 256 * 16) {
   size_t g = (total + block - 1) / block;
   if (g > (size_t)cap) g = cap;
@@ -742,6 +788,24 @@ int sa_f32_to_bf16_padded(const float* src, int n_pix, int C, int CP, void* dst,
   SA_REQUIRE(CP >= C && C > 0, "sa_f32_to_bf16_padded: CP < C");
   hipLaunchKernelGGL(f32_to_bf16_padded_kernel, dim3(grid_for((size_t)n_pix * CP)), dim3(256), 0,
                      (hipStream_t)stream, src, (size_t)n_pix, C, CP, (uint16_t*)dst);
+  SA_LAUNCH_CHECK();
+  return SA_OK;
+}
+
+int sa_tensor_absmax(const void* x, size_t n, int is_f32, float* out2, sa_stream_t stream) {
+  SA_REQUIRE(x && out2 && n > 0, "sa_tensor_absmax: bad arguments");
+  SA_REQUIRE(((uintptr_t)x & 15) == 0, "sa_tensor_absmax: the tensor must be 16-byte aligned");
+  SA_HIP_CHECK(hipMemsetAsync(out2, 0, 2 * sizeof(float), (hipStream_t)stream));
+  const size_t per = is_f32 ? 4 : 8, n_vec = n / per;
+  const int n_tail = (int)(n - n_vec * per);
+  const void* tail = (const char*)x + n_vec * 16;
+  const int grid = (int)std::min<size_t>(std::max<size_t>((n_vec + 255) / 256, 1), 256 * 8);
+  if (is_f32)
+    hipLaunchKernelGGL(tensor_absmax_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const u32x4_t*)x, n_vec, tail,
+                       n_tail, (uint32_t*)out2);
+  else
+    hipLaunchKernelGGL(tensor_absmax_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const u32x4_t*)x, n_vec, tail,
+                       n_tail, (uint32_t*)out2);
   SA_LAUNCH_CHECK();
   return SA_OK;
 }

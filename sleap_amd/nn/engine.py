@@ -85,7 +85,7 @@ class DeviceNetwork:
     def __init__(self, model_config: dict, weights: Dict[str, np.ndarray], device=None, fuse_upsample: Optional[bool] = None,
                  fuse_heads: bool = True, fuse_stem: bool = True, use_stem16: bool = True, mfma_convt: bool = True,
                  mfma_stem: bool = True, fuse_pairs: bool = True, dtype: Optional[str] = None, layout: Optional[str] = None,
-                 range_safe: Optional[bool] = None):
+                 range_safe: Optional[bool] = None, range_log2_scale: Optional[Dict[str, int]] = None):
         """`fuse_upsample`: UpSampling2D(bilinear) folded into the consuming conv. On 16-channel planes the DMA kernel copies the
         half-resolution tile of source chunk c+1 and expands it in LDS into the idle stage while chunk c is multiplied (the
         upsampled tensor never exists in HBM); on NHWC tensors the register-staged first-generation kernel does it on load
@@ -108,6 +108,9 @@ class DeviceNetwork:
         # SA_RANGE_SAFE=0 / range_safe=False restore the FloatingPointError. `range_log2_scale`: None = unscaled.
         self.range_safe = (os.environ.get("SA_RANGE_SAFE", "1") != "0") if range_safe is None else bool(range_safe)
         self.range_log2_scale = None
+        self._range_calibrated = False  # exponents came from calibrate_range() / range_log2_scale= (never changed implicitly)
+        self._range_measured: Dict[str, float] = {}
+        self._preset_scales = dict(range_log2_scale) if range_log2_scale else None
         self.model_config = model_config
         # layout of the 16-bit activation tensors: None = 16-channel planes when every launch of the compiled plan supports
         # them (the UNet family), NHWC otherwise; "nhwc" / "planes16" force one (SA_LAYOUT in the environment likewise)
@@ -129,11 +132,20 @@ class DeviceNetwork:
         self.layers = cfg["layers"]
         self.input_name = cfg["input_layers"][0][0]
         self.output_names = [l[0] for l in cfg["output_layers"]]
-        self.weights = weights
+        self.master_weights = weights  # the model's own float32 weights, never modified
+        self.weights = weights         # what the plan is compiled from: master_weights, or them with range scales folded in
         self.in_channels = None
         for l in self.layers:
             if l["class_name"] == "InputLayer":
                 self.in_channels = l["config"]["batch_input_shape"][-1]
+        if self._preset_scales and self.dtype == "fp16" and any(self._preset_scales.values()):
+            # persisted exponents of an earlier calibration (calibrate_range): the same network on every rank and in every
+            # run, no first-batch measurement, no twin
+            from . import range_scaling as RS
+
+            self.weights = RS.fold_scales(model_config, weights, self._preset_scales)
+            self.range_log2_scale = dict(self._preset_scales)
+            self._range_calibrated = True
         self._compile()
         if auto_up and self.fuse_upsample and not self.planar and any(
                 op[0] == "conv" and op.mode == _lib.SRC1_UPSAMPLE2X for op in self.plan):  # (only the plane kernels gain from it)
@@ -1235,53 +1247,142 @@ class DeviceNetwork:
                 groups.setdefault(id(v), []).append(name)
         return [g for g in groups.values() if len(g) > 1]
 
+    def _scan_tensors(self, tensors: Dict) -> Dict:
+        """key -> (largest finite |x|, an inf was seen, a NaN was seen) for 16-bit storage / float32 device tensors: one
+        `sa_tensor_absmax` launch per tensor (wave-reduced integer max over the magnitude bits, csrc/layers.hip), ONE copy to
+        the host for all of them -- no torch arithmetic."""
+        keys = list(tensors)
+        out = torch.zeros((max(len(keys), 1), 2), dtype=torch.float32, device=self.device)
+        st = _stream()
+        for j, k in enumerate(keys):
+            t = tensors[k]
+            assert t.is_contiguous() and t.dtype in (self._tdtype, torch.float32), (k, t.dtype)
+            check(self._h.sa_tensor_absmax(_ptr(t), t.numel(), 1 if t.dtype == torch.float32 else 0, _ptr(out[j]), st),
+                  "sa_tensor_absmax")
+        host = out.cpu().numpy()
+        flags = host[:, 1].copy().view(np.uint32)
+        return {k: (float(host[j, 0]), bool(flags[j] & 1), bool(flags[j] & 2)) for j, k in enumerate(keys)}
+
     def layer_ranges(self, imgs: torch.Tensor) -> Dict[str, float]:
         """max |activation| of every layer whose output this plan stores in HBM, on the given batch (one forward + one
-        reduction per stored tensor; calibration, not a hot path). Layers sharing a tensor (`layer_aliases`) report the same
-        value; outputs that only ever live in LDS / registers (fused stem, fused encoder block) are absent."""
+        reduction launch per stored tensor; calibration, not a hot path). Layers sharing a tensor (`layer_aliases`) report the
+        same value; outputs that only ever live in LDS / registers (fused stem, fused encoder block) are absent. A tensor that
+        holds an infinity reports `inf`."""
         self.forward(imgs)
         bufs = next(iter(self._buffers.values()))
-        out, seen = {}, {}
+        stored = {v.buf: bufs[v.buf] for v in self._tensor_of.values()
+                  if v.kind in ("real", "f32out") and v.buf is not None and v.buf in bufs}
+        scan = self._scan_tensors(stored)
+        out = {}
         for name, v in self._tensor_of.items():
-            if v.kind not in ("real", "f32out") or v.buf is None or v.buf not in bufs:
-                continue
-            if v.buf not in seen:
-                lo, hi = torch.aminmax(bufs[v.buf].float())
-                seen[v.buf] = max(abs(float(lo)), abs(float(hi)))
-            out[name] = seen[v.buf]
+            if v.kind in ("real", "f32out") and v.buf in scan:
+                m, has_inf, has_nan = scan[v.buf]
+                out[name] = float("inf") if (has_inf or has_nan) else m
         return out
+
+    # ---- what the range gate does, in one place ------------------------------------------------------------------------------
+    #   first batch of an input shape (fp16 storage): scan every stored tensor.
+    #     fits (finite, <= range / 4)                      -> nothing happens, the plan stays bit for bit what it was
+    #     does not fit, range_safe, not yet scaled         -> calibrate on THIS batch (all of its frames), fold, re-compile, re-run
+    #     does not fit and (scaling off | already scaled)  -> inf / NaN seen: FloatingPointError; finite: a warning
+    #   under torch.distributed (world > 1) the scan result and the calibration ranges are MAX-reduced over the ranks first, so
+    #   every rank takes the same branch and folds the same exponents (ranks must run numerically identical networks).
+    #   Deterministic alternative: `calibrate_range(frames)` right after loading, or `range_log2_scale=` (persisted exponents).
+    def _dist_max(self, values: List[float]) -> List[float]:
+        from .range_scaling import dist_max
+
+        return dist_max(values, self.device)
 
     def _range_gate(self, bufs, imgs) -> bool:
         """First batch of an input shape under fp16 storage: scan the stored tensors. -> True when the plan was re-compiled
-        with range scales (the caller runs the batch again), False when the network fits; raises FloatingPointError when it
-        does not fit and scaling is off, was already applied, or cannot help (a model input / output out of range)."""
-        try:
-            worst = self._check_fp16_range(bufs, warn=not self.range_safe or self.range_log2_scale is not None)
-            if worst <= 65504.0 / 4 or not self.range_safe or self.range_log2_scale is not None:
-                return False
-        except FloatingPointError:
-            if not self.range_safe or self.range_log2_scale is not None:
-                raise
-        self._apply_range_scaling(imgs)
-        return True
+        with range scales (the caller runs the batch again), False when the network is left as it is. Raises
+        FloatingPointError only when the scan actually saw inf / NaN and scaling is off, was already applied, or cannot help."""
+        worst, nonfinite, where = self._check_fp16_range(bufs)
+        worst, nf = self._dist_max([worst, 1.0 if nonfinite else 0.0])
+        nonfinite = nf > 0
+        if not nonfinite and worst <= 65504.0 / 4:
+            return False
+        # not yet scaled: calibrate on this batch. Already scaled (from a first batch, not from explicit / persisted exponents
+        # -- those are the user's decision) and this batch still overflowed: calibrate again with the LARGER of the old and the
+        # new ranges (a ratchet: scales only ever get more conservative)
+        may = self.range_log2_scale is None or (nonfinite and not self._range_calibrated)
+        if self.range_safe and may and self._apply_range_scaling(imgs, must=nonfinite):
+            return True
+        if nonfinite:
+            self._range_checked = False
+            raise FloatingPointError(
+                f"activations left the range of fp16 storage (65504) in plan tensor {where}"
+                + (" although range scales are applied (a batch far outside the calibration batch: call calibrate_range() on "
+                   "representative frames)" if self.range_log2_scale is not None else "")
+                + ": load the model with dtype='bf16' (or SLEAP_AMD_DTYPE=bf16), which has fp32's range")
+        import warnings
 
-    def _apply_range_scaling(self, imgs):
+        warnings.warn(f"fp16 storage: the largest activation of the first batch is {worst:.0f}, within 4x of the format's "
+                      "range (65504); consider dtype='bf16' for this model")
+        return False
+
+    def measure_ranges(self, imgs: torch.Tensor, chunk: int = 8) -> Dict[str, float]:
+        """max |activation| per layer over ALL frames of `imgs`, measured with a bf16-storage twin of this network (fp32's
+        range, every layer output stored, built from the un-scaled master weights), `chunk` frames at a time; MAX-reduced over
+        the ranks of the process group when there is one."""
+        twin = DeviceNetwork(self.model_config, self.master_weights, device=self.device, fuse_heads=False, fuse_stem=False,
+                             fuse_pairs=False, fuse_upsample=False, mfma_convt=self.mfma_convt, mfma_stem=self.mfma_stem,
+                             dtype="bf16")
+        ranges: Dict[str, float] = {}
+        n = int(imgs.shape[0])
+        chunk = max(1, min(chunk, n))
+        for i in range(0, n, chunk):
+            part = imgs[i:i + chunk]
+            if part.shape[0] < chunk and i:  # keep ONE buffer shape in the twin: the last chunk overlaps the one before
+                part = imgs[n - chunk:n]
+            for k, v in twin.layer_ranges(part.contiguous()).items():
+                ranges[k] = max(ranges.get(k, 0.0), v)
+        aliases = twin.layer_aliases()
+        del twin
+        keys = sorted(ranges)
+        red = self._dist_max([ranges[k] for k in keys])
+        return dict(zip(keys, red)), aliases
+
+    def calibrate_range(self, imgs: torch.Tensor) -> Dict[str, int]:
+        """Explicit, deterministic range calibration (fp16 storage): measure on `imgs` (uint8 / float32 frames on the device,
+        the shape the model will see), choose the power-of-two scales, fold them into a COPY of the master weights and
+        re-compile. -> the exponents ({} when every tensor fits: the plan is untouched). Persist them
+        (`json.dump(net.range_log2_scale)`) and pass `range_log2_scale=` at construction to skip the measurement."""
+        if self.dtype != "fp16":
+            return {}
+        self._apply_range_scaling(imgs.contiguous(), must=False, quiet=True)
+        self._range_calibrated = True
+        return dict(self.range_log2_scale or {})
+
+    def _apply_range_scaling(self, imgs, must, quiet=False) -> bool:
+        """-> True when scales were folded and the plan re-compiled."""
         from . import range_scaling as RS
 
-        base = self.weights
-        # ranges come from a bf16-storage twin (fp32's range) with every layer output stored (no LDS-only intermediates)
-        twin = DeviceNetwork(self.model_config, base, device=self.device, fuse_heads=False, fuse_stem=False, fuse_pairs=False,
-                             fuse_upsample=False, mfma_convt=self.mfma_convt, mfma_stem=self.mfma_stem, dtype="bf16")
-        n = min(int(imgs.shape[0]), 8)
-        ranges = twin.layer_ranges(imgs[:n].contiguous())
-        ks = RS.plan_scales(self.model_config, ranges, twin.layer_aliases())
-        del twin
+        ranges, aliases = self.measure_ranges(imgs)
+        for k, v in self._range_measured.items():
+            ranges[k] = max(ranges.get(k, 0.0), v)
+        self._range_measured = dict(ranges)
+        ks = RS.plan_scales(self.model_config, ranges, aliases)
+        if ks == (self.range_log2_scale or None):
+            return False
         if not any(ks.values()):
-            raise FloatingPointError(
-                "activations left the range of fp16 storage (65504) in a tensor that cannot be rescaled (a model input or "
-                "output): load the model with dtype='bf16' (or SLEAP_AMD_DTYPE=bf16), which has fp32's range")
-        self.weights = RS.fold_scales(self.model_config, base, ks)
-        self.range_log2_scale = ks
+            # nothing can be rescaled: every tensor fits, or the offender is a model input / output (pinned to scale 1)
+            if must:
+                return False
+            if not quiet:
+                import warnings
+
+                warnings.warn("fp16 storage: range calibration found no tensor to rescale (the large values sit in a model "
+                              "input / output or in a tensor pinned to scale 1); the plan is unchanged")
+            return False
+        self._install_scales(ks)
+        return True
+
+    def _install_scales(self, ks: Dict[str, int]):
+        from . import range_scaling as RS
+
+        self.weights = RS.fold_scales(self.model_config, self.master_weights, ks)  # master_weights stay the model's own
+        self.range_log2_scale = dict(ks)
         net, self._net = getattr(self, "_net", None), None
         if net:
             torch.cuda.synchronize(self.device)
@@ -1289,34 +1390,22 @@ class DeviceNetwork:
         self._buffers = {}
         self._compile()
 
-    def _check_fp16_range(self, bufs, warn=True):
+    def _check_fp16_range(self, bufs):
         """fp16 storage has a finite range. Once per input shape (after the first forward; one synchronisation) every stored
-        activation tensor is scanned: inf / NaN -> FloatingPointError, more than a quarter of the range used -> a warning.
+        activation tensor is scanned (`sa_tensor_absmax`). -> (largest finite value, inf / NaN seen, first offending tensor).
         Why here and not only at the outputs: ReLU is a v_max, which returns the non-NaN operand, so the NaNs that an
         overflowed (+inf) activation produces downstream (inf - inf) are scrubbed to 0 again and the heads of a badly
         overflowed network can come out FINITE; the first tensor that overflowed, however, holds +inf in HBM.
         (Intermediates that live only in LDS -- fused stem / encoder block -- are not seen by this scan; peak finding's
         SA_STATUS_NONFINITE catches what reaches the maps.)"""
         self._range_checked = True
-        worst = 0.0
-        for i, t in bufs.items():
-            if t.dtype != torch.float16:
-                continue
-            lo, hi = torch.aminmax(t)  # no temporary; NaN propagates
-            m = max(abs(float(lo)), abs(float(hi)))
-            m = m if m == m else float("nan")
-            if not np.isfinite(m) or float(lo) != float(lo) or float(hi) != float(hi):
-                self._range_checked = False
-                raise FloatingPointError(
-                    f"activations left the range of fp16 storage (65504) in plan tensor {i}: load the model with dtype='bf16' "
-                    "(or SLEAP_AMD_DTYPE=bf16), which has fp32's range")
+        scan = self._scan_tensors({i: t for i, t in bufs.items() if t.dtype == torch.float16})
+        worst, nonfinite, where = 0.0, False, None
+        for i, (m, has_inf, has_nan) in scan.items():
             worst = max(worst, m)
-        if worst > 65504.0 / 4 and warn:
-            import warnings
-
-            warnings.warn(f"fp16 storage: the largest activation of the first batch is {worst:.0f}, within 4x of the format's "
-                          "range (65504); consider dtype='bf16' for this model")
-        return worst
+            if (has_inf or has_nan) and not nonfinite:
+                nonfinite, where = True, i
+        return worst, nonfinite, where
 
     def conv_flops(self, H, W):
         """2*H*W*Cin*Cout*k*k over all convs for ONE frame (logical channels)."""

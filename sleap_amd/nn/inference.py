@@ -284,6 +284,15 @@ class InferenceModel:
         res["n_valid"] = n_valid.astype(np.int64)
         return res
 
+    def _device_networks(self):
+        """the DeviceNetwork(s) behind this model's layers (attribute `keras_model` of every layer attribute, as the reference)."""
+        nets = []
+        for v in vars(self).values():
+            km = getattr(v, "keras_model", None)
+            if km is not None and hasattr(km, "_range_gate"):
+                nets.append(km)
+        return nets
+
     # hard limits of the device kernels (csrc/postproc.hip: MAXNP; sa_find_local_peaks: max_peaks <= 16384)
     _HARD_MAX_PEAKS = 16384
     _HARD_MAX_NODE_PEAKS = 512
@@ -293,12 +302,22 @@ class InferenceModel:
         """`call` + inspection of the per-frame status words (one tiny D2H copy). The reference's ragged tensors
         have no capacity limits, so on an overflow of the fixed-shape device buffers the caps are doubled (they
         stay grown for later batches) and the batch is re-run; scipy's "infeasible" error is re-raised."""
+        rescanned = False
         while True:
             outs = self.call(data)
             bits = 0
             for v in outs["status"].tolist():
                 bits |= int(v)
             if bits & _lib.STATUS_NONFINITE:
+                # a batch far outside the one the fp16 range scales were chosen on (or the first overflow of a shape whose
+                # first batch fitted): let the networks scan this batch again -- the range gate re-calibrates with the larger
+                # of the old and new ranges (DeviceNetwork._range_gate) -- and run it once more before giving up
+                nets = [n for n in self._device_networks() if getattr(n, "dtype", None) == "fp16" and n.range_safe]
+                if nets and not rescanned:
+                    rescanned = True
+                    for n in nets:
+                        n._range_checked = False
+                    continue
                 raise FloatingPointError(NONFINITE_MESSAGE)
             if bits & _lib.STATUS_LSA_INFEASIBLE:
                 raise ValueError("cost matrix is infeasible")  # what scipy raises inside the reference

@@ -219,3 +219,20 @@ def fold_scales(model_config, weights: Dict[str, np.ndarray], log2_scale: Dict[s
             if ko and f"{name}/beta" in out:
                 out[f"{name}/beta"] *= np.float32(2.0 ** ko)
     return out
+
+
+def dist_max(values: List[float], device=None) -> List[float]:
+    """Element-wise MAX of a list of floats over the ranks of the default torch.distributed process group (the identity
+    without one): the scan result of the range gate and the calibration ranges go through it, so that every rank of a
+    frame-sharded run takes the same decision and folds the same exponents -- ranks must run numerically identical networks
+    whatever frames their shards hold. inf and NaN (as inf) survive the reduction."""
+    import torch
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+        return list(values)
+    on_gpu = dist.get_backend() == "nccl"
+    t = torch.tensor(list(values), dtype=torch.float64, device=device if on_gpu else "cpu")
+    t = torch.nan_to_num(t, nan=float("inf"), posinf=float("inf"))
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return [float(x) for x in t.cpu()]

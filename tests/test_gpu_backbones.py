@@ -520,6 +520,86 @@ def test_resnet50_plain_he_init_overflows_fp16_and_is_rescaled():
     assert _lib.DEFAULT_DTYPE in _lib.DTYPES
 
 
+def test_tensor_absmax_kernel_vs_torch():
+    """`sa_tensor_absmax` (the range scan's reduction; replaces torch.aminmax in the product path): largest finite magnitude
+    and inf / NaN flags, both storage types + float32, sizes with a tail, values placed in the tail and in the body."""
+    import ctypes as C
+
+    from sleap_amd import _lib
+
+    rng = np.random.default_rng(3)
+    for dt, tdt in (("fp16", torch.float16), ("bf16", torch.bfloat16), ("f32", torch.float32)):
+        h = _lib.lib("bf16" if dt == "f32" else dt)
+        for n in (8, 1000, 4099, 1 << 20, (1 << 22) + 5):
+            x = torch.from_numpy(rng.normal(0, 30, n).astype(np.float32)).cuda().to(tdt)
+            x[rng.integers(n)] = -3000.0
+            x[n - 1] = 2000.0
+            for special in (None, float("inf"), float("-inf"), float("nan")):
+                y = x.clone()
+                if special is not None:
+                    y[rng.integers(n)] = special
+                out = torch.full((2,), 7.0, device="cuda")
+                _lib.check(h.sa_tensor_absmax(C.c_void_p(y.data_ptr()), n, 1 if dt == "f32" else 0, C.c_void_p(out.data_ptr()),
+                                              C.c_void_p(torch.cuda.current_stream().cuda_stream)), "sa_tensor_absmax")
+                m = float(out[0])
+                flags = int(out[1:].cpu().numpy().view(np.uint32)[0])
+                fin = y[torch.isfinite(y)]
+                assert m == float(fin.abs().max()), (dt, n, special, m)
+                want = 0 if special is None else (2 if special != special else 1)
+                assert flags == want, (dt, n, special, flags)
+
+
+def test_range_calibration_is_explicit_persistable_and_keeps_the_master_weights():
+    """range scales must not depend on which batch happens to come first. `calibrate_range(frames)` measures on ALL
+    given frames and folds once; the exponents can be persisted and handed to a new network (`range_log2_scale=`), which then
+    computes the same bits with no first-batch measurement; `master_weights` stay the model's float32 weights."""
+    from sleap_amd.nn.engine import DeviceNetwork
+
+    cfg, w = _resnet(128, 96, residual_scale=1.0, features_output_stride=32, pretrained=True,
+                     upsampling=dict(output_stride=4, method="transposed_conv", skip_connections="concatenate"),
+                     heads=[("MultiInstanceConfmapsHead", 5, 4), ("PartAffinityFieldsHead", 8, 8)])
+    rng = np.random.default_rng(0)
+    x = torch.from_numpy(rng.integers(0, 256, (11, 128, 96, 1), dtype=np.uint8)).cuda()  # 11 frames: chunks of 8 + an overlap
+    net = DeviceNetwork(cfg, w, dtype="fp16")
+    ks = net.calibrate_range(x)
+    assert ks and min(ks.values()) <= -5 and net.range_log2_scale == ks
+    assert all(np.array_equal(net.master_weights[k], w[k]) for k in w) and net.master_weights is w
+    assert any(not np.array_equal(net.weights[k], w[k]) for k in w)  # the compiled weights carry the fold
+    a = [o.clone() for o in net.forward(x[:2].contiguous())]
+    import json
+
+    net2 = DeviceNetwork(cfg, w, dtype="fp16", range_log2_scale=json.loads(json.dumps(ks)))
+    b = net2.forward(x[:2].contiguous())
+    assert net2.range_log2_scale == ks
+    for p, q in zip(a, b):
+        assert torch.equal(p, q)
+    # a network that fits is left alone: no exponents, same weights object
+    cfg3, w3 = _resnet(64, 64, residual_scale=0.25, features_output_stride=32)
+    net3 = DeviceNetwork(cfg3, w3, dtype="fp16")
+    assert net3.calibrate_range(x[:2, :64, :64].contiguous()) == {} and net3.weights is w3
+
+
+def test_finite_but_unscalable_range_is_a_warning_not_an_error():
+    """ADVICE r3 (engine.py:1252): a finite first-batch maximum within 4x of the range whose tensor cannot be rescaled (here: the
+    model OUTPUT of a one-conv network) used to raise 'activations left the range'; it overflowed nothing -> a warning."""
+    from sleap_amd.nn import architectures as A
+    from sleap_amd.nn.engine import DeviceNetwork
+
+    layers = [{"class_name": "InputLayer", "name": "input", "config": {"batch_input_shape": [None, 32, 32, 1]}, "inbound_nodes": []},
+              {"class_name": "Conv2D", "name": "c0", "inbound_nodes": [[["input", 0, 0, {}]]],
+               "config": {"filters": 16, "kernel_size": [3, 3], "strides": [1, 1], "padding": "same", "activation": "relu", "use_bias": True}},
+              {"class_name": "Conv2D", "name": "c1", "inbound_nodes": [[["c0", 0, 0, {}]]],
+               "config": {"filters": 16, "kernel_size": [3, 3], "strides": [1, 1], "padding": "same", "activation": "relu", "use_bias": True}}]
+    cfg = {"class_name": "Functional", "config": {"layers": layers, "input_layers": [["input", 0, 0]], "output_layers": [["c1", 0, 0]]}}
+    w = {"c0/kernel": np.full((3, 3, 1, 16), 0.5, np.float32), "c0/bias": np.zeros(16, np.float32),
+         "c1/kernel": np.full((3, 3, 16, 16), 40.0, np.float32), "c1/bias": np.zeros(16, np.float32)}
+    x = torch.full((1, 32, 32, 1), 255, dtype=torch.uint8).cuda()
+    net = DeviceNetwork(cfg, w, dtype="fp16", fuse_stem=False)
+    with pytest.warns(UserWarning, match="within 4x"):
+        out = net.forward(x)[0]
+    assert torch.isfinite(out).all() and 65504 / 4 < float(out.max()) < 65504 and net.range_log2_scale is None
+
+
 def test_resnet50_stride16_bilinear_add_vs_oracle():
     """features_output_stride 16 (conv5 unstrided, dilated 1x1 convs = no-op), bilinear upsampling with additive
     skips through 1x1 projections; RGB input without the ImageNet Lambdas."""

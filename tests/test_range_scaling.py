@@ -95,3 +95,60 @@ def test_hourglass_add_operands_share_a_scale():
     for l in mc["config"]["layers"]:
         if l["class_name"] == "Add":
             assert len({ks[n[0]] for n in l["inbound_nodes"][0]} | {ks[l["name"]]}) == 1
+
+
+# ---- ranks of a frame-sharded run must fold the SAME exponents: the ranges go through a MAX all-reduce
+def _dist_worker(rank, world, port, q):
+    import os
+
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        # rank 0's shard stays small, rank 1's overflows one tensor; a NaN on one rank must win as inf
+        mine = [100.0, 3.0e5, 7.0] if rank else [900.0, 2.0, float("nan")]
+        red = R.dist_max(mine)
+        mc, all_t = _toy_resnet()
+        rng = _ranges(all_t)
+        local = {k: (v * (50.0 if rank else 1.0)) for k, v in rng.items()}
+        keys = sorted(local)
+        merged = dict(zip(keys, R.dist_max([local[k] for k in keys])))
+        q.put((rank, red, R.plan_scales(mc, merged)))
+    finally:
+        dist.destroy_process_group()
+
+
+def _toy_resnet():
+    from oracle.keras_graph import KerasGraph
+    from sleap_amd.nn.architectures import build_resnet_model_config, he_normal_weights
+
+    mc, shapes = build_resnet_model_config((64, 64, 1), "ResNet50", 32, True,
+                                           upsampling=dict(output_stride=4, method="transposed_conv", skip_connections="concatenate"),
+                                           heads=[("MultiInstanceConfmapsHead", 3, 4)])
+    w = he_normal_weights(shapes, seed=1)
+    x = np.random.default_rng(0).random((1, 64, 64, 1)).astype(np.float32)
+    return mc, KerasGraph(mc, w)(x, return_all=True)[1]
+
+
+def test_ranks_agree_on_ranges_and_exponents_gloo_world_2():
+    import socket
+
+    import torch.multiprocessing as mp
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_dist_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    got = sorted([q.get(timeout=240) for _ in ps], key=lambda t: t[0])
+    for p in ps:
+        p.join(60)
+    (_, red0, ks0), (_, red1, ks1) = got
+    assert red0 == red1 == [900.0, 3.0e5, float("inf")]
+    assert ks0 == ks1 and min(ks0.values()) < 0  # rank 1's larger activations decide for both
