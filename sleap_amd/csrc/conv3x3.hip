@@ -266,6 +266,11 @@ struct ConvParams2 {
   int out_pix_bytes;           // the same for the outputs: pixel stride (NHWC: 2 CoutP; planes: 32),
   unsigned out_blk_bytes, out_blk_bytes_pool;  // 16-channel block stride of dst / dst_pool (NHWC: 32; planes: pixels per frame x 32)
   int nt_in;  // input copies carry the non-temporal hint (layers whose input tiles are read by ONE cout tile: streamed once)
+  // tile index -> (cout tile, tile column, tile row, frame): when the three tile counts are powers of two (every layer of the
+  // 1024 x 1024 benchmark plan) the host hands over their log2 and the decode is three scalar shifts / masks; otherwise -1 and
+  // the kernel divides (three runtime divisions = three ~35-instruction float-reciprocal sequences on the vector unit, in front
+  // of the tile's FIRST copy: ~1 us of a 4-5 us one-tile workgroup)
+  int sh_co, sh_tx, sh_ty;
 };
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -371,6 +376,15 @@ conv3x3_dma_kernel(const ConvParams2 p) {
   };
   auto decode = [&](int l) {
     Tile t;
+    if (p.sh_co >= 0) {  // (wave-uniform) power-of-two tile counts: scalar shifts and masks only
+      t.co32_0 = (l & (p.co_tiles - 1)) * MT;
+      l >>= p.sh_co;
+      t.x0 = (l & (p.tiles_x - 1)) * TW;
+      l >>= p.sh_tx;
+      t.y0 = (l & (p.tiles_y - 1)) * TH;
+      t.b = l >> p.sh_ty;
+      return t;
+    }
     t.co32_0 = (l % p.co_tiles) * MT;
     l /= p.co_tiles;
     t.x0 = (l % p.tiles_x) * TW;
@@ -1266,6 +1280,15 @@ int launch2(const ConvParams2& p, hipStream_t st) {
     return !v || atoi(v) != 0;
   }();
   q.nt_in = (nt_on && q.co_tiles == 1 && !STEM_CIN) ? 1 : 0;
+  {
+    auto lg = [](int v) { int k = 0; while ((1 << k) < v) ++k; return (1 << k) == v ? k : -1; };
+    static const bool shifts_on = [] {
+      const char* v = getenv("SA_CONV_POW2_DECODE");
+      return !v || atoi(v) != 0;
+    }();
+    q.sh_co = lg(q.co_tiles), q.sh_tx = lg(q.tiles_x), q.sh_ty = lg(q.tiles_y);
+    if (!shifts_on || q.sh_co < 0 || q.sh_tx < 0 || q.sh_ty < 0) q.sh_co = q.sh_tx = q.sh_ty = -1;
+  }
   if (p.planar && CK != 16 && !STEM_CIN) return sa::fail(SA_ERR_UNSUPPORTED, "sa_conv3x3: SA_LAYOUT_PLANES16 needs 16-channel chunks");
   q.pix_bytes0 = p.planar ? 32 : p.C0P * 2;
   q.pix_bytes1 = p.planar ? 32 : p.C1P * 2;

@@ -259,17 +259,17 @@ int sa_network_forward(const sa_network_t* net, const void* images, int images_a
       case K_CONV1X1:  // [s0, w, bias, relu, stride, has_ext, ps, pt, res_buf, relu_last, o_buf]
         // (stride word: bits 0-7 the stride of a 1x1 conv, bits 8+ the window size k of a stride-1 "same" k x k conv)
         if ((a[4] >> 8) > 1)
-          rc = sa_convk_bf16(bp(a[0]), bc(a[0]), P<void>(a[1]), (int)(a[4] >> 8), P<float>(a[2]), bc(a[10]), (int)a[3], B, bh(a[0]),
+          rc = sa_convk_bf16(bp(a[0]), bc(a[0]), P<void>(a[1]), (int)(a[4] >> 8), P<float>(a[2]), bc(a[10]), (int)a[3] | lay, B, bh(a[0]),
                              bw(a[0]), a[5] ? P<float>(a[6]) : nullptr, a[5] ? P<float>(a[7]) : nullptr, bp(a[8]),
                              a[5] ? (int)a[9] : 0, bp(a[10]), stream);
         else
-          rc = sa_conv1x1_bf16(bp(a[0]), bc(a[0]), P<void>(a[1]), P<float>(a[2]), bc(a[10]), (int)a[3], B, bh(a[0]), bw(a[0]),
+          rc = sa_conv1x1_bf16(bp(a[0]), bc(a[0]), P<void>(a[1]), P<float>(a[2]), bc(a[10]), (int)a[3] | lay, B, bh(a[0]), bw(a[0]),
                                (int)(a[4] & 255), a[5] ? P<float>(a[6]) : nullptr, a[5] ? P<float>(a[7]) : nullptr, bp(a[8]),
                                a[5] ? (int)a[9] : 0, bp(a[10]), stream);
         break;
       case K_CONVT2: {  // [s, w0, w1, w2, w3, ksz, bias, relu, has_ext, ps, pt, relu_last, o_buf]
         const void* wp[4] = {P<void>(a[1]), P<void>(a[2]), P<void>(a[3]), P<void>(a[4])};
-        rc = sa_convt_s2_bf16(bp(a[0]), bc(a[0]), wp, (int)a[5], P<float>(a[6]), bc(a[12]), (int)a[7], B, bh(a[0]), bw(a[0]),
+        rc = sa_convt_s2_bf16(bp(a[0]), bc(a[0]), wp, (int)a[5], P<float>(a[6]), bc(a[12]), (int)a[7] | lay, B, bh(a[0]), bw(a[0]),
                               a[8] ? P<float>(a[9]) : nullptr, a[8] ? P<float>(a[10]) : nullptr, a[8] ? (int)a[11] : 0, bp(a[12]),
                               stream);
         break;
@@ -286,7 +286,11 @@ int sa_network_forward(const sa_network_t* net, const void* images, int images_a
           pt = (th > 0 ? th : 0) / 2;
           pl = (tw > 0 ? tw : 0) / 2;
         }
-        rc = sa_maxpool_bf16(bp(a[0]), B, sh, sw, bc(a[0]), k, st, pt, pl, (int)a[5], oh, ow, bp(a[1]), stream);
+        // (planes: every 16-channel plane of every frame is a frame of 16 channels)
+        if (lay == SA_LAYOUT_PLANES16)
+          rc = sa_maxpool_bf16(bp(a[0]), B * (bc(a[0]) / 16), sh, sw, 16, k, st, pt, pl, (int)a[5], oh, ow, bp(a[1]), stream);
+        else
+          rc = sa_maxpool_bf16(bp(a[0]), B, sh, sw, bc(a[0]), k, st, pt, pl, (int)a[5], oh, ow, bp(a[1]), stream);
         break;
       }
       case K_IMGCONV: {
@@ -308,14 +312,20 @@ int sa_network_forward(const sa_network_t* net, const void* images, int images_a
         break;
       }
       case K_ADD:  // [a, b, b_half_res, relu, o]
-        rc = sa_add_bf16(bp(a[0]), bp(a[1]), B, bh(a[4]), bw(a[4]), bc(a[4]), (int)a[2], (int)a[3], bp(a[4]), stream);
+        if (lay == SA_LAYOUT_PLANES16)
+          rc = sa_add_bf16(bp(a[0]), bp(a[1]), B * (bc(a[4]) / 16), bh(a[4]), bw(a[4]), 16, (int)a[2], (int)a[3], bp(a[4]), stream);
+        else
+          rc = sa_add_bf16(bp(a[0]), bp(a[1]), B, bh(a[4]), bw(a[4]), bc(a[4]), (int)a[2], (int)a[3], bp(a[4]), stream);
         break;
       case K_HEAD:  // [s, w, bias, c, act, o]
         rc = sa_conv1x1_head(bp(a[0]), bc(a[0]), P<float>(a[1]), P<float>(a[2]), (int)a[3], (int)a[4] | lay, B, bh(a[0]), bw(a[0]),
                              static_cast<float*>(bp(a[5])), stream);
         break;
       case K_POOL:  // [s, o]
-        rc = sa_maxpool2x2_bf16(bp(a[0]), B, bh(a[0]), bw(a[0]), bc(a[0]), bp(a[1]), stream);
+        if (lay == SA_LAYOUT_PLANES16)
+          rc = sa_maxpool2x2_bf16(bp(a[0]), B * (bc(a[0]) / 16), bh(a[0]), bw(a[0]), 16, bp(a[1]), stream);
+        else
+          rc = sa_maxpool2x2_bf16(bp(a[0]), B, bh(a[0]), bw(a[0]), bc(a[0]), bp(a[1]), stream);
         break;
       case K_UP:  // [s, o, bilinear]; planes: every 16-channel plane of every frame is a frame of 16 channels
         if (lay == SA_LAYOUT_PLANES16)

@@ -50,6 +50,25 @@ struct Stem16Params {
 #if !defined(SA_STEM16_PLANES8)
 #define SA_STEM16_PLANES8 1  // gray kernel: conv0 activation tile as two 8-channel planes in LDS (0: pixel-major records, A/B)
 #endif
+// conv1's K = 32 steps: step s multiplies the 16 channels of TWO taps (k-blocks 0,1 = tap PAIRS[s][0], k-blocks 2,3 = tap
+// PAIRS[s][1]; -1 = zero weights). Round 4: the pairs follow the kernel's rows and columns instead of the tap index (round 1-3:
+// taps 2s, 2s + 1), so that a B fragment is the SAME data for up to three output rows:
+//   steps 0-2 ("G", kernel row dy): taps (dy,0) | (dy,1) -- halo row R, columns 0 | 1: used by output rows R, R-1, R-2
+//   step 3   ("F0"): taps (0,2) | (1,2)                  -- column 2 of halo rows R | R+1: output row R
+//   step 4   ("F1"): zero | (2,2)                        -- the same fragment: output row R-1
+// A wave's four output rows then read 6 x 2 G + 5 x 2 F = 22 fragments from LDS instead of 40 for the same 40 MFMAs. The
+// counters (profiles/r03_pmc_sq_counters.md) and a cycle count per tile put this kernel at the LDS array: ~1900 LDS cycles per
+// tile (1280 of them conv1's fragment reads) against 800 matrix-core cycles per SIMD.
+#if !defined(SA_STEM16_REUSE)
+#define SA_STEM16_REUSE 1  // 0: the round 1-3 pairing (taps 2s | 2s + 1, one fragment read per MFMA) -- A/B builds
+#endif
+__host__ __device__ constexpr int stem16_pair_tap(int s, int half) {
+#if SA_STEM16_REUSE
+  return s < 3 ? 3 * s + half : (s == 3 ? (half ? 5 : 2) : (half ? 8 : -1));
+#else
+  return 2 * s + half < 9 ? 2 * s + half : -1;
+#endif
+}
 // tile: 16 rows x 32 columns of output per workgroup (4 waves x 4 rows)
 #define SA_STEM16_TH 16
 #define SA_STEM16_TW 32
@@ -168,8 +187,9 @@ stem16_kernel(const Stem16Params p) {
     for (int h = 0; h < 2; ++h) acc[r][h] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
   for (int s = 0; s < 5; ++s) {
-    const int tap = 2 * s + (kb >> 1);
-    const int dy = tap < 9 ? tap / 3 : 0, dx = tap < 9 ? tap % 3 : 0;  // tap 9 (padding) reads any valid address
+    const int t0 = stem16_pair_tap(s, 0) < 0 ? 0 : stem16_pair_tap(s, 0), t1 = stem16_pair_tap(s, 1);  // (a zero-weight half reads any valid address)
+    const int tap = (kb >> 1) ? t1 : t0;
+    const int dy = tap / 3, dx = tap % 3;
 #pragma unroll
     for (int r = 0; r < 4; ++r)
 #pragma unroll
@@ -408,8 +428,7 @@ stem16_gray_kernel(const Stem16Params p) {
   }
   __syncthreads();
 
-  // ---- conv1: wave w owns rows 4w..4w+3, two 16-pixel groups per row; step s covers taps 2s (lanes kb 0,1) and 2s+1
-  // (lanes kb 2,3); tap 9 is zero-weight padding and reads tap 0's address
+  // ---- conv1: wave w owns rows 4w..4w+3, two 16-pixel groups per row; A fragment s covers the tap pair stem16_pair_tap(s, .)
   f32x4 acc[4][2];
 #pragma unroll
   for (int r = 0; r < 4; ++r)
@@ -421,11 +440,31 @@ stem16_gray_kernel(const Stem16Params p) {
   const unsigned char* abase = act + ((wave * 4) * PW + n16) * 32 + (kb & 1) * 16;
 #endif
   constexpr int APIX1 = SA_STEM16_PLANES8 ? 16 : 32;
+#if SA_STEM16_REUSE
+  // fragment reuse (see stem16_pair_tap): halo row R of the wave's six feeds output rows R, R-1, R-2
+  const unsigned char* gb = abase + (kb >> 1) * APIX1;                   // G: columns 0 | 1 of halo row R
+  const unsigned char* fb = abase + ((kb >> 1) ? PW + 2 : 2) * APIX1;    // F: column 2 of halo rows R | R + 1
+#pragma unroll
+  for (int R = 0; R < 6; ++R) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const mfma_h8 g = *reinterpret_cast<const mfma_h8*>(gb + (R * PW + h * 16) * APIX1);
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy) {
+        const int r = R - dy;
+        if (r >= 0 && r < 4) acc[r][h] = SA_MFMA_16x16x32(wb[dy], g, acc[r][h], 0, 0, 0);
+      }
+      if (R < 5) {
+        const mfma_h8 f = *reinterpret_cast<const mfma_h8*>(fb + (R * PW + h * 16) * APIX1);
+        if (R < 4) acc[R][h] = SA_MFMA_16x16x32(wb[3], f, acc[R][h], 0, 0, 0);
+        if (R >= 1) acc[R - 1][h] = SA_MFMA_16x16x32(wb[4], f, acc[R - 1][h], 0, 0, 0);
+      }
+    }
+  }
+#else
 #pragma unroll
   for (int s = 0; s < 5; ++s) {
-    constexpr int dummy = 0;
-    (void)dummy;
-    const int ta = 2 * s, tb = 2 * s + 1 < 9 ? 2 * s + 1 : 0;
+    const int ta = stem16_pair_tap(s, 0), tb = stem16_pair_tap(s, 1) < 0 ? 0 : stem16_pair_tap(s, 1);
     const int off = (kb >> 1) ? ((tb / 3) * PW + tb % 3) : ((ta / 3) * PW + ta % 3);
     const unsigned char* sb = abase + off * APIX1;
 #pragma unroll
@@ -436,6 +475,7 @@ stem16_gray_kernel(const Stem16Params p) {
         acc[r][h] = SA_MFMA_16x16x32(wb[s], bv, acc[r][h], 0, 0, 0);
       }
   }
+#endif
 
   // ---- epilogue: lane holds couts kb*4..+3 of pixel (row, h*16 + n16). ReLU is one v_max against a uniform bound
   // (0 or -inf); every address is one 64-bit base per lane plus compile-time offsets.
@@ -481,7 +521,8 @@ size_t sa_stem16_blob_bytes(void) { return 8 * 64 * 8 * 2 + 32 * 4; }
 // HOST: Keras kernels conv0 (3,3,Cin,C0) f32 / conv1 (3,3,C0,C1) f32 + biases -> the per-lane MFMA A-fragment blob:
 //   wa[3][64][8] bf16: conv0 weights * 1/255 / U8_ACT_SCALE split hi/mid/lo; lane l -> cout l&15, k = (l>>4)*8 + j
 //                      (Cin=1: k-block = kernel row, j = kernel column; Cin=3: k = tap*3 + c)
-//   wb[5][64][8] bf16: conv1, step s covers taps 2s (k-blocks 0,1 = channels 0-7, 8-15) and 2s+1 (k-blocks 2,3)
+//   wb[5][64][8] bf16: conv1, step s covers taps stem16_pair_tap(s, 0) (k-blocks 0,1 = channels 0-7, 8-15) and
+//                      stem16_pair_tap(s, 1) (k-blocks 2,3); -1 = zero weights
 //   bias0[16], bias1[16] f32
 int sa_stem16_pack(const float* k0, const float* b0, int Cin, int C0, const float* k1, const float* b1, int C1,
                    void* blob) {
@@ -507,11 +548,11 @@ int sa_stem16_pack(const float* k0, const float* b0, int Cin, int C0, const floa
       w[(2 * 64 + l) * 8 + j] = sa::f2h(r1 - sa::h2f(h1));
     }
     for (int s = 0; s < 5; ++s) {
-      const int tap = 2 * s + (kb >> 1);
+      const int tap = stem16_pair_tap(s, kb >> 1);
       for (int j = 0; j < 8; ++j) {
         const int ci = (kb & 1) * 8 + j;
         float v = 0.0f;
-        if (tap < 9 && ci < C0 && m < C1) v = k1[((size_t)tap * C0 + ci) * C1 + m];
+        if (tap >= 0 && ci < C0 && m < C1) v = k1[((size_t)tap * C0 + ci) * C1 + m];
         w[((3 + s) * 64 + l) * 8 + j] = sa::f2h(v);
       }
     }

@@ -61,6 +61,10 @@ struct TapParams {
   const uint16_t* ph_w[4];
   int ph_oy[4], ph_ox[4], ph_ntaps[4];
   int ph_dy[4][4], ph_dx[4][4];
+  // 1: src / residual / dst are 16-channel planes [B, CP/16, H, W, 16] (SA_LAYOUT_PLANES16) instead of NHWC: a store instruction
+  // of the epilogue then writes 32 pixels x 32 bytes = 1 KiB contiguously (NHWC: 32 separate 32-byte pieces, one per 128-byte
+  // line -- the 64 -> 256 layers wrote at 2 TB/s), a copy instruction reads 32 pixels x 32 bytes of ONE plane
+  int planar;
 };
 
 // m / w for 0 <= m < 2^23 without the ~40-instruction integer division: float reciprocal estimate + one correction step
@@ -71,7 +75,10 @@ __device__ __forceinline__ int fast_div(int m, int w, float inv_w) {
   return q;
 }
 
-template <int WM, int WN>
+// PL: 16-channel planes (TapParams::planar). The LDS stage is then plane-major too -- [k16 step][pixel][32 B], the two 16-byte
+// halves of a pixel record XOR-swizzled with (pixel >> 3) & 1 as in conv3x3_dma_kernel's 16-channel chunks -- because a copy
+// writes LDS lane-linearly: one copy instruction = the 32 pixels of one pixel group in one plane (1 KiB on both sides).
+template <int WM, int WN, bool PL>
 __global__ void __launch_bounds__(256)
 tapconv_kernel(const TapParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -128,14 +135,17 @@ tapconv_kernel(const TapParams p) {
 #pragma unroll
   for (int j = 0; j < IN_PER_WAVE; ++j) {
     const int i = j * 4 + wave;
-    const int pl = i * 8 + (lane >> 3);
+    // NHWC: copy i covers pixels 8i..8i+7 (8 slots of 16 bytes each); planes: copy i = pixel group i % (TP/32) of k16 step
+    // i / (TP/32): pixels 32 pg .. 32 pg + 31, two 16-byte halves each
+    const int pl = PL ? (i % (TP / 32)) * 32 + (lane >> 1) : i * 8 + (lane >> 3);
     const int m = m0 + pl;
     const bool ok = m < ML;
     const int ly = ok ? fast_div(m, p.Wl, inv_wl) : 0;
     py[j] = ok ? ly * p.in_stride : -(1 << 20);
     px[j] = ok ? (m - ly * p.Wl) * p.in_stride : 0;
-    pslot[j] = (lane & 7) ^ ((pl >> 1) & 7);  // global 16-byte slot this lane fetches
+    pslot[j] = PL ? ((lane & 1) ^ ((pl >> 3) & 1)) : ((lane & 7) ^ ((pl >> 1) & 7));  // global 16-byte slot this lane fetches
   }
+  const unsigned plane_bytes_in = (unsigned)((size_t)p.Hs * p.Ws * 32);
   const unsigned wv = (unsigned)lane * 16;
 
   auto issue = [&](int chunk, int buf) {
@@ -154,6 +164,13 @@ tapconv_kernel(const TapParams p) {
     for (int j = 0; j < IN_PER_WAVE; ++j) {
       const int i = j * 4 + wave;
       const int sy = py[j] + dy, sx = px[j] + dx;
+      if constexpr (PL) {
+        const int k16 = kc * KK + i / (TP / 32);  // the plane this copy reads (wave uniform)
+        const bool ok = sy >= 0 && sy < p.Hs && sx >= 0 && sx < p.Ws && k16 < K16;
+        const unsigned voff = ok ? (unsigned)((sy * p.Ws + sx) * 32 + pslot[j] * 16) : OOB;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(stage + i * 1024), 16, voff, (int)((unsigned)k16 * plane_bytes_in), 0, 0);
+        continue;
+      }
       const bool ok = sy >= 0 && sy < p.Hs && sx >= 0 && sx < p.Ws && (kc * CK + pslot[j] * 8) < p.CinP;
       const unsigned voff = ok ? (unsigned)((sy * p.Ws + sx) * (p.CinP * 2) + pslot[j] * 16) : OOB;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(stage + i * 1024), 16, voff, kc * CK * 2, 0, 0);
@@ -194,10 +211,15 @@ tapconv_kernel(const TapParams p) {
     pix_ok[r] = m < ML;
     const int ly = pix_ok[r] ? fast_div(m, p.Wl, inv_wl) : 0;
     const int lxx = pix_ok[r] ? m - ly * p.Wl : 0;
-    const size_t off = (((size_t)b * p.Ho + (ly * p.out_stride + oy0)) * p.Wo + (lxx * p.out_stride + ox0)) * p.CoutP;
+    // element offset of this pixel's channel 0: NHWC pixel record of CoutP elements; planes: frame base + 16 elements per pixel
+    // inside a plane (channel co adds (co >> 4) planes + (co & 15), `chan_off`)
+    const size_t opix = (size_t)(ly * p.out_stride + oy0) * p.Wo + (lxx * p.out_stride + ox0);
+    const size_t off = PL ? (size_t)b * p.Ho * p.Wo * p.CoutP + opix * 16 : ((size_t)b * p.Ho * p.Wo + opix) * p.CoutP;
     drow[r] = p.dst + off;
     rrow[r] = p.residual ? p.residual + off : nullptr;
   }
+  const size_t plane_elems_out = (size_t)p.Ho * p.Wo * 16;
+  auto chan_off = [&](int co) -> size_t { return PL ? (size_t)(co >> 4) * plane_elems_out + (co & 15) : (size_t)co; };
 #if SA_TAP_PREFETCH_RES
   // the residual of the whole tile is requested BEFORE the K loop (16 eight-byte loads per lane, 32 registers): in the epilogue
   // each of them was a dependent HBM round trip of its own
@@ -210,7 +232,7 @@ tapconv_kernel(const TapParams p) {
       for (int r = 0; r < 2; ++r) {
         const int co = (co32_0 + wn * 2 + mt) * 32 + 8 * g + 4 * half;
         rq[mt][g][r] = make_uint2(0u, 0u);
-        if (rrow[r] && pix_ok[r] && co < p.CoutP) rq[mt][g][r] = *reinterpret_cast<const uint2*>(rrow[r] + co);
+        if (rrow[r] && pix_ok[r] && co < p.CoutP) rq[mt][g][r] = *reinterpret_cast<const uint2*>(rrow[r] + chan_off(co));
       }
 #endif
   issue(0, 0);
@@ -230,8 +252,12 @@ tapconv_kernel(const TapParams p) {
 #pragma unroll
       for (int r = 0; r < 2; ++r) {
         const int pl = (wm * 2 + r) * 32 + lx;
-        const int slot = (kk * 2 + half) ^ ((pl >> 1) & 7);
-        bv[r] = *reinterpret_cast<const mfma_h8*>(in_tile + pl * (CK * 2) + slot * 16);
+        if constexpr (PL) {
+          bv[r] = *reinterpret_cast<const mfma_h8*>(in_tile + kk * (TP * 32) + pl * 32 + ((half ^ ((pl >> 3) & 1)) * 16));
+        } else {
+          const int slot = (kk * 2 + half) ^ ((pl >> 1) & 7);
+          bv[r] = *reinterpret_cast<const mfma_h8*>(in_tile + pl * (CK * 2) + slot * 16);
+        }
       }
 #pragma unroll
       for (int m = 0; m < 2; ++m)
@@ -267,7 +293,7 @@ tapconv_kernel(const TapParams p) {
         const uint2 q = rq[mt][g][r];
 #else
         uint2 q = make_uint2(0u, 0u);
-        if (rrow[r] && pix_ok[r] && cok) q = *reinterpret_cast<const uint2*>(rrow[r] + co);
+        if (rrow[r] && pix_ok[r] && cok) q = *reinterpret_cast<const uint2*>(rrow[r] + chan_off(co));
 #endif
         const float rr[4] = {sa::h2f((uint16_t)(q.x & 0xffff)), sa::h2f((uint16_t)(q.x >> 16)), sa::h2f((uint16_t)(q.y & 0xffff)),
                              sa::h2f((uint16_t)(q.y >> 16))};
@@ -290,13 +316,13 @@ tapconv_kernel(const TapParams p) {
         sa::swap32(a.x, c.x);
         sa::swap32(a.y, c.y);
         const int co = cobase + 16 * pr + 8 * half;
-        if (pix_ok[r] && co < p.CoutP) *reinterpret_cast<uint4*>(drow[r] + co) = make_uint4(a.x, a.y, c.x, c.y);
+        if (pix_ok[r] && co < p.CoutP) *reinterpret_cast<uint4*>(drow[r] + chan_off(co)) = make_uint4(a.x, a.y, c.x, c.y);
       }
   }
 #endif
 }
 
-template <int WM, int WN>
+template <int WM, int WN, bool PL>
 int launch_tap(const TapParams& p0, hipStream_t st) {
   constexpr int TP = 64 * WM, NCO32 = 2 * WN;
   constexpr size_t lds = 2 * ((size_t)TP * CK * 2 + (size_t)NCO32 * (CK / 16) * 1024);
@@ -309,20 +335,22 @@ int launch_tap(const TapParams& p0, hipStream_t st) {
     return sa::fail(SA_ERR_UNSUPPORTED, "tapconv: more than 2^23 output pixels per frame");
   static bool attr_set = false;
   if (!attr_set && lds > 64 * 1024) {
-    SA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&tapconv_kernel<WM, WN>),
+    SA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&tapconv_kernel<WM, WN, PL>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
   // (a single LDS stage for single-chunk launches -- twice the resident workgroups -- measured no change: round 3, gpurun_out/r03n)
-  static_assert(lds >= 4 * 64 * 64 * sizeof(float), "the epilogue transposes 64 x 64 float32 values per wave through LDS");
-  hipLaunchKernelGGL((tapconv_kernel<WM, WN>), dim3((unsigned)nblk), dim3(256), lds, st, p);
+  if (PL && ((size_t)p.Hs * p.Ws * p.CinP * 2 >= 0xFFFFFF00ull || p.CinP % 16 || p.CoutP % 16))
+    return sa::fail(SA_ERR_UNSUPPORTED, "tapconv: SA_LAYOUT_PLANES16 needs channel counts padded to 16 and frames below 4 GiB");
+  hipLaunchKernelGGL((tapconv_kernel<WM, WN, PL>), dim3((unsigned)nblk), dim3(256), lds, st, p);
   SA_LAUNCH_CHECK();
   return SA_OK;
 }
 
 int launch_tap_pick(const TapParams& p, hipStream_t st) {
-  if (p.CoutP <= 64) return launch_tap<4, 1>(p, st);
-  return launch_tap<2, 2>(p, st);
+  if (p.planar) return p.CoutP <= 64 ? launch_tap<4, 1, true>(p, st) : launch_tap<2, 2, true>(p, st);
+  if (p.CoutP <= 64) return launch_tap<4, 1, false>(p, st);
+  return launch_tap<2, 2, false>(p, st);
 }
 
 int fill_common(TapParams& p, const void* src, int CinP, const void* w, const float* bias, int CoutP, int relu, int B,
@@ -341,7 +369,8 @@ int fill_common(TapParams& p, const void* src, int CinP, const void* w, const fl
   p.CinP = CinP;
   p.CoutP = CoutP;
   p.B = B;
-  p.relu = relu;
+  p.relu = relu & 1;  // (`relu`: bit 0 = ReLU, SA_LAYOUT_PLANES16 = src / residual / dst are 16-channel planes)
+  p.planar = (relu & SA_LAYOUT_PLANES16) ? 1 : 0;
   p.relu_last = relu_last;
   return SA_OK;
 }

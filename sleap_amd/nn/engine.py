@@ -616,9 +616,10 @@ class DeviceNetwork:
         fused stem, the fused encoder block, 3x3 convs on the DMA path (plain / concatenated sources, fused heads, pooled
         copies, BatchNormalization / residual epilogues), the materialised upsampling, first-layer convs on the image and
         un-fused 1x1 heads of <= 64 channels (the last three since round 3: the whole hourglass family); 16-bit model outputs
-        only with 16 padded channels (the same bytes in both layouts). Anything else in the plan (1x1 / transposed convs,
-        stand-alone pools and adds: the ResNet family) keeps the whole network NHWC -- one layout per plan, no conversion
-        launches."""
+        only with 16 padded channels (the same bytes in both layouts). Round 4: the tap GEMM (1x1 / k x k / transposed convs) has a
+        plane variant and stand-alone pools / adds run per plane, so the ResNet family is on planes too. What is left for NHWC:
+        the first-generation conv kernels (pooled / upsampled source modes folded into the tile load), the fixture-only
+        VALU transposed conv, the VALU first-layer conv -- one layout per plan, no conversion launches."""
         req = self._layout_request
         if req not in (None, "nhwc", "planes16"):
             raise ValueError(f"layout must be 'nhwc' or 'planes16', got {req!r}")
@@ -632,6 +633,10 @@ class DeviceNetwork:
             if k == "head":  # un-fused 1x1 head on the matrix cores: reads planes (round 3); <= 64 output channels
                 s_, o_ = op[1], op[2]
                 return o_.c <= 64 and s_.cp % 16 == 0 and s_.cp // 16 * 2048 * (1 if o_.c <= 32 else 2) <= 64 * 1024
+            if k in ("conv1x1", "convt2"):  # tap GEMM on planes (round 4: tapconv_kernel<.., PL>): 1x1 (stride 1 / 2), k x k, transposed
+                return all(v is None or v.cp % 16 == 0 for v in (op[1], op.out if k == "conv1x1" else op[4]))
+            if k in ("poolg", "pool", "add"):  # per-plane launches: a plane of a frame is a frame of 16 channels
+                return True
             if k != "conv":
                 return False
             if op.ext is not None:  # BatchNormalization / residual epilogue: plane-capable since round 3 (plain sources only)
@@ -1143,12 +1148,12 @@ class DeviceNetwork:
                 res = ext["res"] if ext else None
                 stride = op.stride
                 if op.ksize > 1:
-                    check(h.sa_convk_bf16(_ptr(bufs[s0.buf]), s0.cp, _ptr(w), op.ksize, _ptr(bias), o.cp, relu, B, sh, sw,
+                    check(h.sa_convk_bf16(_ptr(bufs[s0.buf]), s0.cp, _ptr(w), op.ksize, _ptr(bias), o.cp, relu | self.layout, B, sh, sw,
                                           _ptr(ext["ps"]) if ext else None, _ptr(ext["pt"]) if ext else None,
                                           _ptr(bufs[res.buf]) if res is not None else None, ext["relu_last"] if ext else 0,
                                           _ptr(bufs[o.buf]), st), "sa_convk_bf16")
                 else:
-                    check(h.sa_conv1x1_bf16(_ptr(bufs[s0.buf]), s0.cp, _ptr(w), _ptr(bias), o.cp, relu, B, sh, sw, stride,
+                    check(h.sa_conv1x1_bf16(_ptr(bufs[s0.buf]), s0.cp, _ptr(w), _ptr(bias), o.cp, relu | self.layout, B, sh, sw, stride,
                                             _ptr(ext["ps"]) if ext else None, _ptr(ext["pt"]) if ext else None,
                                             _ptr(bufs[res.buf]) if res is not None else None, ext["relu_last"] if ext else 0,
                                             _ptr(bufs[o.buf]), st), "sa_conv1x1_bf16")
@@ -1156,7 +1161,7 @@ class DeviceNetwork:
                 _, s, phases, bias, o, relu, ksz, ext, _cin = op
                 sh, sw = hw(s)
                 arr = (C.c_void_p * 4)(*[q.data_ptr() for q in phases])
-                check(h.sa_convt_s2_bf16(_ptr(bufs[s.buf]), s.cp, arr, ksz, _ptr(bias), o.cp, relu, B, sh, sw,
+                check(h.sa_convt_s2_bf16(_ptr(bufs[s.buf]), s.cp, arr, ksz, _ptr(bias), o.cp, relu | self.layout, B, sh, sw,
                                          _ptr(ext["ps"]) if ext else None, _ptr(ext["pt"]) if ext else None,
                                          ext["relu_last"] if ext else 0, _ptr(bufs[o.buf]), st), "sa_convt_s2_bf16")
             elif kind == "poolg":
@@ -1168,7 +1173,8 @@ class DeviceNetwork:
                     pad_l = max((ow - 1) * stride + kk - sw, 0) // 2
                 else:
                     pad_t = pad_l = pad
-                check(h.sa_maxpool_bf16(_ptr(bufs[s.buf]), B, sh, sw, s.cp, kk, stride, pad_t, pad_l, pad_zero, oh, ow,
+                nb, cpp = (B * (s.cp // 16), 16) if self.planar else (B, s.cp)  # planes: a plane of a frame = a 16-channel frame
+                check(h.sa_maxpool_bf16(_ptr(bufs[s.buf]), nb, sh, sw, cpp, kk, stride, pad_t, pad_l, pad_zero, oh, ow,
                                         _ptr(bufs[o.buf]), st), "sa_maxpool_bf16")
             elif kind == "imgconv":
                 _, o, w, bias, cin, relu, _nm, k, stride, ps, pt, cin_w, in_affine, pads, mf = op
@@ -1199,7 +1205,8 @@ class DeviceNetwork:
             elif kind == "add":
                 _, a, b, half, relu, o = op
                 oh, ow = hw(o)
-                check(h.sa_add_bf16(_ptr(bufs[a.buf]), _ptr(bufs[b.buf]), B, oh, ow, o.cp, half, relu, _ptr(bufs[o.buf]), st),
+                nb, cpp = (B * (o.cp // 16), 16) if self.planar else (B, o.cp)
+                check(h.sa_add_bf16(_ptr(bufs[a.buf]), _ptr(bufs[b.buf]), nb, oh, ow, cpp, half, relu, _ptr(bufs[o.buf]), st),
                       "sa_add_bf16")
             elif kind == "conv":
                 _, s0, s1, mode, w, bias, o, relu, o_pool, need_full, _heads, _nm, _ext = op
@@ -1216,7 +1223,8 @@ class DeviceNetwork:
             elif kind == "pool":
                 _, s, o = op
                 sh, sw = hw(s)
-                check(h.sa_maxpool2x2_bf16(_ptr(bufs[s.buf]), B, sh, sw, s.cp, _ptr(bufs[o.buf]), st), "sa_maxpool2x2_bf16")
+                nb, cpp = (B * (s.cp // 16), 16) if self.planar else (B, s.cp)
+                check(h.sa_maxpool2x2_bf16(_ptr(bufs[s.buf]), nb, sh, sw, cpp, _ptr(bufs[o.buf]), st), "sa_maxpool2x2_bf16")
             elif kind == "up":
                 _, s, o, bil = op
                 sh, sw = hw(s)
