@@ -25,7 +25,9 @@ SOURCES = [
     # per accumulator register in the (VALU-bound) epilogues: stem16 0.840 -> 0.804 ms, imgconv 0.210 -> 0.137 ms (A/B on one
     # box, tools/ab_lib.sh). The 8-wave conv3x3 kernels are VGPR-form already; forcing it on the others changed nothing.
     ("stem16.hip", ["-fno-honor-nans", "-mllvm", "-amdgpu-mfma-vgpr-form"]),
-    ("tapconv.hip", ["-fno-honor-nans"]),
+    # (round 4: VGPR-form here too -- 64 accumulators in AGPRs cost 192 v_accvgpr moves per tile and 184-220 registers in
+    #  total = two waves per SIMD; in VGPRs 124-156 = three)
+    ("tapconv.hip", ["-fno-honor-nans", "-mllvm", "-amdgpu-mfma-vgpr-form"]),
     ("convpair.hip", ["-fno-honor-nans"]),
     ("imgconv.hip", ["-fno-honor-nans", "-std=c++20", "-mllvm", "-amdgpu-mfma-vgpr-form"]),
     # sparse pyramidal Lucas-Kanade flow of the flow tracker: float32 op by op as the scalar CPU code it restates

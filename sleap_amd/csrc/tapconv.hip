@@ -28,9 +28,6 @@ using sa::mfma_h8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
-#if !defined(SA_TAP_PREFETCH_RES)
-#define SA_TAP_PREFETCH_RES 1
-#endif
 constexpr int MAX_TAPS = 16;
 constexpr int MAX_WINDOW_TAPS = 81;  // sa_convk_bf16: up to 9 x 9 windows (their offsets are computed, not listed)
 constexpr int CK = 64;  // channels per chunk
@@ -78,7 +75,9 @@ __device__ __forceinline__ int fast_div(int m, int w, float inv_w) {
 // PL: 16-channel planes (TapParams::planar). The LDS stage is then plane-major too -- [k16 step][pixel][32 B], the two 16-byte
 // halves of a pixel record XOR-swizzled with (pixel >> 3) & 1 as in conv3x3_dma_kernel's 16-channel chunks -- because a copy
 // writes LDS lane-linearly: one copy instruction = the 32 pixels of one pixel group in one plane (1 KiB on both sides).
-template <int WM, int WN, bool PL>
+// RES: the launch has a residual operand (ResNet shortcut Add). Only those instantiations carry the residual prefetch -- 32
+// registers live across the K loop (every 1x1 / k x k / transposed launch used to pay for it).
+template <int WM, int WN, bool PL, bool RES>
 __global__ void __launch_bounds__(256)
 tapconv_kernel(const TapParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -216,25 +215,28 @@ tapconv_kernel(const TapParams p) {
     const size_t opix = (size_t)(ly * p.out_stride + oy0) * p.Wo + (lxx * p.out_stride + ox0);
     const size_t off = PL ? (size_t)b * p.Ho * p.Wo * p.CoutP + opix * 16 : ((size_t)b * p.Ho * p.Wo + opix) * p.CoutP;
     drow[r] = p.dst + off;
-    rrow[r] = p.residual ? p.residual + off : nullptr;
+    rrow[r] = RES ? p.residual + off : nullptr;
   }
   const size_t plane_elems_out = (size_t)p.Ho * p.Wo * 16;
   auto chan_off = [&](int co) -> size_t { return PL ? (size_t)(co >> 4) * plane_elems_out + (co & 15) : (size_t)co; };
-#if SA_TAP_PREFETCH_RES
-  // the residual of the whole tile is requested BEFORE the K loop (16 eight-byte loads per lane, 32 registers): in the epilogue
-  // each of them was a dependent HBM round trip of its own
-  uint2 rq[2][4][2];
+  // the residual of the whole tile is requested BEFORE the K loop (32 registers): in the epilogue each load was a dependent HBM
+  // round trip of its own. Round 4: 16-byte loads -- the lane fetches the 8 CONSECUTIVE channels it will store (16 pr + 8 half),
+  // and one v_permlane32_swap per dword hands each half-wave the 4-channel groups of its accumulator layout (the store path's
+  // exchange, backwards): 8 load instructions per lane instead of 16, each covering 32 bytes per pixel (planes: 1 KiB contiguous)
+  // (the exchange itself waits for the data, so it is done in the epilogue: the K loop runs with the loads in flight)
+  uint4 rq4[RES ? 2 : 1][2][2];
+  if constexpr (RES) {
 #pragma unroll
-  for (int mt = 0; mt < 2; ++mt)
+    for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-    for (int g = 0; g < 4; ++g)
+      for (int pr = 0; pr < 2; ++pr)
 #pragma unroll
-      for (int r = 0; r < 2; ++r) {
-        const int co = (co32_0 + wn * 2 + mt) * 32 + 8 * g + 4 * half;
-        rq[mt][g][r] = make_uint2(0u, 0u);
-        if (rrow[r] && pix_ok[r] && co < p.CoutP) rq[mt][g][r] = *reinterpret_cast<const uint2*>(rrow[r] + chan_off(co));
-      }
-#endif
+        for (int r = 0; r < 2; ++r) {
+          const int co = (co32_0 + wn * 2 + mt) * 32 + 16 * pr + 8 * half;
+          rq4[mt][pr][r] = make_uint4(0u, 0u, 0u, 0u);
+          if (pix_ok[r] && co < p.CoutP) rq4[mt][pr][r] = *reinterpret_cast<const uint4*>(rrow[r] + chan_off(co));
+        }
+  }
   issue(0, 0);
   int buf = 0;
   for (int chunk = 0; chunk < n_chunks; ++chunk) {
@@ -273,6 +275,20 @@ tapconv_kernel(const TapParams p) {
     const int cobase = (co32_0 + wn * 2 + mt) * 32;
     if (cobase >= p.CoutP) continue;
     uint2 pk[2][4];
+    uint2 rq[4][2];  // residual, back in the accumulator layout: group g = channels 8 g + 4 half + 0..3
+    if constexpr (RES) {
+#pragma unroll
+      for (int pr = 0; pr < 2; ++pr)
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+          const uint4 q = rq4[mt][pr][r];
+          uint2 a = make_uint2(q.x, q.y), c = make_uint2(q.z, q.w);
+          sa::swap32(a.x, c.x);
+          sa::swap32(a.y, c.y);
+          rq[2 * pr][r] = a;
+          rq[2 * pr + 1][r] = c;
+        }
+    }
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       const int co = cobase + 8 * g + 4 * half;
@@ -289,19 +305,18 @@ tapconv_kernel(const TapParams p) {
       const float bb[4] = {bq.x, bq.y, bq.z, bq.w}, ss[4] = {sq.x, sq.y, sq.z, sq.w}, tt[4] = {tq.x, tq.y, tq.z, tq.w};
 #pragma unroll
       for (int r = 0; r < 2; ++r) {
-#if SA_TAP_PREFETCH_RES
-        const uint2 q = rq[mt][g][r];
-#else
-        uint2 q = make_uint2(0u, 0u);
-        if (rrow[r] && pix_ok[r] && cok) q = *reinterpret_cast<const uint2*>(rrow[r] + chan_off(co));
-#endif
-        const float rr[4] = {sa::h2f((uint16_t)(q.x & 0xffff)), sa::h2f((uint16_t)(q.x >> 16)), sa::h2f((uint16_t)(q.y & 0xffff)),
-                             sa::h2f((uint16_t)(q.y >> 16))};
+        float rr[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        if constexpr (RES) {
+          const uint2 q = rq[g][r];
+          rr[0] = sa::h2f((uint16_t)(q.x & 0xffff)), rr[1] = sa::h2f((uint16_t)(q.x >> 16));
+          rr[2] = sa::h2f((uint16_t)(q.y & 0xffff)), rr[3] = sa::h2f((uint16_t)(q.y >> 16));
+        }
         float v[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           float t = fmaxf(acc[mt][r][4 * g + j] + bb[j], lowv);
-          t = fmaf(t, ss[j], tt[j]) + rr[j];
+          t = fmaf(t, ss[j], tt[j]);
+          if constexpr (RES) t += rr[j];  // (the same two roundings as before: fma, then the add)
           v[j] = fmaxf(t, lowl);
         }
         pk[r][g].x = sa::f2h2(v[0], v[1]);
@@ -322,11 +337,17 @@ tapconv_kernel(const TapParams p) {
 #endif
 }
 
-template <int WM, int WN, bool PL>
+template <int WM, int WN, bool PL, bool RES>
 int launch_tap(const TapParams& p0, hipStream_t st) {
   constexpr int TP = 64 * WM, NCO32 = 2 * WN;
-  constexpr size_t lds = 2 * ((size_t)TP * CK * 2 + (size_t)NCO32 * (CK / 16) * 1024);
+  constexpr size_t stage = (size_t)TP * CK * 2 + (size_t)NCO32 * (CK / 16) * 1024;
   TapParams p = p0;
+  // single-chunk launches (one tap, Cin <= 64: the 64 -> 256 convs of ResNet's first stage) never touch the second stage: half
+  // the LDS = twice the workgroups a CU can hold by LDS (round 3 measured "no change" for this -- with the accumulators in AGPRs
+  // the register file capped a SIMD at two waves anyway; built VGPR-form since round 4: 124-156 registers, three waves)
+  int max_taps = p.n_taps;
+  for (int i = 0; i < p.n_phases; ++i) max_taps = p.ph_ntaps[i] > max_taps ? p.ph_ntaps[i] : max_taps;
+  const size_t lds = (max_taps * ((p.CinP + CK - 1) / CK) == 1 ? 1 : 2) * stage;
   p.m_tiles = (p.Hl * p.Wl + TP - 1) / TP;
   p.co_tiles = ((p.CoutP + 31) / 32 + NCO32 - 1) / NCO32;
   const size_t nblk = (size_t)p.m_tiles * p.co_tiles * p.B * (p.n_phases > 1 ? p.n_phases : 1);
@@ -334,23 +355,27 @@ int launch_tap(const TapParams& p0, hipStream_t st) {
   if ((size_t)p.Hl * p.Wl >= (1u << 23))  // fast_div's float estimate is exact below 2^23
     return sa::fail(SA_ERR_UNSUPPORTED, "tapconv: more than 2^23 output pixels per frame");
   static bool attr_set = false;
-  if (!attr_set && lds > 64 * 1024) {
-    SA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&tapconv_kernel<WM, WN, PL>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  if (!attr_set && 2 * stage > 64 * 1024) {
+    SA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&tapconv_kernel<WM, WN, PL, RES>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * stage)));
     attr_set = true;
   }
   // (a single LDS stage for single-chunk launches -- twice the resident workgroups -- measured no change: round 3, gpurun_out/r03n)
   if (PL && ((size_t)p.Hs * p.Ws * p.CinP * 2 >= 0xFFFFFF00ull || p.CinP % 16 || p.CoutP % 16))
     return sa::fail(SA_ERR_UNSUPPORTED, "tapconv: SA_LAYOUT_PLANES16 needs channel counts padded to 16 and frames below 4 GiB");
-  hipLaunchKernelGGL((tapconv_kernel<WM, WN, PL>), dim3((unsigned)nblk), dim3(256), lds, st, p);
+  hipLaunchKernelGGL((tapconv_kernel<WM, WN, PL, RES>), dim3((unsigned)nblk), dim3(256), lds, st, p);
   SA_LAUNCH_CHECK();
   return SA_OK;
 }
 
+template <bool PL, bool RES>
+int launch_tap_shape(const TapParams& p, hipStream_t st) {
+  return p.CoutP <= 64 ? launch_tap<4, 1, PL, RES>(p, st) : launch_tap<2, 2, PL, RES>(p, st);
+}
+
 int launch_tap_pick(const TapParams& p, hipStream_t st) {
-  if (p.planar) return p.CoutP <= 64 ? launch_tap<4, 1, true>(p, st) : launch_tap<2, 2, true>(p, st);
-  if (p.CoutP <= 64) return launch_tap<4, 1, false>(p, st);
-  return launch_tap<2, 2, false>(p, st);
+  if (p.planar) return p.residual ? launch_tap_shape<true, true>(p, st) : launch_tap_shape<true, false>(p, st);
+  return p.residual ? launch_tap_shape<false, true>(p, st) : launch_tap_shape<false, false>(p, st);
 }
 
 int fill_common(TapParams& p, const void* src, int CinP, const void* w, const float* bias, int CoutP, int relu, int B,

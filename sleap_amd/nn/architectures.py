@@ -72,7 +72,7 @@ def build_unet_model_config(input_shape: Tuple[int, int, int], filters: int = 16
     if stacks > 1 and down_blocks != up_blocks:  # encoder_decoder.py:632-639
         raise ValueError("If using a stacked configuration, the backbone must define symmetric encoder and decoder. "
                          "Create a stem for initial downsampling if an output stride > 1 is desired.")
-    if stacks > 1 and heads:
+    if stacks > 1 and heads and not legacy_head_suffix:
         raise ValueError(f'The name "{heads[0][0]}" is used {stacks} times in the model. All layer names should be unique.')
     g = _G()
     shapes = {}
@@ -188,12 +188,17 @@ def build_unet_model_config(input_shape: Tuple[int, int, int], filters: int = 16
 def build_hourglass_model_config(input_shape: Tuple[int, int, int], stem_stride: int = 4, max_stride: int = 64,
                                  output_stride: int = 4, stem_filters: int = 128, filters: int = 256,
                                  filter_increase: int = 128, stacks: int = 3, interp_method: str = "nearest",
-                                 heads: Sequence[Tuple[str, int, int]] = ()) -> Tuple[dict, Dict[str, tuple]]:
+                                 heads: Sequence[Tuple[str, int, int]] = (),
+                                 legacy_head_suffix: bool = False) -> Tuple[dict, Dict[str, tuple]]:
     """Hourglass.from_config (hourglass.py:299-316) + make_backbone (encoder_decoder.py:606-676) + Model.make_model.
 
     Without `heads` the model outputs are the stack outputs (what tests/nn/architectures/test_hourglass.py builds).
     With `heads`, every head attaches to every stack output under the same layer name (model.py:336-359), which
-    Keras rejects for stacks > 1; the same ValueError is raised here.
+    Keras rejects for stacks > 1; the same ValueError is raised here. `legacy_head_suffix=True` names the head of stack s
+    `<head>_<s>` instead -- the naming of models saved by older SLEAP releases (the reference's own fixture models carry
+    `MultiInstanceConfmapsHead_0`), the only way a stacked model with heads reaches inference: outputs in
+    Model.make_model's order (per head: stack 0, stack 1, ...), and `find_head` (inference.py:1204-1226) then picks the FIRST
+    match, i.e. stack 0's head.
     """
     if stem_stride not in (2, 4):
         raise NotImplementedError("hourglass stem_stride must be 2 or 4 (stride-1 'same' max pooling is not implemented)")
@@ -203,7 +208,7 @@ def build_hourglass_model_config(input_shape: Tuple[int, int, int], stem_stride:
     if stacks > 1 and down_blocks != up_blocks:
         raise ValueError("If using a stacked configuration, the backbone must define symmetric encoder and decoder. "
                          "Create a stem for initial downsampling if an output stride > 1 is desired.")
-    if stacks > 1 and heads:
+    if stacks > 1 and heads and not legacy_head_suffix:
         raise ValueError(f'The name "{heads[0][0]}" is used {stacks} times in the model. All layer names should be unique.')
     g = _G()
     shapes: Dict[str, tuple] = {}
@@ -260,17 +265,19 @@ def build_hourglass_model_config(input_shape: Tuple[int, int, int], stem_stride:
     out_layers = [o[0] for o in outs]
     if heads:
         out_layers = []
-        x, c, stride = outs[0]
         for head_name, channels, hs in heads:
-            if hs == stride:
-                src, sc = x, c
-            elif hs in mids_per_stack[0]:
-                src, sc = mids_per_stack[0][hs]
-            else:
-                raise ValueError(f"Could not find a feature activation for output at stride {hs}.")
-            shapes[f"{head_name}/kernel"] = (1, 1, int(sc), int(channels))
-            shapes[f"{head_name}/bias"] = (int(channels),)
-            out_layers.append(_conv(g, src, head_name, channels, k=1))
+            for si in range(stacks if legacy_head_suffix else 1):
+                x, c, stride = outs[si]
+                if hs == stride:
+                    src, sc = x, c
+                elif hs in mids_per_stack[si]:
+                    src, sc = mids_per_stack[si][hs]
+                else:
+                    raise ValueError(f"Could not find a feature activation for output at stride {hs}.")
+                name = f"{head_name}_{si}" if legacy_head_suffix else head_name
+                shapes[f"{name}/kernel"] = (1, 1, int(sc), int(channels))
+                shapes[f"{name}/bias"] = (int(channels),)
+                out_layers.append(_conv(g, src, name, channels, k=1))
     cfg = {"class_name": "Functional",
            "config": {"name": "model", "layers": g.layers, "input_layers": [["input", 0, 0]],
                       "output_layers": [[o, 0, 0] for o in out_layers]}}

@@ -207,3 +207,27 @@ def test_upsampling_stack_structure():
     assert shapes["upsample_s16_to_s8_refine0_conv/kernel"] == (3, 3, 2048 + 512, 16)  # conv3 output (stride 8) is the skip
     assert shapes["upsample_s8_to_s4_refine1_conv/kernel"] == (3, 3, 32, 32)
     assert "upsample_s8_to_s4_refine1_bn/gamma" in shapes
+
+
+def test_two_stack_hourglass_oracle_side_is_the_fitted_one_stack_model():
+    """(no GPU) output 0 of the two-stack graph == the fitted one-stack model's head, and find_head picks it."""
+    import numpy as np
+
+    from oracle.keras_graph import KerasGraph, preprocess
+    from sleap_amd import config_models as C
+    from sleap_amd.nn.inference import find_head
+    from test_gpu_config_parity import _two_stack_hourglass
+
+    frames, _ = C.render("hg_single13", 1, seed=306)
+    x = preprocess(frames[:, :256, :256], pad_stride=32)
+    mc, wts = _two_stack_hourglass(256, 256)
+    names = [o[0] for o in mc["config"]["output_layers"]]
+    assert names == ["SingleInstanceConfmapsHead_0", "SingleInstanceConfmapsHead_1"]
+
+    class _M:
+        output_names = names
+
+    assert find_head(_M, "SingleInstanceConfmapsHead") == 0  # inference.py:1223-1226: the FIRST match = stack 0
+    mc1, w1 = C.load_task_weights("hg_single13", 256, 256)
+    a, b = KerasGraph(mc, wts)(x)[0], KerasGraph(mc1, w1)(x)[0]
+    assert np.array_equal(a, b)

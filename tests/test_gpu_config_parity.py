@@ -80,6 +80,62 @@ def test_configs0_single_instance_unet_256_5_nodes():
     _single_instance_case("c0_single5", 16, 4, seed=300)
 
 
+def _two_stack_hourglass(h, w):
+    """A TWO-stack hourglass with per-stack heads named `<head>_<s>` (older SLEAP naming, the reference's own fixtures): stem,
+    stack 0 and `SingleInstanceConfmapsHead_0` carry the FITTED one-stack weights (stack 0 sees exactly what the one-stack model
+    sees), stack 1 and `..._1` seeded He-normal values (BatchNormalization neutral)."""
+    from sleap_amd import config_models as C
+    from sleap_amd.nn import architectures as A
+
+    t = C.TASKS["hg_single13"]
+    hg = dict(t["hourglass"], stacks=2)
+    mc, shapes = A.build_hourglass_model_config((h, w, 1), heads=t["heads"], legacy_head_suffix=True, **hg)
+    _, fitted = C.load_task_weights("hg_single13", h, w)
+    wts = A.he_normal_weights(shapes, seed=11)
+    for k in wts:
+        if k.endswith(("/gamma", "/moving_variance")):
+            wts[k][:] = 1.0
+        elif k.endswith(("/beta", "/moving_mean")):
+            wts[k][:] = 0.0
+    head = t["heads"][0][0]
+    for k, v in fitted.items():
+        k2 = k.replace(head + "/", head + "_0/")
+        assert k2 in wts and wts[k2].shape == v.shape, k
+        wts[k2] = np.asarray(v, np.float32)
+    return mc, wts
+
+
+def test_two_stack_hourglass_end_to_end_uses_stack_0_head():
+    """SURVEY.md 8(a) a2' caveat (stacks > 1 were features-only): a two-stack hourglass with per-stack heads through
+    SingleInstancePredictor. `find_head` returns the first output whose name contains the head type (inference.py:1223-1226,
+    2885-2888) -- stack 0's head -- on both sides; the device computes BOTH stacks and both heads. Peaks vs the fp32 oracle
+    positionally within 0.5 px; the second stack's maps (a seeded stack on fitted features) within 1e-2 of their range."""
+    from sleap_amd import config_models as C
+    from sleap_amd.nn.engine import DeviceNetwork
+    from sleap_amd.nn.inference import SingleInstancePredictor
+
+    n = 8
+    frames, insts = C.render("hg_single13", n, seed=306)
+    x = preprocess(frames, pad_stride=32)
+    mc, wts = _two_stack_hourglass(x.shape[1], x.shape[2])
+    ref = KerasGraph(mc, wts)(x)
+    want, want_vals = oinf.single_instance_peaks(ref[0], None, 0.2, "integral", 5, 4, 1.0)
+    assert not np.isnan(want).any() and float(want_vals.min()) > 0.4
+    net = DeviceNetwork(mc, wts, dtype="fp16")
+    assert net.output_names == ["SingleInstanceConfmapsHead_0", "SingleInstanceConfmapsHead_1"]
+    pred = SingleInstancePredictor(confmap_config=C.training_config("hg_single13"), confmap_model=net, batch_size=4, verbosity="none")
+    assert pred.inference_model.single_instance_layer.confmaps_ind == 0
+    outs = pred.predict(frames, make_labels=False)
+    got = np.concatenate([o["instance_peaks"] for o in outs])
+    npk, worst = _compare(got, want, "two-stack hourglass")
+    print(f"two-stack hourglass: {npk} peaks, max delta {worst:.4f} px")
+    assert npk == n * 13 and worst <= TOL_PX and worst <= 0.25
+    dev = [o.cpu().numpy() for o in net.forward(torch.from_numpy(frames[:2]).cuda())]
+    for d, r in zip(dev, ref):
+        assert np.isfinite(d).all()
+        assert float(np.abs(d - r[:2]).max()) <= 1e-2 * float(np.abs(r[:2]).max())
+
+
 def test_configs1_single_instance_unet_512_13_nodes_batch_32():
     """configs[1]: baseline_medium_rf.single (UNet f16 r2 s16 -> 2) on 512 x 512 frames, 13-node fly, ONE batch of 32."""
     _single_instance_case("c1_single13", 32, 32, seed=301)
@@ -175,35 +231,35 @@ def test_configs2_topdown_1024_two_animals_oracle_runs_its_own_networks():
     assert worst <= TOL_PX and worst_c <= TOL_PX and float(np.percentile(dist, 95)) <= 0.05, (worst, worst_c)
 
 
+C4_SEED = 304  # (three frames the model was not fitted to: the fit draws seeds >= 10000)
+
+
 @pytest.fixture(scope="module")
 def resnet_workload():
     from sleap_amd import config_models as C
 
     task, n_frames = "c4_resnet", 3
     sk = C.skeleton(task)
-    frames, insts = C.render(task, n_frames, seed=304)
+    frames, insts = C.render(task, n_frames, seed=C4_SEED)
     mc, w = C.load_task_weights(task, 1024, 1024)
     cms, pafs = KerasGraph(mc, w)(preprocess(frames))[:2]
     pts, vals, si, ci = opf.find_local_peaks(cms, 0.2, "integral", 5)
-    from parity_helpers import well_conditioned_peaks
-
     rough = opf.find_local_peaks_rough(cms, 0.2)[0]  # the grid maxima, in the same order
-    ill = ~well_conditioned_peaks(cms, pts, rough, vals, si, ci)
     pts = pts * np.float32(4)
     sc = opg.PAFScorer(sk.nodes, sk.edges, 8, oob="zero")
     B = n_frames
     ref = sc.predict(pafs, [pts[si == b] for b in range(B)], [vals[si == b] for b in range(B)], [ci[si == b] for b in range(B)])
-    return dict(task=task, frames=frames, insts=insts, mc=mc, w=w, ref=ref, cms=cms, pafs=pafs, peaks=(pts, vals, si, ci), ill=ill, rough=rough,
+    return dict(task=task, frames=frames, insts=insts, mc=mc, w=w, ref=ref, cms=cms, pafs=pafs, peaks=(pts, vals, si, ci), rough=rough,
                 n_peaks=[int((si == b).sum()) for b in range(B)])
 
 
 def test_configs4_oracle_detects_the_animals(resnet_workload):
-    """The workload is what configs[4] names for the ORACLE: 8 animals per 1024 x 1024 frame, 24 nodes each. The ResNet task
-    model is a SHORT fit (hours of 8 CPU cores would be needed for a clean one; conv4 / conv5 stay frozen at their seeded values):
-    it resolves 22 of the 24 rendered animals completely and leaves fragments and ~380 maxima per frame, many of them near
-    the threshold -- stated here, not hidden. Asserted (loosely: which borderline maxima survive differs between CPUs): at least
-    half of the 24 rendered animals come back as an instance with >= 17 of their 24 nodes within 3 px (mean), and at least a
-    third of the peaks are WELL CONDITIONED (parity_helpers.well_conditioned_peaks) -- those carry the 0.5 px assertion below."""
+    """The workload is what configs[4] names for the ORACLE: 8 animals per 1024 x 1024 frame, 24 nodes each. Round 4 refitted the
+    ResNet task model with a hard-negative term (tools/train_config_models.py --hard-neg: the strongest 0.05 % of the background
+    cells pushed below 0.05): the maps no longer hold hundreds of cross-type maxima at 0.2-0.4 next to the real peaks (round 3:
+    ~380 maxima per frame for 192 nodes, which needed a six-threshold "well-conditioned" filter to compare anything). Asserted:
+    every rendered animal comes back as one instance with >= 22 of its 24 nodes within 3 px (mean), and at most 2 % of the
+    maxima are not a rendered node."""
     ref, insts = resnet_workload["ref"], resnet_workload["insts"]
     total = 0
     for b, inst in enumerate(ref[0]):
@@ -212,27 +268,24 @@ def test_configs4_oracle_detects_the_animals(resnet_workload):
         for gt in insts[b]:
             d = np.nanmean(np.linalg.norm(inst - gt[None], axis=-1), axis=1)
             j = int(np.nanargmin(d))
-            total += int(nn[j] >= 17 and d[j] < 3.0)
-    n_clear = int((~resnet_workload["ill"]).sum())
-    print(f"configs[4] oracle: {total} of 24 animals resolved, {n_clear} of {len(resnet_workload['ill'])} peaks well conditioned")
-    assert total >= 12, total
-    assert n_clear >= 3 * 8 * 12 and n_clear >= len(resnet_workload["ill"]) // 3, n_clear
-    assert all(n >= 8 * 20 for n in resnet_workload["n_peaks"]), resnet_workload["n_peaks"]
+            total += int(nn[j] >= 22 and d[j] < 3.0)
+    n_true = 3 * 8 * 24
+    print(f"configs[4] oracle: {total} of 24 animals resolved, peaks per frame {resnet_workload['n_peaks']} (rendered nodes: 192)")
+    assert total == 24, total
+    assert all(192 - 4 <= n <= 192 + 4 for n in resnet_workload["n_peaks"]), resnet_workload["n_peaks"]
+    assert abs(sum(resnet_workload["n_peaks"]) - n_true) <= 0.02 * n_true
 
 
-def test_configs4_resnet50_bottomup_every_peak_within_half_a_pixel(resnet_workload):
-    """configs[4]: ResNet-50 (imagenet preprocessing Lambdas folded into the stem) + transposed-conv UpsamplingStack with
-    concatenated skips + PAF head, 24 nodes / 23 edges, 8 animals, fp16 storage (range-safe: the engine's first-batch range scan
-    re-scales the plan if the activations leave fp16's range).
+def test_configs4_resnet50_bottomup_identical_instance_assignments(resnet_workload):
+    """configs[4] at north_star's criterion: ResNet-50 (imagenet preprocessing Lambdas folded into the stem) + transposed-conv
+    UpsamplingStack with concatenated skips + PAF head, 24 nodes / 23 edges, 8 animals, fp16 storage, device path vs the fp32
+    oracle running its own network on float32 master weights. **Every** oracle peak is compared (no conditioning filter):
 
-    The ResNet task model is a short fit whose maps hold borderline maxima next to the real ones, so the comparison separates
-    what MUST agree from what is a decision on nearly equal numbers (tests/parity_helpers.py):
-
-      * every WELL-CONDITIONED oracle peak (confidence >= 0.3, maximum cell 0.02 above its neighbours, positive 5 x 5 patch with
-        sum >= 0.8, centroid within 0.6 cells) has a device peak of its channel within **0.5 px** -- asserted on all of them;
-      * the other oracle peaks must exist on the device (same channel, confidence within 5e-3), or be within 5e-3 of the
-        threshold; a device peak without an oracle partner must be within 5e-3 of the threshold;
-      * frames whose peak sets agree completely are compared at instance level (count, NaN mask, 0.5 px), the others are counted."""
+      * a device peak of the same channel within 2 px must exist and lie within **0.5 px** -- or the difference is a decision on
+        nearly equal numbers, counted and bounded: a confidence within 5e-3 of the 0.2 threshold (a threshold decision) or two
+        neighbouring cells whose oracle values differ by <= 5e-3 (which of them is "the" maximum);
+      * frames without such a decision -- at least 2 of the 3 -- give IDENTICAL instances: same count, same node assignment
+        (NaN mask), every coordinate within 0.5 px (`strict_instances=True`)."""
     from parity_helpers import compare_with_threshold_decisions
     from sleap_amd import config_models as C
     from sleap_amd.nn.engine import DeviceNetwork
@@ -246,23 +299,26 @@ def test_configs4_resnet50_bottomup_every_peak_within_half_a_pixel(resnet_worklo
     layer.return_paf_graph = True
     o = {k: v.cpu().numpy() for k, v in pred.inference_model.call_checked(torch.from_numpy(wl["frames"]).cuda()).items()
          if isinstance(v, torch.Tensor)}
-    from sleap_amd import _lib
-
-    # (STATUS_PAF_OOB is expected here: an ill-conditioned refinement puts a "peak" a thousand pixels outside the frame and its
-    # candidate lines sample the PAFs out of bounds -- zeros on the device and in the oracle's oob="zero" mode)
-    assert not int(np.bitwise_or.reduce(o["status"])) & ~_lib.STATUS_PAF_OOB, "capacity overflow / non-finite status"
+    assert not int(np.bitwise_or.reduce(o["status"])), "capacity overflow / non-finite / out-of-bounds status"
     dev = tuple(o[k] for k in ("peaks", "peak_vals", "peak_channel_inds", "peak_count"))
     stats = {}
     differing, n_common, worst, n_only, n_tie = compare_with_threshold_decisions(
-        wl["peaks"], dev, wl["ref"], o, n_nodes=24, map_eps=5e-3, tol_px=TOL_PX, ill=wl["ill"], cms=wl["cms"], stride=4,
-        strict_instances=False, stats=stats, rough_grid=wl["rough"])
-    print(f"configs[4]: {n_common} common peaks, max delta {worst:.4f} px; {n_only} peaks detected by one path only (all within "
-          f"5e-3 of the threshold); {n_tie} near ties between neighbouring cells; {int(wl['ill'].sum())} peaks that are decisions on "
-          f"nearly equal numbers (existence checked only; {stats.get('ill_within_tol', 0)} of them within 0.5 px anyway); frames with "
-          f"equal peak sets {stats.get('frames_with_equal_peak_sets', [])}, of those with equal instances "
+        wl["peaks"], dev, wl["ref"], o, n_nodes=24, map_eps=5e-3, tol_px=TOL_PX, cms=wl["cms"], stride=4,
+        strict_instances=True, stats=stats)
+    n_oracle = len(wl["peaks"][0])
+    same_sets = stats.get("frames_with_equal_peak_sets", [])
+    print(f"configs[4]: {n_common} of {n_oracle} oracle peaks matched, max delta {worst:.4f} px; {n_only} threshold decisions, {n_tie} "
+          f"neighbouring-cell ties; frames with equal peak sets {same_sets}, of those with identical instances "
           f"{stats.get('frames_with_equal_instances', [])}")
-    assert n_common == int((~wl["ill"]).sum())  # every well-conditioned peak was found within 2 px ...
-    assert worst <= TOL_PX, worst                # ... and within north_star's tolerance
+    assert worst <= TOL_PX, worst
+    assert n_common >= 0.99 * n_oracle, (n_common, n_oracle)  # (a bound on what is NOT compared positionally)
+    assert len(same_sets) >= 2, differing                       # >= 2 of 3 frames reach the instance-level comparison ...
+    assert stats.get("frames_with_equal_instances", []) == same_sets  # ... and are identical there (asserted inside as well)
+    for b in same_sets:  # stated once more, in the words of north_star: same count, same assignment, <= 0.5 px
+        want = np.asarray(wl["ref"][0][b]).reshape(-1, 24, 2)
+        got = o["instance_peaks"][b, : int(o["n_valid"][b])]
+        assert got.shape == want.shape and np.array_equal(np.isnan(got), np.isnan(want))
+        assert float(np.nanmax(np.linalg.norm(got - want, axis=-1))) <= TOL_PX
 
 
 def test_configs4_network_maps_vs_fp32_oracle(resnet_workload):
