@@ -341,6 +341,12 @@ int sa_image_conv_bf16(const void* src, int src_is_u8, int B, int H, int W, int 
 size_t sa_imgconv_packed_elems(int ksize, int CinW, int CoutP);
 int sa_imgconv_pack(const float* w, int ksize, int CinW, int Cout, int CoutP, const float* in_scale, const float* mean,
                     uint16_t* packed, float* bias_io);
+/* The same packer for ResNet's `tile_channels` input (resnet.py:326-362: a single-channel frame repeated three times in front of
+ * a 3-channel first conv): w3 [k][k][3][Cout], in_scale3 / mean3 per weight channel. The three products of a tap share their pixel,
+ * so the packed operand has ONE K slot per tap (float64 channel sum, then the hi + lo split) -- the CinW = 1 layout; run it with
+ * sa_imgconv_u8_bf16(Cin = 1, CinW = 1, has_mean as packed). */
+int sa_imgconv_pack_tiled(const float* w3, int ksize, int Cout, int CoutP, const float* in_scale3, const float* mean3,
+                          uint16_t* packed, float* bias_io);
 int sa_imgconv_u8_bf16(const void* src, int B, int H, int W, int Cin, int CinW, int ksize, int stride, int pad_top,
                        int pad_left, int Ho, int Wo, const void* wfrag, const float* bias, int CoutP, int relu,
                        int has_mean, const float* post_scale, const float* post_shift, void* dst, sa_stream_t stream);

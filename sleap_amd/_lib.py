@@ -68,6 +68,7 @@ SIGNATURES = {
     "sa_image_conv_bf16": (_i, [_p, _i, _i, _i, _i, _i, _i, _p, _i, _i, _i, _i, _i, _i, _i, _p, _p, _i, _i, _p, _p, _p, _p]),
     "sa_imgconv_packed_elems": (C.c_size_t, [_i, _i, _i]),
     "sa_imgconv_pack": (_i, [_p, _i, _i, _i, _i, _p, _p, _p, _p]),
+    "sa_imgconv_pack_tiled": (_i, [_p, _i, _i, _i, _p, _p, _p, _p]),
     "sa_imgconv_u8_bf16": (_i, [_p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p, _i, _i, _i, _p, _p, _p, _p]),
     "sa_conv3x3_pair_bf16": (_i, [_p, _i, _p, _p, _i, _i, _p, _p, _i, _i, _i, _i, _i, _p, _p, _i, _p]),
     "sa_add_bf16": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _p, _p]),

@@ -35,6 +35,7 @@ struct ImgConvParams {
   uint16_t* dst;         // [B,Ho,Wo,CoutP] bf16
   int B, H, W, Ho, Wo, CoutP, pad_t, pad_l, relu, has_mean, src_c;
   int planar;            // dst in 16-channel planes [B, CoutP/16, Ho, Wo, 16] instead of NHWC
+  unsigned pix_elems, blk_elems;  // elements between neighbouring pixels / 16-channel blocks of dst
   int tiles_x, tiles_y;
 };
 
@@ -169,8 +170,9 @@ imgconv_mfma_kernel(const ImgConvParams p) {
           sa::swap32(x.y, y.y);
           const int co = cobase + 16 * pr + 8 * half;
           if (ok && co < p.CoutP) {
-            uint16_t* o = p.planar ? p.dst + (((size_t)b * (p.CoutP >> 4) + (co >> 4)) * p.Ho * p.Wo + (size_t)gy * p.Wo + gx) * 16 + (co & 15)
-                                   : p.dst + (((size_t)b * p.Ho + gy) * p.Wo + gx) * p.CoutP + co;
+            // one formula for both layouts (element strides from the host): NHWC pix = CoutP, blk = 16; planes pix = 16, blk = Ho Wo 16
+            uint16_t* o = p.dst + (size_t)b * p.Ho * p.Wo * p.CoutP + (size_t)(co >> 4) * p.blk_elems +
+                          ((size_t)gy * p.Wo + gx) * p.pix_elems + (co & 15);
             *reinterpret_cast<uint4*>(o) = make_uint4(x.x, x.y, y.x, y.y);
           }
         }
@@ -200,12 +202,15 @@ size_t sa_imgconv_packed_elems(int ksize, int CinW, int CoutP) {
   return (size_t)((CoutP + 31) / 32) * nk * 2 * 64 * 8;
 }
 
-int sa_imgconv_pack(const float* w, int ksize, int CinW, int Cout, int CoutP, const float* in_scale, const float* mean,
-                    uint16_t* packed, float* bias_io) {
-  // w [k][k][CinW][Cout] f32 (Keras layout); in_scale[c] multiplies the raw 0..255 pixel value of weight channel c
-  // (1/255 for ensure_float alone, 1 with imagenet_preproc_v1); mean[c] (or NULL) is subtracted after scaling.
-  // bias_io [CoutP]: in = layer bias, out = bias - sum over ALL taps of v (the interior-pixel constant).
-  SA_REQUIRE(w && packed && bias_io && ksize > 0 && (CinW == 1 || CinW == 3) && Cout <= CoutP, "sa_imgconv_pack: bad arguments");
+// shared packer. `tiled`: w has CinS = 3 weight channels but the IMAGE has one (the `tile_channels` Lambda of ResNet's
+// pretrained-encoder input, resnet.py:326-362: a grayscale frame repeated three times): the three products of a tap share their
+// pixel, so sum_c w[tap][c] * s_c * x collapses to ONE K slot per tap with the summed weight (float64 sum, then the hi + lo
+// split) -- K = 49 instead of 147: 4 instead of 10 k-steps, 64 instead of 112 MFMAs per tile and the CINW = 1 kernel (218
+// registers, two waves per SIMD) instead of the CINW = 3 one (256 + spills, one wave). The mean / indicator term is already
+// per tap. Packed layout = the CinW = 1 layout.
+static int imgconv_pack_impl(const float* w, int ksize, int CinS, bool tiled, int Cout, int CoutP, const float* in_scale,
+                             const float* mean, uint16_t* packed, float* bias_io) {
+  const int CinW = tiled ? 1 : CinS;
   const int KT = ksize * ksize * CinW, NK16 = (KT + 15) / 16, NKI16 = (ksize * ksize + 15) / 16, NKALL = NK16 + NKI16;
   const int co32_n = (CoutP + 31) / 32;
   auto split = [&](float v, uint16_t* hi, uint16_t* lo) {
@@ -224,13 +229,20 @@ int sa_imgconv_pack(const float* w, int ksize, int CinW, int Cout, int CoutP, co
               const int k = ks * 16 + (lane >> 5) * 8 + j;
               if (k < KT) {
                 const int tap = k / CinW, c = k % CinW;
-                v = w[((size_t)tap * CinW + c) * Cout + co] * (in_scale ? in_scale[c] : 1.0f) * (1.0f / sa::U8_ACT_SCALE);
+                if (tiled) {
+                  double acc = 0.0;
+                  for (int cc = 0; cc < CinS; ++cc)
+                    acc += (double)w[((size_t)tap * CinS + cc) * Cout + co] * (in_scale ? (double)in_scale[cc] : 1.0);
+                  v = (float)(acc * (double)(1.0f / sa::U8_ACT_SCALE));
+                } else {
+                  v = w[((size_t)tap * CinW + c) * Cout + co] * (in_scale ? in_scale[c] : 1.0f) * (1.0f / sa::U8_ACT_SCALE);
+                }
               }
             } else if (mean) {
               const int tap = (ks - NK16) * 16 + (lane >> 5) * 8 + j;
               if (tap < ksize * ksize) {
                 double acc = 0.0;
-                for (int c = 0; c < CinW; ++c) acc += (double)w[((size_t)tap * CinW + c) * Cout + co] * mean[c];
+                for (int c = 0; c < CinS; ++c) acc += (double)w[((size_t)tap * CinS + c) * Cout + co] * mean[c];
                 v = (float)acc;
                 vsum[co] += acc;  // every (cout, tap) pair is visited exactly once
               }
@@ -245,6 +257,21 @@ int sa_imgconv_pack(const float* w, int ksize, int CinW, int Cout, int CoutP, co
   if (mean)
     for (int co = 0; co < Cout; ++co) bias_io[co] = (float)((double)bias_io[co] - vsum[co]);
   return SA_OK;
+}
+
+int sa_imgconv_pack(const float* w, int ksize, int CinW, int Cout, int CoutP, const float* in_scale, const float* mean,
+                    uint16_t* packed, float* bias_io) {
+  // w [k][k][CinW][Cout] f32 (Keras layout); in_scale[c] multiplies the raw 0..255 pixel value of weight channel c
+  // (1/255 for ensure_float alone, 1 with imagenet_preproc_v1); mean[c] (or NULL) is subtracted after scaling.
+  // bias_io [CoutP]: in = layer bias, out = bias - sum over ALL taps of v (the interior-pixel constant).
+  SA_REQUIRE(w && packed && bias_io && ksize > 0 && (CinW == 1 || CinW == 3) && Cout <= CoutP, "sa_imgconv_pack: bad arguments");
+  return imgconv_pack_impl(w, ksize, CinW, false, Cout, CoutP, in_scale, mean, packed, bias_io);
+}
+
+int sa_imgconv_pack_tiled(const float* w3, int ksize, int Cout, int CoutP, const float* in_scale3, const float* mean3,
+                          uint16_t* packed, float* bias_io) {
+  SA_REQUIRE(w3 && packed && bias_io && ksize > 0 && Cout <= CoutP, "sa_imgconv_pack_tiled: bad arguments");
+  return imgconv_pack_impl(w3, ksize, 3, true, Cout, CoutP, in_scale3, mean3, packed, bias_io);
 }
 
 int sa_imgconv_u8_bf16(const void* src, int B, int H, int W, int Cin, int CinW, int ksize, int stride, int pad_top,
@@ -271,6 +298,9 @@ int sa_imgconv_u8_bf16(const void* src, int B, int H, int W, int Cin, int CinW, 
   p.pad_l = pad_left;
   p.relu = relu & 1;  // (`relu`: bit 0 = ReLU, SA_LAYOUT_PLANES16 = write 16-channel planes)
   p.planar = (relu & SA_LAYOUT_PLANES16) ? 1 : 0;
+  SA_REQUIRE((size_t)Ho * Wo * 16 < 0xFFFFFFFFull, "sa_imgconv_u8_bf16: output plane too large");
+  p.pix_elems = p.planar ? 16u : (unsigned)CoutP;
+  p.blk_elems = p.planar ? (unsigned)((size_t)Ho * Wo * 16) : 16u;
   p.has_mean = has_mean;
   p.src_c = Cin;
   hipStream_t st = (hipStream_t)stream;

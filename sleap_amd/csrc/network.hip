@@ -118,8 +118,10 @@ int sa_network_create(const int64_t* plan, size_t n_words, sa_network_t** out) {
   if (n->layout == SA_LAYOUT_PLANES16) {
     bool fits = true;
     for (const Op& op : n->ops) {
+      // (round 4: the tap GEMM -- 1x1 / k x k / transposed convs -- has a plane variant; stand-alone pools and adds run per plane)
       fits = fits && (op.kind == K_STEM2 || op.kind == K_PAIR || op.kind == K_UP || op.kind == K_CONV || op.kind == K_IMGCONV ||
-                      op.kind == K_HEAD);
+                      op.kind == K_HEAD || op.kind == K_CONV1X1 || op.kind == K_CONVT2 || op.kind == K_POOLG || op.kind == K_POOL ||
+                      op.kind == K_ADD);
       if (op.kind == K_CONV && op.a.size() >= 10) {  // plain / concat sources; the upsampling source mode without fused heads
         const bool ext = op.a[10 + 5 * (size_t)op.a[9]] != 0;  // and without the extended (BN / residual) epilogue
         fits = fits && (op.a[2] == SA_SRC1_NONE || op.a[2] == SA_SRC1_DIRECT ||
@@ -294,7 +296,7 @@ int sa_network_forward(const sa_network_t* net, const void* images, int images_a
         break;
       }
       case K_IMGCONV: {
-        // [o, w, bias, src_c, relu, kh, kw, stride, ps, pt, cin_w, in_affine, has_pads, pad_t, pad_l, mf_w, mf_bias, has_mean]
+        // [o, w, bias, src_c, relu, kh, kw, stride, ps, pt, cin_w, in_affine, has_pads, pad_t, pad_l, mf_w, mf_bias, has_mean, mf_cin_w]
         const int oh = bh(a[0]), ow = bw(a[0]), kh = (int)a[5], kw = (int)a[6], st = (int)a[7];
         int pt = (int)a[13], pl = (int)a[14];
         if (!a[12]) {
@@ -303,7 +305,8 @@ int sa_network_forward(const sa_network_t* net, const void* images, int images_a
           pl = (tw > 0 ? tw : 0) / 2;
         }
         if (images_are_u8 && a[15])
-          rc = sa_imgconv_u8_bf16(images, B, H, W, (int)a[3], (int)a[10], kh, st, pt, pl, oh, ow, P<void>(a[15]), P<float>(a[16]),
+          // (a[18]: weight channels of the packed operand -- 1 for a tiled grayscale frame under a 3-channel kernel; older plans: a[10])
+          rc = sa_imgconv_u8_bf16(images, B, H, W, (int)a[3], op.a.size() > 18 ? (int)a[18] : (int)a[10], kh, st, pt, pl, oh, ow, P<void>(a[15]), P<float>(a[16]),
                                   bc(a[0]), (int)a[4] | lay, (int)a[17], P<float>(a[8]), P<float>(a[9]), bp(a[0]), stream);
         else
           rc = sa_image_conv_bf16(images, images_are_u8, B, H, W, (int)a[3], (int)a[10], P<float>(a[11]), kh, kw, st, pt, pl, oh, ow,

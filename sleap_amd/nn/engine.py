@@ -365,15 +365,23 @@ class DeviceNetwork:
                         # hi + lo bf16 fragments, ImageNet means folded into the bias + an exact border indicator term
                         h = self._h
                         wk = np.ascontiguousarray(w[..., :cout], dtype=np.float32)
-                        packed = np.zeros((h.sa_imgconv_packed_elems(7, cin, coutp),), np.uint16)
+                        # a tiled grayscale frame (tile_channels) under a 3-channel kernel: one K slot per tap with the channel-
+                        # summed weight (sa_imgconv_pack_tiled) -- the CinW = 1 kernel, 4 instead of 10 k-steps
+                        tiled = bool(img.tile) and cin == 3
+                        cin_k = 1 if tiled else cin
+                        packed = np.zeros((h.sa_imgconv_packed_elems(7, cin_k, coutp),), np.uint16)
                         bias_io = np.ascontiguousarray(b_np, dtype=np.float32).copy()
                         scale = np.full((cin,), 1.0 if img.preproc else 1.0 / 255.0, np.float32)
                         mean = np.array([123.68, 116.779, 103.939], np.float32) if img.preproc else None
                         vp = lambda a: a.ctypes.data_as(C.c_void_p) if a is not None else None  # noqa: E731
-                        check(h.sa_imgconv_pack(vp(wk), 7, cin, cout, coutp, vp(scale), vp(mean), vp(packed), vp(bias_io)),
-                              "sa_imgconv_pack")
+                        if tiled:
+                            check(h.sa_imgconv_pack_tiled(vp(wk), 7, cout, coutp, vp(scale), vp(mean), vp(packed), vp(bias_io)),
+                                  "sa_imgconv_pack_tiled")
+                        else:
+                            check(h.sa_imgconv_pack(vp(wk), 7, cin, cout, coutp, vp(scale), vp(mean), vp(packed), vp(bias_io)),
+                                  "sa_imgconv_pack")
                         mf = {"w": torch.from_numpy(packed.view(np.int16)).to(dev), "bias": upload_f32(bias_io),
-                              "has_mean": int(img.preproc)}
+                              "has_mean": int(img.preproc), "cin_w": cin_k}
                     plan.append(["imgconv", o, upload_f32(np.ascontiguousarray(w)), upload_f32(b_np), src_c, relu, name, k, st,
                                  ps, pt, cin, in_affine, pads, mf])
                 elif k == (1, 1) or window:
@@ -871,7 +879,8 @@ class DeviceNetwork:
                 _, o, w, bias, cin, relu, _nm, kk, stride, ps, pt, cin_w, in_affine, pads, mf = op
                 a = [bid(o), dp(w), dp(bias), cin, relu, kk[0], kk[1], stride, dp(ps), dp(pt), cin_w, dp(in_affine),
                      1 if pads is not None else 0, pads[0] if pads is not None else 0, pads[1] if pads is not None else 0,
-                     dp(mf["w"]) if mf else 0, dp(mf["bias"]) if mf else 0, mf["has_mean"] if mf else 0]
+                     dp(mf["w"]) if mf else 0, dp(mf["bias"]) if mf else 0, mf["has_mean"] if mf else 0,
+                     mf["cin_w"] if mf else 0]  # (weight channels of the PACKED operand: 1 for a tiled grayscale frame)
             elif k == "add":
                 _, ta, tb, half, relu, o = op
                 a = [bid(ta), bid(tb), half, relu, bid(o)]
@@ -1190,7 +1199,7 @@ class DeviceNetwork:
                 if pads is not None:  # explicit ZeroPadding2D + valid conv
                     pt_, pl_ = pads
                 if is_u8 and mf is not None:
-                    check(h.sa_imgconv_u8_bf16(_ptr(imgs), B, H, W, cin, cin_w, k[0], stride, pt_, pl_, oh, ow, _ptr(mf["w"]),
+                    check(h.sa_imgconv_u8_bf16(_ptr(imgs), B, H, W, cin, mf["cin_w"], k[0], stride, pt_, pl_, oh, ow, _ptr(mf["w"]),
                                                _ptr(mf["bias"]), o.cp, relu | self.layout, mf["has_mean"],
                                                _ptr(ps) if ps is not None else None, _ptr(pt) if pt is not None else None,
                                                _ptr(bufs[o.buf]), st), "sa_imgconv_u8_bf16")

@@ -75,7 +75,12 @@ def test_network_plan_validation_without_gpu():
     assert h.sa_network_create(planes.ctypes.data_as(C.c_void_p), planes.size, C.byref(out)) == 0, h.sa_last_error()
     assert h.sa_network_layout(out) == _lib.LAYOUT_PLANES16
     h.sa_network_destroy(out)
-    pool = list(words[:18]) + [12, 2, 0, 0]  # a stand-alone MaxPool2D launch only exists for NHWC tensors
+    pool = list(words[:18]) + [12, 2, 0, 0]  # round 4: a stand-alone MaxPool2D launch runs per plane (a plane of a frame = a frame)
+    pool[6] = _lib.LAYOUT_PLANES16
+    pool = np.array(pool, np.int64)
+    assert h.sa_network_create(pool.ctypes.data_as(C.c_void_p), pool.size, C.byref(out)) == 0, h.sa_last_error()
+    h.sa_network_destroy(out)
+    pool = list(words[:18]) + [7, 5, 0, 0, 0, 0, 0]  # the fixture-only VALU transposed conv only exists for NHWC tensors
     pool[6] = _lib.LAYOUT_PLANES16
     pool = np.array(pool, np.int64)
     assert h.sa_network_create(pool.ctypes.data_as(C.c_void_p), pool.size, C.byref(out)) == -3 and b"PLANES16" in h.sa_last_error()

@@ -130,3 +130,38 @@ def test_make_pipeline_describes_the_reference_chain():
     np.testing.assert_array_equal(np.concatenate([b["image"] for b in batches]), frames)
     np.testing.assert_array_equal(np.concatenate([b["frame_ind"] for b in batches]), np.arange(7))
     assert P().make_pipeline().providers == []
+
+
+def test_imgconv_tiled_packer_collapses_the_three_identical_channels():
+    """sa_imgconv_pack_tiled (ResNet's `tile_channels` input, resnet.py:326-362): a grayscale frame repeated three times under a
+    3-channel k7 kernel == ONE K slot per tap with the channel-summed weight. Host function, no GPU: the image k-steps equal the
+    CinW = 1 packing of the (float64-)summed kernel, the indicator k-steps and the bias carry sum_c w_c * mean_c."""
+    import ctypes as C
+
+    import numpy as np
+
+    from sleap_amd import _lib
+
+    rng = np.random.default_rng(5)
+    k, cout, coutp = 7, 24, 32
+    w3 = rng.normal(0, 0.1, (k, k, 3, cout)).astype(np.float32)
+    scale3 = np.full(3, 1.0, np.float32)
+    mean3 = np.array([123.68, 116.779, 103.939], np.float32)
+    bias = rng.normal(0, 1, coutp).astype(np.float32)
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+    for dt in _lib.DTYPES:
+        h = _lib.lib(dt)
+        n1 = h.sa_imgconv_packed_elems(k, 1, coutp)
+        assert n1 < h.sa_imgconv_packed_elems(k, 3, coutp)
+        pt, bt = np.zeros(n1, np.uint16), bias.copy()
+        _lib.check(h.sa_imgconv_pack_tiled(vp(w3), k, cout, coutp, vp(scale3), vp(mean3), vp(pt), vp(bt)), "sa_imgconv_pack_tiled")
+        w1 = w3.astype(np.float64).sum(axis=2, keepdims=True).astype(np.float32)
+        p1, b1 = np.zeros(n1, np.uint16), bias.copy()
+        _lib.check(h.sa_imgconv_pack(vp(np.ascontiguousarray(w1)), k, 1, cout, coutp, vp(scale3[:1]), None, vp(p1), vp(b1)), "sa_imgconv_pack")
+        nk16, nki16 = (k * k + 15) // 16, (k * k + 15) // 16
+        a = pt.reshape(coutp // 32, nk16 + nki16, 2, 64, 8)
+        b = p1.reshape(coutp // 32, nk16 + nki16, 2, 64, 8)
+        assert np.array_equal(a[:, :nk16], b[:, :nk16])           # image part: the summed kernel
+        assert not a[:, nk16:].any() == False and not b[:, nk16:].any()  # indicator part only with means
+        want = bias[:cout].astype(np.float64) - (w3.astype(np.float64) * mean3[None, None, :, None]).sum(axis=(0, 1, 2))
+        assert np.allclose(bt[:cout], want, rtol=1e-6, atol=1e-4) and np.array_equal(bt[cout:], bias[cout:])
