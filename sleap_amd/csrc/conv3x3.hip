@@ -1279,7 +1279,9 @@ int launch2(const ConvParams2& p, hipStream_t st) {
     const char* v = getenv("SA_CONV_NT");
     return !v || atoi(v) != 0;
   }();
-  q.nt_in = (nt_on && q.co_tiles == 1 && !STEM_CIN) ? 1 : 0;
+  // (round 4: only layers with <= 4 chunks. On the ResNet decoder's concatenated convs -- 320 -> 64 @256^2, 20 chunks -- the hint
+  //  cost 0.52 vs 0.35 ms: with many chunks the halo rows two vertically neighbouring tiles share are worth keeping in L2)
+  q.nt_in = (nt_on && q.co_tiles == 1 && !STEM_CIN && (p.C0P + p.C1P) / CK <= 4) ? 1 : 0;
   {
     auto lg = [](int v) { int k = 0; while ((1 << k) < v) ++k; return (1 << k) == v ? k : -1; };
     static const bool shifts_on = [] {

@@ -30,7 +30,6 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
 constexpr int MAX_TAPS = 16;
 constexpr int MAX_WINDOW_TAPS = 81;  // sa_convk_bf16: up to 9 x 9 windows (their offsets are computed, not listed)
-constexpr int CK = 64;  // channels per chunk
 
 struct TapParams {
   const uint16_t* src;  // [B,Hs,Ws,CinP]
@@ -77,7 +76,9 @@ __device__ __forceinline__ int fast_div(int m, int w, float inv_w) {
 // writes LDS lane-linearly: one copy instruction = the 32 pixels of one pixel group in one plane (1 KiB on both sides).
 // RES: the launch has a residual operand (ResNet shortcut Add). Only those instantiations carry the residual prefetch -- 32
 // registers live across the K loop (every 1x1 / k x k / transposed launch used to pay for it).
-template <int WM, int WN, bool PL, bool RES>
+// CK: channels per K chunk (64 or 32). A stage is TP x 2 CK bytes of pixels + NCO32 x CK / 16 KiB of weights; the kernel is bound by
+// memory latency, so what matters is how many workgroups a CU holds (LDS per workgroup = 1 or 2 stages, registers) -- round 4.
+template <int WM, int WN, bool PL, bool RES, int CK>
 __global__ void __launch_bounds__(256)
 tapconv_kernel(const TapParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -337,7 +338,7 @@ tapconv_kernel(const TapParams p) {
 #endif
 }
 
-template <int WM, int WN, bool PL, bool RES>
+template <int WM, int WN, bool PL, bool RES, int CK>
 int launch_tap(const TapParams& p0, hipStream_t st) {
   constexpr int TP = 64 * WM, NCO32 = 2 * WN;
   constexpr size_t stage = (size_t)TP * CK * 2 + (size_t)NCO32 * (CK / 16) * 1024;
@@ -356,26 +357,51 @@ int launch_tap(const TapParams& p0, hipStream_t st) {
     return sa::fail(SA_ERR_UNSUPPORTED, "tapconv: more than 2^23 output pixels per frame");
   static bool attr_set = false;
   if (!attr_set && 2 * stage > 64 * 1024) {
-    SA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&tapconv_kernel<WM, WN, PL, RES>),
+    SA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&tapconv_kernel<WM, WN, PL, RES, CK>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * stage)));
     attr_set = true;
   }
   // (a single LDS stage for single-chunk launches -- twice the resident workgroups -- measured no change: round 3, gpurun_out/r03n)
   if (PL && ((size_t)p.Hs * p.Ws * p.CinP * 2 >= 0xFFFFFF00ull || p.CinP % 16 || p.CoutP % 16))
     return sa::fail(SA_ERR_UNSUPPORTED, "tapconv: SA_LAYOUT_PLANES16 needs channel counts padded to 16 and frames below 4 GiB");
-  hipLaunchKernelGGL((tapconv_kernel<WM, WN, PL, RES>), dim3((unsigned)nblk), dim3(256), lds, st, p);
+  hipLaunchKernelGGL((tapconv_kernel<WM, WN, PL, RES, CK>), dim3((unsigned)nblk), dim3(256), lds, st, p);
   SA_LAUNCH_CHECK();
   return SA_OK;
 }
 
-template <bool PL, bool RES>
+// Tile shape and chunk size. Defaults: measured on MI355X (profiles/r04_tapconv_sweep.md). SA_TAP_SHAPE = 1 / 2 / 3 forces
+// 256 px x 64 couts / 128 x 128 / 64 x 256 per workgroup, SA_TAP_CK = 32 / 64 the chunk size (A/B runs).
+template <bool PL, bool RES, int CK>
 int launch_tap_shape(const TapParams& p, hipStream_t st) {
-  return p.CoutP <= 64 ? launch_tap<4, 1, PL, RES>(p, st) : launch_tap<2, 2, PL, RES>(p, st);
+  static const int force = [] {
+    const char* v = getenv("SA_TAP_SHAPE");
+    return v ? atoi(v) : 0;
+  }();
+  const int shape = force ? force : (p.CoutP <= 64 ? 1 : 2);
+  if (shape == 1) return launch_tap<4, 1, PL, RES, CK>(p, st);
+  if (shape == 3) return launch_tap<1, 4, PL, RES, CK>(p, st);
+  return launch_tap<2, 2, PL, RES, CK>(p, st);
+}
+
+template <bool PL, bool RES>
+int launch_tap_ck(const TapParams& p, hipStream_t st) {
+  static const int force = [] {
+    const char* v = getenv("SA_TAP_CK");
+    return v ? atoi(v) : 0;
+  }();
+  // measured (profiles/r04_tapconv_sweep.md, ResNet-50 @1024^2, 16 frames): 32-channel chunks take 5-15 % off every 1x1 conv with
+  // >= 128 input channels (a stage is half the LDS: more workgroups per CU for a latency-bound kernel); single-chunk launches
+  // (Cin <= 64) and the multi-tap transposed / k x k convs are better with 64
+  const int ck = force ? force : ((p.n_taps == 1 && p.n_phases <= 1 && p.CinP >= 128) ? 32 : 64);
+  if constexpr (PL) {  // (the NHWC stage layout is written for 128-byte pixel records: 64-channel chunks only)
+    if (ck == 32) return launch_tap_shape<PL, RES, 32>(p, st);
+  }
+  return launch_tap_shape<PL, RES, 64>(p, st);
 }
 
 int launch_tap_pick(const TapParams& p, hipStream_t st) {
-  if (p.planar) return p.residual ? launch_tap_shape<true, true>(p, st) : launch_tap_shape<true, false>(p, st);
-  return p.residual ? launch_tap_shape<false, true>(p, st) : launch_tap_shape<false, false>(p, st);
+  if (p.planar) return p.residual ? launch_tap_ck<true, true>(p, st) : launch_tap_ck<true, false>(p, st);
+  return p.residual ? launch_tap_ck<false, true>(p, st) : launch_tap_ck<false, false>(p, st);
 }
 
 int fill_common(TapParams& p, const void* src, int CinP, const void* w, const float* bias, int CoutP, int relu, int B,
