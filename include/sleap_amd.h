@@ -291,6 +291,24 @@ int sa_conv3x3_ex_bf16(const void* src0, int C0P, const void* src1, int C1P, int
                        const float* post_scale, const float* post_shift, const void* residual, int res_mode,
                        int relu_last, sa_stream_t stream);
 
+/* ResNet bottleneck tail in ONE launch (resnet.py:168-253: ... -> Conv2D(k3, 64) + BN + ReLU -> Conv2D(k1, 4 x 64) + BN ->
+ * Add(shortcut) -> ReLU, and the next block's Conv2D(k1, -> 64) + BN + ReLU). The 3x3 conv (src [B,H,W,CinP] -> 64 padded maps,
+ * `w` / `bias` as for sa_conv3x3_bf16, epilogue relu / post_scale / post_shift / relu_last as sa_conv3x3_ex_bf16) never stores
+ * its activation: it is the B operand of the EXPAND stage
+ *     y = act_last(affine(act(W2 h + xp_bias)) + xp_res)          -> xp_dst [B,H,W,CoutX], CoutX % 32 == 0, <= 256
+ * and y, rounded as stored, is the B operand of the optional REDUCE stage (rd_w != NULL)
+ *     z = act_last(affine(act(W1' y + rd_bias)))                  -> rd_dst [B,H,W,64]
+ * xp_w / rd_w: sa_pack_pointwise_weights of the Keras 1x1 kernels. `layout`: SA_LAYOUT_NHWC or SA_LAYOUT_PLANES16 for all
+ * tensors. Same operations per value as the un-fused sa_conv3x3_ex_bf16 / sa_conv1x1_bf16 launches; the matrix cores add a
+ * k-step's 16 products in a different order, so results agree to float32 rounding (<= 1 ulp of the storage type), not bitwise. */
+size_t sa_pointwise_packed_elems(int CinP, int CoutP);
+int sa_pack_pointwise_weights(const float* w, int Cin, int CinP, int Cout, int CoutP, void* packed);
+int sa_conv3x3_bneck_bf16(const void* src, int CinP, int layout, const void* w, const float* bias, int relu, const float* post_scale,
+                          const float* post_shift, int relu_last, int B, int H, int W, const void* xp_w, const float* xp_bias,
+                          const float* xp_scale, const float* xp_shift, const void* xp_res, int xp_relu, int xp_relu_last,
+                          int CoutX, void* xp_dst, const void* rd_w, const float* rd_bias, const float* rd_scale,
+                          const float* rd_shift, int rd_relu, int rd_relu_last, int CoutR, void* rd_dst, sa_stream_t stream);
+
 /* Same convolution with up to two 1x1 heads (Head.make_head, heads.py:42-62) fused into the epilogue and
  * computed from the fp32 accumulators (no bf16 rounding of the features the heads see). Needs CoutP <= 64 and
  * mode NONE/DIRECT. HOST arrays of length n_heads: head_w[i] -> device [head_c[i]][CoutP] f32, head_b[i] -> device

@@ -60,6 +60,10 @@ SIGNATURES = {
     "sa_stem16_pack": (_i, [_p, _p, _i, _i, _p, _p, _i, _p]),
     "sa_stem16_blob_bytes": (_sz, []),
     "sa_conv3x3_ex_bf16": (_i, [_p, _i, _p, _i, _i, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _i, _i, _p]),
+    "sa_pointwise_packed_elems": (_sz, [_i, _i]),
+    "sa_pack_pointwise_weights": (_i, [_p, _i, _i, _i, _i, _p]),
+    "sa_conv3x3_bneck_bf16": (_i, [_p, _i, _i, _p, _p, _i, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _p, _i, _i, _i, _p, _p, _p, _p, _p,
+                                   _i, _i, _i, _p, _p]),
     "sa_conv3x3_heads_bf16": (_i, [_p, _i, _p, _i, _i, _p, _p, _i, _i, _i, _i, _i, _p, _i, _p, _p, _p, _p, _p, _p]),
     "sa_pack_conv3x3_weights": (_i, [_p, _i, _i, _i, _i, _i, _i, _p]),
     "sa_conv3x3_packed_elems": (_sz, [_i, _i, _i]),

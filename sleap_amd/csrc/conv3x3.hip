@@ -271,6 +271,25 @@ struct ConvParams2 {
   // the kernel divides (three runtime divisions = three ~35-instruction float-reciprocal sequences on the vector unit, in front
   // of the tile's FIRST copy: ~1 us of a 4-5 us one-tile workgroup)
   int sh_co, sh_tx, sh_ty;
+  // ---- fused bottleneck tail (XP kernels, round 4; resnet.py:168-253). This conv's activation h (64 channels, never stored)
+  // goes through the block's 1x1 EXPAND conv in the epilogue -- y = act1(affine1(W2 h + b2) + residual), stored -- and y (as
+  // stored: rounded to 16 bits) through the NEXT block's 1x1 REDUCE conv -- z = act2(affine2(W1' y + b1')), stored. Both are
+  // second / third MFMA stages fed straight from accumulator registers (the fused heads' trick: lane half h, element j <->
+  // channel 16 s + 8 (j >> 2) + 4 h + (j & 3), the weights packed with the same map by sa_pack_pointwise_weights).
+  const uint16_t* xp_w;       // [CoutX / 32][CoutP / 16][64][8]
+  const float* xp_bias;       // [CoutX]
+  const float* xp_scale;      // [CoutX] or nullptr
+  const float* xp_shift;
+  const uint16_t* xp_res;     // y-shaped residual or nullptr
+  uint16_t* xp_dst;           // y: [B,H,W,CoutX] in the launch's layout
+  int CoutX, xp_relu, xp_relu_last;
+  const uint16_t* rd_w;       // [CoutR / 32][CoutX / 16][64][8] or nullptr (no reduce stage)
+  const float* rd_bias;
+  const float* rd_scale;
+  const float* rd_shift;
+  uint16_t* rd_dst;           // z: [B,H,W,CoutR], CoutR == 64
+  int CoutR, rd_relu, rd_relu_last;
+  int xp_pix_bytes;           // bytes between neighbouring pixels of y (NHWC: 2 CoutX; planes: 32)
 };
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -311,8 +330,8 @@ __device__ __forceinline__ int swz(int p) {
 #if !defined(SA_CONV_EXT_WG2)
 #define SA_CONV_EXT_WG2 1
 #endif
-template <int MT, int CK, int NW, int R, int NBUF, bool HEADS, int STEM_CIN, bool EXT, bool UPS, int ITAP>
-__global__ void __launch_bounds__(NW * 64, (NW == 8 && MT <= 2 && NBUF == 2 && (!EXT || SA_CONV_EXT_WG2) && CK == 16 && STEM_CIN == 0) ? 4 : 1)
+template <int MT, int CK, int NW, int R, int NBUF, bool HEADS, int STEM_CIN, bool EXT, bool UPS, int ITAP, bool XP = false>
+__global__ void __launch_bounds__(NW * 64, (NW == 8 && MT <= 2 && NBUF == 2 && (!EXT || SA_CONV_EXT_WG2) && CK == 16 && STEM_CIN == 0 && !XP) ? 4 : 1)
 conv3x3_dma_kernel(const ConvParams2 p) {
 #if defined(__HIP_DEVICE_COMPILE__)  // the body uses device-only types (buffer resources); the host pass only needs the stub
   constexpr int TH = NW * R, TW = 32, PH = TH + 2, PW = TW + 2;
@@ -515,6 +534,17 @@ conv3x3_dma_kernel(const ConvParams2 p) {
 
   const int n_chunks = CinP / CK;
   issue(cur, voff0, voff1, 0, 0);
+  if constexpr (XP) {
+    // the expand / reduce weight fragments -> LDS behind the stages: CoutX * 128 bytes each = CoutX / 8 one-KiB pieces, wave w
+    // takes pieces w, w + NW, ...; they land under the K loop (every chunk waits for vmcnt(0) and meets at a barrier)
+    const int n_pc = p.CoutX >> 3;
+    const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void*)p.xp_w, 0, n_pc * 1024, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsr = __builtin_amdgcn_make_buffer_rsrc((void*)(p.rd_w ? p.rd_w : p.xp_w), 0, n_pc * 1024, 0x00020000);
+    for (int i = wave; i < n_pc; i += NW) {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (lds_ptr_t)(smem + NBUF * STAGE + i * 1024), 16, wv, i * 1024, 0, 0);
+      if (p.rd_w) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsr, (lds_ptr_t)(smem + NBUF * STAGE + (n_pc + i) * 1024), 16, wv, i * 1024, 0, 0);
+    }
+  }
   // UPS: the low-resolution tile of source chunk `chunk` (>= C0P / CK) -> its own buffer, six wave-instructions
   auto issue_low = [&](const Tile& t, int chunk) {
     if constexpr (UPS) {
@@ -904,7 +934,206 @@ conv3x3_dma_kernel(const ConvParams2 p) {
   // channels, i.e. one 16-byte store per pair instead of two 8-byte stores (fewer store instructions, full 64-byte
   // runs per pixel instead of interleaved partial writes).
   const int gx = x0 + lx;
-  if constexpr (EXT) {
+  if constexpr (XP) {
+    // ---- fused bottleneck tail: expand (+ BN + residual + ReLU) and the next block's reduce, see ConvParams2. One workgroup per
+    // CU (the three stages' registers): the launch is HBM-bound -- 272 MFMAs per wave and tile against ~170 KB of tile traffic --
+    // so what matters is that the residual loads and the weight fragments of co-tile t + 1 are in flight while t is computed.
+    static_assert(!XP || (MT == 2 && EXT && !HEADS && !UPS && NBUF == 2 && CK == 16 && R == 2), "XP: the 64-channel extended kernel");
+    const float lowv = p.relu ? 0.0f : -INFINITY;
+    const bool colok = gx < W;
+    // (1) h = this conv's activation (bias is the accumulators' initial value), as B fragments: k-step k = 2 m + s2
+    mfma_h8 hb[4][R];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const int c_lo = m * 32 + 16 * s2 + 4 * half;  // channels c_lo..c_lo+3 and c_lo+8..c_lo+11
+        float sc[8] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f}, sh[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (p.post_scale) {
+          const float4 a0 = *reinterpret_cast<const float4*>(p.post_scale + c_lo), a1 = *reinterpret_cast<const float4*>(p.post_scale + c_lo + 8);
+          const float4 b0 = *reinterpret_cast<const float4*>(p.post_shift + c_lo), b1 = *reinterpret_cast<const float4*>(p.post_shift + c_lo + 8);
+          sc[0] = a0.x, sc[1] = a0.y, sc[2] = a0.z, sc[3] = a0.w, sc[4] = a1.x, sc[5] = a1.y, sc[6] = a1.z, sc[7] = a1.w;
+          sh[0] = b0.x, sh[1] = b0.y, sh[2] = b0.z, sh[3] = b0.w, sh[4] = b1.x, sh[5] = b1.y, sh[6] = b1.z, sh[7] = b1.w;
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          h16x8_t fq;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            float t = fmaxf(acc[m][r][8 * s2 + j], lowv);  // the same operations as the extended epilogue's act()
+            t = fmaf(t, sc[j], sh[j]);
+            if (p.relu_last) t = fmaxf(t, 0.0f);
+            fq[j] = sa::f2h(t);
+          }
+          hb[m * 2 + s2][r] = __builtin_bit_cast(mfma_h8, fq);
+        }
+      }
+    // (2) per 32-channel tile t of y: expand GEMM (K = 64: 4 k-steps), epilogue, store; its rounded values feed the reduce GEMM
+    const int n_t = p.CoutX >> 5, KX = p.CoutX >> 4;
+    const bool has_rd = p.rd_w != nullptr;
+    const unsigned ypix = (unsigned)p.xp_pix_bytes;
+    const size_t yblk = p.planar ? (size_t)H * W * 32 : (size_t)32;  // bytes between 16-channel blocks of y
+    unsigned char* yframe = reinterpret_cast<unsigned char*>(p.xp_dst) + (size_t)b * H * W * p.CoutX * 2;
+    const unsigned char* rframe = p.xp_res ? reinterpret_cast<const unsigned char*>(p.xp_res) + (size_t)b * H * W * p.CoutX * 2 : nullptr;
+    unsigned lane_off[R];
+    bool ok[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int gy = y0 + wave * R + r;
+      ok[r] = colok && gy < H;
+      lane_off[r] = ok[r] ? (unsigned)(gy * W + gx) * ypix + (unsigned)half * 16u : 0u;
+    }
+    f32x16 a2[2][R];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) a2[m][r][i] = 0.0f;
+    // the weight fragments of both stages sit in LDS behind the stages (copied by every workgroup at its start, under the 3x3
+    // conv's K loop): expand [t][k = 0..3] at XW, reduce [m][k16] at XW + CoutX * 128. The residual pieces of co-tile t + 1 are
+    // requested while t is computed (they come from HBM).
+    const unsigned char* XW = smem + NBUF * STAGE;
+    const unsigned char* RW = XW + (size_t)p.CoutX * 128;
+    uint4 RQ[2][R];
+    auto fetch = [&](int t, uint4 (&rq)[2][R]) {
+#pragma unroll
+      for (int pr = 0; pr < 2; ++pr)
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          rq[pr][r] = make_uint4(0u, 0u, 0u, 0u);
+          if (rframe && ok[r]) rq[pr][r] = *reinterpret_cast<const uint4*>(rframe + (size_t)(2 * t + pr) * yblk + lane_off[r]);
+        }
+    };
+    fetch(0, RQ);
+    const float low1 = p.xp_relu ? 0.0f : -INFINITY, lowl1 = p.xp_relu_last ? 0.0f : -INFINITY;
+#pragma clang loop unroll(disable)
+    for (int t = 0; t < n_t; ++t) {
+      uint4 nRQ[2][R];
+      if (t + 1 < n_t) fetch(t + 1, nRQ);
+      f32x16 a1[R];
+#pragma unroll
+      for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) a1[r][i] = 0.0f;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const mfma_h8 a = *reinterpret_cast<const mfma_h8*>(XW + ((size_t)(t * 4 + k) * 64 + lane_e) * 16);
+#pragma unroll
+        for (int r = 0; r < R; ++r) a1[r] = SA_MFMA_32x32x16(a, hb[k][r], a1[r], 0, 0, 0);
+      }
+      // residual back into the accumulator layout (group g = channels 8 g + 4 half + 0..3), as tapconv_kernel does
+      uint2 rq[4][R];
+#pragma unroll
+      for (int pr = 0; pr < 2; ++pr)
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          uint2 a = make_uint2(RQ[pr][r].x, RQ[pr][r].y), c = make_uint2(RQ[pr][r].z, RQ[pr][r].w);
+          sa::swap32(a.x, c.x);
+          sa::swap32(a.y, c.y);
+          rq[2 * pr][r] = a;
+          rq[2 * pr + 1][r] = c;
+        }
+      uint2 pk[R][4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int co = 32 * t + 8 * g + 4 * half;
+        const float4 bq = *reinterpret_cast<const float4*>(p.xp_bias + co);
+        float4 sq = make_float4(1.f, 1.f, 1.f, 1.f), tq = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p.xp_scale) {
+          sq = *reinterpret_cast<const float4*>(p.xp_scale + co);
+          tq = *reinterpret_cast<const float4*>(p.xp_shift + co);
+        }
+        const float bb[4] = {bq.x, bq.y, bq.z, bq.w}, ss[4] = {sq.x, sq.y, sq.z, sq.w}, tt[4] = {tq.x, tq.y, tq.z, tq.w};
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          const uint2 q = rq[g][r];
+          const float rr[4] = {sa::h2f((uint16_t)(q.x & 0xffff)), sa::h2f((uint16_t)(q.x >> 16)), sa::h2f((uint16_t)(q.y & 0xffff)),
+                               sa::h2f((uint16_t)(q.y >> 16))};
+          float v[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {  // (the tap GEMM's epilogue, operation for operation)
+            float u = fmaxf(a1[r][4 * g + j] + bb[j], low1);
+            u = fmaf(u, ss[j], tt[j]);
+            if (rframe) u += rr[j];
+            v[j] = fmaxf(u, lowl1);
+          }
+          pk[r][g].x = sa::f2h2(v[0], v[1]);
+          pk[r][g].y = sa::f2h2(v[2], v[3]);
+        }
+      }
+      if (has_rd) {  // y as stored (rounded) is the reduce conv's input: k-steps 2 t, 2 t + 1
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+          for (int r = 0; r < R; ++r) {
+            const mfma_h8 yf = __builtin_bit_cast(mfma_h8, make_uint4(pk[r][2 * s2].x, pk[r][2 * s2].y, pk[r][2 * s2 + 1].x, pk[r][2 * s2 + 1].y));
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+              const mfma_h8 a = *reinterpret_cast<const mfma_h8*>(RW + ((size_t)(m * KX + 2 * t + s2) * 64 + lane_e) * 16);
+              a2[m][r] = SA_MFMA_32x32x16(a, yf, a2[m][r], 0, 0, 0);
+            }
+          }
+      }
+#pragma unroll
+      for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr) {
+          uint2 a = pk[r][2 * pr], c = pk[r][2 * pr + 1];
+          sa::swap32(a.x, c.x);
+          sa::swap32(a.y, c.y);
+          if (ok[r]) *reinterpret_cast<uint4*>(yframe + (size_t)(2 * t + pr) * yblk + lane_off[r]) = make_uint4(a.x, a.y, c.x, c.y);
+        }
+      if (t + 1 < n_t) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < R; ++j) RQ[i][j] = nRQ[i][j];
+      }
+    }
+    // (3) z = the reduce conv's output (64 channels), in the layout / strides of this launch's 64-channel tensors
+    if (has_rd) {
+      const float low2 = p.rd_relu ? 0.0f : -INFINITY, lowl2 = p.rd_relu_last ? 0.0f : -INFINITY;
+      unsigned char* zframe = reinterpret_cast<unsigned char*>(p.rd_dst) + (size_t)b * H * W * p.CoutR * 2;
+      const unsigned zpix = (unsigned)p.out_pix_bytes;
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        uint2 pk[R][4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int co = 32 * m + 8 * g + 4 * half;
+          const float4 bq = *reinterpret_cast<const float4*>(p.rd_bias + co);
+          float4 sq = make_float4(1.f, 1.f, 1.f, 1.f), tq = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (p.rd_scale) {
+            sq = *reinterpret_cast<const float4*>(p.rd_scale + co);
+            tq = *reinterpret_cast<const float4*>(p.rd_shift + co);
+          }
+          const float bb[4] = {bq.x, bq.y, bq.z, bq.w}, ss[4] = {sq.x, sq.y, sq.z, sq.w}, tt[4] = {tq.x, tq.y, tq.z, tq.w};
+#pragma unroll
+          for (int r = 0; r < R; ++r) {
+            float v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = fmaxf(fmaf(fmaxf(a2[m][r][4 * g + j] + bb[j], low2), ss[j], tt[j]), lowl2);
+            pk[r][g].x = sa::f2h2(v[0], v[1]);
+            pk[r][g].y = sa::f2h2(v[2], v[3]);
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          const int gy = y0 + wave * R + r;
+#pragma unroll
+          for (int pr = 0; pr < 2; ++pr) {
+            uint2 a = pk[r][2 * pr], c = pk[r][2 * pr + 1];
+            sa::swap32(a.x, c.x);
+            sa::swap32(a.y, c.y);
+            if (ok[r])
+              *reinterpret_cast<uint4*>(zframe + (size_t)(2 * m + pr) * p.out_blk_bytes + (size_t)(gy * W + gx) * zpix + (unsigned)half * 16u) =
+                  make_uint4(a.x, a.y, c.x, c.y);
+          }
+        }
+      }
+    }
+  } else if constexpr (EXT) {
     // Extended epilogue, one PAIR of 4-channel groups (= one 16-byte store piece) at a time: post-scale, post-shift and the
     // residual of a whole cout tile live together cost 80 registers beside the accumulators (29 spilled at the 128 of two
     // workgroups per CU); per pair they cost 32. Same operations in the same order as before: same bits.
@@ -1260,13 +1489,15 @@ conv3x3_dma_kernel(const ConvParams2 p) {
 #endif
 }
 
-template <int MT, int CK, int NW, int R, int NBUF, bool HEADS, int STEM_CIN = 0, bool EXT = false, bool UPS = false, int ITAP = -1>
+template <int MT, int CK, int NW, int R, int NBUF, bool HEADS, int STEM_CIN = 0, bool EXT = false, bool UPS = false, int ITAP = -1, bool XP = false>
 int launch2(const ConvParams2& p, hipStream_t st) {
   constexpr int TH = NW * R;
   constexpr int N_IN = ((TH + 2) * 34 * CK * 2 + 1023) / 1024;
   constexpr size_t lds = NBUF * ((size_t)N_IN * 1024 + (size_t)MT * (CK / 16) * 9 * 1024) +
                          (STEM_CIN ? ((size_t)(TH + 4) * 36 * STEM_CIN + (size_t)(9 * STEM_CIN + 1) * CK) * 4 : 0) +
-                         (UPS ? 4096 : 0);  // segment A of the low-resolution tile
+                         (UPS ? 4096 : 0) +  // segment A of the low-resolution tile
+                         (XP ? 65536 : 0);   // expand + reduce weight fragments (CoutX <= 256)
+  if (XP && (p.CoutX > 256 || p.CoutX % 32)) return sa::fail(SA_ERR_UNSUPPORTED, "sa_conv3x3_bneck_bf16: CoutX must be a multiple of 32, <= 256");
   ConvParams2 q = p;
   q.tiles_x = (p.W + 31) / 32;
   q.tiles_y = (p.H + TH - 1) / TH;
@@ -1281,7 +1512,11 @@ int launch2(const ConvParams2& p, hipStream_t st) {
   }();
   // (round 4: only layers with <= 4 chunks. On the ResNet decoder's concatenated convs -- 320 -> 64 @256^2, 20 chunks -- the hint
   //  cost 0.52 vs 0.35 ms: with many chunks the halo rows two vertically neighbouring tiles share are worth keeping in L2)
-  q.nt_in = (nt_on && q.co_tiles == 1 && !STEM_CIN && (p.C0P + p.C1P) / CK <= 4) ? 1 : 0;
+  static const int nt_max_chunks = [] {
+    const char* v = getenv("SA_CONV_NT_MAX_CHUNKS");  // (A/B runs; 99 = round 3's rule)
+    return v ? atoi(v) : 4;
+  }();
+  q.nt_in = (nt_on && q.co_tiles == 1 && !STEM_CIN && (p.C0P + p.C1P) / CK <= nt_max_chunks) ? 1 : 0;
   {
     auto lg = [](int v) { int k = 0; while ((1 << k) < v) ++k; return (1 << k) == v ? k : -1; };
     static const bool shifts_on = [] {
@@ -1308,7 +1543,7 @@ int launch2(const ConvParams2& p, hipStream_t st) {
     return sa::fail(SA_ERR_UNSUPPORTED, "sa_conv3x3_bf16: one frame must be smaller than 4 GiB");
   static bool attr_set = false;
   if (!attr_set && lds > 64 * 1024) {
-    SA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_dma_kernel<MT, CK, NW, R, NBUF, HEADS, STEM_CIN, EXT, UPS, ITAP>),
+    SA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_dma_kernel<MT, CK, NW, R, NBUF, HEADS, STEM_CIN, EXT, UPS, ITAP, XP>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
@@ -1334,7 +1569,7 @@ int launch2(const ConvParams2& p, hipStream_t st) {
       SA_HIP_CHECK(hipGetDevice(&dev));
       SA_HIP_CHECK(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
       SA_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(
-          &nb, reinterpret_cast<const void*>(&conv3x3_dma_kernel<MT, CK, NW, R, NBUF, HEADS, STEM_CIN, EXT, UPS, ITAP>), NW * 64, lds));
+          &nb, reinterpret_cast<const void*>(&conv3x3_dma_kernel<MT, CK, NW, R, NBUF, HEADS, STEM_CIN, EXT, UPS, ITAP, XP>), NW * 64, lds));
       per_cu = nb > 0 ? nb : 1;
     }
     if (g_grid_limit > 0) {
@@ -1344,7 +1579,7 @@ int launch2(const ConvParams2& p, hipStream_t st) {
       if (cap < grid) grid = cap;
     }
   }
-  hipLaunchKernelGGL((conv3x3_dma_kernel<MT, CK, NW, R, NBUF, HEADS, STEM_CIN, EXT, UPS, ITAP>), dim3((unsigned)grid), dim3(NW * 64), lds, st, q);
+  hipLaunchKernelGGL((conv3x3_dma_kernel<MT, CK, NW, R, NBUF, HEADS, STEM_CIN, EXT, UPS, ITAP, XP>), dim3((unsigned)grid), dim3(NW * 64), lds, st, q);
   SA_LAUNCH_CHECK();
   return SA_OK;
 }
@@ -1423,8 +1658,8 @@ static int conv3x3_impl(const void* src0, int C0P, const void* src1, int C1P, in
                         int n_heads, const float* const* head_w, const float* const* head_b, const int* head_c,
                         const int* head_act, float* const* head_dst, sa_stream_t stream,
                         const float* post_scale = nullptr, const float* post_shift = nullptr,
-                        const void* residual = nullptr, int res_mode = 0, int relu_last = 0) {
-  SA_REQUIRE(src0 && w && bias && (dst || dst_pool || n_heads > 0), "sa_conv3x3_bf16: NULL pointer");
+                        const void* residual = nullptr, int res_mode = 0, int relu_last = 0, const ConvParams2* xp = nullptr) {
+  SA_REQUIRE(src0 && w && bias && (dst || dst_pool || n_heads > 0 || xp), "sa_conv3x3_bf16: NULL pointer");
   SA_REQUIRE(n_heads >= 0 && n_heads <= 2, "sa_conv3x3_bf16: at most 2 fused heads");
   SA_REQUIRE(C0P > 0 && C0P % 16 == 0 && C1P % 16 == 0 && CoutP > 0 && CoutP % 16 == 0,
              "sa_conv3x3_bf16: channels must be padded to multiples of 16 (C0P=%d C1P=%d CoutP=%d)", C0P, C1P, CoutP);
@@ -1504,6 +1739,18 @@ static int conv3x3_impl(const void* src0, int C0P, const void* src1, int C1P, in
       q.head_c[hd] = head_c[hd];
       q.head_act[hd] = head_act[hd];
       q.head_dst[hd] = head_dst[hd];
+    }
+    if (xp) {  // fused bottleneck tail (sa_conv3x3_bneck_bf16): the 64-channel extended kernel + expand / reduce stages
+      SA_REQUIRE(CoutP == 64 && C1P == 0 && src_mode == SA_SRC1_NONE && !residual && n_heads == 0 && !dst_pool,
+                 "sa_conv3x3_bneck_bf16: a plain 3x3 conv with 64 (padded) output channels");
+      q.xp_w = xp->xp_w, q.xp_bias = xp->xp_bias, q.xp_scale = xp->xp_scale, q.xp_shift = xp->xp_shift, q.xp_res = xp->xp_res;
+      q.xp_dst = xp->xp_dst, q.CoutX = xp->CoutX, q.xp_relu = xp->xp_relu, q.xp_relu_last = xp->xp_relu_last;
+      q.rd_w = xp->rd_w, q.rd_bias = xp->rd_bias, q.rd_scale = xp->rd_scale, q.rd_shift = xp->rd_shift, q.rd_dst = xp->rd_dst;
+      q.CoutR = xp->CoutR, q.rd_relu = xp->rd_relu, q.rd_relu_last = xp->rd_relu_last;
+      q.xp_pix_bytes = planar ? 32 : q.CoutX * 2;
+      SA_REQUIRE((size_t)H * W * q.CoutX * 2 < 0xFFFFFF00ull, "sa_conv3x3_bneck_bf16: one frame of the expanded tensor must be smaller than 4 GiB");
+      return late_issue((C0P + C1P) / 16) ? launch2<2, 16, 8, 2, 2, false, 0, true, false, SA_CONV_ITAP, true>(q, st)
+                                          : launch2<2, 16, 8, 2, 2, false, 0, true, false, -1, true>(q, st);
     }
     if (n_heads > 0 && co32_n > 2) {
       // heads need every output channel in one workgroup: 4 cout tiles (<= 128 channels), CK = 16 keeps two LDS
@@ -1649,6 +1896,43 @@ int sa_stem_conv3x3x2_bf16(const void* src, int src_is_u8, int B, int H, int W, 
   }
   if (Cin == 1) return two ? launch2<2, 32, 4, 2, 1, false, 1>(q, st) : launch2<1, 32, 4, 2, 1, false, 1>(q, st);
   return two ? launch2<2, 32, 4, 2, 1, false, 3>(q, st) : launch2<1, 32, 4, 2, 1, false, 3>(q, st);
+}
+
+size_t sa_pointwise_packed_elems(int CinP, int CoutP) { return (size_t)((CoutP + 31) / 32) * (CinP / 16) * 64 * 8; }
+
+int sa_pack_pointwise_weights(const float* w, int Cin, int CinP, int Cout, int CoutP, void* packed) {
+  // w: Keras 1x1 kernel [Cin][Cout] f32 -> MFMA A fragments [CoutP/32][CinP/16][64 lanes][8] of the storage type, the input
+  // channels of a k-step in the order the fused stages' B fragments hold them: lane half h, element j <-> channel
+  // 16 k + 8 (j >> 2) + 4 h + (j & 3) (the accumulator layout of v_mfma_f32_32x32x16, read back as an operand)
+  SA_REQUIRE(w && packed && CinP % 16 == 0 && CoutP % 32 == 0 && Cin <= CinP && Cout <= CoutP, "sa_pack_pointwise_weights: bad arguments");
+  uint16_t* o = static_cast<uint16_t*>(packed);
+  const int K16 = CinP / 16;
+  for (int c32 = 0; c32 < CoutP / 32; ++c32)
+    for (int k = 0; k < K16; ++k)
+      for (int lane = 0; lane < 64; ++lane)
+        for (int j = 0; j < 8; ++j) {
+          const int co = c32 * 32 + (lane & 31), ci = 16 * k + 8 * (j >> 2) + 4 * (lane >> 5) + (j & 3);
+          const float v = (co < Cout && ci < Cin) ? w[(size_t)ci * Cout + co] : 0.0f;
+          o[(((size_t)c32 * K16 + k) * 64 + lane) * 8 + j] = sa::f2h(v);
+        }
+  return SA_OK;
+}
+
+int sa_conv3x3_bneck_bf16(const void* src, int CinP, int layout, const void* w, const float* bias, int relu, const float* post_scale,
+                          const float* post_shift, int relu_last, int B, int H, int W, const void* xp_w, const float* xp_bias,
+                          const float* xp_scale, const float* xp_shift, const void* xp_res, int xp_relu, int xp_relu_last,
+                          int CoutX, void* xp_dst, const void* rd_w, const float* rd_bias, const float* rd_scale,
+                          const float* rd_shift, int rd_relu, int rd_relu_last, int CoutR, void* rd_dst, sa_stream_t stream) {
+  SA_REQUIRE(xp_w && xp_bias && xp_dst && CoutX >= 32 && CoutX % 32 == 0, "sa_conv3x3_bneck_bf16: expand stage: weights, bias, dst, CoutX %% 32 == 0");
+  SA_REQUIRE(!xp_scale == !xp_shift && !rd_scale == !rd_shift, "sa_conv3x3_bneck_bf16: scale and shift come together");
+  SA_REQUIRE(!rd_w || (rd_bias && rd_dst && CoutR == 64), "sa_conv3x3_bneck_bf16: reduce stage: bias, dst and 64 (padded) output channels");
+  ConvParams2 x = {};
+  x.xp_w = (const uint16_t*)xp_w, x.xp_bias = xp_bias, x.xp_scale = xp_scale, x.xp_shift = xp_shift, x.xp_res = (const uint16_t*)xp_res;
+  x.xp_dst = (uint16_t*)xp_dst, x.CoutX = CoutX, x.xp_relu = xp_relu, x.xp_relu_last = xp_relu_last;
+  x.rd_w = (const uint16_t*)rd_w, x.rd_bias = rd_bias, x.rd_scale = rd_scale, x.rd_shift = rd_shift, x.rd_dst = (uint16_t*)rd_dst;
+  x.CoutR = CoutR, x.rd_relu = rd_relu, x.rd_relu_last = rd_relu_last;
+  return conv3x3_impl(src, CinP, nullptr, 0, SA_SRC1_NONE | (layout & SA_LAYOUT_PLANES16), w, bias, 64, relu, B, H, W, nullptr, nullptr, 0,
+                      nullptr, nullptr, nullptr, nullptr, nullptr, stream, post_scale, post_shift, nullptr, 0, relu_last, &x);
 }
 
 int sa_conv3x3_heads_bf16(const void* src0, int C0P, const void* src1, int C1P, int mode, const void* w,

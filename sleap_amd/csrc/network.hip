@@ -20,7 +20,7 @@ constexpr int64_t PLAN_MAGIC = 0x53414E4554303032LL;  // "SANET002" (002: + the 
 
 enum OpKind : int64_t {
   K_STEM2 = 1, K_STEM = 2, K_CONV = 3, K_PAIR = 4, K_CONV1X1 = 5, K_CONVT2 = 6, K_CONVT = 7, K_POOLG = 8, K_IMGCONV = 9,
-  K_ADD = 10, K_HEAD = 11, K_POOL = 12, K_UP = 13,
+  K_ADD = 10, K_HEAD = 11, K_POOL = 12, K_UP = 13, K_BNECK = 14,
 };
 
 struct Buf {
@@ -121,7 +121,7 @@ int sa_network_create(const int64_t* plan, size_t n_words, sa_network_t** out) {
       // (round 4: the tap GEMM -- 1x1 / k x k / transposed convs -- has a plane variant; stand-alone pools and adds run per plane)
       fits = fits && (op.kind == K_STEM2 || op.kind == K_PAIR || op.kind == K_UP || op.kind == K_CONV || op.kind == K_IMGCONV ||
                       op.kind == K_HEAD || op.kind == K_CONV1X1 || op.kind == K_CONVT2 || op.kind == K_POOLG || op.kind == K_POOL ||
-                      op.kind == K_ADD);
+                      op.kind == K_ADD || op.kind == K_BNECK);
       if (op.kind == K_CONV && op.a.size() >= 10) {  // plain / concat sources; the upsampling source mode without fused heads
         const bool ext = op.a[10 + 5 * (size_t)op.a[9]] != 0;  // and without the extended (BN / residual) epilogue
         fits = fits && (op.a[2] == SA_SRC1_NONE || op.a[2] == SA_SRC1_DIRECT ||
@@ -251,6 +251,18 @@ int sa_network_forward(const sa_network_t* net, const void* images, int images_a
           rc = sa_conv3x3_bf16(bp(s0), bc(s0), src1, c1p, (int)a[2] | lay, P<void>(a[3]), P<float>(a[4]), coutp, (int)a[6], B, oh, ow,
                                dst, bp(a[7]), stream);
         }
+        break;
+      }
+      case K_BNECK: {
+        // [src, w, bias, relu, ps, pt, relu_last | xw, xbias, xrelu, xps, xpt, xres, xrelu_last, x_out | has_y, yw, ybias, yrelu,
+        //  yps, ypt, yrelu_last, y_out]  (DeviceNetwork._bneck_words)
+        const int64_t xo = a[14];
+        rc = sa_conv3x3_bneck_bf16(bp(a[0]), bc(a[0]), lay, P<void>(a[1]), P<float>(a[2]), (int)a[3], P<float>(a[4]), P<float>(a[5]),
+                                   (int)a[6], B, bh(xo), bw(xo), P<void>(a[7]), P<float>(a[8]), P<float>(a[10]), P<float>(a[11]),
+                                   bp(a[12]), (int)a[9], (int)a[13], bc(xo), bp(xo), a[15] ? P<void>(a[16]) : nullptr,
+                                   a[15] ? P<float>(a[17]) : nullptr, a[15] ? P<float>(a[19]) : nullptr,
+                                   a[15] ? P<float>(a[20]) : nullptr, (int)a[18], (int)a[21], a[15] ? bc(a[22]) : 0,
+                                   a[15] ? bp(a[22]) : nullptr, stream);
         break;
       }
       case K_PAIR:  // [s0, wa, ba, relu_a, c1p, wb, bb, relu_b, o_buf, store, opool_buf]

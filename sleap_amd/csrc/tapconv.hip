@@ -76,6 +76,10 @@ __device__ __forceinline__ int fast_div(int m, int w, float inv_w) {
 // writes LDS lane-linearly: one copy instruction = the 32 pixels of one pixel group in one plane (1 KiB on both sides).
 // RES: the launch has a residual operand (ResNet shortcut Add). Only those instantiations carry the residual prefetch -- 32
 // registers live across the K loop (every 1x1 / k x k / transposed launch used to pay for it).
+// (Round 4, measured and dropped: three / four LDS stages with counted waits -- s_waitcnt vmcnt(k x copies per chunk) so that a
+// wave does not drain its whole copy queue per chunk: 6.78 -> 6.95 / 7.33 ms on the ResNet-50 network, every multi-chunk 1x1 conv
+// slower. The extra LDS costs resident workgroups, and those, not the depth of one workgroup's queue, are what hides the latency
+// here; profiles/r04_tapconv_sweep.md.)
 // CK: channels per K chunk (64 or 32). A stage is TP x 2 CK bytes of pixels + NCO32 x CK / 16 KiB of weights; the kernel is bound by
 // memory latency, so what matters is how many workgroups a CU holds (LDS per workgroup = 1 or 2 stages, registers) -- round 4.
 template <int WM, int WN, bool PL, bool RES, int CK>

@@ -85,7 +85,8 @@ class DeviceNetwork:
     def __init__(self, model_config: dict, weights: Dict[str, np.ndarray], device=None, fuse_upsample: Optional[bool] = None,
                  fuse_heads: bool = True, fuse_stem: bool = True, use_stem16: bool = True, mfma_convt: bool = True,
                  mfma_stem: bool = True, fuse_pairs: bool = True, dtype: Optional[str] = None, layout: Optional[str] = None,
-                 range_safe: Optional[bool] = None, range_log2_scale: Optional[Dict[str, int]] = None):
+                 range_safe: Optional[bool] = None, range_log2_scale: Optional[Dict[str, int]] = None,
+                 fuse_bneck: bool = True):
         """`fuse_upsample`: UpSampling2D(bilinear) folded into the consuming conv. On 16-channel planes the DMA kernel copies the
         half-resolution tile of source chunk c+1 and expands it in LDS into the idle stage while chunk c is multiplied (the
         upsampled tensor never exists in HBM); on NHWC tensors the register-staged first-generation kernel does it on load
@@ -125,6 +126,9 @@ class DeviceNetwork:
         self.use_stem16 = use_stem16
         # 16->32->32 encoder block in one launch (csrc/convpair.hip); SA_FUSE_PAIRS=0 turns it off for A/B measurements
         self.fuse_pairs = fuse_pairs and os.environ.get("SA_FUSE_PAIRS", "1") != "0"
+        # ResNet bottleneck tails in one launch (round 4, sa_conv3x3_bneck_bf16): 3x3 (64 maps) -> 1x1 expand + BN + shortcut Add +
+        # ReLU -> the next block's 1x1 reduce; SA_FUSE_BNECK=0 turns it off for A/B measurements
+        self.fuse_bneck = fuse_bneck and os.environ.get("SA_FUSE_BNECK", "1") != "0"
         self.mfma_stem = mfma_stem  # k7 first-layer convs of uint8 frames on the matrix cores (csrc/imgconv.hip)
         self.mfma_convt = mfma_convt  # Conv2DTranspose on the matrix cores (tap GEMM per output phase) vs the VALU kernel
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
@@ -602,6 +606,7 @@ class DeviceNetwork:
             else:
                 raise NotImplementedError(f"Keras layer {cn} ({name}) is not implemented in the HIP engine")
         plan = self._fuse_heads(plan) if self.fuse_heads else plan
+        plan = self._fuse_bottlenecks(plan, [t[n] for n in self.output_names]) if self.fuse_bneck else plan
         self.plan = self._fuse_stem(plan) if self.fuse_stem else plan
         self.outputs = []
         for n in self.output_names:
@@ -634,7 +639,7 @@ class DeviceNetwork:
 
         def fits(op):
             k = op[0]
-            if k in ("stem2", "pair", "up"):
+            if k in ("stem2", "pair", "up", "bneck"):
                 return True
             if k == "imgconv":  # first-layer conv on the raw image (hourglass / ResNet stems): writes planes (round 3)
                 return op[1].cp % 16 == 0
@@ -677,6 +682,8 @@ class DeviceNetwork:
                 "convt": (4,), "convt2": (4,), "add": (5,), "head": (2,)}.get(k)
         if k in ("stem2", "pair"):
             return DeviceNetwork._writes(op[2], tensor)
+        if k == "bneck":  # ["bneck", C, X, Y | None, xw, yw]: X's (and Y's) outputs; C's activation stays on chip
+            return op[2].out is tensor or (op[3] is not None and op[3].out is tensor)
         return any(op[i] is tensor for i in outs)
 
     @staticmethod
@@ -684,6 +691,11 @@ class DeviceNetwork:
         k = op[0]
         if k == "pair":
             return [op[1][1]]
+        if k == "bneck":
+            r = [op[1].src0]
+            if op[2].ext is not None and op[2].ext["res"] is not None:
+                r.append(op[2].ext["res"])
+            return r
         if k in ("conv", "conv1x1"):
             r = [t for t in (op.src0, op.src1) if t is not None]
             if op.ext is not None and op.ext["res"] is not None:
@@ -711,7 +723,9 @@ class DeviceNetwork:
         for op in self.plan:
             k = op[0]
             rd = list(self._reads(op))
-            if k in ("stem2", "pair"):
+            if k == "bneck":
+                n = sum(tb(t) for t in rd) + tb(op[2].out) + (tb(op[3].out) if op[3] is not None else 0)
+            elif k in ("stem2", "pair"):
                 wr = ([op[2].out] if op[2].need_full else []) + ([op[2].out_pool] if op[2].out_pool is not None else [])
                 n = sum(tb(t) for t in rd) + sum(tb(t) for t in wr) + (H * W * self.in_channels if k == "stem2" else 0)
             else:
@@ -725,6 +739,90 @@ class DeviceNetwork:
                 n = sum(tb(t) for t in rd) + sum(tb(t) for t in wr) + (H * W * self.in_channels if k in ("stem", "imgconv") else 0)
             out.append(int(n))
         return out
+
+    def _fuse_bottlenecks(self, plan, out_tensors):
+        """ResNet bottleneck tails (resnet.py:168-253) as ONE launch each (`sa_conv3x3_bneck_bf16`):
+
+            C: Conv2D(k3, 64 maps) + BN + ReLU       -- its activation never reaches HBM (268 MB per launch at 256 x 256, 16 frames)
+            X: Conv2D(k1, 64 -> 4 x 64) + BN + Add(shortcut) + ReLU   -- stored: it is the next block's shortcut
+            Y: the NEXT block's Conv2D(k1, 4 x 64 -> 64) + BN + ReLU  -- computed from X's stored (rounded) values while they are
+                                                                         still in registers: X's output is not read back
+
+        Conditions: C is a plain 3 x 3 conv with the extended epilogue and exactly 64 padded output channels whose only reader is
+        X; X and Y are stride-1 1 x 1 convs, X with <= 256 padded output channels, Y with 64 and no residual. The fused op takes
+        X's place in the plan (its shortcut operand is ready there); C and Y disappear."""
+        readers: Dict[int, list] = {}
+        for op in plan:
+            for tns in self._reads(op):
+                readers.setdefault(id(tns), []).append(op)
+        drop, repl = set(), {}
+        for c in plan:
+            if not (c[0] == "conv" and c.src1 is None and c.mode == _lib.SRC1_NONE and c.ext is not None and c.ext["res"] is None
+                    and not c.heads and c.out_pool is None and c.out.cp == 64 and id(c) not in drop):
+                continue
+            rs = readers.get(id(c.out), [])
+            if len(rs) != 1:
+                continue
+            x = rs[0]
+            if not (x[0] == "conv1x1" and x.stride == 1 and x.ksize == 1 and x.src0 is c.out and x.out.cp % 32 == 0
+                    and 32 <= x.out.cp <= 256 and id(x) not in repl):
+                continue
+            if x.ext is not None and x.ext["res"] is not None and x.ext["res"].cp != x.out.cp:
+                continue
+            y = None
+            for q in readers.get(id(x.out), []):
+                if (q[0] == "conv1x1" and q.stride == 1 and q.ksize == 1 and q.src0 is x.out and q.out.cp == 64
+                        and (q.ext is None or q.ext["res"] is None) and id(q) not in drop and id(q) not in repl):
+                    y = q
+                    break
+            # a model output must stay a stored tensor: C's activation is not stored any more
+            if any(o is c.out or (y is not None and o is x.out and False) for o in out_tensors):
+                continue
+            drop.add(id(c))
+            if y is not None:
+                drop.add(id(y))
+            repl[id(x)] = ["bneck", c, x, y, self._pointwise_from_tap(x.w, x.src0.cp, x.out.cp),
+                           self._pointwise_from_tap(y.w, y.src0.cp, y.out.cp) if y is not None else None]
+        out = []
+        for op in plan:
+            if id(op) in drop:
+                continue
+            out.append(repl.get(id(op), op))
+        # Y may sit BEFORE X's position only if it read something else; it reads X.out, so it follows X: order is preserved
+        return out
+
+    @staticmethod
+    def _pointwise_from_tap(w_tap: torch.Tensor, cinp: int, coutp: int) -> torch.Tensor:
+        """The tap GEMM's packed 1x1 weights [co32][1 tap][k16][64 lanes][8] (element (half, j) of a lane = input channel
+        16 k + 8 half + j) re-ordered for the fused stages, whose B operands come straight from accumulator registers: element
+        (half', j') = input channel 16 k + 8 (j' >> 2) + 4 half' + (j' & 3) (sa_pack_pointwise_weights' layout). A permutation of
+        stored values on the device -- no arithmetic."""
+        k16, co32 = cinp // 16, (coutp + 31) // 32
+        w = w_tap.reshape(co32, k16, 2, 32, 8)  # [.., half, n, j]
+        hp = torch.arange(2).view(2, 1)  # half'
+        jp = torch.arange(8).view(1, 8)  # j'
+        src_half = (jp >> 2).expand(2, 8)            # half  = j' >> 2
+        src_j = (4 * hp + (jp & 3)).expand(2, 8)     # j     = 4 half' + (j' & 3)
+        dev = w.device
+        o = w[:, :, src_half.to(dev), :, src_j.to(dev)]        # -> [2, 8, co32, k16, 32] (advanced indices first)
+        return o.permute(2, 3, 0, 4, 1).contiguous().reshape(-1)  # [co32, k16, half', n, j']
+
+    @staticmethod
+    def _bneck_words(op, bid, dp):
+        """[src, w, bias, relu, ps, pt, relu_last | xw, xbias, xps, xpt, xres, xrelu, xrelu_last, x_out | has_y, yw, ybias, yps, ypt,
+        yrelu, yrelu_last, y_out] (K_BNECK of csrc/network.hip; the arguments of sa_conv3x3_bneck_bf16)"""
+        _, c, x, y, xw, yw = op
+        ce, xe = c.ext, x.ext
+        a = [bid(c.src0), dp(c.w), dp(c.bias), c.relu, dp(ce["ps"]), dp(ce["pt"]), ce["relu_last"],
+             dp(xw), dp(x.bias), x.relu, dp(xe["ps"]) if xe else 0, dp(xe["pt"]) if xe else 0, bid(xe["res"]) if xe else -1,
+             xe["relu_last"] if xe else 0, bid(x.out)]
+        if y is not None:
+            ye = y.ext
+            a += [1, dp(yw), dp(y.bias), y.relu, dp(ye["ps"]) if ye else 0, dp(ye["pt"]) if ye else 0, ye["relu_last"] if ye else 0,
+                  bid(y.out)]
+        else:
+            a += [0, 0, 0, 0, 0, 0, 0, -1]
+        return a
 
     def _fuse_heads(self, plan):
         """Move 1x1 heads into the epilogue of the conv that produces their input (<= 2 heads, <= 32 channels each,
@@ -813,7 +911,7 @@ class DeviceNetwork:
 
     # ------------------------------------------------------------------ C executor (include/sleap_amd.h: sa_network_*)
     PLAN_MAGIC = 0x53414E4554303032  # "SANET002"
-    _K = {"stem2": 1, "stem": 2, "conv": 3, "pair": 4, "conv1x1": 5, "convt2": 6, "convt": 7, "poolg": 8, "imgconv": 9,
+    _K = {"bneck": 14, "stem2": 1, "stem": 2, "conv": 3, "pair": 4, "conv1x1": 5, "convt2": 6, "convt": 7, "poolg": 8, "imgconv": 9,
           "add": 10, "head": 11, "pool": 12, "up": 13}
 
     def plan_words(self) -> np.ndarray:
@@ -861,6 +959,8 @@ class DeviceNetwork:
                 _, xa, yb = op
                 a = [bid(xa.src0), dp(xa.w), dp(xa.bias), xa.relu, xa.out.cp, dp(yb.w), dp(yb.bias), yb.relu, bid(yb.out),
                      1 if yb.need_full else 0, bid(yb.out_pool)]
+            elif k == "bneck":
+                a = self._bneck_words(op, bid, dp)
             elif k == "conv1x1":
                 e = op.ext
                 a = [bid(op.src0), dp(op.w), dp(op.bias), op.relu, op.stride_word, 1 if e else 0, dp(e["ps"]) if e else 0,
@@ -1015,6 +1115,12 @@ class DeviceNetwork:
                 hh = H * o.num // o.den
                 f = 2 * hh * (W * o.num // o.den) * (s0.c * mid.c + mid.c * o.c) * 9
                 out.append(("conv", f"conv3x3 pair {s0.c}->{mid.c}->{o.c} @{hh}", f))
+            elif k == "bneck":
+                c, x, y = op[1], op[2], op[3]
+                hh, ww = H * c.out.num // c.out.den, W * c.out.num // c.out.den
+                f = 2 * hh * ww * (c.src0.c * c.out.c * 9 + c.out.c * x.out.c + (x.out.c * y.out.c if y is not None else 0))
+                nm = f"bneck 3x3 {c.src0.c}->{c.out.c} | 1x1 ->{x.out.c}" + (" +res" if x.ext and x.ext["res"] is not None else "")
+                out.append(("conv", nm + (f" | 1x1 ->{y.out.c}" if y is not None else "") + f" @{hh}", f))
             elif k == "conv1x1":
                 s0, o = op.src0, op.out
                 f = 2 * (H * o.num // o.den) * (W * o.num // o.den) * s0.c * o.c * op.ksize ** 2
@@ -1151,6 +1257,19 @@ class DeviceNetwork:
                                              _ptr(yb[5]), yb[7], o.cp, B, oh, ow, _ptr(bufs[o.buf]) if need_full else None,
                                              _ptr(bufs[o_pool.buf]) if o_pool is not None else None, self.layout, st),
                       "sa_conv3x3_pair_bf16")
+            elif kind == "bneck":
+                _, c, x, y, xw, yw = op
+                oh, ow = hw(c.out)
+                ce, xe, ye = c.ext, x.ext, (y.ext if y is not None else None)
+                xres = xe["res"] if xe else None
+                check(h.sa_conv3x3_bneck_bf16(
+                    _ptr(bufs[c.src0.buf]), c.src0.cp, self.layout, _ptr(c.w), _ptr(c.bias), c.relu, _ptr(ce["ps"]), _ptr(ce["pt"]),
+                    ce["relu_last"], B, oh, ow, _ptr(xw), _ptr(x.bias), _ptr(xe["ps"]) if xe else None, _ptr(xe["pt"]) if xe else None,
+                    _ptr(bufs[xres.buf]) if xres is not None else None, x.relu, xe["relu_last"] if xe else 0, x.out.cp,
+                    _ptr(bufs[x.out.buf]), _ptr(yw) if y is not None else None, _ptr(y.bias) if y is not None else None,
+                    _ptr(ye["ps"]) if ye else None, _ptr(ye["pt"]) if ye else None, y.relu if y is not None else 0,
+                    ye["relu_last"] if ye else 0, y.out.cp if y is not None else 0, _ptr(bufs[y.out.buf]) if y is not None else None, st),
+                    "sa_conv3x3_bneck_bf16")
             elif kind == "conv1x1":
                 _, s0, _s1, _sw, w, bias, o, relu, _op, _nf, _heads, _nm, ext = op
                 sh, sw = hw(s0)
@@ -1344,7 +1463,7 @@ class DeviceNetwork:
         the ranks of the process group when there is one."""
         twin = DeviceNetwork(self.model_config, self.master_weights, device=self.device, fuse_heads=False, fuse_stem=False,
                              fuse_pairs=False, fuse_upsample=False, mfma_convt=self.mfma_convt, mfma_stem=self.mfma_stem,
-                             dtype="bf16")
+                             dtype="bf16", fuse_bneck=False)
         ranges: Dict[str, float] = {}
         n = int(imgs.shape[0])
         chunk = max(1, min(chunk, n))
@@ -1440,6 +1559,10 @@ class DeviceNetwork:
             elif op[0] == "pair":
                 s0, mid, o = op[1].src0, op[1].out, op[2].out
                 total += 2 * (H * o.num // o.den) * (W * o.num // o.den) * (s0.c * mid.c + mid.c * o.c) * 9
+            elif op[0] == "bneck":
+                c, x, y = op[1], op[2], op[3]
+                total += 2 * (H * c.out.num // c.out.den) * (W * c.out.num // c.out.den) * (
+                    c.src0.c * c.out.c * 9 + c.out.c * x.out.c + (x.out.c * y.out.c if y is not None else 0))
             elif op[0] == "conv1x1":
                 s0, o = op.src0, op.out
                 total += 2 * (H * o.num // o.den) * (W * o.num // o.den) * s0.c * o.c * op.ksize ** 2

@@ -479,7 +479,9 @@ def test_resnet50_pretrained_style_transposed_concat_vs_oracle():
     rng = np.random.default_rng(0)
     net, res = _parity(cfg, w, rng.integers(0, 256, (2, 128, 96, 1), dtype=np.uint8), 5e-2, 3e-2)
     kinds = [op[0] for op in net.plan]
-    assert "add" not in kinds and kinds.count("conv1x1") == 36 and kinds.count("convt2") == 3
+    # 53 convs of the backbone: 36 are 1x1 (stride 1 / 2) launches of their own; round 4 folds the first stage's three 3x3 convs,
+    # their three expand convs and two reduce convs of the following blocks into three bottleneck-tail launches
+    assert "add" not in kinds and kinds.count("conv1x1") + 5 * (kinds.count("bneck") == 3) == 36 and kinds.count("convt2") == 3
 
 
 def test_resnet50_plain_he_init_overflows_fp16_and_is_rescaled():
@@ -598,6 +600,34 @@ def test_finite_but_unscalable_range_is_a_warning_not_an_error():
     with pytest.warns(UserWarning, match="within 4x"):
         out = net.forward(x)[0]
     assert torch.isfinite(out).all() and 65504 / 4 < float(out.max()) < 65504 and net.range_log2_scale is None
+
+
+def test_resnet50_bottleneck_tails_fused_vs_unfused_and_oracle():
+    """Round 4: the three bottleneck tails of ResNet's first stage (64-map 3x3 conv -> 1x1 expand + BN + shortcut Add + ReLU ->
+    the next block's 1x1 reduce) run as ONE launch each (sa_conv3x3_bneck_bf16). Same operations per value as the un-fused
+    launches (the matrix cores add a k-step's products in another order): every model output within 2 fp16 ulp of the output's
+    range of the un-fused plan, and within the usual tolerance of the fp32 oracle; both layouts."""
+    from oracle.keras_graph import KerasGraph, ensure_float
+    from sleap_amd.nn.engine import DeviceNetwork
+
+    cfg, w = _resnet(128, 160, features_output_stride=32, pretrained=True,
+                     upsampling=dict(output_stride=4, method="transposed_conv", skip_connections="concatenate"),
+                     heads=[("MultiInstanceConfmapsHead", 5, 4), ("PartAffinityFieldsHead", 8, 8)])
+    x = torch.from_numpy(np.random.default_rng(7).integers(0, 256, (3, 128, 160, 1), dtype=np.uint8)).cuda()
+    ref = KerasGraph(cfg, w)(ensure_float(x.cpu().numpy()))
+    for layout in (None, "nhwc"):
+        fused = DeviceNetwork(cfg, w, dtype="fp16", layout=layout)
+        plain = DeviceNetwork(cfg, w, dtype="fp16", layout=layout, fuse_bneck=False)
+        kinds = [op[0] for op in fused.plan]
+        assert kinds.count("bneck") == 3 and len(fused.plan) == len(plain.plan) - 5  # 3 x (C, X) + 2 x Y fewer launches
+        assert [op[3] is not None for op in fused.plan if op[0] == "bneck"] == [True, True, False]
+        a = [o.cpu().numpy() for o in fused.forward(x)]
+        b = [o.cpu().numpy() for o in plain.forward(x)]
+        for u, v, r in zip(a, b, ref):
+            rng = float(np.abs(r).max())
+            assert np.isfinite(u).all()
+            assert float(np.abs(u - v).max()) <= 2 * 2.0 ** -10 * rng, (layout, float(np.abs(u - v).max()), rng)
+            assert float(np.abs(u - r).max()) <= 3e-2 * rng
 
 
 def test_resnet50_stride16_bilinear_add_vs_oracle():
