@@ -28,6 +28,12 @@ using sa::mfma_h8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
+#if !defined(SA_TAP_RES_PREFETCH)
+#define SA_TAP_RES_PREFETCH 1  // 0: the residual is loaded in the epilogue (32 registers fewer across the K loop) -- A/B builds
+#endif
+#if !defined(SA_TAP_MIN_WAVES)
+#define SA_TAP_MIN_WAVES 1  // waves per SIMD the register allocation must leave room for (4 = 128 registers) -- A/B builds
+#endif
 constexpr int MAX_TAPS = 16;
 constexpr int MAX_WINDOW_TAPS = 81;  // sa_convk_bf16: up to 9 x 9 windows (their offsets are computed, not listed)
 
@@ -83,7 +89,7 @@ __device__ __forceinline__ int fast_div(int m, int w, float inv_w) {
 // CK: channels per K chunk (64 or 32). A stage is TP x 2 CK bytes of pixels + NCO32 x CK / 16 KiB of weights; the kernel is bound by
 // memory latency, so what matters is how many workgroups a CU holds (LDS per workgroup = 1 or 2 stages, registers) -- round 4.
 template <int WM, int WN, bool PL, bool RES, int CK>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, SA_TAP_MIN_WAVES)
 tapconv_kernel(const TapParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int TP = 64 * WM;          // pixels per workgroup
@@ -230,17 +236,19 @@ tapconv_kernel(const TapParams p) {
   // exchange, backwards): 8 load instructions per lane instead of 16, each covering 32 bytes per pixel (planes: 1 KiB contiguous)
   // (the exchange itself waits for the data, so it is done in the epilogue: the K loop runs with the loads in flight)
   uint4 rq4[RES ? 2 : 1][2][2];
-  if constexpr (RES) {
+  auto load_res = [&](int mt) {
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+    for (int pr = 0; pr < 2; ++pr)
 #pragma unroll
-      for (int pr = 0; pr < 2; ++pr)
-#pragma unroll
-        for (int r = 0; r < 2; ++r) {
-          const int co = (co32_0 + wn * 2 + mt) * 32 + 16 * pr + 8 * half;
-          rq4[mt][pr][r] = make_uint4(0u, 0u, 0u, 0u);
-          if (pix_ok[r] && co < p.CoutP) rq4[mt][pr][r] = *reinterpret_cast<const uint4*>(rrow[r] + chan_off(co));
-        }
+      for (int r = 0; r < 2; ++r) {
+        const int co = (co32_0 + wn * 2 + mt) * 32 + 16 * pr + 8 * half;
+        rq4[mt][pr][r] = make_uint4(0u, 0u, 0u, 0u);
+        if (pix_ok[r] && co < p.CoutP) rq4[mt][pr][r] = *reinterpret_cast<const uint4*>(rrow[r] + chan_off(co));
+      }
+  };
+  if constexpr (RES && SA_TAP_RES_PREFETCH) {
+    load_res(0);
+    load_res(1);
   }
   issue(0, 0);
   int buf = 0;
@@ -281,6 +289,7 @@ tapconv_kernel(const TapParams p) {
     if (cobase >= p.CoutP) continue;
     uint2 pk[2][4];
     uint2 rq[4][2];  // residual, back in the accumulator layout: group g = channels 8 g + 4 half + 0..3
+    if constexpr (RES && !SA_TAP_RES_PREFETCH) load_res(mt);
     if constexpr (RES) {
 #pragma unroll
       for (int pr = 0; pr < 2; ++pr)
