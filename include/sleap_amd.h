@@ -31,7 +31,9 @@
 extern "C" {
 #endif
 
-#define SA_ABI_VERSION 3
+#define SA_ABI_VERSION 4  /* 4 (round 4): + sa_tensor_absmax, sa_imgconv_pack_tiled, sa_pack_pointwise_weights,
+                            sa_pointwise_packed_elems, sa_conv3x3_bneck_bf16; SA_LAYOUT_PLANES16 accepted in the `relu` argument of
+                            sa_conv1x1_bf16 / sa_convk_bf16 / sa_convt_s2_bf16 */
 
 #define SA_OK 0
 #define SA_ERR_INVALID_ARG (-1)
