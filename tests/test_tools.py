@@ -1,4 +1,4 @@
-"""The profile tooling that produces committed numbers (profiles/r03_pmc_hbm_traffic.json is what bench.py reads
+"""The profile tooling that produces committed numbers (profiles/r<NN>_pmc_hbm_traffic.json, newest round, is what bench.py reads
 `roofline.traffic` from): tools/pmc_traffic.py must count the forward passes of a profiled run itself -- bench.py warms up by
 time, so the FETCH and the WRITE pass hold different numbers of launches."""
 import csv
@@ -42,7 +42,11 @@ def test_committed_traffic_file_is_what_bench_reads():
     sys.path.insert(0, ROOT)
     import bench
 
-    t = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_hbm_traffic.json")))
+    import glob
+
+    newest = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_traffic.json")))[-1]  # bench.py reads the newest round's
+    assert os.path.basename(newest) >= "r04_pmc_hbm_traffic.json"
+    t = json.load(open(newest))
     assert t["frames_per_step"] == 64 and t["size"] == 1024
     got = bench.profiled_traffic(64, 1024)
     assert got is not None and abs(got[0] - t["conv_family_bytes_per_step"]) < 1
