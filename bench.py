@@ -316,6 +316,10 @@ def main():
     # (the step COUNT is agreed between the ranks first -- every step holds a collective)
     step()
     torch.cuda.synchronize()
+    if world > 1:  # fp16 range scales: all ranks agree once, after their first forward (a no-op for a network that fits fp16)
+        if net.dist_agree_range():
+            step()
+            torch.cuda.synchronize()
     t_pre = time.perf_counter()
     step()
     torch.cuda.synchronize()

@@ -111,6 +111,9 @@ class DeviceNetwork:
         self.range_log2_scale = None
         self._range_calibrated = False  # exponents came from calibrate_range() / range_log2_scale= (never changed implicitly)
         self._range_measured: Dict[str, float] = {}
+        self._pending_scan = None   # (largest finite value, inf / NaN seen) of forwards under torch.distributed, until the ranks agree
+        self._pending_imgs = None
+        self._dist_agreed = False
         self._preset_scales = dict(range_log2_scale) if range_log2_scale else None
         self.model_config = model_config
         # layout of the 16-bit activation tensors: None = 16-channel planes when every launch of the compiled plan supports
@@ -1421,21 +1424,33 @@ class DeviceNetwork:
     #     fits (finite, <= range / 4)                      -> nothing happens, the plan stays bit for bit what it was
     #     does not fit, range_safe, not yet scaled         -> calibrate on THIS batch (all of its frames), fold, re-compile, re-run
     #     does not fit and (scaling off | already scaled)  -> inf / NaN seen: FloatingPointError; finite: a warning
-    #   under torch.distributed (world > 1) the scan result and the calibration ranges are MAX-reduced over the ranks first, so
-    #   every rank takes the same branch and folds the same exponents (ranks must run numerically identical networks).
+    #   under torch.distributed (world > 1) NOTHING is decided in here (a collective inside forward() would deadlock: shard sizes
+    #   differ, empty shards skip the network): the scan is recorded and the predictor calls `dist_agree_range` on EVERY rank once,
+    #   after the first global batch -- scan results and, if needed, per-layer ranges are MAX-reduced there, so all ranks fold the
+    #   same exponents (ranks must run numerically identical networks) and nothing is rescaled implicitly afterwards.
     #   Deterministic alternative: `calibrate_range(frames)` right after loading, or `range_log2_scale=` (persisted exponents).
-    def _dist_max(self, values: List[float]) -> List[float]:
-        from .range_scaling import dist_max
-
-        return dist_max(values, self.device)
-
     def _range_gate(self, bufs, imgs) -> bool:
         """First batch of an input shape under fp16 storage: scan the stored tensors. -> True when the plan was re-compiled
         with range scales (the caller runs the batch again), False when the network is left as it is. Raises
         FloatingPointError only when the scan actually saw inf / NaN and scaling is off, was already applied, or cannot help."""
         worst, nonfinite, where = self._check_fp16_range(bufs)
-        worst, nf = self._dist_max([worst, 1.0 if nonfinite else 0.0])
-        nonfinite = nf > 0
+        from .range_scaling import dist_world
+
+        if dist_world() > 1:
+            # frame-sharded run: NO collective in here (ranks see different shapes, empty shards skip the network: "first batch
+            # of a shape" is not a common event and a collective would deadlock). The scan is recorded; the predictor lets all
+            # ranks agree once, at one program point (`dist_agree_range`). Until then, and afterwards, nothing is rescaled
+            # implicitly: ranks must run numerically identical networks.
+            pw, pn = self._pending_scan or (0.0, False)
+            self._pending_scan = (max(worst, pw), nonfinite or pn)
+            if not self._dist_agreed:
+                self._pending_imgs = imgs  # (one batch kept until the ranks have agreed: what this rank would calibrate on)
+            if self._dist_agreed and nonfinite:
+                self._range_checked = False
+                raise FloatingPointError(
+                    f"activations left the range of fp16 storage (65504) in plan tensor {where} after the ranks agreed on their range "
+                    "scales: call calibrate_range() on representative frames (or load the model with dtype='bf16')")
+            return False
         if not nonfinite and worst <= 65504.0 / 4:
             return False
         # not yet scaled: calibrate on this batch. Already scaled (from a first batch, not from explicit / persisted exponents
@@ -1475,9 +1490,48 @@ class DeviceNetwork:
                 ranges[k] = max(ranges.get(k, 0.0), v)
         aliases = twin.layer_aliases()
         del twin
-        keys = sorted(ranges)
-        red = self._dist_max([ranges[k] for k in keys])
-        return dict(zip(keys, red)), aliases
+        return ranges, aliases
+
+    def dist_agree_range(self, imgs: Optional[torch.Tensor] = None) -> bool:
+        """Frame-sharded runs (torch.distributed, world > 1): EVERY rank calls this once, at the same program point -- the
+        predictors do after the first global batch. `imgs` = the network input this rank would calibrate on (default: the batch
+        of its first forward, kept by the range gate; a rank whose shard was empty has none and takes part with neutral values).
+        One small MAX all-reduce of the first-forward scans; only if some rank left fp16's comfortable range a second one of the
+        per-layer ranges (each rank measures its own frames), after which all ranks fold the SAME exponents. -> True when the
+        plan was re-compiled (the caller runs its batch again). No-op without a process group or for bf16 storage."""
+        from . import range_scaling as RS
+
+        if RS.dist_world() <= 1 or self.dtype != "fp16" or self._dist_agreed:
+            return False
+        aliases_box = {}
+
+        def twin():
+            return DeviceNetwork(self.model_config, self.master_weights, device=self.device, fuse_heads=False, fuse_stem=False,
+                                 fuse_pairs=False, fuse_upsample=False, mfma_convt=self.mfma_convt, mfma_stem=self.mfma_stem,
+                                 dtype="bf16", fuse_bneck=False)
+
+        def keys():
+            t = twin()
+            aliases_box["a"] = t.layer_aliases()
+            names = sorted(n for n, v in t._tensor_of.items() if v.kind in ("real", "f32out") and v.buf is not None)
+            del t
+            return names
+
+        def measure():
+            r, aliases_box["a"] = self.measure_ranges(imgs.contiguous())
+            return r
+
+        imgs = imgs if imgs is not None else self._pending_imgs
+        self._pending_imgs = None
+        has = imgs is not None and int(imgs.shape[0]) > 0
+        ks = RS.dist_agree(self._pending_scan if has else None, self.range_log2_scale is not None, self.range_safe, keys,
+                           measure if has else None, lambda r: RS.plan_scales(self.model_config, r, aliases_box.get("a")), self.device)
+        self._dist_agreed = True
+        self._range_calibrated = True  # from here on the exponents are every rank's: never changed implicitly
+        if ks:
+            self._install_scales(ks)
+            return True
+        return False
 
     def calibrate_range(self, imgs: torch.Tensor) -> Dict[str, int]:
         """Explicit, deterministic range calibration (fp16 storage): measure on `imgs` (uint8 / float32 frames on the device,

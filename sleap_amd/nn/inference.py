@@ -1132,6 +1132,12 @@ class Predictor:
                         dev = self.inference_model.predict_on_batch(batch, numpy=False)
                         if keep_frames and _up is not None:
                             kept = (batch, _up)  # a flow tracker reads the frames where they already are
+                    if world > 1 and i0 == 0:
+                        # fp16 range scales of a frame-sharded run: every rank (empty shards included) passes here exactly once,
+                        # after the first global batch -- the networks agree on their exponents (DeviceNetwork.dist_agree_range)
+                        nets = self.inference_model._device_networks() if hasattr(self.inference_model, "_device_networks") else []
+                        if any([net.dist_agree_range() for net in nets]) and hi > lo:
+                            dev = self.inference_model.predict_on_batch(batch, numpy=False)  # re-compiled plans: run the batch again
                     pre = None
                     if dev is not None and not set(dev) <= small:
                         # maps / crops may alias network buffers that the next batch overwrites: convert before anything else runs
@@ -1518,6 +1524,8 @@ class BottomUpPredictor(Predictor):
         over_mask = _lib.STATUS_PEAK_OVERFLOW | _lib.STATUS_NODE_PEAK_OVERFLOW | _lib.STATUS_INSTANCE_OVERFLOW
         host_pool = {}
 
+        agreed = [False]
+
         def caps():
             return (layer.max_peaks, layer.paf_scorer.max_node_peaks, layer.paf_scorer.max_instances)
 
@@ -1526,6 +1534,14 @@ class BottomUpPredictor(Predictor):
             packed, ig = None, layer.paf_scorer.max_instances
             if batch is not None:
                 outs = self.inference_model.call(batch)
+            if world > 1 and not agreed[0]:
+                # fp16 range scales of a frame-sharded run: all ranks (empty shards included) agree ONCE, here, after the first
+                # global batch -- the only program point every rank passes (DeviceNetwork.dist_agree_range)
+                agreed[0] = True
+                agree = getattr(layer.keras_model, "dist_agree_range", None)
+                if agree is not None and agree() and batch is not None:
+                    outs = self.inference_model.call(batch)  # the plan was re-compiled with range scales: run the batch again
+            if batch is not None:
                 ig = outs["instance_scores"].shape[1]
                 packed = parallel.pack_results(outs)
             return packed, ig

@@ -236,3 +236,42 @@ def dist_max(values: List[float], device=None) -> List[float]:
     t = torch.nan_to_num(t, nan=float("inf"), posinf=float("inf"))
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return [float(x) for x in t.cpu()]
+
+
+def dist_world() -> int:
+    import torch.distributed as dist
+
+    return dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+
+
+def dist_agree(local_scan, already_scaled: bool, range_safe: bool, keys, measure, plan, device=None):
+    """The range decision of a frame-sharded run, taken ONCE by ALL ranks at one program point (the predictor calls it after the
+    first global batch; a rank whose shard was empty takes part with neutral values). Collectives inside a network's `forward`
+    would deadlock: ranks see different buffer shapes (shard sizes differ, empty shards skip the network), so "first batch of a
+    shape" is not a common event.
+
+    local_scan  (largest finite value, inf / NaN seen) of this rank's first forward, or None (no frames)
+    keys()      sorted layer names of the stored tensors (the same on every rank: a property of the plan, not of the data)
+    measure()   {layer: max |activation|} on this rank's frames, or None (no frames)
+    plan(r)     ranges -> exponents (plan_scales)
+
+    -> the exponents every rank must install ({} / None: leave the network as it is). Raises FloatingPointError on EVERY rank when
+    some rank overflowed and scaling is off / already applied / cannot help."""
+    worst, nonfinite = local_scan if local_scan is not None else (0.0, False)
+    red = dist_max([worst, 1.0 if nonfinite else 0.0, 1.0 if already_scaled else 0.0], device)
+    need = red[1] > 0 or red[0] > 65504.0 / 4
+    if not need:
+        return None
+    if range_safe and red[2] == 0:
+        names = list(keys())
+        mine = measure() if measure is not None else None
+        vec = [float((mine or {}).get(k, 0.0)) for k in names]
+        ranges = dict(zip(names, dist_max(vec, device)))
+        ks = plan(ranges)
+        if any(ks.values()):
+            return ks
+    if red[1] > 0:
+        raise FloatingPointError(
+            "activations left the range of fp16 storage (65504) on at least one rank and could not be rescaled: load the model "
+            "with dtype='bf16' (or SLEAP_AMD_DTYPE=bf16), which has fp32's range, or calibrate_range() on representative frames")
+    return None

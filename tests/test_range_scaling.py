@@ -152,3 +152,69 @@ def test_ranks_agree_on_ranges_and_exponents_gloo_world_2():
     (_, red0, ks0), (_, red1, ks1) = got
     assert red0 == red1 == [900.0, 3.0e5, float("inf")]
     assert ks0 == ks1 and min(ks0.values()) < 0  # rank 1's larger activations decide for both
+
+
+# ---- the agreement point of a frame-sharded run: one decision for all ranks, an empty shard takes part with neutral values
+def _agree_worker(rank, world, port, case, q):
+    import os
+
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        mc, all_t = _toy_resnet()
+        base = _ranges(all_t)
+        names = sorted(base)
+        calls = {"measure": 0}
+
+        def measure():
+            calls["measure"] += 1
+            return {k: v * (60.0 if rank == 1 else 1.0) for k, v in base.items()}
+
+        if case == "fits":  # nobody near the range: one collective, nothing measured, nothing installed
+            scan = (900.0 + rank, False)
+            has = True
+        elif case == "rank1_overflows_rank2_empty":  # rank 1 saw inf, rank 2 has no frames at all
+            scan = {0: (500.0, False), 1: (60000.0, True), 2: None}[rank]
+            has = rank != 2
+        else:  # "already_scaled": an overflow with explicit exponents in place is an error on EVERY rank
+            scan = (100.0, rank == 0)
+            has = True
+        try:
+            ks = R.dist_agree(scan if has else None, case == "already_scaled", True, lambda: names, measure if has else None,
+                              lambda r: R.plan_scales(mc, r))
+            q.put((rank, "ok", ks, calls["measure"]))
+        except FloatingPointError:
+            q.put((rank, "raised", None, calls["measure"]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("case,world", [("fits", 2), ("rank1_overflows_rank2_empty", 3), ("already_scaled", 2)])
+def test_ranks_agree_once_at_one_program_point_gloo(case, world):
+    import socket
+
+    import torch.multiprocessing as mp
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_agree_worker, args=(r, world, port, case, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    got = sorted([q.get(timeout=240) for _ in ps], key=lambda t: t[0])
+    for p in ps:
+        p.join(60)
+    if case == "fits":
+        assert all(g[1] == "ok" and g[2] is None and g[3] == 0 for g in got)
+    elif case == "rank1_overflows_rank2_empty":
+        assert all(g[1] == "ok" for g in got)
+        assert got[0][2] == got[1][2] == got[2][2] and min(got[0][2].values()) < 0  # the same exponents everywhere
+        assert [g[3] for g in got] == [1, 1, 0]  # ranks with frames measured, the empty one did not
+    else:
+        assert all(g[1] == "raised" for g in got)
