@@ -202,3 +202,64 @@ def test_fp16_overflow_is_reported_rescaled_or_run_in_bf16():
             assert all(np.array_equal(a, b) for a, b in zip(got, got2))
     print("relative head error vs the fp32 oracle:", err)
     assert err["fp16"] <= 4e-3 and err["fp16"] < err["bf16"]
+
+
+def _dist_range_worker(rank, world, port, q):
+    """one process per rank, both on cuda:0 (gloo carries the small agreement collectives): rank 0 holds the first global batch's
+    frames, rank 1's shard is EMPTY -- it never runs the network"""
+    import os
+
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from sleap_amd.benchmark_model import build_benchmark_graph
+        from sleap_amd.nn.engine import DeviceNetwork
+        from sleap_amd.synth import render_frames
+
+        torch.cuda.set_device(0)
+        cfg, mc, w = build_benchmark_graph(128, 128, seed=2)
+        w = {k: (v * np.float32(2.5) if k.endswith("/kernel") else v) for k, v in w.items()}  # activations pass 65504
+        net = DeviceNetwork(mc, w, dtype="fp16")
+        x = torch.from_numpy(render_frames(2, 128, 128, n_animals=2, seed=1)[0]).cuda()
+        first_finite = None
+        if rank == 0:
+            outs = net.forward(x)  # under a process group the gate only RECORDS: no collective, nothing rescaled yet
+            first_finite = bool(all(torch.isfinite(o).all() for o in outs))
+            assert net.range_log2_scale is None and net._pending_scan is not None
+        changed = net.dist_agree_range()  # every rank, once, the same program point
+        ks = dict(net.range_log2_scale or {})
+        finite = None
+        if rank == 0:
+            finite = bool(all(torch.isfinite(o).all() for o in net.forward(x)))
+        again = net.dist_agree_range()  # a second call is a no-op (no collective): must not hang with only one rank calling late
+        q.put((rank, changed, ks, first_finite, finite, again))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_ranks_agree_on_range_scales_with_an_empty_shard_real_networks():
+    """DeviceNetwork.dist_agree_range under a real process group (gloo, world 2, both ranks on this GPU): the rank with frames
+    overflows fp16 on its first forward, the rank with an EMPTY shard never runs the network; after the one agreement call both
+    hold the same exponents and the overflowing rank's maps are finite. (A collective inside forward() would have hung here.)"""
+    import socket
+
+    import torch.multiprocessing as mp
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_dist_range_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    got = sorted([q.get(timeout=600) for _ in ps], key=lambda t: t[0])
+    for p in ps:
+        p.join(120)
+    (r0, c0, k0, ff0, f0, a0), (r1, c1, k1, _, _, a1) = got
+    assert c0 and c1 and k0 == k1 and min(k0.values()) < 0
+    assert f0 is True and not a0 and not a1
