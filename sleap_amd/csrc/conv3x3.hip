@@ -269,7 +269,8 @@ struct ConvParams2 {
   // tile index -> (cout tile, tile column, tile row, frame): when the three tile counts are powers of two (every layer of the
   // 1024 x 1024 benchmark plan) the host hands over their log2 and the decode is three scalar shifts / masks; otherwise -1 and
   // the kernel divides (three runtime divisions = three ~35-instruction float-reciprocal sequences on the vector unit, in front
-  // of the tile's FIRST copy: ~1 us of a 4-5 us one-tile workgroup)
+  // of the tile's FIRST copy. Measured against the division form on one box: no difference, the CU's partner workgroup covers that
+  // microsecond -- profiles/r04_ab_session.md section 1; kept as the cheaper code)
   int sh_co, sh_tx, sh_ty;
   // ---- fused bottleneck tail (XP kernels, round 4; resnet.py:168-253). This conv's activation h (64 channels, never stored)
   // goes through the block's 1x1 EXPAND conv in the epilogue -- y = act1(affine1(W2 h + b2) + residual), stored -- and y (as
@@ -1519,12 +1520,8 @@ int launch2(const ConvParams2& p, hipStream_t st) {
   q.nt_in = (nt_on && q.co_tiles == 1 && !STEM_CIN && (p.C0P + p.C1P) / CK <= nt_max_chunks) ? 1 : 0;
   {
     auto lg = [](int v) { int k = 0; while ((1 << k) < v) ++k; return (1 << k) == v ? k : -1; };
-    static const bool shifts_on = [] {
-      const char* v = getenv("SA_CONV_POW2_DECODE");
-      return !v || atoi(v) != 0;
-    }();
     q.sh_co = lg(q.co_tiles), q.sh_tx = lg(q.tiles_x), q.sh_ty = lg(q.tiles_y);
-    if (!shifts_on || q.sh_co < 0 || q.sh_tx < 0 || q.sh_ty < 0) q.sh_co = q.sh_tx = q.sh_ty = -1;
+    if (q.sh_co < 0 || q.sh_tx < 0 || q.sh_ty < 0) q.sh_co = q.sh_tx = q.sh_ty = -1;
   }
   if (p.planar && CK != 16 && !STEM_CIN) return sa::fail(SA_ERR_UNSUPPORTED, "sa_conv3x3: SA_LAYOUT_PLANES16 needs 16-channel chunks");
   q.pix_bytes0 = p.planar ? 32 : p.C0P * 2;

@@ -59,15 +59,10 @@ struct Stem16Params {
 // A wave's four output rows then read 6 x 2 G + 5 x 2 F = 22 fragments from LDS instead of 40 for the same 40 MFMAs. The
 // counters (profiles/r03_pmc_sq_counters.md) and a cycle count per tile put this kernel at the LDS array: ~1900 LDS cycles per
 // tile (1280 of them conv1's fragment reads) against 800 matrix-core cycles per SIMD.
-#if !defined(SA_STEM16_REUSE)
-#define SA_STEM16_REUSE 1  // 0: the round 1-3 pairing (taps 2s | 2s + 1, one fragment read per MFMA) -- A/B builds
-#endif
+// (the round 1-3 pairing -- taps 2s | 2s + 1, one fragment read per MFMA -- measured against this one on one box: 0.502 vs 0.474 ms,
+// profiles/r04_ab_session.md section 1; the A/B switch is gone)
 __host__ __device__ constexpr int stem16_pair_tap(int s, int half) {
-#if SA_STEM16_REUSE
   return s < 3 ? 3 * s + half : (s == 3 ? (half ? 5 : 2) : (half ? 8 : -1));
-#else
-  return 2 * s + half < 9 ? 2 * s + half : -1;
-#endif
 }
 // tile: 16 rows x 32 columns of output per workgroup (4 waves x 4 rows)
 #define SA_STEM16_TH 16
@@ -440,7 +435,6 @@ stem16_gray_kernel(const Stem16Params p) {
   const unsigned char* abase = act + ((wave * 4) * PW + n16) * 32 + (kb & 1) * 16;
 #endif
   constexpr int APIX1 = SA_STEM16_PLANES8 ? 16 : 32;
-#if SA_STEM16_REUSE
   // fragment reuse (see stem16_pair_tap): halo row R of the wave's six feeds output rows R, R-1, R-2
   const unsigned char* gb = abase + (kb >> 1) * APIX1;                   // G: columns 0 | 1 of halo row R
   const unsigned char* fb = abase + ((kb >> 1) ? PW + 2 : 2) * APIX1;    // F: column 2 of halo rows R | R + 1
@@ -461,21 +455,6 @@ stem16_gray_kernel(const Stem16Params p) {
       }
     }
   }
-#else
-#pragma unroll
-  for (int s = 0; s < 5; ++s) {
-    const int ta = stem16_pair_tap(s, 0), tb = stem16_pair_tap(s, 1) < 0 ? 0 : stem16_pair_tap(s, 1);
-    const int off = (kb >> 1) ? ((tb / 3) * PW + tb % 3) : ((ta / 3) * PW + ta % 3);
-    const unsigned char* sb = abase + off * APIX1;
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const mfma_h8 bv = *reinterpret_cast<const mfma_h8*>(sb + (r * PW + h * 16) * APIX1);
-        acc[r][h] = SA_MFMA_16x16x32(wb[s], bv, acc[r][h], 0, 0, 0);
-      }
-  }
-#endif
 
   // ---- epilogue: lane holds couts kb*4..+3 of pixel (row, h*16 + n16). ReLU is one v_max against a uniform bound
   // (0 or -inf); every address is one 64-bit base per lane plus compile-time offsets.

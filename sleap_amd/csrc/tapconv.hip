@@ -28,12 +28,6 @@ using sa::mfma_h8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
-#if !defined(SA_TAP_RES_PREFETCH)
-#define SA_TAP_RES_PREFETCH 1  // 0: the residual is loaded in the epilogue (32 registers fewer across the K loop) -- A/B builds
-#endif
-#if !defined(SA_TAP_MIN_WAVES)
-#define SA_TAP_MIN_WAVES 1  // waves per SIMD the register allocation must leave room for (4 = 128 registers) -- A/B builds
-#endif
 constexpr int MAX_TAPS = 16;
 constexpr int MAX_WINDOW_TAPS = 81;  // sa_convk_bf16: up to 9 x 9 windows (their offsets are computed, not listed)
 
@@ -89,7 +83,7 @@ __device__ __forceinline__ int fast_div(int m, int w, float inv_w) {
 // CK: channels per K chunk (64 or 32). A stage is TP x 2 CK bytes of pixels + NCO32 x CK / 16 KiB of weights; the kernel is bound by
 // memory latency, so what matters is how many workgroups a CU holds (LDS per workgroup = 1 or 2 stages, registers) -- round 4.
 template <int WM, int WN, bool PL, bool RES, int CK>
-__global__ void __launch_bounds__(256, SA_TAP_MIN_WAVES)
+__global__ void __launch_bounds__(256)
 tapconv_kernel(const TapParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int TP = 64 * WM;          // pixels per workgroup
@@ -246,7 +240,7 @@ tapconv_kernel(const TapParams p) {
         if (pix_ok[r] && co < p.CoutP) rq4[mt][pr][r] = *reinterpret_cast<const uint4*>(rrow[r] + chan_off(co));
       }
   };
-  if constexpr (RES && SA_TAP_RES_PREFETCH) {
+  if constexpr (RES) {  // (loading it in the epilogue instead, or a 128-register budget: measured, profiles/r04_tapconv_sweep.md)
     load_res(0);
     load_res(1);
   }
@@ -289,7 +283,6 @@ tapconv_kernel(const TapParams p) {
     if (cobase >= p.CoutP) continue;
     uint2 pk[2][4];
     uint2 rq[4][2];  // residual, back in the accumulator layout: group g = channels 8 g + 4 half + 0..3
-    if constexpr (RES && !SA_TAP_RES_PREFETCH) load_res(mt);
     if constexpr (RES) {
 #pragma unroll
       for (int pr = 0; pr < 2; ++pr)
@@ -382,8 +375,9 @@ int launch_tap(const TapParams& p0, hipStream_t st) {
   return SA_OK;
 }
 
-// Tile shape and chunk size. Defaults: measured on MI355X (profiles/r04_tapconv_sweep.md). SA_TAP_SHAPE = 1 / 2 / 3 forces
-// 256 px x 64 couts / 128 x 128 / 64 x 256 per workgroup, SA_TAP_CK = 32 / 64 the chunk size (A/B runs).
+// Tile shape and chunk size. Defaults: measured on MI355X (profiles/r04_tapconv_sweep.md; the 64 px x 256 couts shape lost
+// everywhere and is not built). SA_TAP_SHAPE = 1 / 2 forces 256 px x 64 couts / 128 x 128 per workgroup, SA_TAP_CK = 32 / 64
+// the chunk size (A/B runs).
 template <bool PL, bool RES, int CK>
 int launch_tap_shape(const TapParams& p, hipStream_t st) {
   static const int force = [] {
@@ -392,7 +386,6 @@ int launch_tap_shape(const TapParams& p, hipStream_t st) {
   }();
   const int shape = force ? force : (p.CoutP <= 64 ? 1 : 2);
   if (shape == 1) return launch_tap<4, 1, PL, RES, CK>(p, st);
-  if (shape == 3) return launch_tap<1, 4, PL, RES, CK>(p, st);
   return launch_tap<2, 2, PL, RES, CK>(p, st);
 }
 
