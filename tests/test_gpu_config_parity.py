@@ -333,3 +333,33 @@ def test_configs4_network_maps_vs_fp32_oracle(resnet_workload):
         o = o.cpu().numpy()
         assert np.isfinite(o).all()
         assert float(np.abs(o - r).max()) <= 1e-2 * float(np.abs(r).max())
+
+
+def test_configs4_model_directory_through_load_model(tmp_path, resnet_workload):
+    """The drop-in boundary for a ResNet backbone: a SLEAP model FOLDER (`training_config.json` + the Keras graph / weights as the
+    extracted `best_model.npz`, inference.py:132-144, 3204-3209) through `load_model` -> `BottomUpPredictor.predict` gives what the
+    directly constructed predictor gives (same networks, same frames), and the backbone block of the config is read as the
+    reference reads it (`max_stride` 32 -> pad_to_stride)."""
+    import json
+
+    from sleap_amd import config_models as C
+    from sleap_amd.nn.engine import DeviceNetwork
+    from sleap_amd.nn.inference import BottomUpPredictor, load_model
+
+    wl = resnet_workload
+    d = tmp_path / "mouse24.ResNet50.bottomup"
+    d.mkdir()
+    (d / "training_config.json").write_text(json.dumps(C.training_config(wl["task"])))
+    np.savez(d / "best_model.npz", __model_config__=np.frombuffer(json.dumps(wl["mc"]).encode(), dtype=np.uint8), **wl["w"])
+    pred = load_model(str(d), batch_size=3, peak_threshold=0.2, refinement="integral", progress_reporting="none")
+    assert isinstance(pred, BottomUpPredictor)
+    layer = pred.inference_model.bottomup_layer
+    assert layer.pad_to_stride == 32 and layer.cm_output_stride == 4 and layer.paf_output_stride == 8
+    assert layer.paf_scorer.n_nodes == 24 and len(layer.paf_scorer.edges) == 23
+    got = pred.predict(wl["frames"], make_labels=False)[0]
+    ref = BottomUpPredictor(bottomup_config=C.training_config(wl["task"]), bottomup_model=DeviceNetwork(wl["mc"], wl["w"]),
+                            batch_size=3, verbosity="none").predict(wl["frames"], make_labels=False)[0]
+    assert np.array_equal(got["n_valid"], ref["n_valid"]) and got["n_valid"].tolist() == [8, 8, 8]
+    np.testing.assert_array_equal(got["instance_peaks"], ref["instance_peaks"])
+    labels = pred.predict(wl["frames"])  # make_labels=True, the reference's default: 3 labeled frames with 8 instances each
+    assert len(labels) == 3 and all(len(lf.instances) == 8 for lf in labels)
