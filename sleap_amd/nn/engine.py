@@ -1472,10 +1472,10 @@ class DeviceNetwork:
                       "range (65504); consider dtype='bf16' for this model")
         return False
 
-    def measure_ranges(self, imgs: torch.Tensor, chunk: int = 8) -> Dict[str, float]:
-        """max |activation| per layer over ALL frames of `imgs`, measured with a bf16-storage twin of this network (fp32's
-        range, every layer output stored, built from the un-scaled master weights), `chunk` frames at a time; MAX-reduced over
-        the ranks of the process group when there is one."""
+    def measure_ranges(self, imgs: torch.Tensor, chunk: int = 8):
+        """-> ({layer: max |activation|} over ALL frames of `imgs`, the twin's layer aliases): measured with a bf16-storage twin
+        of this network (fp32's range, every layer output stored, built from the un-scaled master weights), `chunk` frames at
+        a time. This rank's frames only: ranks combine their ranges in `dist_agree_range`."""
         twin = DeviceNetwork(self.model_config, self.master_weights, device=self.device, fuse_heads=False, fuse_stem=False,
                              fuse_pairs=False, fuse_upsample=False, mfma_convt=self.mfma_convt, mfma_stem=self.mfma_stem,
                              dtype="bf16", fuse_bneck=False)
