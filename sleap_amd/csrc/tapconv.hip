@@ -344,6 +344,233 @@ tapconv_kernel(const TapParams p) {
 #endif
 }
 
+// ---- 1 x 1 convs whose output channels span SEVERAL 128-channel tiles (ResNet's expand convs: 128 -> 512, 256 -> 1024), on planes:
+// ONE workgroup per pixel tile walks all cout tiles. The pixel tile (TP pixels x all input channels) is copied into LDS once and
+// stays; per cout tile only the weights stream (from L2), double buffered in 32-channel chunks, the first chunk of cout tile t + 1
+// queued under the last chunk of t. Against one workgroup per (pixel tile, cout tile): the input is fetched once instead of
+// co_tiles times, the per-chunk copy is 8 KiB of L2-resident weights instead of 8 + 8 KiB with an HBM leg, and the prologue is
+// paid once. Same arithmetic in the same order per output: bitwise the tap-GEMM kernel's results.
+template <int WM, int WN, bool RES>
+__global__ void __launch_bounds__(256)
+tapconv_coloop_kernel(const TapParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int CK = 32, KK = 2;
+  constexpr int TP = 64 * WM, NCO32 = 2 * WN, PG = TP / 32;
+  constexpr int N_W = NCO32 * KK, W_STAGE = N_W * 1024, W_PER_WAVE = N_W / 4;
+  static_assert(N_W % 4 == 0, "weight pieces per wave");
+  constexpr unsigned OOB = 0xFFFFFF00u;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave % WM, wn = wave / WM;
+  int bid;
+  {
+    const int nblk = gridDim.x, q = nblk >> 3, r = nblk & 7, xcd = blockIdx.x & 7, k = blockIdx.x >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+  }
+  const int m_t = bid % p.m_tiles;
+  const int b = bid / p.m_tiles;
+  const int m0 = m_t * TP;
+  const int ML = p.Hl * p.Wl;
+  const int K16 = p.CinP / 16;
+  const float inv_wl = 1.0f / (float)p.Wl;
+  const int co32_n = (p.CoutP + 31) / 32;
+  const int n_chunks = (p.CinP + CK - 1) / CK;   // per cout tile
+  const int n_cot = p.co_tiles;
+  const int in_bytes = K16 * TP * 32;            // the resident pixel tile: [k16][pixel][32 B]
+  unsigned char* wst = smem + in_bytes;           // two weight stages behind it
+
+  const size_t fbytes = (size_t)p.Hs * p.Ws * p.CinP * 2;
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(reinterpret_cast<const unsigned char*>(p.src) + b * fbytes), 0, (int)fbytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (int)((size_t)co32_n * K16 * 1024), 0x00020000);
+  const unsigned plane_bytes_in = (unsigned)((size_t)p.Hs * p.Ws * 32);
+  const unsigned wv = (unsigned)lane * 16;
+
+  // ---- the pixel tile, once: piece i = pixel group i % PG of plane i / PG (1 KiB); wave w takes pieces w, w + 4, ...
+  for (int i = wave; i < PG * K16; i += 4) {
+    const int pg = i % PG, k16 = i / PG;
+    const int pl = pg * 32 + (lane >> 1);
+    const int m = m0 + pl;
+    const bool okp = m < ML;
+    const int ly = okp ? fast_div(m, p.Wl, inv_wl) : 0;
+    const int sy = ly * p.in_stride, sx = (m - ly * p.Wl) * p.in_stride;
+    const unsigned slot = (unsigned)((lane & 1) ^ ((pl >> 3) & 1));
+    const unsigned voff = okp ? (unsigned)((sy * p.Ws + sx) * 32) + slot * 16u : OOB;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(smem + i * 1024), 16, voff, (int)((unsigned)k16 * plane_bytes_in), 0, 0);
+  }
+  // weight chunk `step` = (cout tile step / n_chunks, chunk step % n_chunks) -> stage step & 1
+  auto issue_w = [&](int step) {
+    const int ct = step / n_chunks, kc = step - ct * n_chunks;
+    unsigned char* stage = wst + (step & 1) * W_STAGE;
+#pragma unroll
+    for (int j = 0; j < W_PER_WAVE; ++j) {
+      const int k = j * 4 + wave;
+      const int c32 = k / KK, kk = k - c32 * KK;
+      const int k16 = kc * KK + kk;
+      const int soff = (ct * NCO32 + c32 < co32_n && k16 < K16) ? ((ct * NCO32 + c32) * K16 + k16) * 1024 : (int)0x7FFFF000;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_ptr_t)(stage + k * 1024), 16, wv, soff, 0, 0);
+    }
+  };
+
+  const int half = lane >> 5, lx = lane & 31;
+  uint16_t* drow[2];
+  const uint16_t* rrow[2];
+  bool pix_ok[2];
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    const int m = m0 + (wm * 2 + r) * 32 + lx;
+    pix_ok[r] = m < ML;
+    const int ly = pix_ok[r] ? fast_div(m, p.Wl, inv_wl) : 0;
+    const int lxx = pix_ok[r] ? m - ly * p.Wl : 0;
+    const size_t opix = (size_t)(ly * p.out_stride + p.oy0) * p.Wo + (lxx * p.out_stride + p.ox0);
+    const size_t off = (size_t)b * p.Ho * p.Wo * p.CoutP + opix * 16;
+    drow[r] = p.dst + off;
+    rrow[r] = RES ? p.residual + off : nullptr;
+  }
+  const size_t plane_elems_out = (size_t)p.Ho * p.Wo * 16;
+  auto chan_off = [&](int co) -> size_t { return (size_t)(co >> 4) * plane_elems_out + (co & 15); };
+  const float lowv = p.relu ? 0.0f : -INFINITY, lowl = p.relu_last ? 0.0f : -INFINITY;
+
+  const int total = n_cot * n_chunks;
+  issue_w(0);
+  int step = 0;
+#pragma clang loop unroll(disable)
+  for (int ct = 0; ct < n_cot; ++ct) {
+    const int co32_0 = ct * NCO32;
+    // this cout tile's residual: requested before its K loop (the loop's first wait covers it)
+    uint4 rq4[RES ? 2 : 1][2][2];
+    if constexpr (RES) {
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr)
+#pragma unroll
+          for (int r = 0; r < 2; ++r) {
+            const int co = (co32_0 + wn * 2 + mt) * 32 + 16 * pr + 8 * half;
+            rq4[mt][pr][r] = make_uint4(0u, 0u, 0u, 0u);
+            if (pix_ok[r] && co < p.CoutP) rq4[mt][pr][r] = *reinterpret_cast<const uint4*>(rrow[r] + chan_off(co));
+          }
+    }
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[m][r][i] = 0.0f;
+#pragma clang loop unroll(disable)
+    for (int kc = 0; kc < n_chunks; ++kc, ++step) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (step + 1 < total) issue_w(step + 1);
+      const unsigned char* w_tile = wst + (step & 1) * W_STAGE;
+#pragma unroll
+      for (int kk = 0; kk < KK; ++kk) {
+        mfma_h8 a[2], bv[2];
+#pragma unroll
+        for (int m = 0; m < 2; ++m) a[m] = *reinterpret_cast<const mfma_h8*>(w_tile + ((wn * 2 + m) * KK + kk) * 1024 + lane * 16);
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+          const int pl = (wm * 2 + r) * 32 + lx;
+          bv[r] = *reinterpret_cast<const mfma_h8*>(smem + (kc * KK + kk) * (TP * 32) + pl * 32 + ((half ^ ((pl >> 3) & 1)) * 16));
+        }
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+          for (int r = 0; r < 2; ++r) acc[m][r] = SA_MFMA_32x32x16(a[m], bv[r], acc[m][r], 0, 0, 0);
+      }
+    }
+    // ---- epilogue of this cout tile: the tap-GEMM kernel's, operation for operation
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      const int cobase = (co32_0 + wn * 2 + mt) * 32;
+      if (cobase >= p.CoutP) continue;
+      uint2 pk[2][4];
+      uint2 rq[4][2];
+      if constexpr (RES) {
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr)
+#pragma unroll
+          for (int r = 0; r < 2; ++r) {
+            const uint4 q = rq4[mt][pr][r];
+            uint2 a = make_uint2(q.x, q.y), c = make_uint2(q.z, q.w);
+            sa::swap32(a.x, c.x);
+            sa::swap32(a.y, c.y);
+            rq[2 * pr][r] = a;
+            rq[2 * pr + 1][r] = c;
+          }
+      }
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int co = cobase + 8 * g + 4 * half;
+        const bool cok = co < p.CoutP;
+        float4 bq = make_float4(0.f, 0.f, 0.f, 0.f), sq = make_float4(1.f, 1.f, 1.f, 1.f), tq = bq;
+        if (cok) {
+          bq = *reinterpret_cast<const float4*>(p.bias + co);
+          if (p.post_scale) {
+            sq = *reinterpret_cast<const float4*>(p.post_scale + co);
+            tq = *reinterpret_cast<const float4*>(p.post_shift + co);
+          }
+        }
+        const float bb[4] = {bq.x, bq.y, bq.z, bq.w}, ss[4] = {sq.x, sq.y, sq.z, sq.w}, tt[4] = {tq.x, tq.y, tq.z, tq.w};
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+          float rr[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+          if constexpr (RES) {
+            const uint2 q = rq[g][r];
+            rr[0] = sa::h2f((uint16_t)(q.x & 0xffff)), rr[1] = sa::h2f((uint16_t)(q.x >> 16));
+            rr[2] = sa::h2f((uint16_t)(q.y & 0xffff)), rr[3] = sa::h2f((uint16_t)(q.y >> 16));
+          }
+          float v[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            float t = fmaxf(acc[mt][r][4 * g + j] + bb[j], lowv);
+            t = fmaf(t, ss[j], tt[j]);
+            if constexpr (RES) t += rr[j];
+            v[j] = fmaxf(t, lowl);
+          }
+          pk[r][g].x = sa::f2h2(v[0], v[1]);
+          pk[r][g].y = sa::f2h2(v[2], v[3]);
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr) {
+          uint2 a = pk[r][2 * pr], c = pk[r][2 * pr + 1];
+          sa::swap32(a.x, c.x);
+          sa::swap32(a.y, c.y);
+          const int co = cobase + 16 * pr + 8 * half;
+          if (pix_ok[r] && co < p.CoutP) *reinterpret_cast<uint4*>(drow[r] + chan_off(co)) = make_uint4(a.x, a.y, c.x, c.y);
+        }
+    }
+  }
+#endif
+}
+
+template <int WM, int WN, bool RES>
+int launch_tap_coloop(const TapParams& p0, hipStream_t st) {
+  constexpr int TP = 64 * WM, NCO32 = 2 * WN;
+  TapParams p = p0;
+  p.m_tiles = (p.Hl * p.Wl + TP - 1) / TP;
+  p.co_tiles = ((p.CoutP + 31) / 32 + NCO32 - 1) / NCO32;
+  const size_t lds = (size_t)(p.CinP / 16) * TP * 32 + 2 * (size_t)NCO32 * 2 * 1024;
+  const size_t nblk = (size_t)p.m_tiles * p.B;
+  if (nblk == 0 || nblk > 0x7fffffffull) return sa::fail(SA_ERR_INVALID_ARG, "tapconv: bad grid");
+  if ((size_t)p.Hl * p.Wl >= (1u << 23)) return sa::fail(SA_ERR_UNSUPPORTED, "tapconv: more than 2^23 output pixels per frame");
+  static bool attr_set = false;
+  if (!attr_set) {
+    SA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&tapconv_coloop_kernel<WM, WN, RES>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((tapconv_coloop_kernel<WM, WN, RES>), dim3((unsigned)nblk), dim3(256), lds, st, p);
+  SA_LAUNCH_CHECK();
+  return SA_OK;
+}
+
 template <int WM, int WN, bool PL, bool RES, int CK>
 int launch_tap(const TapParams& p0, hipStream_t st) {
   constexpr int TP = 64 * WM, NCO32 = 2 * WN;
@@ -406,6 +633,18 @@ int launch_tap_ck(const TapParams& p, hipStream_t st) {
 }
 
 int launch_tap_pick(const TapParams& p, hipStream_t st) {
+  // stride-1 1 x 1 convs on planes with >= 2 cout tiles of 128 and <= 128 input channels (ResNet's 64 -> 256 and 128 -> 512):
+  // one workgroup per pixel tile walks the cout tiles (tapconv_coloop_kernel; 0.194 -> 0.162 ms on 128 -> 512 + residual @128^2
+  // x 16). Measured and left to the per-(pixel tile, cout tile) kernel: 256 input channels (80 KiB of LDS, one workgroup per CU:
+  // 0.106 -> 0.108 ms; as 64-pixel x 256-cout tiles, 64 KiB: 0.116) and stride 2 (0.168 -> 0.178) -- profiles/r04_tapconv_sweep.md.
+  // SA_TAP_COLOOP=0: off (A/B)
+  static const bool coloop = [] {
+    const char* v = getenv("SA_TAP_COLOOP");
+    return !v || atoi(v) != 0;
+  }();
+  if (coloop && p.planar && p.n_taps == 1 && p.n_phases <= 1 && p.ksize == 0 && p.in_stride == 1 && p.CoutP >= 256 && p.CinP >= 64 &&
+      p.CinP <= 128 && p.CinP % 32 == 0)
+    return p.residual ? launch_tap_coloop<2, 2, true>(p, st) : launch_tap_coloop<2, 2, false>(p, st);
   if (p.planar) return p.residual ? launch_tap_ck<true, true>(p, st) : launch_tap_ck<true, false>(p, st);
   return p.residual ? launch_tap_ck<false, true>(p, st) : launch_tap_ck<false, false>(p, st);
 }

@@ -320,6 +320,46 @@ def test_conv1x1_vs_torch(B, H, W, Cin, Cout, stride, affine, residual, relu, re
         assert float(pad.abs().max()) == 0.0 
 
 
+@pytest.mark.parametrize("B,H,W,Cin,Cout,stride,residual", [
+    (2, 24, 20, 64, 256, 1, False),    # the cout-tile-walking kernel (stride 1, 64-128 input channels, >= 256 output channels)
+    (1, 19, 23, 128, 512, 1, True),    # + residual, ragged pixel tile
+    (3, 16, 16, 96, 272, 1, True),     # three K chunks of 32, a ragged last cout tile (272 = 2 x 128 + 16)
+    (1, 12, 12, 256, 1024, 1, True),   # 256 input channels: the per-(pixel tile, cout tile) kernel
+    (1, 24, 24, 128, 512, 2, False),   # stride 2: likewise
+])
+def test_conv1x1_on_planes_is_bitwise_nhwc(B, H, W, Cin, Cout, stride, residual):
+    """The 1 x 1 convolution on 16-channel planes -- for ResNet's expand shapes a kernel of its own (tapconv.hip:
+    tapconv_coloop_kernel: the pixel tile resident in LDS, the cout tiles walked by one workgroup) -- gives the bits of the NHWC
+    launch: same products, same accumulation order, same epilogue."""
+    from sleap_amd import _lib, ops
+    from sleap_amd._lib import check
+    from sleap_amd.ops import _ptr, _stream
+
+    g = torch.Generator(device="cpu").manual_seed(B + H + Cin + Cout)
+    k = torch.randn((Cin, Cout), generator=g) * (2.0 / Cin) ** 0.5
+    x = torch.randn((B, H, W, Cin), generator=g)
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    cinp, coutp = ops.pad16(Cin), ops.pad16(Cout)
+    dx = ops.to_bf16_padded(x.cuda().contiguous())
+    dres = ops.to_bf16_padded(torch.randn((B, Ho, Wo, Cout), generator=g).cuda().contiguous()) if residual else None
+    pw = _pack_taps(k[None], cinp, coutp)
+    bp = _padded(0.1 * torch.randn((Cout,), generator=g), coutp)
+    ps = _padded(1.0 + 0.3 * torch.randn((Cout,), generator=g), coutp, 1.0)
+    pt = _padded(0.2 * torch.randn((Cout,), generator=g), coutp)
+    outs = []
+    for lay in (_lib.LAYOUT_NHWC, _lib.LAYOUT_PLANES16):
+        pl = lay == _lib.LAYOUT_PLANES16
+        src = ops.to_planes16(dx) if pl else dx
+        res = (ops.to_planes16(dres) if pl else dres) if residual else None
+        out = torch.full((B, Ho, Wo, coutp), 7.0, dtype=TD, device="cuda")
+        check(_lib.lib().sa_conv1x1_bf16(_ptr(src), cinp, _ptr(pw), _ptr(bp), coutp, lay, B, H, W, stride, _ptr(ps), _ptr(pt),
+                                         _ptr(res), 1, _ptr(out), _stream()), "sa_conv1x1_bf16")
+        outs.append(ops.from_planes16(out) if pl else out)
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0].view(torch.int16), outs[1].view(torch.int16))
+    assert float(outs[0].float().abs().max()) > 0.5
+
+
 @pytest.mark.parametrize("B,H,W,Cin,Cout,ksize,affine", [
     (2, 8, 12, 64, 64, 4, True),
     (1, 9, 7, 48, 80, 4, False),
