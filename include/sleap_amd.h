@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define SA_ABI_VERSION 4  /* 4 (round 4): + sa_tensor_absmax, sa_imgconv_pack_tiled, sa_pack_pointwise_weights,
+#define SA_ABI_VERSION 5  /* 5 (round 4): + sa_conv3x3_ex_heads_bf16. 4 (round 4): + sa_tensor_absmax, sa_imgconv_pack_tiled, sa_pack_pointwise_weights,
                             sa_pointwise_packed_elems, sa_conv3x3_bneck_bf16; SA_LAYOUT_PLANES16 accepted in the `relu` argument of
                             sa_conv1x1_bf16 / sa_convk_bf16 / sa_convt_s2_bf16 */
 
@@ -314,12 +314,21 @@ int sa_conv3x3_bneck_bf16(const void* src, int CinP, int layout, const void* w, 
 /* Same convolution with up to two 1x1 heads (Head.make_head, heads.py:42-62) fused into the epilogue and
  * computed from the fp32 accumulators (no bf16 rounding of the features the heads see). Needs CoutP <= 64 and
  * mode NONE/DIRECT. HOST arrays of length n_heads: head_w[i] -> device [head_c[i]][CoutP] f32, head_b[i] -> device
- * [head_c[i]] f32, head_c[i] <= 32, head_act[i] (0 linear, 1 sigmoid), head_dst[i] -> device [B,H,W,head_c[i]] f32.
+ * [head_c[i]] f32, head_c[i] <= 64 (32 per pass of the matrix-core head GEMM), head_act[i] (0 linear, 1 sigmoid), head_dst[i] -> device [B,H,W,head_c[i]] f32.
  * dst (bf16 features) may be NULL when only the heads consume this layer. */
 int sa_conv3x3_heads_bf16(const void* src0, int C0P, const void* src1, int C1P, int mode, const void* w,
                           const float* bias, int CoutP, int relu, int B, int H, int W, void* dst, int n_heads,
                           const float* const* head_w, const float* const* head_b, const int* head_c,
                           const int* head_act, float* const* head_dst, sa_stream_t stream);
+
+/* sa_conv3x3_heads_bf16 behind the extended epilogue (sa_conv3x3_ex_bf16 without a residual or a pooled output): the ResNet
+ * decoder's Conv2D + BatchNormalization + ReLU in front of its heads (upsampling.py:140-199 refine convs -> heads.py:42-62).
+ * The heads see the value the extended epilogue stores. Needs 33..64 padded output channels; mode NONE/DIRECT.
+ * dst may be NULL when only the heads consume this layer. */
+int sa_conv3x3_ex_heads_bf16(const void* src0, int C0P, const void* src1, int C1P, int mode, const void* w, const float* bias,
+                             int CoutP, int relu, int B, int H, int W, void* dst, const float* post_scale, const float* post_shift,
+                             int relu_last, int n_heads, const float* const* head_w, const float* const* head_b,
+                             const int* head_c, const int* head_act, float* const* head_dst, sa_stream_t stream);
 
 /* Launch policy of the 3x3 MFMA kernels (process-wide, HOST). By default a layer with more tiles than the chip holds
  * workgroups is launched PERSISTENT: occupancy x CUs workgroups, each walking its share of the (frame, tile, cout-tile)

@@ -65,6 +65,7 @@ SIGNATURES = {
     "sa_conv3x3_bneck_bf16": (_i, [_p, _i, _i, _p, _p, _i, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _p, _i, _i, _i, _p, _p, _p, _p, _p,
                                    _i, _i, _i, _p, _p]),
     "sa_conv3x3_heads_bf16": (_i, [_p, _i, _p, _i, _i, _p, _p, _i, _i, _i, _i, _i, _p, _i, _p, _p, _p, _p, _p, _p]),
+    "sa_conv3x3_ex_heads_bf16": (_i, [_p, _i, _p, _i, _i, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _i, _i, _p, _p, _p, _p, _p, _p]),
     "sa_pack_conv3x3_weights": (_i, [_p, _i, _i, _i, _i, _i, _i, _p]),
     "sa_conv3x3_packed_elems": (_sz, [_i, _i, _i]),
     "sa_conv3x3_set_grid_limit": (_i, [_i]),

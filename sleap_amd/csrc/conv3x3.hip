@@ -1394,9 +1394,10 @@ conv3x3_dma_kernel(const ConvParams2 p) {
   // the tile, and the A fragment is gathered from the fp32 head weights with the same channel map. The weights enter
   // as hi + lo bf16 terms (two MFMAs), which keeps ~16 mantissa bits of the fp32 head kernel.
   if constexpr (HEADS) {
-    for (int hd = 0; hd < p.n_heads; ++hd) {
+    for (int hd = 0; hd < p.n_heads; ++hd)
+    for (int nb = 0; nb < p.head_c[hd]; nb += 32) {  // 32 head channels per pass (round 4: up to 64 -- 46 PAF channels of 23 edges)
       const int NH = p.head_c[hd];
-      const int nrow = lane_e & 31;
+      const int nrow = nb + (lane_e & 31);
       f32x16 hacc[R];
 #pragma unroll
       for (int r = 0; r < R; ++r)
@@ -1428,6 +1429,17 @@ conv3x3_dma_kernel(const ConvParams2 p) {
             ahi[j] = sa::f2h(wv[j]);
             alo[j] = sa::f2h(wv[j] - sa::h2f(ahi[j]));
           }
+          // EXT: the heads see the extended epilogue's value (activation -> BatchNormalization affine -> final ReLU; no
+          // residual with fused heads), operation for operation what act() above stores
+          float sc[8] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f}, sh[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+          if constexpr (EXT) {
+            if (p.post_scale) {
+              const float4 a0 = *reinterpret_cast<const float4*>(p.post_scale + c_lo), a1 = *reinterpret_cast<const float4*>(p.post_scale + c_lo + 8);
+              const float4 t0 = *reinterpret_cast<const float4*>(p.post_shift + c_lo), t1 = *reinterpret_cast<const float4*>(p.post_shift + c_lo + 8);
+              sc[0] = a0.x, sc[1] = a0.y, sc[2] = a0.z, sc[3] = a0.w, sc[4] = a1.x, sc[5] = a1.y, sc[6] = a1.z, sc[7] = a1.w;
+              sh[0] = t0.x, sh[1] = t0.y, sh[2] = t0.z, sh[3] = t0.w, sh[4] = t1.x, sh[5] = t1.y, sh[6] = t1.z, sh[7] = t1.w;
+            }
+          }
 #pragma unroll
           for (int r = 0; r < R; ++r) {
             h16x8_t fq;
@@ -1435,7 +1447,14 @@ conv3x3_dma_kernel(const ConvParams2 p) {
             for (int j = 0; j < 8; ++j) {
               float t = acc[m][r][8 * s2 + j];
               if constexpr (!BIAS_INIT) t += bb[j];
-              fq[j] = sa::f2h(p.relu ? fmaxf(t, 0.0f) : t);
+              if constexpr (EXT) {
+                t = fmaxf(t, p.relu ? 0.0f : -INFINITY);
+                t = fmaf(t, sc[j], sh[j]);
+                if (p.relu_last) t = fmaxf(t, 0.0f);
+                fq[j] = sa::f2h(t);
+              } else {
+                fq[j] = sa::f2h(p.relu ? fmaxf(t, 0.0f) : t);
+              }
             }
             const mfma_h8 bf = __builtin_bit_cast(mfma_h8, fq);
             hacc[r] = SA_MFMA_32x32x16(__builtin_bit_cast(mfma_h8, ahi), bf, hacc[r], 0, 0, 0);
@@ -1452,7 +1471,7 @@ conv3x3_dma_kernel(const ConvParams2 p) {
       for (int g = 0; g < 4; ++g)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const int n = j + 8 * g + 4 * half;
+          const int n = nb + j + 8 * g + 4 * half;
           hb[g][j] = n < NH ? p.head_b[hd][n] : 0.0f;
         }
       const bool sig = p.head_act[hd] == 1;
@@ -1463,7 +1482,7 @@ conv3x3_dma_kernel(const ConvParams2 p) {
         float* out = p.head_dst[hd] + (((size_t)b * H + (ok ? gy : 0)) * W + (ok ? gx : 0)) * NH;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-          const int n0 = 8 * g + 4 * half;
+          const int n0 = nb + 8 * g + 4 * half;
           float t[4];
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
@@ -1547,7 +1566,7 @@ int launch2(const ConvParams2& p, hipStream_t st) {
   if (HEADS) {
     if (q.co_tiles != 1) return sa::fail(SA_ERR_UNSUPPORTED, "fused heads need all output channels in one workgroup (CoutP <= %d)", MT * 32);
     for (int hd = 0; hd < p.n_heads; ++hd)
-      if ((size_t)p.head_c[hd] * p.CoutP * 4 > lds || p.head_c[hd] > 32 || p.head_c[hd] < 1)
+      if (p.head_c[hd] > 64 || p.head_c[hd] < 1)
         return sa::fail(SA_ERR_UNSUPPORTED, "fused head %d: %d channels not supported", hd, p.head_c[hd]);
   }
   // Persistent launch for the double-buffered kernels: as many workgroups as the chip holds at once (occupancy x CUs), each
@@ -1599,6 +1618,13 @@ bool late_issue(int n_chunks) {
 template <int MT, int CK>
 int launch2_pick(const ConvParams2& p, hipStream_t st) {
   if (p.post_scale || p.residual || p.relu_last) {  // extended epilogue
+    if (p.n_heads > 0) {  // + fused heads (round 4: the ResNet decoder's Conv + BN + ReLU in front of its heads): 64-channel tiles only
+      if constexpr (MT == 2 && CK == 16)
+        return late_issue((p.C0P + p.C1P) / CK) ? launch2<2, 16, 8, 2, 2, true, 0, true, false, SA_CONV_ITAP>(p, st)
+                                                : launch2<2, 16, 8, 2, 2, true, 0, true>(p, st);
+      else
+        return sa::fail(SA_ERR_UNSUPPORTED, "sa_conv3x3_ex_heads_bf16: fused heads behind the extended epilogue need 33-64 output channels and 16-channel chunks");
+    }
     if ((p.C0P + p.C1P) == CK) return launch2<MT, CK, 4, 2, 1, false, 0, true>(p, st);
     // (CK == 16, planes: the mid-chunk variant holds 2 workgroups per CU -- 128 registers -- without spills, the other one
     //  spills 21, so every multi-chunk layer takes it; hourglass 3x3 convs: 1.0 -> see profiles/r03_ab_session.md section 5)
@@ -1726,7 +1752,9 @@ static int conv3x3_impl(const void* src0, int C0P, const void* src1, int C1P, in
     q.res_mode = res_mode;
     q.relu_last = relu_last;
     q.planar = planar;
-    SA_REQUIRE(!(post_scale || residual || relu_last) || n_heads == 0, "sa_conv3x3: extended epilogue and fused heads are exclusive");
+    SA_REQUIRE(!residual || n_heads == 0, "sa_conv3x3: a residual and fused heads are exclusive");
+    SA_REQUIRE(!(post_scale || relu_last) || n_heads == 0 || (co32_n == 2 && !ck32 && !dst_pool),
+               "sa_conv3x3_ex_heads_bf16: fused heads behind the extended epilogue need 33-64 (padded) output channels");
     SA_REQUIRE(!post_scale == !post_shift, "sa_conv3x3: post_scale and post_shift come together");
     SA_REQUIRE(!(residual && res_mode) || (H % 2 == 0 && W % 2 == 0), "sa_conv3x3: half-resolution residual needs even H, W");
     q.n_heads = n_heads;
@@ -1852,6 +1880,15 @@ int sa_conv3x3_ex_bf16(const void* src0, int C0P, const void* src1, int C1P, int
                        int relu_last, sa_stream_t stream) {
   return conv3x3_impl(src0, C0P, src1, C1P, mode, w, bias, CoutP, relu, B, H, W, dst, dst_pool, 0, nullptr, nullptr,
                       nullptr, nullptr, nullptr, stream, post_scale, post_shift, residual, res_mode, relu_last);
+}
+
+int sa_conv3x3_ex_heads_bf16(const void* src0, int C0P, const void* src1, int C1P, int mode, const void* w, const float* bias,
+                             int CoutP, int relu, int B, int H, int W, void* dst, const float* post_scale, const float* post_shift,
+                             int relu_last, int n_heads, const float* const* head_w, const float* const* head_b,
+                             const int* head_c, const int* head_act, float* const* head_dst, sa_stream_t stream) {
+  SA_REQUIRE(n_heads >= 1 && head_w && head_b && head_c && head_act && head_dst, "sa_conv3x3_ex_heads_bf16: bad head arguments");
+  return conv3x3_impl(src0, C0P, src1, C1P, mode, w, bias, CoutP, relu, B, H, W, dst, nullptr, n_heads, head_w, head_b, head_c,
+                      head_act, head_dst, stream, post_scale, post_shift, nullptr, 0, relu_last);
 }
 
 int sa_stem_conv3x3x2_bf16(const void* src, int src_is_u8, int B, int H, int W, int Cin, const float* w0,

@@ -242,8 +242,12 @@ int sa_network_forward(const sa_network_t* net, const void* images, int images_a
             ha[k] = (int)a[13 + 5 * k];
             hd[k] = static_cast<float*>(bp(a[14 + 5 * k]));
           }
-          rc = sa_conv3x3_heads_bf16(bp(s0), bc(s0), src1, c1p, (int)a[2] | lay, P<void>(a[3]), P<float>(a[4]), coutp, (int)a[6], B, oh,
-                                     ow, dst, nh, hw, hb, hc, ha, hd, stream);
+          if (e[0])  // extended epilogue (no residual: DeviceNetwork._fuse_heads) + heads
+            rc = sa_conv3x3_ex_heads_bf16(bp(s0), bc(s0), src1, c1p, (int)a[2] | lay, P<void>(a[3]), P<float>(a[4]), coutp, (int)a[6], B,
+                                          oh, ow, dst, P<float>(e[1]), P<float>(e[2]), (int)e[5], nh, hw, hb, hc, ha, hd, stream);
+          else
+            rc = sa_conv3x3_heads_bf16(bp(s0), bc(s0), src1, c1p, (int)a[2] | lay, P<void>(a[3]), P<float>(a[4]), coutp, (int)a[6], B, oh,
+                                       ow, dst, nh, hw, hb, hc, ha, hd, stream);
         } else if (e[0]) {
           rc = sa_conv3x3_ex_bf16(bp(s0), bc(s0), src1, c1p, (int)a[2] | lay, P<void>(a[3]), P<float>(a[4]), coutp, (int)a[6], B, oh, ow,
                                   dst, bp(a[7]), P<float>(e[1]), P<float>(e[2]), bp(e[3]), (int)e[4], (int)e[5], stream);

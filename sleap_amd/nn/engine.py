@@ -125,6 +125,7 @@ class DeviceNetwork:
         self.fuse_upsample = ({"1": True, "0": False}.get(env_up, "auto")) if auto_up else bool(fuse_upsample)
         self.fuse_upsample_max_cout = int(os.environ.get("SA_FUSE_UPSAMPLE_MAX_COUT", "64"))
         self.fuse_heads = fuse_heads
+        self.fuse_ext_heads = os.environ.get("SA_FUSE_EXT_HEADS", "1") != "0"  # (A/B: heads behind a Conv + BN + ReLU stay launches)
         self.fuse_stem = fuse_stem
         self.use_stem16 = use_stem16
         # 16->32->32 encoder block in one launch (csrc/convpair.hip); SA_FUSE_PAIRS=0 turns it off for A/B measurements
@@ -828,7 +829,7 @@ class DeviceNetwork:
         return a
 
     def _fuse_heads(self, plan):
-        """Move 1x1 heads into the epilogue of the conv that produces their input (<= 2 heads, <= 32 channels each,
+        """Move 1x1 heads into the epilogue of the conv that produces their input (<= 2 heads, <= 64 channels each,
         producer with <= 128 padded output channels on the DMA path). If the heads were the only readers the bf16
         feature tensor is never written."""
         convs = {id(op.out): op for op in plan if op[0] == "conv"}
@@ -836,8 +837,12 @@ class DeviceNetwork:
         for op in plan:
             if op[0] == "head":  # ("head", src, out, w, bias, activation)
                 prod = convs.get(id(op[1]))
+                # (a producer with the extended epilogue -- Conv + BN + ReLU, the ResNet decoder -- takes heads when it has no
+                #  residual / pooled output and 33..64 padded channels: sa_conv3x3_ex_heads_bf16)
+                ext_ok = prod is not None and (prod.ext is None or (
+                    prod.ext["res"] is None and prod.out_pool is None and prod.out.cp in (48, 64) and self.fuse_ext_heads))
                 if (prod is not None and prod.mode in (_lib.SRC1_NONE, _lib.SRC1_DIRECT) and prod.out.cp <= 128
-                        and len(prod.heads) < 2 and op[2].c <= 32 and prod.ext is None):
+                        and len(prod.heads) < 2 and op[2].c <= 64 and ext_ok):
                     prod.heads.append(op)
                     continue
             out.append(op)
@@ -1226,7 +1231,7 @@ class DeviceNetwork:
                 check(h.sa_stem_conv3x3(_ptr(imgs), is_u8, B, H, W, cin, _ptr(w), _ptr(bias), o.cp, relu,
                                         _ptr(bufs[o.buf]), st), "sa_stem_conv3x3")
             elif kind == "conv" and op.heads:
-                _, s0, s1, mode, w, bias, o, relu, o_pool, need_full, heads, _nm, _ext = op
+                _, s0, s1, mode, w, bias, o, relu, o_pool, need_full, heads, _nm, ext = op
                 oh, ow = hw(o)
                 n = len(heads)
                 arr = (C.c_void_p * n)
@@ -1237,16 +1242,24 @@ class DeviceNetwork:
                 ha_ = (C.c_int * n)(*[hd[5] for hd in heads])
                 for hd in heads:  # the fused kernel indexes head weights with the producer's padded channel count
                     assert hd[3].shape[1] == o.cp
-                check(h.sa_conv3x3_heads_bf16(_ptr(bufs[s0.buf]), s0.cp, _ptr(bufs[s1.buf]) if s1 is not None else None,
-                                              s1.cp if s1 is not None else 0, mode | self.layout, _ptr(w), _ptr(bias), o.cp, relu, B, oh,
-                                              ow, _ptr(bufs[o.buf]) if need_full else None, n, hw_, hb_, hc_, ha_, hd_, st),
-                      "sa_conv3x3_heads_bf16")
+                if ext is not None:  # Conv + BatchNormalization + ReLU in front of the heads (_fuse_heads: no residual)
+                    assert ext["res"] is None and o_pool is None
+                    check(h.sa_conv3x3_ex_heads_bf16(_ptr(bufs[s0.buf]), s0.cp, _ptr(bufs[s1.buf]) if s1 is not None else None,
+                                                     s1.cp if s1 is not None else 0, mode | self.layout, _ptr(w), _ptr(bias), o.cp, relu,
+                                                     B, oh, ow, _ptr(bufs[o.buf]) if need_full else None, _ptr(ext["ps"]),
+                                                     _ptr(ext["pt"]), ext["relu_last"], n, hw_, hb_, hc_, ha_, hd_, st),
+                          "sa_conv3x3_ex_heads_bf16")
+                else:
+                    check(h.sa_conv3x3_heads_bf16(_ptr(bufs[s0.buf]), s0.cp, _ptr(bufs[s1.buf]) if s1 is not None else None,
+                                                  s1.cp if s1 is not None else 0, mode | self.layout, _ptr(w), _ptr(bias), o.cp, relu, B,
+                                                  oh, ow, _ptr(bufs[o.buf]) if need_full else None, n, hw_, hb_, hc_, ha_, hd_, st),
+                          "sa_conv3x3_heads_bf16")
             elif kind == "conv" and op.ext is not None:
                 _, s0, s1, mode, w, bias, o, relu, o_pool, need_full, _heads, _nm, ext = op
                 oh, ow = hw(o)
                 res = ext["res"]
                 check(h.sa_conv3x3_ex_bf16(_ptr(bufs[s0.buf]), s0.cp, _ptr(bufs[s1.buf]) if s1 is not None else None,
-                                           s1.cp if s1 is not None else 0, mode, _ptr(w), _ptr(bias), o.cp, relu, B, oh, ow,
+                                           s1.cp if s1 is not None else 0, mode | self.layout, _ptr(w), _ptr(bias), o.cp, relu, B, oh, ow,
                                            _ptr(bufs[o.buf]) if need_full else None,
                                            _ptr(bufs[o_pool.buf]) if o_pool is not None else None,
                                            _ptr(ext["ps"]), _ptr(ext["pt"]),

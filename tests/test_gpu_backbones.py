@@ -670,6 +670,41 @@ def test_resnet50_bottleneck_tails_fused_vs_unfused_and_oracle():
             assert float(np.abs(u - r).max()) <= 3e-2 * rng
 
 
+def test_resnet50_decoder_heads_fused_behind_batchnorm_vs_unfused_and_oracle(monkeypatch):
+    """Round 4: the decoder's Conv + BatchNormalization + ReLU in front of a head takes the head into its epilogue
+    (sa_conv3x3_ex_heads_bf16: the heads see the value the extended epilogue stores). Fused vs the stand-alone head launches
+    (SA_FUSE_EXT_HEADS=0) vs the fp32 oracle, on planes and on NHWC; and the per-launch Python loop (bench.py --layers,
+    tools/net_profile.py) is the plan's launch sequence bit for bit -- it passes the layout to every launch."""
+    from oracle.keras_graph import KerasGraph, ensure_float
+    from sleap_amd.nn.engine import DeviceNetwork
+
+    cfg, w = _resnet(128, 160, features_output_stride=32, pretrained=True,
+                     upsampling=dict(output_stride=4, method="transposed_conv", skip_connections="concatenate", filters=64, refine_convs=2),
+                     heads=[("MultiInstanceConfmapsHead", 24, 4), ("PartAffinityFieldsHead", 46, 8)])  # configs[4]'s heads
+    x = torch.from_numpy(np.random.default_rng(11).integers(0, 256, (3, 128, 160, 1), dtype=np.uint8)).cuda()
+    ref = KerasGraph(cfg, w)(ensure_float(x.cpu().numpy()))
+    for layout in (None, "nhwc"):
+        fused = DeviceNetwork(cfg, w, dtype="fp16", layout=layout)
+        monkeypatch.setenv("SA_FUSE_EXT_HEADS", "0")
+        plain = DeviceNetwork(cfg, w, dtype="fp16", layout=layout)
+        monkeypatch.delenv("SA_FUSE_EXT_HEADS")
+        assert [op[0] for op in fused.plan].count("head") == 0 and [op[0] for op in plain.plan].count("head") == 2
+        assert sum(1 for op in fused.plan if op[0] == "conv" and op.heads and op.ext is not None) == 2
+        a = [o.clone() for o in fused.forward(x)]
+        b = [o.clone() for o in plain.forward(x)]
+        prof = []
+        c = [o.clone() for o in fused.forward(x, profile=prof)]
+        assert len(prof) == len(fused.plan)
+        for u, v, q, r in zip(a, b, c, ref):
+            assert torch.equal(u, q), layout
+            u, v = u.cpu().numpy(), v.cpu().numpy()
+            rng = float(np.abs(r).max())
+            assert np.isfinite(u).all()
+            # same stored features (bitwise the un-fused tensor); the head GEMM: fp32 FMA chain vs matrix cores on hi + lo weights
+            assert float(np.abs(u - v).max()) <= 2e-3 * rng, (layout, float(np.abs(u - v).max()), rng)
+            assert float(np.abs(u - r).max()) <= 3e-2 * rng
+
+
 def test_resnet50_stride16_bilinear_add_vs_oracle():
     """features_output_stride 16 (conv5 unstrided, dilated 1x1 convs = no-op), bilinear upsampling with additive
     skips through 1x1 projections; RGB input without the ImageNet Lambdas."""

@@ -317,6 +317,30 @@ def test_fusion_variants_agree(fuse):
             assert float((a - b).abs().max()) <= 2e-2 * float(a.abs().max())
 
 
+@pytest.mark.parametrize("layout", [None, "nhwc"])
+def test_fused_heads_with_more_than_32_channels(layout):
+    """Round 4: a fused head may have up to 64 channels (two 32-row passes of the matrix-core head GEMM): 24 nodes / 23 edges
+    = 24 + 46 channels (BASELINE configs[4]'s heads on a UNet). Fused == stand-alone head launches up to the head GEMM's
+    rounding, both within the usual tolerance of the fp32 oracle."""
+    from oracle.keras_graph import KerasGraph, ensure_float
+    from sleap_amd.nn.architectures import build_unet_model_config, he_normal_weights
+    from sleap_amd.nn.engine import DeviceNetwork
+
+    cfg, shapes = build_unet_model_config((96, 128, 1), 16, 2, 32, 4, True, True,
+                                          heads=[("MultiInstanceConfmapsHead", 40, 4), ("PartAffinityFieldsHead", 46, 8)])
+    w = he_normal_weights(shapes, seed=3)
+    x = torch.from_numpy(_fly_frames(2, 96, 128, 9)).cuda()
+    ref = KerasGraph(cfg, w)(ensure_float(x.cpu().numpy()))
+    fused = DeviceNetwork(cfg, w, layout=layout)
+    plain = DeviceNetwork(cfg, w, layout=layout, fuse_heads=False)
+    assert [op[0] for op in fused.plan].count("head") == 0 and [op[0] for op in plain.plan].count("head") == 2
+    for a, b, r in zip(fused.forward(x), plain.forward(x), ref):
+        assert a.shape[-1] in (40, 46)
+        rng = float(np.abs(r).max())
+        assert float((a - b).abs().max()) <= 2e-2 * rng
+        assert float(np.abs(a.cpu().numpy() - r).max()) <= 3e-2 * rng
+
+
 @pytest.mark.parametrize("layout", ["nhwc", "planes16"])
 @pytest.mark.parametrize("B,H,W,full,pooled", [(2, 32, 64, True, False), (1, 48, 96, False, True), (2, 16, 32, True, True),
                                                 (1, 37, 45, True, False), (1, 18, 34, False, True)])
