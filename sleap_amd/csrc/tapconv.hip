@@ -611,7 +611,20 @@ int launch_tap_shape(const TapParams& p, hipStream_t st) {
     const char* v = getenv("SA_TAP_SHAPE");
     return v ? atoi(v) : 0;
   }();
-  const int shape = force ? force : (p.CoutP <= 64 ? 1 : 2);
+  // <= 64 output channels: 256 pixels x 64 couts per workgroup -- unless that leaves the chip with fewer than two workgroups per
+  // CU on a long K loop (the ResNet decoder's first transposed conv, 2048 -> 64 @32^2 x 16 frames: 256 workgroups of 128 chunks
+  // each): then 128 pixels x 128 couts, half of them padding, for twice the workgroups (0.180 -> 0.157 ms)
+  static int n_cu = 0;
+  if (!n_cu) {
+    int dev = 0;
+    SA_HIP_CHECK(hipGetDevice(&dev));
+    SA_HIP_CHECK(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+  }
+  const size_t wg1 = (size_t)((p.Hl * p.Wl + 255) / 256) * p.B * (p.n_phases > 1 ? p.n_phases : 1);
+  int max_taps = p.n_taps > 0 ? p.n_taps : 1;
+  for (int i = 0; i < p.n_phases; ++i) max_taps = p.ph_ntaps[i] > max_taps ? p.ph_ntaps[i] : max_taps;
+  const bool starved = wg1 < (size_t)2 * n_cu && (size_t)p.CinP * max_taps >= 2048;
+  const int shape = force ? force : ((p.CoutP <= 64 && !starved) ? 1 : 2);
   if (shape == 1) return launch_tap<4, 1, PL, RES, CK>(p, st);
   return launch_tap<2, 2, PL, RES, CK>(p, st);
 }

@@ -33,5 +33,6 @@ ff=$(find $O/rfetch -name "*counter_collection.csv" | head -1); fw=$(find $O/rwr
 f=$(find $O/rmfma -name "*counter_collection.csv" | head -1); k=$(find $O/rmfma -name "*kernel_trace.csv" | head -1)
 [ -n "$f" ] && python tools/pmc_mfma.py $f $k > $O/resnet50_pmc_mfma_util.md 2>&1
 rm -rf $O/rkt $O/rfetch $O/rwrite $O/rmfma
+timeout 400 python tools/bench_configs.py 10 > $O/other_configs.md 2> $O/other_configs.err; cat $O/other_configs.md | cut -c1-200
 ls $O; head -30 $O/kt_kernel_stats.md | cut -c1-200
 fi
