@@ -198,6 +198,29 @@ def self_launch(args):
     raise SystemExit(subprocess.call(cmd, env=env))
 
 
+_JSON_FD = None
+
+
+def claim_stdout():
+    """stdout carries ONE JSON line (the driver parses it); libraries write there too -- RCCL prints a version banner at
+    communicator creation, through C stdio, so it can land before or after Python's own output. From here on file descriptor 1
+    is stderr for everything in this process; `emit` writes the line to the descriptor stdout had."""
+    global _JSON_FD
+    if _JSON_FD is None:
+        sys.stdout.flush()
+        _JSON_FD = os.dup(1)
+        os.dup2(2, 1)
+
+
+def emit(obj):
+    line = (json.dumps(obj) + "\n").encode()
+    if _JSON_FD is None:
+        sys.stdout.write(line.decode())
+        sys.stdout.flush()
+    else:
+        os.write(_JSON_FD, line)
+
+
 def dry_run_cpu(args, world, rank):
     """The distributed skeleton of a step on CPU tensors over gloo: shard arithmetic, one all-gather of the packed rows,
     barrier, max-reduce of the time -- everything `main` does around the GPU work. Prints the same distributed fields."""
@@ -220,10 +243,10 @@ def dry_run_cpu(args, world, rank):
     dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     ok = bool(all(float(got[r * B, 0]) == float(r) for r in range(world)))
     if rank == 0:
-        print(json.dumps({"dry_run": True, "n_gpus": world, "steps": args.steps, "rows_in_rank_order": ok,
-                          "scaling": "strong" if args.global_batch else "weak",
-                          "config": {"n_ranks_seen": dist.get_world_size(), "collective_backend": dist.get_backend(),
-                                     "frames_per_gpu_per_step": B, "global_batch": B * world}}), flush=True)
+        emit({"dry_run": True, "n_gpus": world, "steps": args.steps, "rows_in_rank_order": ok,
+              "scaling": "strong" if args.global_batch else "weak",
+              "config": {"n_ranks_seen": dist.get_world_size(), "collective_backend": dist.get_backend(),
+                         "frames_per_gpu_per_step": B, "global_batch": B * world}})
     dist.barrier()
     dist.destroy_process_group()
 
@@ -231,6 +254,7 @@ def dry_run_cpu(args, world, rank):
 def main():
     args = parse()
     self_launch(args)
+    claim_stdout()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -502,7 +526,7 @@ def main():
                                    "reason": ("N>1: the CPU baseline is measured by the N=1 run only" if world > 1
                                               else "--no-cpu-baseline"),
                                    "sample": None}
-        print(json.dumps(out), flush=True)
+        emit(out)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

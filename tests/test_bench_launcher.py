@@ -28,6 +28,9 @@ def test_gpus_2_self_launches_two_ranks_and_gathers_in_rank_order():
     assert r.returncode == 0, r.stderr[-2000:]
     lines = _json_lines(r.stdout)
     assert len(lines) == 1, r.stdout  # rank 0 only
+    # ... and nothing else: library chatter (RCCL's version banner goes to stdout through C stdio) is kept off the descriptor
+    # the driver parses (bench.claim_stdout)
+    assert [l for l in r.stdout.splitlines() if l.strip()] == [l for l in r.stdout.splitlines() if l.startswith("{")]
     d = lines[0]
     assert d["n_gpus"] == 2 and d["config"]["n_ranks_seen"] == 2 and d["config"]["collective_backend"] == "gloo"
     assert d["rows_in_rank_order"] and d["config"]["global_batch"] == 128
@@ -62,3 +65,13 @@ def test_literal_configs3_split_8_ranks_of_8_frames():
     d = lines[0]
     assert d["n_gpus"] == 8 and d["config"]["n_ranks_seen"] == 8 and d["scaling"] == "strong"
     assert d["config"]["frames_per_gpu_per_step"] == 8 and d["config"]["global_batch"] == 64 and d["rows_in_rank_order"]
+
+
+def test_stdout_carries_only_the_json_line_even_when_c_code_prints(tmp_path):
+    """claim_stdout(): what C libraries write to file descriptor 1 after it ends up on stderr; emit() reaches the real stdout."""
+    code = ("import ctypes, os, sys; sys.path.insert(0, %r); import bench; bench.claim_stdout(); "
+            "ctypes.CDLL(None).puts(b'RCCL version : banner'); ctypes.CDLL(None).fflush(None); print('python chatter'); "
+            "bench.emit({'ok': 1})" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert r.stdout == '{"ok": 1}\n' and "banner" in r.stderr and "python chatter" in r.stderr
