@@ -16,6 +16,8 @@ rendered with seeds the models were not fitted to.
                 (inference.py:1747-1966, 2059-2200)
     configs[4]  1024 x 1024 bottom-up ResNet-50 + UpsamplingStack + PAFs, 24 nodes / 23 edges, 8 animals (resnet.py:467-541)
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -233,7 +235,9 @@ def test_configs2_topdown_1024_two_animals_oracle_runs_its_own_networks(seed):
     assert worst <= TOL_PX and worst_c <= TOL_PX and float(np.percentile(dist, 95)) <= 0.05, (worst, worst_c)
 
 
-C4_SEEDS = (304, 308)  # (three frames each that the model was not fitted to: the fit draws seeds >= 10000)
+# (three frames each that the model was not fitted to: the fit draws seeds >= 10000; SA_C4_SEEDS="a,b,..." widens the sweep --
+#  tools/r04_p.sh ran eight seeds once, profiles/r04_ab_session.md section 8)
+C4_SEEDS = tuple(int(v) for v in os.environ["SA_C4_SEEDS"].split(",")) if os.environ.get("SA_C4_SEEDS") else (304, 306, 308, 310)
 
 
 @pytest.fixture(scope="module", params=C4_SEEDS)
@@ -359,7 +363,10 @@ def test_configs4_model_directory_through_load_model(tmp_path, resnet_workload):
     got = pred.predict(wl["frames"], make_labels=False)[0]
     ref = BottomUpPredictor(bottomup_config=C.training_config(wl["task"]), bottomup_model=DeviceNetwork(wl["mc"], wl["w"]),
                             batch_size=3, verbosity="none").predict(wl["frames"], make_labels=False)[0]
-    assert np.array_equal(got["n_valid"], ref["n_valid"]) and got["n_valid"].tolist() == [8, 8, 8]
+    # the fp32 oracle's instance counts: 8 per frame on the default seeds (test_configs4_oracle_detects_the_animals asserts it); in
+    # the eight-seed sweep (SA_C4_SEEDS) one frame of seed 309 has 9 on BOTH sides -- model and oracle split the same mouse
+    n_oracle = [int(np.asarray(x).reshape(-1, 24, 2).shape[0]) for x in wl["ref"][0]]
+    assert np.array_equal(got["n_valid"], ref["n_valid"]) and got["n_valid"].tolist() == n_oracle
     np.testing.assert_array_equal(got["instance_peaks"], ref["instance_peaks"])
     labels = pred.predict(wl["frames"])  # make_labels=True, the reference's default: 3 labeled frames with 8 instances each
-    assert len(labels) == 3 and all(len(lf.instances) == 8 for lf in labels)
+    assert len(labels) == 3 and [len(lf.instances) for lf in labels] == n_oracle
