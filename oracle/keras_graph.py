@@ -24,7 +24,7 @@ import torch.nn.functional as F
 
 
 def load_npz_model(path):
-    """Read the `.npz` written by tools/h5_extract.py -> (model_config dict, {layer/weight: array})."""
+    """Read the `.npz` written by sleap_amd/nn/_h5_extract.py -> (model_config dict, {layer/weight: array})."""
     z = np.load(path)
     cfg = json.loads(bytes(z["__model_config__"]).decode("utf-8"))
     weights = {k: z[k] for k in z.files if k != "__model_config__"}

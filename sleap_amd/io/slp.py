@@ -17,13 +17,12 @@ order (matches first, then new tracks) is the order of the frame's instances, ev
 `track` indexes the list of tracks in order of first appearance, metadata JSON in the layout of
 `Labels.to_dict(skip_labels=True)`.
 
-HDF5 itself is written by h5py: in-process when importable, else by `tools/slp_io.py` under the interpreter named by
+HDF5 itself is written by h5py: in-process when importable, else by `sleap_amd/io/_slp_io.py` (a self-contained file of the package) under the interpreter named by
 SLEAP_AMD_H5_PYTHON (default /opt/conda/bin/python3.9), exactly like `model_io` reads `best_model.h5`.
 """
 import json
 import os
 import subprocess
-import sys
 import tempfile
 from typing import Dict, List, Optional, Sequence
 
@@ -155,7 +154,7 @@ def _h5_python() -> str:
 
 
 def _tool() -> str:
-    return os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tools", "slp_io.py")
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "_slp_io.py")
 
 
 def write_tables(filename: str, t: Dict[str, np.ndarray], part_names: Sequence[str], edges: Sequence[Sequence[int]],
@@ -180,12 +179,9 @@ def write_tables(filename: str, t: Dict[str, np.ndarray], part_names: Sequence[s
         try:
             import h5py  # noqa: F401
 
-            sys.path.insert(0, os.path.dirname(_tool()))
-            try:
-                import slp_io
-            finally:
-                sys.path.pop(0)
-            slp_io.write(npz, filename)
+            from . import _slp_io
+
+            _slp_io.write(npz, filename)
         except ImportError:
             subprocess.run([_h5_python(), _tool(), "write", npz, filename], check=True)
 
@@ -210,12 +206,9 @@ def read_slp(filename: str) -> Dict[str, np.ndarray]:
         try:
             import h5py  # noqa: F401
 
-            sys.path.insert(0, os.path.dirname(_tool()))
-            try:
-                import slp_io
-            finally:
-                sys.path.pop(0)
-            slp_io.read(filename, npz)
+            from . import _slp_io
+
+            _slp_io.read(filename, npz)
         except ImportError:
             subprocess.run([_h5_python(), _tool(), "read", filename, npz], check=True)
         z = np.load(npz, allow_pickle=False)

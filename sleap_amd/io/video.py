@@ -109,7 +109,7 @@ class HDF5Video:
             self._d = self._f[dataset]
         except ImportError:
             # no h5py in this interpreter: the frames dataset is copied ONCE to a memory-mapped .npy next to the file by
-            # tools/slp_io.py under the interpreter that has h5py (SLEAP_AMD_H5_PYTHON), as model_io does for best_model.h5
+            # sleap_amd/io/_slp_io.py under the interpreter that has h5py (SLEAP_AMD_H5_PYTHON), as model_io does for best_model.h5
             import subprocess
 
             from .slp import _h5_python, _tool

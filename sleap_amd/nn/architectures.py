@@ -47,8 +47,13 @@ def build_unet_model_config(input_shape: Tuple[int, int, int], filters: int = 16
                             up_interpolate: bool = True, stem_stride: Optional[int] = None,
                             heads: Sequence[Tuple[str, int, int]] = (), stacks: int = 1, stem_kernel_size: int = 7,
                             stem_blocks: Optional[int] = None, down_blocks: Optional[int] = None,
-                            up_blocks: Optional[int] = None) -> Tuple[dict, Dict[str, tuple]]:
+                            up_blocks: Optional[int] = None,
+                            legacy_head_suffix: bool = False) -> Tuple[dict, Dict[str, tuple]]:
     """`heads` = [(head_class_name, channels, output_stride), ...] in model-output order.
+
+    Heads on a stacked backbone: Model.make_model (model.py:336-359) makes one head per stack output with the SAME layer name,
+    which Keras rejects for stacks > 1 -- the same ValueError is raised here. `legacy_head_suffix=True` names the head of stack
+    s `<head>_<s>` instead (one output per head and stack, stack-major inside a head), as build_hourglass_model_config does.
 
     `stem_stride` / `max_stride` / `output_stride` / `stacks` are UNetConfig's fields (UNet.from_config, unet.py:250-278:
     stem_blocks = log2(stem_stride), down_blocks = log2(max_stride) - stem_blocks, up_blocks = log2(max_stride / output_stride),
@@ -105,6 +110,7 @@ def build_unet_model_config(input_shape: Tuple[int, int, int], filters: int = 16
         stem_skip = (stride, x, cur_c)
     stem_out_stride = stride
     stack_outs = []
+    mids_per_stack = []
     for st in range(stacks):
         # ---- encoder (unet.py:136-205; SimpleConvBlock.make_block encoder_decoder.py:92-144)
         prefix = f"stack{st}_enc"
@@ -143,6 +149,7 @@ def build_unet_model_config(input_shape: Tuple[int, int, int], filters: int = 16
             x = _relu(g, x, f"{name}_act0_relu")
         # ---- decoder (unet.py:207-247; SimpleUpsamplingBlock.make_block encoder_decoder.py:275-399)
         mids = {stride: (x, cur_c)}
+        mids_per_stack.append(mids)
         for block in range(up_blocks):
             f = int(filters * (filters_rate ** (down_blocks + stem_blocks - 1 - block)))
             nxt = stride // 2
@@ -171,12 +178,14 @@ def build_unet_model_config(input_shape: Tuple[int, int, int], filters: int = 16
     # ---- heads (model.py:336-359): main output if strides match, else the decoder feature of that stride
     outs = []
     for head_name, channels, hs in heads:
-        if hs not in mids:
-            raise ValueError(f"Could not find a feature activation for output at stride {hs}.")
-        src, sc = mids[hs]
-        shapes[f"{head_name}/kernel"] = (1, 1, sc, int(channels))
-        shapes[f"{head_name}/bias"] = (int(channels),)
-        outs.append(_conv(g, src, head_name, channels, k=1))
+        for si in (range(stacks) if legacy_head_suffix else [stacks - 1]):
+            if hs not in mids_per_stack[si]:
+                raise ValueError(f"Could not find a feature activation for output at stride {hs}.")
+            src, sc = mids_per_stack[si][hs]
+            name = f"{head_name}_{si}" if legacy_head_suffix else head_name
+            shapes[f"{name}/kernel"] = (1, 1, sc, int(channels))
+            shapes[f"{name}/bias"] = (int(channels),)
+            outs.append(_conv(g, src, name, channels, k=1))
     if not heads:  # a backbone graph (what the architecture tests build): the stack outputs
         outs = stack_outs if stacks > 1 else stack_outs[:1]
     cfg = {"class_name": "Functional",

@@ -114,6 +114,7 @@ class DeviceNetwork:
         self._pending_scan = None   # (largest finite value, inf / NaN seen) of forwards under torch.distributed, until the ranks agree
         self._pending_imgs = None
         self._dist_agreed = False
+        self._dist_defer = False    # defer_range_agreement(): the caller promised a dist_agree_range() on every rank
         self._preset_scales = dict(range_log2_scale) if range_log2_scale else None
         self.model_config = model_config
         # layout of the 16-bit activation tensors: None = 16-channel planes when every launch of the compiled plan supports
@@ -783,6 +784,10 @@ class DeviceNetwork:
             if any(o is c.out or (y is not None and o is x.out and False) for o in out_tensors):
                 continue
             drop.add(id(c))
+            # C's activation never reaches HBM: no workspace tensor (it was still allocated, zeroed and range-scanned -- ~134 MB
+            # per fused block at 1024 x 1024, 16 frames). The plan encoder gives it a shape-only entry (`bid`).
+            self.buf_meta.pop(c.out.buf, None)
+            c.out.buf = None
             if y is not None:
                 drop.add(id(y))
             repl[id(x)] = ["bneck", c, x, y, self._pointwise_from_tap(x.w, x.src0.cp, x.out.cp),
@@ -1437,9 +1442,10 @@ class DeviceNetwork:
     #     fits (finite, <= range / 4)                      -> nothing happens, the plan stays bit for bit what it was
     #     does not fit, range_safe, not yet scaled         -> calibrate on THIS batch (all of its frames), fold, re-compile, re-run
     #     does not fit and (scaling off | already scaled)  -> inf / NaN seen: FloatingPointError; finite: a warning
-    #   under torch.distributed (world > 1) NOTHING is decided in here (a collective inside forward() would deadlock: shard sizes
-    #   differ, empty shards skip the network): the scan is recorded and the predictor calls `dist_agree_range` on EVERY rank once,
-    #   after the first global batch -- scan results and, if needed, per-layer ranges are MAX-reduced there, so all ranks fold the
+    #   under torch.distributed (world > 1) NOTHING is rescaled in here (a collective inside forward() would deadlock: shard sizes
+    #   differ, empty shards skip the network). Without a promise an overflow raises at once; after `defer_range_agreement()` (the
+    #   predictors, bench.py) the scan is recorded and the caller runs `dist_agree_range` on EVERY rank once, after the first
+    #   global batch -- scan results and, if needed, per-layer ranges are MAX-reduced there, so all ranks fold the
     #   same exponents (ranks must run numerically identical networks) and nothing is rescaled implicitly afterwards.
     #   Deterministic alternative: `calibrate_range(frames)` right after loading, or `range_log2_scale=` (persisted exponents).
     def _range_gate(self, bufs, imgs) -> bool:
@@ -1451,18 +1457,43 @@ class DeviceNetwork:
 
         if dist_world() > 1:
             # frame-sharded run: NO collective in here (ranks see different shapes, empty shards skip the network: "first batch
-            # of a shape" is not a common event and a collective would deadlock). The scan is recorded; the predictor lets all
-            # ranks agree once, at one program point (`dist_agree_range`). Until then, and afterwards, nothing is rescaled
-            # implicitly: ranks must run numerically identical networks.
+            # of a shape" is not a common event and a collective would deadlock), and nothing is rescaled implicitly: ranks
+            # must run numerically identical networks.
+            if self._dist_agreed:
+                if nonfinite:
+                    self._range_checked = False
+                    raise FloatingPointError(
+                        f"activations left the range of fp16 storage (65504) in plan tensor {where} after the ranks agreed on their "
+                        "range scales: call calibrate_range() on representative frames (or load the model with dtype='bf16')")
+                return False
+            if not self._dist_defer:
+                # nobody promised an agreement (a custom loop, a tool, DeviceNetwork.forward called directly inside an
+                # initialised process group): an overflow is an error HERE, as without range scaling
+                if nonfinite:
+                    self._range_checked = False
+                    raise FloatingPointError(
+                        f"activations left the range of fp16 storage (65504) in plan tensor {where} inside an initialised process "
+                        "group, where range scales are never chosen implicitly: call calibrate_range() on the same frames on every "
+                        "rank, or defer_range_agreement() before the first forward and dist_agree_range() on EVERY rank after it "
+                        "(the predictors do), or load the model with dtype='bf16'")
+                if worst > 65504.0 / 4:
+                    import warnings
+
+                    warnings.warn(f"fp16 storage: the largest activation of the first batch is {worst:.0f}, within 4x of the "
+                                  "format's range (65504); consider calibrate_range() or dtype='bf16' for this model")
+                return False
+            # deferred mode (the predictors, bench.py): the scan is recorded and all ranks agree once, at one program point
+            # (`dist_agree_range`). A SECOND scan that arrives while an overflow is still waiting for that agreement means the
+            # promise was not kept: raise instead of handing out overflowed results batch after batch.
             pw, pn = self._pending_scan or (0.0, False)
-            self._pending_scan = (max(worst, pw), nonfinite or pn)
-            if not self._dist_agreed:
-                self._pending_imgs = imgs  # (one batch kept until the ranks have agreed: what this rank would calibrate on)
-            if self._dist_agreed and nonfinite:
+            if pn and self._pending_scan is not None:
                 self._range_checked = False
                 raise FloatingPointError(
-                    f"activations left the range of fp16 storage (65504) in plan tensor {where} after the ranks agreed on their range "
-                    "scales: call calibrate_range() on representative frames (or load the model with dtype='bf16')")
+                    "activations left the range of fp16 storage (65504) on an earlier batch and dist_agree_range() was not called "
+                    "since (defer_range_agreement() promises one call on every rank after the first global batch)")
+            self._pending_scan = (max(worst, pw), nonfinite or pn)
+            if self._pending_imgs is None:
+                self._pending_imgs = imgs  # (ONE batch kept until the ranks have agreed: what this rank would calibrate on)
             return False
         if not nonfinite and worst <= 65504.0 / 4:
             return False
@@ -1505,6 +1536,19 @@ class DeviceNetwork:
         del twin
         return ranges, aliases
 
+    def defer_range_agreement(self, on: bool = True) -> None:
+        """Frame-sharded runs: promise that EVERY rank calls `dist_agree_range()` once after the first global batch. Until then
+        the range gate only records its scan (no exception, no rescaling); without this promise an overflow inside an
+        initialised process group raises at once. No effect without a process group."""
+        self._dist_defer = bool(on)
+
+    def reset_pending_range(self) -> None:
+        """Forget the scan / batch recorded for the agreement and scan the next forward again (a network fed by another
+        network that was just re-compiled: what it saw so far came from overflowed inputs)."""
+        self._pending_scan = None
+        self._pending_imgs = None
+        self._range_checked = False
+
     def dist_agree_range(self, imgs: Optional[torch.Tensor] = None) -> bool:
         """Frame-sharded runs (torch.distributed, world > 1): EVERY rank calls this once, at the same program point -- the
         predictors do after the first global batch. `imgs` = the network input this rank would calibrate on (default: the batch
@@ -1540,6 +1584,8 @@ class DeviceNetwork:
         ks = RS.dist_agree(self._pending_scan if has else None, self.range_log2_scale is not None, self.range_safe, keys,
                            measure if has else None, lambda r: RS.plan_scales(self.model_config, r, aliases_box.get("a")), self.device)
         self._dist_agreed = True
+        self._dist_defer = False
+        self._pending_scan = None
         self._range_calibrated = True  # from here on the exponents are every rank's: never changed implicitly
         if ks:
             self._install_scales(ks)
@@ -1650,7 +1696,7 @@ class DeviceNetwork:
 
 
 def load_keras_npz(path):
-    """Read a model extracted by tools/h5_extract.py -> (model_config, weights)."""
+    """Read a model extracted by sleap_amd/nn/_h5_extract.py -> (model_config, weights)."""
     z = np.load(path)
     cfg = json.loads(bytes(z["__model_config__"]).decode("utf-8"))
     return cfg, {k: z[k] for k in z.files if k != "__model_config__"}

@@ -262,6 +262,12 @@ class InferenceModel:
     def call(self, example):  # overridden
         raise NotImplementedError
 
+    def export_model(self, save_path: str, signatures: str = "serving_default", save_traces: bool = True,
+                     model_name: Optional[str] = None, tensors: Optional[Dict[str, str]] = None, unrag_outputs: bool = True):
+        """inference.py:1092-1171 (`InferenceModel.export_model`): see `Predictor.export_model` -- out of scope here."""
+        raise NotImplementedError("out of scope: TF SavedModel / frozen-graph export (InferenceModel.export_model, "
+                                  "sleap/nn/inference.py:1092); the model folder is the deployable artefact of sleap_amd")
+
     def __call__(self, example):
         return self.call(example)
 
@@ -1058,6 +1064,9 @@ class Predictor:
         frames = self._frames_of(data)
         n = len(frames)
         rank, world = parallel.rank_world()
+        if world > 1 and hasattr(self.inference_model, "_device_networks"):
+            for net in self.inference_model._device_networks():
+                net.defer_range_agreement()  # kept in submit(): dist_agree_range() after the first global batch, on every rank
         small = {"instance_peaks", "instance_peak_vals", "instance_scores", "n_valid", "centroids", "centroid_vals", "status", "_input"}
         from ..io.video import Video, VideoReader
 
@@ -1135,9 +1144,16 @@ class Predictor:
                     if world > 1 and i0 == 0:
                         # fp16 range scales of a frame-sharded run: every rank (empty shards included) passes here exactly once,
                         # after the first global batch -- the networks agree on their exponents (DeviceNetwork.dist_agree_range)
+                        # Network by network: when an earlier network (the centroid model) is re-compiled, what the
+                        # later ones (the centred-instance model) saw so far came from its overflowed outputs -- they forget it,
+                        # the batch runs again, and only then are they asked to agree.
                         nets = self.inference_model._device_networks() if hasattr(self.inference_model, "_device_networks") else []
-                        if any([net.dist_agree_range() for net in nets]) and hi > lo:
-                            dev = self.inference_model.predict_on_batch(batch, numpy=False)  # re-compiled plans: run the batch again
+                        for k, net in enumerate(nets):
+                            if net.dist_agree_range():
+                                for later in nets[k + 1:]:
+                                    later.reset_pending_range()
+                                if hi > lo:  # re-compiled plan: run the batch again
+                                    dev = self.inference_model.predict_on_batch(batch, numpy=False)
                     pre = None
                     if dev is not None and not set(dev) <= small:
                         # maps / crops may alias network buffers that the next batch overwrites: convert before anything else runs
@@ -1228,6 +1244,17 @@ class Predictor:
         tn = self.tracker.spawned_tracks if self.tracker and hasattr(self.tracker, "spawned_tracks") else None
         return Labels.from_predictions(outs, names, edges, video=video, track_names=tn,
                                        max_instances=getattr(self, "max_instances", None))
+
+    def export_model(self, save_path: str, signatures: str = "serving_default", save_traces: bool = True,
+                     model_name: Optional[str] = None, tensors: Optional[Dict[str, str]] = None, unrag_outputs: bool = True,
+                     max_instances: Optional[int] = None):
+        """inference.py:533-591 (and the per-predictor overrides, :1615, :2707, :4196): exports the Keras model as a frozen
+        TensorFlow graph for TF-Serving-style deployments. Present so that the attribute path of the reference exists; there is no
+        TensorFlow graph on this path to freeze (SURVEY.md section 2 marks export out of scope)."""
+        raise NotImplementedError(
+            "out of scope: TF SavedModel / frozen-graph export (Predictor.export_model, sleap/nn/inference.py:533). The model folder "
+            "(training_config.json + best_model.h5) IS the deployable artefact of sleap_amd: load it with sleap_amd.nn.inference."
+            "load_model(path); use the reference's own `sleap-export` for a TensorFlow graph.")
 
     def save_predictions(self, filename: str, outs: List[Dict[str, np.ndarray]], video: Optional[dict] = None,
                          part_names: Optional[List[str]] = None, edges=None):
@@ -1509,6 +1536,8 @@ class BottomUpPredictor(Predictor):
         image_hw = np.asarray(reader.video.shape[1:3], np.int64)  # raw frame size (tracker similarities; present on every rank)
         layer = self.inference_model.bottomup_layer
         rank, world = parallel.rank_world()
+        if world > 1 and hasattr(layer.keras_model, "defer_range_agreement"):
+            layer.keras_model.defer_range_agreement()  # kept below: dist_agree_range() after the first global batch, on every rank
         batches = [(i0, min(i0 + self.batch_size, n)) for i0 in range(0, n, self.batch_size)]
         mine = [parallel.shard_range(i0, i1, rank, world) for i0, i1 in batches]
         # This rank's frames are read ahead by a producer thread into page-locked buffers (sleap_amd/io/video.py). The loop is a

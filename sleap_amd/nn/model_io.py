@@ -1,8 +1,8 @@
 """Reading SLEAP model folders: `training_config.json` + `best_model.h5` (inference.py:132-144, 3204-3209).
 
 The config is consumed as plain JSON (fields listed in SURVEY.md §8b). The Keras HDF5 is read with
-h5py when the running interpreter has it; otherwise `tools/h5_extract.py` is run once under an
-interpreter that does (env `SLEAP_AMD_H5_PYTHON`, default /opt/conda/bin/python3.9) and the result is
+h5py when the running interpreter has it; otherwise `sleap_amd/nn/_h5_extract.py` (part of the package: no
+repository checkout needed) is run once under an interpreter that does (env `SLEAP_AMD_H5_PYTHON`, default /opt/conda/bin/python3.9) and the result is
 cached as `best_model.npz` next to the HDF5 (or in `$SLEAP_AMD_CACHE` if the folder is read-only).
 A pre-extracted `best_model.npz` in the folder is used directly.
 """
@@ -12,7 +12,6 @@ import math
 import os
 import re
 import subprocess
-import sys
 from typing import Dict, Tuple
 
 import numpy as np
@@ -85,22 +84,22 @@ def load_keras_model(folder: str) -> Tuple[dict, Dict[str, np.ndarray]]:
     if stale or not os.path.exists(npz):
         if not os.path.exists(h5):
             raise FileNotFoundError(f"neither best_model.h5 nor best_model.npz in {folder}")
-        tools = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "tools")
-        sys.path.insert(0, tools)
+        target = _cache_path(folder, h5)
         try:
-            try:
-                import h5py  # noqa: F401
-                from h5_extract import extract
+            import h5py  # noqa: F401
+        except ImportError:
+            script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_h5_extract.py")
+            py = _h5_python()
+            if not os.path.exists(py):
+                raise ImportError(f"reading {h5} needs h5py: not importable here, and SLEAP_AMD_H5_PYTHON ({py}) does not exist -- "
+                                  "install h5py, point SLEAP_AMD_H5_PYTHON at an interpreter that has it, or put a pre-extracted "
+                                  "best_model.npz (python sleap_amd/nn/_h5_extract.py best_model.h5 best_model.npz) beside it")
+            subprocess.check_call([py, script, h5, target])
+        else:
+            from ._h5_extract import extract
 
-                target = _cache_path(folder, h5)
-                extract(h5, target)
-                npz = target
-            except ImportError:
-                target = _cache_path(folder, h5)
-                subprocess.check_call([_h5_python(), os.path.join(tools, "h5_extract.py"), h5, target])
-                npz = target
-        finally:
-            sys.path.remove(tools)
+            extract(h5, target)
+        npz = target
     z = np.load(npz)
     cfg = json.loads(bytes(z["__model_config__"]).decode("utf-8"))
     return cfg, {k: z[k] for k in z.files if k != "__model_config__"}

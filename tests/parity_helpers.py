@@ -1,5 +1,14 @@
 """Shared comparison of a device bottom-up result with the oracle's when the maps hold borderline local maxima."""
+import os
+
 import numpy as np
+
+# Storage types the parametrised GPU tests run. fp16 is the product default; the bf16 build (fp32's range, 8 mantissa bits) is
+# still compiled -- the range calibration's measuring twin runs on it -- and keeps ONE end-to-end case
+# (test_gpu_benchmark_parity.py: identical instances, 0.64 px worst peak = why it is not the default) plus the fp16-vs-bf16
+# characterisation tests; the layer / pin / persistence parametrisations only add it under SLEAP_AMD_DTYPE=bf16 or
+# SLEAP_AMD_TEST_BF16=1 (a mode INTEGRATION.md tells users not to use doubled the GPU suite's pin tests).
+STORAGE_DTYPES = ["fp16"] + (["bf16"] if (os.environ.get("SLEAP_AMD_DTYPE") == "bf16" or os.environ.get("SLEAP_AMD_TEST_BF16") == "1") else [])
 
 
 def compare_with_threshold_decisions(oracle_peaks, device_peaks, ref, o, n_nodes, map_eps, tol_px, threshold=0.2, cms=None,

@@ -149,6 +149,26 @@ def test_hourglass_heads_and_errors():
         build_hourglass_model_config((128, 128, 1), stem_stride=4, max_stride=64, output_stride=8, stacks=2)
 
 
+def test_stacked_unet_heads_and_errors():
+    """A stacked UNet with heads: Keras' duplicate-layer-name ValueError (model.py:336-359 names every stack's head alike);
+    `legacy_head_suffix=True` gives one `<head>_<s>` output per stack (this used to be a NameError)."""
+    from sleap_amd.nn.architectures import build_unet_model_config
+
+    kw = dict(filters=8, stacks=2, down_blocks=2, up_blocks=2)
+    with pytest.raises(ValueError, match="used 2 times"):
+        build_unet_model_config((64, 64, 1), heads=[("H", 3, 1)], **kw)
+    cfg, shapes = build_unet_model_config((64, 64, 1), heads=[("H", 3, 1), ("P", 4, 2)], legacy_head_suffix=True, **kw)
+    assert [o[0] for o in cfg["config"]["output_layers"]] == ["H_0", "H_1", "P_0", "P_1"]
+    by = {l["name"]: l for l in cfg["config"]["layers"]}
+    assert by["H_0"]["inbound_nodes"][0][0][0].startswith("stack0_dec1")
+    assert by["H_1"]["inbound_nodes"][0][0][0].startswith("stack1_dec1")
+    assert by["P_1"]["inbound_nodes"][0][0][0].startswith("stack1_dec0")
+    assert shapes["H_1/kernel"] == (1, 1, 8, 3) and shapes["P_0/kernel"] == (1, 1, 16, 4)
+    # one stack: unchanged, unsuffixed
+    cfg1, _ = build_unet_model_config((64, 64, 1), filters=8, down_blocks=2, up_blocks=2, heads=[("H", 3, 1)])
+    assert [o[0] for o in cfg1["config"]["output_layers"]] == ["H"]
+
+
 def _counts(cfg, shapes):
     tr = {k: v for k, v in shapes.items() if not k.endswith(("/moving_mean", "/moving_variance"))}
     return (len(cfg["config"]["layers"]), len(tr), sum(int(np.prod(v)) for v in tr.values()),

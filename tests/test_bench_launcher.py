@@ -34,6 +34,11 @@ def test_gpus_2_self_launches_two_ranks_and_gathers_in_rank_order():
     d = lines[0]
     assert d["n_gpus"] == 2 and d["config"]["n_ranks_seen"] == 2 and d["config"]["collective_backend"] == "gloo"
     assert d["rows_in_rank_order"] and d["config"]["global_batch"] == 128
+    # both readings of "batch = 64 over N GPUs" are in the ONE line under explicit names: `value` is the
+    # weak curve (64 frames per GPU), the configs[3]-literal global batch of 64 rides beside it
+    assert d["scaling"] == "weak" and d["value_weak_64_per_gpu"] is not None and d["value_strong_global_batch_64"] is not None
+    lit = d["configs3_global_batch_64"]
+    assert lit["frames_per_gpu_per_step"] == 32 and lit["global_batch"] == 64 and lit["scaling"] == "strong" and lit["rows_in_rank_order"]
 
 
 def test_global_batch_is_split_over_the_ranks():
@@ -65,6 +70,7 @@ def test_literal_configs3_split_8_ranks_of_8_frames():
     d = lines[0]
     assert d["n_gpus"] == 8 and d["config"]["n_ranks_seen"] == 8 and d["scaling"] == "strong"
     assert d["config"]["frames_per_gpu_per_step"] == 8 and d["config"]["global_batch"] == 64 and d["rows_in_rank_order"]
+    assert d["value_strong_global_batch_64"] is not None and d["value_weak_64_per_gpu"] is None
 
 
 def test_stdout_carries_only_the_json_line_even_when_c_code_prints(tmp_path):

@@ -226,7 +226,18 @@ def _dist_range_worker(rank, world, port, q):
         x = torch.from_numpy(render_frames(2, 128, 128, n_animals=2, seed=1)[0]).cuda()
         first_finite = None
         if rank == 0:
-            outs = net.forward(x)  # under a process group the gate only RECORDS: no collective, nothing rescaled yet
+            # nobody promised an agreement: an overflow inside a process group is an error at once, nothing is rescaled
+            lone = DeviceNetwork(mc, w, dtype="fp16")
+            try:
+                lone.forward(x)
+                raised = False
+            except FloatingPointError as e:
+                raised = "defer_range_agreement" in str(e)
+            assert raised and lone.range_log2_scale is None
+            del lone
+        net.defer_range_agreement()  # what the predictors do before their first forward
+        if rank == 0:
+            outs = net.forward(x)  # deferred: the gate only RECORDS -- no collective, nothing rescaled yet
             first_finite = bool(all(torch.isfinite(o).all() for o in outs))
             assert net.range_log2_scale is None and net._pending_scan is not None
         changed = net.dist_agree_range()  # every rank, once, the same program point

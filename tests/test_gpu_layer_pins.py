@@ -51,7 +51,7 @@ def _run(mc, w, x, dtype):
     return [o.cpu().numpy() for o in outs]
 
 
-DTYPES = ["fp16", "bf16"]
+from parity_helpers import STORAGE_DTYPES as DTYPES  # noqa: E402  (fp16; + bf16 under SLEAP_AMD_TEST_BF16=1)
 
 
 def _convt_graph(k, cin, cout):

@@ -14,6 +14,8 @@ import os
 import numpy as np
 import pytest
 
+from parity_helpers import STORAGE_DTYPES  # noqa: E402
+
 from test_oracle_network_pin import MODEL, oracle_robot_predictions, robot_golden
 
 pytestmark = pytest.mark.gpu
@@ -21,7 +23,7 @@ pytestmark = pytest.mark.gpu
 TOL_PX = 0.5  # BASELINE.json north_star: "peak coordinates within +-0.5 px"
 
 
-@pytest.mark.parametrize("dtype", ["fp16", "bf16"])
+@pytest.mark.parametrize("dtype", STORAGE_DTYPES)
 @pytest.mark.parametrize("batch_size", [4, 2])
 def test_robot_frames_end_to_end_within_half_pixel(dtype, batch_size):
     from sleap_amd.nn.inference import SingleInstancePredictor, load_model
@@ -48,7 +50,7 @@ def test_robot_frames_end_to_end_within_half_pixel(dtype, batch_size):
                 np.testing.assert_allclose(got[f, 0, n], gt[0, n], atol=10.0)
 
 
-@pytest.mark.parametrize("dtype", ["fp16", "bf16"])
+@pytest.mark.parametrize("dtype", STORAGE_DTYPES)
 def test_robot_confidence_maps_vs_oracle(dtype):
     """The maps themselves (return_confmaps=True) against the fp32 oracle: the network half in isolation."""
     from sleap_amd.nn.inference import load_model

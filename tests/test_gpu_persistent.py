@@ -8,6 +8,8 @@ import ctypes as C
 
 import numpy as np
 import pytest
+
+from parity_helpers import STORAGE_DTYPES  # noqa: E402
 import torch
 
 pytestmark = pytest.mark.gpu
@@ -27,7 +29,7 @@ def grid_limit():
     set_(0)
 
 
-@pytest.mark.parametrize("dtype", ["fp16", "bf16"])
+@pytest.mark.parametrize("dtype", STORAGE_DTYPES)
 @pytest.mark.parametrize("B,H,W,C0,C1,Cout,mode,pooled", [
     (3, 48, 96, 32, 0, 64, 0, True),     # 2 chunks, 27 tiles, pooled + full
     (2, 40, 70, 64, 0, 64, 0, False),    # 4 chunks, ragged right/bottom tiles
@@ -64,7 +66,7 @@ def test_persistent_schedule_is_bitwise_neutral(grid_limit, dtype, B, H, W, C0, 
             assert torch.equal(a.view(torch.int16), b.view(torch.int16)), f"grid limit {n} of {n_tiles} tiles"
 
 
-@pytest.mark.parametrize("dtype", ["fp16", "bf16"])
+@pytest.mark.parametrize("dtype", STORAGE_DTYPES)
 def test_persistent_network_forward_is_bitwise_neutral(grid_limit, dtype):
     """The benchmark UNet (fused stem / pair / heads included) at a small size: heads identical for every schedule."""
     from sleap_amd.nn.architectures import build_unet_model_config, he_normal_weights

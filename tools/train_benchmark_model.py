@@ -19,7 +19,7 @@ machine/torch build. The targets are the reference's own training targets for th
 
 The stored weights are rounded to fp16-representable values (the fp32 oracle and the fp16-storage device path then hold
 IDENTICAL weights; only activation rounding separates them) and saved as float16 arrays + the Keras-style graph JSON, the
-same layout tools/h5_extract.py writes for a real `best_model.h5`.
+same layout sleap_amd/nn/_h5_extract.py writes for a real `best_model.h5`.
 """
 import argparse
 import json
