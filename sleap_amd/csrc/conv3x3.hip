@@ -31,6 +31,34 @@ namespace {
 
 int g_grid_limit = 0;  // sa_conv3x3_set_grid_limit
 
+// SA_CONV_STAMP (an instrumented A/B build, tools/stall_probe.py -- never the product library): every wave of
+// conv3x3_dma_kernel sums, in scalar registers, the shader cycles (s_memtime) it spends in five segments of its life -- tile
+// prologue (entry / previous epilogue -> the first chunk's wait), the `s_waitcnt vmcnt` in front of a chunk, the workgroup
+// barrier behind it, the chunk body (nine taps of MFMAs + the next chunk's copy instructions), the epilogue -- and adds them to
+// g_stamp at its end: [0] waves, [1] prologue, [2] vmcnt wait, [3] barrier, [4] chunk body, [5] epilogue, [6] whole wave, [7] chunks.
+#if defined(SA_CONV_STAMP)
+__device__ unsigned long long g_stamp[8];
+#define SA_STAMP_DECL unsigned long long st_t = __builtin_readcyclecounter(), st_t0 = st_t, st_pro = 0, st_vm = 0, st_bar = 0, st_body = 0, st_epi = 0, st_n = 0
+#define SA_STAMP(acc)                                        \
+  do {                                                       \
+    const unsigned long long st_now = __builtin_readcyclecounter(); \
+    acc += st_now - st_t;                                    \
+    st_t = st_now;                                           \
+  } while (0)
+#define SA_STAMP_FLUSH                                                            \
+  do {                                                                            \
+    if ((threadIdx.x & 63) == 0) {                                                \
+      atomicAdd(&g_stamp[0], 1ull), atomicAdd(&g_stamp[1], st_pro), atomicAdd(&g_stamp[2], st_vm); \
+      atomicAdd(&g_stamp[3], st_bar), atomicAdd(&g_stamp[4], st_body), atomicAdd(&g_stamp[5], st_epi); \
+      atomicAdd(&g_stamp[6], __builtin_readcyclecounter() - st_t0), atomicAdd(&g_stamp[7], st_n); \
+    }                                                                             \
+  } while (0)
+#else
+#define SA_STAMP_DECL
+#define SA_STAMP(acc)
+#define SA_STAMP_FLUSH
+#endif
+
 using sa::h16x8_t;
 using sa::mfma_h8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
@@ -331,7 +359,14 @@ __device__ __forceinline__ int swz(int p) {
 #if !defined(SA_CONV_EXT_WG2)
 #define SA_CONV_EXT_WG2 1
 #endif
-template <int MT, int CK, int NW, int R, int NBUF, bool HEADS, int STEM_CIN, bool EXT, bool UPS, int ITAP, bool XP = false>
+// PERS (round 5): the persistent tile loop for the TWO-workgroups-per-CU kernels (MT <= 2, plain epilogue). Round 2 measured that
+// loop 1-9 % SLOWER there because the wait in front of a tile's first chunk -- `s_waitcnt vmcnt(0)` -- also waited for the previous
+// tile's epilogue STORES (gfx9 counts loads and stores in one counter). The counter retires IN ORDER, though (LLVM's gfx9 model
+// treats VMEM loads and stores as one in-order event type and emits counted waits across them), and the next tile's first-chunk
+// copies are queued BEFORE the epilogue's stores: `s_waitcnt vmcnt(S)` with S = the number of store instructions this wave issued
+// after them waits for exactly the copies. What else would touch the counter at a tile boundary is moved off it: the bias comes
+// from LDS (staged once per workgroup) instead of global loads at every tile's start.
+template <int MT, int CK, int NW, int R, int NBUF, bool HEADS, int STEM_CIN, bool EXT, bool UPS, int ITAP, bool XP = false, bool PERS = false>
 __global__ void __launch_bounds__(NW * 64, (NW == 8 && MT <= 2 && NBUF == 2 && (!EXT || SA_CONV_EXT_WG2) && CK == 16 && STEM_CIN == 0 && !XP) ? 4 : 1)
 conv3x3_dma_kernel(const ConvParams2 p) {
 #if defined(__HIP_DEVICE_COMPILE__)  // the body uses device-only types (buffer resources); the host pass only needs the stub
@@ -360,12 +395,15 @@ conv3x3_dma_kernel(const ConvParams2 p) {
                 "UPS: 16-channel chunks, two stages, plain epilogue");
   static_assert(!UPS || (LOW_NB > 0 && LOW_NB <= 64 && LOW_NC > 0 && LOW_NC <= LOW_NB), "UPS: the low tile's three segments");
   static_assert(!UPS || ((PH / 2) * (PW / 2) * 2 <= NW * 64 && PH % 2 == 0 && PW % 2 == 0), "UPS: one 2x2 block and half per thread");
+  static_assert(!PERS || (NBUF == 2 && STEM_CIN == 0 && !EXT && !HEADS && !UPS && !XP && CK == 16 && MT <= 2 && R == 2),
+                "PERS: the plain double-buffered 16-channel-chunk kernels");
   // LDS byte address of piece q of the low-resolution tile
   auto low_addr = [&](int q) -> int {
     return q < LOW_NA ? LOW_A + q * 16 : (q < LOW_NA + LOW_NB ? LOW_B + (q - LOW_NA) * 16 : LOW_C + (q - LOW_NA - LOW_NB) * 16);
   };
   (void)low_addr;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  SA_STAMP_DECL;
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -509,6 +547,9 @@ conv3x3_dma_kernel(const ConvParams2 p) {
   // Multi-chunk kernels (NBUF == 2) start the accumulators at the bias (the loads hide behind the first copy, the
   // epilogue saves one add per value); single-chunk kernels are latency-bound on their prologue and add it at the end.
   constexpr bool BIAS_INIT = (NBUF == 2);
+  float* lds_bias = reinterpret_cast<float*>(smem + NBUF * STAGE);  // PERS only
+  const unsigned lds_bias_addr = (unsigned)(uintptr_t)(lds_ptr_t)(smem + NBUF * STAGE);
+  (void)lds_bias, (void)lds_bias_addr;
   f32x16 acc[MT][R];
   auto init_acc = [&](const Tile& t) {
     int ln_i = lane;
@@ -520,7 +561,19 @@ conv3x3_dma_kernel(const ConvParams2 p) {
         float4 bq = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         if constexpr (BIAS_INIT) {
           const int co = (t.co32_0 + m) * 32 + 8 * g + 4 * (ln_i >> 5);
-          if (co < p.CoutP) bq = *reinterpret_cast<const float4*>(p.bias + co);
+          if constexpr (PERS) {
+            // (an opaque ds_read: in front of a C++ load from LDS the compiler waits for EVERY outstanding VMEM operation --
+            // it cannot tell the read from the copies' LDS writes -- which would put the epilogue's stores back on the path)
+            if (t.co32_0 + m < co32_n) {  // (zero beyond CoutP)
+              typedef float f32x4v __attribute__((ext_vector_type(4)));
+              f32x4v v;
+              const unsigned a = lds_bias_addr + (unsigned)co * 4u;
+              asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(a) : "memory");
+              bq = make_float4(v[0], v[1], v[2], v[3]);
+            }
+          } else {
+            if (co < p.CoutP) bq = *reinterpret_cast<const float4*>(p.bias + co);
+          }
         }
 #pragma unroll
         for (int r = 0; r < R; ++r) {
@@ -534,7 +587,13 @@ conv3x3_dma_kernel(const ConvParams2 p) {
   };
 
   const int n_chunks = CinP / CK;
+  // PERS: the bias of EVERY output channel -> LDS behind the stages (<= 2 KiB), loaded before the first copy is queued so that the
+  // wait for these loads waits for nothing else; the barrier below orders the writes before init_acc's reads
+  if constexpr (PERS) {
+    for (int i = tid; i < co32_n * 32; i += NW * 64) lds_bias[i] = i < p.CoutP ? p.bias[i] : 0.0f;
+  }
   issue(cur, voff0, voff1, 0, 0);
+  if constexpr (PERS) __syncthreads();
   if constexpr (XP) {
     // the expand / reduce weight fragments -> LDS behind the stages: CoutX * 128 bytes each = CoutX / 8 one-KiB pieces, wave w
     // takes pieces w, w + NW, ...; they land under the K loop (every chunk waits for vmcnt(0) and meets at a barrier)
@@ -715,6 +774,8 @@ conv3x3_dma_kernel(const ConvParams2 p) {
     }
   }
   int buf = 0;
+  int stores_behind = 0;  // PERS: store instructions this wave certainly issued AFTER the copies that are in flight (wave-uniform)
+  (void)stores_behind;
   // LDS byte offsets (inside a stage) of this lane's B fragments for k-step 0: halo row wave*R + (r + dy) in 0..R+1,
   // column lane&31 + dx; one register each (left to the compiler, pixel offset and swizzled slot are kept apart: 2 x 12
   // registers, which with the tile loop around everything spills into the MFMA loop). k-step kk flips bit 1 of the slot:
@@ -740,13 +801,32 @@ conv3x3_dma_kernel(const ConvParams2 p) {
   // (0.416 -> 0.393 ms); with two workgroups per CU the other workgroup already covers that gap, and the persistent loop
   // only adds a wait for the epilogue's STORES (vmcnt counts them together with the copies) in front of every tile: 2-9 %
   // slower on every MT <= 2 layer, most on the HBM-bound 256x256 ones. Those keep one tile per workgroup.
-  constexpr bool PERSIST = (NBUF == 2) && (STEM_CIN == 0) && !EXT && (CK == 16) && (MT == 4);
+  constexpr bool PERSIST = (NBUF == 2) && (STEM_CIN == 0) && !EXT && (CK == 16) && (MT == 4 || PERS);
   const bool more = PERSIST && L_next < L_end;  // wave-uniform
   Tile nxt = cur;
 #pragma clang loop unroll(disable)
   for (int chunk = 0; chunk < n_chunks; ++chunk) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#if defined(SA_CONV_STAMP)
+    if (chunk == 0) SA_STAMP(st_pro);
+    st_n += 1;
+#endif
+    if constexpr (PERS) {
+      // first chunk of a later tile: its copies were queued before the previous tile's `stores_behind` store instructions --
+      // wait for the copies, not for the stores (in-order counter; a smaller immediate only waits for a few stores as well)
+      if (chunk == 0 && stores_behind >= 4) {  // wave-uniform
+        if (stores_behind >= 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        else if (stores_behind >= 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (stores_behind >= 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    SA_STAMP(st_vm);
     __syncthreads();
+    SA_STAMP(st_bar);
     // the copies of the next chunk: queued right after the barrier (ITAP < 0) or after tap ITAP of the MFMA sequence below
     auto prefetch = [&](int lo, int hi) {
       if constexpr (NBUF == 2) {
@@ -917,6 +997,7 @@ conv3x3_dma_kernel(const ConvParams2 p) {
         }
       }
     }
+    SA_STAMP(st_body);
     if (NBUF == 2) {
       buf ^= 1;
     } else if (chunk + 1 < n_chunks) {  // single stage: refill after everyone finished reading it
@@ -1384,6 +1465,18 @@ conv3x3_dma_kernel(const ConvParams2 p) {
       }
     }
   }
+  if constexpr (PERS) {
+    // store instructions this wave has just issued, as a LOWER bound (a store whose lanes are all switched off may be branched
+    // over): a tile that lies completely inside the image issues R (+ R / 2 pooled) stores per valid 16-channel piece
+    int n_valid = 0;
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int pr = 0; pr < 2; ++pr)
+        if ((co32_0 + m) * 32 + pr * 16 < p.CoutP) ++n_valid;
+    const bool full = x0 + TW <= W && y0 + TH <= H;
+    stores_behind = full ? n_valid * ((p.dst ? R : 0) + (p.dst_pool ? R / 2 : 0)) : 0;
+  }
   }
 
   // ---- fused 1x1 heads on the matrix cores: out[n, pixel] = act(b[n] + sum_co Wh[n][co] * f[co, pixel]) with
@@ -1501,22 +1594,27 @@ conv3x3_dma_kernel(const ConvParams2 p) {
       }
     }
   }
+  SA_STAMP(st_epi);
   // ---- next tile of this workgroup (its first chunk is in flight already when NBUF == 2)
   if (!more) break;
   cur = nxt;
   L = L_next;
   }  // tiles
+  SA_STAMP_FLUSH;
 #endif
 }
 
-template <int MT, int CK, int NW, int R, int NBUF, bool HEADS, int STEM_CIN = 0, bool EXT = false, bool UPS = false, int ITAP = -1, bool XP = false>
+template <int MT, int CK, int NW, int R, int NBUF, bool HEADS, int STEM_CIN = 0, bool EXT = false, bool UPS = false, int ITAP = -1, bool XP = false,
+          bool PERS = false>
 int launch2(const ConvParams2& p, hipStream_t st) {
   constexpr int TH = NW * R;
   constexpr int N_IN = ((TH + 2) * 34 * CK * 2 + 1023) / 1024;
   constexpr size_t lds = NBUF * ((size_t)N_IN * 1024 + (size_t)MT * (CK / 16) * 9 * 1024) +
                          (STEM_CIN ? ((size_t)(TH + 4) * 36 * STEM_CIN + (size_t)(9 * STEM_CIN + 1) * CK) * 4 : 0) +
                          (UPS ? 4096 : 0) +  // segment A of the low-resolution tile
-                         (XP ? 65536 : 0);   // expand + reduce weight fragments (CoutX <= 256)
+                         (XP ? 65536 : 0) +  // expand + reduce weight fragments (CoutX <= 256)
+                         (PERS ? 2048 : 0);  // the bias of every output channel (CoutP <= 512)
+  if (PERS && p.CoutP > 512) return sa::fail(SA_ERR_UNSUPPORTED, "sa_conv3x3: the persistent two-workgroup kernels hold at most 512 biases in LDS");
   if (XP && (p.CoutX > 256 || p.CoutX % 32)) return sa::fail(SA_ERR_UNSUPPORTED, "sa_conv3x3_bneck_bf16: CoutX must be a multiple of 32, <= 256");
   ConvParams2 q = p;
   q.tiles_x = (p.W + 31) / 32;
@@ -1559,7 +1657,7 @@ int launch2(const ConvParams2& p, hipStream_t st) {
     return sa::fail(SA_ERR_UNSUPPORTED, "sa_conv3x3_bf16: one frame must be smaller than 4 GiB");
   static bool attr_set = false;
   if (!attr_set && lds > 64 * 1024) {
-    SA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_dma_kernel<MT, CK, NW, R, NBUF, HEADS, STEM_CIN, EXT, UPS, ITAP, XP>),
+    SA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_dma_kernel<MT, CK, NW, R, NBUF, HEADS, STEM_CIN, EXT, UPS, ITAP, XP, PERS>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
@@ -1574,7 +1672,7 @@ int launch2(const ConvParams2& p, hipStream_t st) {
   // SA_CONV_PERSIST=0 launches one workgroup per tile (the pre-persistent behaviour, for A/B runs); SA_CONV_PERSIST=n (n > 0)
   // forces n workgroups per CU.
   size_t grid = nblk;
-  if (NBUF == 2 && STEM_CIN == 0 && !EXT && CK == 16 && MT == 4) {  // = PERSIST in the kernel
+  if (NBUF == 2 && STEM_CIN == 0 && !EXT && CK == 16 && (MT == 4 || PERS)) {  // = PERSIST in the kernel
     static const int persist = [] {
       const char* v = getenv("SA_CONV_PERSIST");
       return v ? atoi(v) : -1;
@@ -1585,8 +1683,11 @@ int launch2(const ConvParams2& p, hipStream_t st) {
       SA_HIP_CHECK(hipGetDevice(&dev));
       SA_HIP_CHECK(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
       SA_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(
-          &nb, reinterpret_cast<const void*>(&conv3x3_dma_kernel<MT, CK, NW, R, NBUF, HEADS, STEM_CIN, EXT, UPS, ITAP, XP>), NW * 64, lds));
+          &nb, reinterpret_cast<const void*>(&conv3x3_dma_kernel<MT, CK, NW, R, NBUF, HEADS, STEM_CIN, EXT, UPS, ITAP, XP, PERS>), NW * 64, lds));
       per_cu = nb > 0 ? nb : 1;
+      // (the occupancy API can answer one block too many -- MI355X_MICROARCH.md, correctness boundaries; LDS is the real limit here)
+      const int by_lds = (int)((160u * 1024u) / (lds ? lds : 1));
+      if (by_lds >= 1 && per_cu > by_lds) per_cu = by_lds;
     }
     if (g_grid_limit > 0) {
       if ((size_t)g_grid_limit < grid) grid = (size_t)g_grid_limit;
@@ -1595,7 +1696,7 @@ int launch2(const ConvParams2& p, hipStream_t st) {
       if (cap < grid) grid = cap;
     }
   }
-  hipLaunchKernelGGL((conv3x3_dma_kernel<MT, CK, NW, R, NBUF, HEADS, STEM_CIN, EXT, UPS, ITAP, XP>), dim3((unsigned)grid), dim3(NW * 64), lds, st, q);
+  hipLaunchKernelGGL((conv3x3_dma_kernel<MT, CK, NW, R, NBUF, HEADS, STEM_CIN, EXT, UPS, ITAP, XP, PERS>), dim3((unsigned)grid), dim3(NW * 64), lds, st, q);
   SA_LAUNCH_CHECK();
   return SA_OK;
 }
@@ -1638,6 +1739,17 @@ int launch2_pick(const ConvParams2& p, hipStream_t st) {
   // single-chunk layers (Cin <= CK) are HBM-bound: small single-stage tiles, many workgroups per CU
   if ((p.C0P + p.C1P) == CK) return launch2<MT, CK, 4, 2, 1, false>(p, st);
   // (4-wave / 8x32 and 4-wave / 16x32 tiles were measured 4-6 % slower than 8 waves x 2 rows on every multi-chunk layer)
+  // Round 5: the persistent tile loop with a counted wait (PERS, see the kernel); SA_CONV_PERS=0 launches one workgroup per tile
+  // (A/B), SA_CONV_PERS=2 only the few-chunk (ITAP < 0) layers, 3 only the many-chunk ones.
+  if constexpr (CK == 16) {
+    static const int pers = [] {
+      const char* v = getenv("SA_CONV_PERS");
+      return v ? atoi(v) : 1;
+    }();
+    if (p.CoutP <= 512 && (pers == 1 || (pers == 2 && !mid) || (pers == 3 && mid)))
+      return mid ? launch2<MT, CK, 8, 2, 2, false, 0, false, false, SA_CONV_ITAP, false, true>(p, st)
+                 : launch2<MT, CK, 8, 2, 2, false, 0, false, false, -1, false, true>(p, st);
+  }
   return mid ? launch2<MT, CK, 8, 2, 2, false, 0, false, false, SA_CONV_ITAP>(p, st) : launch2<MT, CK, 8, 2, 2, false>(p, st);
 }
 
@@ -1830,6 +1942,20 @@ static int conv3x3_impl(const void* src0, int C0P, const void* src1, int C1P, in
 
 
 extern "C" {
+
+#if defined(SA_CONV_STAMP)
+// instrumented build only (not part of the ABI): zero / read the segment sums of the launches in between
+int sa_conv3x3_stamp_reset() {
+  unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  SA_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_stamp), z, sizeof(z)));
+  return SA_OK;
+}
+int sa_conv3x3_stamp_read(unsigned long long* out) {
+  SA_HIP_CHECK(hipDeviceSynchronize());
+  SA_HIP_CHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamp), 8 * sizeof(unsigned long long)));
+  return SA_OK;
+}
+#endif
 
 int sa_conv3x3_set_grid_limit(int n) {
   const int prev = g_grid_limit;

@@ -66,6 +66,46 @@ def test_persistent_schedule_is_bitwise_neutral(grid_limit, dtype, B, H, W, C0, 
             assert torch.equal(a.view(torch.int16), b.view(torch.int16)), f"grid limit {n} of {n_tiles} tiles"
 
 
+@pytest.mark.parametrize("B,H,W,C0,C1,Cout,pooled,limit", [
+    (8, 256, 256, 64, 0, 64, True, 0),      # the 64 -> 64 @256 layer of the benchmark plan at 8 frames: 1024 tiles on 512 workgroups
+    (8, 256, 256, 32, 0, 64, False, 96),    # 2 chunks (the shortest K loop: the wait is reached soonest after the stores)
+    (16, 128, 128, 64, 0, 128, False, 0),   # 4 chunks, 2 cout tiles
+    (16, 64, 64, 256, 0, 256, False, 200),  # 16 chunks (copies queued mid-chunk), 4 cout tiles, 200 workgroups: not a multiple of 8
+    (6, 128, 128, 128, 256, 128, False, 64),  # concat, 24 chunks
+])
+def test_counted_wait_of_the_two_workgroup_persistent_loop_at_real_sizes(grid_limit, B, H, W, C0, C1, Cout, pooled, limit):
+    """Round 5 (`PERS` kernels, csrc/conv3x3.hip): in front of a later tile's first chunk a wave waits with `s_waitcnt vmcnt(S)`
+    -- S = the store instructions of the previous tile's epilogue, issued AFTER the next tile's copies -- instead of
+    vmcnt(0). That relies on the in-order retirement of gfx9's one VMEM counter; if a copy could still be in flight behind
+    that wait, tiles would be computed from a stale LDS stage. Full-size layers, every tile inside the image (the counted path;
+    ragged tiles fall back to vmcnt(0)), many tiles per workgroup, three runs each: bitwise the one-workgroup-per-tile result."""
+    from sleap_amd import ops
+
+    dtype = "fp16"
+    g = torch.Generator(device="cpu").manual_seed(B + H + C0 + C1 + Cout)
+    k = torch.randn((3, 3, C0 + C1, Cout), generator=g) * (2.0 / (9 * (C0 + C1))) ** 0.5
+    x0 = ops.to_bf16_padded(torch.randn((B, H, W, C0), generator=g).cuda(), dtype=dtype)
+    x1 = ops.to_bf16_padded(torch.randn((B, H, W, C1), generator=g).cuda(), dtype=dtype) if C1 else None
+    pw = ops.pack_conv3x3_weights(k.numpy(), C0, C1, dtype=dtype)
+    coutp = ops.pad16(Cout)
+    bias = (torch.randn((coutp,), generator=g) * 0.1).cuda()
+    from sleap_amd import _lib
+
+    mode = (1 if C1 else 0) | _lib.LAYOUT_PLANES16  # the layout of the benchmark plan (the same bytes read as 16-channel planes)
+
+    def run():
+        out = ops.conv3x3(x0, x1, mode, pw, bias, coutp, True, (H, W), full=True, pooled=pooled)
+        torch.cuda.synchronize()
+        return [o.clone() for o in (out if pooled else (out,))]
+
+    grid_limit(-1)  # one workgroup per tile: no tile boundary inside a workgroup, the counted wait is never taken
+    ref = run()
+    grid_limit(limit)  # 0: the automatic policy (occupancy x CUs workgroups)
+    for rep in range(3):
+        for a, b in zip(run(), ref):
+            assert torch.equal(a.view(torch.int16), b.view(torch.int16)), f"run {rep}"
+
+
 @pytest.mark.parametrize("dtype", STORAGE_DTYPES)
 def test_persistent_network_forward_is_bitwise_neutral(grid_limit, dtype):
     """The benchmark UNet (fused stem / pair / heads included) at a small size: heads identical for every schedule."""

@@ -129,6 +129,32 @@ def test_local_peaks_with_offsets_vs_oracle(pf):
     assert_allclose(_n(g[0]), o[0], atol=1e-6)
 
 
+def test_local_peaks_with_offsets_on_the_sleap_trained_fixtures_own_maps(pf):
+    """Row a5 on REAL weights: the confidence maps and the learned offset maps of the one bottom-up model
+    SLEAP itself trained (`minimal_instance.UNet.bottomup`: OffsetRefinementHead, peak_finding.py:646-707), computed by the fp32
+    oracle on six synthetic frames and handed to BOTH peak finders -- same fp32 maps in, so there is no storage error and no
+    excuse: identical peak sets (sample, channel, value, order) at three thresholds, coordinates within 1e-5 px. The maps are
+    noisy far outside the training data (211 maxima per frame above 0.2, margins over a neighbour down to 4e-5), i.e. a harder
+    input for the strict-`>` scan and the ordering than the smooth synthetic maps above."""
+    import os
+
+    from oracle.keras_graph import KerasGraph, load_npz_model, preprocess
+    from sleap_amd.synth import render_frames
+
+    model = os.path.join(os.path.dirname(__file__), "golden", "models", "minimal_instance.UNet.bottomup")
+    frames = render_frames(6, 384, 384, n_animals=2, seed=11)[0]
+    cms, _, offs = KerasGraph(*load_npz_model(os.path.join(model, "best_model.npz")))(preprocess(frames))
+    assert cms.shape == (6, 192, 192, 2) and offs.shape == (6, 192, 192, 4)
+    for thr, at_least in ((0.2, 1000), (0.5, 400), (0.9, 20)):
+        o = opf.find_local_peaks_with_offsets(cms, offs, thr)
+        g = pf.find_local_peaks_with_offsets(cms, offs, thr, max_peaks=2048)
+        assert len(o[0]) >= at_least
+        assert_array_equal(_n(g[2]), o[2])
+        assert_array_equal(_n(g[3]), o[3])
+        assert_array_equal(_n(g[1]), o[1])
+        assert_allclose(_n(g[0]), o[0], atol=TOL)
+
+
 def test_peak_overflow_is_flagged(pf):
     rng = np.random.default_rng(3)
     cms = rng.random((1, 64, 64, 4)).astype(np.float32)
