@@ -832,7 +832,7 @@ conv3x3_dma_kernel(const ConvParams2 p) {
       if constexpr (NBUF == 2) {
         if (chunk + 1 < n_chunks) {
           issue(cur, voff0, voff1, chunk + 1, buf ^ 1, lo, hi);
-        } else if (more) {  // cross-tile prefetch: chunk 0 of the next tile lands while this tile's epilogue runs
+        } else if (more && !PERS) {  // cross-tile prefetch: chunk 0 of the next tile lands while this tile's epilogue runs
           if (lo <= 0) {
             nxt = decode(L_next);
             int ln = lane;
@@ -978,6 +978,25 @@ conv3x3_dma_kernel(const ConvParams2 p) {
             acc[m][r] = SA_MFMA_32x32x16(a[m], bv, acc[m][r], 0, 0, 0);
         }
       }
+#if defined(SA_CONV_SGB)
+      // Explicit software pipeline of a scheduling region (A/B build): the operand fragments of tap t + 1 are read from LDS before
+      // the MFMAs of tap t are issued -- two fragment sets in flight, whatever the register-pressure heuristic thinks
+      if constexpr (PERS || SA_CONV_SGB >= 2) {
+        constexpr int NR_ = (MT + R) * KK, NM_ = MT * R * KK;
+        // (`tap` is a constant after unrolling, not a constant expression)
+        const int first_ = (ISSUE_TAP >= 0 && tap > ISSUE_TAP) ? ISSUE_TAP + 1 : 0;
+        const int last_ = (ISSUE_TAP >= 0 && tap <= ISSUE_TAP) ? ISSUE_TAP : 8;
+        if (tap == last_) {
+          __builtin_amdgcn_sched_group_barrier(0x100, NR_, 0);
+#pragma unroll
+          for (int t_ = first_; t_ < last_; ++t_) {
+            __builtin_amdgcn_sched_group_barrier(0x100, NR_, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, NM_, 0);
+          }
+          __builtin_amdgcn_sched_group_barrier(0x008, NM_, 0);
+        }
+      }
+#endif
       if constexpr (ISSUE_TAP >= 0 || W_TAP >= 0) {
         if (tap == ISSUE_TAP || tap == W_TAP) {
           __builtin_amdgcn_sched_barrier(0);
@@ -1003,6 +1022,20 @@ conv3x3_dma_kernel(const ConvParams2 p) {
     } else if (chunk + 1 < n_chunks) {  // single stage: refill after everyone finished reading it
       __syncthreads();
       issue(cur, voff0, voff1, chunk + 1, 0);
+    }
+  }
+  if constexpr (PERS) {
+    // Cross-tile prefetch of the two-workgroup kernels: queued HERE, between the last chunk's MFMAs and the epilogue, not inside
+    // the chunk loop (round 5, first form: the branch in the middle of the last chunk cost the hot loop its register room -- 4
+    // operand fragments in flight instead of 10, an `s_waitcnt lgkmcnt(0)` in front of every MFMA pair, every layer ~10 % slower
+    // than one workgroup per tile). `buf` is the stage of chunk n-2 by now: every wave left it before the last chunk's barrier.
+    // The copies are older than the epilogue's stores, which is what the counted wait of the next tile's first chunk needs.
+    if (more) {
+      nxt = decode(L_next);
+      int ln = lane;
+      asm volatile("" : "+v"(ln));
+      make_voff(nxt, ln, voff0, voff1);  // this tile issues no more copies: its offsets are dead
+      issue(nxt, voff0, voff1, 0, buf);
     }
   }
   const int co32_0 = cur.co32_0, x0 = cur.x0, y0 = cur.y0, b = cur.b;
