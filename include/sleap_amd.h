@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define SA_ABI_VERSION 5  /* 5 (round 4): + sa_conv3x3_ex_heads_bf16. 4 (round 4): + sa_tensor_absmax, sa_imgconv_pack_tiled, sa_pack_pointwise_weights,
+#define SA_ABI_VERSION 6  /* 6 (round 5): + sa_conv3x3_set_persistent. 5 (round 4): + sa_conv3x3_ex_heads_bf16. 4 (round 4): + sa_tensor_absmax, sa_imgconv_pack_tiled, sa_pack_pointwise_weights,
                             sa_pointwise_packed_elems, sa_conv3x3_bneck_bf16; SA_LAYOUT_PLANES16 accepted in the `relu` argument of
                             sa_conv1x1_bf16 / sa_convk_bf16 / sa_convt_s2_bf16 */
 
@@ -338,6 +338,14 @@ int sa_conv3x3_ex_heads_bf16(const void* src0, int C0P, const void* src1, int C1
  *   n  < 0  one workgroup per tile
  * Returns the previous value. Results do not depend on it (each tile's arithmetic is the same). */
 int sa_conv3x3_set_grid_limit(int n);
+
+/* The persistent tile loop of the TWO-workgroups-per-CU plain kernels (round 5; `PERS` in csrc/conv3x3.hip: the next tile's first
+ * chunk is copied while the epilogue runs, and the wait in front of it is `s_waitcnt vmcnt(S)`, S = the epilogue's store
+ * instructions, instead of vmcnt(0)). Bitwise neutral; measured 3-10 % SLOWER than one workgroup per tile on every layer of the
+ * benchmark plan (profiles/r05_ab_session.md), so it is OFF by default -- this switch exists for A/B runs and for the tests that
+ * keep the kernels correct.  mode: 0 off, 1 every plain multi-chunk layer, 2 few-chunk layers only, 3 many-chunk layers only,
+ * -1 = back to the environment's choice (SA_CONV_PERS, default 0). Process-wide, HOST. Returns the previous value. */
+int sa_conv3x3_set_persistent(int mode);
 
 
 /* HOST helper: Keras Conv2D kernel (3,3,Cin,Cout) f32 -> the packed bf16 layout above. The input

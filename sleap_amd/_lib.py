@@ -69,6 +69,7 @@ SIGNATURES = {
     "sa_pack_conv3x3_weights": (_i, [_p, _i, _i, _i, _i, _i, _i, _p]),
     "sa_conv3x3_packed_elems": (_sz, [_i, _i, _i]),
     "sa_conv3x3_set_grid_limit": (_i, [_i]),
+    "sa_conv3x3_set_persistent": (_i, [_i]),
     "sa_convt3x3s2_bf16": (_i, [_p, _i, _p, _p, _i, _i, _i, _i, _i, _p, _p]),
     "sa_image_conv_bf16": (_i, [_p, _i, _i, _i, _i, _i, _i, _p, _i, _i, _i, _i, _i, _i, _i, _p, _p, _i, _i, _p, _p, _p, _p]),
     "sa_imgconv_packed_elems": (C.c_size_t, [_i, _i, _i]),

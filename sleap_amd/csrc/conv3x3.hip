@@ -30,6 +30,7 @@
 namespace {
 
 int g_grid_limit = 0;  // sa_conv3x3_set_grid_limit
+int g_persistent = -1;  // sa_conv3x3_set_persistent (-1: SA_CONV_PERS of the environment, default 0)
 
 // SA_CONV_STAMP (an instrumented A/B build, tools/stall_probe.py -- never the product library): every wave of
 // conv3x3_dma_kernel sums, in scalar registers, the shader cycles (s_memtime) it spends in five segments of its life -- tile
@@ -981,7 +982,7 @@ conv3x3_dma_kernel(const ConvParams2 p) {
 #if defined(SA_CONV_SGB)
       // Explicit software pipeline of a scheduling region (A/B build): the operand fragments of tap t + 1 are read from LDS before
       // the MFMAs of tap t are issued -- two fragment sets in flight, whatever the register-pressure heuristic thinks
-      if constexpr (PERS || SA_CONV_SGB >= 2) {
+      if constexpr ((SA_CONV_SGB == 1 && PERS) || SA_CONV_SGB == 2 || (SA_CONV_SGB == 3 && !HEADS)) {
         constexpr int NR_ = (MT + R) * KK, NM_ = MT * R * KK;
         // (`tap` is a constant after unrolling, not a constant expression)
         const int first_ = (ISSUE_TAP >= 0 && tap > ISSUE_TAP) ? ISSUE_TAP + 1 : 0;
@@ -1724,6 +1725,9 @@ int launch2(const ConvParams2& p, hipStream_t st) {
     }
     if (g_grid_limit > 0) {
       if ((size_t)g_grid_limit < grid) grid = (size_t)g_grid_limit;
+      // the tile schedule hands every XCD (workgroup index mod 8) one contiguous range of the tiles: fewer than 8 workgroups
+      // would leave whole ranges unprocessed (round 5: the test hook allowed that, and stale buffer contents hid it)
+      if (grid < 8 && nblk >= 8) grid = 8;
     } else if (g_grid_limit == 0 && persist != 0) {
       const size_t cap = (size_t)(persist > 0 ? persist : per_cu) * (size_t)n_cu;
       if (cap < grid) grid = cap;
@@ -1772,13 +1776,15 @@ int launch2_pick(const ConvParams2& p, hipStream_t st) {
   // single-chunk layers (Cin <= CK) are HBM-bound: small single-stage tiles, many workgroups per CU
   if ((p.C0P + p.C1P) == CK) return launch2<MT, CK, 4, 2, 1, false>(p, st);
   // (4-wave / 8x32 and 4-wave / 16x32 tiles were measured 4-6 % slower than 8 waves x 2 rows on every multi-chunk layer)
-  // Round 5: the persistent tile loop with a counted wait (PERS, see the kernel); SA_CONV_PERS=0 launches one workgroup per tile
-  // (A/B), SA_CONV_PERS=2 only the few-chunk (ITAP < 0) layers, 3 only the many-chunk ones.
+  // Round 5: the persistent tile loop with a counted wait (PERS, see the kernel) -- built, bitwise neutral, and SLOWER on every
+  // layer in both of its forms (profiles/r05_ab_session.md section 1: 3-10 %), so one workgroup per tile stays the default.
+  // SA_CONV_PERS=1 turns it on (A/B), 2 only for the few-chunk (ITAP < 0) layers, 3 only for the many-chunk ones.
   if constexpr (CK == 16) {
-    static const int pers = [] {
+    static const int pers_env = [] {
       const char* v = getenv("SA_CONV_PERS");
-      return v ? atoi(v) : 1;
+      return v ? atoi(v) : 0;
     }();
+    const int pers = g_persistent >= 0 ? g_persistent : pers_env;
     if (p.CoutP <= 512 && (pers == 1 || (pers == 2 && !mid) || (pers == 3 && mid)))
       return mid ? launch2<MT, CK, 8, 2, 2, false, 0, false, false, SA_CONV_ITAP, false, true>(p, st)
                  : launch2<MT, CK, 8, 2, 2, false, 0, false, false, -1, false, true>(p, st);
@@ -1989,6 +1995,12 @@ int sa_conv3x3_stamp_read(unsigned long long* out) {
   return SA_OK;
 }
 #endif
+
+int sa_conv3x3_set_persistent(int mode) {
+  const int prev = g_persistent;
+  g_persistent = mode;
+  return prev;
+}
 
 int sa_conv3x3_set_grid_limit(int n) {
   const int prev = g_grid_limit;

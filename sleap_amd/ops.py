@@ -311,13 +311,21 @@ def pack_conv3x3_weights(kernel, c0, c1=0, dtype: str = None):
     return torch.from_numpy(packed.view(np.int16)).cuda()
 
 
-def conv3x3(src0, src1, mode, packed_w, bias_padded, coutp, relu, out_hw, full=True, pooled=False):
+def conv3x3(src0, src1, mode, packed_w, bias_padded, coutp, relu, out_hw, full=True, pooled=False, out=None, out_pool=None):
     """sa_conv3x3_bf16. `mode` may carry _lib.LAYOUT_PLANES16: sources and outputs are then 16-channel planes
-    ([B,CP/16,H,W,16] bytes held in tensors of the NHWC shape; to_planes16 / from_planes16 convert)."""
+    ([B,CP/16,H,W,16] bytes held in tensors of the NHWC shape; to_planes16 / from_planes16 convert). `out` / `out_pool`:
+    caller-owned output tensors (tests poison them first: a tile the launch skipped must not look computed)."""
     B = src0.shape[0]
     H, W = out_hw
-    out = torch.empty((B, H, W, coutp), dtype=src0.dtype, device=src0.device) if full else None
-    outp = torch.empty((B, H // 2, W // 2, coutp), dtype=src0.dtype, device=src0.device) if pooled else None
+    if full and out is None:
+        out = torch.empty((B, H, W, coutp), dtype=src0.dtype, device=src0.device)
+    outp = out_pool
+    if pooled and outp is None:
+        outp = torch.empty((B, H // 2, W // 2, coutp), dtype=src0.dtype, device=src0.device)
+    if not full:
+        out = None
+    if not pooled:
+        outp = None
     check(_lib.lib(_dtype_of(src0)).sa_conv3x3_bf16(_ptr(src0), src0.shape[3], _ptr(src1), src1.shape[3] if src1 is not None else 0,
                                      mode, _ptr(packed_w), _ptr(bias_padded), coutp, int(relu), B, H, W, _ptr(out),
                                      _ptr(outp), _stream()), "sa_conv3x3_bf16")

@@ -25,8 +25,12 @@ def grid_limit():
         for h in libs:
             h.sa_conv3x3_set_grid_limit(int(n))
 
+    for h in libs:  # the two-workgroup persistent kernels are off by default (slower): these tests keep them correct
+        h.sa_conv3x3_set_persistent(1)
     yield set_
     set_(0)
+    for h in libs:
+        h.sa_conv3x3_set_persistent(-1)
 
 
 @pytest.mark.parametrize("dtype", STORAGE_DTYPES)
@@ -51,9 +55,16 @@ def test_persistent_schedule_is_bitwise_neutral(grid_limit, dtype, B, H, W, C0, 
     bias = bias.cuda()
 
     def run():
-        out = ops.conv3x3(x0, x1, mode, pw, bias, coutp, True, (H, W), full=True, pooled=pooled)
+        # caller-owned outputs, poisoned: a tile that a schedule skipped must not look computed (round 5: with fewer than 8
+        # workgroups whole XCD ranges of tiles were left out, and the allocator's stale -- correct -- bytes hid it)
+        o_full = torch.full((B, H, W, coutp), float("nan"), dtype=x0.dtype, device="cuda")
+        o_pool = torch.full((B, H // 2, W // 2, coutp), float("nan"), dtype=x0.dtype, device="cuda") if pooled else None
+        out = ops.conv3x3(x0, x1, mode, pw, bias, coutp, True, (H, W), full=True, pooled=pooled, out=o_full, out_pool=o_pool)
         torch.cuda.synchronize()
-        return [o.clone() for o in (out if pooled else (out,))]
+        outs = [o.clone() for o in (out if pooled else (out,))]
+        for o in outs:
+            assert not torch.isnan(o.float()).any(), "a tile was not written"
+        return outs
 
     grid_limit(-1)  # one workgroup per tile
     ref = run()
@@ -94,7 +105,9 @@ def test_counted_wait_of_the_two_workgroup_persistent_loop_at_real_sizes(grid_li
     mode = (1 if C1 else 0) | _lib.LAYOUT_PLANES16  # the layout of the benchmark plan (the same bytes read as 16-channel planes)
 
     def run():
-        out = ops.conv3x3(x0, x1, mode, pw, bias, coutp, True, (H, W), full=True, pooled=pooled)
+        o_full = torch.full((B, H, W, coutp), float("nan"), dtype=x0.dtype, device="cuda")  # poisoned: a skipped tile shows
+        o_pool = torch.full((B, H // 2, W // 2, coutp), float("nan"), dtype=x0.dtype, device="cuda") if pooled else None
+        out = ops.conv3x3(x0, x1, mode, pw, bias, coutp, True, (H, W), full=True, pooled=pooled, out=o_full, out_pool=o_pool)
         torch.cuda.synchronize()
         return [o.clone() for o in (out if pooled else (out,))]
 
