@@ -1727,7 +1727,7 @@ int launch2(const ConvParams2& p, hipStream_t st) {
       if ((size_t)g_grid_limit < grid) grid = (size_t)g_grid_limit;
       // the tile schedule hands every XCD (workgroup index mod 8) one contiguous range of the tiles: fewer than 8 workgroups
       // would leave whole ranges unprocessed (round 5: the test hook allowed that, and stale buffer contents hid it)
-      if (grid < 8 && nblk >= 8) grid = 8;
+      if (grid < 8) grid = nblk < 8 ? nblk : 8;
     } else if (g_grid_limit == 0 && persist != 0) {
       const size_t cap = (size_t)(persist > 0 ? persist : per_cu) * (size_t)n_cu;
       if (cap < grid) grid = cap;

@@ -163,6 +163,54 @@ maxpool_kernel(const uint16_t* __restrict__ src, int B, int H, int W, int CP, in
   }
 }
 
+// MaxPooling2D(3, s2) on ONE 16-channel plane per "frame" (ResNet's ZeroPadding2D(1) + MaxPool(3, s2) after the stem, resnet.py:
+// 109-126, run per plane), round 5: the general kernel above reads nine 16-byte pieces per output piece straight from global
+// memory -- 2.25 x the input through the vector cache, 0.207 ms for 16 frames of 512 x 512 x 64 (3.2 TB/s of algorithmic bytes).
+// Here a workgroup copies the (2 TO + 1) x 65 input pixels under its TO x 32 outputs into LDS once (row-contiguous 16-byte
+// loads: every fetched line is used completely; 1.14 x the input) and takes the nine taps from there; a wave = one output row,
+// a store instruction = 1 KiB contiguous. Taps outside the image are 0 (pad_zero) or neutral (-inf): the general kernel's
+// result, bit for bit (max of stored values is exact).
+template <int TO>
+__global__ void __launch_bounds__(64 * TO)
+maxpool3x3s2_c16_kernel(const uint16_t* __restrict__ src, int H, int W, int pad_t, int pad_l, int pad_zero, int Ho, int Wo,
+                        uint16_t* __restrict__ dst) {
+  constexpr int IR = 2 * TO + 1, IC = 65;
+  __shared__ __attribute__((aligned(16))) h16x8_t tile[IR * IC * 2];
+  const int tid = threadIdx.x;
+  const int x0 = blockIdx.x * 32, y0 = blockIdx.y * TO;
+  const size_t b = blockIdx.z;
+  const uint16_t* frame = src + b * (size_t)H * W * 16;
+  const uint16_t fillv = sa::f2h(pad_zero ? 0.0f : -INFINITY);
+  const h16x8_t fill = {fillv, fillv, fillv, fillv, fillv, fillv, fillv, fillv};
+  for (int i = tid; i < IR * IC * 2; i += 64 * TO) {
+    const int pix = i >> 1, hf = i & 1;
+    const int r = pix / IC, c = pix - r * IC;
+    const int gy = 2 * y0 - pad_t + r, gx = 2 * x0 - pad_l + c;
+    h16x8_t v = fill;
+    if (gy >= 0 && gy < H && gx >= 0 && gx < W) v = *reinterpret_cast<const h16x8_t*>(frame + ((size_t)gy * W + gx) * 16 + hf * 8);
+    tile[i] = v;
+  }
+  __syncthreads();
+  const int hf = tid & 1, ox = (tid >> 1) & 31, oy = tid >> 6;
+  const int gy = y0 + oy, gx = x0 + ox;
+  if (gy >= Ho || gx >= Wo) return;
+  float m[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) m[j] = -INFINITY;
+#pragma unroll
+  for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) {
+      const h16x8_t v = tile[((2 * oy + dy) * IC + 2 * ox + dx) * 2 + hf];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) m[j] = fmaxf(m[j], sa::h2f(v[j]));
+    }
+  h16x8_t o;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) o[j] = sa::f2h(m[j]);
+  *reinterpret_cast<h16x8_t*>(dst + ((b * Ho + gy) * (size_t)Wo + gx) * 16 + hf * 8) = o;
+}
+
 // Add layer: dst = a + b (bf16, same shape); b may be half resolution read with nearest-neighbour x2 upsampling
 __global__ void __launch_bounds__(256)
 add_kernel(const uint16_t* __restrict__ a, const uint16_t* __restrict__ bsrc, int B, int H, int W, int CP, int b_half,
@@ -670,6 +718,19 @@ int sa_maxpool_bf16(const void* src, int B, int H, int W, int CP, int k, int str
                     int pad_is_zero, int Ho, int Wo, void* dst, sa_stream_t stream) {
   SA_REQUIRE(src && dst && CP % 8 == 0 && B > 0 && k > 0 && stride > 0 && Ho > 0 && Wo > 0, "sa_maxpool_bf16: bad arguments");
   SA_REQUIRE((Ho - 1) * stride - pad_top < H && (Wo - 1) * stride - pad_left < W, "sa_maxpool_bf16: window outside the image");
+  // SA_POOL_TILED=0: the general kernel for every shape (A/B)
+  static const bool tiled = [] {
+    const char* v = getenv("SA_POOL_TILED");
+    return !v || atoi(v) != 0;
+  }();
+  if (tiled && CP == 16 && k == 3 && stride == 2 && B <= 65535 && (Ho + 3) / 4 <= 65535) {
+    constexpr int TO = 4;
+    hipLaunchKernelGGL(maxpool3x3s2_c16_kernel<TO>, dim3((unsigned)((Wo + 31) / 32), (unsigned)((Ho + TO - 1) / TO), (unsigned)B),
+                       dim3(64 * TO), 0, (hipStream_t)stream, (const uint16_t*)src, H, W, pad_top, pad_left, pad_is_zero, Ho, Wo,
+                       (uint16_t*)dst);
+    SA_LAUNCH_CHECK();
+    return SA_OK;
+  }
   const size_t total = (size_t)B * Ho * Wo * (CP / 8);
   hipLaunchKernelGGL(maxpool_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)src, B, H, W,
                      CP, k, stride, pad_top, pad_left, pad_is_zero, Ho, Wo, (uint16_t*)dst);

@@ -426,6 +426,27 @@ def test_maxpool_general_vs_torch(k, stride, pad, pad_zero, H, W):
     assert torch.equal(out.float().cpu(), ref)
 
 
+@pytest.mark.parametrize("pad,pad_zero,H,W,B", [(1, 1, 64, 96, 6), (1, 1, 37, 71, 3), (1, 0, 40, 130, 2), (0, 0, 33, 65, 4), (1, 1, 512, 512, 8)])
+def test_maxpool3x3s2_tiled_plane_kernel_vs_torch(pad, pad_zero, H, W, B):
+    """Round 5: MaxPooling2D(3, s2) on 16-channel planes (what ResNet's pool after the stem is, per plane) runs an LDS-tiled
+    kernel (`maxpool3x3s2_c16_kernel`): every size class -- tiles inside, ragged right / bottom edges, odd sizes, both padding
+    semantics (ZeroPadding2D zeros take part / Keras `same` taps are skipped) and the benchmark's 512 x 512 -- bit for bit
+    torch's max pool of the same stored values."""
+    from sleap_amd import _lib, ops
+    from sleap_amd._lib import check
+    from sleap_amd.ops import _ptr, _stream
+
+    g = torch.Generator(device="cpu").manual_seed(H + W)
+    x = torch.randn((B, H, W, 16), generator=g) - (1.0 if pad_zero else 0.0)
+    dx = ops.to_bf16_padded(x.cuda())
+    Ho, Wo = (H + 2 * pad - 3) // 2 + 1, (W + 2 * pad - 3) // 2 + 1
+    out = torch.full((B, Ho, Wo, 16), float("nan"), dtype=TD, device="cuda")
+    check(_lib.lib().sa_maxpool_bf16(_ptr(dx), B, H, W, 16, 3, 2, pad, pad, pad_zero, Ho, Wo, _ptr(out), _stream()), "sa_maxpool_bf16")
+    xp = F.pad(_bf(x).permute(0, 3, 1, 2), (pad, pad, pad, pad), value=0.0 if pad_zero else float("-inf"))
+    ref = F.max_pool2d(xp, 3, 2).permute(0, 2, 3, 1)
+    assert torch.equal(out.float().cpu(), ref)
+
+
 @pytest.mark.parametrize("B,H,W,Cin,Cout,ksize,affine,relu", [
     (2, 40, 56, 16, 16, 7, False, True),     # stem0_conv1 of a UNet stem (unet.py:105-127): k7, 16 -> 16
     (1, 33, 47, 32, 32, 7, False, True),     # odd sizes: every border case of the hardware zero fill
