@@ -10,17 +10,20 @@ kernels, 8 x 2.5 GHz on light kernels). With 256 CUs x 4 SIMDs:
 
     utilisation = MFMA_BUSY / (GUI_ACTIVE / 8 * 1024)     -- independent of the clock the chip settled at
     effective clock = GUI_ACTIVE / 8 / duration           -- needs the kernel trace of the same run
+
+The derived clock is only printed for launches of >= 100 us (round 5): GUI_ACTIVE covers the command processor's work around a
+dispatch too, and on short launches the quotient came out at 3.1-3.6 GHz -- impossible on this part.
 """
 import csv
 import re
 import sys
 from collections import defaultdict
 
-PAT = re.compile(r"(conv3x3_dma_kernel<[^>]*>|conv3x3_mfma_kernel<[^>]*>|stem16_kernel<\d>|stem16_gray_kernel|convpair_16_32_32_kernel|convpair_persist_kernel|tapconv_kernel<[^>]*>)")
+PAT = re.compile(r"(conv3x3_dma_kernel<[^>]*>|conv3x3_mfma_kernel<[^>]*>|stem16_kernel<\d>|stem16_gray_kernel|convpair_16_32_32_kernel|convpair_persist_kernel|tapconv_kernel<[^>]*>|tapconv_coloop_kernel<[^>]*>|imgconv_mfma_kernel<[^>]*>|conv1x1_head_mfma_kernel)")
 
 
 def main(path, trace=None):
-    busy, act, clk = defaultdict(list), defaultdict(list), defaultdict(list)
+    busy, act, clk, durs = defaultdict(list), defaultdict(list), defaultdict(list), defaultdict(list)
     dur = {}
     if trace:
         for r in csv.DictReader(open(trace)):
@@ -32,6 +35,7 @@ def main(path, trace=None):
         key = (m.group(1), int(r["Grid_Size"]))
         if r["Counter_Name"] == "GRBM_GUI_ACTIVE" and r["Dispatch_Id"] in dur:
             clk[key].append(float(r["Counter_Value"]) / 8 / dur[r["Dispatch_Id"]])
+            durs[key].append(dur[r["Dispatch_Id"]])
         if r["Counter_Name"] == "SQ_VALU_MFMA_BUSY_CYCLES":
             busy[key].append(float(r["Counter_Value"]))
         elif r["Counter_Name"] == "GRBM_GUI_ACTIVE":
@@ -42,6 +46,8 @@ def main(path, trace=None):
     for key in sorted(busy, key=lambda k: -sum(busy[k])):
         b, a = sum(busy[key]) / len(busy[key]), sum(act[key]) / max(len(act[key]), 1) / 8
         ck = f"{sum(clk[key]) / len(clk[key]):.2f}" if clk[key] else "-"
+        if durs[key] and sum(durs[key]) / len(durs[key]) < 100e3:  # ns
+            ck = "n/a (< 100 us)"
         print(f"| `{key[0]}` | {key[1]} | {len(busy[key])} | {b:.4g} | {a:.4g} | {b / (a * 1024):.3f} | {ck} |")
         tb += sum(busy[key])
         ta += sum(act[key]) / 8
