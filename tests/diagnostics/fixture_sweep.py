@@ -1,0 +1,31 @@
+"""The asserted comparison of the SLEAP-trained bottom-up fixture (tests/test_gpu_fp16.py) over more synthetic seeds than the suite
+runs: counts per seed and threshold. GPU.   python tests/diagnostics/fixture_sweep.py [first_seed] [n_seeds]"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import test_gpu_fp16 as T  # noqa: E402
+
+s0 = int(sys.argv[1]) if len(sys.argv) > 1 else 11
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+tot = {}
+for thr in (0.5, 0.9):
+    for seed in range(s0, s0 + n):
+        try:
+            r = T.sleap_trained_fixture_decisions(thr, seed=seed)
+        except AssertionError as e:
+            print(f"threshold {thr} seed {seed}: ASSERTION {str(e)[:300]}")
+            tot.setdefault(thr, []).append(None)
+            continue
+        print(f"threshold {thr} seed {seed}: {r['n_common']} of {r['n_oracle']} peaks within 0.5 px (max {r['worst']:.4f}); excused "
+              f"{sum(r['excused'].values())} {r['excused']}; frames without a decision {r['clean']}: {r['inst_peaks']} instance peaks, max "
+              f"{r['inst_worst']:.4f} px; map errors cms {r['err']['cms']:.2e} pafs {r['err']['pafs']:.2e} offsets {r['err']['offsets']:.2e}")
+        tot.setdefault(thr, []).append(r)
+for thr, rs in tot.items():
+    ok = [r for r in rs if r]
+    print(f"threshold {thr}: {len(ok)} of {len(rs)} seeds without an unexplained difference; {sum(r['n_common'] for r in ok)} of "
+          f"{sum(r['n_oracle'] for r in ok)} oracle peaks within 0.5 px (max {max(r['worst'] for r in ok):.4f}), "
+          f"{sum(sum(r['excused'].values()) for r in ok)} excused; {sum(len(r['clean']) for r in ok)} of {6 * len(ok)} frames compared at "
+          f"instance level: {sum(r['inst_peaks'] for r in ok)} instance peaks, max {max(r['inst_worst'] for r in ok):.4f} px")

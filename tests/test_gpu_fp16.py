@@ -171,24 +171,9 @@ def _nms_margin(cm, y, x):
     return float(cm[y, x]) - float(max(nb))
 
 
-@pytest.mark.parametrize("thr", [0.5, 0.9])
-def test_sleap_trained_bottomup_fixture_differences_are_last_bit_decisions(thr):
-    """The ONE bottom-up model SLEAP itself trained (`minimal_instance.UNet.bottomup`, the reference's fixture of
-    tests/nn/test_inference.py:769-806: UNet, 2 nodes, 1 edge, confidence maps at stride 2 with a learned OFFSET-refinement head
-    -- row a5 on real weights -- and PAFs at stride 4). Its own frame is H.264 and cannot be decoded here, so the frames are six
-    synthetic ones, far from its training data: the maps carry ~80 (threshold 0.5) / 4 (0.9) local maxima per frame, and at 0.5
-    every frame holds maxima that beat a neighbour by less than 1e-3 (tests/diagnostics: the oracle's own margins). fp16-storage device
-    path vs the fp32 oracle running the same Keras graph, ASSERTED (round 4 only printed this comparison):
-
-      * the device's maps are within 4e-3 (confidence maps) / 1e-2 (offsets, PAFs) of the oracle's range; `eps` = twice the measured
-        confidence-map error is the only slack anything below gets;
-      * every oracle peak has a device peak of its channel within 0.5 px -- or it is a decision on nearly equal numbers, read off
-        the ORACLE's own map: its value within eps of the threshold, or a neighbouring cell within eps of it (which of two nearly
-        equal cells is "the" strict local maximum is decided by the last bits);
-      * every device peak without a partner is the same kind of decision on the DEVICE's map;
-      * frames without any such decision are identical at the instance level: count, node assignment (NaN mask), every
-        coordinate within 0.5 px.
-    The counts are printed: how many of the peaks were excused, and why."""
+def sleap_trained_fixture_decisions(thr, seed=11):
+    """The comparison behind `test_sleap_trained_bottomup_fixture_differences_are_last_bit_decisions` (asserts every difference to
+    be a last-bit decision as it goes) -> its counts. Also run over more seeds by tests/diagnostics/fixture_sweep.py."""
     from oracle import paf_grouping as opg
     from oracle import peak_finding as opf
     from oracle.keras_graph import KerasGraph, load_npz_model, preprocess
@@ -197,7 +182,7 @@ def test_sleap_trained_bottomup_fixture_differences_are_last_bit_decisions(thr):
 
     model = os.path.join(MODELS, "minimal_instance.UNet.bottomup")
     B, stride = 6, 2
-    frames = render_frames(B, 384, 384, n_animals=2, seed=11)[0]
+    frames = render_frames(B, 384, 384, n_animals=2, seed=seed)[0]
     cfg, w = load_npz_model(os.path.join(model, "best_model.npz"))
     cms, pafs, offs = KerasGraph(cfg, w)(preprocess(frames))
     p = load_model(model, batch_size=B, progress_reporting="none", dtype="fp16", peak_threshold=thr)
@@ -271,11 +256,32 @@ def test_sleap_trained_bottomup_fixture_differences_are_last_bit_decisions(thr):
         inst_peaks += d.size
         if d.size:
             inst_worst = max(inst_worst, float(d.max()))
-    n_oracle = len(pts)
-    print(f"SLEAP-trained fixture at threshold {thr}: map errors {err} (eps {eps:.2e}); {n_common} of {n_oracle} oracle peaks have a "
-          f"device peak within 0.5 px (max {worst:.4f} px); excused {excused}; frames without a decision {clean}: {inst_peaks} "
-          f"instance peaks compared, max {inst_worst:.4f} px")
-    assert worst <= 0.5 and inst_worst <= 0.5
+    return dict(thr=thr, seed=seed, err=err, eps=eps, n_oracle=len(pts), n_common=n_common, worst=worst, excused=excused, clean=clean,
+                inst_peaks=inst_peaks, inst_worst=inst_worst)
+@pytest.mark.parametrize("thr", [0.5, 0.9])
+def test_sleap_trained_bottomup_fixture_differences_are_last_bit_decisions(thr):
+    """The ONE bottom-up model SLEAP itself trained (`minimal_instance.UNet.bottomup`, the reference's fixture of
+    tests/nn/test_inference.py:769-806: UNet, 2 nodes, 1 edge, confidence maps at stride 2 with a learned OFFSET-refinement head
+    -- row a5 on real weights -- and PAFs at stride 4). Its own frame is H.264 and cannot be decoded here, so the frames are six
+    synthetic ones, far from its training data: the maps carry ~80 (threshold 0.5) / 4 (0.9) local maxima per frame, and at 0.5
+    every frame holds maxima that beat a neighbour by less than 1e-3 (tests/diagnostics: the oracle's own margins). fp16-storage device
+    path vs the fp32 oracle running the same Keras graph, ASSERTED (round 4 only printed this comparison):
+
+      * the device's maps are within 4e-3 (confidence maps) / 1e-2 (offsets, PAFs) of the oracle's range; `eps` = twice the measured
+        confidence-map error is the only slack anything below gets;
+      * every oracle peak has a device peak of its channel within 0.5 px -- or it is a decision on nearly equal numbers, read off
+        the ORACLE's own map: its value within eps of the threshold, or a neighbouring cell within eps of it (which of two nearly
+        equal cells is "the" strict local maximum is decided by the last bits);
+      * every device peak without a partner is the same kind of decision on the DEVICE's map;
+      * frames without any such decision are identical at the instance level: count, node assignment (NaN mask), every
+        coordinate within 0.5 px.
+    The counts are printed: how many of the peaks were excused, and why."""
+    r = sleap_trained_fixture_decisions(thr, seed=11)
+    n_oracle, n_common, worst, excused, clean = r["n_oracle"], r["n_common"], r["worst"], r["excused"], r["clean"]
+    print(f"SLEAP-trained fixture at threshold {thr}: map errors {r['err']} (eps {r['eps']:.2e}); {n_common} of {n_oracle} oracle peaks have a "
+          f"device peak within 0.5 px (max {worst:.4f} px); excused {excused}; frames without a decision {clean}: {r['inst_peaks']} "
+          f"instance peaks compared, max {r['inst_worst']:.4f} px")
+    assert worst <= 0.5 and r["inst_worst"] <= 0.5
     budget = 0.05 * n_oracle + 2  # (the oracle's map has 23 of 480 maxima with a margin below 3e-3 at 0.5, 2 of 24 at 0.9)
     assert n_common >= n_oracle - budget, (n_common, n_oracle, excused)
     assert sum(excused.values()) <= 2 * budget, excused
