@@ -21,11 +21,12 @@ for thr in (0.5, 0.9):
             continue
         print(f"threshold {thr} seed {seed}: {r['n_common']} of {r['n_oracle']} peaks within 0.5 px (max {r['worst']:.4f}); excused "
               f"{sum(r['excused'].values())} {r['excused']}; frames without a decision {r['clean']}: {r['inst_peaks']} instance peaks, max "
-              f"{r['inst_worst']:.4f} px; map errors cms {r['err']['cms']:.2e} pafs {r['err']['pafs']:.2e} offsets {r['err']['offsets']:.2e}")
+              f"{r['inst_worst']:.4f} px; matching decisions {r['matching']}; map errors cms {r['err']['cms']:.2e} pafs {r['err']['pafs']:.2e} offsets {r['err']['offsets']:.2e}")
         tot.setdefault(thr, []).append(r)
 for thr, rs in tot.items():
     ok = [r for r in rs if r]
     print(f"threshold {thr}: {len(ok)} of {len(rs)} seeds without an unexplained difference; {sum(r['n_common'] for r in ok)} of "
           f"{sum(r['n_oracle'] for r in ok)} oracle peaks within 0.5 px (max {max(r['worst'] for r in ok):.4f}), "
           f"{sum(sum(r['excused'].values()) for r in ok)} excused; {sum(len(r['clean']) for r in ok)} of {6 * len(ok)} frames compared at "
-          f"instance level: {sum(r['inst_peaks'] for r in ok)} instance peaks, max {max(r['inst_worst'] for r in ok):.4f} px")
+          f"instance level: {sum(r['inst_peaks'] for r in ok)} instance peaks, max {max(r['inst_worst'] for r in ok):.4f} px; frames with equal "
+          f"peak sets and a different MATCHING: {sum(len(r['matching']) for r in ok)}")

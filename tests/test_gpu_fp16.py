@@ -207,7 +207,7 @@ def sleap_trained_fixture_decisions(thr, seed=11):
         pafs, [pts[si == b] for b in range(B)], [vals[si == b] for b in range(B)], [ci[si == b] for b in range(B)])
     n_common, worst, excused = 0, 0.0, {"oracle-only: threshold": 0, "oracle-only: neighbour tie": 0,
                                         "device-only: threshold": 0, "device-only: neighbour tie": 0}
-    clean, inst_peaks, inst_worst = [], 0, 0.0
+    clean, inst_peaks, inst_worst, matching = [], 0, 0.0, []
     for b in range(B):
         m = si == b
         wp, wv, wc = pts[m], vals[m], ci[m]
@@ -246,18 +246,39 @@ def sleap_trained_fixture_decisions(thr, seed=11):
                 excused["device-only: neighbour tie"] += 1
         if not same:
             continue
-        clean.append(b)
         want = np.asarray(ref[0][b]).reshape(-1, 2, 2)
         got = o["instance_peaks"][b, : int(o["n_valid"][b])]
-        assert got.shape == want.shape, f"frame {b}: same peaks, {len(got)} instances instead of {len(want)}"
-        assert np.array_equal(np.isnan(got), np.isnan(want)), f"frame {b}: same peaks, different node assignment"
+        same_inst = (got.shape == want.shape and np.array_equal(np.isnan(got), np.isnan(want))
+                     and (not np.isfinite(got).any() or float(np.nanmax(np.linalg.norm(got - want, axis=-1))) <= 0.5))
+        if not same_inst:
+            # the SAME peaks grouped differently: a decision of the MATCHING stage (Hungarian assignment on PAF line scores that the
+            # two paths compute from maps 7e-3 apart). Described in the oracle's own scores: every connection only one side made,
+            # with the score the oracle gives it -- a near tie shows as nearly equal sums.
+            def pairs(inst):
+                out = set()
+                for a, b_ in inst:
+                    ia = [int(np.argmin(np.linalg.norm(wp - q, axis=-1) + 1e6 * (wc != ch))) if np.isfinite(q).all() else -1
+                          for ch, q in ((0, a), (1, b_))]
+                    if min(ia) >= 0:
+                        out.add(tuple(ia))
+                return out
+
+            score = {(int(p_[0]), int(p_[1])): float(v_) for p_, v_ in zip(np.asarray(ref[4][b]).reshape(-1, 2), np.asarray(ref[5][b]).reshape(-1))}
+            po, pd = pairs(want), pairs(got)
+            only_o, only_d = sorted(po - pd), sorted(pd - po)
+            matching.append(dict(frame=b, oracle_only=[(q, round(score.get(q, float("nan")), 4)) for q in only_o],
+                                 device_only=[(q, round(score.get(q, float("nan")), 4)) for q in only_d],
+                                 oracle_sum=round(sum(score.get(q, 0.0) for q in only_o), 4),
+                                 device_sum_in_oracle_scores=round(sum(score.get(q, 0.0) for q in only_d), 4)))
+            continue
+        clean.append(b)
         d = np.linalg.norm(got - want, axis=-1)
         d = d[np.isfinite(d)]
         inst_peaks += d.size
         if d.size:
             inst_worst = max(inst_worst, float(d.max()))
     return dict(thr=thr, seed=seed, err=err, eps=eps, n_oracle=len(pts), n_common=n_common, worst=worst, excused=excused, clean=clean,
-                inst_peaks=inst_peaks, inst_worst=inst_worst)
+                inst_peaks=inst_peaks, inst_worst=inst_worst, matching=matching)
 @pytest.mark.parametrize("thr", [0.5, 0.9])
 def test_sleap_trained_bottomup_fixture_differences_are_last_bit_decisions(thr):
     """The ONE bottom-up model SLEAP itself trained (`minimal_instance.UNet.bottomup`, the reference's fixture of
@@ -282,6 +303,7 @@ def test_sleap_trained_bottomup_fixture_differences_are_last_bit_decisions(thr):
           f"device peak within 0.5 px (max {worst:.4f} px); excused {excused}; frames without a decision {clean}: {r['inst_peaks']} "
           f"instance peaks compared, max {r['inst_worst']:.4f} px")
     assert worst <= 0.5 and r["inst_worst"] <= 0.5
+    assert not r["matching"], r["matching"]  # (seed 11: none; tests/diagnostics/fixture_sweep.py reports the rate over more seeds)
     budget = 0.05 * n_oracle + 2  # (the oracle's map has 23 of 480 maxima with a margin below 3e-3 at 0.5, 2 of 24 at 0.9)
     assert n_common >= n_oracle - budget, (n_common, n_oracle, excused)
     assert sum(excused.values()) <= 2 * budget, excused
