@@ -276,7 +276,8 @@ int sa_conv3x3_bf16(const void* src0, int C0P, const void* src1, int C1P, int mo
 /* One encoder block in one launch: Conv2D(k3, 16 -> 32)+bias+ReLU -> Conv2D(k3, 32 -> 32)+bias+ReLU [-> dst] [-> MaxPool2D(2)
  * -> dst_pool] (encoder_decoder.py:109-131). The 32-channel intermediate lives only in LDS (bf16, the rounding a stored tensor
  * would get); results are bitwise those of two sa_conv3x3_bf16 calls. wa / wb: sa_pack_conv3x3_weights of the two kernels.
- * Only C0P = 16, C1P = C2P = 32 is implemented (SA_ERR_UNSUPPORTED otherwise). */
+ * Implemented: C0P = 16, C1P = C2P = 32 (block 1; csrc/convpair.hip) and, round 6, C0P = 32, C1P = C2P = 64 (block 2;
+ * csrc/convpair64.hip: one persistent 158.5-KiB workgroup per CU, src / dst / dst_pool in `layout`); SA_ERR_UNSUPPORTED otherwise. */
 int sa_conv3x3_pair_bf16(const void* src, int C0P, const void* wa, const float* bias_a, int relu_a, int C1P,
                          const void* wb, const float* bias_b, int relu_b, int C2P, int B, int H, int W, void* dst,
                          void* dst_pool, int layout, sa_stream_t stream);

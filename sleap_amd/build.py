@@ -29,6 +29,7 @@ SOURCES = [
     #  total = two waves per SIMD; in VGPRs 124-156 = three)
     ("tapconv.hip", ["-fno-honor-nans", "-mllvm", "-amdgpu-mfma-vgpr-form"]),
     ("convpair.hip", ["-fno-honor-nans"]),
+    ("convpair64.hip", ["-fno-honor-nans"]),
     ("imgconv.hip", ["-fno-honor-nans", "-std=c++20", "-mllvm", "-amdgpu-mfma-vgpr-form"]),
     # sparse pyramidal Lucas-Kanade flow of the flow tracker: float32 op by op as the scalar CPU code it restates
     ("flow.hip", ["-ffp-contract=off"]),

@@ -1827,6 +1827,8 @@ int launch_mode(const ConvParams& p, int mode, hipStream_t st) {
 
 }  // namespace
 
+int sa_internal_grid_limit() { return g_grid_limit; }
+
 static int conv3x3_impl(const void* src0, int C0P, const void* src1, int C1P, int mode, const void* w,
                         const float* bias, int CoutP, int relu, int B, int H, int W, void* dst, void* dst_pool,
                         int n_heads, const float* const* head_w, const float* const* head_b, const int* head_c,

@@ -573,16 +573,22 @@ convpair_persist_kernel(const PairParams p, int n_tiles) {
 
 }  // namespace
 
+// convpair64.hip: the 32 -> 64 -> 64 block (one persistent workgroup per CU)
+int sa_convpair64_launch(const void* src, const void* wa, const float* bias_a, int relu_a, const void* wb, const float* bias_b,
+                         int relu_b, int B, int H, int W, void* dst, void* dst_pool, int layout, hipStream_t stream);
+
 extern "C" int sa_conv3x3_pair_bf16(const void* src, int C0P, const void* wa, const float* bias_a, int relu_a, int C1P,
                                     const void* wb, const float* bias_b, int relu_b, int C2P, int B, int H, int W, void* dst,
                                     void* dst_pool, int layout, sa_stream_t stream) {
   SA_REQUIRE(src && wa && wb && bias_a && bias_b && (dst || dst_pool), "sa_conv3x3_pair_bf16: NULL pointer");
-  if (C0P != 16 || C1P != 32 || C2P != 32)
-    return sa::fail(SA_ERR_UNSUPPORTED, "sa_conv3x3_pair_bf16: only the 16 -> 32 -> 32 block is implemented (got %d -> %d -> %d)",
+  const bool is64 = C0P == 32 && C1P == 64 && C2P == 64;
+  if (!is64 && (C0P != 16 || C1P != 32 || C2P != 32))
+    return sa::fail(SA_ERR_UNSUPPORTED, "sa_conv3x3_pair_bf16: only the 16 -> 32 -> 32 and 32 -> 64 -> 64 blocks are implemented (got %d -> %d -> %d)",
                     C0P, C1P, C2P);
   SA_REQUIRE(B > 0 && H > 0 && W > 0, "sa_conv3x3_pair_bf16: bad shape");
   SA_REQUIRE(layout == SA_LAYOUT_NHWC || layout == SA_LAYOUT_PLANES16, "sa_conv3x3_pair_bf16: bad layout");
   SA_REQUIRE(!dst_pool || (H % 2 == 0 && W % 2 == 0), "sa_conv3x3_pair_bf16: pooled output needs even H, W");
+  if (is64) return sa_convpair64_launch(src, wa, bias_a, relu_a, wb, bias_b, relu_b, B, H, W, dst, dst_pool, layout, (hipStream_t)stream);
   SA_REQUIRE((size_t)H * W * 32 < 0xFFFFFF00ull, "sa_conv3x3_pair_bf16: one frame must be smaller than 4 GiB");
   PairParams p;
   p.src = (const uint16_t*)src;

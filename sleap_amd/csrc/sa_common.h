@@ -25,6 +25,9 @@ inline int fail(int code, const char* fmt, ...) {
 
 }  // namespace sa
 
+// internal (not ABI): the workgroup limit of sa_conv3x3_set_grid_limit (conv3x3.hip), honoured by every persistent kernel
+int sa_internal_grid_limit();
+
 #define SA_HIP_CHECK(expr)                                                                   \
   do {                                                                                       \
     hipError_t _e = (expr);                                                                  \

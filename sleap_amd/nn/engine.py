@@ -862,21 +862,25 @@ class DeviceNetwork:
         return out
 
     def _fuse_pairs(self, plan):
-        """conv(16 -> 32) whose only reader is a conv(32 -> 32) -> one launch (sa_conv3x3_pair_bf16); the intermediate tensor
-        is never allocated. Plain convs only (no concat / pooled-source / heads / extended epilogue on either)."""
+        """conv(16 -> 32) whose only reader is a conv(32 -> 32), or (round 6) conv(32 -> 64) whose only reader is a conv(64 -> 64)
+        -> one launch (sa_conv3x3_pair_bf16); the intermediate tensor is never allocated. Plain convs only (no concat /
+        pooled-source / heads / extended epilogue on either). SA_FUSE_PAIRS64=0 keeps the second form as two launches (A/B)."""
         out = list(plan)
+        shapes = {(16, 32, 32)}
+        if os.environ.get("SA_FUSE_PAIRS64", "1") != "0":
+            shapes.add((32, 64, 64))
 
         def plain(op):
             return (op[0] == "conv" and op.src1 is None and op.mode == _lib.SRC1_NONE and not op.heads and op.ext is None)
 
         for x in list(out):
-            if not plain(x) or x.src0.cp != 16 or x.out.cp != 32 or x.out_pool is not None or x.out.buf is None:
+            if not plain(x) or x.out_pool is not None or x.out.buf is None:
                 continue
             readers = [q for q in out if any(t is x.out for t in self._reads(q))]
             if len(readers) != 1 or not plain(readers[0]):
                 continue
             y = readers[0]
-            if y.src0 is not x.out or y.out.cp != 32 or any(x.out is o for o in self.outputs):
+            if y.src0 is not x.out or (x.src0.cp, x.out.cp, y.out.cp) not in shapes or any(x.out is o for o in self.outputs):
                 continue
             i = next(k for k, q in enumerate(out) if q is y)
             out[i] = ["pair", x, y]

@@ -16,6 +16,7 @@ pytestmark = pytest.mark.gpu
 
 # the suite follows the storage type of the library build under test (SLEAP_AMD_DTYPE, default fp16); the tolerances below were
 # written for bf16 (8 mantissa bits) and hold a fortiori for fp16 (11)
+from parity_helpers import STORAGE_DTYPES  # noqa: E402
 from sleap_amd import _lib as _L  # noqa: E402
 
 TD = {"bf16": torch.bfloat16, "fp16": torch.float16}[_L.DEFAULT_DTYPE]
@@ -366,6 +367,51 @@ def test_conv_pair_is_bitwise_two_convs(B, H, W, full, pooled, layout):
     check(_lib.lib().sa_conv3x3_pair_bf16(_ptr(x), 16, _ptr(wa), _ptr(ba), 1, 32, _ptr(wb), _ptr(bb), 1, 32, B, H, W, _ptr(out),
                                           _ptr(outp), lay, _stream()), "sa_conv3x3_pair_bf16")
     back = ops.from_planes16 if lay else (lambda t: t)
+    if full:
+        assert torch.equal(back(out), ref[0])
+    if pooled:
+        assert torch.equal(back(outp), ref[1])
+
+
+@pytest.mark.parametrize("dtype", STORAGE_DTYPES)
+@pytest.mark.parametrize("layout", ["nhwc", "planes16"])
+@pytest.mark.parametrize("B,H,W,full,pooled,limit", [
+    (2, 32, 64, True, True, 0), (1, 48, 96, False, True, 0), (2, 16, 32, True, False, 0), (1, 37, 45, True, False, 0),
+    (1, 18, 34, True, True, 0),       # ragged right / bottom tiles whose halo is mostly outside the image
+    (3, 64, 160, True, True, 9),      # 60 tiles on 9 workgroups: 6-7 tiles each, XCD ranges of uneven length
+    (5, 128, 128, True, True, 0),     # 160 tiles, one per workgroup
+    (2, 256, 256, False, True, 0)])   # 256 tiles at the benchmark layer's size
+def test_conv_pair64_is_bitwise_two_convs(B, H, W, full, pooled, limit, layout, dtype):
+    """Round 6: the 32 -> 64 -> 64 form of sa_conv3x3_pair_bf16 (encoder block 2, csrc/convpair64.hip: one persistent workgroup
+    per CU, the 64-channel intermediate only in LDS) == sa_conv3x3_bf16 twice, bit for bit -- same rounding of the intermediate,
+    same MFMA accumulation order (chunk-major, taps inside); image borders, ragged tiles, several tiles per workgroup
+    (sa_conv3x3_set_grid_limit), both layouts, both storage types. Outputs are poisoned first: a skipped tile must not pass."""
+    from sleap_amd import _lib, ops
+    from sleap_amd._lib import check
+    from sleap_amd.ops import _ptr, _stream
+
+    td = torch.float16 if dtype == "fp16" else torch.bfloat16
+    g = torch.Generator(device="cpu").manual_seed(H * 10 + W)
+    ka = torch.randn((3, 3, 32, 64), generator=g) * (2.0 / (9 * 32)) ** 0.5
+    kb = torch.randn((3, 3, 64, 64), generator=g) * (2.0 / (9 * 64)) ** 0.5
+    ba, bb = (0.1 * torch.randn((64,), generator=g)).cuda(), (0.1 * torch.randn((64,), generator=g)).cuda()
+    x = ops.to_bf16_padded(torch.randn((B, H, W, 32), generator=g).cuda(), dtype=dtype)
+    wa, wb = ops.pack_conv3x3_weights(ka.numpy(), 32, dtype=dtype), ops.pack_conv3x3_weights(kb.numpy(), 64, dtype=dtype)
+    mid = ops.conv3x3(x, None, 0, wa, ba, 64, True, (H, W))
+    ref = ops.conv3x3(mid, None, 0, wb, bb, 64, True, (H, W), full=full, pooled=pooled)
+    ref = ref if isinstance(ref, tuple) else ((ref, None) if full else (None, ref))
+    out = torch.full((B, H, W, 64), float("nan"), dtype=td, device="cuda") if full else None
+    outp = torch.full((B, H // 2, W // 2, 64), float("nan"), dtype=td, device="cuda") if pooled else None
+    planes = layout == "planes16"
+    lay = _lib.LAYOUT_PLANES16 if planes else _lib.LAYOUT_NHWC
+    h = _lib.lib(dtype)
+    h.sa_conv3x3_set_grid_limit(limit)
+    try:
+        check(h.sa_conv3x3_pair_bf16(_ptr(ops.to_planes16(x) if planes else x), 32, _ptr(wa), _ptr(ba), 1, 64, _ptr(wb), _ptr(bb), 1, 64,
+                                     B, H, W, _ptr(out), _ptr(outp), lay, _stream()), "sa_conv3x3_pair_bf16")
+    finally:
+        h.sa_conv3x3_set_grid_limit(0)
+    back = ops.from_planes16 if planes else (lambda t: t)
     if full:
         assert torch.equal(back(out), ref[0])
     if pooled:
