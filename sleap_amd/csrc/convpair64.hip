@@ -17,8 +17,8 @@
 //   A1  conv-a, input channels 16-31 (plane 1, slot 1), epilogue a  queues: conv-b chunk 0 -> slot 0, NEXT tile's input plane 0
 //   B0..B3  conv-b, intermediate channels 16c..16c+15 (slot c & 1)  queues: chunk c+1 (B3: the next tile's conv-a k-half 0),
 //                                                                           B0 also the next tile's input plane 1
-//   epilogue b (stores) -- behind a wait for the copies queued in B3, so that no later wait ever sees a store (gfx9 counts
-//   loads and stores in one vmcnt; the stores drain under the next tile's A0).
+//   epilogue b -- ReLU, 2 x 2 max and rounding on packed pairs; the 12 store instructions per wave are DEFERRED into the next
+//   tile's A0, one behind each tap's MFMAs (conv-a k-half 1 is queued in front of them and waited for with a counted vmcnt).
 // LDS map (bytes):
 //   [0, 78336)         intermediate tile as FOUR 16-channel planes of 18 x 34 pixels x 32 B (what a stage of conv3x3_dma_kernel
 //                      holds: phase B's inner loop is that kernel's), 16-byte slot XOR (column >> 3) & 1
@@ -68,6 +68,33 @@ constexpr int LDS_BYTES = BIAS_OFF + 128 * 4;
 static_assert(LDS_BYTES <= 160 * 1024, "one workgroup per CU: 160 KiB");
 constexpr unsigned OOB = 0xFFFFFF00u;
 
+// SA_PAIR64_STAMP (an instrumented A/B build, tools/pair64_probe.py -- never the product library): every wave sums the shader
+// cycles (s_memtime) of the segments of its tiles and adds them to g_stamp64 at its end: [0] waves, [1] tiles, [2] life,
+// [3] A bodies, [4] epilogue a, [5] B bodies, [6] epilogue b (behind its wait), [8 + i] the wait + barrier in front of stage i
+// (A0, A1, B0..B3), [14] the wait in front of epilogue b, [15] tile set-up (accumulator init, decode), [16 + i] the memory wait alone
+// ([8 + i] is then the barrier alone), [22] epilogue b up to its first store.
+#if defined(SA_PAIR64_STAMP)
+__device__ unsigned long long g_stamp64[24];
+#define ST_DECL unsigned long long st_t = __builtin_readcyclecounter(), st_t0 = st_t, st_a[24] = {0}
+#define ST(i)                                                       \
+  do {                                                              \
+    const unsigned long long st_now = __builtin_readcyclecounter(); \
+    st_a[i] += st_now - st_t;                                       \
+    st_t = st_now;                                                  \
+  } while (0)
+#define ST_FLUSH                                                                            \
+  do {                                                                                      \
+    if ((threadIdx.x & 63) == 0) {                                                          \
+      st_a[0] = 1, st_a[2] = __builtin_readcyclecounter() - st_t0;                          \
+      for (int i_ = 0; i_ < 24; ++i_) atomicAdd(&g_stamp64[i_], st_a[i_]);                  \
+    }                                                                                       \
+  } while (0)
+#else
+#define ST_DECL
+#define ST(i)
+#define ST_FLUSH
+#endif
+
 __global__ void __launch_bounds__(NW * 64, 2)
 convpair64_kernel(const Pair64Params p) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -76,7 +103,6 @@ convpair64_kernel(const Pair64Params p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int half = lane >> 5, lx = lane & 31;
   const int H = p.H, W = p.W;
-  const float* bias_lds = reinterpret_cast<const float*>(smem + BIAS_OFF);
 
   // ---- tile schedule: a contiguous range of the (frame, tile row, tile column) order per XCD (block i runs on XCD i % 8), the
   // j-th workgroup of an XCD walks start + j, start + j + g8, ...
@@ -122,10 +148,12 @@ convpair64_kernel(const Pair64Params p) {
   };
   // per-lane source offsets of this wave's (up to) three copy pieces of an input plane (the same for both planes)
   auto make_voff = [&](const Tile& t, unsigned (&v)[3]) {
+    int ln = lane;  // (an opaque copy: what is derived from it is re-derived per tile, not kept in registers across the stages)
+    asm volatile("" : "+v"(ln));
 #pragma unroll
     for (int jj = 0; jj < 3; ++jj) {
       const int i = jj * NW + wave;
-      const int o = i * 1024 + lane * 16;
+      const int o = i * 1024 + ln * 16;
       const int pl = o >> 5, s = (o >> 4) & 1;
       const int ty = pl / QW, tx = pl - ty * QW;
       const int gy = t.y0 + ty - 2, gx = t.x0 + tx - 2;
@@ -158,18 +186,24 @@ convpair64_kernel(const Pair64Params p) {
   const int m_x = wave & 1;
   const int xg = 16 + (wave >> 1);
   const bool x_rows = xg < 18;  // wave uniform
-  const int xq = (xg - 18) * 32 + lx;
-  const bool xvalid = x_rows || xq < 2 * PH;
-  const int xqc = (!x_rows && xq < 2 * PH) ? xq : 0;
-  const int xrow = x_rows ? xg : xqc >> 1, xcol = x_rows ? lx : 32 + (xqc & 1);
+  struct XPix {
+    int row, col;
+    bool valid;
+  };
+  auto xpix = [&](int lx_) {
+    const int xq = (xg - 18) * 32 + lx_;
+    const int xqc = (!x_rows && xq < 2 * PH) ? xq : 0;
+    return XPix{x_rows ? xg : xqc >> 1, x_rows ? lx_ : 32 + (xqc & 1), x_rows || xq < 2 * PH};
+  };
   unsigned xoff[3];
+  {
+    const XPix xp = xpix(lx);
 #pragma unroll
-  for (int dx = 0; dx < 3; ++dx) {
-    const int c = xcol + dx;
-    xoff[dx] = (unsigned)(xrow * IN_ROW + c * 32 + ((half ^ ((c >> 3) & 1)) * 16));
+    for (int dx = 0; dx < 3; ++dx) {
+      const int c = xp.col + dx;
+      xoff[dx] = (unsigned)(xp.row * IN_ROW + c * 32 + ((half ^ ((c >> 3) & 1)) * 16));
+    }
   }
-  const unsigned xwoff = (unsigned)(xrow * IP_ROW + xcol * 32 + ((half ^ ((xcol >> 3) & 1)) * 16));
-  const unsigned woff = (unsigned)(2 * wave * IP_ROW + lx * 32 + ((half ^ ((lx >> 3) & 1)) * 16));  // big item: row 2 wave, column lx
   const float low_a = p.relu_a ? 0.0f : -INFINITY, low_b = p.relu_b ? 0.0f : -INFINITY;
   const unsigned pixb_out = p.planar ? 32u : 128u;
 
@@ -184,23 +218,22 @@ convpair64_kernel(const Pair64Params p) {
 #define SA_WAIT_VM_LGKM0(n) __builtin_amdgcn_s_waitcnt(0x0070 | (n))
   // One stage of MFMAs: nine taps on the B fragments of halo rows 0..3 x columns 0..2 (read ONCE, up front) and the slot's A
   // fragments (read one tap ahead); XTRA (conv-a) adds the wave's extra unit: one more pixel group x one cout tile, its two
-  // fragments read one tap ahead as well. sched_barrier(0) between the taps keeps the compiler from sinking the reads down to
+  // fragments read one tap ahead as well; `between(tap)` runs behind the MFMAs of a tap. sched_barrier(0) between the taps keeps the compiler from sinking the reads down to
   // their uses (it did: three fragments in flight, a wait in front of every MFMA pair).
   auto stage = [&](auto xtra_c, const unsigned char* bb, const unsigned (&off)[3], int row_bytes, const unsigned char* wt,
-                   f32x16 (&acc)[2][R], f32x16& accx) {
+                   f32x16 (&acc)[2][R], f32x16& accx, auto&& between) {
     constexpr bool XTRA = decltype(xtra_c)::value;
     const unsigned char* wl = wt + lane * 16;
-    mfma_h8 bfr[R + 2][3], a[2][2], xa[2], xb[2];
+    mfma_h8 bfr[R + 2][3], a[2][2], xa, xb;
     a[0][0] = *reinterpret_cast<const mfma_h8*>(wl);
     a[0][1] = *reinterpret_cast<const mfma_h8*>(wl + 9 * 1024);
+    // halo rows 0, 1 up front; rows 2, 3 one fragment per tap, three taps ahead of their first use (36 fragment registers live
+    // instead of 48: room for the deferred stores' 48)
 #pragma unroll
-    for (int rr = 0; rr < R + 2; ++rr)
+    for (int rr = 0; rr < 2; ++rr)
 #pragma unroll
       for (int dx = 0; dx < 3; ++dx) bfr[rr][dx] = *reinterpret_cast<const mfma_h8*>(bb + off[dx] + rr * row_bytes);
-    if constexpr (XTRA) {
-      xa[0] = *reinterpret_cast<const mfma_h8*>(wl + (m_x * 9) * 1024);
-      xb[0] = *reinterpret_cast<const mfma_h8*>(bb + xoff[0]);
-    }
+    between(-1);  // (while the first fragments are on their way)
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
@@ -208,35 +241,81 @@ convpair64_kernel(const Pair64Params p) {
       if (tap < 8) {
         a[nb][0] = *reinterpret_cast<const mfma_h8*>(wl + (tap + 1) * 1024);
         a[nb][1] = *reinterpret_cast<const mfma_h8*>(wl + (9 + tap + 1) * 1024);
-        if constexpr (XTRA) {
-          xa[nb] = *reinterpret_cast<const mfma_h8*>(wl + (m_x * 9 + tap + 1) * 1024);
-          xb[nb] = *reinterpret_cast<const mfma_h8*>(bb + xoff[(tap + 1) % 3] + ((tap + 1) / 3) * IN_ROW);
-        }
       }
+      if constexpr (XTRA) {  // the extra unit's fragments: read at the head of the tap, used behind its four other MFMAs
+        xa = *reinterpret_cast<const mfma_h8*>(wl + (m_x * 9 + tap) * 1024);
+        xb = *reinterpret_cast<const mfma_h8*>(bb + xoff[dx] + dy * IN_ROW);
+      }
+      if (tap < 6) bfr[2 + tap / 3][tap % 3] = *reinterpret_cast<const mfma_h8*>(bb + off[tap % 3] + (2 + tap / 3) * row_bytes);
+      __builtin_amdgcn_sched_barrier(0);  // (reads first: left alone the scheduler puts them behind the tap's third MFMA)
+#if defined(SA_PAIR64_PRIO)
+      // the two waves of a SIMD (w, w + 4) take turns at the matrix pipe tap by tap: at equal priority the OLDER wave is served
+      // first throughout, finishes its stage in half the time and waits at the barrier while the younger one runs alone
+      if (((tap ^ (wave >> 2)) & 1)) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);  // (wave uniform)
+#endif
 #pragma unroll
       for (int r = 0; r < R; ++r) {
         acc[0][r] = SA_MFMA_32x32x16(a[cb][0], bfr[r + dy][dx], acc[0][r], 0, 0, 0);
         acc[1][r] = SA_MFMA_32x32x16(a[cb][1], bfr[r + dy][dx], acc[1][r], 0, 0, 0);
       }
-      if constexpr (XTRA) accx = SA_MFMA_32x32x16(xa[cb], xb[cb], accx, 0, 0, 0);
+      if constexpr (XTRA) accx = SA_MFMA_32x32x16(xa, xb, accx, 0, 0, 0);
+      between(tap);  // (the previous tile's deferred stores, one piece per tap: issued in the shadow of this tap's MFMAs)
       __builtin_amdgcn_sched_barrier(0);
     }
   };
+  auto nothing = [](int) {};
   f32x16 accA[2][R], accX;
+  // Bias reads are OPAQUE ds_reads (inline asm) behind one explicit lgkmcnt(0): in front of a C++ load from LDS the compiler drains
+  // vmcnt whenever it believes a copy in flight whose target it cannot tell from the load's address -- it cannot follow the
+  // counted waits below across the `pend` branches -- and with it the deferred stores.
+  typedef float f32x4v __attribute__((ext_vector_type(4)));
+  const unsigned bias_addr = (unsigned)(uintptr_t)(lds_ptr_t)(smem + BIAS_OFF) + (unsigned)half * 16u;
+#define SA_LDS_READ4(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off) : "memory")
   auto init_a = [&]() {  // conv-a's accumulators start at its bias
+    f32x4v bq[2][4], bx[4];
+    const unsigned ax = bias_addr + (unsigned)m_x * 128u;
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      SA_LDS_READ4(bq[m][0], bias_addr, 0 + 128 * m);
+      SA_LDS_READ4(bq[m][1], bias_addr, 32 + 128 * m);
+      SA_LDS_READ4(bq[m][2], bias_addr, 64 + 128 * m);
+      SA_LDS_READ4(bq[m][3], bias_addr, 96 + 128 * m);
+    }
+    SA_LDS_READ4(bx[0], ax, 0);
+    SA_LDS_READ4(bx[1], ax, 32);
+    SA_LDS_READ4(bx[2], ax, 64);
+    SA_LDS_READ4(bx[3], ax, 96);
+    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+          for (int r = 0; r < R; ++r) accA[m][r][4 * g + j] = bq[m][g][j];
+        accX[4 * g + j] = bx[g][j];
+      }
+    }
+  };
+  auto init_b = [&](f32x16 (&acc)[2][R]) {  // conv-b's
+    f32x4v bq[2][4];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      SA_LDS_READ4(bq[m][0], bias_addr, 256 + 128 * m);
+      SA_LDS_READ4(bq[m][1], bias_addr, 288 + 128 * m);
+      SA_LDS_READ4(bq[m][2], bias_addr, 320 + 128 * m);
+      SA_LDS_READ4(bq[m][3], bias_addr, 352 + 128 * m);
+    }
+    __builtin_amdgcn_s_waitcnt(0xC07F);
 #pragma unroll
     for (int m = 0; m < 2; ++m)
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const float4 bq = *reinterpret_cast<const float4*>(bias_lds + m * 32 + 8 * g + 4 * half);
+      for (int g = 0; g < 4; ++g)
 #pragma unroll
-        for (int r = 0; r < R; ++r) accA[m][r][4 * g + 0] = bq.x, accA[m][r][4 * g + 1] = bq.y, accA[m][r][4 * g + 2] = bq.z, accA[m][r][4 * g + 3] = bq.w;
-      }
+        for (int j = 0; j < 4; ++j)
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const float4 bq = *reinterpret_cast<const float4*>(bias_lds + m_x * 32 + 8 * g + 4 * half);
-      accX[4 * g + 0] = bq.x, accX[4 * g + 1] = bq.y, accX[4 * g + 2] = bq.z, accX[4 * g + 3] = bq.w;
-    }
+          for (int r = 0; r < R; ++r) acc[m][r][4 * g + j] = bq[m][g][j];
   };
 
   // ---- once per workgroup: biases -> LDS, the first tile's copies
@@ -251,48 +330,150 @@ convpair64_kernel(const Pair64Params p) {
   }
   SA_WAIT_VM(0);
   __syncthreads();  // the biases are in LDS for every wave
+  ST_DECL;
 
+  // ---- conv-b's outputs of a tile, packed to the storage type (ReLU and the 2 x 2 max applied), and their stores. The stores
+  // of tile t are DEFERRED into stage A0 of tile t + 1, one 16-byte piece per lane behind each tap's MFMAs: as an epilogue of
+  // their own they cost 5-7 k cycles per tile during which no wave of the CU issues an MFMA (the whole workgroup reaches the
+  // epilogue together: there is no second workgroup to cover it -- profiles/r06_pair64_stamps.md).
+  uint2 pkf[2][R][4];  // [cout tile][row][4-channel group]
+  // max of two packed pairs of the storage type. Rounding is monotonic, so the max of ROUNDED values is the rounded max (the
+  // bits the fp32 form produces, up to the sign of a zero): ReLU and the 2 x 2 max run on the packed values.
+  auto pkmax = [](uint32_t u, uint32_t v) -> uint32_t {
+#if SA_HAS_PK_MAX
+    return sa::pk_max(u, v);
+#else
+    const float a0 = sa::h2f((uint16_t)u), a1 = sa::h2f((uint16_t)(u >> 16)), b0 = sa::h2f((uint16_t)v), b1 = sa::h2f((uint16_t)(v >> 16));
+    return sa::f2h2(fmaxf(a0, b0), fmaxf(a1, b1));  // (bf16 -> f32 is exact: the same values back)
+#endif
+  };
+  auto pack_b = [&](const f32x16 (&acc)[2][R]) {
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+#if SA_HAS_PK_MAX
+          const uint32_t lowpk = p.relu_b ? 0u : SA_PK_NEG_INF;
+          pkf[m][r][g].x = sa::pk_max(sa::f2h2(acc[m][r][4 * g + 0], acc[m][r][4 * g + 1]), lowpk);
+          pkf[m][r][g].y = sa::pk_max(sa::f2h2(acc[m][r][4 * g + 2], acc[m][r][4 * g + 3]), lowpk);
+#else
+          pkf[m][r][g].x = sa::f2h2(fmaxf(acc[m][r][4 * g + 0], low_b), fmaxf(acc[m][r][4 * g + 1], low_b));
+          pkf[m][r][g].y = sa::f2h2(fmaxf(acc[m][r][4 * g + 2], low_b), fmaxf(acc[m][r][4 * g + 3], low_b));
+#endif
+        }
+  };
+  auto pool2 = [&](uint32_t u, uint32_t v) -> uint32_t {  // rows: the wave's two; columns: lanes l, l ^ 1
+    const uint32_t t = pkmax(u, v);
+    return pkmax(t, (uint32_t)__builtin_amdgcn_update_dpp((int)t, (int)t, 0xB1, 0xF, 0xF, false));
+  };
+  const size_t blk_full = p.planar ? (size_t)H * W * 32 : (size_t)32, blk_pool = p.planar ? (size_t)(H / 2) * (W / 2) * 32 : (size_t)32;
+  // piece i of the full-resolution output: cout tile i >> 2, row (i >> 1) & 1, 16-channel block i & 1 of the cout tile
+  int ln_s = lane;  // (opaque per tile, see the loop: the stores' lane offsets are not kept across the stages)
+  auto store_full = [&](const Tile& t, int i, auto checked_c) {
+    const int m = i >> 2, r = (i >> 1) & 1, pr = i & 1;
+    const int gy = t.y0 + wave * R + r, gx = t.x0 + (ln_s & 31);  // gy wave uniform
+    uint2 x = pkf[m][r][2 * pr], y = pkf[m][r][2 * pr + 1];
+    sa::swap32(x.x, y.x);
+    sa::swap32(x.y, y.y);
+    unsigned char* base = reinterpret_cast<unsigned char*>(p.dst) + (size_t)t.b * H * W * 128 + (size_t)(2 * m + pr) * blk_full +
+                          (size_t)gy * W * pixb_out;
+    const unsigned lane_off = (unsigned)gx * pixb_out + (unsigned)(ln_s >> 5) * 16u;
+    if (!decltype(checked_c)::value || (gx < W && gy < H)) *reinterpret_cast<uint4*>(base + lane_off) = make_uint4(x.x, x.y, y.x, y.y);
+  };
+  // piece i of the pooled output: cout tile i >> 1, 16-channel block i & 1
+  auto store_pool = [&](const Tile& t, int i, auto checked_c) {
+    const int m = i >> 1, pr = i & 1;
+    const int gy = t.y0 + wave * R, gx = t.x0 + (ln_s & 31);
+    uint2 x, y;  // (computed here, from the full-resolution values: 16 registers less to carry into the next tile)
+    x.x = pool2(pkf[m][0][2 * pr].x, pkf[m][1][2 * pr].x), x.y = pool2(pkf[m][0][2 * pr].y, pkf[m][1][2 * pr].y);
+    y.x = pool2(pkf[m][0][2 * pr + 1].x, pkf[m][1][2 * pr + 1].x), y.y = pool2(pkf[m][0][2 * pr + 1].y, pkf[m][1][2 * pr + 1].y);
+    sa::swap32(x.x, y.x);
+    sa::swap32(x.y, y.y);
+    unsigned char* base = reinterpret_cast<unsigned char*>(p.dst_pool) + (size_t)t.b * (H / 2) * (W / 2) * 128 + (size_t)(2 * m + pr) * blk_pool +
+                          (size_t)(gy >> 1) * (W / 2) * pixb_out;
+    const unsigned lane_off = (unsigned)(gx >> 1) * pixb_out + (unsigned)(ln_s >> 5) * 16u;
+    if (!(ln_s & 1) && (!decltype(checked_c)::value || (gx < W && gy < H))) *reinterpret_cast<uint4*>(base + lane_off) = make_uint4(x.x, x.y, y.x, y.y);
+  };
+  const bool has_full = p.dst != nullptr, has_pool = p.dst_pool != nullptr;  // uniform
+
+  bool pend = false;  // the previous tile's stores are still to be issued (workgroup uniform)
+  Tile prev = cur;
 #pragma clang loop unroll(disable)
   for (;;) {
     const int L_next = L + L_step;
     const bool more = L_next < L_end;  // workgroup uniform
-    init_a();  // (LDS reads behind the previous tile's stores: the compiler knows that no LDS-DMA is in flight -- SA_WAIT_VM)
+#if defined(SA_PAIR64_STAMP)
+    st_a[1] += 1;
+#endif
+    // Memory waits of the tile loop. A stage's copies are queued at its head, the (up to) TWO deferred stores of the stage behind
+    // them: the wait in front of the NEXT stage is `vmcnt(2)` -- the copies, not the stores (the counter retires in order; a
+    // vmcnt(0) would put a store's round trip to HBM in front of every barrier). Without deferred stores it is vmcnt(0).
+    init_a();  // (this wave's copies for the tile -- conv-a k-half 0, the input planes -- were waited for at the end of the previous tile)
+    ln_s = lane;
+    asm volatile("" : "+v"(ln_s));
+    // the deferred stores of the PREVIOUS tile (`prev`), two pieces per stage: pooled 0-3 in A0 / A1, full-resolution 0-7 in B0-B3
+    auto deferred = [&](int stage_i, int tap) {
+      if (!pend || (tap != 2 && tap != 6)) return;
+      const int j = tap == 6 ? 1 : 0;
+      if (stage_i < 2)
+        store_pool(prev, 2 * stage_i + j, std::false_type{});
+      else
+        store_full(prev, 2 * (stage_i - 2) + j, std::false_type{});
+    };
 
     // ================= phase A: conv-a (32 -> 64) on the 18 x 34 halo pixels, k-halves 0 and 1
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-      if (k == 0) {
-        __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0) only: the stores of the previous epilogue stay in flight
-        __builtin_amdgcn_s_barrier();  // every wave's copies for this tile landed (each waited for its own in front of the previous epilogue / in
-                          // the prologue); the previous tile's B3 is finished (slot 1, the intermediate tile)
-        issue_w(rwa, 2, 1, 1);
-      } else {
-        SA_WAIT_VM_LGKM0(0);
-        __builtin_amdgcn_s_barrier();  // k-half 1 landed; A0 is finished (slot 0)
-        issue_w(rwb, 4, 0, 0);
-      }
-      const unsigned char* inp = smem + IN_OFF + k * IN_PLANE;
-      const unsigned char* wt = smem + RING_OFF + k * SLOT;
-      stage(std::true_type{}, inp, aoff, IN_ROW, wt, accA, accX);
-    }
+    ST(16);
+    __builtin_amdgcn_s_barrier();  // every wave's copies landed; the previous tile's B3 is finished (slot 1, the intermediate tile)
+    ST(8);
+    issue_w(rwa, 2, 1, 1);
+    stage(std::true_type{}, smem + IN_OFF, aoff, IN_ROW, smem + RING_OFF, accA, accX, [&](int tap) { deferred(0, tap); });
+    ST(3);
+    if (pend) SA_WAIT_VM_LGKM0(2); else SA_WAIT_VM_LGKM0(0);  // conv-a k-half 1
+    ST(17);
+    __builtin_amdgcn_s_barrier();  // k-half 1 landed; A0 is finished (slot 0)
+    ST(9);
+    issue_w(rwb, 4, 0, 0);
+    stage(std::true_type{}, smem + IN_OFF + IN_PLANE, aoff, IN_ROW, smem + RING_OFF + SLOT, accA, accX, [&](int tap) { deferred(1, tap); });
+    ST(3);
     // ---- epilogue a: ReLU, 16-bit pack, zero outside the image (= conv-b's SAME padding), 16-byte stores into the planes
     {
+#if SA_HAS_PK_MAX
+      const uint32_t lowpk_a = p.relu_a ? 0u : SA_PK_NEG_INF;
+#endif
       auto put = [&](const f32x16& d, unsigned mask, bool store, unsigned char* base, int m) {
         uint2 pk[4];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
+#if SA_HAS_PK_MAX
+          pk[g].x = sa::pk_max(sa::f2h2(d[4 * g + 0], d[4 * g + 1]), lowpk_a) & mask;
+          pk[g].y = sa::pk_max(sa::f2h2(d[4 * g + 2], d[4 * g + 3]), lowpk_a) & mask;
+#else
           pk[g].x = sa::f2h2(fmaxf(d[4 * g + 0], low_a), fmaxf(d[4 * g + 1], low_a)) & mask;
           pk[g].y = sa::f2h2(fmaxf(d[4 * g + 2], low_a), fmaxf(d[4 * g + 3], low_a)) & mask;
+#endif
         }
 #pragma unroll
         for (int pr = 0; pr < 2; ++pr) {
           uint2 x = pk[2 * pr], y = pk[2 * pr + 1];
           sa::swap32(x.x, y.x);
           sa::swap32(x.y, y.y);
-          if (store) *reinterpret_cast<uint4*>(base + (2 * m + pr) * IP_PLANE) = make_uint4(x.x, x.y, y.x, y.y);
+          // (an opaque ds_write: in front of a C++ store to LDS the compiler drains vmcnt -- it cannot tell the target from that of
+          //  the copy of conv-b's chunk 0, in flight since A1's head -- and with it the stage's deferred stores)
+          if (store) {
+            typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
+            const u32x4v v = {x.x, x.y, y.x, y.y};
+            const unsigned addr = (unsigned)(uintptr_t)(lds_ptr_t)base + (unsigned)((2 * m + pr) * IP_PLANE);
+            asm volatile("ds_write_b128 %0, %1" ::"v"(addr), "v"(v) : "memory");
+          }
         }
       };
-      const bool colok = (unsigned)(cur.x0 + lx - 1) < (unsigned)W;
+      int ln = lane;  // (re-derived per tile: see make_voff)
+      asm volatile("" : "+v"(ln));
+      const int hf = ln >> 5, lxe = ln & 31;
+      const unsigned woff = (unsigned)(2 * wave * IP_ROW + lxe * 32 + ((hf ^ ((lxe >> 3) & 1)) * 16));  // row 2 wave, column lx
+      const bool colok = (unsigned)(cur.x0 + lxe - 1) < (unsigned)W;
 #pragma unroll
       for (int r = 0; r < R; ++r) {
         const bool rowok = (unsigned)(cur.y0 + 2 * wave + r - 1) < (unsigned)H;  // wave uniform
@@ -301,11 +482,14 @@ convpair64_kernel(const Pair64Params p) {
         for (int m = 0; m < 2; ++m) put(accA[m][r], mask, true, smem + INTER_OFF + woff + r * IP_ROW, m);
       }
       {
-        const bool in_img = (unsigned)(cur.y0 + xrow - 1) < (unsigned)H && (unsigned)(cur.x0 + xcol - 1) < (unsigned)W;
-        put(accX, in_img ? 0xFFFFFFFFu : 0u, xvalid, smem + INTER_OFF + xwoff, m_x);
+        const XPix xp = xpix(lxe);
+        const unsigned xwoff = (unsigned)(xp.row * IP_ROW + xp.col * 32 + ((hf ^ ((xp.col >> 3) & 1)) * 16));
+        const bool in_img = (unsigned)(cur.y0 + xp.row - 1) < (unsigned)H && (unsigned)(cur.x0 + xp.col - 1) < (unsigned)W;
+        put(accX, in_img ? 0xFFFFFFFFu : 0u, xp.valid, smem + INTER_OFF + xwoff, m_x);
       }
     }
 
+    ST(4);
     // ================= phase B: conv-b (64 -> 64), wave owns rows 2 wave, 2 wave + 1 x both cout tiles
     f32x16 acc[2][R];
     Tile nxt = cur;
@@ -313,22 +497,19 @@ convpair64_kernel(const Pair64Params p) {
     for (int c = 0; c < 4; ++c) {
       // chunk c landed; the stage before is finished (c == 0: the intermediate tile is complete). c == 1: the next tile's input
       // planes, queued BEHIND chunk 1 in B0, may stay in flight (the counter retires in order): they have until B2.
-      if (c == 1 && more) {
-        if (wave < N_INP - 2 * NW) SA_WAIT_VM_LGKM0(6); else SA_WAIT_VM_LGKM0(4);  // (wave uniform) 2 x 3 or 2 x 2 input pieces per wave
+      if (c == 1 && more) {  // (wave uniform) 2 x 3 or 2 x 2 input pieces per wave, + the stage's two deferred stores
+        if (wave < N_INP - 2 * NW) {
+          if (pend) SA_WAIT_VM_LGKM0(8); else SA_WAIT_VM_LGKM0(6);
+        } else {
+          if (pend) SA_WAIT_VM_LGKM0(6); else SA_WAIT_VM_LGKM0(4);
+        }
       } else {
-        SA_WAIT_VM_LGKM0(0);  // (c == 0: and this wave's ds_writes of the intermediate tile)
+        if (pend) SA_WAIT_VM_LGKM0(2); else SA_WAIT_VM_LGKM0(0);  // (c == 0: lgkmcnt(0) = this wave's ds_writes of the intermediate tile)
       }
+      ST(18 + c);
       __builtin_amdgcn_s_barrier();
-      if (c == 0) {
-#pragma unroll
-        for (int m = 0; m < 2; ++m)
-#pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            const float4 bq = *reinterpret_cast<const float4*>(bias_lds + 64 + m * 32 + 8 * g + 4 * half);
-#pragma unroll
-            for (int r = 0; r < R; ++r) acc[m][r][4 * g + 0] = bq.x, acc[m][r][4 * g + 1] = bq.y, acc[m][r][4 * g + 2] = bq.z, acc[m][r][4 * g + 3] = bq.w;
-          }
-      }
+      ST(10 + c);
+      if (c == 0) init_b(acc);
       if (c < 3) {
         issue_w(rwb, 4, c + 1, (c + 1) & 1);
         if (c == 0 && more) {  // A1 is finished: both input planes are free
@@ -341,74 +522,54 @@ convpair64_kernel(const Pair64Params p) {
       } else if (more) {
         issue_w(rwa, 2, 0, 0);
       }
-      stage(std::false_type{}, smem + INTER_OFF + c * IP_PLANE, boff, IP_ROW, smem + RING_OFF + (c & 1) * SLOT, acc, accX);
+      stage(std::false_type{}, smem + INTER_OFF + c * IP_PLANE, boff, IP_ROW, smem + RING_OFF + (c & 1) * SLOT, acc, accX,
+            [&](int tap) { deferred(2 + c, tap); });
+      ST(5);
     }
 
-    // ---- epilogue b (as conv3x3_dma_kernel's plain epilogue). The copies queued in B3 are waited for HERE, in front of the
-    // stores, so that the next tile's first barrier needs no memory wait at all.
-    SA_WAIT_VM(0);
-    {
-      const int gx = cur.x0 + lx;
-      const bool colok = gx < W;
-      auto act = [&](int m, int r, int i) { return fmaxf(acc[m][r][i], low_b); };
-      auto store_pieces = [&](unsigned char* row_base, size_t blk_bytes, int m, unsigned lane_off, bool ok, const uint2 (&pk)[4]) {
+    ln_s = lane;
+    asm volatile("" : "+v"(ln_s));
+    // ---- epilogue b: pack now; store now only where the stores cannot be deferred (the workgroup's last tile, ragged tiles)
+    pack_b(acc);
+    ST(14);
+    const bool pend_next = more && has_full && has_pool && cur.x0 + TW <= W && cur.y0 + TH <= H;  // workgroup uniform
+    if (!pend_next) {
+      if (has_full) {
 #pragma unroll
-        for (int pr = 0; pr < 2; ++pr) {
-          uint2 x = pk[2 * pr], y = pk[2 * pr + 1];
-          sa::swap32(x.x, y.x);
-          sa::swap32(x.y, y.y);
-          if (ok) *reinterpret_cast<uint4*>(row_base + (size_t)(2 * m + pr) * blk_bytes + lane_off) = make_uint4(x.x, x.y, y.x, y.y);
-        }
-      };
-      if (p.dst) {
-        unsigned char* frame = reinterpret_cast<unsigned char*>(p.dst) + (size_t)cur.b * H * W * 128;
-        const size_t blk = p.planar ? (size_t)H * W * 32 : (size_t)32;
-        const unsigned lane_off = (unsigned)gx * pixb_out + (unsigned)half * 16u;
-#pragma unroll
-        for (int m = 0; m < 2; ++m)
-#pragma unroll
-          for (int r = 0; r < R; ++r) {
-            const int gy = cur.y0 + wave * R + r;  // wave uniform
-            uint2 pk[4];
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-              pk[g].x = sa::f2h2(act(m, r, 4 * g + 0), act(m, r, 4 * g + 1));
-              pk[g].y = sa::f2h2(act(m, r, 4 * g + 2), act(m, r, 4 * g + 3));
-            }
-            store_pieces(frame + (size_t)gy * W * pixb_out, blk, m, lane_off, colok && gy < H, pk);
-          }
+        for (int i = 0; i < 8; ++i) store_full(cur, i, std::true_type{});
       }
-      if (p.dst_pool) {
-        const int gy = cur.y0 + wave * R;  // wave uniform, even
-        unsigned char* frame = reinterpret_cast<unsigned char*>(p.dst_pool) + (size_t)cur.b * (H / 2) * (W / 2) * 128;
-        const size_t blk = p.planar ? (size_t)(H / 2) * (W / 2) * 32 : (size_t)32;
-        const unsigned lane_off = (unsigned)(gx >> 1) * pixb_out + (unsigned)half * 16u;
+      if (has_pool) {
 #pragma unroll
-        for (int m = 0; m < 2; ++m) {
-          uint2 pk[4];
-#pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            float t4[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              const float t = fmaxf(act(m, 0, 4 * g + j), act(m, 1, 4 * g + j));
-              t4[j] = fmaxf(t, sa::dpp_xor1(t));
-            }
-            pk[g].x = sa::f2h2(t4[0], t4[1]);
-            pk[g].y = sa::f2h2(t4[2], t4[3]);
-          }
-          store_pieces(frame + (size_t)(gy >> 1) * (W / 2) * pixb_out, blk, m, lane_off, !(lane & 1) && colok && gy < H, pk);
-        }
+        for (int i = 0; i < 4; ++i) store_pool(cur, i, std::true_type{});
       }
     }
+    ST(6);
     if (!more) break;
+    // the next tile's conv-a k-half 0 (queued in B3, in front of B3's two deferred stores -- governed by THIS tile's `pend`)
+    if (pend && pend_next) SA_WAIT_VM_LGKM0(2); else SA_WAIT_VM_LGKM0(0);
+    pend = pend_next;
+    prev = cur;
     cur = nxt;
     L = L_next;
   }
+  ST_FLUSH;
 #endif
 }
 
 }  // namespace
+
+#if defined(SA_PAIR64_STAMP)
+extern "C" int sa_pair64_stamp_reset() {
+  unsigned long long z[24] = {0};
+  SA_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_stamp64), z, sizeof(z)));
+  return SA_OK;
+}
+extern "C" int sa_pair64_stamp_read(unsigned long long* out) {
+  SA_HIP_CHECK(hipDeviceSynchronize());
+  SA_HIP_CHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamp64), 24 * sizeof(unsigned long long)));
+  return SA_OK;
+}
+#endif
 
 // the 32 -> 64 -> 64 form of sa_conv3x3_pair_bf16 (convpair.hip checks the arguments and dispatches here)
 int sa_convpair64_launch(const void* src, const void* wa, const float* bias_a, int relu_a, const void* wb, const float* bias_b,
