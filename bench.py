@@ -25,6 +25,8 @@ fences, MAX over ranks. Measured after that region, reported beside it: `sustain
 `literal_split_8_per_gpu` (8 frames per GPU per step: configs[3]'s global batch of 64 over 8 GPUs), and two extra objects:
   roofline      conv3x3 MFMA kernel family: algorithmic TFLOP/s (2*H*W*Cin*Cout*9 over its launches) over
                 its HIP-event-measured time inside this process, vs the 2.5 PFLOP/s dense fp16 / bf16 MFMA peak
+  roofline_postproc  SURVEY 8(d)'s HBM fraction of the post-processing: the NMS scan's bytes (the confidence maps, once) over its
+                HIP-event time, and the same bytes over the whole post-processing
   cpu_baseline  the CPU oracle (torch-CPU fp32 convs + NumPy/SciPy post-processing; "port") timed on the
                 host cores over a bounded sample of the same workload (N=1 only)
 """
@@ -381,6 +383,11 @@ def main():
         dt = float(tmax.item())
 
     res = parallel.unpack_results(host_out[:B].clone(), scorer.max_instances, scorer.n_nodes)
+    # digest of the gathered packed rows of the last timed step (rank 0's copy of the WHOLE job's results): the same frames give the
+    # same digest with and without the process group (tests/test_gpu_dist_path.py compares the two)
+    import hashlib
+
+    result_digest = hashlib.sha1(np.ascontiguousarray(host_out.numpy()).tobytes()).hexdigest()[:16]
     status_bits = int(np.bitwise_or.reduce(res["status"].numpy().astype(np.int64)))
     mean_instances = float(res["n_valid"].float().mean())
 
@@ -498,6 +505,33 @@ def main():
         torch.cuda.synchronize()
         post_ms = e0.elapsed_time(e1)
         mean_peaks = float(pp["peak_count"].float().mean())
+        # achieved_hbm(postproc) = 3.41e6 B (the confidence maps of a frame: 256 x 256 x 13 f32, read once by the NMS
+        # scan) x frames / time / 8 TB/s -- for the scan kernel alone (sa_find_local_peaks_rough, timed here on this stream: the
+        # one pass of the post-processing that touches every map value) and over the WHOLE post-processing (scan + sort /
+        # refinement + PAF scoring + matching + grouping: `post_ms` above; the part behind the scan is latency-bound, one
+        # workgroup per frame)
+        from sleap_amd import ops as _ops
+
+        for rep in range(3):
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(10):
+                _ops.find_local_peaks_rough(cms, layer.peak_threshold, layer.max_peaks)
+            e1.record()
+        torch.cuda.synchronize()
+        scan_ms = e0.elapsed_time(e1) / 10
+        cms_bytes = float(cms.numel() * cms.element_size())
+        PEAK_HBM_GBS = 8000.0
+        roofline_postproc = {
+            "kernel": "nms_scan_kernel (find_local_peaks_rough: the confidence maps read once)", "bound": "hbm",
+            "achieved": round(cms_bytes / (scan_ms * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+            "frac": round(cms_bytes / (scan_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4), "avg_launch_ms": round(scan_ms, 4),
+            "algorithmic_bytes_per_frame": cms_bytes / B, "frames_per_launch": B,
+            "whole_postproc": {"ms_per_step": round(post_ms, 3), "achieved": round(cms_bytes / (post_ms * 1e-3) / 1e9, 1),
+                               "frac": round(cms_bytes / (post_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
+                               "note": "same bytes over scan + sort/refine + PAF scoring + matching + grouping; runs on the second stream "
+                                       "under the next batch's network in the timed step"},
+        }
         achieved = conv_fl / (conv_ms * 1e-3) / 1e12
         roofline = {
             "kernel": f"conv3x3_dma_kernel + convpair + stem16_gray_kernel (the {n_conv} MFMA conv launches of one step)", "bound": "mfma", "achieved": round(achieved, 2),
@@ -543,8 +577,9 @@ def main():
                        "collective_backend": (dist.get_backend() + " (RCCL)" if use_dist else None),
                        "activation_layout": "planes16" if net.planar else "nhwc",
                        "peak_threshold": 0.2, "refinement": "integral", "mean_peaks_per_frame": round(mean_peaks, 1),
-                       "mean_instances_per_frame": round(mean_instances, 2), "status_bits": status_bits},
-            "roofline": roofline,
+                       "mean_instances_per_frame": round(mean_instances, 2), "status_bits": status_bits,
+                       "result_digest": result_digest},
+            "roofline": roofline, "roofline_postproc": roofline_postproc,
             "sustained": sustained, "literal_split_8_per_gpu": small,
             # the two readings of "batch = 64, frame-sharded over N GPUs", both named so that a SCALE record cannot be read as the
             # wrong one: `value` above is `value_weak_64_per_gpu` unless --global-batch was given (then it is the strong one)

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define SA_ABI_VERSION 6  /* 6 (round 5): + sa_conv3x3_set_persistent. 5 (round 4): + sa_conv3x3_ex_heads_bf16. 4 (round 4): + sa_tensor_absmax, sa_imgconv_pack_tiled, sa_pack_pointwise_weights,
+#define SA_ABI_VERSION 7  /* 7 (round 6): + sa_find_local_peaks_rough; sa_conv3x3_pair_bf16 accepts 32 -> 64 -> 64. 6 (round 5): + sa_conv3x3_set_persistent. 5 (round 4): + sa_conv3x3_ex_heads_bf16. 4 (round 4): + sa_tensor_absmax, sa_imgconv_pack_tiled, sa_pack_pointwise_weights,
                             sa_pointwise_packed_elems, sa_conv3x3_bneck_bf16; SA_LAYOUT_PLANES16 accepted in the `relu` argument of
                             sa_conv1x1_bf16 / sa_convk_bf16 / sa_convt_s2_bf16 */
 
@@ -84,6 +84,14 @@ int sa_find_local_peaks(const float* cms, const float* offsets, int B, int H, in
                         int max_peaks, float* peak_xy, float* peak_val, int32_t* peak_chan,
                         int32_t* peak_count, int32_t* status, void* workspace, size_t ws_bytes,
                         sa_stream_t stream);
+
+/* find_local_peaks_rough alone (peak_finding.py:249-308): the NMS scan of the confidence maps -- the one pass of the
+ * post-processing that reads every map value (H W C x 4 bytes per frame: the HBM-bound kernel bench.py's `roofline_postproc`
+ * is quoted on). keys [B,max_peaks] u32 = the linear (y, x, c) index of every local maximum above `threshold`, in arrival
+ * order (sa_find_local_peaks sorts them: row-major order); peak_count [B] i32 (may exceed max_peaks: status bit
+ * SA_STATUS_PEAK_OVERFLOW); status [B] i32 (bits OR-ed in, the caller zeroes). */
+int sa_find_local_peaks_rough(const float* cms, int B, int H, int W, int C, float threshold, int max_peaks, uint32_t* keys,
+                              int32_t* peak_count, int32_t* status, sa_stream_t stream);
 
 /* find_global_peaks_rough + find_global_peaks / find_global_peaks_with_offsets
  * (peak_finding.py:193-246, 337-420, 566-643). Row and column argmax are taken independently.

@@ -33,6 +33,7 @@ SIGNATURES = {
     "sa_last_error": (C.c_char_p, []),
     "sa_device_info": (_i, [_i, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), C.c_char_p, _i]),
     "sa_find_local_peaks_workspace": (_sz, [_i, _i]),
+    "sa_find_local_peaks_rough": (_i, [_p, _i, _i, _i, _i, _f, _i, _p, _p, _p, _p]),
     "sa_find_local_peaks": (_i, [_p, _p, _i, _i, _i, _i, _f, _i, _i, _f, _i, _p, _p, _p, _p, _p, _p, _sz, _p]),
     "sa_find_global_peaks": (_i, [_p, _p, _i, _i, _i, _i, _f, _i, _i, _f, _p, _p, _p]),
     "sa_select_centroids": (_i, [_p, _p, _p, _i, _i, _i, _i, _f, _f, _i, _p, _p, _p, _p, _p, _p, _p]),

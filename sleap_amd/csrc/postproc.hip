@@ -1221,6 +1221,24 @@ int sa_find_local_peaks(const float* cms, const float* offsets, int B, int H, in
   return SA_OK;
 }
 
+int sa_find_local_peaks_rough(const float* cms, int B, int H, int W, int C, float threshold, int max_peaks, uint32_t* keys,
+                              int32_t* peak_count, int32_t* status, sa_stream_t stream) {
+  SA_REQUIRE(cms && keys && peak_count && status, "sa_find_local_peaks_rough: NULL pointer");
+  SA_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0, "sa_find_local_peaks_rough: bad shape %dx%dx%dx%d", B, H, W, C);
+  SA_REQUIRE((uint64_t)H * W * C < 0xFFFFFFFFull, "sa_find_local_peaks_rough: H*W*C exceeds 32-bit keys");
+  SA_REQUIRE(max_peaks > 0 && max_peaks <= 16384, "sa_find_local_peaks_rough: max_peaks %d out of range", max_peaks);
+  hipStream_t st = (hipStream_t)stream;
+  SA_HIP_CHECK(hipMemsetAsync(peak_count, 0, sizeof(int32_t) * B, st));
+  const size_t plane = (size_t)H * W * C;
+  const int vec4 = (plane % 4 == 0) && (((uintptr_t)cms) % 16 == 0);
+  const size_t work = vec4 ? plane / 4 : plane;
+  int gx = (int)((work + 255) / 256);
+  if (gx > 2048) gx = 2048;
+  hipLaunchKernelGGL(nms_scan_kernel, dim3(gx, B), dim3(256), 0, st, cms, H, W, C, threshold, max_peaks, keys, peak_count, status, vec4);
+  SA_LAUNCH_CHECK();
+  return SA_OK;
+}
+
 int sa_find_global_peaks(const float* cms, const float* offsets, int B, int H, int W, int C,
                          float threshold, int refinement, int patch_size, float xy_scale,
                          float* peak_xy, float* peak_val, sa_stream_t stream) {

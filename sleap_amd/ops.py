@@ -73,6 +73,19 @@ def find_local_peaks(cms, offsets=None, threshold=0.2, refinement=None, patch_si
     return peak_xy, peak_val, peak_chan, peak_count, status
 
 
+def find_local_peaks_rough(cms, threshold=0.2, max_peaks=512, status=None):
+    """sa_find_local_peaks_rough: the NMS scan alone -> keys [B,max_peaks] (linear (y, x, c) indices as int32 bit patterns, arrival
+    order), peak_count [B] i32, status [B] i32."""
+    B, H, W, Cc = cms.shape
+    keys = torch.empty((B, max_peaks), dtype=torch.int32, device=cms.device)
+    peak_count = torch.empty((B,), dtype=torch.int32, device=cms.device)
+    if status is None:
+        status = torch.zeros((B,), dtype=torch.int32, device=cms.device)
+    check(_lib.lib().sa_find_local_peaks_rough(_ptr(cms), B, H, W, Cc, float(threshold), int(max_peaks), _ptr(keys), _ptr(peak_count),
+                                               _ptr(status), _stream()), "sa_find_local_peaks_rough")
+    return keys, peak_count, status
+
+
 def find_global_peaks(cms, offsets=None, threshold=0.2, refinement=None, patch_size=5, xy_scale=1.0):
     """-> peak_xy [B,C,2] (NaN below threshold), peak_val [B,C]."""
     B, H, W, Cc = cms.shape

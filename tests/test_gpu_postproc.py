@@ -105,6 +105,23 @@ def test_local_peaks_vs_oracle(pf, refinement):
     assert_allclose(_n(g[0]), o[0], atol=TOL)
 
 
+def test_rough_scan_entry_point_vs_oracle():
+    """sa_find_local_peaks_rough (round 6: the NMS scan alone -- the kernel bench.py's roofline_postproc times): the SET of
+    linear (y, x, c) keys per frame == the oracle's find_local_peaks_rough (peak_finding.py:249-308); arrival order is free."""
+    from sleap_amd import ops
+
+    cms, _, _ = _synth_batch(0)
+    B, H, W, C = cms.shape
+    keys, cnt, st = ops.find_local_peaks_rough(torch.from_numpy(cms).cuda(), 0.2, max_peaks=1024)
+    assert int(st.max()) == 0
+    pts, _, si, ci = opf.find_local_peaks_rough(cms, 0.2)
+    want = ((pts[:, 1].astype(np.int64) * W + pts[:, 0].astype(np.int64)) * C + ci)
+    keys, cnt = _n(keys).view(np.uint32), _n(cnt)
+    assert int(cnt.sum()) == len(want) > 100
+    for b in range(B):
+        assert_array_equal(np.sort(keys[b, :cnt[b]].astype(np.int64)), np.sort(want[si == b]))
+
+
 def test_local_peaks_random_noise_many_peaks(pf):
     rng = np.random.default_rng(1)
     cms = rng.random((2, 37, 53, 5)).astype(np.float32)  # odd sizes: scalar (non-float4) path, borders everywhere
