@@ -342,7 +342,9 @@ int sa_conv3x3_ex_heads_bf16(const void* src0, int C0P, const void* src1, int C1
 /* Launch policy of the 3x3 MFMA kernels (process-wide, HOST). By default a layer with more tiles than the chip holds
  * workgroups is launched PERSISTENT: occupancy x CUs workgroups, each walking its share of the (frame, tile, cout-tile)
  * list with the first chunk of its next tile prefetched into the idle LDS stage while the current tile's epilogue runs.
- *   n  > 0  launch at most n workgroups in total (tests: a handful of workgroups over many tiles, uneven tails)
+ *   n  > 0  launch at most n workgroups in total (tests: a handful of workgroups over many tiles, uneven tails); raised to
+ *           min(tiles, 8): the tile schedule hands each of the 8 XCDs a contiguous range, fewer workgroups would skip ranges.
+ *           Also honoured by the persistent 32 -> 64 -> 64 block of sa_conv3x3_pair_bf16
  *   n == 0  automatic (default; SA_CONV_PERSIST=0 in the environment = one workgroup per tile, =k = k workgroups per CU)
  *   n  < 0  one workgroup per tile
  * Returns the previous value. Results do not depend on it (each tile's arithmetic is the same). */

@@ -1720,7 +1720,9 @@ int launch2(const ConvParams2& p, hipStream_t st) {
           &nb, reinterpret_cast<const void*>(&conv3x3_dma_kernel<MT, CK, NW, R, NBUF, HEADS, STEM_CIN, EXT, UPS, ITAP, XP, PERS>), NW * 64, lds));
       per_cu = nb > 0 ? nb : 1;
       // (the occupancy API can answer one block too many -- MI355X_MICROARCH.md, correctness boundaries; LDS is the real limit here)
-      const int by_lds = (int)((160u * 1024u) / (lds ? lds : 1));
+      int lds_cu = 0;
+      SA_HIP_CHECK(hipDeviceGetAttribute(&lds_cu, hipDeviceAttributeMaxSharedMemoryPerMultiprocessor, dev));
+      const int by_lds = lds ? (int)((size_t)lds_cu / lds) : 0;
       if (by_lds >= 1 && per_cu > by_lds) per_cu = by_lds;
     }
     if (g_grid_limit > 0) {
@@ -1732,6 +1734,8 @@ int launch2(const ConvParams2& p, hipStream_t st) {
       const size_t cap = (size_t)(persist > 0 ? persist : per_cu) * (size_t)n_cu;
       if (cap < grid) grid = cap;
     }
+    // whatever policy chose the grid: the XCD tile schedule needs one workgroup per XCD range (or one per tile)
+    if (grid < 8 && grid != nblk) grid = nblk < 8 ? nblk : 8;
   }
   hipLaunchKernelGGL((conv3x3_dma_kernel<MT, CK, NW, R, NBUF, HEADS, STEM_CIN, EXT, UPS, ITAP, XP, PERS>), dim3((unsigned)grid), dim3(NW * 64), lds, st, q);
   SA_LAUNCH_CHECK();

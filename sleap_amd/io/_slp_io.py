@@ -50,9 +50,9 @@ def write(npz, path):
         g = f.require_group("metadata")
         g.attrs["format_id"] = float(z["format_id"])
         for key in ("videos_json", "tracks_json", "suggestions_json"):
-            data = [np.string_(s) for s in z[key].tolist()]
+            data = [np.bytes_(s) for s in z[key].tolist()]
             f.create_dataset(key, data=data, maxshape=(None,))
-        g.attrs["json"] = np.string_(str(z["json"]))
+        g.attrs["json"] = np.bytes_(str(z["json"]))
         for key in ("points", "pred_points", "instances", "frames"):
             f.create_dataset(key, data=z[key], maxshape=(None,), dtype=z[key].dtype)
 

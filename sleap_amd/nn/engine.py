@@ -1495,9 +1495,12 @@ class DeviceNetwork:
                 raise FloatingPointError(
                     "activations left the range of fp16 storage (65504) on an earlier batch and dist_agree_range() was not called "
                     "since (defer_range_agreement() promises one call on every rank after the first global batch)")
+            # ONE batch is kept until the ranks have agreed -- what this rank would calibrate on: the batch of the WORST scan so far
+            # (round 5 kept the first one: an overflow that came from a later shape was then calibrated on a batch that had not
+            # overflowed, and the next batch raised "after the ranks agreed")
+            if self._pending_imgs is None or worst > pw or (nonfinite and not pn):
+                self._pending_imgs = imgs
             self._pending_scan = (max(worst, pw), nonfinite or pn)
-            if self._pending_imgs is None:
-                self._pending_imgs = imgs  # (ONE batch kept until the ranks have agreed: what this rank would calibrate on)
             return False
         if not nonfinite and worst <= 65504.0 / 4:
             return False

@@ -318,8 +318,10 @@ class InferenceModel:
                 # a batch far outside the one the fp16 range scales were chosen on (or the first overflow of a shape whose
                 # first batch fitted): let the networks scan this batch again -- the range gate re-calibrates with the larger
                 # of the old and new ranges (DeviceNetwork._range_gate) -- and run it once more before giving up
+                # (not while a network's range agreement is deferred to dist_agree_range(): its second scan of a pending overflow
+                #  would raise "dist_agree_range() was not called" -- the wrong message for this caller)
                 nets = [n for n in self._device_networks() if getattr(n, "dtype", None) == "fp16" and n.range_safe]
-                if nets and not rescanned:
+                if nets and not rescanned and not any(getattr(n, "_dist_defer", False) for n in nets):
                     rescanned = True
                     for n in nets:
                         n._range_checked = False
@@ -1211,8 +1213,20 @@ class Predictor:
 
     def predict(self, data, make_labels: bool = True):
         """inference.py:496-531 (see BottomUpPredictor.predict for the output contract)."""
-        outs = self._apply_tracker(self._predict_generator(data), data)
+        try:
+            outs = self._apply_tracker(self._predict_generator(data), data)
+        finally:
+            self._clear_range_deferral()
         return self._make_labels(outs, data) if make_labels else outs
+
+    def _clear_range_deferral(self):
+        """The generators switch the networks' fp16 range gate to its deferred mode under torch.distributed (one agreement of all
+        ranks after the first global batch). No batch (n == 0) or an exception before that point would leave the promise
+        standing: later direct forward() calls would record an overflow silently instead of raising."""
+        nets = getattr(self.inference_model, "_device_networks", None)
+        for net in (nets() if nets is not None else []):
+            if getattr(net, "_dist_defer", False):
+                net.defer_range_agreement(False)
 
     def _skeleton_info(self):
         """(part_names, edge_inds) for the result containers; edges are only known to the bottom-up predictor (PAFScorer)."""
@@ -1676,7 +1690,10 @@ class BottomUpPredictor(Predictor):
         (`instance_peaks (b, Imax, N, 2)` NaN-padded, `instance_peak_vals`, `instance_scores`, `n_valid`,
         `video_ind`, `frame_ind`, ...). `make_labels=True` (the reference's default) returns the array-backed
         `sleap_amd.io.labels.Labels` (`len`, indexing, `.numpy()`, `.save("x.slp")`, `.to_sleap()`)."""
-        outs = self._apply_tracker(self._predict_generator(data), data)
+        try:
+            outs = self._apply_tracker(self._predict_generator(data), data)
+        finally:
+            self._clear_range_deferral()
         return self._make_labels(outs, data) if make_labels else outs
 
 

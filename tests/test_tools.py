@@ -50,3 +50,16 @@ def test_committed_traffic_file_is_what_bench_reads():
     assert t["frames_per_step"] == 64 and t["size"] == 1024
     got = bench.profiled_traffic(64, 1024)
     assert got is not None and abs(got[0] - t["conv_family_bytes_per_step"]) < 1
+
+
+def test_pers_store_count_model_matches_the_isa():
+    """the PERS kernels' counted `s_waitcnt vmcnt(S)` rests on ONE global_store per valid 16-channel piece and output
+    row; the ISA of the translation unit (cross-compiled here, ~30 s) must hold exactly that many store instructions per PERS
+    instantiation, or a compiler change could let a tile start on an LDS stage whose copy is still in flight."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import check_pers_stores
+
+    res = check_pers_stores.pers_store_counts()
+    assert len(res) == 4
+    for name, got, want in res:
+        assert got == want, (name, got, want)
