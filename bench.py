@@ -512,14 +512,19 @@ def main():
         # workgroup per frame)
         from sleap_amd import ops as _ops
 
-        for rep in range(3):
-            torch.cuda.synchronize()
+        # (one launch per measurement, behind a 512-MiB fill: the maps of 64 frames are 218 MB and would otherwise be re-read from
+        #  the 256-MiB Infinity Cache, not from HBM -- ten back-to-back launches measured 4.0 TB/s that way)
+        evict = torch.empty((512 << 20,), dtype=torch.uint8, device="cuda")
+        scans = []
+        for rep in range(7):
+            evict.fill_(rep)
             e0.record()
-            for _ in range(10):
-                _ops.find_local_peaks_rough(cms, layer.peak_threshold, layer.max_peaks)
+            _ops.find_local_peaks_rough(cms, layer.peak_threshold, layer.max_peaks)
             e1.record()
-        torch.cuda.synchronize()
-        scan_ms = e0.elapsed_time(e1) / 10
+            torch.cuda.synchronize()
+            scans.append(e0.elapsed_time(e1))
+        del evict
+        scan_ms = float(np.median(scans[1:]))
         cms_bytes = float(cms.numel() * cms.element_size())
         PEAK_HBM_GBS = 8000.0
         roofline_postproc = {
