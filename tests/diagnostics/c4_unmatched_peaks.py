@@ -9,7 +9,7 @@ sys.path.insert(0, ".")
 sys.path.insert(0, "tests")
 from oracle import peak_finding as opf  # noqa: E402
 from oracle.keras_graph import KerasGraph, preprocess  # noqa: E402
-from sleap_amd import config_models as C  # noqa: E402
+import config_models as C  # noqa: E402
 from sleap_amd.nn.engine import DeviceNetwork  # noqa: E402
 from sleap_amd.nn.inference import BottomUpPredictor  # noqa: E402
 

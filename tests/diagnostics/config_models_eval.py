@@ -1,15 +1,16 @@
-"""What the fp32 ORACLE sees on fresh frames with the fitted config models (sleap_amd/config_models.py): peak values vs the 0.2
+"""What the fp32 ORACLE sees on fresh frames with the fitted config models (tests/config_models.py): peak values vs the 0.2
 threshold, background maxima, distance to the rendered truth. Diagnostic, CPU only:  python tests/diagnostics/config_models_eval.py [task ...]"""
 import sys
 
 import numpy as np
 
 sys.path.insert(0, ".")
+sys.path.insert(0, "tests")  # config_models.py: test infrastructure
 from oracle import inference as oinf  # noqa: E402
 from oracle import paf_grouping as opg  # noqa: E402
 from oracle import peak_finding as opf  # noqa: E402
 from oracle.keras_graph import KerasGraph, preprocess  # noqa: E402
-from sleap_amd import config_models as C  # noqa: E402
+import config_models as C  # noqa: E402
 
 
 def single(task, n=8, seed=300):

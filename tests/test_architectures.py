@@ -234,7 +234,7 @@ def test_two_stack_hourglass_oracle_side_is_the_fitted_one_stack_model():
     import numpy as np
 
     from oracle.keras_graph import KerasGraph, preprocess
-    from sleap_amd import config_models as C
+    import config_models as C
     from sleap_amd.nn.inference import find_head
     from test_gpu_config_parity import _two_stack_hourglass
 

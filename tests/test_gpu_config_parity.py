@@ -5,7 +5,7 @@ finding / cropping / PAF grouping) on the SAME uint8 frames with the SAME float3
 8(d) prescribes: same number of instances per frame, same NaN mask, every peak within north_star's 0.5 px.
 
 The networks are the architectures of the reference's shipped training profiles, fitted to the synthetic videos of
-`sleap_amd.synth.render_animals` (sleap_amd/config_models.py, tools/train_config_models.py) and stored as float32 masters: the
+`sleap_amd.synth.render_animals` (tests/config_models.py, tools/train_config_models.py) and stored as float32 masters: the
 oracle computes with the fp32 values, the device rounds them to fp16 itself -- as it would real SLEAP weights. Frames are
 rendered with seeds the models were not fitted to.
 
@@ -33,7 +33,7 @@ TOL_PX = 0.5
 
 
 def _net(task, h, w, dtype="fp16"):
-    from sleap_amd import config_models as C
+    import config_models as C
     from sleap_amd.nn.engine import DeviceNetwork
 
     mc, wts = C.load_task_weights(task, h, w)
@@ -51,7 +51,7 @@ def _compare(got, want, what):
 
 
 def _single_instance_case(task, n_frames, batch, seed, margin_px=0.1):
-    from sleap_amd import config_models as C
+    import config_models as C
     from sleap_amd.nn.inference import SingleInstancePredictor
 
     t = C.TASKS[task]
@@ -86,7 +86,7 @@ def _two_stack_hourglass(h, w):
     """A TWO-stack hourglass with per-stack heads named `<head>_<s>` (older SLEAP naming, the reference's own fixtures): stem,
     stack 0 and `SingleInstanceConfmapsHead_0` carry the FITTED one-stack weights (stack 0 sees exactly what the one-stack model
     sees), stack 1 and `..._1` seeded He-normal values (BatchNormalization neutral)."""
-    from sleap_amd import config_models as C
+    import config_models as C
     from sleap_amd.nn import architectures as A
 
     t = C.TASKS["hg_single13"]
@@ -112,7 +112,7 @@ def test_two_stack_hourglass_end_to_end_uses_stack_0_head():
     SingleInstancePredictor. `find_head` returns the first output whose name contains the head type (inference.py:1223-1226,
     2885-2888) -- stack 0's head -- on both sides; the device computes BOTH stacks and both heads. Peaks vs the fp32 oracle
     positionally within 0.5 px; the second stack's maps (a seeded stack on fitted features) within 1e-2 of their range."""
-    from sleap_amd import config_models as C
+    import config_models as C
     from sleap_amd.nn.engine import DeviceNetwork
     from sleap_amd.nn.inference import SingleInstancePredictor
 
@@ -153,7 +153,7 @@ def test_hourglass_single_instance_end_to_end_512_13_nodes():
 
 
 def _topdown_oracle(frames, crop_size):
-    from sleap_amd import config_models as C
+    import config_models as C
 
     x = preprocess(frames, input_scale=0.5, pad_stride=16)
     mc, w = C.load_task_weights("c2_centroid", x.shape[1], x.shape[2])
@@ -169,7 +169,7 @@ def test_configs0_centroid_model_through_centroid_crop_256():
     """configs[0]'s other reading ("centroid model"): the centroid UNet (input x0.5) through CentroidCrop / find_local_peaks on
     256 x 256 frames with one animal: same centroids (count, order, <= 0.5 px) and the same crops up to the resampling of a
     sub-0.01-px centroid difference."""
-    from sleap_amd import config_models as C
+    import config_models as C
     from sleap_amd.nn.inference import CentroidCrop
 
     frames, insts = C.render("c0_single5", 8, seed=302, skeleton=C.skeleton("c2_centroid"))  # a whole 13-node fly per 256 x 256 frame
@@ -199,7 +199,7 @@ def test_configs2_topdown_1024_two_animals_oracle_runs_its_own_networks(seed):
     configs[2]: centroid UNet (baseline.centroid, x0.5) + centered-instance UNet (baseline_medium_rf.topdown, f24) on
     160 x 160 crops, 1024 x 1024 frames with 2 animals. The ORACLE runs both of its own networks (centroids from its fp32
     centroid maps, crops at its own centroids, peaks from its fp32 crop maps) -- nothing of the device path enters it."""
-    from sleap_amd import config_models as C
+    import config_models as C
     from sleap_amd.nn.engine import DeviceNetwork
     from sleap_amd.nn.inference import TopDownPredictor
 
@@ -242,7 +242,7 @@ C4_SEEDS = tuple(int(v) for v in os.environ["SA_C4_SEEDS"].split(",")) if os.env
 
 @pytest.fixture(scope="module", params=C4_SEEDS)
 def resnet_workload(request):
-    from sleap_amd import config_models as C
+    import config_models as C
 
     task, n_frames = "c4_resnet", 3
     sk = C.skeleton(task)
@@ -293,7 +293,7 @@ def test_configs4_resnet50_bottomup_identical_instance_assignments(resnet_worklo
       * frames without such a decision -- at least 2 of the 3 -- give IDENTICAL instances: same count, same node assignment
         (NaN mask), every coordinate within 0.5 px (`strict_instances=True`)."""
     from parity_helpers import compare_with_threshold_decisions
-    from sleap_amd import config_models as C
+    import config_models as C
     from sleap_amd.nn.engine import DeviceNetwork
     from sleap_amd.nn.inference import BottomUpPredictor
 
@@ -346,7 +346,7 @@ def test_configs4_model_directory_through_load_model(tmp_path, resnet_workload):
     reference reads it (`max_stride` 32 -> pad_to_stride)."""
     import json
 
-    from sleap_amd import config_models as C
+    import config_models as C
     from sleap_amd.nn.engine import DeviceNetwork
     from sleap_amd.nn.inference import BottomUpPredictor, load_model
 

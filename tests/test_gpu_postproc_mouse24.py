@@ -146,7 +146,7 @@ def test_mouse24_postproc_on_the_devices_own_resnet_maps_equals_oracle():
     """The configs[4] network's OWN outputs (ResNet-50 + UpsamplingStack task model, fp16 storage) handed to the oracle's
     post-processing: same instance count, same node assignment (NaN mask), coordinates to float32 summation order -- the
     device's peak finder / scorer / matcher / grouper at 24 nodes / 23 edges / 8 animals on real network maps."""
-    from sleap_amd import config_models as C
+    import config_models as C
     from sleap_amd.nn.engine import DeviceNetwork
     from sleap_amd.nn.inference import BottomUpPredictor
 

@@ -52,13 +52,20 @@ def test_deferred_mode_records_one_batch_and_raises_when_the_promise_is_not_kept
     assert n._pending_scan == (1e9, True) and n._pending_imgs == "first batch"
     with pytest.raises(FloatingPointError, match="dist_agree_range"):
         n.gate("second batch")                       # a second scan while an overflow waits for the agreement
-    # a finite first scan followed by other shapes: maxima accumulate, ONE batch is kept
+    # a finite first scan followed by other shapes: maxima accumulate, ONE batch is kept -- the batch of the WORST scan (ADVICE r5:
+    # the first batch was kept, so an overflow coming from a later shape was calibrated on a batch that had not overflowed)
     n = _net((10.0, False, None))
     n.defer()
     assert n.gate("a") is False
     n.scans.append((20.0, False, None))
     assert n.gate("b") is False
-    assert n._pending_scan == (20.0, False) and n._pending_imgs == "a"
+    assert n._pending_scan == (20.0, False) and n._pending_imgs == "b"
+    n.scans.append((15.0, False, None))
+    assert n.gate("c") is False                      # a milder batch does not replace it
+    assert n._pending_scan == (20.0, False) and n._pending_imgs == "b"
+    n.scans.append((1.0, True, 4))
+    assert n.gate("d") is False                      # the first non-finite scan does, whatever its finite maximum
+    assert n._pending_scan == (20.0, True) and n._pending_imgs == "d"
 
 
 def test_after_the_agreement_an_overflow_raises_and_a_fitting_batch_passes(world2):

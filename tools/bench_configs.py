@@ -12,6 +12,7 @@ import numpy as np
 import torch
 
 sys.path.insert(0, ".")
+sys.path.insert(0, "tests")  # config_models.py: test infrastructure
 from sleap_amd.nn import architectures as A
 from sleap_amd.nn.engine import DeviceNetwork
 from sleap_amd.nn.inference import (BottomUpInferenceLayer, BottomUpInferenceModel, CentroidCrop, FindInstancePeaks,
@@ -128,7 +129,7 @@ print(f"|   (configs[4] status bits {int(np.bitwise_or.reduce(o['status'].cpu().
 # configs[4] with the FITTED task model of the parity test (tests/data/config_c4_resnet.npz: 8 mice per frame found as 8 instances,
 # 192 peaks) instead of random weights: the same architecture, post-processing on realistic counts
 try:
-    from sleap_amd import config_models as C
+    import config_models as C
     from sleap_amd.nn.inference import BottomUpPredictor
 
     frames, _ = C.render("c4_resnet", 16, seed=400)

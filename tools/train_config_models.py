@@ -34,11 +34,12 @@ import torch.nn.functional as F
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))  # config_models.py: test infrastructure
 
 from sleap_amd.nn import architectures as A  # noqa: E402  (plain data, no GPU)
 from sleap_amd import synth  # noqa: E402
 
-from sleap_amd.config_models import ANCHOR, DATA_DIR as OUT_DIR, TASKS, load_task_weights, task_graph  # noqa: E402
+from config_models import ANCHOR, DATA_DIR as OUT_DIR, TASKS, load_task_weights, task_graph  # noqa: E402
 
 
 class TorchGraph(torch.nn.Module):
