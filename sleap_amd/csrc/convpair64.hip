@@ -56,7 +56,7 @@ struct Pair64Params {
   int B, H, W, relu_a, relu_b, tiles_x, tiles_y, planar, n_tiles;
 };
 
-constexpr int NW = 8, R = 2, TH = NW * R, TW = 32;
+constexpr int TH = 16, TW = 32;
 constexpr int PH = TH + 2, PW = TW + 2;  // intermediate halo tile
 constexpr int QH = TH + 4, QW = TW + 4;  // input halo tile
 constexpr int IP_ROW = PW * 32, IP_PLANE = PH * IP_ROW;            // 1088, 19584
@@ -95,9 +95,17 @@ __device__ unsigned long long g_stamp64[24];
 #define ST_FLUSH
 #endif
 
-__global__ void __launch_bounds__(NW * 64, 2)
+// NW = waves per workgroup, R = TH / NW output rows per wave. NW = 8: two waves per SIMD (256 registers each); NW = 4: ONE wave per
+// SIMD with 512 registers -- nothing arbitrates for the matrix pipe, a tap is 8-10 MFMAs (256-320 cycles) behind one set of
+// fragment reads, and half the LDS fragment traffic (every A fragment feeds four rows instead of two).
+template <int NW>
+__global__ void __launch_bounds__(NW * 64, NW == 8 ? 2 : 1)
 convpair64_kernel(const Pair64Params p) {
 #if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int R = TH / NW;
+  constexpr int XM = NW == 8 ? 1 : 2;            // cout tiles of a wave's extra conv-a unit
+  constexpr int NWJ = (18 + NW - 1) / NW;        // weight slabs per wave and copy (<=)
+  constexpr int NIJ = (N_INP + NW - 1) / NW;     // input pieces per wave and plane (<=)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -137,7 +145,7 @@ convpair64_kernel(const Pair64Params p) {
   // conv-a weights of k-half k / conv-b weights of chunk c -> slot s: slab j = m * 9 + tap of the slot <- slab (m * K16 + k) * 9 + tap
   auto issue_w = [&](const __amdgpu_buffer_rsrc_t& rw, int k16n, int k, int s) {
 #pragma unroll
-    for (int jj = 0; jj < 3; ++jj) {
+    for (int jj = 0; jj < NWJ; ++jj) {
       const int j = jj * NW + wave;  // wave uniform
       if (j < 18) {
         const int m = j >= 9 ? 1 : 0, tap = j - 9 * m;
@@ -147,11 +155,11 @@ convpair64_kernel(const Pair64Params p) {
     }
   };
   // per-lane source offsets of this wave's (up to) three copy pieces of an input plane (the same for both planes)
-  auto make_voff = [&](const Tile& t, unsigned (&v)[3]) {
+  auto make_voff = [&](const Tile& t, unsigned (&v)[NIJ]) {
     int ln = lane;  // (an opaque copy: what is derived from it is re-derived per tile, not kept in registers across the stages)
     asm volatile("" : "+v"(ln));
 #pragma unroll
-    for (int jj = 0; jj < 3; ++jj) {
+    for (int jj = 0; jj < NIJ; ++jj) {
       const int i = jj * NW + wave;
       const int o = i * 1024 + ln * 16;
       const int pl = o >> 5, s = (o >> 4) & 1;
@@ -161,11 +169,11 @@ convpair64_kernel(const Pair64Params p) {
       v[jj] = ok ? (unsigned)(gy * W + gx) * pixb_in + (unsigned)((s ^ ((tx >> 3) & 1)) * 16) : OOB;
     }
   };
-  auto issue_in = [&](const Tile& t, const unsigned (&v)[3], int k) {
+  auto issue_in = [&](const Tile& t, const unsigned (&v)[NIJ], int k) {
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(reinterpret_cast<const unsigned char*>(p.src) + t.b * fbytes), 0, (int)fbytes, 0x00020000);
 #pragma unroll
-    for (int jj = 0; jj < 3; ++jj) {
+    for (int jj = 0; jj < NIJ; ++jj) {
       const int i = jj * NW + wave;  // wave uniform
       if (i < N_INP)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(smem + IN_OFF + k * IN_PLANE + i * 1024), 16, v[jj],
@@ -178,13 +186,14 @@ convpair64_kernel(const Pair64Params p) {
 #pragma unroll
   for (int dx = 0; dx < 3; ++dx) {
     const int c = lx + dx;
-    aoff[dx] = (unsigned)(2 * wave * IN_ROW + c * 32 + ((half ^ ((c >> 3) & 1)) * 16));
-    boff[dx] = (unsigned)(2 * wave * IP_ROW + c * 32 + ((half ^ ((c >> 3) & 1)) * 16));
+    aoff[dx] = (unsigned)(R * wave * IN_ROW + c * 32 + ((half ^ ((c >> 3) & 1)) * 16));
+    boff[dx] = (unsigned)(R * wave * IP_ROW + c * 32 + ((half ^ ((c >> 3) & 1)) * 16));
   }
   // the extra unit of this wave: pixel group xg = 16 + (wave >> 1) -- 16, 17: halo rows 16, 17, columns lx; 18, 19: the 36 pixels of
   // columns 32, 33 (pixel q = 32 (xg - 18) + lx -> row q >> 1, column 32 + (q & 1)) -- x cout tile wave & 1
-  const int m_x = wave & 1;
-  const int xg = 16 + (wave >> 1);
+  // (NW = 4: group 16 + wave x BOTH cout tiles)
+  const int m_x = NW == 8 ? (wave & 1) : 0;
+  const int xg = NW == 8 ? 16 + (wave >> 1) : 16 + wave;
   const bool x_rows = xg < 18;  // wave uniform
   struct XPix {
     int row, col;
@@ -214,23 +223,22 @@ convpair64_kernel(const Pair64Params p) {
 // Barriers inside the tile loop are the bare s_barrier: __syncthreads() carries a workgroup-scope fence, in front of which the
   // compiler drains vmcnt whenever an LDS-DMA is in flight (LDS-DMA completes through vmcnt) -- which is exactly what the
   // counted wait of stage B1 must not do. Every barrier is preceded by this wave's own waits (copies: vmcnt, LDS: lgkmcnt).
-#define SA_WAIT_VM(n) __builtin_amdgcn_s_waitcnt(0x0F70 | (n))
-#define SA_WAIT_VM_LGKM0(n) __builtin_amdgcn_s_waitcnt(0x0070 | (n))
+#define SA_WAIT_VM(n) __builtin_amdgcn_s_waitcnt(0x0F70 | ((n) & 15) | (((n) >> 4) << 14))
+#define SA_WAIT_VM_LGKM0(n) __builtin_amdgcn_s_waitcnt(0x0070 | ((n) & 15) | (((n) >> 4) << 14))
   // One stage of MFMAs: nine taps on the B fragments of halo rows 0..3 x columns 0..2 (read ONCE, up front) and the slot's A
   // fragments (read one tap ahead); XTRA (conv-a) adds the wave's extra unit: one more pixel group x one cout tile, its two
   // fragments read one tap ahead as well; `between(tap)` runs behind the MFMAs of a tap. sched_barrier(0) between the taps keeps the compiler from sinking the reads down to
   // their uses (it did: three fragments in flight, a wait in front of every MFMA pair).
   auto stage = [&](auto xtra_c, const unsigned char* bb, const unsigned (&off)[3], int row_bytes, const unsigned char* wt,
-                   f32x16 (&acc)[2][R], f32x16& accx, auto&& between) {
+                   f32x16 (&acc)[2][R], f32x16 (&accx)[XM], auto&& between) {
     constexpr bool XTRA = decltype(xtra_c)::value;
     const unsigned char* wl = wt + lane * 16;
     mfma_h8 bfr[R + 2][3], a[2][2], xa, xb;
     a[0][0] = *reinterpret_cast<const mfma_h8*>(wl);
     a[0][1] = *reinterpret_cast<const mfma_h8*>(wl + 9 * 1024);
-    // halo rows 0, 1 up front; rows 2, 3 one fragment per tap, three taps ahead of their first use (36 fragment registers live
-    // instead of 48: room for the deferred stores' 48)
+    // halo rows 0 .. R-1 up front; rows R, R+1 one fragment per tap, three taps ahead of their first use
 #pragma unroll
-    for (int rr = 0; rr < 2; ++rr)
+    for (int rr = 0; rr < R; ++rr)
 #pragma unroll
       for (int dx = 0; dx < 3; ++dx) bfr[rr][dx] = *reinterpret_cast<const mfma_h8*>(bb + off[dx] + rr * row_bytes);
     between(-1);  // (while the first fragments are on their way)
@@ -242,29 +250,31 @@ convpair64_kernel(const Pair64Params p) {
         a[nb][0] = *reinterpret_cast<const mfma_h8*>(wl + (tap + 1) * 1024);
         a[nb][1] = *reinterpret_cast<const mfma_h8*>(wl + (9 + tap + 1) * 1024);
       }
-      if constexpr (XTRA) {  // the extra unit's fragments: read at the head of the tap, used behind its four other MFMAs
-        xa = *reinterpret_cast<const mfma_h8*>(wl + (m_x * 9 + tap) * 1024);
+      if constexpr (XTRA) {  // the extra unit's fragments: read at the head of the tap, used behind its other MFMAs
+        if constexpr (XM == 1) xa = *reinterpret_cast<const mfma_h8*>(wl + (m_x * 9 + tap) * 1024);
         xb = *reinterpret_cast<const mfma_h8*>(bb + xoff[dx] + dy * IN_ROW);
       }
-      if (tap < 6) bfr[2 + tap / 3][tap % 3] = *reinterpret_cast<const mfma_h8*>(bb + off[tap % 3] + (2 + tap / 3) * row_bytes);
+      if (tap < 6) bfr[R + tap / 3][tap % 3] = *reinterpret_cast<const mfma_h8*>(bb + off[tap % 3] + (R + tap / 3) * row_bytes);
       __builtin_amdgcn_sched_barrier(0);  // (reads first: left alone the scheduler puts them behind the tap's third MFMA)
-#if defined(SA_PAIR64_PRIO)
-      // the two waves of a SIMD (w, w + 4) take turns at the matrix pipe tap by tap: at equal priority the OLDER wave is served
-      // first throughout, finishes its stage in half the time and waits at the barrier while the younger one runs alone
-      if (((tap ^ (wave >> 2)) & 1)) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);  // (wave uniform)
-#endif
 #pragma unroll
       for (int r = 0; r < R; ++r) {
         acc[0][r] = SA_MFMA_32x32x16(a[cb][0], bfr[r + dy][dx], acc[0][r], 0, 0, 0);
         acc[1][r] = SA_MFMA_32x32x16(a[cb][1], bfr[r + dy][dx], acc[1][r], 0, 0, 0);
       }
-      if constexpr (XTRA) accx = SA_MFMA_32x32x16(xa, xb, accx, 0, 0, 0);
-      between(tap);  // (the previous tile's deferred stores, one piece per tap: issued in the shadow of this tap's MFMAs)
+      if constexpr (XTRA) {
+        if constexpr (XM == 1) {
+          accx[0] = SA_MFMA_32x32x16(xa, xb, accx[0], 0, 0, 0);
+        } else {
+          accx[0] = SA_MFMA_32x32x16(a[cb][0], xb, accx[0], 0, 0, 0);
+          accx[1] = SA_MFMA_32x32x16(a[cb][1], xb, accx[1], 0, 0, 0);
+        }
+      }
+      between(tap);  // (the previous tile's deferred stores: issued in the shadow of this tap's MFMAs)
       __builtin_amdgcn_sched_barrier(0);
     }
   };
   auto nothing = [](int) {};
-  f32x16 accA[2][R], accX;
+  f32x16 accA[2][R], accX[XM];
   // Bias reads are OPAQUE ds_reads (inline asm) behind one explicit lgkmcnt(0): in front of a C++ load from LDS the compiler drains
   // vmcnt whenever it believes a copy in flight whose target it cannot tell from the load's address -- it cannot follow the
   // counted waits below across the `pend` branches -- and with it the deferred stores.
@@ -272,8 +282,7 @@ convpair64_kernel(const Pair64Params p) {
   const unsigned bias_addr = (unsigned)(uintptr_t)(lds_ptr_t)(smem + BIAS_OFF) + (unsigned)half * 16u;
 #define SA_LDS_READ4(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off) : "memory")
   auto init_a = [&]() {  // conv-a's accumulators start at its bias
-    f32x4v bq[2][4], bx[4];
-    const unsigned ax = bias_addr + (unsigned)m_x * 128u;
+    f32x4v bq[2][4];
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
       SA_LDS_READ4(bq[m][0], bias_addr, 0 + 128 * m);
@@ -281,22 +290,22 @@ convpair64_kernel(const Pair64Params p) {
       SA_LDS_READ4(bq[m][2], bias_addr, 64 + 128 * m);
       SA_LDS_READ4(bq[m][3], bias_addr, 96 + 128 * m);
     }
-    SA_LDS_READ4(bx[0], ax, 0);
-    SA_LDS_READ4(bx[1], ax, 32);
-    SA_LDS_READ4(bx[2], ax, 64);
-    SA_LDS_READ4(bx[3], ax, 96);
     __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
+    for (int g = 0; g < 4; ++g)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
           for (int r = 0; r < R; ++r) accA[m][r][4 * g + j] = bq[m][g][j];
-        accX[4 * g + j] = bx[g][j];
+        if constexpr (XM == 1) {
+          accX[0][4 * g + j] = m_x ? bq[1][g][j] : bq[0][g][j];  // (wave uniform)
+        } else {
+          accX[0][4 * g + j] = bq[0][g][j];
+          accX[XM - 1][4 * g + j] = bq[1][g][j];
+        }
       }
-    }
   };
   auto init_b = [&](f32x16 (&acc)[2][R]) {  // conv-b's
     f32x4v bq[2][4];
@@ -322,7 +331,7 @@ convpair64_kernel(const Pair64Params p) {
   if (tid < 128) reinterpret_cast<float*>(smem + BIAS_OFF)[tid] = tid < 64 ? p.bias_a[tid] : p.bias_b[tid - 64];
   Tile cur = decode(L);
   {
-    unsigned v[3];
+    unsigned v[NIJ];
     make_voff(cur, v);
     issue_w(rwa, 2, 0, 0);
     issue_in(cur, v, 0);
@@ -369,10 +378,10 @@ convpair64_kernel(const Pair64Params p) {
     return pkmax(t, (uint32_t)__builtin_amdgcn_update_dpp((int)t, (int)t, 0xB1, 0xF, 0xF, false));
   };
   const size_t blk_full = p.planar ? (size_t)H * W * 32 : (size_t)32, blk_pool = p.planar ? (size_t)(H / 2) * (W / 2) * 32 : (size_t)32;
-  // piece i of the full-resolution output: cout tile i >> 2, row (i >> 1) & 1, 16-channel block i & 1 of the cout tile
   int ln_s = lane;  // (opaque per tile, see the loop: the stores' lane offsets are not kept across the stages)
+  // piece i of the full-resolution output (4 R per wave): cout tile i / (2 R), row (i / 2) % R, 16-channel block i & 1 of the tile
   auto store_full = [&](const Tile& t, int i, auto checked_c) {
-    const int m = i >> 2, r = (i >> 1) & 1, pr = i & 1;
+    const int m = i / (2 * R), r = (i >> 1) % R, pr = i & 1;
     const int gy = t.y0 + wave * R + r, gx = t.x0 + (ln_s & 31);  // gy wave uniform
     uint2 x = pkf[m][r][2 * pr], y = pkf[m][r][2 * pr + 1];
     sa::swap32(x.x, y.x);
@@ -382,13 +391,13 @@ convpair64_kernel(const Pair64Params p) {
     const unsigned lane_off = (unsigned)gx * pixb_out + (unsigned)(ln_s >> 5) * 16u;
     if (!decltype(checked_c)::value || (gx < W && gy < H)) *reinterpret_cast<uint4*>(base + lane_off) = make_uint4(x.x, x.y, y.x, y.y);
   };
-  // piece i of the pooled output: cout tile i >> 1, 16-channel block i & 1
+  // piece i of the pooled output (2 R per wave): cout tile i / R, row pair (i / 2) % (R / 2), 16-channel block i & 1
   auto store_pool = [&](const Tile& t, int i, auto checked_c) {
-    const int m = i >> 1, pr = i & 1;
-    const int gy = t.y0 + wave * R, gx = t.x0 + (ln_s & 31);
+    const int m = i / R, rp = (i >> 1) % (R / 2), pr = i & 1;
+    const int gy = t.y0 + wave * R + 2 * rp, gx = t.x0 + (ln_s & 31);
     uint2 x, y;  // (computed here, from the full-resolution values: 16 registers less to carry into the next tile)
-    x.x = pool2(pkf[m][0][2 * pr].x, pkf[m][1][2 * pr].x), x.y = pool2(pkf[m][0][2 * pr].y, pkf[m][1][2 * pr].y);
-    y.x = pool2(pkf[m][0][2 * pr + 1].x, pkf[m][1][2 * pr + 1].x), y.y = pool2(pkf[m][0][2 * pr + 1].y, pkf[m][1][2 * pr + 1].y);
+    x.x = pool2(pkf[m][2 * rp][2 * pr].x, pkf[m][2 * rp + 1][2 * pr].x), x.y = pool2(pkf[m][2 * rp][2 * pr].y, pkf[m][2 * rp + 1][2 * pr].y);
+    y.x = pool2(pkf[m][2 * rp][2 * pr + 1].x, pkf[m][2 * rp + 1][2 * pr + 1].x), y.y = pool2(pkf[m][2 * rp][2 * pr + 1].y, pkf[m][2 * rp + 1][2 * pr + 1].y);
     sa::swap32(x.x, y.x);
     sa::swap32(x.y, y.y);
     unsigned char* base = reinterpret_cast<unsigned char*>(p.dst_pool) + (size_t)t.b * (H / 2) * (W / 2) * 128 + (size_t)(2 * m + pr) * blk_pool +
@@ -407,20 +416,28 @@ convpair64_kernel(const Pair64Params p) {
 #if defined(SA_PAIR64_STAMP)
     st_a[1] += 1;
 #endif
-    // Memory waits of the tile loop. A stage's copies are queued at its head, the (up to) TWO deferred stores of the stage behind
-    // them: the wait in front of the NEXT stage is `vmcnt(2)` -- the copies, not the stores (the counter retires in order; a
-    // vmcnt(0) would put a store's round trip to HBM in front of every barrier). Without deferred stores it is vmcnt(0).
+    // Memory waits of the tile loop. A stage's copies are queued at its head, the R deferred stores of the stage behind them: the
+    // wait in front of the NEXT stage is `vmcnt(R)` -- the copies, not the stores (the counter retires in order; a vmcnt(0)
+    // would put a store's round trip to HBM in front of every barrier). Without deferred stores it is vmcnt(0).
     init_a();  // (this wave's copies for the tile -- conv-a k-half 0, the input planes -- were waited for at the end of the previous tile)
     ln_s = lane;
     asm volatile("" : "+v"(ln_s));
-    // the deferred stores of the PREVIOUS tile (`prev`), two pieces per stage: pooled 0-3 in A0 / A1, full-resolution 0-7 in B0-B3
+    // the deferred stores of the PREVIOUS tile (`prev`), R pieces per stage (behind taps 2, 6 / 1, 3, 5, 7): the 2 R pooled
+    // pieces in A0 / A1, the 4 R full-resolution pieces in B0-B3
     auto deferred = [&](int stage_i, int tap) {
-      if (!pend || (tap != 2 && tap != 6)) return;
-      const int j = tap == 6 ? 1 : 0;
+      if (!pend || tap < 0) return;
+      int j;
+      if constexpr (R == 2) {
+        if (tap != 2 && tap != 6) return;
+        j = tap == 6 ? 1 : 0;
+      } else {
+        if (!(tap & 1)) return;
+        j = tap >> 1;
+      }
       if (stage_i < 2)
-        store_pool(prev, 2 * stage_i + j, std::false_type{});
+        store_pool(prev, R * stage_i + j, std::false_type{});
       else
-        store_full(prev, 2 * (stage_i - 2) + j, std::false_type{});
+        store_full(prev, R * (stage_i - 2) + j, std::false_type{});
     };
 
     // ================= phase A: conv-a (32 -> 64) on the 18 x 34 halo pixels, k-halves 0 and 1
@@ -430,7 +447,7 @@ convpair64_kernel(const Pair64Params p) {
     issue_w(rwa, 2, 1, 1);
     stage(std::true_type{}, smem + IN_OFF, aoff, IN_ROW, smem + RING_OFF, accA, accX, [&](int tap) { deferred(0, tap); });
     ST(3);
-    if (pend) SA_WAIT_VM_LGKM0(2); else SA_WAIT_VM_LGKM0(0);  // conv-a k-half 1
+    if (pend) SA_WAIT_VM_LGKM0(R); else SA_WAIT_VM_LGKM0(0);  // conv-a k-half 1
     ST(17);
     __builtin_amdgcn_s_barrier();  // k-half 1 landed; A0 is finished (slot 0)
     ST(9);
@@ -472,11 +489,11 @@ convpair64_kernel(const Pair64Params p) {
       int ln = lane;  // (re-derived per tile: see make_voff)
       asm volatile("" : "+v"(ln));
       const int hf = ln >> 5, lxe = ln & 31;
-      const unsigned woff = (unsigned)(2 * wave * IP_ROW + lxe * 32 + ((hf ^ ((lxe >> 3) & 1)) * 16));  // row 2 wave, column lx
+      const unsigned woff = (unsigned)(R * wave * IP_ROW + lxe * 32 + ((hf ^ ((lxe >> 3) & 1)) * 16));  // row R wave, column lx
       const bool colok = (unsigned)(cur.x0 + lxe - 1) < (unsigned)W;
 #pragma unroll
       for (int r = 0; r < R; ++r) {
-        const bool rowok = (unsigned)(cur.y0 + 2 * wave + r - 1) < (unsigned)H;  // wave uniform
+        const bool rowok = (unsigned)(cur.y0 + R * wave + r - 1) < (unsigned)H;  // wave uniform
         const unsigned mask = (rowok && colok) ? 0xFFFFFFFFu : 0u;
 #pragma unroll
         for (int m = 0; m < 2; ++m) put(accA[m][r], mask, true, smem + INTER_OFF + woff + r * IP_ROW, m);
@@ -485,7 +502,8 @@ convpair64_kernel(const Pair64Params p) {
         const XPix xp = xpix(lxe);
         const unsigned xwoff = (unsigned)(xp.row * IP_ROW + xp.col * 32 + ((hf ^ ((xp.col >> 3) & 1)) * 16));
         const bool in_img = (unsigned)(cur.y0 + xp.row - 1) < (unsigned)H && (unsigned)(cur.x0 + xp.col - 1) < (unsigned)W;
-        put(accX, in_img ? 0xFFFFFFFFu : 0u, xp.valid, smem + INTER_OFF + xwoff, m_x);
+#pragma unroll
+        for (int xm = 0; xm < XM; ++xm) put(accX[xm], in_img ? 0xFFFFFFFFu : 0u, xp.valid, smem + INTER_OFF + xwoff, XM == 1 ? m_x : xm);
       }
     }
 
@@ -497,14 +515,14 @@ convpair64_kernel(const Pair64Params p) {
     for (int c = 0; c < 4; ++c) {
       // chunk c landed; the stage before is finished (c == 0: the intermediate tile is complete). c == 1: the next tile's input
       // planes, queued BEHIND chunk 1 in B0, may stay in flight (the counter retires in order): they have until B2.
-      if (c == 1 && more) {  // (wave uniform) 2 x 3 or 2 x 2 input pieces per wave, + the stage's two deferred stores
-        if (wave < N_INP - 2 * NW) {
-          if (pend) SA_WAIT_VM_LGKM0(8); else SA_WAIT_VM_LGKM0(6);
+      if (c == 1 && more) {  // (wave uniform) 2 x NIJ or 2 x (NIJ - 1) input pieces per wave, + the stage's R deferred stores
+        if (wave < N_INP - (NIJ - 1) * NW) {
+          if (pend) SA_WAIT_VM_LGKM0(2 * NIJ + R); else SA_WAIT_VM_LGKM0(2 * NIJ);
         } else {
-          if (pend) SA_WAIT_VM_LGKM0(6); else SA_WAIT_VM_LGKM0(4);
+          if (pend) SA_WAIT_VM_LGKM0(2 * NIJ - 2 + R); else SA_WAIT_VM_LGKM0(2 * NIJ - 2);
         }
       } else {
-        if (pend) SA_WAIT_VM_LGKM0(2); else SA_WAIT_VM_LGKM0(0);  // (c == 0: lgkmcnt(0) = this wave's ds_writes of the intermediate tile)
+        if (pend) SA_WAIT_VM_LGKM0(R); else SA_WAIT_VM_LGKM0(0);  // (c == 0: lgkmcnt(0) = this wave's ds_writes of the intermediate tile)
       }
       ST(18 + c);
       __builtin_amdgcn_s_barrier();
@@ -513,7 +531,7 @@ convpair64_kernel(const Pair64Params p) {
       if (c < 3) {
         issue_w(rwb, 4, c + 1, (c + 1) & 1);
         if (c == 0 && more) {  // A1 is finished: both input planes are free
-          unsigned vnext[3];
+          unsigned vnext[NIJ];
           nxt = decode(L_next);
           make_voff(nxt, vnext);
           issue_in(nxt, vnext, 0);
@@ -536,17 +554,17 @@ convpair64_kernel(const Pair64Params p) {
     if (!pend_next) {
       if (has_full) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) store_full(cur, i, std::true_type{});
+        for (int i = 0; i < 4 * R; ++i) store_full(cur, i, std::true_type{});
       }
       if (has_pool) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) store_pool(cur, i, std::true_type{});
+        for (int i = 0; i < 2 * R; ++i) store_pool(cur, i, std::true_type{});
       }
     }
     ST(6);
     if (!more) break;
-    // the next tile's conv-a k-half 0 (queued in B3, in front of B3's two deferred stores -- governed by THIS tile's `pend`)
-    if (pend && pend_next) SA_WAIT_VM_LGKM0(2); else SA_WAIT_VM_LGKM0(0);
+    // the next tile's conv-a k-half 0 (queued in B3, in front of B3's R deferred stores -- governed by THIS tile's `pend`)
+    if (pend && pend_next) SA_WAIT_VM_LGKM0(R); else SA_WAIT_VM_LGKM0(0);
     pend = pend_next;
     prev = cur;
     cur = nxt;
@@ -602,7 +620,8 @@ int sa_convpair64_launch(const void* src, const void* wa, const float* bias_a, i
     if (lds_max < LDS_BYTES)
       return sa::fail(SA_ERR_UNSUPPORTED, "sa_conv3x3_pair_bf16: the 32 -> 64 -> 64 block needs %d bytes of LDS per workgroup (device: %d)",
                       LDS_BYTES, lds_max);
-    SA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&convpair64_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+    SA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&convpair64_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+    SA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&convpair64_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
     SA_HIP_CHECK(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
   }
   // one workgroup per CU (LDS); sa_conv3x3_set_grid_limit(n) launches at most n workgroups (tests: uneven tile shares)
@@ -611,7 +630,13 @@ int sa_convpair64_launch(const void* src, const void* wa, const float* bias_a, i
   if (limit > 0 && (size_t)limit < grid) grid = (size_t)limit;
   if (grid > nblk) grid = nblk;
   if (grid < 8 && nblk >= 8) grid = 8;  // the XCD schedule hands every XCD a range: at least one workgroup each
-  hipLaunchKernelGGL(convpair64_kernel, dim3((unsigned)grid), dim3(NW * 64), LDS_BYTES, stream, p);
+  // SA_PAIR64_WAVES=8: two waves per SIMD x two rows each (A/B); default 4: one wave per SIMD x four rows
+  const char* wv_env = getenv("SA_PAIR64_WAVES");  // (read per launch: the tests switch it)
+  const int waves = wv_env && atoi(wv_env) == 8 ? 8 : 4;
+  if (waves == 8)
+    hipLaunchKernelGGL(convpair64_kernel<8>, dim3((unsigned)grid), dim3(512), LDS_BYTES, stream, p);
+  else
+    hipLaunchKernelGGL(convpair64_kernel<4>, dim3((unsigned)grid), dim3(256), LDS_BYTES, stream, p);
   SA_LAUNCH_CHECK();
   return SA_OK;
 }

@@ -373,6 +373,7 @@ def test_conv_pair_is_bitwise_two_convs(B, H, W, full, pooled, layout):
         assert torch.equal(back(outp), ref[1])
 
 
+@pytest.mark.parametrize("waves", [4, 8])
 @pytest.mark.parametrize("dtype", STORAGE_DTYPES)
 @pytest.mark.parametrize("layout", ["nhwc", "planes16"])
 @pytest.mark.parametrize("B,H,W,full,pooled,limit", [
@@ -381,11 +382,13 @@ def test_conv_pair_is_bitwise_two_convs(B, H, W, full, pooled, layout):
     (3, 64, 160, True, True, 9),      # 60 tiles on 9 workgroups: 6-7 tiles each, XCD ranges of uneven length
     (5, 128, 128, True, True, 0),     # 160 tiles, one per workgroup
     (2, 256, 256, False, True, 0)])   # 256 tiles at the benchmark layer's size
-def test_conv_pair64_is_bitwise_two_convs(B, H, W, full, pooled, limit, layout, dtype):
+def test_conv_pair64_is_bitwise_two_convs(B, H, W, full, pooled, limit, layout, dtype, waves, monkeypatch):
     """Round 6: the 32 -> 64 -> 64 form of sa_conv3x3_pair_bf16 (encoder block 2, csrc/convpair64.hip: one persistent workgroup
     per CU, the 64-channel intermediate only in LDS) == sa_conv3x3_bf16 twice, bit for bit -- same rounding of the intermediate,
     same MFMA accumulation order (chunk-major, taps inside); image borders, ragged tiles, several tiles per workgroup
-    (sa_conv3x3_set_grid_limit), both layouts, both storage types. Outputs are poisoned first: a skipped tile must not pass."""
+    (sa_conv3x3_set_grid_limit), both layouts, both storage types, both workgroup shapes (SA_PAIR64_WAVES: one wave per SIMD x four
+    rows -- the default -- and two waves per SIMD x two rows). Outputs are poisoned first: a skipped tile must not pass."""
+    monkeypatch.setenv("SA_PAIR64_WAVES", str(waves))
     from sleap_amd import _lib, ops
     from sleap_amd._lib import check
     from sleap_amd.ops import _ptr, _stream
