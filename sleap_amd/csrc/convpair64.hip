@@ -39,6 +39,13 @@
 #include "bf16.h"
 #include "sa_common.h"
 
+// the tap of a stage behind which the copies for a later stage are queued (-1: at the stage's head). Measured on one box, the
+// benchmark network's data (profiles/r06_pair64.md): -1 0.417, 3 0.409, 1 0.404 ms -- the copy instructions (2-3 per wave, ~100
+// cycles of issue each) go out under the wave's own MFMAs instead of in front of its first fragment reads.
+#if !defined(SA_PAIR64_ITAP)
+#define SA_PAIR64_ITAP 1
+#endif
+
 namespace {
 
 using sa::mfma_h8;
@@ -106,6 +113,10 @@ convpair64_kernel(const Pair64Params p) {
   constexpr int XM = NW == 8 ? 1 : 2;            // cout tiles of a wave's extra conv-a unit
   constexpr int NWJ = (18 + NW - 1) / NW;        // weight slabs per wave and copy (<=)
   constexpr int NIJ = (N_INP + NW - 1) / NW;     // input pieces per wave and plane (<=)
+  // ITAP: the tap of a stage behind which the copies for a LATER stage are queued (-1: at the stage's head, in front of its first
+  // fragment reads). YS = the stage's deferred stores that are queued behind those copies (store taps: 2, 6 / 1, 3, 5, 7).
+  constexpr int ITAP = SA_PAIR64_ITAP;
+  constexpr int YS = ITAP < 0 ? R : (R == 2 ? (ITAP <= 2 ? 2 : (ITAP <= 6 ? 1 : 0)) : (ITAP <= 1 ? 4 : (ITAP <= 3 ? 3 : (ITAP <= 5 ? 2 : (ITAP <= 7 ? 1 : 0)))));
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -424,7 +435,29 @@ convpair64_kernel(const Pair64Params p) {
     asm volatile("" : "+v"(ln_s));
     // the deferred stores of the PREVIOUS tile (`prev`), R pieces per stage (behind taps 2, 6 / 1, 3, 5, 7): the 2 R pooled
     // pieces in A0 / A1, the 4 R full-resolution pieces in B0-B3
+    Tile nxt = cur;
+    // the copies queued during stage i: A0 conv-a k-half 1; A1 conv-b chunk 0; B0 chunk 1 + the NEXT tile's input planes (A1 is
+    // finished: both are free); B1, B2 chunks 2, 3; B3 the next tile's conv-a k-half 0
+    auto copies = [&](int stage_i) {
+      if (stage_i == 0) {
+        issue_w(rwa, 2, 1, 1);
+      } else if (stage_i == 1) {
+        issue_w(rwb, 4, 0, 0);
+      } else if (stage_i < 5) {
+        issue_w(rwb, 4, stage_i - 1, (stage_i - 1) & 1);
+        if (stage_i == 2 && more) {
+          unsigned vnext[NIJ];
+          nxt = decode(L_next);
+          make_voff(nxt, vnext);
+          issue_in(nxt, vnext, 0);
+          issue_in(nxt, vnext, 1);
+        }
+      } else if (more) {
+        issue_w(rwa, 2, 0, 0);
+      }
+    };
     auto deferred = [&](int stage_i, int tap) {
+      if (ITAP >= 0 && tap == ITAP) copies(stage_i);
       if (!pend || tap < 0) return;
       int j;
       if constexpr (R == 2) {
@@ -444,14 +477,14 @@ convpair64_kernel(const Pair64Params p) {
     ST(16);
     __builtin_amdgcn_s_barrier();  // every wave's copies landed; the previous tile's B3 is finished (slot 1, the intermediate tile)
     ST(8);
-    issue_w(rwa, 2, 1, 1);
+    if (ITAP < 0) copies(0);
     stage(std::true_type{}, smem + IN_OFF, aoff, IN_ROW, smem + RING_OFF, accA, accX, [&](int tap) { deferred(0, tap); });
     ST(3);
-    if (pend) SA_WAIT_VM_LGKM0(R); else SA_WAIT_VM_LGKM0(0);  // conv-a k-half 1
+    if (pend) SA_WAIT_VM_LGKM0(YS); else SA_WAIT_VM_LGKM0(0);  // conv-a k-half 1
     ST(17);
     __builtin_amdgcn_s_barrier();  // k-half 1 landed; A0 is finished (slot 0)
     ST(9);
-    issue_w(rwb, 4, 0, 0);
+    if (ITAP < 0) copies(1);
     stage(std::true_type{}, smem + IN_OFF + IN_PLANE, aoff, IN_ROW, smem + RING_OFF + SLOT, accA, accX, [&](int tap) { deferred(1, tap); });
     ST(3);
     // ---- epilogue a: ReLU, 16-bit pack, zero outside the image (= conv-b's SAME padding), 16-byte stores into the planes
@@ -510,36 +543,24 @@ convpair64_kernel(const Pair64Params p) {
     ST(4);
     // ================= phase B: conv-b (64 -> 64), wave owns rows 2 wave, 2 wave + 1 x both cout tiles
     f32x16 acc[2][R];
-    Tile nxt = cur;
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       // chunk c landed; the stage before is finished (c == 0: the intermediate tile is complete). c == 1: the next tile's input
       // planes, queued BEHIND chunk 1 in B0, may stay in flight (the counter retires in order): they have until B2.
       if (c == 1 && more) {  // (wave uniform) 2 x NIJ or 2 x (NIJ - 1) input pieces per wave, + the stage's R deferred stores
         if (wave < N_INP - (NIJ - 1) * NW) {
-          if (pend) SA_WAIT_VM_LGKM0(2 * NIJ + R); else SA_WAIT_VM_LGKM0(2 * NIJ);
+          if (pend) SA_WAIT_VM_LGKM0(2 * NIJ + YS); else SA_WAIT_VM_LGKM0(2 * NIJ);
         } else {
-          if (pend) SA_WAIT_VM_LGKM0(2 * NIJ - 2 + R); else SA_WAIT_VM_LGKM0(2 * NIJ - 2);
+          if (pend) SA_WAIT_VM_LGKM0(2 * NIJ - 2 + YS); else SA_WAIT_VM_LGKM0(2 * NIJ - 2);
         }
       } else {
-        if (pend) SA_WAIT_VM_LGKM0(R); else SA_WAIT_VM_LGKM0(0);  // (c == 0: lgkmcnt(0) = this wave's ds_writes of the intermediate tile)
+        if (pend) SA_WAIT_VM_LGKM0(YS); else SA_WAIT_VM_LGKM0(0);  // (c == 0: lgkmcnt(0) = this wave's ds_writes of the intermediate tile)
       }
       ST(18 + c);
       __builtin_amdgcn_s_barrier();
       ST(10 + c);
       if (c == 0) init_b(acc);
-      if (c < 3) {
-        issue_w(rwb, 4, c + 1, (c + 1) & 1);
-        if (c == 0 && more) {  // A1 is finished: both input planes are free
-          unsigned vnext[NIJ];
-          nxt = decode(L_next);
-          make_voff(nxt, vnext);
-          issue_in(nxt, vnext, 0);
-          issue_in(nxt, vnext, 1);
-        }
-      } else if (more) {
-        issue_w(rwa, 2, 0, 0);
-      }
+      if (ITAP < 0) copies(2 + c);
       stage(std::false_type{}, smem + INTER_OFF + c * IP_PLANE, boff, IP_ROW, smem + RING_OFF + (c & 1) * SLOT, acc, accX,
             [&](int tap) { deferred(2 + c, tap); });
       ST(5);
@@ -564,7 +585,7 @@ convpair64_kernel(const Pair64Params p) {
     ST(6);
     if (!more) break;
     // the next tile's conv-a k-half 0 (queued in B3, in front of B3's R deferred stores -- governed by THIS tile's `pend`)
-    if (pend && pend_next) SA_WAIT_VM_LGKM0(R); else SA_WAIT_VM_LGKM0(0);
+    if (pend && pend_next) SA_WAIT_VM_LGKM0(YS); else SA_WAIT_VM_LGKM0(0);
     pend = pend_next;
     prev = cur;
     cur = nxt;
@@ -630,9 +651,10 @@ int sa_convpair64_launch(const void* src, const void* wa, const float* bias_a, i
   if (limit > 0 && (size_t)limit < grid) grid = (size_t)limit;
   if (grid > nblk) grid = nblk;
   if (grid < 8 && nblk >= 8) grid = 8;  // the XCD schedule hands every XCD a range: at least one workgroup each
-  // SA_PAIR64_WAVES=8: two waves per SIMD x two rows each (A/B); default 4: one wave per SIMD x four rows
+  // default: 8 waves (two per SIMD x two rows each). SA_PAIR64_WAVES=4: one wave per SIMD x four rows (A/B: 0.49 vs 0.42 ms --
+  // alone on its SIMD a wave's stage heads (five copy pieces, fourteen fragment reads) and epilogues are covered by nobody)
   const char* wv_env = getenv("SA_PAIR64_WAVES");  // (read per launch: the tests switch it)
-  const int waves = wv_env && atoi(wv_env) == 8 ? 8 : 4;
+  const int waves = wv_env && atoi(wv_env) == 4 ? 4 : 8;
   if (waves == 8)
     hipLaunchKernelGGL(convpair64_kernel<8>, dim3((unsigned)grid), dim3(512), LDS_BYTES, stream, p);
   else

@@ -386,8 +386,8 @@ def test_conv_pair64_is_bitwise_two_convs(B, H, W, full, pooled, limit, layout, 
     """Round 6: the 32 -> 64 -> 64 form of sa_conv3x3_pair_bf16 (encoder block 2, csrc/convpair64.hip: one persistent workgroup
     per CU, the 64-channel intermediate only in LDS) == sa_conv3x3_bf16 twice, bit for bit -- same rounding of the intermediate,
     same MFMA accumulation order (chunk-major, taps inside); image borders, ragged tiles, several tiles per workgroup
-    (sa_conv3x3_set_grid_limit), both layouts, both storage types, both workgroup shapes (SA_PAIR64_WAVES: one wave per SIMD x four
-    rows -- the default -- and two waves per SIMD x two rows). Outputs are poisoned first: a skipped tile must not pass."""
+    (sa_conv3x3_set_grid_limit), both layouts, both storage types, both workgroup shapes (SA_PAIR64_WAVES: two waves per SIMD x two
+    rows -- the default -- and one wave per SIMD x four rows). Outputs are poisoned first: a skipped tile must not pass."""
     monkeypatch.setenv("SA_PAIR64_WAVES", str(waves))
     from sleap_amd import _lib, ops
     from sleap_amd._lib import check
