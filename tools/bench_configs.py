@@ -123,6 +123,22 @@ bl = BottomUpInferenceLayer(rnet, scorer, pad_to_stride=32, cm_output_stride=4, 
 bl.assume_inputs_ready = True
 bm = BottomUpInferenceModel(bl)
 o = timed(bm.call_checked, fr, "configs[4] bottom-up ResNet-50 + transposed-conv upsampling stack + PAFs, 1024x1024, 24 nodes / 23 edges", 16)
+# the ResNet forward alone against BOTH rooflines (round 6, VERDICT r5 item 8: 25 of its 58 launches are 1x1 convs that move their
+# bytes at 3-4.5 TB/s -- the HBM roofline, not the MFMA one, is the yardstick of this network): algorithmic bytes = every launch's
+# inputs read once and outputs written once (DeviceNetwork.op_bytes), FLOPs = DeviceNetwork.op_descriptions
+for _ in range(3):
+    rnet.forward(fr)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(STEPS):
+    rnet.forward(fr)
+torch.cuda.synchronize()
+net_ms = (time.perf_counter() - t0) / STEPS * 1e3
+nb4 = float(sum(rnet.op_bytes(1024, 1024))) * 16
+fl4 = float(sum(f for _, _, f in rnet.op_descriptions(1024, 1024))) * 16
+print(f"|   (configs[4] network forward alone: {net_ms:.2f} ms per 16 frames; algorithmic {nb4 / 1e9:.2f} GB -> {nb4 / net_ms / 1e9:.2f} TB/s = "
+      f"**{nb4 / net_ms / 1e9 / 8.0:.3f} of the 8 TB/s HBM roofline**; {fl4 / 1e12:.2f} TFLOP -> {fl4 / net_ms / 1e9:.0f} TFLOP/s = "
+      f"{fl4 / net_ms / 1e9 / 2500.0:.3f} of the MFMA roofline) | | | | |")
 print(f"|   (configs[4] status bits {int(np.bitwise_or.reduce(o['status'].cpu().numpy().astype(np.int64)))}, "
       f"instances per frame {float(o['n_valid'].float().mean()):.2f}; configs[0] {o0}) | | | | |")
 

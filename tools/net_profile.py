@@ -60,5 +60,13 @@ print("---- by kind (TB/s = algorithmic bytes: every input read once, every outp
 for key, (ms, fl, n, nb) in sorted(agg.items(), key=lambda kv: -kv[1][0]):
     print(f"{key:20s} n={n:3d} {ms:8.3f} ms {fl / ms / 1e9 if ms else 0:8.1f} TFLOP/s {nb / ms / 1e9 if ms else 0:7.2f} TB/s")
 tot_f = sum(f for _, _, f in descs) * B
+tot_b = float(sum(nbytes)) * B
 print(f"total {acc.sum():.3f} ms for {B} frames of {H}x{H}: {B / acc.sum() * 1e3:.1f} frames/s, {tot_f / acc.sum() / 1e9:.1f} TFLOP/s, "
       f"{tot_f / B / 1e9:.1f} GFLOP/frame")
+# both rooflines of the whole forward (round 6, VERDICT r5 item 8: for a backbone of 1x1 convs the MFMA fraction is the wrong
+# yardstick -- its launches move their bytes at 3-4.5 TB/s): FLOPs / time / 2.5 PFLOP/s, and ALGORITHMIC bytes (every launch's
+# inputs read once, outputs written once) / time / 8 TB/s; the share of the time spent in launches that move > 3 TB/s
+hbm_ms = sum(ms for ms, nb in zip(acc, nbytes) if ms > 0 and nb * B / ms / 1e9 > 3.0)
+print(f"roofline of the forward: MFMA {tot_f / acc.sum() / 1e9 / 2500.0:.3f} of 2.5 PFLOP/s; HBM {tot_b / acc.sum() / 1e9 / 8.0:.3f} of 8 TB/s "
+      f"({tot_b / 1e9:.2f} GB algorithmic per {B} frames, {tot_b / acc.sum() / 1e9:.2f} TB/s average); "
+      f"{hbm_ms / acc.sum():.0%} of the time in launches above 3 TB/s")
