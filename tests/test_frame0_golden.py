@@ -1,0 +1,110 @@
+"""The one end-to-end golden the reference holds that TensorFlow itself produced (VERDICT r5 "missing" 2-3):
+
+    tests/data/models/minimal_instance.UNet.bottomup/labels_pr.val.slp  (tests/golden/slp/bottomup.labels_pr.val.npz)
+      = BottomUpPredictor.predict on frame 0 of tests/data/json_format_v1/centered_pair_low_quality.mp4: two instances, four
+        points, their scores -- the predictions sleap-train wrote with the trained model, a UNet with a DECODER
+        (UpSampling2D(bilinear) + Concatenate + refine convs), confidence maps + PAFs + offset-free integral refinement.
+
+Until round 6 that frame could not be read: it lives in an H.264 stream and neither the build container nor the GPU box has a
+decoder (profiles/r06_decoder_probe.txt). The package now decodes the key frames of such a file itself
+(sleap_amd/io/_h264_intra.py, `MediaVideo`); the MP4 is committed as a fixture (a data file of the reference's test suite).
+
+Pinned here, on CPU:
+  * the decoder: all eight key frames decode with the CABAC self-checks (end_of_slice_flag exactly at the last macroblock, the
+    slice data exhausted, a grey stream's chroma planes constant 128); frame 0 equals the frozen planes of the fixture;
+  * the ORACLE (fp32 restatement of the network + peak finding + PAF grouping) on that frame == the TensorFlow result: every
+    point within 1e-3 px, instance scores and point scores within 1e-4 -- measured 0.0000 px / 0.00000 with libswscale's SIMD
+    limited -> full range conversion (its rounding C-table form gives 0.07 px: the test asserts that too, as the reason for the
+    choice) -- and within 1.75 px of the user labels, the reference's own assertion (tests/nn/test_inference.py:769-786).
+The device path against the same golden: tests/test_gpu_frame0_golden.py."""
+import os
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+MP4 = os.path.join(ROOT, "tests", "golden", "video", "centered_pair_low_quality.mp4")
+MODEL = os.path.join(ROOT, "tests", "golden", "models", "minimal_instance.UNet.bottomup")
+FROZEN = os.path.join(ROOT, "tests", "golden", "centered_pair_frame0.npz")
+
+
+def golden_predictions():
+    """-> (points (2 instances, 2 nodes, 2), point scores (2, 2), instance scores (2,)) of labels_pr.val.slp"""
+    z = np.load(os.path.join(ROOT, "tests", "golden", "slp", "bottomup.labels_pr.val.npz"), allow_pickle=True)
+    pp, inst = z["pred_points"], z["instances"]
+    assert len(z["frames"]) == 1 and int(z["frames"][0]["frame_idx"]) == 0 and len(inst) == 2 and len(pp) == 4
+    pts = np.array([[[pp[i]["x"], pp[i]["y"]] for i in range(int(r["point_id_start"]), int(r["point_id_end"]))] for r in inst])
+    sc = np.array([[pp[i]["score"] for i in range(int(r["point_id_start"]), int(r["point_id_end"]))] for r in inst])
+    return pts, sc, np.array([float(r["score"]) for r in inst])
+
+
+def match_instances(got, want):
+    """order the predicted instances as the golden ones (nearest mean point distance) -> index array"""
+    return [int(np.argmin([np.nanmean(np.linalg.norm(g - w, axis=-1)) for g in got])) for w in want]
+
+
+def test_media_video_reads_the_key_frames_and_refuses_the_others():
+    from sleap_amd.io.video import MediaVideo, Video
+
+    v = Video.from_filename(MP4)
+    assert isinstance(v.backend, MediaVideo) and v.shape == (1100, 384, 384, 1) and v.dtype == np.uint8
+    assert v.backend.grayscale is True and v.backend.keyframes == [0, 150, 300, 450, 600, 750, 900, 1050] and abs(v.backend.fps - 15.0) < 1e-9
+    assert v.backend_dict() == {"filename": MP4, "grayscale": True, "bgr": True, "dataset": "", "input_format": ""}
+    z = np.load(FROZEN)
+    np.testing.assert_array_equal(v[0][..., 0], z["gray"])
+    assert v.backend.get_frame(0, grayscale=False).shape == (384, 384, 3)
+    with pytest.raises(KeyError, match="only key frames"):
+        v[1]
+    with pytest.raises(KeyError, match="Unable to load frame 5000"):
+        v.get_frame(5000)
+
+
+def test_every_key_frame_decodes_with_its_self_checks():
+    from sleap_amd.io import _h264_intra as H
+
+    tr = H.Mp4H264(MP4)
+    z = np.load(FROZEN)
+    for k, i in enumerate(tr.sync):
+        y, cb, cr, st = H.decode_intra(tr, i)  # asserts: end_of_slice_flag at macroblock 575 exactly, <= 16 bits left
+        assert y.shape == (384, 384) and cb.shape == cr.shape == (192, 192) and st["I4"] + st["I16"] == 576
+        assert int(cb.min()) == int(cb.max()) == int(cr.min()) == int(cr.max()) == 128
+        assert 15 <= float(y.mean()) <= 30 and int(y.min()) >= 8
+        if k == 0:
+            np.testing.assert_array_equal(y, z["luma"])
+            np.testing.assert_array_equal(H.swscale_bgr(y, cb, cr)[..., 0], z["gray"])
+
+
+def _oracle(gray):
+    from oracle import paf_grouping as opg
+    from oracle import peak_finding as opf
+    from oracle.keras_graph import KerasGraph, load_npz_model, preprocess
+
+    cfg, w = load_npz_model(os.path.join(MODEL, "best_model.npz"))
+    cms, pafs, offs = KerasGraph(cfg, w)(preprocess(gray[None, :, :, None]))
+    pts, vals, si, ci = opf.find_local_peaks_with_offsets(cms, offs, 0.2)
+    pts = pts * np.float32(2)
+    ref = opg.PAFScorer(["A", "B"], [("A", "B")], 4, oob="zero").predict(pafs, [pts], [vals], [ci])
+    return np.asarray(ref[0][0]).reshape(-1, 2, 2), np.asarray(ref[1][0]).reshape(-1, 2), np.asarray(ref[2][0])
+
+
+def test_oracle_reproduces_the_tensorflow_golden_on_the_real_frame():
+    z = np.load(FROZEN)
+    want_pts, want_sc, want_inst = golden_predictions()
+    pts, sc, inst = _oracle(z["gray"])
+    assert pts.shape == (2, 2, 2)
+    order = match_instances(pts, want_pts)
+    assert sorted(order) == [0, 1]
+    d = np.linalg.norm(pts[order] - want_pts, axis=-1)
+    print(f"oracle vs labels_pr.val.slp: max point distance {d.max():.5f} px, point score delta {np.abs(sc[order] - want_sc).max():.6f}, "
+          f"instance score delta {np.abs(inst[order] - want_inst).max():.6f}")
+    assert d.max() <= 1e-3
+    assert np.abs(sc[order] - want_sc).max() <= 1e-4 and np.abs(inst[order] - want_inst).max() <= 1e-4
+    # the reference's own assertion about this prediction (tests/nn/test_inference.py:780-786): within 1.75 px of the user labels
+    gt = z["gt_points"]
+    np.testing.assert_allclose(pts[match_instances(pts, gt)], gt, atol=1.75)  # (elementwise, as the reference's assert_allclose)
+    # why the SIMD form of the colour conversion: the rounding C-table form of libswscale moves the same points by up to 0.07 px
+    luma = z["luma"].astype(np.int64) - 16
+    ctab = np.clip((luma * 76309 + 32768) >> 16, 0, 255).astype(np.uint8)
+    p2 = _oracle(ctab)[0]
+    d2 = np.linalg.norm(p2[match_instances(p2, want_pts)] - want_pts, axis=-1).max()
+    assert 0.02 <= d2 <= 0.2, d2
