@@ -12,7 +12,11 @@ Pinning status (see DESIGN.md "Oracle"):
   * peak_finding / paf_grouping restatements: pinned by the reference's own known-answer
     tests (tests/nn/test_peak_finding.py, tests/nn/test_paf_grouping.py), re-expressed in
     tests/test_oracle_peak_finding.py and tests/test_oracle_paf_grouping.py.
-  * network forward (Keras graph interpreter): parity UNPINNED numerically -- the
-    reference can not be imported here (no TensorFlow) and its tests pin only layer
-    shapes / parameter counts, which tests/test_oracle_keras_graph.py checks.
+  * network forward (Keras graph interpreter): PINNED to TensorFlow since round 6 for the layer kinds of a SLEAP UNet with a
+    decoder (Conv2D, MaxPooling2D, UpSampling2D(bilinear), Concatenate, the 1x1 heads): on frame 0 of the reference's
+    centered_pair_low_quality.mp4 the oracle reproduces the predictions TensorFlow wrote into
+    tests/data/models/minimal_instance.UNet.bottomup/labels_pr.val.slp to 2e-5 px and 1e-6 in the scores
+    (tests/test_frame0_golden.py), and the encoder-only robot model's within the reference's own tolerance
+    (tests/test_oracle_network_pin.py). Conv2DTranspose, BatchNormalization and the ResNet / hourglass graphs stay pinned to
+    hand-derived vectors only (tests/layer_pin_vectors.py): no reference golden runs them.
 """

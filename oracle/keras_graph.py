@@ -2,8 +2,10 @@
 (TEST INFRASTRUCTURE ONLY).
 
 Stands in for `tf.keras.models.load_model(...)(imgs)` (sleap/nn/inference.py:3207, 2864-2890).
-Numerics are parity-UNPINNED w.r.t. TensorFlow (TF is not installable here); layer
-semantics follow the documented TF/Keras rules collected in SURVEY.md §8(a):
+Pinned to TensorFlow since round 6 for Conv2D / MaxPooling2D / UpSampling2D(bilinear) / Concatenate / 1x1 heads: the
+TensorFlow-produced predictions of the reference's bottom-up fixture are reproduced to 2e-5 px (tests/test_frame0_golden.py);
+Conv2DTranspose and BatchNormalization rest on hand-derived vectors (tests/layer_pin_vectors.py). Layer semantics follow the
+documented TF/Keras rules collected in SURVEY.md §8(a):
 
   SAME padding: pad_total = max((ceil(n/s) - 1) * s + k - n, 0), pad_before = pad_total // 2
   Conv2D kernel (kh, kw, Cin, Cout), cross-correlation
