@@ -13,10 +13,11 @@ Pinning status (see DESIGN.md "Oracle"):
     tests (tests/nn/test_peak_finding.py, tests/nn/test_paf_grouping.py), re-expressed in
     tests/test_oracle_peak_finding.py and tests/test_oracle_paf_grouping.py.
   * network forward (Keras graph interpreter): PINNED to TensorFlow since round 6 for the layer kinds of a SLEAP UNet with a
-    decoder (Conv2D, MaxPooling2D, UpSampling2D(bilinear), Concatenate, the 1x1 heads): on frame 0 of the reference's
+    decoder (Conv2D, MaxPooling2D, Conv2DTranspose(k3, s2, same), Concatenate, the 1x1 heads; odd channel counts): on frame 0 of the reference's
     centered_pair_low_quality.mp4 the oracle reproduces the predictions TensorFlow wrote into
     tests/data/models/minimal_instance.UNet.bottomup/labels_pr.val.slp to 2e-5 px and 1e-6 in the scores
     (tests/test_frame0_golden.py), and the encoder-only robot model's within the reference's own tolerance
-    (tests/test_oracle_network_pin.py). Conv2DTranspose, BatchNormalization and the ResNet / hourglass graphs stay pinned to
-    hand-derived vectors only (tests/layer_pin_vectors.py): no reference golden runs them.
+    (tests/test_oracle_network_pin.py); the centered-instance model's peaks on ground-truth crops likewise (3e-5 px).
+    UpSampling2D(bilinear) -- the benchmark network's decoder -- BatchNormalization and the ResNet / hourglass graphs stay
+    pinned to hand-derived vectors only (tests/layer_pin_vectors.py): no reference golden runs them.
 """

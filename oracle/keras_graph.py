@@ -2,9 +2,10 @@
 (TEST INFRASTRUCTURE ONLY).
 
 Stands in for `tf.keras.models.load_model(...)(imgs)` (sleap/nn/inference.py:3207, 2864-2890).
-Pinned to TensorFlow since round 6 for Conv2D / MaxPooling2D / UpSampling2D(bilinear) / Concatenate / 1x1 heads: the
-TensorFlow-produced predictions of the reference's bottom-up fixture are reproduced to 2e-5 px (tests/test_frame0_golden.py);
-Conv2DTranspose and BatchNormalization rest on hand-derived vectors (tests/layer_pin_vectors.py). Layer semantics follow the
+Pinned to TensorFlow since round 6 for Conv2D / MaxPooling2D / Conv2DTranspose(k3 s2 same) / Concatenate / 1x1 heads: the
+TensorFlow-produced predictions of the reference's bottom-up and centered-instance fixtures are reproduced to 3e-5 px
+(tests/test_frame0_golden.py); UpSampling2D(bilinear) and BatchNormalization rest on hand-derived vectors
+(tests/layer_pin_vectors.py). Layer semantics follow the
 documented TF/Keras rules collected in SURVEY.md §8(a):
 
   SAME padding: pad_total = max((ceil(n/s) - 1) * s + k - n, 0), pad_before = pad_total // 2

@@ -3,7 +3,8 @@
     tests/data/models/minimal_instance.UNet.bottomup/labels_pr.val.slp  (tests/golden/slp/bottomup.labels_pr.val.npz)
       = BottomUpPredictor.predict on frame 0 of tests/data/json_format_v1/centered_pair_low_quality.mp4: two instances, four
         points, their scores -- the predictions sleap-train wrote with the trained model, a UNet with a DECODER
-        (UpSampling2D(bilinear) + Concatenate + refine convs), confidence maps + PAFs + offset-free integral refinement.
+        (filters 16 x 1.5: 16 / 24 / 36 / 54 channels; Conv2DTranspose(k3, s2) + Concatenate + refine convs), confidence maps,
+        PAFs and an offset-refinement head.
 
 Until round 6 that frame could not be read: it lives in an H.264 stream and neither the build container nor the GPU box has a
 decoder (profiles/r06_decoder_probe.txt). The package now decodes the key frames of such a file itself
@@ -28,9 +29,9 @@ MODEL = os.path.join(ROOT, "tests", "golden", "models", "minimal_instance.UNet.b
 FROZEN = os.path.join(ROOT, "tests", "golden", "centered_pair_frame0.npz")
 
 
-def golden_predictions():
-    """-> (points (2 instances, 2 nodes, 2), point scores (2, 2), instance scores (2,)) of labels_pr.val.slp"""
-    z = np.load(os.path.join(ROOT, "tests", "golden", "slp", "bottomup.labels_pr.val.npz"), allow_pickle=True)
+def golden_predictions(which="bottomup"):
+    """-> (points (2 instances, 2 nodes, 2), point scores (2, 2), instance scores (2,)) of the model's labels_pr.val.slp"""
+    z = np.load(os.path.join(ROOT, "tests", "golden", "slp", which + ".labels_pr.val.npz"), allow_pickle=True)
     pp, inst = z["pred_points"], z["instances"]
     assert len(z["frames"]) == 1 and int(z["frames"][0]["frame_idx"]) == 0 and len(inst) == 2 and len(pp) == 4
     pts = np.array([[[pp[i]["x"], pp[i]["y"]] for i in range(int(r["point_id_start"]), int(r["point_id_end"]))] for r in inst])
@@ -108,3 +109,66 @@ def test_oracle_reproduces_the_tensorflow_golden_on_the_real_frame():
     p2 = _oracle(ctab)[0]
     d2 = np.linalg.norm(p2[match_instances(p2, want_pts)] - want_pts, axis=-1).max()
     assert 0.02 <= d2 <= 0.2, d2
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# The two top-down models of the same fixture set hold TensorFlow-produced prediction files for the same frame too
+# (sleap-train evaluates each model of a top-down pair ALONE, the other half replaced by ground truth):
+#   minimal_instance.UNet.centroid/labels_pr.val.slp           points = the user labels (FindInstancePeaksGroundTruth), instance
+#                                                              score = the CENTROID model's confidence at the matched centroid
+#   minimal_instance.UNet.centered_instance/labels_pr.val.slp  crops around the ground-truth centroids (CentroidCropGroundTruth,
+#                                                              inference.py:721-809: bounding-box midpoint, crop 96) through the
+#                                                              centered-instance model + FindInstancePeaks (offset refinement)
+# ---------------------------------------------------------------------------------------------------------------------------
+def gt_centroids(gt_points):
+    """instance_centroids.py:12-33 (anchor_part None): midpoint of the bounding box of an instance's points, float32 as TF"""
+    p = gt_points.astype(np.float32)
+    return ((p.max(axis=1) + p.min(axis=1)) * np.float32(0.5)).astype(np.float32)
+
+
+def test_oracle_centroid_model_confidences_equal_tensorflows():
+    from oracle import peak_finding as opf
+    from oracle.keras_graph import KerasGraph, load_npz_model, preprocess
+
+    z = np.load(FROZEN)
+    cfg, w = load_npz_model(os.path.join(ROOT, "tests", "golden", "models", "minimal_instance.UNet.centroid", "best_model.npz"))
+    cms, offs = KerasGraph(cfg, w)(preprocess(z["gray"][None, :, :, None]))[:2]
+    pts, vals, si, ci = opf.find_local_peaks_with_offsets(cms, offs, 0.2)
+    pts = pts * np.float32(4)
+    assert len(pts) == 2
+    _, _, want_inst = golden_predictions("centroid")
+    cen = gt_centroids(z["gt_points"])
+    order = [int(np.argmin(np.linalg.norm(pts - c, axis=-1))) for c in cen]
+    assert sorted(order) == [0, 1] and np.linalg.norm(pts[order] - cen, axis=-1).max() <= 3.0
+    print(f"oracle centroid confidences {vals[order]} vs TensorFlow's {want_inst}")
+    # NOT to 1e-4 like the two other files: 1.0369 / 0.9245 here against 1.0423 / 0.9288 in the file. The file was evidently
+    # written from another decode of the frame -- with the rounding C-table form of libswscale's colour conversion the same
+    # model gives 1.0466 / 0.9361: the two forms bracket TensorFlow's numbers, neither reproduces them, while the bottom-up
+    # and the centered-instance files (other training runs) are reproduced to 1e-6 with the SIMD form. Asserted: within 8e-3.
+    assert np.abs(vals[order] - want_inst).max() <= 8e-3
+
+
+def _gt_crops(gray, gt_points, crop=96):
+    from oracle import peak_finding as opf
+
+    cen = gt_centroids(gt_points)
+    img = gray[None, :, :, None]
+    crops = opf.crop_bboxes(img.astype(np.float32), opf.make_centered_bboxes(cen, crop, crop), np.zeros(len(cen), np.int32)).astype(np.uint8)
+    return cen, crops, (cen - np.float32(crop / 2)).astype(np.float32)
+
+
+def test_oracle_centered_instance_model_on_ground_truth_crops_equals_tensorflows():
+    from oracle import inference as oinf
+    from oracle.keras_graph import KerasGraph, load_npz_model, preprocess
+
+    z = np.load(FROZEN)
+    cfg, w = load_npz_model(os.path.join(ROOT, "tests", "golden", "models", "minimal_instance.UNet.centered_instance", "best_model.npz"))
+    _, crops, crop_offsets = _gt_crops(z["gray"], z["gt_points"])
+    cms, offs = KerasGraph(cfg, w)(preprocess(crops))[:2]
+    pts, vals = oinf.find_instance_peaks(cms, offs, crop_offsets, 0.2, None, 5, 2, 1.0)
+    want_pts, want_sc, _ = golden_predictions("centered_instance")
+    order = match_instances(pts, want_pts)
+    assert sorted(order) == [0, 1]
+    d = np.linalg.norm(pts[order] - want_pts, axis=-1)
+    print(f"oracle centered-instance peaks vs TensorFlow: max distance {d.max():.5f} px, score delta {np.abs(vals[order] - want_sc).max():.6f}")
+    assert d.max() <= 1e-3 and np.abs(vals[order] - want_sc).max() <= 1e-4

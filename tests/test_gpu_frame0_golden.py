@@ -8,7 +8,7 @@ import os
 import numpy as np
 import pytest
 
-from test_frame0_golden import FROZEN, MODEL, MP4, golden_predictions, match_instances
+from test_frame0_golden import FROZEN, MODEL, MP4, _gt_crops, golden_predictions, gt_centroids, match_instances
 
 pytestmark = pytest.mark.gpu
 
@@ -40,3 +40,50 @@ def test_bottomup_predictor_on_the_real_frame_matches_tensorflow(dtype, tol_px, 
     # labels through the default path (make_labels=True), as the reference test reads them
     labels = predictor.predict(VideoReader(video, example_indices=[0]))
     assert len(labels) == 1 and len(labels[0].instances) == 2
+
+
+def test_top_down_models_on_the_real_frame_match_tensorflow():
+    """The top-down pair of the same fixture set against ITS TensorFlow-produced files (tests/test_frame0_golden.py explains what
+    they hold): the centroid model's confidences at the two animals, and the centered-instance model's peaks on crops around the
+    ground-truth centroids (sa_crop_and_resize at fractional centres, uint8 crops) -- then the pair end to end through
+    `load_model([centroid, centered_instance])`, which must land within the reference's 1.75 px of the user labels."""
+    import torch
+
+    from sleap_amd import ops
+    from sleap_amd.nn.inference import TopDownPredictor, load_model
+
+    z = np.load(FROZEN)
+    models = os.path.dirname(MODEL)
+    p = load_model([os.path.join(models, "minimal_instance.UNet.centroid"), os.path.join(models, "minimal_instance.UNet.centered_instance")],
+                   batch_size=1, progress_reporting="none")
+    assert isinstance(p, TopDownPredictor)
+    frame = torch.from_numpy(z["gray"][None, :, :, None]).cuda()
+    cen = gt_centroids(z["gt_points"])
+    # (a) the centroid model: confidences
+    crop_layer = p.inference_model.centroid_crop
+    o = crop_layer.call(frame)
+    cpts, cvals = o["centroids"].cpu().numpy().reshape(-1, 2), o["centroid_vals"].cpu().numpy().reshape(-1)
+    assert len(cpts) == 2
+    order = [int(np.argmin(np.linalg.norm(cpts - c, axis=-1))) for c in cen]
+    _, _, want_conf = golden_predictions("centroid")
+    print(f"device centroid confidences {cvals[order]} vs TensorFlow's {want_conf}")
+    assert sorted(order) == [0, 1] and np.abs(cvals[order] - want_conf).max() <= 1e-2  # (8e-3 of it is the file's other decode)
+    # (b) the centered-instance model on ground-truth crops
+    peaks_layer = p.inference_model.instance_peaks
+    crops = ops.crop_and_resize(frame, torch.from_numpy(cen).cuda(), torch.zeros(2, dtype=torch.int32, device="cuda"), 96)
+    _, want_crops, crop_offsets = _gt_crops(z["gray"], z["gt_points"])
+    np.testing.assert_array_equal(crops.cpu().numpy(), want_crops)
+    out = peaks_layer.call({"crops": crops, "crop_offsets": torch.from_numpy(crop_offsets).cuda()})
+    pts = out["instance_peaks"].cpu().numpy().reshape(-1, 2, 2)
+    vals = out["instance_peak_vals"].cpu().numpy().reshape(-1, 2)
+    want_pts, want_sc, _ = golden_predictions("centered_instance")
+    order = match_instances(pts, want_pts)
+    d = np.linalg.norm(pts[order] - want_pts, axis=-1)
+    print(f"device centered-instance peaks vs TensorFlow: max distance {d.max():.5f} px, score delta {np.abs(vals[order] - want_sc).max():.5f}")
+    assert sorted(order) == [0, 1] and d.max() <= 0.05 and np.abs(vals[order] - want_sc).max() <= 5e-3
+    # (c) the pair end to end (predicted centroids -> crops -> peaks), the reference's test_topdown_predictor assertions
+    outs = p.predict(z["gray"][None, :, :, None], make_labels=False)
+    n = int(outs[0]["n_valid"][0])
+    assert n == 2
+    got = outs[0]["instance_peaks"][0, :n]
+    np.testing.assert_allclose(got[match_instances(got, z["gt_points"])], z["gt_points"], atol=1.75)
