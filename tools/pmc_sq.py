@@ -31,5 +31,10 @@ def main(paths, min_grid=500000):
 
 
 if __name__ == "__main__":
-    a = [x for x in sys.argv[1:] if not x.startswith("--")]
-    main(a)
+    argv = sys.argv[1:]
+    mg = 500000
+    if "--min-grid" in argv:
+        i = argv.index("--min-grid")
+        mg = int(argv[i + 1])
+        del argv[i:i + 2]
+    main([x for x in argv if not x.startswith("--")], mg)
