@@ -269,11 +269,30 @@ int sa_network_forward(const sa_network_t* net, const void* images, int images_a
                                    a[15] ? bp(a[22]) : nullptr, stream);
         break;
       }
-      case K_PAIR:  // [s0, wa, ba, relu_a, c1p, wb, bb, relu_b, o_buf, store, opool_buf]
+      case K_PAIR: {  // [s0, wa, ba, relu_a, c1p, wb, bb, relu_b, o_buf, store, opool_buf, (mid_buf)]
+        // round 6: the 32 -> 64 -> 64 block names its intermediate buffer; a launch with fewer than ~6 tiles per CU runs as the
+        // two convolutions through it (one persistent workgroup per CU has too few tiles to amortise its pipeline: 8 frames of
+        // 1024^2 0.790 vs 0.780 ms per step; from 16 frames on the fused launch wins -- engine.py:_fuse_pairs)
+        const int64_t mid = op.a.size() > 11 ? a[11] : -1;
+        static int n_cu = 0;
+        if (!n_cu) {
+          int dev = 0;
+          if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n_cu = 256;
+        }
+        const int64_t tiles = (int64_t)B * ((bh(a[8]) + 15) / 16) * ((bw(a[8]) + 31) / 32);
+        if (mid >= 0 && tiles < 6 * (int64_t)n_cu) {
+          rc = sa_conv3x3_bf16(bp(a[0]), bc(a[0]), nullptr, 0, lay, P<void>(a[1]), P<float>(a[2]), (int)a[4], (int)a[3], B, bh(a[8]), bw(a[8]),
+                               bp(mid), nullptr, stream);
+          if (rc == SA_OK)
+            rc = sa_conv3x3_bf16(bp(mid), (int)a[4], nullptr, 0, lay, P<void>(a[5]), P<float>(a[6]), bc(a[8]), (int)a[7], B, bh(a[8]), bw(a[8]),
+                                 a[9] ? bp(a[8]) : nullptr, bp(a[10]), stream);
+          break;
+        }
         rc = sa_conv3x3_pair_bf16(bp(a[0]), bc(a[0]), P<void>(a[1]), P<float>(a[2]), (int)a[3], (int)a[4], P<void>(a[5]),
                                   P<float>(a[6]), (int)a[7], bc(a[8]), B, bh(a[8]), bw(a[8]), a[9] ? bp(a[8]) : nullptr, bp(a[10]),
                                   lay, stream);
         break;
+      }
       case K_CONV1X1:  // [s0, w, bias, relu, stride, has_ext, ps, pt, res_buf, relu_last, o_buf]
         // (stride word: bits 0-7 the stride of a 1x1 conv, bits 8+ the window size k of a stride-1 "same" k x k conv)
         if ((a[4] >> 8) > 1)

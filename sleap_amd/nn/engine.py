@@ -861,6 +861,13 @@ class DeviceNetwork:
                     o.buf = None
         return out
 
+    def _n_cu(self) -> int:
+        if getattr(self, "_n_cu_cached", None) is None:
+            from .. import ops as _ops
+
+            self._n_cu_cached = int(_ops.device_info(self.device.index or 0)["n_cu"])
+        return self._n_cu_cached
+
     def _fuse_pairs(self, plan):
         """conv(16 -> 32) whose only reader is a conv(32 -> 32), or (round 6) conv(32 -> 64) whose only reader is a conv(64 -> 64)
         -> one launch (sa_conv3x3_pair_bf16); the intermediate tensor is never allocated. Plain convs only (no concat /
@@ -885,6 +892,12 @@ class DeviceNetwork:
             i = next(k for k, q in enumerate(out) if q is y)
             out[i] = ["pair", x, y]
             del out[next(k for k, q in enumerate(out) if q is x)]
+            if x.src0.cp == 32:
+                # the 32 -> 64 -> 64 block keeps its intermediate BUFFER (never touched at the sizes the fused launch is for): one
+                # persistent workgroup per CU needs >= ~6 tiles each to beat two launches (measured: 8 frames of 1024^2 = 4 tiles
+                # per CU 0.790 vs 0.780 ms per step, 16 frames 1.37 vs 1.40, 32 frames 2.66 vs 2.70), so small launches run as
+                # the two convolutions through it (decided per launch by the executor: csrc/network.hip K_PAIR, _launch_pair)
+                continue
             self.buf_meta.pop(x.out.buf, None)
             x.out.buf = None
         return out
@@ -975,7 +988,7 @@ class DeviceNetwork:
             elif k == "pair":
                 _, xa, yb = op
                 a = [bid(xa.src0), dp(xa.w), dp(xa.bias), xa.relu, xa.out.cp, dp(yb.w), dp(yb.bias), yb.relu, bid(yb.out),
-                     1 if yb.need_full else 0, bid(yb.out_pool)]
+                     1 if yb.need_full else 0, bid(yb.out_pool), bid(xa.out) if xa.out.buf is not None else -1]
             elif k == "bneck":
                 a = self._bneck_words(op, bid, dp)
             elif k == "conv1x1":
@@ -1278,10 +1291,19 @@ class DeviceNetwork:
                 _, xa, yb = op
                 s0, o, o_pool, need_full = xa[1], yb[6], yb[8], yb[9]
                 oh, ow = hw(o)
-                check(h.sa_conv3x3_pair_bf16(_ptr(bufs[s0.buf]), s0.cp, _ptr(xa[4]), _ptr(xa[5]), xa[7], xa[6].cp, _ptr(yb[4]),
-                                             _ptr(yb[5]), yb[7], o.cp, B, oh, ow, _ptr(bufs[o.buf]) if need_full else None,
-                                             _ptr(bufs[o_pool.buf]) if o_pool is not None else None, self.layout, st),
-                      "sa_conv3x3_pair_bf16")
+                mid = xa[6]
+                if mid.buf is not None and B * ((oh + 15) // 16) * ((ow + 31) // 32) < 6 * self._n_cu():
+                    # (a small launch of the 32 -> 64 -> 64 block: two convolutions through the kept intermediate buffer, see _fuse_pairs)
+                    check(h.sa_conv3x3_bf16(_ptr(bufs[s0.buf]), s0.cp, None, 0, self.layout, _ptr(xa[4]), _ptr(xa[5]), mid.cp, xa[7], B, oh, ow,
+                                            _ptr(bufs[mid.buf]), None, st), "sa_conv3x3_bf16")
+                    check(h.sa_conv3x3_bf16(_ptr(bufs[mid.buf]), mid.cp, None, 0, self.layout, _ptr(yb[4]), _ptr(yb[5]), o.cp, yb[7], B, oh, ow,
+                                            _ptr(bufs[o.buf]) if need_full else None,
+                                            _ptr(bufs[o_pool.buf]) if o_pool is not None else None, st), "sa_conv3x3_bf16")
+                else:
+                    check(h.sa_conv3x3_pair_bf16(_ptr(bufs[s0.buf]), s0.cp, _ptr(xa[4]), _ptr(xa[5]), xa[7], xa[6].cp, _ptr(yb[4]),
+                                                 _ptr(yb[5]), yb[7], o.cp, B, oh, ow, _ptr(bufs[o.buf]) if need_full else None,
+                                                 _ptr(bufs[o_pool.buf]) if o_pool is not None else None, self.layout, st),
+                          "sa_conv3x3_pair_bf16")
             elif kind == "bneck":
                 _, c, x, y, xw, yw = op
                 oh, ow = hw(c.out)

@@ -577,3 +577,29 @@ def test_pair_fusion_switch_is_bitwise_neutral():
     other = [o.clone() for o in DeviceNetwork(cfg, w, fuse_pairs=False, layout="nhwc").forward(x)]
     for p, q in zip(base, other):
         assert torch.equal(p, q)
+
+
+def test_block2_fusion_is_bitwise_neutral_in_the_network_on_both_sides_of_its_size_rule(monkeypatch):
+    """Round 6: the plan of the benchmark UNet holds TWO "pair" ops (16 -> 32 -> 32 and 32 -> 64 -> 64). The second one is launched
+    fused from ~6 tiles per CU on and as two convolutions through its kept intermediate buffer below that (engine.py:_fuse_pairs,
+    csrc/network.hip K_PAIR) -- heads bitwise equal to the plan without it (SA_FUSE_PAIRS64=0) on both sides of the rule, through
+    the C executor and through the per-launch Python loop."""
+    from sleap_amd.nn.engine import DeviceNetwork
+
+    cfg, w = _benchmark_unet(512, 512)
+    g = torch.Generator(device="cpu").manual_seed(3)
+    for B in (2, 56):  # 2 x 32 = 64 tiles of the 128 x 128 layer (two launches); 56 x 32 = 1792 >= 6 x 256 (the fused launch)
+        x = torch.randint(0, 256, (B, 512, 512, 1), generator=g, dtype=torch.uint8).cuda()
+        monkeypatch.delenv("SA_FUSE_PAIRS64", raising=False)
+        a = DeviceNetwork(cfg, w)
+        assert [op[0] for op in a.plan].count("pair") == 2
+        base = [o.clone() for o in a.forward(x)]
+        prof = []
+        for p, q in zip(base, a.forward(x, profile=prof)):
+            assert torch.equal(p, q)
+        monkeypatch.setenv("SA_FUSE_PAIRS64", "0")
+        b = DeviceNetwork(cfg, w)
+        assert [op[0] for op in b.plan].count("pair") == 1
+        for p, q in zip(base, b.forward(x)):
+            assert torch.equal(p, q)
+        del a, b
