@@ -539,7 +539,7 @@ def main():
         }
         achieved = conv_fl / (conv_ms * 1e-3) / 1e12
         roofline = {
-            "kernel": f"conv3x3_dma_kernel + convpair + stem16_gray_kernel (the {n_conv} MFMA conv launches of one step)", "bound": "mfma", "achieved": round(achieved, 2),
+            "kernel": f"conv3x3_dma_kernel + convpair / convpair64 + stem16_gray_kernel (the {n_conv} MFMA conv launches of one step)", "bound": "mfma", "achieved": round(achieved, 2),
             "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
             # the same FLOPs over the TIMED step of the contract's K-step region (network + peak finding + PAF scoring + matching +
             # grouping + packing + gather + D2H, un-instrumented): the fraction the driver's clock implies. It can exceed
