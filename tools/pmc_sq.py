@@ -10,7 +10,7 @@ from collections import defaultdict
 PAT = re.compile(r"([A-Za-z_0-9]+_kernel(?:<[^>]*>)?)")
 
 
-def main(paths, min_grid=500000):
+def main(paths, min_grid=100000):
     vals = defaultdict(lambda: defaultdict(list))
     names = []
     for path in paths:
@@ -32,7 +32,7 @@ def main(paths, min_grid=500000):
 
 if __name__ == "__main__":
     argv = sys.argv[1:]
-    mg = 500000
+    mg = 100000  # (persistent kernels launch one workgroup per CU: 131072-262144 threads)
     if "--min-grid" in argv:
         i = argv.index("--min-grid")
         mg = int(argv[i + 1])
