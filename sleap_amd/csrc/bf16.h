@@ -123,6 +123,26 @@ __device__ __forceinline__ float dpp_xor1(float v) {
   const int i = __float_as_int(v);
   return __int_as_float(__builtin_amdgcn_update_dpp(i, i, 0xB1, 0xF, 0xF, false));
 }
+// t4[j] = max(t[j], t[j] of lane ^ 1) for four values: `v_max_f32_dpp` takes the neighbour lane as an operand modifier (the
+// compiler's DPP combine leaves dpp_xor1 + fmaxf as v_mov_b32_dpp + v_max_f32). `s_nop 1`: a VALU result read through DPP needs
+// two wait states and the hazard recogniser does not look into asm. SA_DPPMAX=0: the two-instruction form (A/B).
+#if !defined(SA_DPPMAX)
+#define SA_DPPMAX 1
+#endif
+__device__ __forceinline__ void max_xor1_x4(const float (&t)[4], float (&t4)[4]) {
+#if SA_DPPMAX
+  asm("s_nop 1\n\t"
+      "v_max_f32_dpp %0, %4, %4 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_max_f32_dpp %1, %5, %5 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_max_f32_dpp %2, %6, %6 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_max_f32_dpp %3, %7, %7 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf"
+      : "=&v"(t4[0]), "=&v"(t4[1]), "=&v"(t4[2]), "=&v"(t4[3])
+      : "v"(t[0]), "v"(t[1]), "v"(t[2]), "v"(t[3]));
+#else
+#pragma unroll
+  for (int j = 0; j < 4; ++j) t4[j] = fmaxf(t[j], dpp_xor1(t[j]));
+#endif
+}
 // v_permlane32_swap: exchanges a's upper 32 lanes with b's lower 32 lanes. Afterwards lane l < 32 holds
 // {a[l], a[l+32]} in (a, b) and lane l >= 32 holds {b[l-32], b[l]}: one instruction per dword turns the MFMA
 // accumulator split (channels 0-3 in the lower half-wave, 4-7 in the upper) into 8 consecutive channels per lane.

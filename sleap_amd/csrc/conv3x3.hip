@@ -1350,12 +1350,10 @@ conv3x3_dma_kernel(const ConvParams2 p) {
             uint2 pk[2];
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
-              float t4[4];
+              float t4[4], t[4];
 #pragma unroll
-              for (int j = 0; j < 4; ++j) {
-                const float t = fmaxf(act(r, e, j), act(r + 1, e, j));
-                t4[j] = fmaxf(t, sa::dpp_xor1(t));
-              }
+              for (int j = 0; j < 4; ++j) t[j] = fmaxf(act(r, e, j), act(r + 1, e, j));
+              sa::max_xor1_x4(t, t4);
               pk[e].x = sa::f2h2(t4[0], t4[1]);
               pk[e].y = sa::f2h2(t4[2], t4[3]);
             }
@@ -1486,12 +1484,10 @@ conv3x3_dma_kernel(const ConvParams2 p) {
         uint2 pk[4];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-          float t4[4];
+          float t4[4], t[4];
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const float t = fmaxf(act(r, g, j), act(r + 1, g, j));
-            t4[j] = fmaxf(t, sa::dpp_xor1(t));
-          }
+          for (int j = 0; j < 4; ++j) t[j] = fmaxf(act(r, g, j), act(r + 1, g, j));
+          sa::max_xor1_x4(t, t4);
           pk[g].x = sa::f2h2(t4[0], t4[1]);
           pk[g].y = sa::f2h2(t4[2], t4[3]);
         }

@@ -276,12 +276,10 @@ convpair_16_32_32_kernel(const PairParams p) {
     uint2 pk[4];
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      float t4[4];
+      float t4[4], t[4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float t = fmaxf(act(0, g, j), act(1, g, j));
-        t4[j] = fmaxf(t, sa::dpp_xor1(t));
-      }
+      for (int j = 0; j < 4; ++j) t[j] = fmaxf(act(0, g, j), act(1, g, j));
+      sa::max_xor1_x4(t, t4);
       pk[g].x = sa::f2h2(t4[0], t4[1]);
       pk[g].y = sa::f2h2(t4[2], t4[3]);
     }
@@ -552,13 +550,11 @@ convpair_persist_kernel(const PairParams p, int n_tiles) {
       uint2 pk[4];
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        float t4[4], bj[4];
+        float t4[4], t[4], bj[4];
         bias4(g, bj);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const float t = fmaxf(fmaxf(acc[0][4 * g + j] + bj[j], low_b), fmaxf(acc[1][4 * g + j] + bj[j], low_b));
-          t4[j] = fmaxf(t, sa::dpp_xor1(t));
-        }
+        for (int j = 0; j < 4; ++j) t[j] = fmaxf(fmaxf(acc[0][4 * g + j] + bj[j], low_b), fmaxf(acc[1][4 * g + j] + bj[j], low_b));
+        sa::max_xor1_x4(t, t4);
         pk[g].x = sa::f2h2(t4[0], t4[1]);
         pk[g].y = sa::f2h2(t4[2], t4[3]);
       }

@@ -50,6 +50,14 @@ struct Stem16Params {
 #if !defined(SA_STEM16_PLANES8)
 #define SA_STEM16_PLANES8 1  // gray kernel: conv0 activation tile as two 8-channel planes in LDS (0: pixel-major records, A/B)
 #endif
+#if !defined(SA_STEM16_READ2)
+// gray kernel, folded conv0 (round 6): the B operand {triplet, triplet} comes from ONE `ds_read2_b64` whose two offsets are
+// equal -- the LDS returns the same 8 bytes into both register pairs -- instead of a ds_read_b64 and two v_mov (18 of conv0's
+// ~60 VALU instructions per wave and tile). MEASURED SLOWER (kernel trace, three alternating runs on one box: 490.9 against
+// 488.5 us; with the DPP max below 479.7 against 476.4): the LDS serves the two addresses of a read2 one after the other, and
+// the array (0.54 busy) is the more loaded unit. 0 = the round 2-5 form = the default; 1 kept as the A/B switch.
+#define SA_STEM16_READ2 0
+#endif
 // conv1's K = 32 steps: step s multiplies the 16 channels of TWO taps (k-blocks 0,1 = tap PAIRS[s][0], k-blocks 2,3 = tap
 // PAIRS[s][1]; -1 = zero weights). Round 4: the pairs follow the kernel's rows and columns instead of the tap index (round 1-3:
 // taps 2s, 2s + 1), so that a B fragment is the SAME data for up to three output rows:
@@ -292,6 +300,11 @@ stem16_gray_kernel(const Stem16Params p) {
   // ---- triplet table: thread (row, dq) loads the two aligned dwords covering image columns x0-4+4dq .. +7 and emits
   // the entries of raw columns tx = 4dq-2 .. 4dq+1 (raw column tx <-> image column x0 - 2 + tx; zero outside the image)
   if (tid == 255) rawt[RH * RS] = make_uint2(0u, 0u);
+#if SA_STEM16_FOLD && SA_STEM16_READ2
+  // entry RS - 1 of every table row (never a pixel: raw columns end at PW + 1 < RS - 1) is a zero operand that is reached with
+  // the SAME row stride as the pixel entries, so that all lanes of a conv0 group read with one compile-time offset
+  if (tid >= 192 && tid < 192 + RH) rawt[(tid - 192) * RS + RS - 1] = make_uint2(0u, 0u);
+#endif
   if (tid < RH * 9) {
     const int ty = tid / 9, dq = tid - ty * 9;
     const int gy = y0 + ty - 2, gx = x0 - 4 + dq * 4;
@@ -367,8 +380,16 @@ stem16_gray_kernel(const Stem16Params p) {
     const int seg = wave & 1, tx = seg * 16 + n16;
     const bool colok = (unsigned)(x0 + tx - 1) < (unsigned)W;
     // lanes kb == 3 carry K slots 24..31 (no taps): they read the zero entry with stride 0
+#if SA_STEM16_FOLD && SA_STEM16_READ2
+    const uint2* src = kb < 3 ? rawt + ((wave >> 1) + kb) * RS + tx : rawt + (wave >> 1) * RS + RS - 1;
+    // LDS byte addresses of groups 0, 3, 6 (ds_read2_b64 offsets are 8 bits of 8-byte units: three groups of 2 * RS entries each)
+    typedef __attribute__((address_space(3))) const void* lds_cptr_t;
+    const unsigned sa0 = (unsigned)(uintptr_t)(lds_cptr_t)src;
+    static_assert(2 * 2 * RS <= 255, "ds_read2_b64 offset range");
+#else
     const uint2* src = kb < 3 ? rawt + ((wave >> 1) + kb) * RS + tx : rawt + RH * RS;
     const int sstep = kb < 3 ? 2 * RS : 0;
+#endif
 #if SA_STEM16_PLANES8
     unsigned char* dstp = act + (kb >> 1) * APLANE + ((wave >> 1) * PW + tx) * 16 + (kb & 1) * 8;
 #else
@@ -378,11 +399,40 @@ stem16_gray_kernel(const Stem16Params p) {
     auto rowok = [&](int it) { return (unsigned)(y0 + (wave >> 1) + 2 * it - 1) < (unsigned)H; };  // wave uniform
     // three groups at a time: the hi / mid / lo MFMAs of one group depend on each other, those of different groups do not
     uint4 opq[3] = {make_uint4(0u, 0u, 0u, 0u), make_uint4(0u, 0u, 0u, 0u), make_uint4(0u, 0u, 0u, 0u)};
+    (void)opq;
+#if SA_STEM16_FOLD && SA_STEM16_READ2
+    typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
+    u32x4v oqs[2][3];
+#endif
     auto rows = [&](auto masked_c) {  // the loop exists twice: with and without the padding select (a REAL branch on `interior`)
       constexpr bool MASKED = decltype(masked_c)::value;
 #pragma unroll
       for (int it = 0; it < PH / 2; it += 3) {
         f32x4 d[3];
+#if SA_STEM16_FOLD && SA_STEM16_READ2
+        // Three groups' operands are requested one batch AHEAD (under the previous batch's conversions and stores). The reads
+        // are opaque to the compiler's wait-count pass: its own waits can only come out stricter (the counter retires in order);
+        // ours is "at most the three newest LGKM operations outstanding" = the next batch's reads, whatever number of ds_write
+        // instructions the compiler made of the stores in between, and it carries the operands it releases, so no MFMA can be
+        // scheduled above it.
+#define SA_STEM16_REQUEST(q, adr)                                                                                        \
+  do {                                                                                                                   \
+    const unsigned adr_ = (adr);                                                                                         \
+    asm volatile("ds_read2_b64 %0, %1 offset0:%2 offset1:%2" : "=v"((q)[0]) : "v"(adr_), "n"(0) : "memory");            \
+    asm volatile("ds_read2_b64 %0, %1 offset0:%2 offset1:%2" : "=v"((q)[1]) : "v"(adr_), "n"(2 * RS) : "memory");       \
+    asm volatile("ds_read2_b64 %0, %1 offset0:%2 offset1:%2" : "=v"((q)[2]) : "v"(adr_), "n"(4 * RS) : "memory");       \
+  } while (0)
+        u32x4v(&oq)[3] = oqs[(it / 3) & 1];
+        if (it == 0) SA_STEM16_REQUEST(oq, sa0);
+        if (it + 3 < PH / 2) {
+          SA_STEM16_REQUEST(oqs[(it / 3 + 1) & 1], sa0 + (it + 3) * 2 * RS * 8);
+          asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(oq[0]), "+v"(oq[1]), "+v"(oq[2])::"memory");
+        } else {
+          asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(oq[0]), "+v"(oq[1]), "+v"(oq[2])::"memory");
+        }
+#pragma unroll
+        for (int u = 0; u < 3; ++u) d[u] = (f32x4){bias0[0], bias0[1], bias0[2], bias0[3]};
+#else
 #pragma unroll
         for (int u = 0; u < 3; ++u) {
           const uint2 tq = src[(it + u) * sstep];
@@ -394,10 +444,16 @@ stem16_gray_kernel(const Stem16Params p) {
 #endif
           d[u] = (f32x4){bias0[0], bias0[1], bias0[2], bias0[3]};
         }
+#endif
 #pragma unroll
         for (int t = 0; t < NMF0; ++t)
 #pragma unroll
-          for (int u = 0; u < 3; ++u) d[u] = SA_MFMA_16x16x32(wf[t], __builtin_bit_cast(mfma_h8, opq[u]), d[u], 0, 0, 0);
+          for (int u = 0; u < 3; ++u)
+#if SA_STEM16_FOLD && SA_STEM16_READ2
+            d[u] = SA_MFMA_16x16x32(wf[t], __builtin_bit_cast(mfma_h8, oq[u]), d[u], 0, 0, 0);
+#else
+            d[u] = SA_MFMA_16x16x32(wf[t], __builtin_bit_cast(mfma_h8, opq[u]), d[u], 0, 0, 0);
+#endif
 #pragma unroll
         for (int u = 0; u < 3; ++u) conv0_store(d[u], MASKED, MASKED && colok && rowok(it + u), dstp + (it + u) * (2 * PW * APIX));
       }
@@ -478,11 +534,10 @@ stem16_gray_kernel(const Stem16Params p) {
 #pragma unroll
       for (int r = 0; r < 4; r += 2) {
         float t4[4];
+        float t[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const float t = fmaxf(fmaxf(acc[r][h][j], acc[r + 1][h][j]), low1);  // relu(max(.)) == max(relu(.))
-          t4[j] = fmaxf(t, sa::dpp_xor1(t));
-        }
+        for (int j = 0; j < 4; ++j) t[j] = fmaxf(fmaxf(acc[r][h][j], acc[r + 1][h][j]), low1);  // relu(max(.)) == max(relu(.))
+        sa::max_xor1_x4(t, t4);
         if (!(lane & 1) && gy0 + r < H && gx0 + h * 16 < W)
           *reinterpret_cast<uint2*>(pp + ((size_t)(r / 2) * (W / 2) + h * 8) * 16) =
               make_uint2(sa::f2h2(t4[0], t4[1]), sa::f2h2(t4[2], t4[3]));
