@@ -357,6 +357,9 @@ __device__ __forceinline__ int swz(int p) {
 // 2-4 chunk 256 x 256 layers lose 3-5 % with any t > 0.
 // SA_CONV_EXT_WG2: the extended-epilogue kernels on 16-channel chunks keep to 128 registers (two workgroups per CU) like the
 // plain ones (0: 148 registers, one workgroup per CU -- A/B builds)
+#if !defined(SA_UPS_DX_SWAP)
+#define SA_UPS_DX_SWAP 1  // UPS expansion: see the chunk loop (0: every lane writes column parity 0 first -- A/B)
+#endif
 #if !defined(SA_CONV_EXT_WG2)
 #define SA_CONV_EXT_WG2 1
 #endif
@@ -867,6 +870,11 @@ conv3x3_dma_kernel(const ConvParams2 p) {
         unsigned woff[4];   // (swizzled) offsets of the four pixels of the 2 x 2 block in the stage
         unsigned keepbits = 0;
         bool actv;
+        // SA_UPS_DX_SWAP (round 6): which of its block's two columns a lane writes first alternates with bit 1 of the block index.
+        // The eight lanes of a ds_write_b128 group are four blocks x two halves; with every lane on the SAME column parity their
+        // pixels are 64 bytes apart and fall on two of the four 32-byte bank groups (2-way: the one source of LDS conflicts in
+        // this kernel, 10 % of its LDS-active cycles); alternating, they cover all four.
+        int sw;
         // tiles whose whole halo lies inside the image (all but the border ring) skip the padding masks (wave-uniform)
         const bool interior = __builtin_amdgcn_readfirstlane((int)(cur.x0 >= 1 && cur.y0 >= 1 && cur.x0 + PW - 1 <= W && cur.y0 + PH - 1 <= H));
         {
@@ -875,11 +883,12 @@ conv3x3_dma_kernel(const ConvParams2 p) {
           constexpr int NBX = PW / 2, NBLK = (PH / 2) * NBX;  // 2x2 blocks of the halo tile: 9 rows of 17
           const int u = t_id < NBLK * 2 ? t_id : 0, hf = u & 1, blk = u >> 1;
           const int rp = blk / NBX, cp = blk - rp * NBX;
+          sw = SA_UPS_DX_SWAP ? (blk >> 1) & 1 : 0;
           const int q0 = (rp * LW + cp) * 2 + hf;
           la[0] = low_addr(q0), la[1] = low_addr(q0 + 2), la[2] = low_addr(q0 + 2 * LW), la[3] = low_addr(q0 + 2 * LW + 2);
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
-            const int ty = 2 * rp + (k >> 1), tx = 2 * cp + (k & 1), pl = ty * PW + tx;
+            const int ty = 2 * rp + (k >> 1), tx = 2 * cp + ((k & 1) ^ sw), pl = ty * PW + tx;
             woff[k] = (unsigned)(pl * PIXB + ((hf ^ swz<CK>(pl)) * 16));
             if (!interior) {
               const int gy = cur.y0 - 1 + ty, gx = cur.x0 - 1 + tx;
@@ -910,7 +919,7 @@ conv3x3_dma_kernel(const ConvParams2 p) {
         };
         auto blend = [&](int dx, unsigned ua, unsigned ub, unsigned uc, unsigned ud, unsigned (&r)[2]) {
           const hp2 a = as_h2(ua), b_ = as_h2(ub), cc = as_h2(uc), d = as_h2(ud);
-          const hp2 wx = dx ? q75 : q25;                             // odd / even image column
+          const hp2 wx = (dx ^ sw) ? q75 : q25;                      // odd / even image column
           const hp2 t = a + (b_ - a) * wx, u_ = cc + (d - cc) * wx;  // source rows rp, rp + 1 at this column
           const hp2 dv = u_ - t;
           r[0] = as_u(t + dv * q25), r[1] = as_u(t + dv * q75);
@@ -919,7 +928,7 @@ conv3x3_dma_kernel(const ConvParams2 p) {
         // fp32 interpolation in the order of the stand-alone kernel, one rounding: bitwise the materialised tensor
         auto blend = [&](int dx, unsigned ua, unsigned ub, unsigned uc, unsigned ud, unsigned (&r)[2]) {
           float v[2][2];
-          const float wx = dx ? 0.75f : 0.25f;
+          const float wx = (dx ^ sw) ? 0.75f : 0.25f;
 #pragma unroll
           for (int e = 0; e < 2; ++e) {
             const float a = sa::h2f((uint16_t)(ua >> (16 * e))), b_ = sa::h2f((uint16_t)(ub >> (16 * e)));
