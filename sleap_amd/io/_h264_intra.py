@@ -146,6 +146,36 @@ class Mp4H264:
             self.sync = [v - 1 for v in struct.unpack(f">{n}I", b[ss[0] + 8:ss[0] + 8 + 4 * n])]
         except KeyError:
             self.sync = list(range(count))  # no sync table: every sample is a sync sample
+        # composition time offsets (ctts): sample i (decoding order) is shown at dts(i) + cts(i); `display_order[k]` = the sample
+        # shown k-th. Without a ctts box (no B pictures) the two orders are the same.
+        self.cts = [0] * count
+        try:
+            ct_ = _find(b, [b"ctts"], s, e)
+            ver = b[ct_[0]]
+            n = struct.unpack(">I", b[ct_[0] + 4:ct_[0] + 8])[0]
+            k = 0
+            for j in range(n):
+                cnt, off = struct.unpack(">Ii" if ver else ">II", b[ct_[0] + 8 + 8 * j:ct_[0] + 16 + 8 * j])
+                for _ in range(cnt):
+                    if k < count:
+                        self.cts[k] = off
+                        k += 1
+        except KeyError:
+            pass
+        dts, tt = [], 0
+        try:
+            ts_ = _find(b, [b"stts"], s, e)
+            n = struct.unpack(">I", b[ts_[0] + 4:ts_[0] + 8])[0]
+            for j in range(n):
+                cnt, delta = struct.unpack(">II", b[ts_[0] + 8 + 8 * j:ts_[0] + 16 + 8 * j])
+                for _ in range(cnt):
+                    dts.append(tt)
+                    tt += delta
+        except KeyError:
+            pass
+        if len(dts) != count:
+            dts = list(range(count))
+        self.display_order = sorted(range(count), key=lambda i: (dts[i] + self.cts[i], i))
         cl, cr, ct, cb = self.sps["crop"]
         self.width, self.height = self.sps["mb_w"] * 16 - 2 * (cl + cr), self.sps["mb_h"] * 16 - 2 * (ct + cb)
         # frames per second from the media header (timescale) and the first stts entry
@@ -191,14 +221,14 @@ def parse_sps(nal):
         r.u(1), r.se(), r.se()
         for _ in range(r.ue()):
             r.se()
-    r.ue()
-    r.u(1)
+    s["num_ref_frames"] = r.ue()
+    r.u(1)  # gaps_in_frame_num_value_allowed_flag
     s["mb_w"] = r.ue() + 1
     s["mb_h"] = r.ue() + 1
     s["frame_mbs_only"] = r.u(1)
     if not s["frame_mbs_only"]:
         raise NotImplementedError("interlaced (field / MBAFF) streams are not implemented")
-    r.u(1)  # direct_8x8_inference
+    s["direct_8x8_inference"] = r.u(1)
     s["crop"] = (0, 0, 0, 0)
     if r.u(1):
         s["crop"] = tuple(r.ue() for _ in range(4))  # left, right, top, bottom in 2-pixel units (4:2:0)
@@ -213,8 +243,8 @@ def parse_pps(nal):
     p["pic_order_present"] = r.u(1)
     if r.ue() != 0:
         raise NotImplementedError("slice groups (FMO) are not implemented")
-    r.ue(), r.ue()
-    r.u(1), r.u(2)
+    p["num_ref_idx_default"] = (r.ue() + 1, r.ue() + 1)
+    p["weighted_pred"], p["weighted_bipred_idc"] = r.u(1), r.u(2)
     p["pic_init_qp"] = 26 + r.se()
     r.se()
     p["chroma_qp_offset"] = r.se()
@@ -277,14 +307,14 @@ assert sorted(CTX_I) == list(range(0, 11)) + list(range(60, 276)), "context tabl
 
 
 class Cabac:
-    def __init__(self, bits: Bits, qp: int):
+    def __init__(self, bits: Bits, qp: int, table=None):
         self.b = bits
         self.range = 510
         self.offset = bits.u(9)
         self.state = {}
         self.mps = {}
         q = min(max(qp, 0), 51)
-        for k, (m, n) in CTX_I.items():
+        for k, (m, n) in (CTX_I if table is None else table).items():
             pre = min(max(((m * q) >> 4) + n, 1), 126)
             if pre <= 63:
                 self.state[k], self.mps[k] = 63 - pre, 0

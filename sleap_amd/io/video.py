@@ -6,8 +6,8 @@ sleap/nn/data/providers.py:371-439, "we don't parallelize here for thread safety
 * `Video` -- the thin facade of sleap/io/video.py:1023-1508 over array-like backends: `NumpyVideo` (in-memory array or a
   memory-mapped `.npy`, sleap/io/video.py:511-590) and `HDF5Video` (dataset of frames in an HDF5 file with the reference's
   `input_format` / `convert_range` options, sleap/io/video.py:47-338). `MediaVideo` (sleap/io/video.py:340-504, cv2 / FFmpeg
-  there): no decoder exists in this image or on the GPU box, so round 6 brought its own for the part of H.264 that fits a
-  few hundred lines -- the KEY frames of a Baseline / Main-profile CABAC stream (io/_h264_intra.py); inter-coded frames raise.
+  there): no decoder exists in this image or on the GPU box, so round 6 brought its own -- progressive Main-profile H.264 (I, P
+  and B pictures, CABAC) in MP4 (io/_h264.py over io/_h264_intra.py); Baseline / CAVLC and High-profile files raise.
 * `VideoReader` -- the provider surface (`videos`, `example_indices`, `len`, `make_dataset()` yielding the same example
   dictionaries).
 * `FramePrefetcher` -- the throughput piece: a producer thread reads whole batches ahead of the consumer into a small ring
@@ -244,25 +244,31 @@ class SingleImageVideo:
 
 
 class MediaVideo:
-    """sleap/io/video.py:340-504 (`MediaVideo`: cv2.VideoCapture over FFmpeg) for H.264 in MP4, KEY FRAMES ONLY: frame 0 and
-    every sync sample of the file decode with the package's own intra-picture decoder (io/_h264_intra.py: pure Python, ~2 s per
-    384 x 384 frame, bit-exact planes by the standard's definition); any other frame raises `KeyError` with the reason, as an
-    undecodable frame does in the reference (video.py:497-498). Colour conversion, channel handling and the `grayscale` / `bgr`
-    attributes follow the reference: BGR as libswscale delivers it to cv2, `grayscale` "auto" = detected on the first frame
-    (all channels equal), a grayscale video yields channel 0, `bgr=True` reverses the channel order of colour frames."""
+    """sleap/io/video.py:340-504 (`MediaVideo`: cv2.VideoCapture over FFmpeg) for H.264 in MP4 / MOV through the package's own
+    decoder (neither this image nor the GPU box holds one: profiles/r06_decoder_probe.txt): io/_h264.py decodes the I, P and B
+    pictures of progressive Main-profile CABAC streams (x264's default for `-profile main`: the reference's
+    centered_pair_low_quality.mp4, centered_pair_small.mp4, dance.mp4); Baseline / CAVLC and High-profile files raise
+    NotImplementedError naming the missing coding tool. Frame k is the k-th picture in PRESENTATION order (the MP4's composition
+    times), as cv2 numbers frames. Pure Python + NumPy: ~0.2-0.8 s per 384 x 384 picture; sequential reads decode every picture
+    once, a jump decodes from the key frame in front of the target (`keyframes`). Colour conversion, channel handling and the
+    `grayscale` / `bgr` attributes follow the reference: BGR as libswscale delivers it to cv2, `grayscale` "auto" = detected on
+    the first frame (all channels equal), a grayscale video yields channel 0, `bgr=True` reverses the channel order of colour
+    frames. An index past the end raises `KeyError` like the reference's failed read (video.py:497-498)."""
 
     EXTS = ("mp4", "mov", "m4v")
 
     def __init__(self, filename: str, grayscale: Optional[bool] = None, bgr: bool = True):
-        from . import _h264_intra as H
+        from . import _h264, _h264_intra
 
         if not os.path.isfile(filename):
             raise FileNotFoundError(f"Could not find filename video filename named {filename}")
         self.filename, self.bgr = filename, bgr
         self.dataset, self.input_format = "", ""
-        self._track = H.Mp4H264(filename)
+        self._track = _h264_intra.Mp4H264(filename)
+        self._reader = _h264.H264Reader(self._track)
+        self._swscale = _h264_intra.swscale_bgr
         self._cache = {}
-        self._H = H
+        self._lock = threading.Lock()  # (the decoder is a sequential state machine)
         self.grayscale = grayscale
         if grayscale is None:  # (video.py:391-396: detect on the first frame)
             t = self._bgr_frame(0)
@@ -274,18 +280,19 @@ class MediaVideo:
     channels = property(lambda self: 1 if self.grayscale else 3)
     dtype = property(lambda self: np.dtype(np.uint8))
     fps = property(lambda self: self._track.fps)
-    keyframes = property(lambda self: list(self._track.sync))
+    keyframes = property(lambda self: [self._track.display_order.index(s) for s in self._track.sync])
 
     def _bgr_frame(self, idx: int) -> np.ndarray:
-        if idx not in self._cache:
-            if len(self._cache) >= 16:
-                self._cache.pop(next(iter(self._cache)))
-            try:
-                y, cb, cr, _ = self._H.decode_intra(self._track, idx)
-            except self._H.NotIntraCoded as e:
-                raise KeyError(f"Unable to load frame {idx} from {self.filename}: {e}") from e
-            self._cache[idx] = self._H.swscale_bgr(y, cb, cr)
-        return self._cache[idx]
+        with self._lock:
+            if idx not in self._cache:
+                if len(self._cache) >= 16:
+                    self._cache.pop(next(iter(self._cache)))
+                try:
+                    y, cb, cr = self._reader.frame(idx)
+                except IndexError as e:
+                    raise KeyError(f"Unable to load frame {idx} from {self.filename}: the video has {len(self._track)} frames") from e
+                self._cache[idx] = self._swscale(y, cb, cr)
+            return self._cache[idx]
 
     def get_frame(self, idx: int, grayscale: Optional[bool] = None) -> np.ndarray:
         frame = self._bgr_frame(int(idx))
@@ -324,7 +331,7 @@ class Video:
 
     @classmethod
     def from_media(cls, filename: str, *args, **kwargs) -> "Video":
-        """video.py:1211-1225: a media file (here: H.264 in MP4 / MOV, key frames only)."""
+        """video.py:1211-1225: a media file (here: Main-profile H.264 in MP4 / MOV)."""
         return cls(MediaVideo(filename, *args, **kwargs))
 
     @classmethod
