@@ -55,7 +55,7 @@ def test_media_video_reads_key_frames_and_inter_coded_frames():
     np.testing.assert_array_equal(v[0][..., 0], z["gray"])
     assert v.backend.get_frame(0, grayscale=False).shape == (384, 384, 3)
     f1 = v[1]  # (display order: frame 1 is sample 3, a B picture predicted from samples 0, 1 and 2 -- tests/test_h264_inter.py)
-    assert f1.shape == v[0].shape and 15 <= float(f1.mean()) <= 30 and not np.array_equal(f1, v[0])
+    assert f1.shape == v[0].shape and abs(float(f1.mean()) - float(v[0].mean())) < 1.0 and not np.array_equal(f1, v[0])
     with pytest.raises(KeyError, match="Unable to load frame 5000"):
         v.get_frame(5000)
 
