@@ -24,7 +24,7 @@ def test_video_facade(clip, tmp_path):
     m = Video.from_filename(str(tmp_path / "clip.npy"))  # memory mapped
     assert len(m) == 23 and np.array_equal(m[10:14], clip[10:14]) and m.backend_dict()["grayscale"]
     assert Video.from_numpy(clip[..., 0]).shape == (23, 12, 16, 1)  # (frames, h, w) gets a channel axis
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(FileNotFoundError):  # (MediaVideo exists since round 6: a missing file fails like the reference's, video.py:370)
         Video.from_filename("movie.mp4")
     with pytest.raises(ValueError, match="Could not detect backend"):
         Video.from_filename("movie.xyz")
