@@ -1,30 +1,35 @@
-"""H.264 decoder for progressive Main-profile streams: I, P and B pictures (CABAC, 4:2:0, frame macroblocks, one slice per
-picture, 4x4 transform) -- what x264 writes at its default settings for `-profile main` and what the reference's test videos
-are (tests/data/json_format_v1/centered_pair_low_quality.mp4, tests/data/videos/centered_pair_small.mp4, dance.mp4). Pure
-Python + NumPy on top of io/_h264_intra.py (bit reader, MP4 tables, CABAC engine, intra prediction, transforms, edge filter);
-~0.2-0.8 s per 384 x 384 picture. `sleap_amd.io.video.MediaVideo` reads every frame of such a file through `H264Reader`
-(display order = the MP4's composition times, as cv2.VideoCapture numbers frames: sleap/io/video.py:340-504).
+"""H.264 decoder for progressive Baseline / Main-profile streams: I, P and B pictures, CABAC or CAVLC, 4:2:0, frame
+macroblocks, one slice per picture, 4x4 transform -- what x264 writes for `-profile baseline` / `-profile main`, and what the
+reference's test videos are: tests/data/videos/small_robot.mp4 (Baseline: CAVLC, P pictures; the file its MediaVideo tests
+read), tests/data/json_format_v1/centered_pair_low_quality.mp4, tests/data/videos/centered_pair_small.mp4, dance.mp4 (Main:
+CABAC, B pyramids, weighted prediction). Pure Python + NumPy on top of io/_h264_intra.py (bit reader, MP4 tables, CABAC engine,
+intra prediction, transforms, edge filter); ~0.2-0.8 s per 384 x 384 picture. `sleap_amd.io.video.MediaVideo` reads every frame of
+such a file through `H264Reader` (display order = the MP4's composition times, as cv2.VideoCapture numbers frames:
+sleap/io/video.py:340-504).
 
 Implemented beyond the intra module (clause numbers of ITU-T H.264): slice headers of P / B slices incl. reference picture list
 modification, the prediction weight table and memory management control operation 1 (7.3.3); picture order count type 0
 (8.2.1.1); reference list initialisation and modification (8.2.4), sliding-window and adaptive marking (8.2.5); the CABAC
 syntax of P and B macroblocks for cabac_init_idc 0 (9.3: mb_skip_flag, mb_type, sub_mb_type, ref_idx, mvd, intra macroblocks in
-inter slices); motion vector prediction incl. P_Skip, spatial and temporal direct with direct_8x8_inference (8.4.1); quarter-
+inter slices) and the CAVLC syntax of I and P slices (9.2: coeff_token, levels, total_zeros, run_before; mb_skip_run, me(v) / te(v)
+/ se(v) elements); motion vector prediction incl. P_Skip, spatial and temporal direct with direct_8x8_inference (8.4.1); quarter-
 sample luma and eighth-sample chroma interpolation, default / explicit / implicit weighted prediction (8.4.2); the edge
-filter's boundary strengths for inter pictures (8.7.2.1). NOT implemented, each refused with a message: CAVLC (Baseline
-streams such as tests/data/videos/small_robot.mp4), the 8x8 transform / scaling matrices (High profile), cabac_init_idc 1 and 2
-(their context tables are not held: no stream here uses them and nothing could validate them), I_PCM, long-term references,
-fields / MBAFF, several slices per picture, constrained intra prediction.
+filter's boundary strengths for inter pictures (8.7.2.1). NOT implemented, each refused with a message: the 8x8 transform /
+scaling matrices (High profile: tests/data/videos/small_robot_3_frame.mp4), cabac_init_idc 1 and 2 (their context tables are not
+held: no stream here uses them and nothing could validate them), B slices with CAVLC, I_PCM, long-term references, fields /
+MBAFF, several slices per picture, constrained intra prediction.
 
-Checks. (1) A decode is self-checking like the intra module's: a wrong context-table entry, binarisation or neighbour rule
-desynchronises the arithmetic decoder, and end_of_slice_flag then misses the last macroblock / the slice data is not exhausted --
-asserted for every picture (all 1100 + 1100 + 450 pictures of the three files decode). (2) Key frames are decoded by BOTH modules
-and must agree bit for bit (tests/test_h264_inter.py). (3) What the self-check cannot see is arithmetic that does not feed back
-into parsing (interpolation taps, weights, the edge filter): there is no second decoder in this image to compare pixels with
-("unpinned"), so the tests bound it indirectly -- drift: the last picture before every key frame must match that key frame as
-closely as neighbouring pictures match each other (a wrong tap or weight accumulates over a 150-picture GOP into tens of grey
-levels); and the reference's own predictions for inter-coded frames (tests/data/json_format_v1/centered_pair_predictions.slp)
-are reproduced by the bottom-up fixture model on the decoded frames to within a few pixels.
+Checks. (1) A decode is self-checking like the intra module's: a wrong table entry, binarisation or neighbour rule
+desynchronises the entropy decoder, and the slice then does not end exactly at the last macroblock with its data used up --
+asserted for every picture (all 1100 + 1100 + 450 + 166 pictures of the four files decode); the VLC tables are checked to be
+prefix-free codes at import. (2) Key frames are decoded by BOTH modules and must agree bit for bit. (3) An external decoder's
+pixels: tests/data/videos/robot0..2.jpg are frames 56, 86, 116 of small_robot.mp4 as FFmpeg decoded them -- this decoder lands on
+them at 38.3-38.5 dB (the JPEGs' own compression loss; neighbouring frames: ~30 dB), equally at the end of a 116-picture P chain.
+(4) The same video encoded twice (centered_pair_low_quality / centered_pair_small): the two decodes agree on P and B pictures
+as on key frames (49 dB at key frames, 47-48 after them, following the encoders' quantisers down to 45 at the end of a GOP;
+tools/h264_cross_check.py, profiles/r06_h264_cross_check.txt). What remains unpinned: bit-exactness of inter pictures against
+FFmpeg (no second decoder in this image), and the tools no fixture exercises (explicit bi-prediction weights, temporal direct is
+exercised by dance.mp4's parser checks only). tests/test_h264_inter.py.
 """
 import numpy as np
 
@@ -90,7 +95,7 @@ SHAPE_PARTS = {"16x16": [(0, 0, 4, 4)], "16x8": [(0, 0, 4, 2), (0, 2, 4, 2)], "8
 
 class MBInfo:
     __slots__ = ("typ", "i16", "qp", "cbp_luma", "cbp_chroma", "chroma_mode", "modes", "cbf_dc", "cbf_luma", "cbf_cdc", "cbf_cac",
-                 "qp_delta_nz", "skip", "direct16", "intra")
+                 "qp_delta_nz", "skip", "direct16", "intra", "ref0")
 
     def __init__(self):
         self.typ = None        # "I4", "I16", "P" (any inter macroblock)
@@ -106,6 +111,7 @@ class MBInfo:
         self.skip = False
         self.direct16 = False  # B_Skip or B_Direct_16x16 (mb_type's context increment)
         self.intra = False
+        self.ref0 = False      # P_8x8ref0 (CAVLC): no ref_idx is sent, all zero
         self.i16 = 0
         self.qp = 0
 
@@ -217,8 +223,6 @@ class H264Decoder:
     def __init__(self, sps, pps):
         if sps["profile"] not in (66, 77):
             raise Unsupported(f"profile_idc {sps['profile']}: Baseline / Main only")
-        if not pps["cabac"]:
-            raise Unsupported("CAVLC entropy coding is not implemented (CABAC streams only)")
         if pps["constrained_intra"]:
             raise Unsupported("constrained_intra_pred_flag = 1 is not implemented")
         self.sps, self.pps = sps, pps
@@ -299,7 +303,7 @@ class H264Decoder:
                     if op != 1:
                         raise Unsupported(f"memory_management_control_operation {op}")
                     h["mmco"].append((op, r.ue()))
-        h["cabac_init_idc"] = r.ue() if h["type"] != 2 else None
+        h["cabac_init_idc"] = r.ue() if (h["type"] != 2 and pps["cabac"]) else None
         if h["cabac_init_idc"] not in (None, 0):
             raise Unsupported(f"cabac_init_idc {h['cabac_init_idc']}: only the tables of cabac_init_idc 0 are held")
         h["qp"] = pps["pic_init_qp"] + r.se()
@@ -310,8 +314,9 @@ class H264Decoder:
                 h["off"] = (2 * r.se(), 2 * r.se())
         if h["dbf"] == 2:
             raise Unsupported("disable_deblocking_filter_idc 2")
-        while r.p & 7:
-            assert r.u(1) == 1, "cabac_alignment_one_bit"
+        if pps["cabac"]:
+            while r.p & 7:
+                assert r.u(1) == 1, "cabac_alignment_one_bit"
         if h["first_mb"] != 0:
             raise Unsupported("several slices per picture")
         return h, r
@@ -401,17 +406,18 @@ class H264Decoder:
         for p in self.dpb:
             p.frame_num_wrap = p.frame_num - (1 << sps["log2_max_frame_num"]) if p.frame_num > cur.frame_num else p.frame_num
         lists = self._ref_lists(h, cur) if h["type"] != 2 else [[], []]
-        _SliceDecoder(self, h, r, cur, lists).run()
+        (_SliceDecoder if pps["cabac"] else _CavlcSliceDecoder)(self, h, r, cur, lists, payload_bits=h["n_bits"], payload=rbsp(nal)).run()
         self._mark(h, cur)
         return cur
 
 
 class _SliceDecoder:
-    def __init__(self, dec, h, r, cur, lists):
+    def __init__(self, dec, h, r, cur, lists, payload_bits=0, payload=b""):
         self.dec, self.h, self.r, self.pic, self.lists = dec, h, r, cur, lists
         self.sps, self.pps = dec.sps, dec.pps
         self.stype = h["type"]
-        self.cab = Cabac(r, h["qp"], CTX_I if self.stype == 2 else CTX_PB0)
+        self.cab = Cabac(r, h["qp"], CTX_I if self.stype == 2 else CTX_PB0) if self.pps["cabac"] else None
+        self._payload = payload
         self.qp = h["qp"]
         self.prev_qp_delta_nz = 0
         self.stats = {"I4": 0, "I16": 0, "skip": 0, "inter": 0, "type": "PBI"[self.stype], "slice_qp": h["qp"]}
@@ -563,6 +569,38 @@ class _SliceDecoder:
         pm = 2 * cab.decision(base + 3)
         pm += cab.decision(base + 3)
         return "I16", (pm, 15 if ac else 0, chroma)
+
+    def _sub_mb_types(self):
+        """the four sub_mb_type elements of P_8x8 / B_8x8 -> [(sub-partition shape | "direct", prediction)]"""
+        cab, stype = self.cab, self.stype
+        subs = []
+        for q in range(4):
+            if stype == 0:
+                if cab.decision(21):
+                    st = 0
+                elif cab.decision(22) == 0:
+                    st = 1
+                else:
+                    st = 3 if cab.decision(23) == 0 else 2
+                subs.append((P_SUB[st], 0))
+            else:
+                if cab.decision(36) == 0:
+                    subs.append(("direct", None))
+                    continue
+                if cab.decision(37) == 0:
+                    st = 1 + cab.decision(39)
+                else:
+                    st = 3
+                    if cab.decision(38):
+                        if cab.decision(39):
+                            st = 11 + cab.decision(39)
+                            subs.append(B_SUB[st])
+                            continue
+                        st += 4
+                    st += 2 * cab.decision(39)
+                    st += cab.decision(39)
+                subs.append(B_SUB[st])
+        return subs
 
     def _ref_idx(self, lst, x4, y4):
         pic, cab = self.pic, self.cab
@@ -742,6 +780,30 @@ class _SliceDecoder:
             deblock_inter(pic, h["off"][0], h["off"][1])
         pic.stats = self.stats
 
+    def _skip_mb(self, addr, mx, my, m):
+        """P_Skip / B_Skip: inferred motion, no residual"""
+        pic, stype = self.pic, self.stype
+        X4, Y4 = mx * 4, my * 4
+        m.skip, m.typ, m.qp = True, "P", self.qp
+        self.prev_qp_delta_nz = 0
+        self.stats["skip"] += 1
+        if stype == 0:
+            a, b = self._nb(0, X4 - 1, Y4), self._nb(0, X4, Y4 - 1)
+            if not a[0] or not b[0] or (a[1] == 0 and a[2] == (0, 0)) or (b[1] == 0 and b[2] == (0, 0)):
+                mv = (0, 0)
+            else:
+                mv = self._mvp(0, X4, Y4, 4, 4, 0)
+            self._set_motion(0, X4, Y4, 4, 4, 0, mv)
+            parts = [(0, 0, 4, 4)]
+        else:
+            m.direct16 = True
+            self._direct(mx, my, (0, 1, 2, 3))
+            parts = [(0, 0, 2, 2), (2, 0, 2, 2), (0, 2, 2, 2), (2, 2, 2, 2)] if self.sps["direct_8x8_inference"] else \
+                [(i, j, 1, 1) for j in range(4) for i in range(4)]
+        pic.done[Y4:Y4 + 4, X4:X4 + 4] = True
+        pic.mbs[addr] = m
+        self._predict_inter(mx, my, parts)
+
     def _macroblock(self, addr, mx, my):
         pic, cab, stype = self.pic, self.cab, self.stype
         X4, Y4 = mx * 4, my * 4
@@ -752,25 +814,7 @@ class _SliceDecoder:
         if stype != 2:
             ctx = (11 if stype == 0 else 24) + (1 if (A is not None and not A.skip) else 0) + (1 if (Bn is not None and not Bn.skip) else 0)
             if cab.decision(ctx):
-                m.skip, m.typ, m.qp = True, "P", self.qp
-                self.prev_qp_delta_nz = 0
-                self.stats["skip"] += 1
-                if stype == 0:
-                    a, b = self._nb(0, X4 - 1, Y4), self._nb(0, X4, Y4 - 1)
-                    if not a[0] or not b[0] or (a[1] == 0 and a[2] == (0, 0)) or (b[1] == 0 and b[2] == (0, 0)):
-                        mv = (0, 0)
-                    else:
-                        mv = self._mvp(0, X4, Y4, 4, 4, 0)
-                    self._set_motion(0, X4, Y4, 4, 4, 0, mv)
-                    parts = [(0, 0, 4, 4)]
-                else:
-                    m.direct16 = True
-                    self._direct(mx, my, (0, 1, 2, 3))
-                    parts = [(0, 0, 2, 2), (2, 0, 2, 2), (0, 2, 2, 2), (2, 2, 2, 2)] if self.sps["direct_8x8_inference"] else \
-                        [(i, j, 1, 1) for j in range(4) for i in range(4)]
-                mb_done[:] = True
-                pic.mbs[addr] = m
-                self._predict_inter(mx, my, parts)
+                self._skip_mb(addr, mx, my, m)
                 return
         # ---- mb_type
         inter = None  # (shape, [prediction of partition 0, 1]) or "8x8"
@@ -833,12 +877,16 @@ class _SliceDecoder:
                 shape, p0, p1 = B_MB[t]
                 inter = (shape, [p0, p1])
         if inter is None:
-            m.intra = True
-            pic.intra4[Y4:Y4 + 4, X4:X4 + 4] = True
-            self.stats[m.typ] += 1
-            mb_done[:] = True  # (refIdx -1 in both lists: "available, not inter")
             self._intra_tail(addr, mx, my, m, A, Bn)
-            return
+        else:
+            self._inter_tail(addr, mx, my, m, A, Bn, inter)
+
+    def _inter_tail(self, addr, mx, my, m, A, Bn, inter):
+        """motion data, prediction, coded_block_pattern, mb_qp_delta and residual of an inter macroblock; `inter` = "direct",
+        "8x8" or (partition shape, [prediction of partition 0, 1])"""
+        pic, stype = self.pic, self.stype
+        X4, Y4 = mx * 4, my * 4
+        mb_done = pic.done[Y4:Y4 + 4, X4:X4 + 4]
         m.typ = "P"
         self.stats["inter"] += 1
         # ---- motion data
@@ -849,33 +897,7 @@ class _SliceDecoder:
             mb_done[:] = True
         else:
             if inter == "8x8":
-                subs = []
-                for q in range(4):
-                    if stype == 0:
-                        if cab.decision(21):
-                            st = 0
-                        elif cab.decision(22) == 0:
-                            st = 1
-                        else:
-                            st = 3 if cab.decision(23) == 0 else 2
-                        subs.append((P_SUB[st], 0))
-                    else:
-                        if cab.decision(36) == 0:
-                            subs.append(("direct", None))
-                            continue
-                        if cab.decision(37) == 0:
-                            st = 1 + cab.decision(39)
-                        else:
-                            st = 3
-                            if cab.decision(38):
-                                if cab.decision(39):
-                                    st = 11 + cab.decision(39)
-                                    subs.append(B_SUB[st])
-                                    continue
-                                st += 4
-                            st += 2 * cab.decision(39)
-                            st += cab.decision(39)
-                        subs.append(B_SUB[st])
+                subs = self._sub_mb_types()
                 # partitions: (x, y, w, h, prediction, shape for the directional rule, index for it, reference group)
                 plist = []
                 dq = [q for q in range(4) if subs[q][0] == "direct"]
@@ -899,7 +921,7 @@ class _SliceDecoder:
             for lst in (0, 1):
                 for g, gx, gy, gw, gh, pr in refgroups:
                     if pr in (lst, 2):
-                        rf = self._ref_idx(lst, X4 + gx, Y4 + gy) if self.h["nref"][lst] > 1 else 0
+                        rf = self._ref_idx(lst, X4 + gx, Y4 + gy) if (self.h["nref"][lst] > 1 and not getattr(m, "ref0", False)) else 0
                         assert rf < self.h["nref"][lst], "ref_idx beyond the list: the CABAC decode lost synchronisation"
                         refs[(lst, g)] = rf
                         self.pic.ref[lst, Y4 + gy:Y4 + gy + gh, X4 + gx:X4 + gx + gw] = rf
@@ -984,9 +1006,33 @@ class _SliceDecoder:
         self.prev_qp_delta_nz = m.qp_delta_nz
         m.qp = self.qp
 
+    def _i4_mode(self):
+        """prev_intra4x4_pred_mode_flag / rem_intra4x4_pred_mode -> None (use the predicted mode) or rem"""
+        cab = self.cab
+        if cab.decision(68):
+            return None
+        return cab.decision(69) | (cab.decision(69) << 1) | (cab.decision(69) << 2)
+
+    def _chroma_mode(self, A, Bn):
+        cab = self.cab
+        inc = (1 if (A is not None and A.chroma_mode != 0) else 0) + (1 if (Bn is not None and Bn.chroma_mode != 0) else 0)
+        cm = 0
+        if cab.decision(64 + inc):
+            cm = 1
+            if cab.decision(64 + 3):
+                cm = 2
+                if cab.decision(64 + 3):
+                    cm = 3
+        return cm
+
     def _intra_tail(self, addr, mx, my, m, A, Bn):
         """prediction modes, chroma mode, coded_block_pattern, mb_qp_delta and residual of an intra macroblock"""
         pic, cab = self.pic, self.cab
+        X4, Y4 = mx * 4, my * 4
+        m.intra = True
+        pic.intra4[Y4:Y4 + 4, X4:X4 + 4] = True
+        self.stats[m.typ] += 1
+        pic.done[Y4:Y4 + 4, X4:X4 + 4] = True  # (refIdx -1 in both lists: "available, not inter")
         if m.typ == "I4":
             for blk in range(16):
                 bx, by = BLK_XY[blk]
@@ -1002,21 +1048,9 @@ class _SliceDecoder:
 
                 ma, mb_ = nmode(-1, 0), nmode(0, -1)
                 pred = 2 if (ma is None or mb_ is None) else min(ma, mb_)
-                if cab.decision(68):
-                    mode = pred
-                else:
-                    rem = cab.decision(69) | (cab.decision(69) << 1) | (cab.decision(69) << 2)
-                    mode = rem if rem < pred else rem + 1
-                m.modes[blk] = mode
-        inc = (1 if (A is not None and A.chroma_mode != 0) else 0) + (1 if (Bn is not None and Bn.chroma_mode != 0) else 0)
-        cm = 0
-        if cab.decision(64 + inc):
-            cm = 1
-            if cab.decision(64 + 3):
-                cm = 2
-                if cab.decision(64 + 3):
-                    cm = 3
-        m.chroma_mode = cm
+                rem = self._i4_mode()
+                m.modes[blk] = pred if rem is None else (rem if rem < pred else rem + 1)
+        m.chroma_mode = self._chroma_mode(A, Bn)
         if m.typ == "I4":
             self._cbp(m, A, Bn)
         self._qp_delta(m, coded=(m.typ == "I16" or bool(m.cbp_luma or m.cbp_chroma)))
@@ -1109,6 +1143,253 @@ class _SliceDecoder:
                     P = pic.C[comp]
                     ys, xs = slice(my * 8 + by * 4, my * 8 + by * 4 + 4), slice(mx * 8 + bx * 4, mx * 8 + bx * 4 + 4)
                     P[ys, xs] = np.clip(P[ys, xs] + rr, 0, 255)
+
+
+# ----------------------------------------------------------------------------------------------------------------- CAVLC (9.2)
+# coeff_token: [table by nC][4 * TotalCoeff + TrailingOnes] -> (length, code); Tables 9-5 (a prefix-free code each: checked at import)
+_CT_LEN = [
+    [1, 0, 0, 0, 6, 2, 0, 0, 8, 6, 3, 0, 9, 8, 7, 5, 10, 9, 8, 6, 11, 10, 9, 7, 13, 11, 10, 8, 13, 13, 11, 9, 13, 13, 13, 10, 14, 14, 13, 11,
+     14, 14, 14, 13, 15, 15, 14, 14, 15, 15, 15, 14, 16, 15, 15, 15, 16, 16, 16, 15, 16, 16, 16, 16, 16, 16, 16, 16],
+    [2, 0, 0, 0, 6, 2, 0, 0, 6, 5, 3, 0, 7, 6, 6, 4, 8, 6, 6, 4, 8, 7, 7, 5, 9, 8, 8, 6, 11, 9, 9, 6, 11, 11, 11, 7, 12, 11, 11, 9,
+     12, 12, 12, 11, 12, 12, 12, 11, 13, 13, 13, 12, 13, 13, 13, 13, 13, 14, 13, 13, 14, 14, 14, 13, 14, 14, 14, 14],
+    [4, 0, 0, 0, 6, 4, 0, 0, 6, 5, 4, 0, 6, 5, 5, 4, 7, 5, 5, 4, 7, 5, 5, 4, 7, 6, 6, 4, 7, 6, 6, 4, 8, 7, 7, 5, 8, 8, 7, 6,
+     9, 8, 8, 7, 9, 9, 8, 8, 9, 9, 9, 8, 10, 9, 9, 9, 10, 10, 10, 10, 10, 10, 10, 10, 10, 10, 10, 10],
+    [6, 0, 0, 0, 6, 6, 0, 0, 6, 6, 6, 0] + [6] * 56]
+_CT_BITS = [
+    [1, 0, 0, 0, 5, 1, 0, 0, 7, 4, 1, 0, 7, 6, 5, 3, 7, 6, 5, 3, 7, 6, 5, 4, 15, 6, 5, 4, 11, 14, 5, 4, 8, 10, 13, 4, 15, 14, 9, 4,
+     11, 10, 13, 12, 15, 14, 9, 12, 11, 10, 13, 8, 15, 1, 9, 12, 11, 14, 13, 8, 7, 10, 9, 12, 4, 6, 5, 8],
+    [3, 0, 0, 0, 11, 2, 0, 0, 7, 7, 3, 0, 7, 10, 9, 5, 7, 6, 5, 4, 4, 6, 5, 6, 7, 6, 5, 8, 15, 6, 5, 4, 11, 14, 13, 4, 15, 10, 9, 4,
+     11, 14, 13, 12, 8, 10, 9, 8, 15, 14, 13, 12, 11, 10, 9, 12, 7, 11, 6, 8, 9, 8, 10, 1, 7, 6, 5, 4],
+    [15, 0, 0, 0, 15, 14, 0, 0, 11, 15, 13, 0, 8, 12, 14, 12, 15, 10, 11, 11, 11, 8, 9, 10, 9, 14, 13, 9, 8, 10, 9, 8, 15, 14, 13, 13,
+     11, 14, 10, 12, 15, 10, 13, 12, 11, 14, 9, 12, 8, 10, 13, 8, 13, 7, 9, 12, 9, 12, 11, 10, 5, 8, 7, 6, 1, 4, 3, 2],
+    [3, 0, 0, 0, 0, 1, 0, 0, 4, 5, 6, 0] + list(range(8, 64))]
+_CDC_LEN = [2, 0, 0, 0, 6, 1, 0, 0, 6, 6, 3, 0, 6, 7, 7, 6, 6, 8, 8, 7]
+_CDC_BITS = [1, 0, 0, 0, 7, 1, 0, 0, 4, 6, 1, 0, 3, 3, 2, 5, 2, 3, 2, 0]
+# total_zeros: [TotalCoeff - 1][total_zeros] (Tables 9-7, 9-8), chroma DC (Table 9-9a); run_before: [min(zerosLeft, 7) - 1][run] (9-10)
+_TZ_LEN = [[1, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 9], [3, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 6, 6, 6, 6], [4, 3, 3, 3, 4, 4, 3, 3, 4, 5, 5, 6, 5, 6],
+           [5, 3, 4, 4, 3, 3, 3, 4, 3, 4, 5, 5, 5], [4, 4, 4, 3, 3, 3, 3, 3, 4, 5, 4, 5], [6, 5, 3, 3, 3, 3, 3, 3, 4, 3, 6],
+           [6, 5, 3, 3, 3, 2, 3, 4, 3, 6], [6, 4, 5, 3, 2, 2, 3, 3, 6], [6, 6, 4, 2, 2, 3, 2, 5], [5, 5, 3, 2, 2, 2, 4], [4, 4, 3, 3, 1, 3],
+           [4, 4, 2, 1, 3], [3, 3, 1, 2], [2, 2, 1], [1, 1]]
+_TZ_BITS = [[1, 3, 2, 3, 2, 3, 2, 3, 2, 3, 2, 3, 2, 3, 2, 1], [7, 6, 5, 4, 3, 5, 4, 3, 2, 3, 2, 3, 2, 1, 0], [5, 7, 6, 5, 4, 3, 4, 3, 2, 3, 2, 1, 1, 0],
+            [3, 7, 5, 4, 6, 5, 4, 3, 3, 2, 2, 1, 0], [5, 4, 3, 7, 6, 5, 4, 3, 2, 1, 1, 0], [1, 1, 7, 6, 5, 4, 3, 2, 1, 1, 0],
+            [1, 1, 5, 4, 3, 3, 2, 1, 1, 0], [1, 1, 1, 3, 3, 2, 2, 1, 0], [1, 0, 1, 3, 2, 1, 1, 1], [1, 0, 1, 3, 2, 1, 1], [0, 1, 1, 2, 1, 3],
+            [0, 1, 1, 1, 1], [0, 1, 1, 1], [0, 1, 1], [0, 1]]
+_CTZ_LEN, _CTZ_BITS = [[1, 2, 3, 3], [1, 2, 2], [1, 1]], [[1, 1, 1, 0], [1, 1, 0], [1, 0]]
+_RUN_LEN = [[1, 1], [1, 2, 2], [2, 2, 2, 2], [2, 2, 2, 3, 3], [2, 2, 3, 3, 3, 3], [2, 3, 3, 3, 3, 3, 3], [3, 3, 3, 3, 3, 3, 3, 4, 5, 6, 7, 8, 9, 10, 11]]
+_RUN_BITS = [[1, 0], [1, 1, 0], [3, 2, 1, 0], [3, 2, 1, 1, 0], [3, 2, 3, 2, 1, 0], [3, 0, 1, 3, 2, 5, 4], [7, 6, 5, 4, 3, 2, 1, 1, 1, 1, 1, 1, 1, 1, 1]]
+# coded_block_pattern me(v), Table 9-4 (chroma formats 1, 2): codeNum -> cbp for Intra_4x4 and for inter macroblocks
+_CBP_INTRA = [47, 31, 15, 0, 23, 27, 29, 30, 7, 11, 13, 14, 39, 43, 45, 46, 16, 3, 5, 10, 12, 19, 21, 26, 28, 35, 37, 42, 44, 1, 2, 4, 8, 17, 18, 20, 24,
+              6, 9, 22, 25, 32, 33, 34, 36, 40, 38, 41]
+_CBP_INTER = [0, 16, 1, 2, 4, 8, 32, 3, 5, 10, 12, 15, 47, 7, 11, 13, 14, 6, 9, 31, 35, 37, 42, 44, 33, 34, 36, 40, 39, 43, 45, 46, 17, 18, 20, 24, 19,
+              21, 26, 28, 23, 27, 29, 30, 22, 25, 38, 41]
+assert sorted(_CBP_INTRA) == list(range(48)) and sorted(_CBP_INTER) == list(range(48))
+
+
+def _vlc(lens, bits):
+    """{(length, code): symbol} of one table, checked to be a prefix-free code (a mistyped entry cannot hide)"""
+    t = {(ln, b): k for k, (ln, b) in enumerate(zip(lens, bits)) if ln}
+    strs = [format(b, "0%db" % ln) for ln, b in t]
+    assert len(set(strs)) == len(strs) and not any(x != y and y.startswith(x) for x in strs for y in strs), "VLC table is not prefix-free"
+    assert sum(2.0 ** -ln for ln, _ in t) <= 1.0 + 1e-12
+    return t, max(ln for ln, _ in t)
+
+
+_VLC_CT = [_vlc(a, b) for a, b in zip(_CT_LEN, _CT_BITS)]
+_VLC_CDC = _vlc(_CDC_LEN, _CDC_BITS)
+_VLC_TZ = [_vlc(a, b) for a, b in zip(_TZ_LEN, _TZ_BITS)]
+_VLC_CTZ = [_vlc(a, b) for a, b in zip(_CTZ_LEN, _CTZ_BITS)]
+_VLC_RUN = [_vlc(a, b) for a, b in zip(_RUN_LEN, _RUN_BITS)]
+
+
+class _CavlcSliceDecoder(_SliceDecoder):
+    """The same macroblock semantics with the syntax of 7.3.4 / 7.3.5 read as Exp-Golomb and CAVLC codes (Baseline streams)."""
+
+    def __init__(self, *a, **k):
+        super().__init__(*a, **k)
+        if self.stype == 1:
+            raise Unsupported("B slices with CAVLC entropy coding")
+        pic = self.pic
+        pic.tc = np.zeros((pic.Hh * 4, pic.W * 4), np.int32)                              # TotalCoeff of luma 4x4 blocks
+        pic.tcc = [np.zeros((pic.Hh * 2, pic.W * 2), np.int32) for _ in range(2)]         # ... of chroma AC blocks
+        # position of the rbsp stop bit: more_rbsp_data() is "the read position is in front of it"
+        pl = self._payload
+        n = len(pl)
+        while n and pl[n - 1] == 0:
+            n -= 1
+        assert n, "empty slice payload"
+        last = pl[n - 1]
+        self._stop = (n - 1) * 8 + 7 - ((last & -last).bit_length() - 1)
+        self._mb_xy = (0, 0)
+
+    def _more(self):
+        return self.r.p < self._stop
+
+    def _read_vlc(self, table):
+        t, maxlen = table
+        r = self.r
+        code = 0
+        for ln in range(1, maxlen + 1):
+            code = (code << 1) | r.u(1)
+            k = t.get((ln, code))
+            if k is not None:
+                return k
+        raise AssertionError("no CAVLC codeword matches: the decode lost synchronisation")
+
+    # ---- slice data (7.3.4)
+    def run(self):
+        pic, r, h = self.pic, self.r, self.h
+        n_mb = pic.W * pic.Hh
+        addr = 0
+        more = True
+        while more:
+            if self.stype != 2:
+                run = r.ue()
+                assert addr + run <= n_mb, "mb_skip_run beyond the picture: the CAVLC decode lost synchronisation"
+                for _ in range(run):
+                    self._skip_mb(addr, addr % pic.W, addr // pic.W, MBInfo())
+                    addr += 1
+                if run:
+                    more = self._more()
+            if more:
+                assert addr < n_mb, "macroblock data beyond the picture: the CAVLC decode lost synchronisation"
+                self._macroblock(addr, addr % pic.W, addr // pic.W)
+                addr += 1
+                more = self._more()
+        assert addr == n_mb, f"slice data ended at macroblock {addr} of {n_mb}: the CAVLC decode lost synchronisation"
+        self.stats["bits_left"] = self._stop - r.p
+        assert self.stats["bits_left"] == 0, self.stats
+        if h["dbf"] != 1:
+            deblock_inter(pic, h["off"][0], h["off"][1])
+        pic.stats = self.stats
+
+    def _macroblock(self, addr, mx, my):
+        pic, r = self.pic, self.r
+        self._mb_xy = (mx, my)
+        m = MBInfo()
+        A, Bn = pic.mb(mx - 1, my), pic.mb(mx, my - 1)
+        t = r.ue()
+        inter = None
+        if self.stype == 0:
+            if t < 5:
+                inter = [("16x16", [0, None]), ("16x8", [0, 0]), ("8x16", [0, 0]), "8x8", "8x8"][t]
+                m.ref0 = t == 4
+            else:
+                t -= 5
+        if inter is None:
+            if t == 0:
+                m.typ = "I4"
+            elif t == 25:
+                raise Unsupported("I_PCM macroblocks")
+            else:
+                assert t < 25, "mb_type out of range: the CAVLC decode lost synchronisation"
+                m.typ = "I16"
+                m.i16, m.cbp_chroma, m.cbp_luma = (t - 1) % 4, ((t - 1) // 4) % 3, (15 if t >= 13 else 0)
+            self._intra_tail(addr, mx, my, m, A, Bn)
+        else:
+            self._inter_tail(addr, mx, my, m, A, Bn, inter)
+
+    # ---- syntax elements
+    def _sub_mb_types(self):
+        out = []
+        for _ in range(4):
+            st = self.r.ue()
+            assert st < 4, "sub_mb_type out of range: the CAVLC decode lost synchronisation"
+            out.append((P_SUB[st], 0))
+        return out
+
+    def _ref_idx(self, lst, x4, y4):
+        n = self.h["nref"][lst]
+        return (1 - self.r.u(1)) if n == 2 else self.r.ue()
+
+    def _mvd(self, lst, comp, x4, y4):
+        return self.r.se()
+
+    def _i4_mode(self):
+        return None if self.r.u(1) else self.r.u(3)
+
+    def _chroma_mode(self, A, Bn):
+        v = self.r.ue()
+        assert v < 4, "intra_chroma_pred_mode out of range: the CAVLC decode lost synchronisation"
+        return v
+
+    def _cbp(self, m, A, Bn):
+        v = self.r.ue()
+        assert v < 48, "coded_block_pattern out of range: the CAVLC decode lost synchronisation"
+        cbp = (_CBP_INTRA if m.intra else _CBP_INTER)[v]
+        m.cbp_luma, m.cbp_chroma = cbp & 15, cbp >> 4
+
+    def _qp_delta(self, m, coded):
+        if coded:
+            dqp = self.r.se()
+            assert -26 <= dqp <= 25, "mb_qp_delta out of range: the CAVLC decode lost synchronisation"
+            self.qp = (self.qp + dqp + 52) % 52
+        m.qp = self.qp
+
+    # ---- residual_block_cavlc (7.3.5.3.2, 9.2)
+    def _residual_block(self, m, A, Bn, cat, n_coef, bx=0, by=0, comp=0):
+        pic, r = self.pic, self.r
+        mx, my = self._mb_xy
+        if cat == 3:
+            table = _VLC_CDC
+        else:
+            if cat == 4:
+                arr, gx, gy = pic.tcc[comp], mx * 2 + bx, my * 2 + by
+            else:
+                arr, gx, gy = pic.tc, mx * 4 + (0 if cat == 0 else bx), my * 4 + (0 if cat == 0 else by)
+            na = int(arr[gy, gx - 1]) if gx > 0 else None
+            nb = int(arr[gy - 1, gx]) if gy > 0 else None
+            nc = (na + nb + 1) >> 1 if (na is not None and nb is not None) else (na if na is not None else (nb if nb is not None else 0))
+            table = _VLC_CT[0 if nc < 2 else (1 if nc < 4 else (2 if nc < 8 else 3))]
+        k = self._read_vlc(table)
+        total, t1 = k >> 2, k & 3
+        if cat in (1, 2):
+            pic.tc[my * 4 + by, mx * 4 + bx] = total
+        elif cat == 4:
+            pic.tcc[comp][my * 2 + by, mx * 2 + bx] = total
+        coef = [0] * n_coef
+        if total == 0:
+            return coef, 0
+        assert total <= n_coef and t1 <= min(total, 3), "coeff_token out of range: the CAVLC decode lost synchronisation"
+        levels = []
+        suffix_len = 1 if (total > 10 and t1 < 3) else 0
+        for i in range(total):
+            if i < t1:
+                levels.append(1 - 2 * r.u(1))
+                continue
+            prefix = 0
+            while r.u(1) == 0:
+                prefix += 1
+                assert prefix < 32, "level_prefix runaway: the CAVLC decode lost synchronisation"
+            code = min(15, prefix) << suffix_len
+            if suffix_len > 0 or prefix >= 14:
+                size = 4 if (prefix == 14 and suffix_len == 0) else (prefix - 3 if prefix >= 15 else suffix_len)
+                if size:
+                    code += r.u(size)
+            if prefix >= 15 and suffix_len == 0:
+                code += 15
+            if prefix >= 16:
+                code += (1 << (prefix - 3)) - 4096
+            if i == t1 and t1 < 3:
+                code += 2
+            lv = (code + 2) >> 1 if code % 2 == 0 else (-code - 1) >> 1
+            levels.append(lv)
+            if suffix_len == 0:
+                suffix_len = 1
+            if abs(lv) > (3 << (suffix_len - 1)) and suffix_len < 6:
+                suffix_len += 1
+        zeros_left = 0
+        if total < n_coef:
+            zeros_left = self._read_vlc(_VLC_CTZ[total - 1] if cat == 3 else _VLC_TZ[total - 1])
+            assert total + zeros_left <= n_coef, "total_zeros out of range: the CAVLC decode lost synchronisation"
+        pos = total + zeros_left - 1  # scan position of the highest-frequency coefficient (levels[0])
+        for i in range(total):
+            coef[pos] = levels[i]
+            if i < total - 1:
+                run = self._read_vlc(_VLC_RUN[min(zeros_left, 7) - 1]) if zeros_left > 0 else 0
+                assert run <= zeros_left, "run_before out of range: the CAVLC decode lost synchronisation"
+                zeros_left -= run
+                pos -= 1 + run
+        return coef, 1
 
 
 # ----------------------------------------------------------------------------------------------------------------- edge filter (8.7)

@@ -6,8 +6,8 @@ sleap/nn/data/providers.py:371-439, "we don't parallelize here for thread safety
 * `Video` -- the thin facade of sleap/io/video.py:1023-1508 over array-like backends: `NumpyVideo` (in-memory array or a
   memory-mapped `.npy`, sleap/io/video.py:511-590) and `HDF5Video` (dataset of frames in an HDF5 file with the reference's
   `input_format` / `convert_range` options, sleap/io/video.py:47-338). `MediaVideo` (sleap/io/video.py:340-504, cv2 / FFmpeg
-  there): no decoder exists in this image or on the GPU box, so round 6 brought its own -- progressive Main-profile H.264 (I, P
-  and B pictures, CABAC) in MP4 (io/_h264.py over io/_h264_intra.py); Baseline / CAVLC and High-profile files raise.
+  there): no decoder exists in this image or on the GPU box, so round 6 brought its own -- progressive Baseline / Main-profile H.264
+  (I, P and B pictures, CAVLC and CABAC) in MP4 (io/_h264.py over io/_h264_intra.py); High-profile files raise.
 * `VideoReader` -- the provider surface (`videos`, `example_indices`, `len`, `make_dataset()` yielding the same example
   dictionaries).
 * `FramePrefetcher` -- the throughput piece: a producer thread reads whole batches ahead of the consumer into a small ring
@@ -246,9 +246,9 @@ class SingleImageVideo:
 class MediaVideo:
     """sleap/io/video.py:340-504 (`MediaVideo`: cv2.VideoCapture over FFmpeg) for H.264 in MP4 / MOV through the package's own
     decoder (neither this image nor the GPU box holds one: profiles/r06_decoder_probe.txt): io/_h264.py decodes the I, P and B
-    pictures of progressive Main-profile CABAC streams (x264's default for `-profile main`: the reference's
-    centered_pair_low_quality.mp4, centered_pair_small.mp4, dance.mp4); Baseline / CAVLC and High-profile files raise
-    NotImplementedError naming the missing coding tool. Frame k is the k-th picture in PRESENTATION order (the MP4's composition
+    pictures of progressive Baseline / Main-profile streams (CAVLC and CABAC: the reference's small_robot.mp4,
+    centered_pair_low_quality.mp4, centered_pair_small.mp4, dance.mp4); High-profile files raise NotImplementedError naming the
+    missing coding tool. Frame k is the k-th picture in PRESENTATION order (the MP4's composition
     times), as cv2 numbers frames. Pure Python + NumPy: ~0.2-0.8 s per 384 x 384 picture; sequential reads decode every picture
     once, a jump decodes from the key frame in front of the target (`keyframes`). Colour conversion, channel handling and the
     `grayscale` / `bgr` attributes follow the reference: BGR as libswscale delivers it to cv2, `grayscale` "auto" = detected on
@@ -331,7 +331,7 @@ class Video:
 
     @classmethod
     def from_media(cls, filename: str, *args, **kwargs) -> "Video":
-        """video.py:1211-1225: a media file (here: Main-profile H.264 in MP4 / MOV)."""
+        """video.py:1211-1225: a media file (here: Baseline / Main-profile H.264 in MP4 / MOV)."""
         return cls(MediaVideo(filename, *args, **kwargs))
 
     @classmethod
@@ -348,7 +348,7 @@ class Video:
         if ext.lstrip(".") in MediaVideo.EXTS:
             return cls(MediaVideo(filename, grayscale=kwargs.get("grayscale"), bgr=kwargs.get("bgr", True)))
         if ext in (".avi", ".mj2", ".mkv"):
-            raise NotImplementedError("only H.264 in MP4 / MOV containers can be read (key frames; sleap_amd.io.video.MediaVideo): "
+            raise NotImplementedError("only H.264 in MP4 / MOV containers can be read (sleap_amd.io.video.MediaVideo): "
                                       "no general video decoder (cv2 / ffmpeg) exists in this environment")
         raise ValueError(f"Could not detect backend for specified filename: {filename}")
 

