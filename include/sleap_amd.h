@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define SA_ABI_VERSION 7  /* 7 (round 6): + sa_find_local_peaks_rough; sa_conv3x3_pair_bf16 accepts 32 -> 64 -> 64. 6 (round 5): + sa_conv3x3_set_persistent. 5 (round 4): + sa_conv3x3_ex_heads_bf16. 4 (round 4): + sa_tensor_absmax, sa_imgconv_pack_tiled, sa_pack_pointwise_weights,
+#define SA_ABI_VERSION 8  /* 8 (round 6): + sa_h264_decode_slice. 7 (round 6): + sa_find_local_peaks_rough; sa_conv3x3_pair_bf16 accepts 32 -> 64 -> 64. 6 (round 5): + sa_conv3x3_set_persistent. 5 (round 4): + sa_conv3x3_ex_heads_bf16. 4 (round 4): + sa_tensor_absmax, sa_imgconv_pack_tiled, sa_pack_pointwise_weights,
                             sa_pointwise_packed_elems, sa_conv3x3_bneck_bf16; SA_LAYOUT_PLANES16 accepted in the `relu` argument of
                             sa_conv1x1_bf16 / sa_convk_bf16 / sa_convt_s2_bf16 */
 
@@ -665,6 +665,41 @@ size_t sa_bottomup_workspace_bytes(const sa_network_t* net, const sa_bottomup_pa
 int sa_bottomup_predict(const sa_network_t* net, const sa_bottomup_params* params, const void* images, int images_are_u8, int B,
                         int H, int W, int C, float* instance_peaks, float* instance_peak_vals, float* instance_scores,
                         int32_t* n_instances, int32_t* status, void* workspace, size_t ws_bytes, sa_stream_t stream);
+
+/* ---- video ingest: slice_data() of one H.264 picture, HOST code. The reference reads video through
+ * cv2.VideoCapture / FFmpeg (sleap/io/video.py:340-504, `MediaVideo.get_frame`); neither exists in this image. The container,
+ * parameter sets, slice header, picture order counts and reference lists are handled by the caller (sleap_amd/io/_h264.py,
+ * whose pure-Python slice decoder is this function's checker: tests/test_h264_native.py, bit-exact picture by picture); this
+ * entry decodes the macroblocks of one slice = one picture: entropy decoding (CABAC with cabac_init_idc 0, or CAVLC), intra and
+ * inter prediction (P_Skip, spatial / temporal direct, weighted prediction), residual reconstruction, the in-loop edge filter.
+ * Progressive Baseline / Main profile; returns SA_ERR_INVALID_ARG with the reason for anything else or for a slice whose
+ * entropy decode does not end exactly on the last macroblock. */
+typedef struct sa_h264_pic {   /* buffers of one picture, all HOST memory owned by the caller */
+  uint8_t *y, *cb, *cr;        /* [16 mb_h][16 mb_w], [8 mb_h][8 mb_w] x 2 */
+  int16_t* mv;                 /* [2 lists][4 mb_h][4 mb_w][2]: quarter-sample motion vector of every 4x4 block */
+  int8_t* ref;                 /* [2][4 mb_h][4 mb_w]: reference index into the slice's list, -1 = list not used */
+  int32_t* refid;              /* [2][4 mb_h][4 mb_w]: `id` of the referenced picture, -1 */
+  uint8_t* intra4;             /* [4 mb_h][4 mb_w]: block belongs to an intra macroblock */
+  int32_t poc, id;             /* picture order count; identity (unique among the pictures alive at one time) */
+} sa_h264_pic;
+typedef struct sa_h264_slice {
+  int32_t mb_w, mb_h;
+  int32_t slice_type;                      /* 0 P, 1 B, 2 I */
+  int32_t cabac;                           /* entropy_coding_mode_flag */
+  int32_t qp, chroma_qp_offset;            /* SliceQPY, chroma_qp_index_offset */
+  int32_t disable_deblock, filter_offset_a, filter_offset_b;
+  int32_t direct_spatial, direct_8x8_inference;
+  int32_t nref[2];                         /* num_ref_idx_l0 / l1_active */
+  int32_t weighted_mode;                   /* 0 default, 1 explicit (`weights`), 2 implicit (from the picture order counts) */
+  int32_t luma_log2_denom, chroma_log2_denom;
+  int32_t weights[2][32][3][2];            /* explicit mode: [list][refIdx][Y, Cb, Cr][weight, offset] */
+  int32_t data_bit_offset;                 /* first bit of slice_data() in `rbsp` (behind cabac_alignment_one_bit) */
+} sa_h264_slice;
+/* rbsp: the slice NAL unit's payload without header byte and emulation prevention bytes; list0 / list1: nref[] entries each
+ * (an entry with y == NULL is "no reference picture"); cur: written completely (planes and motion data); stats (8 ints or
+ * NULL): Intra4x4, Intra16x16, skipped and inter macroblock counts, bits left at the end of the slice data. */
+int sa_h264_decode_slice(const sa_h264_slice* s, const uint8_t* rbsp, int64_t n_bytes, const sa_h264_pic* list0,
+                         const sa_h264_pic* list1, sa_h264_pic* cur, int32_t* stats);
 
 #ifdef __cplusplus
 }

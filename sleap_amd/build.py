@@ -34,6 +34,7 @@ SOURCES = [
     # sparse pyramidal Lucas-Kanade flow of the flow tracker: float32 op by op as the scalar CPU code it restates
     ("flow.hip", ["-ffp-contract=off"]),
     ("tracker.hip", []),
+    ("h264dec.hip", []),  # host code: the slice decoder behind MediaVideo
     ("network.hip", []),
 ]
 COMMON = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function"]

@@ -214,13 +214,105 @@ def mc_chroma(ref, x8, y8, w, h):
     return ((8 - fx) * (8 - fy) * A + fx * (8 - fy) * B + (8 - fx) * fy * C + fx * fy * D + 32) >> 6
 
 
+# ----------------------------------------------------------------------------------------------------------------- native engine
+# The macroblock layer as host C++ in the package's library (csrc/h264dec.hip, `sa_h264_decode_slice`): the same state machine,
+# several hundred pictures per second instead of 1-5. The Python classes below stay as its checker (tests/test_h264_native.py:
+# planes AND motion data equal, picture by picture) and as the engine of last resort (`engine="python"`).
+import ctypes as _C
+
+
+class _CPic(_C.Structure):
+    _fields_ = [("y", _C.c_void_p), ("cb", _C.c_void_p), ("cr", _C.c_void_p), ("mv", _C.c_void_p), ("ref", _C.c_void_p),
+                ("refid", _C.c_void_p), ("intra4", _C.c_void_p), ("poc", _C.c_int32), ("id", _C.c_int32)]
+
+
+class _CSlice(_C.Structure):
+    _fields_ = [(n, _C.c_int32) for n in ("mb_w", "mb_h", "slice_type", "cabac", "qp", "chroma_qp_offset", "disable_deblock",
+                                          "filter_offset_a", "filter_offset_b", "direct_spatial", "direct_8x8_inference")] + \
+               [("nref", _C.c_int32 * 2), ("weighted_mode", _C.c_int32), ("luma_log2_denom", _C.c_int32), ("chroma_log2_denom", _C.c_int32),
+                ("weights", _C.c_int32 * (2 * 32 * 3 * 2)), ("data_bit_offset", _C.c_int32)]
+
+
+class NativePic:
+    """A picture decoded by the native engine: uint8 planes and the per-4x4 motion data in the layout of `sa_h264_pic`."""
+
+    def __init__(self, sps, pps):
+        self.sps, self.pps = sps, pps
+        self.W, self.Hh = sps["mb_w"], sps["mb_h"]
+        h4, w4 = self.Hh * 4, self.W * 4
+        self.Y = np.zeros((self.Hh * 16, self.W * 16), np.uint8)
+        self.C = [np.zeros((self.Hh * 8, self.W * 8), np.uint8) for _ in range(2)]
+        self.mv = np.zeros((2, h4, w4, 2), np.int16)
+        self.ref = np.full((2, h4, w4), -1, np.int8)
+        self.refid = np.full((2, h4, w4), -1, np.int32)
+        self.intra4 = np.zeros((h4, w4), np.uint8)
+        self.poc = self.frame_num = self.frame_num_wrap = 0
+        self.is_ref = False
+        self.id = Pic._next_id
+        Pic._next_id = (Pic._next_id + 1) & 0x3FFFFFFF
+        self.sample = -1
+        self.stats = {}
+
+    def c_struct(self):
+        return _CPic(self.Y.ctypes.data, self.C[0].ctypes.data, self.C[1].ctypes.data, self.mv.ctypes.data, self.ref.ctypes.data,
+                     self.refid.ctypes.data, self.intra4.ctypes.data, int(self.poc), int(self.id))
+
+
+def _decode_native(dec, h, r, cur, lists, payload):
+    from .. import _lib
+
+    lib = _lib.lib()
+    sps, pps = dec.sps, dec.pps
+    cs = _CSlice()
+    cs.mb_w, cs.mb_h, cs.slice_type, cs.cabac = sps["mb_w"], sps["mb_h"], h["type"], pps["cabac"]
+    cs.qp, cs.chroma_qp_offset = h["qp"], pps["chroma_qp_offset"]
+    cs.disable_deblock, cs.filter_offset_a, cs.filter_offset_b = h["dbf"], h["off"][0], h["off"][1]
+    cs.direct_spatial, cs.direct_8x8_inference = h["direct_spatial"], sps["direct_8x8_inference"]
+    n0 = h["nref"][0] if h["type"] != 2 else 0
+    n1 = h["nref"][1] if h["type"] == 1 else 0
+    cs.nref[0], cs.nref[1] = n0, n1
+    cs.weighted_mode = 1 if h["pwt"] is not None else (2 if (h["type"] == 1 and pps["weighted_bipred_idc"] == 2) else 0)
+    if h["pwt"] is not None:
+        ld, cd, tabs = h["pwt"]
+        cs.luma_log2_denom, cs.chroma_log2_denom = ld, cd
+        for lst, t in enumerate(tabs):
+            for i, (lw, lo, cw, co) in enumerate(t):
+                base = ((lst * 32 + i) * 3) * 2
+                cs.weights[base:base + 6] = [lw, lo, cw[0], co[0], cw[1], co[1]]
+    cs.data_bit_offset = r.p
+    arrs = []
+    for lst, n in ((0, n0), (1, n1)):
+        a = (_CPic * max(n, 1))()
+        for i in range(n):
+            p = lists[lst][i]
+            if p is not None:
+                a[i] = p.c_struct()
+        arrs.append(a)
+    cc = cur.c_struct()
+    stats = (_C.c_int32 * 8)()
+    buf = (_C.c_uint8 * len(payload)).from_buffer_copy(payload)
+    rc = lib.sa_h264_decode_slice(_C.byref(cs), buf, len(payload), arrs[0], arrs[1], _C.byref(cc), stats)
+    if rc != 0:
+        msg = lib.sa_last_error()
+        msg = msg.decode() if msg else ""
+        if "not implemented" in msg:
+            raise Unsupported(msg)
+        raise AssertionError(f"{msg} ({'PBI'[h['type']]} picture, sample {cur.sample})")
+    cur.stats = {"I4": stats[0], "I16": stats[1], "skip": stats[2], "inter": stats[3], "type": "PBI"[h["type"]], "slice_qp": h["qp"],
+                 "bits_left": stats[4]}
+
+
+
 # ----------------------------------------------------------------------------------------------------------------- the decoder
 
 
 class H264Decoder:
     """Feed the NAL units of consecutive samples (decoding order); `decode_sample` returns the decoded Pic of that sample."""
 
-    def __init__(self, sps, pps):
+    def __init__(self, sps, pps, engine="native"):
+        if engine not in ("native", "python"):
+            raise ValueError(f"engine {engine!r}: 'native' (csrc/h264dec.hip) or 'python'")
+        self.engine = engine
         if sps["profile"] not in (66, 77):
             raise Unsupported(f"profile_idc {sps['profile']}: Baseline / Main only")
         if pps["constrained_intra"]:
@@ -385,7 +477,7 @@ class H264Decoder:
         nal = slices[0]
         h, r = self._header(nal)
         sps, pps = self.sps, self.pps
-        cur = Pic(sps, pps)
+        cur = (NativePic if self.engine == "native" else Pic)(sps, pps)
         cur.sample = sample
         cur.frame_num = h["frame_num"]
         # picture order count, type 0 (8.2.1.1)
@@ -406,7 +498,10 @@ class H264Decoder:
         for p in self.dpb:
             p.frame_num_wrap = p.frame_num - (1 << sps["log2_max_frame_num"]) if p.frame_num > cur.frame_num else p.frame_num
         lists = self._ref_lists(h, cur) if h["type"] != 2 else [[], []]
-        (_SliceDecoder if pps["cabac"] else _CavlcSliceDecoder)(self, h, r, cur, lists, payload_bits=h["n_bits"], payload=rbsp(nal)).run()
+        if self.engine == "native":
+            _decode_native(self, h, r, cur, lists, rbsp(nal))
+        else:
+            (_SliceDecoder if pps["cabac"] else _CavlcSliceDecoder)(self, h, r, cur, lists, payload_bits=h["n_bits"], payload=rbsp(nal)).run()
         self._mark(h, cur)
         return cur
 
@@ -1485,7 +1580,8 @@ class H264Reader:
     """Frames of an MP4's H.264 track in DISPLAY order. Sequential access decodes every picture once; a jump restarts at the key
     frame in front of the target (in decoding order) and decodes up to it."""
 
-    def __init__(self, path, cache=8):
+    def __init__(self, path, cache=8, engine="native"):
+        self.engine = engine
         self.track = path if isinstance(path, Mp4H264) else Mp4H264(path)
         self._dec = None
         self._next = 0      # next sample (decoding order) the decoder expects
@@ -1512,10 +1608,10 @@ class H264Reader:
             return self._cache[s]
         if self._dec is None or s < self._next:
             start = max(i for i in tr.sync if i <= s)
-            self._dec, self._next = H264Decoder(tr.sps, tr.pps), start
+            self._dec, self._next = H264Decoder(tr.sps, tr.pps, self.engine), start
         elif any(self._next <= i <= s for i in tr.sync):
             start = max(i for i in tr.sync if i <= s)  # a key frame lies between: skip ahead to it
-            self._dec, self._next = H264Decoder(tr.sps, tr.pps), start
+            self._dec, self._next = H264Decoder(tr.sps, tr.pps, self.engine), start
         while self._next <= s:
             i = self._next
             pic = self._dec.decode_sample(tr.nal_units(i), i)
@@ -1536,7 +1632,7 @@ if __name__ == "__main__":
 
     rd = H264Reader(sys.argv[1])
     n = int(sys.argv[2]) if len(sys.argv) > 2 else len(rd)
-    dec = H264Decoder(rd.track.sps, rd.track.pps)
+    dec = H264Decoder(rd.track.sps, rd.track.pps, sys.argv[3] if len(sys.argv) > 3 else "native")
     t0 = time.time()
     for i in range(n):
         p = dec.decode_sample(rd.track.nal_units(i), i)

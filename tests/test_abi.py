@@ -26,7 +26,7 @@ def test_all_declared_symbols_exported_and_bound(dtype):
         assert hasattr(h, n), f"{n} declared in sleap_amd.h but not exported"
         assert n in _lib.SIGNATURES, f"{n} has no ctypes signature"
     assert set(_lib.SIGNATURES) == set(names)
-    assert h.sa_abi_version() == 7
+    assert h.sa_abi_version() == 8
     assert h.sa_storage_dtype().decode() == dtype
 
 

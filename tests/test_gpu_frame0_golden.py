@@ -87,3 +87,32 @@ def test_top_down_models_on_the_real_frame_match_tensorflow():
     assert n == 2
     got = outs[0]["instance_peaks"][0, :n]
     np.testing.assert_allclose(got[match_instances(got, z["gt_points"])], z["gt_points"], atol=1.75)
+
+
+def test_bottomup_predictor_on_inter_coded_frames_of_the_mp4_matches_the_oracle():
+    """Frames 1-4 of the same file are B and P pictures (display order: samples 3, 2, 4, 1): read through `MediaVideo` (the
+    package's P / B decoder, tests/test_h264_inter.py), predicted by the device path, compared with the fp32 oracle on the same
+    decoded frames -- the whole chain mp4 -> frames -> network -> peaks -> grouping from the reference's default input format."""
+    from sleap_amd.io.video import Video, VideoReader
+    from sleap_amd.nn.inference import load_model
+    from test_frame0_golden import _oracle
+
+    predictor = load_model(MODEL, batch_size=4, progress_reporting="none")
+    video = Video.from_filename(MP4)
+    idx = [0, 1, 2, 3, 4]
+    outs = predictor.predict(VideoReader(video, example_indices=idx), make_labels=False)
+    got = {int(f): (o["instance_peaks"][k, :int(o["n_valid"][k])], o["instance_scores"][k, :int(o["n_valid"][k])])
+           for o in outs for k, f in enumerate(o["frame_ind"].tolist())}
+    assert sorted(got) == idx
+    worst = 0.0
+    for f in idx:
+        gray = video.get_frame(f)[..., 0]
+        want_pts, _, want_inst = _oracle(gray)
+        pts, inst = got[f]
+        assert len(pts) == len(want_pts) == 2, (f, len(pts), len(want_pts))  # two flies in every frame
+        order = match_instances(pts, want_pts)
+        assert sorted(order) == [0, 1]
+        d = np.linalg.norm(pts[order] - want_pts, axis=-1)
+        worst = max(worst, float(np.nanmax(d)))
+        assert np.nanmax(d) <= 0.1 and np.abs(inst[order] - want_inst).max() <= 2e-2, (f, d, inst, want_inst)
+    print(f"device vs fp32 oracle on display frames 0-4 of the mp4 (I, B, B, B, P pictures): max point distance {worst:.4f} px")

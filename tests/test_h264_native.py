@@ -1,0 +1,62 @@
+"""The native slice decoder (sleap_amd/csrc/h264dec.hip, `sa_h264_decode_slice`: what `MediaVideo` runs) against the Python
+decoder it restates (sleap_amd/io/_h264.py; its own pins: tests/test_h264_inter.py, tests/test_frame0_golden.py): the decoded
+planes AND the per-4x4 motion data (vectors, reference indices, intra map) must be equal picture by picture. Here the first
+pictures of the four reference files -- CABAC I / P / B with weighted prediction and a B pyramid, spatial and temporal direct
+(dance.mp4, samples 4 and 7), CAVLC I / P; the whole files (1100 + 1100 + 450 + 166 pictures): tools/h264_native_vs_python.py,
+profiles/r06_h264_native_vs_python.txt. Host code only: runs without a GPU."""
+import os
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+VID = os.path.join(ROOT, "tests", "golden", "video")
+
+
+@pytest.mark.parametrize("name,n", [("centered_pair_low_quality.mp4", 9), ("centered_pair_small.mp4", 6), ("dance.mp4", 8), ("small_robot.mp4", 6)])
+def test_native_decoder_equals_the_python_decoder(name, n):
+    from sleap_amd.io import _h264 as D
+    from sleap_amd.io import _h264_intra as H
+
+    tr = H.Mp4H264(os.path.join(VID, name))
+    a, b = D.H264Decoder(tr.sps, tr.pps, "native"), D.H264Decoder(tr.sps, tr.pps, "python")
+    kinds = []
+    for i in range(n):
+        pa, pb = a.decode_sample(tr.nal_units(i), i), b.decode_sample(tr.nal_units(i), i)
+        assert pa.stats == pb.stats, (i, pa.stats, pb.stats)
+        kinds.append(pa.stats["type"])
+        assert pa.Y.dtype == np.uint8
+        np.testing.assert_array_equal(pa.Y, pb.Y, err_msg=f"{name} sample {i} luma")
+        np.testing.assert_array_equal(pa.C[0], pb.C[0])
+        np.testing.assert_array_equal(pa.C[1], pb.C[1])
+        np.testing.assert_array_equal(pa.mv, pb.mv)
+        np.testing.assert_array_equal(pa.ref, pb.ref)
+        np.testing.assert_array_equal(pa.intra4.astype(bool), pb.intra4)
+        assert (pa.poc, pa.frame_num) == (pb.poc, pb.frame_num)
+    assert kinds[0] == "I" and "P" in kinds and (name == "small_robot.mp4" or "B" in kinds)
+
+
+def test_native_decoder_reports_a_corrupted_slice_instead_of_decoding_garbage():
+    from sleap_amd.io import _h264 as D
+    from sleap_amd.io import _h264_intra as H
+
+    tr = H.Mp4H264(os.path.join(VID, "centered_pair_low_quality.mp4"))
+    dec = D.H264Decoder(tr.sps, tr.pps, "native")
+    nals = [bytes(n) for n in tr.nal_units(0)]
+    k = max(range(len(nals)), key=lambda i: len(nals[i]))
+    broken = bytearray(nals[k])
+    for j in range(200, 260):  # flip bits in the middle of the slice data
+        broken[j] ^= 0x5A
+    nals[k] = bytes(broken)
+    # (garbage usually ends in "end_of_slice_flag is not at the last macroblock"; it may also name a tool such as I_PCM first)
+    with pytest.raises((AssertionError, NotImplementedError), match="sa_h264_decode_slice"):
+        dec.decode_sample(nals, 0)
+
+
+def test_media_video_runs_on_the_native_engine():
+    from sleap_amd.io.video import MediaVideo
+
+    v = MediaVideo(os.path.join(VID, "small_robot.mp4"))
+    assert v._reader.engine == "native"
+    f = v.get_frames(0, 12)
+    assert f.shape == (12, 320, 560, 3) and f.dtype == np.uint8 and 90 < float(f.mean()) < 130
