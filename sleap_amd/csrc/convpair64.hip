@@ -70,10 +70,10 @@ constexpr int IP_ROW = PW * 32, IP_PLANE = PH * IP_ROW;            // 1088, 1958
 constexpr int IN_ROW = QW * 32, IN_USED = QH * IN_ROW;             // 1152, 23040
 constexpr int N_INP = (IN_USED + 1023) / 1024, IN_PLANE = N_INP * 1024;  // 23, 23552
 constexpr int SLOT = 18 * 1024;
-constexpr int INTER_OFF = 0, IN_OFF = 4 * IP_PLANE, RING_OFF = IN_OFF + 2 * IN_PLANE, BIAS_OFF = RING_OFF + 2 * SLOT;
+[[maybe_unused]] constexpr int INTER_OFF = 0, IN_OFF = 4 * IP_PLANE, RING_OFF = IN_OFF + 2 * IN_PLANE, BIAS_OFF = RING_OFF + 2 * SLOT;
 constexpr int LDS_BYTES = BIAS_OFF + 128 * 4;
 static_assert(LDS_BYTES <= 160 * 1024, "one workgroup per CU: 160 KiB");
-constexpr unsigned OOB = 0xFFFFFF00u;
+[[maybe_unused]] constexpr unsigned OOB = 0xFFFFFF00u;
 
 // SA_PAIR64_STAMP (an instrumented A/B build, tools/pair64_probe.py -- never the product library): every wave sums the shader
 // cycles (s_memtime) of the segments of its tiles and adds them to g_stamp64 at its end: [0] waves, [1] tiles, [2] life,
@@ -224,7 +224,7 @@ convpair64_kernel(const Pair64Params p) {
       xoff[dx] = (unsigned)(xp.row * IN_ROW + c * 32 + ((half ^ ((c >> 3) & 1)) * 16));
     }
   }
-  const float low_a = p.relu_a ? 0.0f : -INFINITY, low_b = p.relu_b ? 0.0f : -INFINITY;
+  [[maybe_unused]] const float low_a = p.relu_a ? 0.0f : -INFINITY, low_b = p.relu_b ? 0.0f : -INFINITY;
   const unsigned pixb_out = p.planar ? 32u : 128u;
 
   // Waits are the BUILTIN s_waitcnt (vmcnt in bits 3:0, expcnt 7 and lgkmcnt 15 = "do not wait"), not inline asm: the compiler's
@@ -284,7 +284,6 @@ convpair64_kernel(const Pair64Params p) {
       __builtin_amdgcn_sched_barrier(0);
     }
   };
-  auto nothing = [](int) {};
   f32x16 accA[2][R], accX[XM];
   // Bias reads are OPAQUE ds_reads (inline asm) behind one explicit lgkmcnt(0): in front of a C++ load from LDS the compiler drains
   // vmcnt whenever it believes a copy in flight whose target it cannot tell from the load's address -- it cannot follow the
