@@ -1023,14 +1023,19 @@ def swscale_bgr(Y, Cb, Cr):
     centered_pair_low_quality.mp4 to the last printed digit (the rounding C-table form of swscale, `(76309 (Y - 16) + 32768)
     >> 16`, is 0.07 px off; tests/test_frame0_golden.py). The chroma coefficients (13-bit forms of 1.596 / 0.813 / 0.391 / 2.018)
     are not pinned by any reference golden."""
-    y = (Y.astype(np.int32) - 16) << 3
-    u = (np.repeat(np.repeat(Cb.astype(np.int32), 2, 0), 2, 1)[:Y.shape[0], :Y.shape[1]] - 128) << 3
-    v = (np.repeat(np.repeat(Cr.astype(np.int32), 2, 0), 2, 1)[:Y.shape[0], :Y.shape[1]] - 128) << 3
-    yy = (y * 9539) >> 16
-    b = yy + ((u * 16531) >> 16)
-    g = yy - ((u * 3203) >> 16) - ((v * 6660) >> 16)
-    r = yy + ((v * 13075) >> 16)
-    return np.stack([np.clip(b, 0, 255), np.clip(g, 0, 255), np.clip(r, 0, 255)], axis=-1).astype(np.uint8)
+    yy = _SWS_Y[Y]                                    # ((Y - 16) << 3) * 9539 >> 16 through a 256-entry table
+    if not (Cb != 128).any() and not (Cr != 128).any():  # grey stream: the three channels are the luma term
+        g8 = np.clip(yy, 0, 255).astype(np.uint8)
+        return np.stack([g8, g8, g8], axis=-1)
+    H, W = Y.shape
+    up = lambda t: np.repeat(np.repeat(t, 2, 0), 2, 1)[:H, :W]  # noqa: E731  (chroma replicated 2 x 2)
+    bu, gu, gv, rv = up(_SWS_BU[Cb]), up(_SWS_GU[Cb]), up(_SWS_GV[Cr]), up(_SWS_RV[Cr])
+    return np.stack([np.clip(yy + bu, 0, 255), np.clip(yy - gu - gv, 0, 255), np.clip(yy + rv, 0, 255)], axis=-1).astype(np.uint8)
+
+
+_SWS_Y = (((np.arange(256, dtype=np.int32) - 16) << 3) * 9539) >> 16
+_SWS_C = (np.arange(256, dtype=np.int32) - 128) << 3
+_SWS_BU, _SWS_GU, _SWS_GV, _SWS_RV = (_SWS_C * 16531) >> 16, (_SWS_C * 3203) >> 16, (_SWS_C * 6660) >> 16, (_SWS_C * 13075) >> 16
 
 
 if __name__ == "__main__":

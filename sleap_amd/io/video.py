@@ -257,7 +257,7 @@ class MediaVideo:
 
     EXTS = ("mp4", "mov", "m4v")
 
-    def __init__(self, filename: str, grayscale: Optional[bool] = None, bgr: bool = True):
+    def __init__(self, filename: str, grayscale: Optional[bool] = None, bgr: bool = True, workers: Optional[int] = None):
         from . import _h264, _h264_intra
 
         if not os.path.isfile(filename):
@@ -266,6 +266,16 @@ class MediaVideo:
         self.dataset, self.input_format = "", ""
         self._track = _h264_intra.Mp4H264(filename)
         self._reader = _h264.H264Reader(self._track)
+        # `workers` > 1: whole GOPs decoded ahead on threads (the native macroblock layer runs without the GIL); default = the
+        # CPU quota up to 8, 1 = the sequential reader only
+        if workers is None:
+            try:
+                workers = min(len(os.sched_getaffinity(0)), 8)
+            except AttributeError:
+                workers = 1
+        self._gops = _h264.GopPool(self._track, workers) if workers > 1 else None
+        if self._gops is not None and not self._gops.closed:
+            self._gops = None
         self._swscale = _h264_intra.swscale_bgr
         self._cache = {}
         self._lock = threading.Lock()  # (the decoder is a sequential state machine)
@@ -288,7 +298,7 @@ class MediaVideo:
                 if len(self._cache) >= 16:
                     self._cache.pop(next(iter(self._cache)))
                 try:
-                    y, cb, cr = self._reader.frame(idx)
+                    y, cb, cr = (self._gops or self._reader).frame(idx)
                 except IndexError as e:
                     raise KeyError(f"Unable to load frame {idx} from {self.filename}: the video has {len(self._track)} frames") from e
                 self._cache[idx] = self._swscale(y, cb, cr)

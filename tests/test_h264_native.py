@@ -60,3 +60,16 @@ def test_media_video_runs_on_the_native_engine():
     assert v._reader.engine == "native"
     f = v.get_frames(0, 12)
     assert f.shape == (12, 320, 560, 3) and f.dtype == np.uint8 and 90 < float(f.mean()) < 130
+
+
+def test_gop_parallel_reads_equal_sequential_reads_across_a_key_frame():
+    from sleap_amd.io.video import MediaVideo
+
+    path = os.path.join(VID, "centered_pair_low_quality.mp4")
+    seq, par = MediaVideo(path, workers=1), MediaVideo(path, workers=4)
+    assert seq._gops is None and par._gops is not None and par._gops.closed
+    a, b = seq.get_frames(140, 160), par.get_frames(140, 160)  # frames 140..149 end the first GOP, 150 is a key frame
+    np.testing.assert_array_equal(a, b)
+    np.testing.assert_array_equal(par.get_frame(3), seq.get_frame(3))  # backwards
+    with pytest.raises(KeyError, match="Unable to load frame 1100"):
+        par.get_frame(1100)
