@@ -24,6 +24,9 @@
 #include "bf16.h"
 #include "sa_common.h"
 
+#if !defined(SA_PAIR_SWZ2)
+#define SA_PAIR_SWZ2 1  // persistent pair kernel: conflict-free intermediate-tile stores (0: the round 1-5 swizzle, A/B)
+#endif
 namespace {
 
 using sa::h16x8_t;
@@ -351,13 +354,19 @@ convpair_persist_kernel(const PairParams p, int n_tiles) {
   // ds_write_b128 group always share their row, so this is as conflict-free as the pixel-index form, and a fragment offset
   // becomes (per-lane column part) + (compile-time row part) -- 3 + 6 + 2 offset registers instead of 9 + 24 + 2, which is what
   // lets everything tile-independent stay resident next to the 36 registers of conv-a's A fragments without spilling.
+  // Round 6: the intermediate tile's slot swizzle is ((column >> 2) + 2 ((column >> 1) & 1)) & 3 instead of (column >> 2) & 3. The
+  // reads do not care (a ds_read_b128 group's columns are 4 k apart: the added term is constant inside a group, the sum still runs
+  // through 0, 3, 1, 2); the WRITES of phase A do: a ds_write_b128 group is eight consecutive columns of one k-slot, 64 bytes apart
+  // = two 16-byte bank quads per column pair -- with the old swizzle columns c and c + 2 shared their quad (2-way on every
+  // store: 14 % of this kernel's LDS-active cycles were conflicts, profiles/r06_pmc_sq_counters.md), now the eight are distinct.
+  auto iswz = [](int c) { return SA_PAIR_SWZ2 ? (((c >> 2) + ((c >> 1) & 1) * 2) & 3) : ((c >> 2) & 3); };
   // phase B fragment offsets of halo row wave*2, columns lx + dx, both k-steps (row rr adds rr * PW * 64)
   unsigned boff[3][2];
 #pragma unroll
   for (int dx = 0; dx < 3; ++dx)
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
-      boff[dx][kk] = (unsigned)(((wave * R) * PW + lx + dx) * 64 + (((2 * kk + half) ^ (((lx + dx) >> 2) & 3)) * 16));
+      boff[dx][kk] = (unsigned)(((wave * R) * PW + lx + dx) * 64 + (((2 * kk + half) ^ iswz(lx + dx)) * 16));
       asm volatile("" : "+v"(boff[dx][kk]));
     }
   const float low_a = p.relu_a ? 0.0f : -INFINITY, low_b = p.relu_b ? 0.0f : -INFINITY;
@@ -434,7 +443,7 @@ convpair_persist_kernel(const PairParams p, int n_tiles) {
 #pragma unroll
     for (int dx = 0; dx < 3; ++dx) roff[dx] = (unsigned)((wave * QW + lx + dx) * 32 + ((half ^ (((lx + dx) >> 3) & 1)) * 16));
 #pragma unroll
-    for (int pr = 0; pr < 2; ++pr) woff[pr] = (unsigned)((wave * PW + lx) * 64 + (((2 * pr + half) ^ ((lx >> 2) & 3)) * 16));
+    for (int pr = 0; pr < 2; ++pr) woff[pr] = (unsigned)((wave * PW + lx) * 64 + (((2 * pr + half) ^ iswz(lx)) * 16));
     const bool colok = (unsigned)(t.x0 + lx - 1) < (unsigned)W;
 #pragma unroll
     for (int it = 0; it < 3; ++it) {
@@ -452,7 +461,7 @@ convpair_persist_kernel(const PairParams p, int n_tiles) {
 #pragma unroll
       for (int dx = 0; dx < 3; ++dx) rd[dx] = (unsigned)((ty2 * QW + tx2 + dx) * 32 + ((half ^ (((tx2 + dx) >> 3) & 1)) * 16));
 #pragma unroll
-      for (int pr = 0; pr < 2; ++pr) wr[pr] = (unsigned)((ty2 * PW + tx2) * 64 + (((2 * pr + half) ^ ((tx2 >> 2) & 3)) * 16));
+      for (int pr = 0; pr < 2; ++pr) wr[pr] = (unsigned)((ty2 * PW + tx2) * 64 + (((2 * pr + half) ^ iswz(tx2)) * 16));
       const bool in_img = (unsigned)(t.y0 + ty2 - 1) < (unsigned)H && (unsigned)(t.x0 + tx2 - 1) < (unsigned)W;
       group(rd, 0, wr, 0, masked_c, in_img, valid2, 4 * half);
     }

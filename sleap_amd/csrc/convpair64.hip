@@ -46,6 +46,9 @@
 #define SA_PAIR64_ITAP 1
 #endif
 
+#if !defined(SA_PAIR64_SWZ2)
+#define SA_PAIR64_SWZ2 1  // conflict-free stores of the intermediate planes (0: the first form, A/B)
+#endif
 namespace {
 
 using sa::mfma_h8;
@@ -193,12 +196,18 @@ convpair64_kernel(const Pair64Params p) {
   };
 
   // ---- tile-independent per-lane LDS offsets. Swizzles depend on the tile COLUMN only, so a row is a compile-time stride.
+  // Slot swizzle of the INTERMEDIATE planes (round 6, after the first profile set): ((c >> 2) ^ (c >> 3)) & 1 instead of the input
+  // planes' (c >> 3) & 1. A ds_write_b128 group is eight consecutive columns of 32 bytes: with one slot for all eight, columns c and
+  // c + 4 fall on the same 16-byte bank quad (2-way on every store of conv-a's output: 12 % of this kernel's LDS-active cycles);
+  // flipping the slot every four columns makes the eight distinct, and the ds_read_b128 groups of conv-b (columns {0-3, 12-15,
+  // 20-27} + dx and their complement) stay conflict-free -- the sixteen period-16 swizzles with both properties were enumerated.
+  auto ipswz = [](int c) { return SA_PAIR64_SWZ2 ? (((c >> 2) ^ (c >> 3)) & 1) : ((c >> 3) & 1); };
   unsigned aoff[3], boff[3];  // conv-a reads (input plane, halo row 2 * wave, column lx + dx); conv-b reads (intermediate plane)
 #pragma unroll
   for (int dx = 0; dx < 3; ++dx) {
     const int c = lx + dx;
     aoff[dx] = (unsigned)(R * wave * IN_ROW + c * 32 + ((half ^ ((c >> 3) & 1)) * 16));
-    boff[dx] = (unsigned)(R * wave * IP_ROW + c * 32 + ((half ^ ((c >> 3) & 1)) * 16));
+    boff[dx] = (unsigned)(R * wave * IP_ROW + c * 32 + ((half ^ ipswz(c)) * 16));
   }
   // the extra unit of this wave: pixel group xg = 16 + (wave >> 1) -- 16, 17: halo rows 16, 17, columns lx; 18, 19: the 36 pixels of
   // columns 32, 33 (pixel q = 32 (xg - 18) + lx -> row q >> 1, column 32 + (q & 1)) -- x cout tile wave & 1
@@ -521,7 +530,7 @@ convpair64_kernel(const Pair64Params p) {
       int ln = lane;  // (re-derived per tile: see make_voff)
       asm volatile("" : "+v"(ln));
       const int hf = ln >> 5, lxe = ln & 31;
-      const unsigned woff = (unsigned)(R * wave * IP_ROW + lxe * 32 + ((hf ^ ((lxe >> 3) & 1)) * 16));  // row R wave, column lx
+      const unsigned woff = (unsigned)(R * wave * IP_ROW + lxe * 32 + ((hf ^ ipswz(lxe)) * 16));  // row R wave, column lx
       const bool colok = (unsigned)(cur.x0 + lxe - 1) < (unsigned)W;
 #pragma unroll
       for (int r = 0; r < R; ++r) {
@@ -532,7 +541,7 @@ convpair64_kernel(const Pair64Params p) {
       }
       {
         const XPix xp = xpix(lxe);
-        const unsigned xwoff = (unsigned)(xp.row * IP_ROW + xp.col * 32 + ((hf ^ ((xp.col >> 3) & 1)) * 16));
+        const unsigned xwoff = (unsigned)(xp.row * IP_ROW + xp.col * 32 + ((hf ^ ipswz(xp.col)) * 16));
         const bool in_img = (unsigned)(cur.y0 + xp.row - 1) < (unsigned)H && (unsigned)(cur.x0 + xp.col - 1) < (unsigned)W;
 #pragma unroll
         for (int xm = 0; xm < XM; ++xm) put(accX[xm], in_img ? 0xFFFFFFFFu : 0u, xp.valid, smem + INTER_OFF + xwoff, XM == 1 ? m_x : xm);
