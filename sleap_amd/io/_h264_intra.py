@@ -5,9 +5,12 @@ Why it exists: neither the build container nor the GPU box has ANY H.264 decoder
 ffmpeg, GStreamer, VA-API, rocDecode), the reference's default input format is H.264 in MP4 (`MediaVideo`,
 sleap/io/video.py:340-504), and the only TensorFlow-produced end-to-end golden the reference holds --
 tests/data/models/minimal_instance.UNet.bottomup/labels_pr.val.slp -- was predicted on frame 0 of
-tests/data/json_format_v1/centered_pair_low_quality.mp4. With this module `sleap_amd.io.video.MediaVideo` reads the key frames
-of such a file (frame 0 and every sync sample; inter-coded frames raise), which is what the golden test needs
-(tests/test_frame0_golden.py: the fp32 oracle reproduces the TensorFlow result on the decoded frame to 1e-4 px).
+tests/data/json_format_v1/centered_pair_low_quality.mp4. This module decodes the key frames of such a file (frame 0 and every
+sync sample), which is what the golden test needs (tests/test_frame0_golden.py: the fp32 oracle reproduces the TensorFlow
+result on the decoded frame to 1e-4 px); `decode_intra` refuses everything else. P and B pictures, CAVLC and the native
+engine that `sleap_amd.io.video.MediaVideo` runs came later in the round and live in io/_h264.py / csrc/h264dec.hip, which
+reuse this module's bit reader, MP4 tables, CABAC engine, prediction and transform routines and must reproduce its planes on
+key frames bit for bit.
 
 What it implements of the standard (clause numbers of ITU-T H.264): the MP4 sample tables, NAL unit extraction, SPS / PPS /
 slice header parsing (7.3), the CABAC engine and the syntax elements of I slices (9.3: mb_type, prev/rem_intra4x4_pred_mode,
