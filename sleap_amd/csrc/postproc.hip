@@ -17,6 +17,9 @@
 #include "lsa.h"
 #include "sa_common.h"
 
+#if !defined(SA_POSTPROC_PAR)
+#define SA_POSTPROC_PAR 1  // round 6: the fused post-processing kernel's memory-latency chains taken apart (0: the round 2-5 form, A/B)
+#endif
 namespace {
 
 constexpr int MAXNP = 512;  // cap on max_node_peaks (peaks of one node type per frame); bounds table sizes only
@@ -193,7 +196,8 @@ __device__ void frame_sort_refine(int b, uint32_t* sk, const float* __restrict__
                                   int W, int C, int mode, int k, float xy_scale, int max_peaks,
                                   const uint32_t* __restrict__ keys, int32_t* __restrict__ counts,
                                   float* __restrict__ peak_xy, float* __restrict__ peak_val,
-                                  int32_t* __restrict__ peak_chan, int32_t* __restrict__ scan_counts = nullptr) {
+                                  int32_t* __restrict__ peak_chan, int32_t* __restrict__ scan_counts = nullptr,
+                                  float* samp = nullptr, int samp_words = 0) {
   // `scan_counts` (optional): the NMS scan's atomic counters when they are not `counts` itself; they are handed back ZEROED
   // for the next call (no memset launch in front of the scan)
   const int tid = threadIdx.x, nt = blockDim.x;
@@ -221,6 +225,51 @@ __device__ void frame_sort_refine(int b, uint32_t* sk, const float* __restrict__
   const size_t plane = (size_t)H * W * C;
   const float* img = cms + (size_t)b * plane;
   const float* off = offsets ? offsets + (size_t)b * plane * 2 : nullptr;
+  if (mode == SA_REFINE_INTEGRAL && samp && samp_words >= k * k) {
+    // Round 6 (this kernel at small batches is a chain of memory latencies, not work): the k x k bilinear
+    // samples of every peak are independent -- (peak, i, j) work items spread over the workgroup fetch them at once into LDS,
+    // then one thread per peak adds them up IN THE REFERENCE'S ORDER (row-major, one fp32 add at a time: the same bits as the
+    // serial loop of refine_offset, whose 25 dependent round trips to memory were the longest stage of the kernel).
+    const int kk = k * k, chunk = min(samp_words / kk, max(n, 1));
+    const float half = (float)(k - 1) * 0.5f;
+    for (int base = 0; base < n; base += chunk) {
+      const int m = min(chunk, n - base);
+      for (int t = tid; t < m * kk; t += nt) {
+        const int pi = t / kk, r = t - pi * kk, i = r / k, j = r - i * k;
+        const uint32_t e = sk[base + pi];
+        const int c = (int)(e % C);
+        const uint32_t p = e / C;
+        const int x = (int)(p % W), y = (int)(p / W);
+        const CropAxis ay = crop_axis(y, k, i, H), ax = crop_axis(x, k, j, W);
+        samp[t] = crop_sample(img, W, C, c, ay, ax);
+      }
+      __syncthreads();
+      for (int pi = tid; pi < m; pi += nt) {
+        const uint32_t e = sk[base + pi];
+        const int c = (int)(e % C);
+        const uint32_t p = e / C;
+        const int x = (int)(p % W), y = (int)(p / W);
+        float z = 0.0f, sx = 0.0f, sy = 0.0f;
+        for (int i = 0; i < k; ++i) {
+          const float gy = __fsub_rn((float)i, half);
+          for (int j = 0; j < k; ++j) {
+            const float pv = samp[pi * kk + i * k + j];
+            const float gx = __fsub_rn((float)j, half);
+            z = __fadd_rn(z, pv);
+            sx = __fadd_rn(sx, __fmul_rn(gx, pv));
+            sy = __fadd_rn(sy, __fmul_rn(gy, pv));
+          }
+        }
+        const float dx = __fdiv_rn(sx, z), dy = __fdiv_rn(sy, z);
+        const size_t o = (size_t)b * max_peaks + base + pi;
+        peak_xy[o * 2 + 0] = __fmul_rn(__fadd_rn((float)x, dx), xy_scale);
+        peak_xy[o * 2 + 1] = __fmul_rn(__fadd_rn((float)y, dy), xy_scale);
+        peak_val[o] = img[e];
+        peak_chan[o] = c;
+      }
+      __syncthreads();
+    }
+  } else
   for (int i = tid; i < n; i += nt) {
     const uint32_t e = sk[i];
     const int c = (int)(e % C);
@@ -520,7 +569,7 @@ __device__ void frame_score(int b, unsigned char* smem_raw, const float* __restr
                             const int32_t* __restrict__ edges, int N, int n_points, float pafs_stride,
                             float max_edge_length, float dist_penalty_weight, int NP,
                             int32_t* __restrict__ node_count, int32_t* __restrict__ node_peaks,
-                            float* __restrict__ line_scores, int32_t* __restrict__ status) {
+                            float* __restrict__ line_scores, int32_t* __restrict__ status, int s_ch_words = 0) {
 
   int32_t* s_cnt = reinterpret_cast<int32_t*>(smem_raw);  // [N]
   int32_t* s_list = s_cnt + N;                            // [N][NP]
@@ -529,11 +578,17 @@ __device__ void frame_score(int b, unsigned char* smem_raw, const float* __restr
   const int32_t* ch = peak_chan + (size_t)b * max_peaks;
   const float* xy = peak_xy + (size_t)b * max_peaks * 2;
   for (int i = tid; i < N; i += nt) s_cnt[i] = 0;
+  // (round 6) the frame's peak channels once into LDS: the rank loop below read ch[0 .. i) from global memory per thread
+  int32_t* s_ch = s_ch_words > 0 ? s_cnt + N + N * NP + E + 1 : nullptr;
+  const bool ch_lds = s_ch && n <= s_ch_words;
+  if (ch_lds)
+    for (int i = tid; i < n; i += nt) s_ch[i] = ch[i];
   __syncthreads();
+  const int32_t* chr = ch_lds ? s_ch : ch;
   for (int i = tid; i < n; i += nt) {
-    const int c = ch[i];
+    const int c = chr[i];
     int rank = 0;
-    for (int j = 0; j < i; ++j) rank += (ch[j] == c);
+    for (int j = 0; j < i; ++j) rank += (chr[j] == c);
     if (rank < NP)
       s_list[c * NP + rank] = i;
     else
@@ -577,6 +632,25 @@ __device__ void frame_score(int b, unsigned char* smem_raw, const float* __restr
     const float sx = xy[2 * ps], sy = xy[2 * ps + 1], ex = xy[2 * pd], ey = xy[2 * pd + 1];
     const LineDir ld = line_dir(sx, sy, ex, ey, n_points);
     float acc = 0.0f;
+    if (SA_POSTPROC_PAR && n_points == 10) {
+      // (round 6) the reference's default count with a compile-time trip count: the ten gathers are independent and go out
+      // together; the sum stays one fp32 add at a time in the line's order
+      float fxs[10], fys[10];
+#pragma unroll
+      for (int i = 0; i < 10; ++i) {
+        float px, py;
+        line_point(ld, sx, sy, ex, ey, i, 10, px, py);
+        const float rx = rintf(__fdiv_rn(px, pafs_stride)), ry = rintf(__fdiv_rn(py, pafs_stride));
+        const bool in = rx >= 0.0f && rx < (float)Wp && ry >= 0.0f && ry < (float)Hp;
+        const float* q = paf + ((size_t)(in ? (int)ry : 0) * Wp + (in ? (int)rx : 0)) * PC + 2 * k;
+        const float2 v = *reinterpret_cast<const float2*>(q);
+        fxs[i] = in ? v.x : 0.0f;
+        fys[i] = in ? v.y : 0.0f;
+        oob = oob || !in;
+      }
+#pragma unroll
+      for (int i = 0; i < 10; ++i) acc = __fadd_rn(acc, line_dot(ld, fxs[i], fys[i]));
+    } else
     for (int i = 0; i < n_points; ++i) {
       float px, py;
       line_point(ld, sx, sy, ex, ey, i, n_points, px, py);
@@ -1132,6 +1206,7 @@ struct FusedIn {
   float* line_scores;
   int32_t* match_dst;
   float* match_score;
+  int sort_words, samp_words, ch_words;  // LDS behind the sort keys (sample buffer of the refinement) / behind the scoring tables
 };
 
 __global__ void __launch_bounds__(1024)
@@ -1139,10 +1214,12 @@ bottomup_postproc_kernel(const FusedIn f, const GroupIn g) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int b = blockIdx.x;
   frame_sort_refine(b, reinterpret_cast<uint32_t*>(smem_raw), f.cms, f.offsets, f.H, f.W, f.C, f.mode, f.patch, f.xy_scale,
-                    f.max_peaks, f.keys, f.peak_count, f.peak_xy, f.peak_val, f.peak_chan, f.scan_counts);
+                    f.max_peaks, f.keys, f.peak_count, f.peak_xy, f.peak_val, f.peak_chan, f.scan_counts,
+                    reinterpret_cast<float*>(smem_raw) + f.sort_words, f.samp_words);
   __syncthreads();  // (workgroup-scope release/acquire of the global tables written above)
   frame_score(b, smem_raw, f.pafs, f.Hp, f.Wp, g.E, f.peak_xy, f.peak_chan, f.peak_count, f.max_peaks, g.edges, g.N, f.n_points,
-              f.pafs_stride, f.max_edge_length, f.dist_penalty_weight, g.NP, f.node_count, f.node_peaks, f.line_scores, g.status);
+              f.pafs_stride, f.max_edge_length, f.dist_penalty_weight, g.NP, f.node_count, f.node_peaks, f.line_scores, g.status,
+              f.ch_words);
   frame_group_fill(g, b);
   __syncthreads();
   const int wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
@@ -1492,8 +1569,13 @@ int sa_bottomup_postproc(const float* cms, const float* offsets, int B, int H, i
   int n_waves = 4;
   if (B <= 16) n_waves = E < 4 ? 4 : (E > 16 ? 16 : E);
   while (n_waves > 4 && (size_t)n_waves * match_lds_bytes(max_node_peaks) > 60 * 1024) --n_waves;
-  size_t lds = (size_t)n2 * sizeof(uint32_t);
-  const size_t l2 = score_lds_bytes(N, max_node_peaks, E), l3 = (size_t)n_waves * match_lds_bytes(max_node_peaks),
+  // (round 6) + a sample buffer for the parallel integral refinement (256 peaks x k x k floats at a time, fewer if k is large) and
+  // the frame's peak channels behind the scoring tables
+  const int kk = patch_size > 0 ? patch_size * patch_size : 1;
+  const int samp_words = (SA_POSTPROC_PAR && refinement == SA_REFINE_INTEGRAL && kk <= 8192) ? (256 * kk < 8192 ? 256 * kk : 8192) : 0;
+  const int ch_words = SA_POSTPROC_PAR ? max_peaks : 0;
+  size_t lds = (size_t)n2 * sizeof(uint32_t) + (size_t)samp_words * sizeof(float);
+  const size_t l2 = score_lds_bytes(N, max_node_peaks, E) + (size_t)ch_words * sizeof(int32_t), l3 = (size_t)n_waves * match_lds_bytes(max_node_peaks),
                l4 = group_lds_bytes(N, max_node_peaks, max_instances, E);
   lds = lds > l2 ? lds : l2;
   lds = lds > l3 ? lds : l3;
@@ -1507,6 +1589,7 @@ int sa_bottomup_postproc(const float* cms, const float* offsets, int B, int H, i
     f.peak_chan = peak_chan, f.pafs = pafs, f.Hp = Hp, f.Wp = Wp, f.n_points = n_points, f.pafs_stride = pafs_stride;
     f.max_edge_length = max_edge_length, f.dist_penalty_weight = dist_penalty_weight, f.node_count = node_count;
     f.node_peaks = node_peaks, f.line_scores = line_scores, f.match_dst = match_dst, f.match_score = match_score;
+    f.sort_words = n2, f.samp_words = samp_words, f.ch_words = ch_words;
     hipLaunchKernelGGL(bottomup_postproc_kernel, dim3(B), dim3(64 * n_waves), lds, st, f, g);
     SA_LAUNCH_CHECK();
     return SA_OK;
