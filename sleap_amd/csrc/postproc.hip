@@ -20,6 +20,9 @@
 #if !defined(SA_POSTPROC_PAR)
 #define SA_POSTPROC_PAR 1  // round 6: the fused post-processing kernel's memory-latency chains taken apart (0: the round 2-5 form, A/B)
 #endif
+#if !defined(SA_NMS_ILP_DEFAULT)
+#define SA_NMS_ILP_DEFAULT 1
+#endif
 namespace {
 
 constexpr int MAXNP = 512;  // cap on max_node_peaks (peaks of one node type per frame); bounds table sizes only
@@ -60,6 +63,7 @@ __device__ __forceinline__ void nms_emit(uint32_t e, int b, int max_peaks, uint3
 
 // One pass over the confidence maps: threshold test on coalesced float4 loads, the (rare)
 // survivors do the 8-neighbour test and append their flat (y,x,c) key to the frame's list.
+template <int ILP>
 __global__ void __launch_bounds__(256)
 nms_scan_kernel(const float* __restrict__ cms, int H, int W, int C, float thr, int max_peaks,
                 uint32_t* __restrict__ keys, int32_t* __restrict__ counts,
@@ -71,8 +75,21 @@ nms_scan_kernel(const float* __restrict__ cms, int H, int W, int C, float thr, i
   if (vec4) {
     const size_t n4 = plane / 4;
     const float4* img4 = reinterpret_cast<const float4*>(img);
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
-      const float4 q = img4[i];
+    // ILP 16-byte loads per thread are requested before the first is looked at (a workgroup's ILP x 256 loads are ILP coalesced
+    // 4-KiB rows): with one load per thread and iteration the launch moved 2.6 TB/s alone -- wave launch and one round trip per
+    // 16 bytes, not bandwidth
+    for (size_t i0 = (size_t)blockIdx.x * blockDim.x * ILP + threadIdx.x; i0 < n4; i0 += stride * ILP) {
+      float4 qs[ILP];
+#pragma unroll
+      for (int u = 0; u < ILP; ++u) {
+        const size_t iu = i0 + (size_t)u * blockDim.x;
+        qs[u] = iu < n4 ? img4[iu] : make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+      }
+#pragma unroll
+      for (int u = 0; u < ILP; ++u) {
+      const size_t i = i0 + (size_t)u * blockDim.x;
+      if (i >= n4) continue;
+      const float4 q = qs[u];
       // inf - inf and NaN - NaN are NaN: one test for "any of the four is not finite"
       const float qs = __fadd_rn(__fadd_rn(q.x, q.y), __fadd_rn(q.z, q.w));
       if (__fsub_rn(qs, qs) != 0.0f) atomicOr(&status[b], SA_STATUS_NONFINITE);
@@ -87,6 +104,7 @@ nms_scan_kernel(const float* __restrict__ cms, int H, int W, int C, float thr, i
         const size_t p = e / C;
         const int x = (int)(p % W), y = (int)(p / W);
         if (nms_is_peak(img, H, W, C, y, x, c, v)) nms_emit((uint32_t)e, b, max_peaks, keys, counts, status);
+      }
       }
     }
   } else {
@@ -1236,6 +1254,27 @@ bottomup_postproc_kernel(const FusedIn f, const GroupIn g) {
 
 }  // namespace
 
+// the scan's launch: ILP loads per thread (SA_NMS_ILP = 1 / 2 / 4 / 8 at run time for A/B; default below), at most SA_NMS_GX
+// workgroups per frame
+static void launch_nms_scan(hipStream_t st, const float* cms, int B, int H, int W, int C, float threshold, int max_peaks, uint32_t* keys,
+                            int32_t* counts, int32_t* status) {
+  static const int ilp = getenv("SA_NMS_ILP") ? atoi(getenv("SA_NMS_ILP")) : SA_NMS_ILP_DEFAULT;
+  static const int gx_cap = getenv("SA_NMS_GX") ? atoi(getenv("SA_NMS_GX")) : 2048;
+  const size_t plane = (size_t)H * W * C;
+  const int vec4 = (plane % 4 == 0) && (((uintptr_t)cms) % 16 == 0);
+  const size_t work = vec4 ? plane / 4 : plane;
+  const int per = 256 * (vec4 ? ilp : 1);
+  int gx = (int)((work + per - 1) / per);
+  if (gx > gx_cap) gx = gx_cap;
+  if (gx < 1) gx = 1;
+#define SA_SCAN(I) hipLaunchKernelGGL(nms_scan_kernel<I>, dim3(gx, B), dim3(256), 0, st, cms, H, W, C, threshold, max_peaks, keys, counts, status, vec4)
+  if (ilp >= 8) SA_SCAN(8);
+  else if (ilp >= 4) SA_SCAN(4);
+  else if (ilp >= 2) SA_SCAN(2);
+  else SA_SCAN(1);
+#undef SA_SCAN
+}
+
 // ------------------------------------------------------------------------------------------------
 // C ABI
 // ------------------------------------------------------------------------------------------------
@@ -1281,13 +1320,7 @@ int sa_find_local_peaks(const float* cms, const float* offsets, int B, int H, in
   hipStream_t st = (hipStream_t)stream;
   uint32_t* keys = (uint32_t*)workspace;
   SA_HIP_CHECK(hipMemsetAsync(peak_count, 0, sizeof(int32_t) * B, st));
-  const size_t plane = (size_t)H * W * C;
-  const int vec4 = (plane % 4 == 0) && (((uintptr_t)cms) % 16 == 0);
-  const size_t work = vec4 ? plane / 4 : plane;
-  int gx = (int)((work + 255) / 256);
-  if (gx > 2048) gx = 2048;
-  hipLaunchKernelGGL(nms_scan_kernel, dim3(gx, B), dim3(256), 0, st, cms, H, W, C, threshold, max_peaks,
-                     keys, peak_count, status, vec4);
+  launch_nms_scan(st, cms, B, H, W, C, threshold, max_peaks, keys, peak_count, status);
   SA_LAUNCH_CHECK();
   int n2 = 1;
   while (n2 < max_peaks) n2 <<= 1;
@@ -1306,12 +1339,7 @@ int sa_find_local_peaks_rough(const float* cms, int B, int H, int W, int C, floa
   SA_REQUIRE(max_peaks > 0 && max_peaks <= 16384, "sa_find_local_peaks_rough: max_peaks %d out of range", max_peaks);
   hipStream_t st = (hipStream_t)stream;
   SA_HIP_CHECK(hipMemsetAsync(peak_count, 0, sizeof(int32_t) * B, st));
-  const size_t plane = (size_t)H * W * C;
-  const int vec4 = (plane % 4 == 0) && (((uintptr_t)cms) % 16 == 0);
-  const size_t work = vec4 ? plane / 4 : plane;
-  int gx = (int)((work + 255) / 256);
-  if (gx > 2048) gx = 2048;
-  hipLaunchKernelGGL(nms_scan_kernel, dim3(gx, B), dim3(256), 0, st, cms, H, W, C, threshold, max_peaks, keys, peak_count, status, vec4);
+  launch_nms_scan(st, cms, B, H, W, C, threshold, max_peaks, keys, peak_count, status);
   SA_LAUNCH_CHECK();
   return SA_OK;
 }
@@ -1548,13 +1576,7 @@ int sa_bottomup_postproc(const float* cms, const float* offsets, int B, int H, i
   uint32_t* keys = (uint32_t*)((unsigned char*)workspace + pp_counts_bytes(B));
   unsigned char* paf_ws = (unsigned char*)keys + pp_keys_bytes(B, max_peaks);
   const size_t paf_ws_bytes = sa_paf_workspace(B, E, N, max_node_peaks);
-  const size_t plane = (size_t)H * W * C;
-  const int vec4 = (plane % 4 == 0) && (((uintptr_t)cms) % 16 == 0);
-  const size_t work = vec4 ? plane / 4 : plane;
-  int gx = (int)((work + 255) / 256);
-  if (gx > 2048) gx = 2048;
-  hipLaunchKernelGGL(nms_scan_kernel, dim3(gx, B), dim3(256), 0, st, cms, H, W, C, threshold, max_peaks, keys, scan_counts, status,
-                     vec4);
+  launch_nms_scan(st, cms, B, H, W, C, threshold, max_peaks, keys, scan_counts, status);
   SA_LAUNCH_CHECK();
   int n2 = 1;
   while (n2 < max_peaks) n2 <<= 1;
