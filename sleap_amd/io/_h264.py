@@ -1024,13 +1024,10 @@ class _SliceDecoder:
                         refs[(lst, g)] = rf
                         self.pic.ref[lst, Y4 + gy:Y4 + gy + gh, X4 + gx:X4 + gx + gw] = rf
             # mvd_l0 of every partition, then mvd_l1; the prediction sees the partitions derived before it in THIS list's pass
-            direct_mask = pic.direct[Y4:Y4 + 4, X4:X4 + 4].copy()
             for lst in (0, 1):
                 mb_done[:] = False
-                if inter == "8x8":
-                    # direct quadrants count as derived (their motion data exists before any mvd is parsed); the standard's order of
-                    # availability inside the macroblock is the quadrant order, so a direct quadrant q only serves quadrants > q
-                    pass
+                # (8x8: direct quadrants count as derived -- their motion data exists before any mvd is parsed; availability inside
+                #  the macroblock follows the quadrant order, so a direct quadrant q only serves quadrants > q)
                 qdone = -1
                 for (sx, sy, w, hh, pr, shape, pi, g) in plist:
                     if inter == "8x8":
@@ -1054,7 +1051,6 @@ class _SliceDecoder:
                     if subs[q][0] == "direct":
                         qx, qy = (q & 1) * 2, (q >> 1) * 2
                         parts += [(qx, qy, 2, 2)] if self.sps["direct_8x8_inference"] else [(qx + i, qy + j, 1, 1) for j in range(2) for i in range(2)]
-            assert (pic.direct[Y4:Y4 + 4, X4:X4 + 4] == direct_mask).all()
         pic.mbs[addr] = m
         self._predict_inter(mx, my, parts)
         # ---- coded_block_pattern, mb_qp_delta, residual
