@@ -1631,19 +1631,22 @@ class GopPool:
     throughput (`MediaVideo` with `workers` > 1). Falls back to None (-> the sequential `H264Reader`) for files whose GOPs are not
     closed in display order."""
 
-    def __init__(self, track, workers=4, engine="native", keep=None):
+    def __init__(self, track, workers=4, engine="native", keep=None, budget_bytes=2 << 30):
         from concurrent.futures import ThreadPoolExecutor
 
-        self.track, self.engine, self.workers = track, engine, max(int(workers), 1)
+        self.track, self.engine = track, engine
         n = len(track)
         self.starts = sorted(track.sync)
         self.ends = self.starts[1:] + [n]
+        # decoded GOPs are held whole: no more of them in flight than `budget_bytes` of planes (long GOPs of large pictures)
+        gop_bytes = max((b - a for a, b in zip(self.starts, self.ends)), default=1) * track.sps["mb_w"] * track.sps["mb_h"] * 384
+        self.workers = max(1, min(int(workers), budget_bytes // max(gop_bytes * 2, 1)))
         rank = {s: k for k, s in enumerate(track.display_order)}
         self.closed = bool(self.starts) and self.starts[0] == 0 and all(
             sorted(rank[i] for i in range(a, b)) == list(range(a, b)) for a, b in zip(self.starts, self.ends))
         self._pool = ThreadPoolExecutor(max_workers=self.workers) if self.closed else None
         self._futures = {}          # GOP index -> future of {display index: (Y, Cb, Cr)}
-        self._keep = keep or self.workers + 2
+        self._keep = keep or self.workers + 1
         self._cl = track.sps["crop"]
 
     def _decode(self, g):
