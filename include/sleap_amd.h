@@ -672,7 +672,7 @@ int sa_bottomup_predict(const sa_network_t* net, const sa_bottomup_params* param
  * whose pure-Python slice decoder is this function's checker: tests/test_h264_native.py, bit-exact picture by picture); this
  * entry decodes the macroblocks of one slice = one picture: entropy decoding (CABAC with cabac_init_idc 0, or CAVLC), intra and
  * inter prediction (P_Skip, spatial / temporal direct, weighted prediction), residual reconstruction, the in-loop edge filter.
- * Progressive Baseline / Main profile; returns SA_ERR_INVALID_ARG with the reason for anything else or for a slice whose
+ * Progressive Baseline / Main / High (8-bit 4:2:0, flat scaling matrices) profile; returns SA_ERR_INVALID_ARG with the reason for anything else or for a slice whose
  * entropy decode does not end exactly on the last macroblock. */
 typedef struct sa_h264_pic {   /* buffers of one picture, all HOST memory owned by the caller */
   uint8_t *y, *cb, *cr;        /* [16 mb_h][16 mb_w], [8 mb_h][8 mb_w] x 2 */
@@ -694,10 +694,13 @@ typedef struct sa_h264_slice {
   int32_t luma_log2_denom, chroma_log2_denom;
   int32_t weights[2][32][3][2];            /* explicit mode: [list][refIdx][Y, Cb, Cr][weight, offset] */
   int32_t data_bit_offset;                 /* first bit of slice_data() in `rbsp` (behind cabac_alignment_one_bit) */
+  int32_t transform_8x8_mode;              /* PPS transform_8x8_mode_flag (High profile) */
+  int32_t chroma_qp_offset_cr;             /* second_chroma_qp_index_offset (= chroma_qp_offset when the PPS has none) */
 } sa_h264_slice;
 /* rbsp: the slice NAL unit's payload without header byte and emulation prevention bytes; list0 / list1: nref[] entries each
  * (an entry with y == NULL is "no reference picture"); cur: written completely (planes and motion data); stats (8 ints or
- * NULL): Intra4x4, Intra16x16, skipped and inter macroblock counts, bits left at the end of the slice data. */
+ * NULL): Intra4x4, Intra16x16, skipped and inter macroblock counts, bits left at the end of the slice data, Intra8x8 and 8x8-
+ * transform inter macroblock counts. */
 int sa_h264_decode_slice(const sa_h264_slice* s, const uint8_t* rbsp, int64_t n_bytes, const sa_h264_pic* list0,
                          const sa_h264_pic* list1, sa_h264_pic* cur, int32_t* stats);
 

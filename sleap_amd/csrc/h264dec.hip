@@ -4,8 +4,8 @@
 // decoder is the checker (1-5 pictures / s), this file is what `MediaVideo` runs (several hundred). Python keeps what is cheap
 // and stateful: MP4 tables, parameter sets, the slice header, picture order counts, reference marking and list construction; it
 // hands over the header's fields, the reference lists (planes + per-4x4 motion data of every entry) and the current picture's
-// buffers. Scope as the Python module: progressive Baseline / Main profile (I / P / B slices, CABAC with cabac_init_idc 0 or
-// CAVLC, one slice per picture, 4x4 transform). tests/test_h264_native.py: bit-exact against the Python decoder, picture by
+// buffers. Scope as the Python module: progressive 8-bit 4:2:0 Baseline / Main / High profile (I / P / B slices, CABAC with
+// cabac_init_idc 0 or CAVLC, one slice per picture, 4x4 and -- CABAC only -- 8x8 transform with flat scaling matrices). tests/test_h264_native.py: bit-exact against the Python decoder, picture by
 // picture, on all four reference files.
 #include <algorithm>
 #include <cstdint>
@@ -103,6 +103,22 @@ const int8_t CTX_PB0[276][2] = {
     {0, 58}, {0, 64}, {-3, 74}, {-10, 90}, {0, 70}, {-4, 29}, {5, 31}, {7, 42}, {1, 59}, {-2, 58}, {-3, 72}, {-3, 81}, {-11, 97},
     {0, 58}, {8, 5}, {10, 14}, {14, 18}, {13, 27}, {2, 40}, {0, 58}, {-3, 70}, {-6, 79}, {-8, 85}};
 
+// High profile: ctxIdx 399..435 (transform_size_8x8_flag; 8x8 luma blocks of frame macroblocks: significant_coeff_flag 402..416,
+// last_significant_coeff_flag 417..425, coeff_abs_level_minus1 426..435), I slices / cabac_init_idc 0
+const int8_t CTX8_I[37][2] = {{31, 21}, {31, 31}, {25, 50}, {-17, 120}, {-20, 112}, {-18, 114}, {-11, 85}, {-15, 92}, {-14, 89}, {-26, 71}, {-15, 81},
+                              {-14, 80}, {0, 68}, {-14, 70}, {-24, 56}, {-23, 68}, {-24, 50}, {-11, 74}, {23, -13}, {26, -13}, {40, -15}, {49, -14},
+                              {44, 3}, {45, 6}, {44, 34}, {33, 54}, {19, 82}, {-3, 75}, {-1, 23}, {1, 34}, {1, 43}, {0, 54}, {-2, 55}, {0, 61},
+                              {1, 64}, {0, 68}, {-9, 92}};
+const int8_t CTX8_PB0[37][2] = {{12, 40}, {11, 51}, {14, 59}, {-4, 79}, {-7, 71}, {-5, 69}, {-9, 70}, {-8, 66}, {-10, 68}, {-19, 73}, {-12, 69},
+                                {-16, 70}, {-15, 67}, {-20, 62}, {-19, 70}, {-16, 66}, {-22, 65}, {-20, 63}, {9, -2}, {26, -9}, {33, -9}, {39, -7},
+                                {41, -2}, {45, 3}, {49, 9}, {45, 27}, {36, 59}, {-6, 66}, {-7, 35}, {-7, 42}, {-8, 45}, {-5, 48}, {-12, 56},
+                                {-6, 60}, {-5, 62}, {-8, 66}, {-8, 76}};
+const uint8_t SIG8[63] = {0, 1, 2, 3, 4, 5, 5, 4, 4, 3, 3, 4, 4, 4, 5, 5, 4, 4, 4, 4, 3, 3, 6, 7, 7, 7, 8, 9, 10, 9, 8, 7,
+                          7, 6, 11, 12, 13, 11, 6, 7, 8, 9, 14, 10, 9, 8, 6, 11, 12, 13, 11, 6, 9, 14, 10, 9, 11, 12, 13, 11, 14, 10, 12};
+const uint8_t LAST8[63] = {0, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2,
+                           3, 3, 3, 3, 3, 3, 3, 3, 4, 4, 4, 4, 4, 4, 4, 4, 5, 5, 5, 5, 6, 6, 6, 6, 7, 7, 7, 7, 8, 8, 8};
+const int NORM_ADJUST8[6][6] = {{20, 18, 32, 19, 25, 24}, {22, 19, 35, 21, 28, 26}, {26, 23, 42, 24, 33, 31},
+                                {28, 25, 45, 26, 35, 33}, {32, 28, 51, 30, 40, 38}, {36, 32, 58, 34, 46, 43}};
 const uint8_t BLK_X[16] = {0, 1, 0, 1, 2, 3, 2, 3, 0, 1, 0, 1, 2, 3, 2, 3}, BLK_Y[16] = {0, 0, 1, 1, 0, 0, 1, 1, 2, 2, 3, 3, 2, 2, 3, 3};
 const uint8_t XY_BLK[4][4] = {{0, 1, 4, 5}, {2, 3, 6, 7}, {8, 9, 12, 13}, {10, 11, 14, 15}};  // [y][x]
 const uint8_t ZZ_X[16] = {0, 1, 0, 0, 1, 2, 3, 2, 1, 0, 1, 2, 3, 3, 2, 3}, ZZ_Y[16] = {0, 0, 1, 2, 1, 0, 0, 1, 2, 3, 3, 2, 1, 2, 3, 3};
@@ -165,6 +181,17 @@ const uint8_t CBP_INTRA[48] = {47, 31, 15, 0,  23, 27, 29, 30, 7,  11, 13, 14, 3
 const uint8_t CBP_INTER[48] = {0,  16, 1,  2,  4,  8,  32, 3,  5,  10, 12, 15, 47, 7,  11, 13, 14, 6,  9,  31, 35, 37, 42, 44,
                                33, 34, 36, 40, 39, 43, 45, 46, 17, 18, 20, 24, 19, 21, 26, 28, 23, 27, 29, 30, 22, 25, 38, 41};
 
+inline int level_scale8(int qp, int i, int j) {
+  const int* v = NORM_ADJUST8[qp % 6];
+  int k;
+  if (i % 4 == 0 && j % 4 == 0) k = 0;
+  else if (i % 2 == 1 && j % 2 == 1) k = 1;
+  else if (i % 4 == 2 && j % 4 == 2) k = 2;
+  else if ((i % 4 == 0 && j % 2 == 1) || (i % 2 == 1 && j % 4 == 0)) k = 3;
+  else if ((i % 4 == 0 && j % 4 == 2) || (i % 4 == 2 && j % 4 == 0)) k = 4;
+  else k = 5;
+  return 16 * v[k];
+}
 inline int clip3(int lo, int hi, int v) { return v < lo ? lo : (v > hi ? hi : v); }
 inline int clip1(int v) { return v < 0 ? 0 : (v > 255 ? 255 : v); }
 inline int level_scale(int qp, int x, int y) {
@@ -215,13 +242,18 @@ struct Bits {
 struct Cabac {
   Bits* b;
   int range = 510, offset = 0;
-  uint8_t state[276], mps[276];
-  void init(Bits* bits, int qp, const int8_t (*tab)[2]) {
+  uint8_t state[436], mps[436];
+  void init(Bits* bits, int qp, const int8_t (*tab)[2], const int8_t (*tab8)[2]) {
     b = bits;
     offset = b->u(9);
     const int q = clip3(0, 51, qp);
-    for (int k = 0; k < 276; ++k) {
-      const int pre = clip3(1, 126, ((tab[k][0] * q) >> 4) + tab[k][1]);
+    for (int k = 0; k < 436; ++k) {
+      if (k >= 276 && k < 399) {
+        state[k] = 0, mps[k] = 0;
+        continue;
+      }
+      const int8_t* mn = k < 276 ? tab[k] : tab8[k - 399];
+      const int pre = clip3(1, 126, ((mn[0] * q) >> 4) + mn[1]);
       if (pre <= 63) {
         state[k] = (uint8_t)(63 - pre);
         mps[k] = 0;
@@ -271,9 +303,9 @@ struct Cabac {
   }
 };
 
-enum { T_NONE = 0, T_I4 = 1, T_I16 = 2, T_INTER = 3 };
+enum { T_NONE = 0, T_I4 = 1, T_I16 = 2, T_INTER = 3, T_I8 = 4 };  // T_I4 and T_I8 are both mb_type I_NxN
 struct MB {
-  uint8_t typ = T_NONE, skip = 0, direct16 = 0, intra = 0, ref0 = 0, i16 = 0, cbp_luma = 0, cbp_chroma = 0, chroma_mode = 0, cbf_dc = 0, qp_delta_nz = 0;
+  uint8_t typ = T_NONE, skip = 0, direct16 = 0, intra = 0, ref0 = 0, t8 = 0, i16 = 0, cbp_luma = 0, cbp_chroma = 0, chroma_mode = 0, cbf_dc = 0, qp_delta_nz = 0;
   int8_t qp = 0;
   uint8_t modes[16], cbf_luma[16], cbf_cdc[2], cbf_cac[2][4];
   MB() {
@@ -691,6 +723,106 @@ struct Slice {
       }
     }
   }
+  static void idct8_1d(const int* v, int stride, int* o, int ostride) {
+    const int d0 = v[0], d1 = v[stride], d2 = v[2 * stride], d3 = v[3 * stride], d4 = v[4 * stride], d5 = v[5 * stride], d6 = v[6 * stride], d7 = v[7 * stride];
+    const int a0 = d0 + d4, a4 = d0 - d4, a2 = (d2 >> 1) - d6, a6 = d2 + (d6 >> 1);
+    const int b0 = a0 + a6, b2 = a4 + a2, b4 = a4 - a2, b6 = a0 - a6;
+    const int a1 = -d3 + d5 - d7 - (d7 >> 1), a3 = d1 + d7 - d3 - (d3 >> 1), a5 = -d1 + d7 + d5 + (d5 >> 1), a7 = d3 + d5 + d1 + (d1 >> 1);
+    const int b1 = a1 + (a7 >> 2), b7 = a7 - (a1 >> 2), b3 = a3 + (a5 >> 2), b5 = (a3 >> 2) - a5;
+    o[0] = b0 + b7, o[ostride] = b2 + b5, o[2 * ostride] = b4 + b3, o[3 * ostride] = b6 + b1;
+    o[4 * ostride] = b6 - b1, o[5 * ostride] = b4 - b3, o[6 * ostride] = b2 - b5, o[7 * ostride] = b0 - b7;
+  }
+  static void idct8(const int d[8][8], int r[8][8]) {  // 8.5.13
+    int t[8][8];
+    for (int y = 0; y < 8; ++y) idct8_1d(&d[y][0], 1, &t[y][0], 1);
+    for (int x = 0; x < 8; ++x) idct8_1d(&t[0][x], 8, &r[0][x], 8);
+    for (int y = 0; y < 8; ++y)
+      for (int x = 0; x < 8; ++x) r[y][x] = (r[y][x] + 32) >> 6;
+  }
+  void pred8(const MB& m, int mx, int my, int b8) {  // Intra 8x8 (8.3.2): filtered reference samples, nine modes
+    const int bx = b8 & 1, by = b8 >> 1, x0 = mx * 16 + bx * 8, y0 = my * 16 + by * 8;
+    const bool left = bx > 0 || mx > 0, top = by > 0 || my > 0;
+    bool tr, tl;
+    if (b8 == 0) tr = top, tl = mx > 0 && my > 0;
+    else if (b8 == 1) tr = my > 0 && mx + 1 < W, tl = top;
+    else if (b8 == 2) tr = true, tl = left;
+    else tr = false, tl = true;
+    int T[16], L[8], c = 0;
+    for (int i = 0; i < 16; ++i) T[i] = 0;
+    for (int i = 0; i < 8; ++i) L[i] = 0;
+    if (top) {
+      for (int i = 0; i < 8; ++i) T[i] = Y(y0 - 1, x0 + i);
+      for (int i = 8; i < 16; ++i) T[i] = tr ? Y(y0 - 1, x0 + i) : T[7];
+    }
+    if (left)
+      for (int j = 0; j < 8; ++j) L[j] = Y(y0 + j, x0 - 1);
+    if (tl) c = Y(y0 - 1, x0 - 1);
+    int FT[16], FL[8], fc = 0;
+    for (int i = 0; i < 16; ++i) FT[i] = 0;
+    for (int i = 0; i < 8; ++i) FL[i] = 0;
+    if (top) {
+      FT[0] = tl ? (c + 2 * T[0] + T[1] + 2) >> 2 : (3 * T[0] + T[1] + 2) >> 2;
+      for (int x = 1; x < 15; ++x) FT[x] = (T[x - 1] + 2 * T[x] + T[x + 1] + 2) >> 2;
+      FT[15] = (T[14] + 3 * T[15] + 2) >> 2;
+    }
+    if (tl) fc = (top && left) ? (T[0] + 2 * c + L[0] + 2) >> 2 : (top ? (3 * c + T[0] + 2) >> 2 : (left ? (3 * c + L[0] + 2) >> 2 : c));
+    if (left) {
+      FL[0] = tl ? (c + 2 * L[0] + L[1] + 2) >> 2 : (3 * L[0] + L[1] + 2) >> 2;
+      for (int y = 1; y < 7; ++y) FL[y] = (L[y - 1] + 2 * L[y] + L[y + 1] + 2) >> 2;
+      FL[7] = (L[6] + 3 * L[7] + 2) >> 2;
+    }
+    auto P = [&](int x, int y) -> int { return y < 0 ? (x < 0 ? fc : FT[x]) : FL[y]; };
+    const int mode = m.modes[b8 * 4];
+    int dc = 128;
+    if (mode == 2) {
+      int st = 0, sl = 0;
+      for (int i = 0; i < 8; ++i) st += FT[i], sl += FL[i];
+      dc = (top && left) ? (st + sl + 8) >> 4 : (left ? (sl + 4) >> 3 : (top ? (st + 4) >> 3 : 128));
+    }
+    for (int y = 0; y < 8; ++y)
+      for (int x = 0; x < 8; ++x) {
+        int v;
+        switch (mode) {
+          case 0: v = P(x, -1); break;
+          case 1: v = P(-1, y); break;
+          case 2: v = dc; break;
+          case 3: v = (x == 7 && y == 7) ? (P(14, -1) + 3 * P(15, -1) + 2) >> 2 : (P(x + y, -1) + 2 * P(x + y + 1, -1) + P(x + y + 2, -1) + 2) >> 2; break;
+          case 4:
+            if (x > y) v = (P(x - y - 2, -1) + 2 * P(x - y - 1, -1) + P(x - y, -1) + 2) >> 2;
+            else if (x < y) v = (P(-1, y - x - 2) + 2 * P(-1, y - x - 1) + P(-1, y - x) + 2) >> 2;
+            else v = (P(0, -1) + 2 * P(-1, -1) + P(-1, 0) + 2) >> 2;
+            break;
+          case 5: {
+            const int z = 2 * x - y;
+            if (z >= 0 && z % 2 == 0) v = (P(x - (y >> 1) - 1, -1) + P(x - (y >> 1), -1) + 1) >> 1;
+            else if (z >= 0) v = (P(x - (y >> 1) - 2, -1) + 2 * P(x - (y >> 1) - 1, -1) + P(x - (y >> 1), -1) + 2) >> 2;
+            else if (z == -1) v = (P(-1, 0) + 2 * P(-1, -1) + P(0, -1) + 2) >> 2;
+            else v = (P(-1, y - 2 * x - 1) + 2 * P(-1, y - 2 * x - 2) + P(-1, y - 2 * x - 3) + 2) >> 2;
+            break;
+          }
+          case 6: {
+            const int z = 2 * y - x;
+            if (z >= 0 && z % 2 == 0) v = (P(-1, y - (x >> 1) - 1) + P(-1, y - (x >> 1)) + 1) >> 1;
+            else if (z >= 0) v = (P(-1, y - (x >> 1) - 2) + 2 * P(-1, y - (x >> 1) - 1) + P(-1, y - (x >> 1)) + 2) >> 2;
+            else if (z == -1) v = (P(-1, 0) + 2 * P(-1, -1) + P(0, -1) + 2) >> 2;
+            else v = (P(x - 2 * y - 1, -1) + 2 * P(x - 2 * y - 2, -1) + P(x - 2 * y - 3, -1) + 2) >> 2;
+            break;
+          }
+          case 7:
+            v = (y % 2 == 0) ? (P(x + (y >> 1), -1) + P(x + (y >> 1) + 1, -1) + 1) >> 1
+                             : (P(x + (y >> 1), -1) + 2 * P(x + (y >> 1) + 1, -1) + P(x + (y >> 1) + 2, -1) + 2) >> 2;
+            break;
+          default: {
+            const int z = x + 2 * y;
+            if (z > 13) v = P(-1, 7);
+            else if (z == 13) v = (P(-1, 6) + 3 * P(-1, 7) + 2) >> 2;
+            else if (z % 2 == 0) v = (P(-1, y + (x >> 1)) + P(-1, y + (x >> 1) + 1) + 1) >> 1;
+            else v = (P(-1, y + (x >> 1)) + 2 * P(-1, y + (x >> 1) + 1) + P(-1, y + (x >> 1) + 2) + 2) >> 2;
+          }
+        }
+        Y(y0 + y, x0 + x) = (uint8_t)v;
+      }
+  }
   static void idct4(const int d[4][4], int r[4][4]) {
     int f[4][4];
     for (int i = 0; i < 4; ++i) {
@@ -806,6 +938,48 @@ struct Slice {
       }
     }
     return cab.bypass() ? -v : v;
+  }
+  int t8_flag(const MB* A, const MB* B) {
+    H264_CHECK(cabac(), "the 8x8 transform with CAVLC entropy coding is not implemented");
+    return cab.decision(399 + ((A && A->t8) ? 1 : 0) + ((B && B->t8) ? 1 : 0));
+  }
+  void residual_block8(int* coef) {  // 64 levels in scan order (ctxBlockCat 5; coded_block_flag inferred 1)
+    for (int i = 0; i < 64; ++i) coef[i] = 0;
+    int sig[64], ns = 0;
+    bool last_found = false;
+    for (int i = 0; i < 63; ++i)
+      if (cab.decision(402 + SIG8[i])) {
+        sig[ns++] = i;
+        if (cab.decision(417 + LAST8[i])) {
+          last_found = true;
+          break;
+        }
+      }
+    if (!last_found) sig[ns++] = 63;
+    int eq1 = 0, gt1 = 0;
+    for (int k = ns - 1; k >= 0; --k) {
+      const int inc = gt1 ? 0 : std::min(4, 1 + eq1);
+      int v = 0;
+      if (cab.decision(426 + inc)) {
+        const int inc2 = 5 + std::min(4, gt1);
+        v = 1;
+        while (v < 14 && cab.decision(426 + inc2)) ++v;
+        if (v == 14) {
+          int kk = 0;
+          while (cab.bypass()) {
+            v += 1 << kk;
+            ++kk;
+            H264_CHECK(kk < 24, "coefficient runaway");
+          }
+          while (kk) {
+            --kk;
+            v += cab.bypass() << kk;
+          }
+        }
+      }
+      if (v == 0) ++eq1; else ++gt1;
+      coef[sig[k]] = cab.bypass() ? -(v + 1) : v + 1;
+    }
   }
   int i4_mode() {  // -1: use the predicted mode
     if (!cabac()) return bits.u1() ? -1 : bits.u(3);
@@ -1049,7 +1223,39 @@ struct Slice {
       have_dc = true;
       pred16(m, mx, my);
     }
-    for (int blk = 0; blk < 16; ++blk) {
+    if (m.t8) {
+      // 8x8 transform: four luma blocks of 64 levels (coded_block_flag inferred), Intra 8x8 prediction interleaved
+      int lv8[64], d8[8][8], r8[8][8];
+      for (int b8 = 0; b8 < 4; ++b8) {
+        const int bx8 = b8 & 1, by8 = b8 >> 1;
+        if (m.typ == T_I8) pred8(m, mx, my, b8);
+        if (!((m.cbp_luma >> b8) & 1)) continue;
+        residual_block8(lv8);
+        memset(d8, 0, sizeof(d8));
+        // 8x8 zig-zag: anti-diagonals, odd ones from the top right down, even ones from the bottom left up
+        int k = 0;
+        for (int dg = 0; dg < 15; ++dg) {
+          const int lo = std::max(dg - 7, 0), hi = std::min(dg, 7);
+          for (int t = 0; t <= hi - lo; ++t, ++k) {
+            const int x = (dg % 2) ? hi - t : lo + t, y = dg - x;
+            if (lv8[k]) {
+              const int ls8 = level_scale8(qpy, y, x);
+              d8[y][x] = qpy >= 36 ? (lv8[k] * ls8) * (1 << (qpy / 6 - 6)) : (lv8[k] * ls8 + (1 << (5 - qpy / 6))) >> (6 - qpy / 6);
+            }
+          }
+        }
+        idct8(d8, r8);
+        for (int y = 0; y < 8; ++y)
+          for (int x = 0; x < 8; ++x) {
+            uint8_t& p = Y(py + by8 * 8 + y, px + bx8 * 8 + x);
+            p = (uint8_t)clip1(p + r8[y][x]);
+          }
+        for (int q = 0; q < 4; ++q) m.cbf_luma[b8 * 4 + q] = 1;
+        for (int y = 0; y < 2; ++y)
+          for (int x = 0; x < 2; ++x) nz[(size_t)(Y4 + by8 * 2 + y) * W4 + X4 + bx8 * 2 + x] = 1;
+      }
+    }
+    for (int blk = 0; blk < (m.t8 ? 0 : 16); ++blk) {
       const int bx = BLK_X[blk], by = BLK_Y[blk];
       bool coded = false;
       memset(d, 0, sizeof(d));
@@ -1085,10 +1291,11 @@ struct Slice {
       }
     }
     if (m.intra) pred_chroma(m, mx, my);
-    const int qpc = QPC[clip3(0, 51, qpy + s->chroma_qp_offset)];
+    const int qpcs[2] = {QPC[clip3(0, 51, qpy + s->chroma_qp_offset)], QPC[clip3(0, 51, qpy + s->chroma_qp_offset_cr)]};
     int dcs[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
     if (m.cbp_chroma) {
       for (int comp = 0; comp < 2; ++comp) {
+        const int qpc = qpcs[comp];
         m.cbf_cdc[comp] = (uint8_t)residual_block(m, A, B, 3, 4, 0, 0, comp, lv);
         const int c00 = lv[0], c01 = lv[1], c10 = lv[2], c11 = lv[3];
         const int f[4] = {c00 + c01 + c10 + c11, c00 - c01 + c10 - c11, c00 + c01 - c10 - c11, c00 - c01 - c10 + c11};
@@ -1109,7 +1316,7 @@ struct Slice {
     const int CW = W * 8;
     for (int comp = 0; comp < 2; ++comp)
       for (int blk = 0; blk < 4; ++blk) {
-        const int bx = blk & 1, by = blk >> 1;
+        const int bx = blk & 1, by = blk >> 1, qpc = qpcs[comp];
         memset(d, 0, sizeof(d));
         bool any = false;
         if (have_ac)
@@ -1180,10 +1387,12 @@ struct Slice {
     m.intra = 1;
     for (int y = 0; y < 4; ++y)
       for (int x = 0; x < 4; ++x) cur->intra4[(size_t)(Y4 + y) * W4 + X4 + x] = 1;
-    ++stats[m.typ == T_I4 ? 0 : 1];
+    if (m.typ == T_I4 && s->transform_8x8_mode && t8_flag(A, B)) m.typ = T_I8, m.t8 = 1;
+    ++stats[m.typ == T_I4 ? 0 : (m.typ == T_I8 ? 5 : 1)];
     mark_done(mx, my, 0, 0, 4, 4, 1);
-    if (m.typ == T_I4) {
-      for (int blk = 0; blk < 16; ++blk) {
+    if (m.typ == T_I4 || m.typ == T_I8) {
+      // Intra 8x8: four blocks whose neighbours are the 4x4 blocks left of / above their first 4x4 block; a mode is kept per 4x4 slot
+      for (int blk = 0; blk < 16; blk += (m.typ == T_I4 ? 1 : 4)) {
         const int bx = BLK_X[blk], by = BLK_Y[blk];
         auto nmode = [&](int dx, int dy) -> int {  // -1: not available
           const int x = bx + dx, y = by + dy;
@@ -1191,17 +1400,19 @@ struct Slice {
           if (x >= 0 && x < 4 && y >= 0 && y < 4) n = &m;
           else n = mb(mx + (x < 0 ? -1 : (x > 3 ? 1 : 0)), my + (y < 0 ? -1 : (y > 3 ? 1 : 0)));
           if (!n) return -1;
-          if (n->typ != T_I4) return 2;
+          if (n->typ != T_I4 && n->typ != T_I8) return 2;
           return n->modes[XY_BLK[(y + 4) % 4][(x + 4) % 4]];
         };
         const int ma = nmode(-1, 0), mb_ = nmode(0, -1);
         const int pred = (ma < 0 || mb_ < 0) ? 2 : std::min(ma, mb_);
         const int rem = i4_mode();
-        m.modes[blk] = (uint8_t)(rem < 0 ? pred : (rem < pred ? rem : rem + 1));
+        const uint8_t mode = (uint8_t)(rem < 0 ? pred : (rem < pred ? rem : rem + 1));
+        if (m.typ == T_I4) m.modes[blk] = mode;
+        else m.modes[blk] = m.modes[blk + 1] = m.modes[blk + 2] = m.modes[blk + 3] = mode;
       }
     }
     m.chroma_mode = (uint8_t)read_chroma_mode(A, B);
-    if (m.typ == T_I4) read_cbp(m, A, B);
+    if (m.typ == T_I4 || m.typ == T_I8) read_cbp(m, A, B);
     read_qp_delta(m, m.typ == T_I16 || m.cbp_luma || m.cbp_chroma);
     residual(mx, my, m, A, B);
   }
@@ -1212,6 +1423,7 @@ struct Slice {
     ++stats[3];
     Part plist[16], parts[20];
     int npl = 0, np = 0;
+    bool no_sub8 = kind == 2 ? s->direct_8x8_inference != 0 : true;  // noSubMbPartSizeLessThan8x8Flag (7.3.5)
     if (kind == 2) {
       const int quads[4] = {0, 1, 2, 3};
       direct_pred(mx, my, quads, 4);
@@ -1225,6 +1437,7 @@ struct Slice {
       if (kind == 1) {
         int sshape[4], spred[4];
         sub_mb_types(sshape, spred);
+        for (int q = 0; q < 4; ++q) no_sub8 = no_sub8 && (sshape[q] == 0 || (sshape[q] < 0 && s->direct_8x8_inference));
         int dq[4], ndq = 0;
         for (int q = 0; q < 4; ++q)
           if (sshape[q] < 0) dq[ndq++] = q, dmask |= 1 << q;
@@ -1287,6 +1500,10 @@ struct Slice {
     }
     predict_inter(mx, my, parts, np);
     read_cbp(m, A, B);
+    if (s->transform_8x8_mode && m.cbp_luma && no_sub8 && t8_flag(A, B)) {
+      m.t8 = 1;
+      ++stats[6];
+    }
     read_qp_delta(m, m.cbp_luma || m.cbp_chroma);
     residual(mx, my, m, A, B);
   }
@@ -1304,7 +1521,7 @@ struct Slice {
     }
     int kind = -1, shape = 0, p0 = 0, p1 = -1;
     if (stype == 2) {
-      const int inc = ((A && A->typ != T_I4) ? 1 : 0) + ((B && B->typ != T_I4) ? 1 : 0);
+      const int inc = ((A && A->typ != T_I4 && A->typ != T_I8) ? 1 : 0) + ((B && B->typ != T_I4 && B->typ != T_I8) ? 1 : 0);
       if (cab.decision(3 + inc) == 0) {
         m.typ = T_I4;
       } else {
@@ -1444,8 +1661,8 @@ struct Slice {
     return true;
   }
   void deblock() {
-    const int cqo = s->chroma_qp_offset, off_a = s->filter_offset_a, off_b = s->filter_offset_b;
-    auto qpc = [&](int q) { return (int)QPC[clip3(0, 51, q + cqo)]; };
+    const int cqo[2] = {s->chroma_qp_offset, s->chroma_qp_offset_cr}, off_a = s->filter_offset_a, off_b = s->filter_offset_b;
+    auto qpc = [&](int q, int comp) { return (int)QPC[clip3(0, 51, q + cqo[comp])]; };
     for (int my = 0; my < Hh; ++my)
       for (int mx = 0; mx < W; ++mx) {
         const MB& m = mbs[(size_t)my * W + mx];
@@ -1453,6 +1670,7 @@ struct Slice {
           const MB* n = vertical ? (mx > 0 ? &mbs[(size_t)my * W + mx - 1] : nullptr) : (my > 0 ? &mbs[(size_t)(my - 1) * W + mx] : nullptr);
           for (int e = 0; e < 4; ++e) {
             if (e == 0 && !n) continue;
+            if (m.t8 && (e % 2)) continue;  // 8x8 transform: no luma edges inside the 8x8 blocks (odd edges carry no chroma either)
             int bss[4];
             bool any = false;
             for (int k = 0; k < 4; ++k) {
@@ -1469,7 +1687,7 @@ struct Slice {
               const bool luma = plane == 0;
               const int size = luma ? 16 : 8, stride = luma ? W * 16 : W * 8, PH = luma ? Hh * 16 : Hh * 8;
               uint8_t* P = luma ? cur->y : C(plane - 1);
-              const int qpav = luma ? (qp_p + m.qp + 1) >> 1 : (qpc(qp_p) + qpc(m.qp) + 1) >> 1;
+              const int qpav = luma ? (qp_p + m.qp + 1) >> 1 : (qpc(qp_p, plane - 1) + qpc(m.qp, plane - 1) + 1) >> 1;
               const int idx_a = clip3(0, 51, qpav + off_a), idx_b = clip3(0, 51, qpav + off_b);
               const int alpha = ALPHA[idx_a], beta = BETA[idx_b];
               if (alpha == 0) continue;
@@ -1531,7 +1749,7 @@ struct Slice {
     }
     bits.d = rbsp, bits.n_bits = n_bytes * 8, bits.p = s->data_bit_offset;
     if (cabac()) {
-      cab.init(&bits, qp, stype == 2 ? CTX_I : CTX_PB0);
+      cab.init(&bits, qp, stype == 2 ? CTX_I : CTX_PB0, stype == 2 ? CTX8_I : CTX8_PB0);
       for (int addr = 0; addr < n_mb; ++addr) {
         macroblock_cabac(addr, addr % W, addr / W);
         const int end = cab.terminate();

@@ -1,6 +1,7 @@
-"""H.264 decoder for progressive Baseline / Main-profile streams: I, P and B pictures, CABAC or CAVLC, 4:2:0, frame
-macroblocks, one slice per picture, 4x4 transform -- what x264 writes for `-profile baseline` / `-profile main`, and what the
-reference's test videos are: tests/data/videos/small_robot.mp4 (Baseline: CAVLC, P pictures; the file its MediaVideo tests
+"""H.264 decoder for progressive 8-bit 4:2:0 Baseline / Main / High-profile streams: I, P and B pictures, CABAC or CAVLC, frame
+macroblocks, one slice per picture, 4x4 and 8x8 transform with flat scaling matrices -- what x264 writes for `-profile baseline`
+/ `main` / `high`, and what ALL the reference's test videos are: tests/data/videos/small_robot_3_frame.mp4 and
+tests/data/tracks/clip.mp4 (High: Intra 8x8, 8x8 transform; the latter 1500 frames of 1024 x 1024), tests/data/videos/small_robot.mp4 (Baseline: CAVLC, P pictures; the file its MediaVideo tests
 read), tests/data/json_format_v1/centered_pair_low_quality.mp4, tests/data/videos/centered_pair_small.mp4, dance.mp4 (Main:
 CABAC, B pyramids, weighted prediction). Two engines for the macroblock layer behind the same Python front end (MP4 tables,
 parameter sets, slice headers, picture order, reference lists and marking): `engine="native"` -- `sa_h264_decode_slice`, host C++
@@ -17,14 +18,16 @@ syntax of P and B macroblocks for cabac_init_idc 0 (9.3: mb_skip_flag, mb_type, 
 inter slices) and the CAVLC syntax of I and P slices (9.2: coeff_token, levels, total_zeros, run_before; mb_skip_run, me(v) / te(v)
 / se(v) elements); motion vector prediction incl. P_Skip, spatial and temporal direct with direct_8x8_inference (8.4.1); quarter-
 sample luma and eighth-sample chroma interpolation, default / explicit / implicit weighted prediction (8.4.2); the edge
-filter's boundary strengths for inter pictures (8.7.2.1). NOT implemented, each refused with a message: the 8x8 transform /
-scaling matrices (High profile: tests/data/videos/small_robot_3_frame.mp4), cabac_init_idc 1 and 2 (their context tables are not
+filter's boundary strengths for inter pictures (8.7.2.1); the High-profile tools for CABAC streams: transform_size_8x8_flag, 8x8
+residual blocks (ctxBlockCat 5), Intra 8x8 prediction with its reference sample filter (8.3.2), the 8x8 inverse transform and
+scaling (8.5.13), edge filtering by transform size, second_chroma_qp_index_offset. NOT implemented, each refused with a
+message: scaling matrices, 4:2:2 / 4:4:4 and more than 8 bits, the 8x8 transform with CAVLC, cabac_init_idc 1 and 2 (their context tables are not
 held: no stream here uses them and nothing could validate them), B slices with CAVLC, I_PCM, long-term references, fields /
 MBAFF, several slices per picture, constrained intra prediction.
 
 Checks. (1) A decode is self-checking like the intra module's: a wrong table entry, binarisation or neighbour rule
 desynchronises the entropy decoder, and the slice then does not end exactly at the last macroblock with its data used up --
-asserted for every picture (all 1100 + 1100 + 450 + 166 pictures of the four files decode); the VLC tables are checked to be
+asserted for every picture (all 1100 + 1100 + 450 + 166 + 3 + 1500 pictures of the six files decode); the VLC tables are checked to be
 prefix-free codes at import. (2) Key frames are decoded by BOTH modules and must agree bit for bit. (3) An external decoder's
 pixels: tests/data/videos/robot0..2.jpg are frames 56, 86, 116 of small_robot.mp4 as FFmpeg decoded them -- this decoder lands on
 them at 38.3-38.5 dB (the JPEGs' own compression loss; neighbouring frames: ~30 dB), equally at the end of a 116-picture P chain.
@@ -81,6 +84,181 @@ _fill(227, [(-6, 76), (-2, 44), (0, 45), (0, 52), (-3, 64), (-2, 59), (-4, 70), 
             (0, 58), (0, 64), (-3, 74), (-10, 90), (0, 70), (-4, 29), (5, 31), (7, 42), (1, 59), (-2, 58), (-3, 72), (-3, 81), (-11, 97),
             (0, 58), (8, 5), (10, 14), (14, 18), (13, 27), (2, 40), (0, 58), (-3, 70), (-6, 79), (-8, 85)], 275)
 assert sorted(CTX_PB0) == list(range(276))
+# High profile: transform_size_8x8_flag (399..401) and the 8x8 luma blocks of frame macroblocks (ctxBlockCat 5: significant_coeff_flag
+# 402..416, last_significant_coeff_flag 417..425, coeff_abs_level_minus1 426..435), I slices / cabac_init_idc 0
+_CTX8_I = [(31, 21), (31, 31), (25, 50), (-17, 120), (-20, 112), (-18, 114), (-11, 85), (-15, 92), (-14, 89), (-26, 71), (-15, 81), (-14, 80),
+           (0, 68), (-14, 70), (-24, 56), (-23, 68), (-24, 50), (-11, 74), (23, -13), (26, -13), (40, -15), (49, -14), (44, 3), (45, 6),
+           (44, 34), (33, 54), (19, 82), (-3, 75), (-1, 23), (1, 34), (1, 43), (0, 54), (-2, 55), (0, 61), (1, 64), (0, 68), (-9, 92)]
+_CTX8_PB0 = [(12, 40), (11, 51), (14, 59), (-4, 79), (-7, 71), (-5, 69), (-9, 70), (-8, 66), (-10, 68), (-19, 73), (-12, 69), (-16, 70),
+             (-15, 67), (-20, 62), (-19, 70), (-16, 66), (-22, 65), (-20, 63), (9, -2), (26, -9), (33, -9), (39, -7), (41, -2), (45, 3),
+             (49, 9), (45, 27), (36, 59), (-6, 66), (-7, 35), (-7, 42), (-8, 45), (-5, 48), (-12, 56), (-6, 60), (-5, 62), (-8, 66), (-8, 76)]
+assert len(_CTX8_I) == len(_CTX8_PB0) == 37
+CTX_I_HIGH = {**CTX_I, **{399 + k: v for k, v in enumerate(_CTX8_I)}}
+CTX_PB0_HIGH = {**CTX_PB0, **{399 + k: v for k, v in enumerate(_CTX8_PB0)}}
+# ctxIdxInc of significant_coeff_flag / last_significant_coeff_flag for the 63 scan positions of an 8x8 block (Table 9-43, frame)
+SIG8 = [0, 1, 2, 3, 4, 5, 5, 4, 4, 3, 3, 4, 4, 4, 5, 5, 4, 4, 4, 4, 3, 3, 6, 7, 7, 7, 8, 9, 10, 9, 8, 7, 7, 6, 11, 12, 13, 11, 6, 7, 8, 9, 14, 10, 9, 8,
+        6, 11, 12, 13, 11, 6, 9, 14, 10, 9, 11, 12, 13, 11, 14, 10, 12]
+LAST8 = [0, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 3, 3, 3, 3, 3, 3, 3, 3, 4, 4, 4, 4, 4, 4, 4, 4,
+         5, 5, 5, 5, 6, 6, 6, 6, 7, 7, 7, 7, 8, 8, 8]
+assert len(SIG8) == len(LAST8) == 63
+# 8x8 zig-zag scan (Figure 6-? / Table 8-?: the classic one): (x, y) per scan position
+ZIGZAG8 = []
+for _d in range(15):
+    _xs = range(min(_d, 7), max(_d - 7, 0) - 1, -1) if _d % 2 else range(max(_d - 7, 0), min(_d, 7) + 1)
+    ZIGZAG8 += [(_x, _d - _x) for _x in _xs]
+assert len(ZIGZAG8) == 64 and ZIGZAG8[:6] == [(0, 0), (1, 0), (0, 1), (0, 2), (1, 1), (2, 0)] and ZIGZAG8[-1] == (7, 7)
+NORM_ADJUST8 = [(20, 18, 32, 19, 25, 24), (22, 19, 35, 21, 28, 26), (26, 23, 42, 24, 33, 31), (28, 25, 45, 26, 35, 33), (32, 28, 51, 30, 40, 38),
+                (36, 32, 58, 34, 46, 43)]
+
+
+def level_scale8(qp, i, j):
+    """16 x normAdjust8x8 (8.5.9, flat scaling matrix) for row i, column j"""
+    v = NORM_ADJUST8[qp % 6]
+    if i % 4 == 0 and j % 4 == 0:
+        k = 0
+    elif i % 2 == 1 and j % 2 == 1:
+        k = 1
+    elif i % 4 == 2 and j % 4 == 2:
+        k = 2
+    elif (i % 4 == 0 and j % 2 == 1) or (i % 2 == 1 and j % 4 == 0):
+        k = 3
+    elif (i % 4 == 0 and j % 4 == 2) or (i % 4 == 2 and j % 4 == 0):
+        k = 4
+    else:
+        k = 5
+    return 16 * v[k]
+
+
+def idct8(d):
+    """8.5.13: d[y][x] scaled coefficients of an 8x8 block -> residual ((x + 32) >> 6 applied)"""
+    def one(v):
+        d0, d1, d2, d3, d4, d5, d6, d7 = v
+        a0, a4, a2, a6 = d0 + d4, d0 - d4, (d2 >> 1) - d6, d2 + (d6 >> 1)
+        b0, b2, b4, b6 = a0 + a6, a4 + a2, a4 - a2, a0 - a6
+        a1 = -d3 + d5 - d7 - (d7 >> 1)
+        a3 = d1 + d7 - d3 - (d3 >> 1)
+        a5 = -d1 + d7 + d5 + (d5 >> 1)
+        a7 = d3 + d5 + d1 + (d1 >> 1)
+        b1, b7, b3, b5 = a1 + (a7 >> 2), a7 - (a1 >> 2), a3 + (a5 >> 2), (a3 >> 2) - a5
+        return [b0 + b7, b2 + b5, b4 + b3, b6 + b1, b6 - b1, b4 - b3, b2 - b5, b0 - b7]
+
+    rows = [one(r) for r in d]
+    cols = [one([rows[y][x] for y in range(8)]) for x in range(8)]
+    return [[(cols[x][y] + 32) >> 6 for x in range(8)] for y in range(8)]
+
+
+def pred8(pic, m, mx, my, b8):
+    """Intra 8x8 prediction of luma 8x8 block b8 (8.3.2): reference samples low-pass filtered, nine modes"""
+    bx, by = b8 & 1, b8 >> 1
+    x0, y0 = mx * 16 + bx * 8, my * 16 + by * 8
+    Y = pic.Y
+    left = bx > 0 or pic.mb(mx - 1, my) is not None
+    top = by > 0 or pic.mb(mx, my - 1) is not None
+    if b8 == 0:
+        tr, tl = top, pic.mb(mx - 1, my - 1) is not None
+    elif b8 == 1:
+        tr, tl = pic.mb(mx + 1, my - 1) is not None, top
+    elif b8 == 2:
+        tr, tl = True, left
+    else:
+        tr, tl = False, True
+    p = {}
+    if top:
+        for i in range(8):
+            p[(i, -1)] = int(Y[y0 - 1, x0 + i])
+        for i in range(8, 16):
+            p[(i, -1)] = int(Y[y0 - 1, x0 + i]) if tr else p[(7, -1)]
+    if left:
+        for j in range(8):
+            p[(-1, j)] = int(Y[y0 + j, x0 - 1])
+    if tl:
+        p[(-1, -1)] = int(Y[y0 - 1, x0 - 1])
+    q = {}  # filtered samples (8.3.2.2.1)
+    if top:
+        q[(0, -1)] = (p[(-1, -1)] + 2 * p[(0, -1)] + p[(1, -1)] + 2) >> 2 if tl else (3 * p[(0, -1)] + p[(1, -1)] + 2) >> 2
+        for x in range(1, 15):
+            q[(x, -1)] = (p[(x - 1, -1)] + 2 * p[(x, -1)] + p[(x + 1, -1)] + 2) >> 2
+        q[(15, -1)] = (p[(14, -1)] + 3 * p[(15, -1)] + 2) >> 2
+    if tl:
+        if top and left:
+            q[(-1, -1)] = (p[(0, -1)] + 2 * p[(-1, -1)] + p[(-1, 0)] + 2) >> 2
+        elif top:
+            q[(-1, -1)] = (3 * p[(-1, -1)] + p[(0, -1)] + 2) >> 2
+        elif left:
+            q[(-1, -1)] = (3 * p[(-1, -1)] + p[(-1, 0)] + 2) >> 2
+        else:
+            q[(-1, -1)] = p[(-1, -1)]
+    if left:
+        q[(-1, 0)] = (p[(-1, -1)] + 2 * p[(-1, 0)] + p[(-1, 1)] + 2) >> 2 if tl else (3 * p[(-1, 0)] + p[(-1, 1)] + 2) >> 2
+        for y in range(1, 7):
+            q[(-1, y)] = (p[(-1, y - 1)] + 2 * p[(-1, y)] + p[(-1, y + 1)] + 2) >> 2
+        q[(-1, 7)] = (p[(-1, 6)] + 3 * p[(-1, 7)] + 2) >> 2
+    mode = m.modes[BLK8_FIRST[b8]]
+    out = [[0] * 8 for _ in range(8)]
+    for y in range(8):
+        for x in range(8):
+            if mode == 0:
+                v = q[(x, -1)]
+            elif mode == 1:
+                v = q[(-1, y)]
+            elif mode == 2:
+                if top and left:
+                    v = (sum(q[(i, -1)] for i in range(8)) + sum(q[(-1, j)] for j in range(8)) + 8) >> 4
+                elif left:
+                    v = (sum(q[(-1, j)] for j in range(8)) + 4) >> 3
+                elif top:
+                    v = (sum(q[(i, -1)] for i in range(8)) + 4) >> 3
+                else:
+                    v = 128
+            elif mode == 3:
+                v = (q[(14, -1)] + 3 * q[(15, -1)] + 2) >> 2 if (x == 7 and y == 7) else (q[(x + y, -1)] + 2 * q[(x + y + 1, -1)] + q[(x + y + 2, -1)] + 2) >> 2
+            elif mode == 4:
+                if x > y:
+                    v = (q[(x - y - 2, -1)] + 2 * q[(x - y - 1, -1)] + q[(x - y, -1)] + 2) >> 2
+                elif x < y:
+                    v = (q[(-1, y - x - 2)] + 2 * q[(-1, y - x - 1)] + q[(-1, y - x)] + 2) >> 2
+                else:
+                    v = (q[(0, -1)] + 2 * q[(-1, -1)] + q[(-1, 0)] + 2) >> 2
+            elif mode == 5:
+                z = 2 * x - y
+                if z >= 0 and z % 2 == 0:
+                    v = (q[(x - (y >> 1) - 1, -1)] + q[(x - (y >> 1), -1)] + 1) >> 1
+                elif z >= 0:
+                    v = (q[(x - (y >> 1) - 2, -1)] + 2 * q[(x - (y >> 1) - 1, -1)] + q[(x - (y >> 1), -1)] + 2) >> 2
+                elif z == -1:
+                    v = (q[(-1, 0)] + 2 * q[(-1, -1)] + q[(0, -1)] + 2) >> 2
+                else:
+                    v = (q[(-1, y - 2 * x - 1)] + 2 * q[(-1, y - 2 * x - 2)] + q[(-1, y - 2 * x - 3)] + 2) >> 2
+            elif mode == 6:
+                z = 2 * y - x
+                if z >= 0 and z % 2 == 0:
+                    v = (q[(-1, y - (x >> 1) - 1)] + q[(-1, y - (x >> 1))] + 1) >> 1
+                elif z >= 0:
+                    v = (q[(-1, y - (x >> 1) - 2)] + 2 * q[(-1, y - (x >> 1) - 1)] + q[(-1, y - (x >> 1))] + 2) >> 2
+                elif z == -1:
+                    v = (q[(-1, 0)] + 2 * q[(-1, -1)] + q[(0, -1)] + 2) >> 2
+                else:
+                    v = (q[(x - 2 * y - 1, -1)] + 2 * q[(x - 2 * y - 2, -1)] + q[(x - 2 * y - 3, -1)] + 2) >> 2
+            elif mode == 7:
+                if y % 2 == 0:
+                    v = (q[(x + (y >> 1), -1)] + q[(x + (y >> 1) + 1, -1)] + 1) >> 1
+                else:
+                    v = (q[(x + (y >> 1), -1)] + 2 * q[(x + (y >> 1) + 1, -1)] + q[(x + (y >> 1) + 2, -1)] + 2) >> 2
+            else:
+                z = x + 2 * y
+                if z > 13:
+                    v = q[(-1, 7)]
+                elif z == 13:
+                    v = (q[(-1, 6)] + 3 * q[(-1, 7)] + 2) >> 2
+                elif z % 2 == 0:
+                    v = (q[(-1, y + (x >> 1))] + q[(-1, y + (x >> 1) + 1)] + 1) >> 1
+                else:
+                    v = (q[(-1, y + (x >> 1))] + 2 * q[(-1, y + (x >> 1) + 1)] + q[(-1, y + (x >> 1) + 2)] + 2) >> 2
+            out[y][x] = v
+    Y[y0:y0 + 8, x0:x0 + 8] = np.array(out, np.int32)
+
+
+BLK8_FIRST = [0, 4, 8, 12]  # luma4x4BlkIdx of the first 4x4 block of 8x8 block b8
 
 # B slice mb_type (Table 7-14): (partition shape, prediction of partition 0, of partition 1); predictions: 0 = L0, 1 = L1, 2 = Bi
 B_MB = {1: ("16x16", 0, None), 2: ("16x16", 1, None), 3: ("16x16", 2, None), 4: ("16x8", 0, 0), 5: ("8x16", 0, 0), 6: ("16x8", 1, 1),
@@ -98,10 +276,10 @@ SHAPE_PARTS = {"16x16": [(0, 0, 4, 4)], "16x8": [(0, 0, 4, 2), (0, 2, 4, 2)], "8
 
 class MBInfo:
     __slots__ = ("typ", "i16", "qp", "cbp_luma", "cbp_chroma", "chroma_mode", "modes", "cbf_dc", "cbf_luma", "cbf_cdc", "cbf_cac",
-                 "qp_delta_nz", "skip", "direct16", "intra", "ref0")
+                 "qp_delta_nz", "skip", "direct16", "intra", "ref0", "t8")
 
     def __init__(self):
-        self.typ = None        # "I4", "I16", "P" (any inter macroblock)
+        self.typ = None        # "I4", "I8" (both mb_type I_NxN), "I16", "P" (any inter macroblock)
         self.modes = [2] * 16
         self.cbf_dc = 0
         self.cbf_luma = [0] * 16
@@ -115,6 +293,7 @@ class MBInfo:
         self.direct16 = False  # B_Skip or B_Direct_16x16 (mb_type's context increment)
         self.intra = False
         self.ref0 = False      # P_8x8ref0 (CAVLC): no ref_idx is sent, all zero
+        self.t8 = False        # transform_size_8x8_flag
         self.i16 = 0
         self.qp = 0
 
@@ -233,7 +412,8 @@ class _CSlice(_C.Structure):
     _fields_ = [(n, _C.c_int32) for n in ("mb_w", "mb_h", "slice_type", "cabac", "qp", "chroma_qp_offset", "disable_deblock",
                                           "filter_offset_a", "filter_offset_b", "direct_spatial", "direct_8x8_inference")] + \
                [("nref", _C.c_int32 * 2), ("weighted_mode", _C.c_int32), ("luma_log2_denom", _C.c_int32), ("chroma_log2_denom", _C.c_int32),
-                ("weights", _C.c_int32 * (2 * 32 * 3 * 2)), ("data_bit_offset", _C.c_int32)]
+                ("weights", _C.c_int32 * (2 * 32 * 3 * 2)), ("data_bit_offset", _C.c_int32), ("transform_8x8_mode", _C.c_int32),
+                ("chroma_qp_offset_cr", _C.c_int32)]
 
 
 class NativePic:
@@ -283,6 +463,7 @@ def _decode_native(dec, h, r, cur, lists, payload):
                 base = ((lst * 32 + i) * 3) * 2
                 cs.weights[base:base + 6] = [lw, lo, cw[0], co[0], cw[1], co[1]]
     cs.data_bit_offset = r.p
+    cs.transform_8x8_mode, cs.chroma_qp_offset_cr = int(pps.get("transform8x8", 0)), pps.get("chroma_qp_offset2", pps["chroma_qp_offset"])
     arrs = []
     for lst, n in ((0, n0), (1, n1)):
         a = (_CPic * max(n, 1))()
@@ -301,8 +482,10 @@ def _decode_native(dec, h, r, cur, lists, payload):
         if "not implemented" in msg:
             raise Unsupported(msg)
         raise AssertionError(f"{msg} ({'PBI'[h['type']]} picture, sample {cur.sample})")
-    cur.stats = {"I4": stats[0], "I16": stats[1], "skip": stats[2], "inter": stats[3], "type": "PBI"[h["type"]], "slice_qp": h["qp"],
-                 "bits_left": stats[4]}
+    cur.stats = {"I4": stats[0], "I16": stats[1], "skip": stats[2], "inter": stats[3], "type": "PBI"[h["type"]], "slice_qp": h["qp"]}
+    if pps.get("transform8x8"):
+        cur.stats["I8"], cur.stats["t8"] = stats[5], stats[6]
+    cur.stats["bits_left"] = stats[4]
 
 
 
@@ -316,8 +499,8 @@ class H264Decoder:
         if engine not in ("native", "python"):
             raise ValueError(f"engine {engine!r}: 'native' (csrc/h264dec.hip) or 'python'")
         self.engine = engine
-        if sps["profile"] not in (66, 77):
-            raise Unsupported(f"profile_idc {sps['profile']}: Baseline / Main only")
+        if sps["profile"] not in (66, 77, 100):
+            raise Unsupported(f"profile_idc {sps['profile']}: Baseline / Main / High (8-bit 4:2:0) only")
         if pps["constrained_intra"]:
             raise Unsupported("constrained_intra_pred_flag = 1 is not implemented")
         self.sps, self.pps = sps, pps
@@ -514,11 +697,14 @@ class _SliceDecoder:
         self.dec, self.h, self.r, self.pic, self.lists = dec, h, r, cur, lists
         self.sps, self.pps = dec.sps, dec.pps
         self.stype = h["type"]
-        self.cab = Cabac(r, h["qp"], CTX_I if self.stype == 2 else CTX_PB0) if self.pps["cabac"] else None
+        self.cab = Cabac(r, h["qp"], CTX_I_HIGH if self.stype == 2 else CTX_PB0_HIGH) if self.pps["cabac"] else None
         self._payload = payload
         self.qp = h["qp"]
         self.prev_qp_delta_nz = 0
         self.stats = {"I4": 0, "I16": 0, "skip": 0, "inter": 0, "type": "PBI"[self.stype], "slice_qp": h["qp"]}
+        self.t8mode = bool(self.pps.get("transform8x8"))
+        if self.t8mode:
+            self.stats["I8"] = self.stats["t8"] = 0
         # implicit bi-prediction weights per (ref0, ref1) index pair (8.4.2.3.1)
         self.implicit = {}
         if self.stype == 1 and self.pps["weighted_bipred_idc"] == 2:
@@ -917,7 +1103,7 @@ class _SliceDecoder:
         # ---- mb_type
         inter = None  # (shape, [prediction of partition 0, 1]) or "8x8"
         if stype == 2:
-            inc = (1 if (A is not None and A.typ != "I4") else 0) + (1 if (Bn is not None and Bn.typ != "I4") else 0)
+            inc = (1 if (A is not None and A.typ not in ("I4", "I8")) else 0) + (1 if (Bn is not None and Bn.typ not in ("I4", "I8")) else 0)
             if cab.decision(3 + inc) == 0:
                 m.typ = "I4"
             else:
@@ -988,6 +1174,8 @@ class _SliceDecoder:
         m.typ = "P"
         self.stats["inter"] += 1
         # ---- motion data
+        inf8 = bool(self.sps["direct_8x8_inference"])
+        no_sub8 = inf8 if inter == "direct" else True  # noSubMbPartSizeLessThan8x8Flag (7.3.5), refined for 8x8 below
         if inter == "direct":
             self._direct(mx, my, (0, 1, 2, 3))
             parts = [(0, 0, 2, 2), (2, 0, 2, 2), (0, 2, 2, 2), (2, 2, 2, 2)] if self.sps["direct_8x8_inference"] else \
@@ -996,6 +1184,7 @@ class _SliceDecoder:
         else:
             if inter == "8x8":
                 subs = self._sub_mb_types()
+                no_sub8 = all((sh == "8x8") or (sh == "direct" and inf8) for sh, _ in subs)
                 # partitions: (x, y, w, h, prediction, shape for the directional rule, index for it, reference group)
                 plist = []
                 dq = [q for q in range(4) if subs[q][0] == "direct"]
@@ -1055,6 +1244,9 @@ class _SliceDecoder:
         self._predict_inter(mx, my, parts)
         # ---- coded_block_pattern, mb_qp_delta, residual
         self._cbp(m, A, Bn)
+        if self.t8mode and m.cbp_luma and no_sub8 and self._t8_flag(A, Bn):
+            m.t8 = True
+            self.stats["t8"] += 1
         self._qp_delta(m, coded=bool(m.cbp_luma or m.cbp_chroma))
         self._residual(mx, my, m, A, Bn)
 
@@ -1100,6 +1292,49 @@ class _SliceDecoder:
         self.prev_qp_delta_nz = m.qp_delta_nz
         m.qp = self.qp
 
+    def _t8_flag(self, A, Bn):
+        """transform_size_8x8_flag (ctxIdx 399 + the neighbours' flags)"""
+        return self.cab.decision(399 + (1 if (A is not None and A.t8) else 0) + (1 if (Bn is not None and Bn.t8) else 0))
+
+    def _residual_block8(self):
+        """the 64 levels of an 8x8 luma block in scan order (ctxBlockCat 5; its coded_block_flag is not sent in 4:2:0: inferred 1)"""
+        cab = self.cab
+        coef = [0] * 64
+        sig = []
+        last = 63
+        for i in range(63):
+            if cab.decision(402 + SIG8[i]):
+                sig.append(i)
+                if cab.decision(417 + LAST8[i]):
+                    last = None
+                    break
+        if last is not None:
+            sig.append(63)
+        eq1, gt1 = 0, 0
+        for i in reversed(sig):
+            inc_ = 0 if gt1 else min(4, 1 + eq1)
+            v = 0
+            if cab.decision(426 + inc_):
+                inc2 = 5 + min(4, gt1)
+                v = 1
+                while v < 14 and cab.decision(426 + inc2):
+                    v += 1
+                if v == 14:
+                    k = 0
+                    while cab.bypass():
+                        v += 1 << k
+                        k += 1
+                        assert k < 24, "coefficient runaway: the CABAC decode lost synchronisation"
+                    while k:
+                        k -= 1
+                        v += cab.bypass() << k
+            if v == 0:
+                eq1 += 1
+            else:
+                gt1 += 1
+            coef[i] = -(v + 1) if cab.bypass() else v + 1
+        return coef
+
     def _i4_mode(self):
         """prev_intra4x4_pred_mode_flag / rem_intra4x4_pred_mode -> None (use the predicted mode) or rem"""
         cab = self.cab
@@ -1125,10 +1360,14 @@ class _SliceDecoder:
         X4, Y4 = mx * 4, my * 4
         m.intra = True
         pic.intra4[Y4:Y4 + 4, X4:X4 + 4] = True
+        if m.typ == "I4" and self.t8mode and self._t8_flag(A, Bn):
+            m.typ, m.t8 = "I8", True  # (mb_type I_NxN with transform_size_8x8_flag: Intra 8x8)
         self.stats[m.typ] += 1
         pic.done[Y4:Y4 + 4, X4:X4 + 4] = True  # (refIdx -1 in both lists: "available, not inter")
-        if m.typ == "I4":
-            for blk in range(16):
+        if m.typ in ("I4", "I8"):
+            # Intra 4x4: sixteen blocks; Intra 8x8: four, whose neighbours are the 4x4 blocks left of / above their first 4x4 block
+            # (8.3.2.1: Intra4x4PredMode[8x8 index * 4 + 1] of the left, [... + 2] of the upper neighbour); a mode is kept per 4x4 slot
+            for blk in (range(16) if m.typ == "I4" else BLK8_FIRST):
                 bx, by = BLK_XY[blk]
 
                 def nmode(dx, dy):
@@ -1136,16 +1375,21 @@ class _SliceDecoder:
                     nb = m if (0 <= x < 4 and 0 <= y < 4) else pic.mb(mx + (x // 4 if x < 0 or x > 3 else 0), my + (y // 4 if y < 0 or y > 3 else 0))
                     if nb is None:
                         return None
-                    if nb.typ != "I4":
+                    if nb.typ not in ("I4", "I8"):
                         return 2
                     return nb.modes[XY_BLK[(x % 4, y % 4)]]
 
                 ma, mb_ = nmode(-1, 0), nmode(0, -1)
                 pred = 2 if (ma is None or mb_ is None) else min(ma, mb_)
                 rem = self._i4_mode()
-                m.modes[blk] = pred if rem is None else (rem if rem < pred else rem + 1)
+                mode = pred if rem is None else (rem if rem < pred else rem + 1)
+                if m.typ == "I4":
+                    m.modes[blk] = mode
+                else:
+                    for k in range(4):
+                        m.modes[blk + k] = mode
         m.chroma_mode = self._chroma_mode(A, Bn)
-        if m.typ == "I4":
+        if m.typ in ("I4", "I8"):
             self._cbp(m, A, Bn)
         self._qp_delta(m, coded=(m.typ == "I16" or bool(m.cbp_luma or m.cbp_chroma)))
         pic.mbs[addr] = m
@@ -1172,7 +1416,26 @@ class _SliceDecoder:
             else:
                 dc16 = [[(f[i][j] * ls + (1 << (5 - qpy // 6))) >> (6 - qpy // 6) for j in range(4)] for i in range(4)]
             pred16(pic, m, mx, my)
-        for blk in range(16):
+        if m.t8:
+            # 8x8 transform: four luma blocks of 64 levels each (their coded_block_flag is inferred), Intra 8x8 prediction interleaved
+            for b8 in range(4):
+                bx8, by8 = b8 & 1, b8 >> 1
+                if m.typ == "I8":
+                    pred8(pic, m, mx, my, b8)
+                if (m.cbp_luma >> b8) & 1:
+                    lv = self._residual_block8()
+                    d = [[0] * 8 for _ in range(8)]
+                    for k, (x, y) in enumerate(ZIGZAG8):
+                        if lv[k]:
+                            ls8 = level_scale8(qpy, y, x)
+                            d[y][x] = (lv[k] * ls8) << (qpy // 6 - 6) if qpy >= 36 else (lv[k] * ls8 + (1 << (5 - qpy // 6))) >> (6 - qpy // 6)
+                    rr = np.array(idct8(d), np.int32)
+                    ys, xs = slice(py + by8 * 8, py + by8 * 8 + 8), slice(px + bx8 * 8, px + bx8 * 8 + 8)
+                    pic.Y[ys, xs] = np.clip(pic.Y[ys, xs] + rr, 0, 255)
+                    for k in range(4):
+                        m.cbf_luma[BLK8_FIRST[b8] + k] = 1
+                    pic.nz[Y4 + by8 * 2:Y4 + by8 * 2 + 2, X4 + bx8 * 2:X4 + bx8 * 2 + 2] = True
+        for blk in (range(16) if not m.t8 else ()):
             bx, by = BLK_XY[blk]
             d = None
             coded = False
@@ -1203,10 +1466,11 @@ class _SliceDecoder:
                 pic.Y[ys, xs] = np.clip(pic.Y[ys, xs] + rr, 0, 255)
         if m.intra:
             pred_chroma(pic, m, mx, my)
-        qpc = QPC[min(max(qpy + pps["chroma_qp_offset"], 0), 51)]
+        qpcs = [QPC[min(max(qpy + pps[key], 0), 51)] for key in ("chroma_qp_offset", "chroma_qp_offset2")]
         dcs = [[0] * 4, [0] * 4]
         if m.cbp_chroma:
             for comp in range(2):
+                qpc = qpcs[comp]
                 lv, m.cbf_cdc[comp] = self._residual_block(m, A, Bn, 3, 4, comp=comp)
                 c = [[lv[0], lv[1]], [lv[2], lv[3]]]
                 f = [[c[0][0] + c[0][1] + c[1][0] + c[1][1], c[0][0] - c[0][1] + c[1][0] - c[1][1]],
@@ -1220,6 +1484,7 @@ class _SliceDecoder:
                     lv, m.cbf_cac[comp][blk] = self._residual_block(m, A, Bn, 4, 15, blk & 1, blk >> 1, comp)
                     acs[comp][blk] = [0] + lv
         for comp in range(2):
+            qpc = qpcs[comp]
             for blk in range(4):
                 bx, by = blk & 1, blk >> 1
                 d = [[0] * 4 for _ in range(4)]
@@ -1302,6 +1567,8 @@ class _CavlcSliceDecoder(_SliceDecoder):
         super().__init__(*a, **k)
         if self.stype == 1:
             raise Unsupported("B slices with CAVLC entropy coding")
+        if self.t8mode:
+            raise Unsupported("the 8x8 transform with CAVLC entropy coding")
         pic = self.pic
         pic.tc = np.zeros((pic.Hh * 4, pic.W * 4), np.int32)                              # TotalCoeff of luma 4x4 blocks
         pic.tcc = [np.zeros((pic.Hh * 2, pic.W * 2), np.int32) for _ in range(2)]         # ... of chroma AC blocks
@@ -1516,10 +1783,10 @@ def _bs(pic, py4, px4, qy4, qx4, mb_edge):
 
 
 def deblock_inter(pic, off_a, off_b):
-    cqo = pic.pps["chroma_qp_offset"]
+    cqos = (pic.pps["chroma_qp_offset"], pic.pps.get("chroma_qp_offset2", pic.pps["chroma_qp_offset"]))
 
-    def qpc(q):
-        return QPC[min(max(q + cqo, 0), 51)]
+    def qpc(q, comp):
+        return QPC[min(max(q + cqos[comp], 0), 51)]
 
     all_intra = bool(pic.intra4.all())
     for my in range(pic.Hh):
@@ -1530,6 +1797,9 @@ def deblock_inter(pic, off_a, off_b):
                 for e in range(4):
                     if e == 0 and nb is None:
                         continue
+                    luma_edge = not (m.t8 and e % 2)  # (8x8 transform: the luma edges inside the 8x8 blocks are not filtered)
+                    if not luma_edge and e % 2:
+                        continue                      # (odd edges never carry chroma)
                     # boundary strengths of the edge's four 4-sample segments
                     bss = []
                     for k in range(4):
@@ -1543,9 +1813,9 @@ def deblock_inter(pic, off_a, off_b):
                     if not any(bss):
                         continue
                     qp_p = nb.qp if e == 0 else m.qp
-                    planes = [(pic.Y, 16, True, (qp_p + m.qp + 1) >> 1)]
+                    planes = [(pic.Y, 16, True, (qp_p + m.qp + 1) >> 1)] if luma_edge else []
                     if e % 2 == 0:
-                        planes += [(P, 8, False, (qpc(qp_p) + qpc(m.qp) + 1) >> 1) for P in pic.C]
+                        planes += [(P, 8, False, (qpc(qp_p, c) + qpc(m.qp, c) + 1) >> 1) for c, P in enumerate(pic.C)]
                     for P, size, luma, qpav in planes:
                         idx_a, idx_b = min(max(qpav + off_a, 0), 51), min(max(qpav + off_b, 0), 51)
                         alpha, beta = ALPHA[idx_a], BETA[idx_b]

@@ -214,8 +214,14 @@ def parse_sps(nal):
     r.u(8)
     s["level"] = r.u(8)
     r.ue()
-    if s["profile"] not in (66, 77):
-        raise NotImplementedError(f"H.264 profile_idc {s['profile']}: only Baseline / Main are implemented (no 8x8 transform, no scaling matrices)")
+    if s["profile"] not in (66, 77, 100):
+        raise NotImplementedError(f"H.264 profile_idc {s['profile']}: only Baseline / Main / High (8-bit 4:2:0) are implemented")
+    if s["profile"] == 100:
+        cf = r.ue()
+        bd_l, bd_c, qpz, ssm = r.ue(), r.ue(), r.u(1), r.u(1)
+        if cf != 1 or bd_l or bd_c or qpz or ssm:
+            raise NotImplementedError(f"High profile with chroma_format_idc {cf}, bit depths 8 + {bd_l} / 8 + {bd_c}, "
+                                      f"qpprime_y_zero_transform_bypass {qpz}, scaling matrices {ssm}: only 8-bit 4:2:0 with flat matrices")
     s["log2_max_frame_num"] = r.ue() + 4
     s["poc_type"] = r.ue()
     if s["poc_type"] == 0:
@@ -254,6 +260,19 @@ def parse_pps(nal):
     p["deblocking_control"] = r.u(1)
     p["constrained_intra"] = r.u(1)
     p["redundant_pic_cnt"] = r.u(1)
+    # High profile tail, present if more_rbsp_data(): transform_8x8_mode_flag, pic_scaling_matrix_present_flag,
+    # second_chroma_qp_index_offset
+    p["transform8x8"], p["chroma_qp_offset2"] = 0, p["chroma_qp_offset"]
+    d = r.d
+    n = len(d)
+    while n and d[n - 1] == 0:
+        n -= 1
+    stop = (n - 1) * 8 + 7 - ((d[n - 1] & -d[n - 1]).bit_length() - 1) if n else 0
+    if r.p < stop:
+        p["transform8x8"] = r.u(1)
+        if r.u(1):
+            raise NotImplementedError("pic_scaling_matrix_present_flag = 1 (scaling matrices) is not implemented")
+        p["chroma_qp_offset2"] = r.se()
     return p
 
 
@@ -449,6 +468,8 @@ def decode_intra(track, index=0):
     sps, pps = track.sps, track.pps
     if not pps["cabac"]:
         raise NotIntraCoded("CAVLC entropy coding is not implemented (CABAC streams only)")
+    if pps.get("transform8x8"):
+        raise NotIntraCoded("the 8x8 transform (High profile) is not implemented in the intra-only module: use io/_h264.py")
     slices = [n for n in track.nal_units(index) if n and (n[0] & 31) in (1, 5)]
     if len(slices) != 1 or (slices[0][0] & 31) != 5:
         raise NotIntraCoded(f"sample {index} of {track.path} is not a single-slice IDR picture: only key frames can be decoded "

@@ -6,8 +6,9 @@ sleap/nn/data/providers.py:371-439, "we don't parallelize here for thread safety
 * `Video` -- the thin facade of sleap/io/video.py:1023-1508 over array-like backends: `NumpyVideo` (in-memory array or a
   memory-mapped `.npy`, sleap/io/video.py:511-590) and `HDF5Video` (dataset of frames in an HDF5 file with the reference's
   `input_format` / `convert_range` options, sleap/io/video.py:47-338). `MediaVideo` (sleap/io/video.py:340-504, cv2 / FFmpeg
-  there): no decoder exists in this image or on the GPU box, so round 6 brought its own -- progressive Baseline / Main-profile H.264
-  (I, P and B pictures, CAVLC and CABAC) in MP4 (io/_h264.py over io/_h264_intra.py); High-profile files raise.
+  there): no decoder exists in this image or on the GPU box, so round 6 brought its own -- progressive 8-bit 4:2:0 Baseline / Main / High-
+  profile H.264 (I, P and B pictures, CAVLC and CABAC, 8x8 transform) in MP4 (io/_h264.py over io/_h264_intra.py, native engine
+  csrc/h264dec.hip).
 * `VideoReader` -- the provider surface (`videos`, `example_indices`, `len`, `make_dataset()` yielding the same example
   dictionaries).
 * `FramePrefetcher` -- the throughput piece: a producer thread reads whole batches ahead of the consumer into a small ring
@@ -246,9 +247,9 @@ class SingleImageVideo:
 class MediaVideo:
     """sleap/io/video.py:340-504 (`MediaVideo`: cv2.VideoCapture over FFmpeg) for H.264 in MP4 / MOV through the package's own
     decoder (neither this image nor the GPU box holds one: profiles/r06_decoder_probe.txt): io/_h264.py decodes the I, P and B
-    pictures of progressive Baseline / Main-profile streams (CAVLC and CABAC: the reference's small_robot.mp4,
-    centered_pair_low_quality.mp4, centered_pair_small.mp4, dance.mp4); High-profile files raise NotImplementedError naming the
-    missing coding tool. Frame k is the k-th picture in PRESENTATION order (the MP4's composition
+    pictures of progressive 8-bit 4:2:0 Baseline / Main / High-profile streams (CAVLC and CABAC, 8x8 transform: all six .mp4
+    files of the reference's test data); scaling matrices, fields and several slices per picture raise NotImplementedError naming
+    the missing coding tool. Frame k is the k-th picture in PRESENTATION order (the MP4's composition
     times), as cv2 numbers frames. The macroblock layer runs in the package's library (`sa_h264_decode_slice`, host C++:
     240-450 pictures/s on one core); sequential reads decode every picture once, a jump decodes from the key frame in front of the target (`keyframes`). Colour conversion, channel handling and the
     `grayscale` / `bgr` attributes follow the reference: BGR as libswscale delivers it to cv2, `grayscale` "auto" = detected on

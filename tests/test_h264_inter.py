@@ -113,8 +113,8 @@ def test_unsupported_streams_are_refused_by_name():
     sps = {"profile": 77, "mb_w": 2, "mb_h": 2, "log2_max_frame_num": 4, "poc_type": 0, "log2_max_poc_lsb": 4, "num_ref_frames": 1,
            "direct_8x8_inference": 1, "crop": (0, 0, 0, 0)}
     pps = {"cabac": 1, "constrained_intra": 0, "num_ref_idx_default": (1, 1), "weighted_pred": 0, "weighted_bipred_idc": 0}
-    with pytest.raises(NotImplementedError, match="profile_idc 100"):
-        D.H264Decoder(dict(sps, profile=100), pps)
+    with pytest.raises(NotImplementedError, match="profile_idc 110"):  # High 10 (High itself is read since the 8x8 transform exists)
+        D.H264Decoder(dict(sps, profile=110), pps)
     with pytest.raises(NotImplementedError, match="constrained_intra_pred"):
         D.H264Decoder(sps, dict(pps, constrained_intra=1))
 

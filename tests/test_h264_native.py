@@ -13,7 +13,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 VID = os.path.join(ROOT, "tests", "golden", "video")
 
 
-@pytest.mark.parametrize("name,n", [("centered_pair_low_quality.mp4", 9), ("centered_pair_small.mp4", 6), ("dance.mp4", 8), ("small_robot.mp4", 6)])
+@pytest.mark.parametrize("name,n", [("centered_pair_low_quality.mp4", 9), ("centered_pair_small.mp4", 6), ("dance.mp4", 8), ("small_robot.mp4", 6),
+                                    ("small_robot_3_frame.mp4", 3), ("clip.mp4", 3)])
 def test_native_decoder_equals_the_python_decoder(name, n):
     from sleap_amd.io import _h264 as D
     from sleap_amd.io import _h264_intra as H
@@ -34,6 +35,8 @@ def test_native_decoder_equals_the_python_decoder(name, n):
         np.testing.assert_array_equal(pa.intra4.astype(bool), pb.intra4)
         assert (pa.poc, pa.frame_num) == (pb.poc, pb.frame_num)
     assert kinds[0] == "I" and "P" in kinds and (name == "small_robot.mp4" or "B" in kinds)
+    if name in ("small_robot_3_frame.mp4", "clip.mp4"):  # High profile: Intra 8x8 macroblocks and the 8x8 transform are in play
+        assert tr.sps["profile"] == 100 and tr.pps["transform8x8"] == 1 and a.dpb[0].stats["I8"] > 100
 
 
 def test_native_decoder_reports_a_corrupted_slice_instead_of_decoding_garbage():
@@ -73,3 +76,30 @@ def test_gop_parallel_reads_equal_sequential_reads_across_a_key_frame():
     np.testing.assert_array_equal(par.get_frame(3), seq.get_frame(3))  # backwards
     with pytest.raises(KeyError, match="Unable to load frame 1100"):
         par.get_frame(1100)
+
+
+def test_high_profile_file_against_the_baseline_encoding_of_the_same_frames():
+    """tests/data/videos/small_robot_3_frame.mp4 (High profile: Intra 8x8, 8x8 transform, CABAC, I + P + B) holds frames 56, 86, 116 of
+    small_robot.mp4 re-encoded from full-range images: its planes are the Baseline file's through the limited -> full range map
+    (gains 255 / 219 and 255 / 224), so after an affine fit per plane the two decodes -- different profiles, entropy coders,
+    transforms and picture types -- must agree to the encoders' quantisation (measured: luma 39.9 / 39.0 / 38.5 dB, chroma 41-43)."""
+    from sleap_amd.io import _h264 as D
+
+    hi = D.H264Reader(os.path.join(VID, "small_robot_3_frame.mp4"))
+    base = D.H264Reader(os.path.join(VID, "small_robot.mp4"))
+    for k, j in enumerate((56, 86, 116)):
+        for comp, want_gain in ((0, 255 / 219), (1, 255 / 224), (2, 255 / 224)):
+            a, b = hi.frame(k)[comp].astype(np.float64), base.frame(j)[comp].astype(np.float64)
+            A = np.vstack([b.ravel(), np.ones(b.size)]).T
+            gain, off = np.linalg.lstsq(A, a.ravel(), rcond=None)[0]
+            ps = 10 * np.log10(255.0 ** 2 / np.mean((a - (gain * b + off)) ** 2))
+            assert abs(gain - want_gain) < 0.03 and ps >= (37.5 if comp == 0 else 40.0), (k, comp, gain, off, ps)
+
+
+def test_media_video_reads_the_1024_high_profile_clip():
+    from sleap_amd.io.video import Video
+
+    v = Video.from_filename(os.path.join(VID, "clip.mp4"))  # tests/data/tracks/clip.mp4: 1500 frames of 1024 x 1024, grey
+    assert v.shape == (1500, 1024, 1024, 1) and v.backend.keyframes[:3] == [0, 250, 500]
+    f = v.get_frames([0, 1, 2, 3])
+    assert f.shape == (4, 1024, 1024, 1) and 5 < float(f.mean()) < 60

@@ -1,5 +1,5 @@
 """Native slice decoder (csrc/h264dec.hip) against the Python one (io/_h264.py), picture by picture: planes and motion data must be
-equal.    python tools/h264_native_vs_python.py <file.mp4> [n_samples]     (result: profiles/r06_h264_native_vs_python.txt)"""
+equal.    python tools/h264_native_vs_python.py <file.mp4> [n_samples] [first sample: a key frame]     (result: profiles/r06_h264_native_vs_python.txt)"""
 import sys
 import time
 
@@ -11,11 +11,13 @@ from sleap_amd.io import _h264_intra as H
 
 path = sys.argv[1]
 tr = H.Mp4H264(path)
-n = min(int(sys.argv[2]) if len(sys.argv) > 2 else len(tr), len(tr))
+first = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+assert first in tr.sync, tr.sync
+n = min(int(sys.argv[2]) if len(sys.argv) > 2 else len(tr), len(tr) - first)
 a, b = D.H264Decoder(tr.sps, tr.pps, "native"), D.H264Decoder(tr.sps, tr.pps, "python")
 ta = tb = 0.0
 types = {"I": 0, "P": 0, "B": 0}
-for i in range(n):
+for i in range(first, first + n):
     nals = tr.nal_units(i)
     t0 = time.perf_counter()
     pa = a.decode_sample(nals, i)
