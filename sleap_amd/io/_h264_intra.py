@@ -1057,7 +1057,18 @@ def swscale_bgr(Y, Cb, Cr):
     return np.stack([np.clip(yy + bu, 0, 255), np.clip(yy - gu - gv, 0, 255), np.clip(yy + rv, 0, 255)], axis=-1).astype(np.uint8)
 
 
+def swscale_blue(Y, Cb):
+    """channel 0 (blue) of `swscale_bgr` alone -- what the reference keeps of a video it flagged grayscale (video.py:482-485);
+    a 256-entry uint8 table when the chroma plane is neutral"""
+    if not (Cb != 128).any():
+        return _SWS_GRAY[Y]
+    H, W = Y.shape
+    bu = np.repeat(np.repeat(_SWS_BU[Cb], 2, 0), 2, 1)[:H, :W]
+    return np.clip(_SWS_Y[Y] + bu, 0, 255).astype(np.uint8)
+
+
 _SWS_Y = (((np.arange(256, dtype=np.int32) - 16) << 3) * 9539) >> 16
+_SWS_GRAY = np.clip(_SWS_Y, 0, 255).astype(np.uint8)
 _SWS_C = (np.arange(256, dtype=np.int32) - 128) << 3
 _SWS_BU, _SWS_GU, _SWS_GV, _SWS_RV = (_SWS_C * 16531) >> 16, (_SWS_C * 3203) >> 16, (_SWS_C * 6660) >> 16, (_SWS_C * 13075) >> 16
 

@@ -274,7 +274,8 @@ class MediaVideo:
                 workers = min(len(os.sched_getaffinity(0)), 8)
             except AttributeError:
                 workers = 1
-        self._gops = _h264.GopPool(self._track, workers) if workers > 1 else None
+        self._blue = _h264_intra.swscale_blue
+        self._gops = _h264.GopPool(self._track, workers, convert=self._convert) if workers > 1 else None
         if self._gops is not None and not self._gops.closed:
             self._gops = None
         self._swscale = _h264_intra.swscale_bgr
@@ -282,7 +283,7 @@ class MediaVideo:
         self._lock = threading.Lock()  # (the decoder is a sequential state machine)
         self.grayscale = grayscale
         if grayscale is None:  # (video.py:391-396: detect on the first frame)
-            t = self._bgr_frame(0)
+            t = self._bgr_frame(0, want_bgr=True)
             self.grayscale = bool(np.all(t[..., 0] == t[..., -1]))
 
     frames = property(lambda self: len(self._track))
@@ -293,23 +294,38 @@ class MediaVideo:
     fps = property(lambda self: self._track.fps)
     keyframes = property(lambda self: [self._track.display_order.index(s) for s in self._track.sync])
 
-    def _bgr_frame(self, idx: int) -> np.ndarray:
+    def _convert(self, y, cb, cr):
+        """planes -> what the reference's reader yields before its channel handling: BGR, or -- once the video is known to be
+        grayscale -- its channel 0 alone (one table look-up for a grey stream). Runs on the decode threads."""
+        if self.grayscale:
+            return self._blue(y, cb)[..., None]
+        return self._swscale(y, cb, cr)
+
+    def _bgr_frame(self, idx: int, want_bgr: bool = False) -> np.ndarray:
+        """-> (H, W, 3) BGR, or (H, W, 1) channel 0 for a grayscale video unless `want_bgr`"""
         with self._lock:
-            if idx not in self._cache:
+            key = (idx, bool(want_bgr or not self.grayscale))
+            if key not in self._cache:
                 if len(self._cache) >= 16:
                     self._cache.pop(next(iter(self._cache)))
                 try:
-                    y, cb, cr = (self._gops or self._reader).frame(idx)
+                    if key[1] and self.grayscale is not False:  # all three channels of a (possibly) grayscale video: from the planes
+                        y, cb, cr = self._reader.frame(idx)
+                        self._cache[key] = self._swscale(y, cb, cr)
+                    elif self._gops is not None:
+                        self._cache[key] = self._gops.frame(idx)
+                    else:
+                        self._cache[key] = self._convert(*self._reader.frame(idx))
                 except IndexError as e:
                     raise KeyError(f"Unable to load frame {idx} from {self.filename}: the video has {len(self._track)} frames") from e
-                self._cache[idx] = self._swscale(y, cb, cr)
-            return self._cache[idx]
+            return self._cache[key]
 
     def get_frame(self, idx: int, grayscale: Optional[bool] = None) -> np.ndarray:
-        frame = self._bgr_frame(int(idx))
-        if self.grayscale if grayscale is None else grayscale:
+        gray = self.grayscale if grayscale is None else grayscale
+        frame = self._bgr_frame(int(idx), want_bgr=not gray)
+        if gray and frame.shape[-1] != 1:
             frame = frame[..., 0][..., None]
-        if self.bgr:
+        if self.bgr and frame.shape[-1] == 3:
             frame = frame[..., ::-1]
         return np.ascontiguousarray(frame)
 

@@ -2,7 +2,7 @@
 GOPs decoded ahead on host threads) -> `Predictor.predict` of a SLEAP-trained model folder -> instances, and optionally the flow
 tracker. Prints frames/s of the whole call and how many frames hold two instances (the video shows two flies).
 
-    python tools/predict_mp4.py [video.mp4] [model dir] [tracker]
+    python tools/predict_mp4.py [video.mp4] [model dir | benchmark] [tracker]
 """
 import os
 import sys
@@ -17,7 +17,12 @@ model = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "tests", "golde
 from sleap_amd.io.video import Video, VideoReader
 from sleap_amd.nn.inference import load_model
 
-predictor = load_model(model, batch_size=64, progress_reporting="none")
+if model == "benchmark":  # the bench line's fitted flies13 UNet (1024 x 1024, 13 nodes): the headline network on a REAL 1024 x 1024 video
+    from sleap_amd.benchmark_model import build_benchmark_predictor
+
+    predictor = build_benchmark_predictor(1024, 1024, batch_size=64, seed=0)[0]
+else:
+    predictor = load_model(model, batch_size=64, progress_reporting="none")
 if len(sys.argv) > 3:
     from sleap_amd.nn.tracking import Tracker
 
