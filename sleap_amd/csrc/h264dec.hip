@@ -340,6 +340,7 @@ struct Slice {
   std::vector<int> implicit;     // [n0][n1][2]
   int64_t stop_bit = 0;
   int cur_mx = 0, cur_my = 0;
+  int cur_dx4 = 0, cur_dy4 = 0;  // 4x4 position of the macroblock direct_parts looks at
   int stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // I4, I16, skip, inter, bits_left
 
   // ---- accessors
@@ -523,6 +524,79 @@ struct Slice {
             fx * fy * S(p, w, h, xi + 1, yi + 1) + 32) >> 6;
   }
 
+  // Block forms of the two sample functions above (the same arithmetic; tests/test_h264_native.py compares whole pictures with the
+  // Python decoder): the (w + 5) x (h + 5) source window is gathered once -- rows copied when it lies inside the plane, clamped
+  // per sample at the picture border -- and the half-sample intermediates are computed per row / column instead of per sample.
+  static void gather(const uint8_t* p, int W_, int H_, int x0, int y0, int w, int h, int* R) {
+    if (x0 >= 0 && y0 >= 0 && x0 + w <= W_ && y0 + h <= H_) {
+      for (int j = 0; j < h; ++j) {
+        const uint8_t* r = p + (size_t)(y0 + j) * W_ + x0;
+        for (int i = 0; i < w; ++i) R[j * w + i] = r[i];
+      }
+    } else {
+      for (int j = 0; j < h; ++j) {
+        const uint8_t* r = p + (size_t)clip3(0, H_ - 1, y0 + j) * W_;
+        for (int i = 0; i < w; ++i) R[j * w + i] = r[clip3(0, W_ - 1, x0 + i)];
+      }
+    }
+  }
+  static void luma_block(const uint8_t* p, int W_, int H_, int xq, int yq, int w, int h, int* out) {
+    const int xi = xq >> 2, yi = yq >> 2, fx = xq & 3, fy = yq & 3;
+    if (fx == 0 && fy == 0) {
+      gather(p, W_, H_, xi, yi, w, h, out);
+      return;
+    }
+    const int RW = w + 5, RH = h + 5;
+    int R[21 * 21], B1[21 * 16], H1[16 * 21];
+    gather(p, W_, H_, xi - 2, yi - 2, RW, RH, R);  // R[r][c] = sample (xi - 2 + c, yi - 2 + r)
+    auto Rv = [&](int r, int c) { return R[r * RW + c]; };
+    const bool need_b = fy == 0 || fx == 2 || (fx != 0 && fy != 0);  // horizontal intermediates b1[r][c]: between columns xi + c, xi + c + 1, row yi - 2 + r
+    const bool need_h = fx == 0 || fy == 2 || (fx != 0 && fy != 0);  // vertical intermediates h1[r][c]: between rows yi + r, yi + r + 1, column xi - 2 + c
+    if (need_b || fx == 2 || fy == 2)
+      for (int r = 0; r < RH; ++r)
+        for (int c = 0; c < w; ++c) B1[r * 16 + c] = Rv(r, c) - 5 * Rv(r, c + 1) + 20 * Rv(r, c + 2) + 20 * Rv(r, c + 3) - 5 * Rv(r, c + 4) + Rv(r, c + 5);
+    if (need_h)
+      for (int r = 0; r < h; ++r)
+        for (int c = 0; c < RW; ++c) H1[r * 21 + c] = Rv(r, c) - 5 * Rv(r + 1, c) + 20 * Rv(r + 2, c) + 20 * Rv(r + 3, c) - 5 * Rv(r + 4, c) + Rv(r + 5, c);
+    for (int j = 0; j < h; ++j)
+      for (int i = 0; i < w; ++i) {
+        const int G = Rv(j + 2, i + 2);
+        int v;
+        if (fy == 0) {
+          const int b = clip1((B1[(j + 2) * 16 + i] + 16) >> 5);
+          v = fx == 2 ? b : ((b + (fx == 1 ? G : Rv(j + 2, i + 3)) + 1) >> 1);
+        } else if (fx == 0) {
+          const int hh = clip1((H1[j * 21 + i + 2] + 16) >> 5);
+          v = fy == 2 ? hh : ((hh + (fy == 1 ? G : Rv(j + 3, i + 2)) + 1) >> 1);
+        } else if (fx == 2 || fy == 2) {
+          const int j1 = B1[j * 16 + i] - 5 * B1[(j + 1) * 16 + i] + 20 * B1[(j + 2) * 16 + i] + 20 * B1[(j + 3) * 16 + i] - 5 * B1[(j + 4) * 16 + i] + B1[(j + 5) * 16 + i];
+          const int jj = clip1((j1 + 512) >> 10);
+          if (fx == 2 && fy == 2) {
+            v = jj;
+          } else {
+            const int o = fx == 2 ? clip1((B1[(j + (fy == 1 ? 2 : 3)) * 16 + i] + 16) >> 5) : clip1((H1[j * 21 + i + (fx == 1 ? 2 : 3)] + 16) >> 5);
+            v = (jj + o + 1) >> 1;
+          }
+        } else {
+          const int bb = clip1((B1[(j + (fy == 1 ? 2 : 3)) * 16 + i] + 16) >> 5), hh = clip1((H1[j * 21 + i + (fx == 1 ? 2 : 3)] + 16) >> 5);
+          v = (bb + hh + 1) >> 1;
+        }
+        out[j * w + i] = v;
+      }
+  }
+  static void chroma_block(const uint8_t* p, int W_, int H_, int x8, int y8, int w, int h, int* out) {
+    const int xi = x8 >> 3, yi = y8 >> 3, fx = x8 & 7, fy = y8 & 7;
+    if (fx == 0 && fy == 0) {
+      gather(p, W_, H_, xi, yi, w, h, out);
+      return;
+    }
+    int R[9 * 9];
+    gather(p, W_, H_, xi, yi, w + 1, h + 1, R);
+    const int RW = w + 1, w00 = (8 - fx) * (8 - fy), w10 = fx * (8 - fy), w01 = (8 - fx) * fy, w11 = fx * fy;
+    for (int j = 0; j < h; ++j)
+      for (int i = 0; i < w; ++i)
+        out[j * w + i] = (w00 * R[j * RW + i] + w10 * R[j * RW + i + 1] + w01 * R[(j + 1) * RW + i] + w11 * R[(j + 1) * RW + i + 1] + 32) >> 6;
+  }
   void predict_inter(int mx, int my, const Part* parts, int np) {
     const int X4 = mx * 4, Y4 = my * 4, LW = W * 16, LH = Hh * 16, CW = W * 8, CH = Hh * 8;
     const int mode = s->weighted_mode;
@@ -530,19 +604,43 @@ struct Slice {
     for (int k = 0; k < np; ++k) {
       const int x4 = X4 + parts[k].sx, y4 = Y4 + parts[k].sy, w = parts[k].w * 4, hh = parts[k].h * 4;
       int n = 0, rl[2], rr[2];
+      // the plain copy (one reference, whole-sample vector, no weighting, window inside the picture: most of a static scene's
+      // skipped macroblocks) goes row by row from plane to plane
+      {
+        const int r0 = REF(0, y4, x4), r1 = REF(1, y4, x4);
+        if ((r0 >= 0) != (r1 >= 0)) {
+          const int l = r0 >= 0 ? 0 : 1, rf = l ? r1 : r0;
+          const sa_h264_pic& rp = list(l)[rf];
+          H264_CHECK(rp.y, "prediction from an empty reference list entry");
+          const int mvx = MV(l, y4, x4)[0], mvy = MV(l, y4, x4)[1];
+          bool plain = mode != 1;
+          if (mode == 1) {
+            const int32_t(*wt)[2] = s->weights[l][rf];
+            plain = wt[0][0] == (1 << s->luma_log2_denom) && wt[0][1] == 0 && wt[1][0] == (1 << s->chroma_log2_denom) && wt[1][1] == 0 &&
+                    wt[2][0] == (1 << s->chroma_log2_denom) && wt[2][1] == 0;
+          }
+          const int sx = x4 * 4 + (mvx >> 2), sy = y4 * 4 + (mvy >> 2);
+          if (plain && !(mvx & 7) && !(mvy & 7) && sx >= 0 && sy >= 0 && sx + w <= LW && sy + hh <= LH) {
+            for (int j = 0; j < hh; ++j) memcpy(cur->y + (size_t)(y4 * 4 + j) * LW + x4 * 4, rp.y + (size_t)(sy + j) * LW + sx, (size_t)w);
+            for (int c = 0; c < 2; ++c) {
+              const uint8_t* src = c ? rp.cr : rp.cb;
+              uint8_t* dst = C(c);
+              for (int j = 0; j < hh / 2; ++j)
+                memcpy(dst + (size_t)(y4 * 2 + j) * CW + x4 * 2, src + (size_t)(sy / 2 + j) * CW + sx / 2, (size_t)(w / 2));
+            }
+            ++stats[7];
+            continue;
+          }
+        }
+      }
       for (int l = 0; l < 2; ++l) {
         const int rf = REF(l, y4, x4);
         if (rf < 0) continue;
         const sa_h264_pic& rp = list(l)[rf];
         H264_CHECK(rp.y, "prediction from an empty reference list entry");
         const int mvx = MV(l, y4, x4)[0], mvy = MV(l, y4, x4)[1];
-        for (int j = 0; j < hh; ++j)
-          for (int i = 0; i < w; ++i) py[n][j * w + i] = luma_sample(rp.y, LW, LH, (x4 * 4 + i) * 4 + mvx, (y4 * 4 + j) * 4 + mvy);
-        for (int c = 0; c < 2; ++c) {
-          const uint8_t* cp = c ? rp.cr : rp.cb;
-          for (int j = 0; j < hh / 2; ++j)
-            for (int i = 0; i < w / 2; ++i) pc[n][c][j * (w / 2) + i] = chroma_sample(cp, CW, CH, (x4 * 2 + i) * 8 + mvx, (y4 * 2 + j) * 8 + mvy);
-        }
+        luma_block(rp.y, LW, LH, x4 * 16 + mvx, y4 * 16 + mvy, w, hh, py[n]);
+        for (int c = 0; c < 2; ++c) chroma_block(c ? rp.cr : rp.cb, CW, CH, x4 * 16 + mvx, y4 * 16 + mvy, w / 2, hh / 2, pc[n][c]);
         rl[n] = l, rr[n] = rf;
         ++n;
       }
@@ -554,26 +652,29 @@ struct Slice {
         const int* a = comp ? pc[0][comp - 1] : py[0];
         const int* b = comp ? pc[1][comp - 1] : py[1];
         const int dn = comp ? cd : ld;
-        for (int j = 0; j < bh; ++j)
-          for (int i = 0; i < bw; ++i) {
-            int v;
-            if (n == 1) {
-              v = a[j * bw + i];
-              if (mode == 1) {
-                const int32_t* wt = s->weights[rl[0]][rr[0]][comp];
-                v = clip1((dn >= 1 ? ((v * wt[0] + (1 << (dn - 1))) >> dn) : v * wt[0]) + wt[1]);
-              }
-            } else if (mode == 1) {
-              const int32_t *w0 = s->weights[0][rr[0]][comp], *w1 = s->weights[1][rr[1]][comp];
-              v = clip1(((a[j * bw + i] * w0[0] + b[j * bw + i] * w1[0] + (1 << dn)) >> (dn + 1)) + ((w0[1] + w1[1] + 1) >> 1));
-            } else if (mode == 2) {
-              const int* iw = &implicit[((size_t)rr[0] * s->nref[1] + rr[1]) * 2];
-              v = clip1((a[j * bw + i] * iw[0] + b[j * bw + i] * iw[1] + 32) >> 6);
-            } else {
-              v = (a[j * bw + i] + b[j * bw + i] + 1) >> 1;
-            }
-            dst[(size_t)j * stride + i] = (uint8_t)v;
-          }
+        // (one loop per weighting form: the form is the same for every sample of the block)
+        if (n == 1 && mode != 1) {
+          for (int j = 0; j < bh; ++j)
+            for (int i = 0; i < bw; ++i) dst[(size_t)j * stride + i] = (uint8_t)a[j * bw + i];
+        } else if (n == 1) {
+          const int32_t* wt = s->weights[rl[0]][rr[0]][comp];
+          const int w0 = wt[0], o0 = wt[1], rnd = dn >= 1 ? 1 << (dn - 1) : 0;
+          for (int j = 0; j < bh; ++j)
+            for (int i = 0; i < bw; ++i) dst[(size_t)j * stride + i] = (uint8_t)clip1((dn >= 1 ? ((a[j * bw + i] * w0 + rnd) >> dn) : a[j * bw + i] * w0) + o0);
+        } else if (mode == 1) {
+          const int32_t *w0 = s->weights[0][rr[0]][comp], *w1 = s->weights[1][rr[1]][comp];
+          const int wa = w0[0], wb = w1[0], off = (w0[1] + w1[1] + 1) >> 1;
+          for (int j = 0; j < bh; ++j)
+            for (int i = 0; i < bw; ++i) dst[(size_t)j * stride + i] = (uint8_t)clip1(((a[j * bw + i] * wa + b[j * bw + i] * wb + (1 << dn)) >> (dn + 1)) + off);
+        } else if (mode == 2) {
+          const int* iw = &implicit[((size_t)rr[0] * s->nref[1] + rr[1]) * 2];
+          const int wa = iw[0], wb = iw[1];
+          for (int j = 0; j < bh; ++j)
+            for (int i = 0; i < bw; ++i) dst[(size_t)j * stride + i] = (uint8_t)clip1((a[j * bw + i] * wa + b[j * bw + i] * wb + 32) >> 6);
+        } else {
+          for (int j = 0; j < bh; ++j)
+            for (int i = 0; i < bw; ++i) dst[(size_t)j * stride + i] = (uint8_t)((a[j * bw + i] + b[j * bw + i] + 1) >> 1);
+        }
       }
     }
   }
@@ -1347,6 +1448,26 @@ struct Slice {
       for (int x = sx; x < sx + w; ++x) done[(size_t)(my * 4 + y) * W4 + mx * 4 + x] = v;
   }
   int direct_parts(Part* parts, int n, int q_mask) {  // the MC partitions of direct-predicted quadrants
+    if (q_mask == 15 && n == 0) {
+      // a wholly direct macroblock whose sixteen blocks ended up with the same motion (static background: the usual case) is
+      // predicted as ONE 16 x 16 partition -- the same samples as sixteen or four separate blocks, a quarter of the calls
+      const int X4 = cur_dx4, Y4 = cur_dy4;
+      bool same = true;
+      for (int l = 0; l < 2 && same; ++l) {
+        const int r = REF(l, Y4, X4);
+        const int16_t* m0 = MV(l, Y4, X4);
+        for (int y = 0; y < 4 && same; ++y)
+          for (int x = 0; x < 4; ++x)
+            if (REF(l, Y4 + y, X4 + x) != r || MV(l, Y4 + y, X4 + x)[0] != m0[0] || MV(l, Y4 + y, X4 + x)[1] != m0[1]) {
+              same = false;
+              break;
+            }
+      }
+      if (same) {
+        parts[n++] = {0, 0, 4, 4, 0, 0, 0, 0};
+        return n;
+      }
+    }
     for (int q = 0; q < 4; ++q) {
       if (!((q_mask >> q) & 1)) continue;
       const int qx = (q & 1) * 2, qy = (q >> 1) * 2;
@@ -1377,6 +1498,7 @@ struct Slice {
       m.direct16 = 1;
       const int quads[4] = {0, 1, 2, 3};
       direct_pred(mx, my, quads, 4);
+      cur_dx4 = mx * 4, cur_dy4 = my * 4;
       np = direct_parts(parts, 0, 15);
     }
     mark_done(mx, my, 0, 0, 4, 4, 1);
@@ -1427,6 +1549,7 @@ struct Slice {
     if (kind == 2) {
       const int quads[4] = {0, 1, 2, 3};
       direct_pred(mx, my, quads, 4);
+      cur_dx4 = mx * 4, cur_dy4 = my * 4;
       np = direct_parts(parts, 0, 15);
       mark_done(mx, my, 0, 0, 4, 4, 1);
     } else {
@@ -1496,7 +1619,10 @@ struct Slice {
         mark_done(mx, my, 0, 0, 4, 4, 1);
       }
       for (int k = 0; k < npl; ++k) parts[np++] = plist[k];
-      if (kind == 1) np = direct_parts(parts, np, dmask);
+      if (kind == 1) {
+        cur_dx4 = mx * 4, cur_dy4 = my * 4;
+        np = direct_parts(parts, np, dmask);
+      }
     }
     predict_inter(mx, my, parts, np);
     read_cbp(m, A, B);

@@ -486,6 +486,7 @@ def _decode_native(dec, h, r, cur, lists, payload):
     if pps.get("transform8x8"):
         cur.stats["I8"], cur.stats["t8"] = stats[5], stats[6]
     cur.stats["bits_left"] = stats[4]
+    cur.plain_copies = stats[7]
 
 
 
