@@ -704,6 +704,12 @@ typedef struct sa_h264_slice {
 int sa_h264_decode_slice(const sa_h264_slice* s, const uint8_t* rbsp, int64_t n_bytes, const sa_h264_pic* list0,
                          const sa_h264_pic* list1, sa_h264_pic* cur, int32_t* stats);
 
+/* The colour conversion behind cv2.VideoCapture.read as `MediaVideo` sees it (video.py:470-485: BGR frames, channel 0 kept for a
+ * grayscale video): limited-range BT.601 YCbCr 4:2:0 planes -> [height][width][channels] uint8, channels 3 = BGR, 1 = blue alone, with
+ * libswscale's SIMD arithmetic (13-bit coefficients, truncation). HOST buffers; strides in bytes. Checker: io/_h264_intra.py swscale_bgr. */
+int sa_yuv420_to_bgr(const uint8_t* y, const uint8_t* cb, const uint8_t* cr, int width, int height, int y_stride, int c_stride,
+                     uint8_t* out, int channels);
+
 #ifdef __cplusplus
 }
 #endif

@@ -125,6 +125,7 @@ SIGNATURES = {
     "sa_bottomup_workspace_bytes": (_sz, [_p, _p, _i, _i, _i]),
     "sa_bottomup_predict": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _sz, _p]),
     "sa_h264_decode_slice": (_i, [_p, _p, C.c_int64, _p, _p, _p, _p]),
+    "sa_yuv420_to_bgr": (_i, [_p, _p, _p, _i, _i, _i, _i, _p, _i]),
 }
 
 _lib = None

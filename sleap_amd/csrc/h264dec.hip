@@ -1789,14 +1789,50 @@ struct Slice {
   void deblock() {
     const int cqo[2] = {s->chroma_qp_offset, s->chroma_qp_offset_cr}, off_a = s->filter_offset_a, off_b = s->filter_offset_b;
     auto qpc = [&](int q, int comp) { return (int)QPC[clip3(0, 51, q + cqo[comp])]; };
+    // "flat" macroblocks -- inter, no coded luma block, one motion for all sixteen blocks (static background, skipped macroblocks) --
+    // have boundary strength 0 on every inner edge, and on an outer edge whose neighbour is flat with the same motion: most of a
+    // typical picture is decided here instead of by thirty-two block-pair comparisons per macroblock
+    std::vector<uint8_t> flat((size_t)W * Hh, 0);
+    for (int my = 0; my < Hh; ++my)
+      for (int mx = 0; mx < W; ++mx) {
+        const int X4 = mx * 4, Y4 = my * 4;
+        bool f = !mbs[(size_t)my * W + mx].intra;
+        for (int l = 0; l < 2 && f; ++l) {
+          const int32_t id0 = REFID(l, Y4, X4);
+          const int r0 = REF(l, Y4, X4);
+          const int16_t* m0 = MV(l, Y4, X4);
+          for (int y = 0; y < 4 && f; ++y)
+            for (int x = 0; x < 4; ++x)
+              if (REF(l, Y4 + y, X4 + x) != r0 || REFID(l, Y4 + y, X4 + x) != id0 || MV(l, Y4 + y, X4 + x)[0] != m0[0] || MV(l, Y4 + y, X4 + x)[1] != m0[1] ||
+                  (l == 0 && nz[(size_t)(Y4 + y) * W4 + X4 + x])) {
+                f = false;
+                break;
+              }
+        }
+        flat[(size_t)my * W + mx] = f;
+      }
+    auto same_motion = [&](int ax, int ay, int bx, int by) {  // of two flat macroblocks (their first blocks stand for all)
+      for (int l = 0; l < 2; ++l)
+        if (REF(l, ay * 4, ax * 4) < 0 ? REF(l, by * 4, bx * 4) >= 0
+                                       : (REF(l, by * 4, bx * 4) < 0 || REFID(l, ay * 4, ax * 4) != REFID(l, by * 4, bx * 4) ||
+                                          MV(l, ay * 4, ax * 4)[0] != MV(l, by * 4, bx * 4)[0] || MV(l, ay * 4, ax * 4)[1] != MV(l, by * 4, bx * 4)[1]))
+          return false;
+      return true;
+    };
     for (int my = 0; my < Hh; ++my)
       for (int mx = 0; mx < W; ++mx) {
         const MB& m = mbs[(size_t)my * W + mx];
+        const bool mflat = flat[(size_t)my * W + mx];
         for (int vertical = 1; vertical >= 0; --vertical) {
           const MB* n = vertical ? (mx > 0 ? &mbs[(size_t)my * W + mx - 1] : nullptr) : (my > 0 ? &mbs[(size_t)(my - 1) * W + mx] : nullptr);
           for (int e = 0; e < 4; ++e) {
             if (e == 0 && !n) continue;
             if (m.t8 && (e % 2)) continue;  // 8x8 transform: no luma edges inside the 8x8 blocks (odd edges carry no chroma either)
+            if (mflat && e > 0) continue;
+            if (mflat && e == 0) {
+              const int nx = vertical ? mx - 1 : mx, ny = vertical ? my : my - 1;
+              if (flat[(size_t)ny * W + nx] && same_motion(mx, my, nx, ny)) continue;
+            }
             int bss[4];
             bool any = false;
             for (int k = 0; k < 4; ++k) {
@@ -1936,5 +1972,30 @@ extern "C" int sa_h264_decode_slice(const sa_h264_slice* s, const uint8_t* rbsp,
   }
   if (stats)
     for (int i = 0; i < 8; ++i) stats[i] = sl.stats[i];
+  return SA_OK;
+}
+
+// Limited-range BT.601 YCbCr 4:2:0 -> BGR as libswscale's x86 SIMD path produces it (what cv2.VideoCapture hands to the reference's
+// MediaVideo; io/_h264_intra.py `swscale_bgr` / `swscale_blue` are the same arithmetic in NumPy and this function's checker):
+// 13-bit coefficients, truncating products of the samples shifted left by 3, chroma replicated 2 x 2, saturating pack.
+extern "C" int sa_yuv420_to_bgr(const uint8_t* y, const uint8_t* cb, const uint8_t* cr, int width, int height, int y_stride, int c_stride,
+                                uint8_t* out, int channels) {
+  SA_REQUIRE(y && cb && cr && out && width > 0 && height > 0 && y_stride >= width && c_stride >= (width + 1) / 2 && (channels == 1 || channels == 3),
+             "sa_yuv420_to_bgr: bad arguments");
+  for (int j = 0; j < height; ++j) {
+    const uint8_t *yr = y + (size_t)j * y_stride, *ur = cb + (size_t)(j >> 1) * c_stride, *vr = cr + (size_t)(j >> 1) * c_stride;
+    uint8_t* o = out + (size_t)j * width * channels;
+    for (int i = 0; i < width; ++i) {
+      const int yy = ((((int)yr[i] - 16) * 8) * 9539) >> 16;
+      const int u = ((int)ur[i >> 1] - 128) * 8, v = ((int)vr[i >> 1] - 128) * 8;
+      const int b = yy + ((u * 16531) >> 16);
+      if (channels == 1) {
+        o[i] = (uint8_t)clip1(b);
+      } else {
+        const int g = yy - ((u * 3203) >> 16) - ((v * 6660) >> 16), r = yy + ((v * 13075) >> 16);
+        o[3 * i] = (uint8_t)clip1(b), o[3 * i + 1] = (uint8_t)clip1(g), o[3 * i + 2] = (uint8_t)clip1(r);
+      }
+    }
+  }
   return SA_OK;
 }

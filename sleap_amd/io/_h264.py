@@ -1902,7 +1902,7 @@ class GopPool:
     throughput (`MediaVideo` with `workers` > 1). Falls back to None (-> the sequential `H264Reader`) for files whose GOPs are not
     closed in display order."""
 
-    def __init__(self, track, workers=4, engine="native", keep=None, budget_bytes=6 << 30, convert=None):
+    def __init__(self, track, workers=4, engine="native", keep=None, budget_bytes=6 << 30, convert=None, convert_pic=None):
         from concurrent.futures import ThreadPoolExecutor
 
         self.track, self.engine = track, engine
@@ -1920,6 +1920,7 @@ class GopPool:
         self._keep = keep or self.workers + 1
         self._cl = track.sps["crop"]
         self.convert = convert  # (Y, Cb, Cr) -> what `frame` returns (run on the worker threads); None: the planes
+        self.convert_pic = convert_pic  # or: picture -> what `frame` returns (native conversion straight from the picture's buffers)
 
     def _decode(self, g):
         tr = self.track
@@ -1929,6 +1930,9 @@ class GopPool:
         out = {}
         for i in range(self.starts[g], self.ends[g]):
             pic = dec.decode_sample(tr.nal_units(i), i)
+            if self.convert_pic is not None:
+                out[rank[i]] = self.convert_pic(pic)
+                continue
             Y = pic.Y[2 * ct:pic.Hh * 16 - 2 * cb, 2 * cl:pic.W * 16 - 2 * cr].astype(np.uint8)
             Cb, Cr = (p[ct:pic.Hh * 8 - cb, cl:pic.W * 8 - cr].astype(np.uint8) for p in pic.C)
             out[rank[i]] = (Y, Cb, Cr) if self.convert is None else self.convert(Y, Cb, Cr)

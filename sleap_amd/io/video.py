@@ -275,7 +275,7 @@ class MediaVideo:
             except AttributeError:
                 workers = 1
         self._blue = _h264_intra.swscale_blue
-        self._gops = _h264.GopPool(self._track, workers, convert=self._convert) if workers > 1 else None
+        self._gops = _h264.GopPool(self._track, workers, convert_pic=self._convert_pic) if workers > 1 else None
         if self._gops is not None and not self._gops.closed:
             self._gops = None
         self._swscale = _h264_intra.swscale_bgr
@@ -300,6 +300,23 @@ class MediaVideo:
         if self.grayscale:
             return self._blue(y, cb)[..., None]
         return self._swscale(y, cb, cr)
+
+    def _convert_pic(self, pic):
+        """the same conversion straight from a natively decoded picture's buffers by the library (`sa_yuv420_to_bgr`: no GIL, no
+        intermediate copies) -- what the decode threads run"""
+        import ctypes as C
+
+        from .. import _lib
+
+        cl, cr, ct, cb = self._track.sps["crop"]
+        h, w = self._track.height, self._track.width
+        ch = 1 if self.grayscale else 3
+        out = np.empty((h, w, ch), np.uint8)
+        ys, cs = pic.Y.shape[1], pic.C[0].shape[1]
+        rc = _lib.lib().sa_yuv420_to_bgr(C.c_void_p(pic.Y.ctypes.data + 2 * ct * ys + 2 * cl), C.c_void_p(pic.C[0].ctypes.data + ct * cs + cl),
+                                         C.c_void_p(pic.C[1].ctypes.data + ct * cs + cl), w, h, ys, cs, C.c_void_p(out.ctypes.data), ch)
+        _lib.check(rc, "sa_yuv420_to_bgr")
+        return out
 
     def _bgr_frame(self, idx: int, want_bgr: bool = False) -> np.ndarray:
         """-> (H, W, 3) BGR, or (H, W, 1) channel 0 for a grayscale video unless `want_bgr`"""

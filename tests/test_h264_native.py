@@ -103,3 +103,23 @@ def test_media_video_reads_the_1024_high_profile_clip():
     assert v.shape == (1500, 1024, 1024, 1) and v.backend.keyframes[:3] == [0, 250, 500]
     f = v.get_frames([0, 1, 2, 3])
     assert f.shape == (4, 1024, 1024, 1) and 5 < float(f.mean()) < 60
+
+
+def test_native_colour_conversion_equals_the_numpy_one():
+    import ctypes as C
+
+    from sleap_amd import _lib
+    from sleap_amd.io._h264_intra import swscale_blue, swscale_bgr
+
+    lib = _lib.lib()
+    rng = np.random.default_rng(0)
+    for (h, w) in ((320, 560), (31, 45), (384, 384)):
+        y = rng.integers(0, 256, (h, w)).astype(np.uint8)
+        cb = rng.integers(0, 256, ((h + 1) // 2, (w + 1) // 2)).astype(np.uint8)
+        cr = rng.integers(0, 256, cb.shape).astype(np.uint8)
+        for ch, want in ((3, swscale_bgr(y, cb, cr)), (1, swscale_blue(y, cb)[..., None])):
+            out = np.empty((h, w, ch), np.uint8)
+            rc = lib.sa_yuv420_to_bgr(C.c_void_p(y.ctypes.data), C.c_void_p(cb.ctypes.data), C.c_void_p(cr.ctypes.data), w, h, w, cb.shape[1],
+                                      C.c_void_p(out.ctypes.data), ch)
+            assert rc == 0
+            np.testing.assert_array_equal(out, want)
