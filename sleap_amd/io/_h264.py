@@ -5,7 +5,7 @@ tests/data/tracks/clip.mp4 (High: Intra 8x8, 8x8 transform; the latter 1500 fram
 read), tests/data/json_format_v1/centered_pair_low_quality.mp4, tests/data/videos/centered_pair_small.mp4, dance.mp4 (Main:
 CABAC, B pyramids, weighted prediction). Two engines for the macroblock layer behind the same Python front end (MP4 tables,
 parameter sets, slice headers, picture order, reference lists and marking): `engine="native"` -- `sa_h264_decode_slice`, host C++
-in the package's library (csrc/h264dec.hip), 230 (1024 x 1024) ... 540 (384 x 384) pictures/s per core, what `MediaVideo` runs -- and `engine="python"` -- the classes of
+in the package's library (csrc/h264dec.hip), 325 (1024 x 1024) ... 545 (384 x 384) pictures/s per core, what `MediaVideo` runs -- and `engine="python"` -- the classes of
 this file on top of io/_h264_intra.py (bit reader, CABAC engine, intra prediction, transforms, edge filter), ~0.2-0.8 s per
 384 x 384 picture, the restatement the native engine is checked against (tests/test_h264_native.py: equal planes and motion data).
 `sleap_amd.io.video.MediaVideo` reads every frame of such a file through `H264Reader` (display order = the MP4's composition times, as cv2.VideoCapture numbers frames:

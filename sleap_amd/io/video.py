@@ -251,7 +251,7 @@ class MediaVideo:
     files of the reference's test data); scaling matrices, fields and several slices per picture raise NotImplementedError naming
     the missing coding tool. Frame k is the k-th picture in PRESENTATION order (the MP4's composition
     times), as cv2 numbers frames. The macroblock layer runs in the package's library (`sa_h264_decode_slice`, host C++:
-    230-540 pictures/s on one core); sequential reads decode every picture once, a jump decodes from the key frame in front of the target (`keyframes`). Colour conversion, channel handling and the
+    325-545 pictures/s on one core); sequential reads decode every picture once, a jump decodes from the key frame in front of the target (`keyframes`). Colour conversion, channel handling and the
     `grayscale` / `bgr` attributes follow the reference: BGR as libswscale delivers it to cv2, `grayscale` "auto" = detected on
     the first frame (all channels equal), a grayscale video yields channel 0, `bgr=True` reverses the channel order of colour
     frames. An index past the end raises `KeyError` like the reference's failed read (video.py:497-498)."""
