@@ -1917,6 +1917,10 @@ class GopPool:
             sorted(rank[i] for i in range(a, b)) == list(range(a, b)) for a, b in zip(self.starts, self.ends))
         self._pool = ThreadPoolExecutor(max_workers=self.workers) if self.closed else None
         self._futures = {}          # GOP index -> future of {display index: (Y, Cb, Cr)}
+        if engine == "native":
+            from .. import _lib
+
+            _lib.lib()  # (loaded once here, not by eight worker threads at the same time)
         self._keep = keep or self.workers + 1
         self._cl = track.sps["crop"]
         self.convert = convert  # (Y, Cb, Cr) -> what `frame` returns (run on the worker threads); None: the planes
