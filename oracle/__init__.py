@@ -20,4 +20,9 @@ Pinning status (see DESIGN.md "Oracle"):
     (tests/test_oracle_network_pin.py); the centered-instance model's peaks on ground-truth crops likewise (3e-5 px).
     UpSampling2D(bilinear) -- the benchmark network's decoder -- BatchNormalization and the ResNet / hourglass graphs stay
     pinned to hand-derived vectors only (tests/layer_pin_vectors.py): no reference golden runs them.
+  * NOT in this package: the checker of the native H.264 slice decoder (csrc/h264dec.hip). It is the pure-Python decoder
+    sleap_amd/io/_h264.py + _h264_intra.py, which ships with the package because it is also `MediaVideo`'s selectable second engine
+    (`engine="python"`); the product default is the native engine and there is no silent fall-back between them
+    (tests/test_h264_native.py compares the two picture by picture; what pins the Python decoder: tests/test_frame0_golden.py,
+    tests/test_h264_inter.py).
 """
