@@ -633,6 +633,41 @@ struct Slice {
           }
         }
       }
+      // the plain average (two references, whole-sample vectors, default weighting or implicit weights 32 / 32 -- the same
+      // arithmetic -- and both windows inside the picture: the static background of B pictures) also goes plane to plane
+      {
+        const int r0 = REF(0, y4, x4), r1 = REF(1, y4, x4);
+        if (r0 >= 0 && r1 >= 0 && mode != 1) {
+          const sa_h264_pic &p0 = l0[r0], &p1 = l1[r1];
+          H264_CHECK(p0.y && p1.y, "prediction from an empty reference list entry");
+          const int m0x = MV(0, y4, x4)[0], m0y = MV(0, y4, x4)[1], m1x = MV(1, y4, x4)[0], m1y = MV(1, y4, x4)[1];
+          bool avg = mode == 0;
+          if (mode == 2) {
+            const int* iw = &implicit[((size_t)r0 * s->nref[1] + r1) * 2];
+            avg = iw[0] == 32 && iw[1] == 32;
+          }
+          const int ax = x4 * 4 + (m0x >> 2), ay = y4 * 4 + (m0y >> 2), bx = x4 * 4 + (m1x >> 2), by = y4 * 4 + (m1y >> 2);
+          if (avg && !((m0x | m0y | m1x | m1y) & 7) && ax >= 0 && ay >= 0 && ax + w <= LW && ay + hh <= LH && bx >= 0 && by >= 0 && bx + w <= LW &&
+              by + hh <= LH) {
+            for (int j = 0; j < hh; ++j) {
+              const uint8_t *a = p0.y + (size_t)(ay + j) * LW + ax, *b = p1.y + (size_t)(by + j) * LW + bx;
+              uint8_t* d = cur->y + (size_t)(y4 * 4 + j) * LW + x4 * 4;
+              for (int i = 0; i < w; ++i) d[i] = (uint8_t)((a[i] + b[i] + 1) >> 1);
+            }
+            for (int c = 0; c < 2; ++c) {
+              const uint8_t *sa_ = c ? p0.cr : p0.cb, *sb_ = c ? p1.cr : p1.cb;
+              uint8_t* dst = C(c);
+              for (int j = 0; j < hh / 2; ++j) {
+                const uint8_t *a = sa_ + (size_t)(ay / 2 + j) * CW + ax / 2, *b = sb_ + (size_t)(by / 2 + j) * CW + bx / 2;
+                uint8_t* d = dst + (size_t)(y4 * 2 + j) * CW + x4 * 2;
+                for (int i = 0; i < w / 2; ++i) d[i] = (uint8_t)((a[i] + b[i] + 1) >> 1);
+              }
+            }
+            ++stats[7];
+            continue;
+          }
+        }
+      }
       for (int l = 0; l < 2; ++l) {
         const int rf = REF(l, y4, x4);
         if (rf < 0) continue;
@@ -1893,7 +1928,7 @@ struct Slice {
     memset(cur->ref, 0xFF, (size_t)2 * H4 * W4);
     for (size_t i = 0; i < (size_t)2 * H4 * W4; ++i) cur->refid[i] = -1;
     memset(cur->intra4, 0, (size_t)H4 * W4);
-    memset(cur->y, 0, (size_t)W * 16 * Hh * 16), memset(cur->cb, 0, (size_t)W * 8 * Hh * 8), memset(cur->cr, 0, (size_t)W * 8 * Hh * 8);
+    // (the planes need no clearing: every sample is written by a prediction before anything reads it)
     if (stype == 1 && s->weighted_mode == 2) {
       implicit.assign((size_t)s->nref[0] * s->nref[1] * 2, 32);
       for (int i = 0; i < s->nref[0]; ++i)
