@@ -50,6 +50,9 @@ struct Stem16Params {
 #if !defined(SA_STEM16_PLANES8)
 #define SA_STEM16_PLANES8 1  // gray kernel: conv0 activation tile as two 8-channel planes in LDS (0: pixel-major records, A/B)
 #endif
+#if !defined(SA_STEM16_TABLE_B128)
+#define SA_STEM16_TABLE_B128 1  // gray kernel: the triplet table written 16 bytes at a time (0: 8 bytes, A/B)
+#endif
 #if !defined(SA_STEM16_READ2)
 // gray kernel, folded conv0 (round 6): the B operand {triplet, triplet} comes from ONE `ds_read2_b64` whose two offsets are
 // equal -- the LDS returns the same 8 bytes into both register pairs -- instead of a ds_read_b64 and two v_mov (18 of conv0's
@@ -320,11 +323,23 @@ stem16_gray_kernel(const Stem16Params p) {
       const unsigned byte = e < 4 ? (v0 >> (8 * e)) & 0xFF : (v1 >> (8 * (e - 4))) & 0xFF;
       h[e] = sa::f2h((float)byte * sa::U8_ACT_SCALE);
     }
+#if SA_STEM16_TABLE_B128
+    // (round 6) the four entries of a thread are 32 contiguous, 16-byte aligned bytes: two ds_write_b128 (lanes 32 bytes apart:
+    // 2-way) instead of four ds_write_b64 (4-way: 144 of this kernel's 343 conflict cycles per tile). Entries come in valid pairs
+    // (tx = -2, -1 at the left edge; tx <= 33 < PW + 2 at the right: entries 34, 35 of a row are never read).
+#pragma unroll
+    for (int e = 0; e < 4; e += 2) {
+      const int tx = dq * 4 - 2 + e;
+      if (tx >= 0 && tx < PW)
+        *reinterpret_cast<uint4*>(&rawt[ty * RS + tx]) = make_uint4(h[e] | (h[e + 1] << 16), h[e + 2], h[e + 1] | (h[e + 2] << 16), h[e + 3]);
+    }
+#else
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const int tx = dq * 4 - 2 + e;
       if (tx >= 0 && tx < PW) rawt[ty * RS + tx] = make_uint2(h[e] | (h[e + 1] << 16), h[e + 2]);
     }
+#endif
   }
 #if SA_STEM16_FOLD
   // A lane's conv0 K block holds one kernel row: 3 taps in 8 slots. The hi and the mid term of the weight split share ONE MFMA:
