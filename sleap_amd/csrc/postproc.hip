@@ -23,6 +23,12 @@
 #if !defined(SA_NMS_ILP_DEFAULT)
 #define SA_NMS_ILP_DEFAULT 1
 #endif
+#if !defined(SA_GROUP_LDS_EDGES)
+#define SA_GROUP_LDS_EDGES 1  // grouping walk: edge list and edge order read from LDS (0: from global memory as before, A/B)
+#endif
+#if !defined(SA_GROUP_COMPACT)
+#define SA_GROUP_COMPACT 1  // grouping: the connections as a compact list built in parallel (0: cursor over the match tables, A/B)
+#endif
 namespace {
 
 constexpr int MAXNP = 512;  // cap on max_node_peaks (peaks of one node type per frame); bounds table sizes only
@@ -880,7 +886,7 @@ struct GroupIn {
 
 // assign, order, remap[+1], cell_last, + the frame's match tables and node counts staged for the sequential walk
 __host__ __device__ inline size_t group_lds_bytes(int N, int NP, int max_instances, int E) {
-  return sizeof(int32_t) * (3 * (size_t)N * NP + 1 + (size_t)max_instances * N + 2 * (size_t)E * NP + N);
+  return sizeof(int32_t) * (3 * (size_t)N * NP + 1 + (size_t)max_instances * N + 2 * (size_t)E * NP + N + 3 * (size_t)E + 3 * (size_t)E * NP);  // (+ edges, edge order, the compact connection list)
 }
 
 __device__ __forceinline__ int wave_max_i32(int v) {
@@ -922,13 +928,25 @@ __device__ __forceinline__ bool next_conn(const GroupIn& g, int b, const int32_t
   return false;
 }
 
-__device__ void frame_group_wave(const GroupIn& g, int b, int32_t* assign, int32_t* order, int32_t* remap, int32_t* cell_last) {
+__device__ void frame_group_wave(const GroupIn& g_in, int b, int32_t* assign, int32_t* order, int32_t* remap, int32_t* cell_last) {
   const int lane = threadIdx.x & 63;
-  const int N = g.N, NP = g.NP, NN = N * NP;
+  const int N = g_in.N, NP = g_in.NP, NN = N * NP;
   // stage the tables the sequential walk reads (match_dst / match_score / node_count of this frame) in LDS
-  int32_t* md = cell_last + g.max_instances * N;
-  float* msc = reinterpret_cast<float*>(md + g.E * NP);
-  int32_t* ncnt = md + 2 * g.E * NP;
+  int32_t* md = cell_last + g_in.max_instances * N;
+  float* msc = reinterpret_cast<float*>(md + g_in.E * NP);
+  int32_t* ncnt = md + 2 * g_in.E * NP;
+  // ... and, since round 6, the skeleton's edge list and edge order: the walk below looked both up in GLOBAL memory on every one
+  // of its ~50 strictly sequential steps (two or three dependent L2 round trips per connection: 75 of this kernel's 110 us at
+  // 4 animals x 13 nodes, measured with s_memtime stamps), and so did every lane of the instance-score loop
+  int32_t* s_edges = ncnt + N;
+  int32_t* s_sorted = s_edges + 2 * g_in.E;
+  for (int i = lane; i < 2 * g_in.E; i += 64) s_edges[i] = g_in.edges[i];
+  for (int i = lane; i < g_in.n_sorted; i += 64) s_sorted[i] = g_in.sorted_edge_inds[i];
+  GroupIn g = g_in;
+  if (SA_GROUP_LDS_EDGES) {
+    g.edges = s_edges;
+    if (g_in.sorted_edge_inds) g.sorted_edge_inds = s_sorted;
+  }
   if (!g.conn_edge) {
     for (int i = lane; i < g.E * NP; i += 64) {
       md[i] = g.match_dst[(size_t)b * g.E * NP + i];
@@ -943,13 +961,60 @@ __device__ void frame_group_wave(const GroupIn& g, int b, int32_t* assign, int32
     for (int i = lane; i < n_order; i += 64) order[i] = g.order_in[(size_t)b * NN + i];
   }
   SA_WAVE_SYNC();
+  // Round 6: the connections of the match tables as ONE compact list in processing order (sorted edges, sources ascending,
+  // unmatched sources and scores below min_line_scores left out), built by the wave in parallel: (source slot | destination slot
+  // << 16, score). Walking the tables with a cursor cost every step of the greedy walk -- and every step of every lane of the
+  // instance-score loop -- about eight DEPENDENT LDS reads (edge order -> edge -> count -> match -> ...): 2-3 k cycles per
+  // connection, two thirds of this kernel (s_memtime stamps, tools/pp_stamp_probe.py). Same connections, same order, same sums.
+  int32_t* c_pair = s_sorted + g_in.E;
+  float* c_sc = reinterpret_cast<float*>(c_pair + g_in.E * NP);
+  int32_t* c_inst = reinterpret_cast<int32_t*>(c_sc + g_in.E * NP);
+  const bool compact = SA_GROUP_COMPACT && !g.conn_edge && !g.assign_in && NN <= 65535;
+  int T = 0;
+  if (compact) {
+    for (int base = 0; base < g.n_sorted; base += 64) {
+      const int e = base + lane;
+      int cnt = 0, kk = 0, n_src = 0, sn = 0, dn = 0;
+      if (e < g.n_sorted) {
+        kk = s_sorted[e];
+        sn = s_edges[2 * kk], dn = s_edges[2 * kk + 1];
+        n_src = ncnt[sn];
+        for (int ss = 0; ss < n_src; ++ss) cnt += (md[kk * NP + ss] >= 0 && msc[kk * NP + ss] >= g.min_line_scores) ? 1 : 0;
+      }
+      int incl = cnt;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const int v = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += v;
+      }
+      const int total = __shfl(incl, 63, 64);
+      int pos = T + incl - cnt;
+      for (int ss = 0; ss < n_src; ++ss) {
+        const int dd = md[kk * NP + ss];
+        const float scv = msc[kk * NP + ss];
+        if (dd >= 0 && scv >= g.min_line_scores) {
+          c_pair[pos] = (sn * NP + ss) | ((dn * NP + dd) << 16);
+          c_sc[pos] = scv;
+          ++pos;
+        }
+      }
+      T += total;
+    }
+    SA_WAVE_SYNC();
+  }
   // ---- assign_connections_to_instances (paf_grouping.py:799-914)
   ConnCursor cur = {0, 0, 0};
-  int k, s, d;
-  float sc;
-  while (!g.assign_in && next_conn(g, b, md, msc, ncnt, cur, k, s, d, sc)) {
-    if (!(sc >= g.min_line_scores)) continue;  // group_instances_sample :1067
-    const int src_id = g.edges[2 * k] * NP + s, dst_id = g.edges[2 * k + 1] * NP + d;
+  int k = 0, s = 0, d = 0, jc = 0;
+  float sc = 0.0f;
+  while (!g.assign_in && (compact ? jc < T : next_conn(g, b, md, msc, ncnt, cur, k, s, d, sc))) {
+    int src_id, dst_id;
+    if (compact) {
+      const unsigned pr = (unsigned)c_pair[jc++];
+      src_id = (int)(pr & 0xFFFFu), dst_id = (int)(pr >> 16);
+    } else {
+      if (!(sc >= g.min_line_scores)) continue;  // group_instances_sample :1067
+      src_id = g.edges[2 * k] * NP + s, dst_id = g.edges[2 * k + 1] * NP + d;
+    }
     const int si = assign[src_id], di = assign[dst_id];
     SA_WAVE_SYNC();
     if (si < 0 && di < 0) {
@@ -1036,6 +1101,19 @@ __device__ void frame_group_wave(const GroupIn& g, int b, int32_t* assign, int32
   float* iv = g.instance_peak_vals + (size_t)b * g.max_instances * N;
   float* is = g.instance_scores + (size_t)b * g.max_instances;
   // instance score = sum of its matched edge scores IN CONNECTION ORDER (fp32): one lane per instance walks the list
+  if (compact) {  // the output instance of every connection once, in parallel; then one lane per instance adds its scores in order
+    for (int j = lane; j < T; j += 64) {
+      const int a = assign[(unsigned)c_pair[j] & 0xFFFFu];
+      c_inst[j] = a >= 0 ? remap[a] : -1;
+    }
+    SA_WAVE_SYNC();
+    for (int ii = lane; ii < n_out; ii += 64) {
+      float acc = 0.0f;
+      for (int j = 0; j < T; ++j)
+        if (c_inst[j] == ii) acc = __fadd_rn(acc, c_sc[j]);
+      is[ii] = acc;
+    }
+  } else
   for (int ii = lane; ii < n_out; ii += 64) {
     float acc = 0.0f;
     ConnCursor c2 = {0, 0, 0};
@@ -1204,6 +1282,9 @@ paf_group_kernel(const GroupIn g, int32_t* __restrict__ workspace) {
 // anyway) with workgroup barriers in between; LDS is re-used stage by stage. Replaces four dependent launches
 // (~20 us of dispatch + drain each at small batch sizes).
 // ------------------------------------------------------------------------------------------------
+#if defined(SA_POSTPROC_STAMP)
+__device__ unsigned long long pp_stamp_dev[8];
+#endif
 struct FusedIn {
   const float* cms;
   const float* offsets;
@@ -1231,25 +1312,49 @@ __global__ void __launch_bounds__(1024)
 bottomup_postproc_kernel(const FusedIn f, const GroupIn g) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int b = blockIdx.x;
+  // SA_POSTPROC_STAMP (an instrumented A/B build, tools/pp_stamp_probe.py -- never the product library): s_memtime at the stage
+  // boundaries, summed over the workgroups
+#if defined(SA_POSTPROC_STAMP)
+  unsigned long long ts[6];
+#define PP_STAMP(i)                          \
+  do {                                       \
+    __syncthreads();                         \
+    ts[i] = __builtin_amdgcn_s_memtime();    \
+  } while (0)
+#else
+#define PP_STAMP(i)
+#endif
+  PP_STAMP(0);
   frame_sort_refine(b, reinterpret_cast<uint32_t*>(smem_raw), f.cms, f.offsets, f.H, f.W, f.C, f.mode, f.patch, f.xy_scale,
                     f.max_peaks, f.keys, f.peak_count, f.peak_xy, f.peak_val, f.peak_chan, f.scan_counts,
                     reinterpret_cast<float*>(smem_raw) + f.sort_words, f.samp_words);
   __syncthreads();  // (workgroup-scope release/acquire of the global tables written above)
+  PP_STAMP(1);
   frame_score(b, smem_raw, f.pafs, f.Hp, f.Wp, g.E, f.peak_xy, f.peak_chan, f.peak_count, f.max_peaks, g.edges, g.N, f.n_points,
               f.pafs_stride, f.max_edge_length, f.dist_penalty_weight, g.NP, f.node_count, f.node_peaks, f.line_scores, g.status,
               f.ch_words);
+  PP_STAMP(2);
   frame_group_fill(g, b);
   __syncthreads();
+  PP_STAMP(3);
   const int wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
   for (int k = wave; k < g.E; k += n_waves)
     edge_match_wave(b, k, smem_raw + (size_t)wave * match_lds_bytes(g.NP), f.line_scores, f.node_count, g.edges, g.E, g.N, g.NP,
                     f.match_dst, f.match_score, g.status);
   __syncthreads();
+  PP_STAMP(4);
   if (wave == 0) {
     const int NN = g.N * g.NP;
     int32_t* assign = reinterpret_cast<int32_t*>(smem_raw);
     frame_group_wave(g, b, assign, assign + NN, assign + 2 * NN, assign + 3 * NN + 1);
   }
+  PP_STAMP(5);
+#if defined(SA_POSTPROC_STAMP)
+  if (threadIdx.x == 0) {
+    for (int i = 0; i < 5; ++i) atomicAdd(&pp_stamp_dev[i], ts[i + 1] - ts[i]);
+    atomicAdd(&pp_stamp_dev[5], 1ull);
+  }
+#endif
 }
 
 }  // namespace
@@ -1676,3 +1781,12 @@ static int lsa_host_impl(const double* cost, int nr, int nc, int64_t* row_ind, i
 }
 
 }  // extern "C"
+
+#if defined(SA_POSTPROC_STAMP)
+extern "C" int sa_pp_stamp_read(unsigned long long* out, int reset) {
+  unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(pp_stamp_dev), sizeof(z)) != hipSuccess) return -1;
+  if (reset && hipMemcpyToSymbol(HIP_SYMBOL(pp_stamp_dev), z, sizeof(z)) != hipSuccess) return -1;
+  return 0;
+}
+#endif
